@@ -1,0 +1,152 @@
+/*
+ * include/wfmash_hip.h -- C ABI of libwfmash_hip.so (MI355X / gfx950).
+ *
+ * Drop-in boundary for the wfmash hot path.  Every entry point below replaces
+ * one seam of the reference (file:line relative to waveygang/wfmash):
+ *
+ *   align path
+ *     wfm_align_batch   <- wfa::WFAlignerGapAffine2Pieces::alignEnd2End /
+ *                          alignEndsFree + getAlignment as used at
+ *                          src/common/wflign/src/wflign.cpp:136-148 (main BiWFA,
+ *                          MemoryUltralow), :280-309 (head patch, MemoryMed),
+ *                          :368-401 (tail patch) and
+ *                          src/common/wflign/src/wflign_alignment.cpp:665-678
+ *                          (wflign_edit_cigar_copy).  One call aligns a whole
+ *                          batch of mapping records (the batch seam above
+ *                          Aligner::processAlignment,
+ *                          src/align/include/computeAlignments.hpp:661).
+ *   map path
+ *     wfm_hash_kmers        <- CommonFunc::getHash, src/map/include/commonFunc.hpp:173-182
+ *                              (MurmurHash3_x64_128 seed 42, src/common/murmur3.h:226-302)
+ *     wfm_sketch_fragments  <- CommonFunc::sketchSequence, commonFunc.hpp:218-323
+ *                              via MappingCore::getSeedHits, mappingCore.hpp:62-76
+ *     wfm_add_minmers       <- CommonFunc::addMinmers, commonFunc.hpp:440-708
+ *
+ * All pointers are HOST memory unless stated; the library owns every device
+ * buffer.  No torch types.  A handle is bound to one GPU and is not
+ * thread-safe; use one handle per host thread / per rank.
+ * Every function returns 0 on success or a negative WFM_E_* code; there is no
+ * CPU fallback: without a visible gfx950 device wfm_create fails.
+ */
+#ifndef WFMASH_HIP_H_
+#define WFMASH_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WFM_OK              0
+#define WFM_E_NODEVICE     (-1)
+#define WFM_E_HIP          (-2)   /* a HIP runtime call failed; see wfm_last_error */
+#define WFM_E_ARG          (-3)
+#define WFM_E_NOMEM        (-4)
+#define WFM_E_UNSUPPORTED  (-5)   /* e.g. penalties whose score scope exceeds the ring */
+#define WFM_E_ARENA        (-6)   /* caller's ops arena too small */
+
+/* per-problem status (wfm_result_t.status); 0 mirrors WF_STATUS_ALG_COMPLETED
+ * tested at wflign.cpp:150,307,399 */
+#define WFM_ST_OK            0
+#define WFM_ST_UNREACHABLE (-300)
+#define WFM_ST_OOM         (-200)
+
+typedef struct wfm_handle wfm_handle_t;
+
+/* wflign_penalties_t (wflign_alignment.hpp:21) minus match (always 0) */
+typedef struct { int32_t x, o1, e1, o2, e2; } wfm_penalties_t;
+
+/* alignment mode = the WFAligner memory model / entry point the reference uses */
+#define WFM_MODE_END2END_BIWFA 0   /* alignEnd2End, MemoryUltralow  (wflign.cpp:136-148) */
+#define WFM_MODE_ENDSFREE      1   /* alignEndsFree, MemoryMed      (wflign.cpp:280-305,368-397) */
+#define WFM_MODE_END2END_UNI   2   /* alignEnd2End, full backtrace (MemoryHigh)            */
+
+typedef struct {
+  const char* pattern;  int32_t plen;     /* wfmash passes pattern = target */
+  const char* text;     int32_t tlen;     /* wfmash passes text    = query  */
+  int32_t mode;                           /* WFM_MODE_*                      */
+  int32_t pattern_begin_free, pattern_end_free;   /* ENDSFREE only */
+  int32_t text_begin_free, text_end_free;
+} wfm_problem_t;
+
+typedef struct {
+  int32_t  status;     /* WFM_ST_*                                             */
+  int32_t  score;      /* gap-affine-2p penalty of the returned alignment      */
+  uint64_t ops_off;    /* offset of this problem's op string in ops_arena      */
+  uint32_t ops_len;    /* number of ops over {M,X,I,D}; I = text-only, D = pattern-only */
+  uint32_t n_runs;     /* number of run-length encoded CIGAR runs             */
+  uint64_t cells;      /* (score,diagonal) cells computed on the device        */
+} wfm_result_t;
+
+typedef struct {
+  uint64_t cells;            /* cells computed in the last batch                  */
+  uint64_t bytes_algorithmic;/* 48*cells + sum(plen+tlen)         */
+  double   ms_kernels;       /* device time of all WFA kernels (hipEvent)         */
+  double   ms_breakpoint;    /* device time of the BiWFA breakpoint kernels       */
+  double   ms_base;          /* device time of the base / backtrace kernels       */
+  double   ms_total;         /* host wall time of the whole call                  */
+  uint32_t levels;           /* BiWFA recursion levels executed                   */
+  uint32_t bp_jobs, base_jobs;
+  uint32_t bp_launches, base_launches;
+} wfm_stats_t;
+
+int  wfm_create(int device, wfm_handle_t** out);
+void wfm_destroy(wfm_handle_t* h);
+const char* wfm_last_error(const wfm_handle_t* h);
+int  wfm_device_name(const wfm_handle_t* h, char* buf, size_t buflen);
+
+/* Upper bound of the ops_arena bytes wfm_align_batch needs for these problems
+ * (sum of plen+tlen+1). */
+size_t wfm_align_arena_bytes(const wfm_problem_t* problems, size_t n);
+
+/* Align n problems.  out[i].ops_off/ops_len locate the op string of problem i
+ * inside ops_arena (not NUL-terminated).  Returns the number of problems whose
+ * status != 0, or a negative WFM_E_* code if the call itself failed. */
+int  wfm_align_batch(wfm_handle_t* h, const wfm_penalties_t* pen,
+                     const wfm_problem_t* problems, size_t n,
+                     wfm_result_t* out, char* ops_arena, size_t arena_bytes);
+
+/* Same, but sequences are already resident in device memory (the timed region
+ * of bench.py starts here): d_seqs is a device pointer, offsets index into it.
+ * Sequences must be laid out by wfm_upload_sequences. */
+typedef struct wfm_seqset wfm_seqset_t;
+int  wfm_upload_sequences(wfm_handle_t* h, const wfm_problem_t* problems, size_t n, wfm_seqset_t** out);
+void wfm_free_sequences(wfm_handle_t* h, wfm_seqset_t* s);
+int  wfm_align_resident(wfm_handle_t* h, const wfm_penalties_t* pen, wfm_seqset_t* s,
+                        wfm_result_t* out, char* ops_arena, size_t arena_bytes);
+
+int  wfm_get_stats(const wfm_handle_t* h, wfm_stats_t* out);
+
+/* ---- map path (see header comment for the reference functions) ---- */
+
+/* Canonical k-mer hashes of every k-mer start 0..len-k of seq (upper-cased,
+ * non-ACGT treated as N as makeUpperCaseAndValidDNA, commonFunc.hpp:132-142).
+ * hash[i]   = min(getHash(fwd), getHash(revcomp)) ; strand[i] = +1 fwd < rev,
+ * -1 rev < fwd, 0 palindromic or contains N (hash[i] undefined = UINT64_MAX). */
+int  wfm_hash_kmers(wfm_handle_t* h, const char* seq, int64_t len, int k,
+                    uint64_t* hash, int8_t* strand);
+
+/* skch::MinmerInfo (base_types.hpp:28-35), 32 bytes */
+typedef struct {
+  uint64_t hash;
+  int64_t  wpos;
+  int64_t  wpos_end;
+  int32_t  seqId;
+  int16_t  strand;
+  int16_t  pad_;
+} wfm_minmer_t;
+
+/* sketchSequence over n fragments of one buffer: fragment f = seq[frag_off[f] ..
+ * frag_off[f]+frag_len[f]).  For each fragment the bottom-s distinct canonical
+ * hashes ascending (commonFunc.hpp:218-323).  out holds n*s entries;
+ * out_count[f] <= s. */
+int  wfm_sketch_fragments(wfm_handle_t* h, const char* seq, int64_t seq_len,
+                          const int64_t* frag_off, const int32_t* frag_len, size_t n,
+                          int k, int s, int32_t seq_id,
+                          wfm_minmer_t* out, int32_t* out_count);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,28 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle import pyoracle
+    pyoracle.lib()
+    return pyoracle
+
+
+@pytest.fixture(scope="session")
+def gpu():
+    """One device handle for the whole session; fails loudly when the HIP library or device is missing."""
+    from wfmash_amd import capi
+    h = capi.Handle(0)
+    yield h
+    h.close()

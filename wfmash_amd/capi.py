@@ -1,0 +1,263 @@
+"""ctypes bindings of libwfmash_hip.so (the C ABI declared in include/wfmash_hip.h).
+
+This is plumbing for tests and bench.py; the product is the shared library.
+There is no CPU fallback: if the library is missing or no gfx950 device is
+visible, loading / `Handle()` raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libwfmash_hip.so")
+
+WFM_MODE_END2END_BIWFA = 0
+WFM_MODE_ENDSFREE = 1
+WFM_MODE_END2END_UNI = 2
+
+DEFAULT_PEN = (5, 8, 2, 24, 1)  # parse_args.hpp:290-294
+
+EXPORTS = [
+    "wfm_create", "wfm_destroy", "wfm_last_error", "wfm_device_name",
+    "wfm_align_arena_bytes", "wfm_align_batch", "wfm_upload_sequences",
+    "wfm_free_sequences", "wfm_align_resident", "wfm_get_stats",
+    "wfm_hash_kmers", "wfm_sketch_fragments",
+]
+
+
+class Penalties(C.Structure):
+    _fields_ = [("x", C.c_int32), ("o1", C.c_int32), ("e1", C.c_int32),
+                ("o2", C.c_int32), ("e2", C.c_int32)]
+
+
+class Problem(C.Structure):
+    _fields_ = [("pattern", C.c_char_p), ("plen", C.c_int32),
+                ("text", C.c_char_p), ("tlen", C.c_int32),
+                ("mode", C.c_int32),
+                ("pattern_begin_free", C.c_int32), ("pattern_end_free", C.c_int32),
+                ("text_begin_free", C.c_int32), ("text_end_free", C.c_int32)]
+
+
+class Result(C.Structure):
+    _fields_ = [("status", C.c_int32), ("score", C.c_int32),
+                ("ops_off", C.c_uint64), ("ops_len", C.c_uint32),
+                ("n_runs", C.c_uint32), ("cells", C.c_uint64)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("cells", C.c_uint64), ("bytes_algorithmic", C.c_uint64),
+                ("ms_kernels", C.c_double), ("ms_breakpoint", C.c_double),
+                ("ms_base", C.c_double), ("ms_total", C.c_double),
+                ("levels", C.c_uint32), ("bp_jobs", C.c_uint32), ("base_jobs", C.c_uint32),
+                ("bp_launches", C.c_uint32), ("base_launches", C.c_uint32)]
+
+
+class Minmer(C.Structure):
+    _fields_ = [("hash", C.c_uint64), ("wpos", C.c_int64), ("wpos_end", C.c_int64),
+                ("seqId", C.c_int32), ("strand", C.c_int16), ("pad_", C.c_int16)]
+
+
+MINMER_DTYPE = np.dtype([("hash", "<u8"), ("wpos", "<i8"), ("wpos_end", "<i8"),
+                         ("seqId", "<i4"), ("strand", "<i2"), ("pad_", "<i2")])
+
+_LIB = None
+
+
+def load():
+    """Load libwfmash_hip.so; raises if it has not been built."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    vp = C.c_void_p
+    L.wfm_create.restype = C.c_int
+    L.wfm_create.argtypes = [C.c_int, C.POINTER(vp)]
+    L.wfm_destroy.restype = None
+    L.wfm_destroy.argtypes = [vp]
+    L.wfm_last_error.restype = C.c_char_p
+    L.wfm_last_error.argtypes = [vp]
+    L.wfm_device_name.restype = C.c_int
+    L.wfm_device_name.argtypes = [vp, C.c_char_p, C.c_size_t]
+    L.wfm_align_arena_bytes.restype = C.c_size_t
+    L.wfm_align_arena_bytes.argtypes = [C.POINTER(Problem), C.c_size_t]
+    L.wfm_align_batch.restype = C.c_int
+    L.wfm_align_batch.argtypes = [vp, C.POINTER(Penalties), C.POINTER(Problem), C.c_size_t,
+                                  C.POINTER(Result), vp, C.c_size_t]
+    L.wfm_upload_sequences.restype = C.c_int
+    L.wfm_upload_sequences.argtypes = [vp, C.POINTER(Problem), C.c_size_t, C.POINTER(vp)]
+    L.wfm_free_sequences.restype = None
+    L.wfm_free_sequences.argtypes = [vp, vp]
+    L.wfm_align_resident.restype = C.c_int
+    L.wfm_align_resident.argtypes = [vp, C.POINTER(Penalties), vp, C.POINTER(Result), vp, C.c_size_t]
+    L.wfm_get_stats.restype = C.c_int
+    L.wfm_get_stats.argtypes = [vp, C.POINTER(Stats)]
+    L.wfm_hash_kmers.restype = C.c_int
+    L.wfm_hash_kmers.argtypes = [vp, vp, C.c_int64, C.c_int, vp, vp]
+    L.wfm_sketch_fragments.restype = C.c_int
+    L.wfm_sketch_fragments.argtypes = [vp, vp, C.c_int64, vp, vp, C.c_size_t, C.c_int, C.c_int, C.c_int32, vp, vp]
+    for name in EXPORTS:  # every symbol include/wfmash_hip.h declares must be exported
+        getattr(L, name)
+    _LIB = L
+    return L
+
+
+class WfmError(RuntimeError):
+    pass
+
+
+class AlignResult:
+    __slots__ = ("status", "score", "ops", "n_runs", "cells")
+
+    def __init__(self, status, score, ops, n_runs, cells):
+        self.status, self.score, self.ops, self.n_runs, self.cells = status, score, ops, n_runs, cells
+
+
+def _make_problems(items):
+    """items: iterable of (pattern, text) or (pattern, text, mode, pbf, pef, tbf, tef)."""
+    items = list(items)
+    arr = (Problem * max(len(items), 1))()
+    keep = []
+    for i, it in enumerate(items):
+        p, t = bytes(it[0]), bytes(it[1])
+        keep.append((p, t))
+        arr[i].pattern, arr[i].plen = p, len(p)
+        arr[i].text, arr[i].tlen = t, len(t)
+        if len(it) > 2:
+            arr[i].mode = it[2]
+            if len(it) > 3:
+                (arr[i].pattern_begin_free, arr[i].pattern_end_free,
+                 arr[i].text_begin_free, arr[i].text_end_free) = it[3:7]
+        else:
+            arr[i].mode = WFM_MODE_END2END_BIWFA
+    return arr, keep, len(items)
+
+
+class SeqSet:
+    def __init__(self, handle, items):
+        self._h = handle
+        self.problems, self._keep, self.n = _make_problems(items)
+        sp = C.c_void_p()
+        rc = handle._L.wfm_upload_sequences(handle._p, self.problems, self.n, C.byref(sp))
+        if rc != 0:
+            raise WfmError(f"wfm_upload_sequences failed ({rc}): {handle.last_error()}")
+        self._p = sp
+        self.arena_bytes = handle._L.wfm_align_arena_bytes(self.problems, self.n)
+        self.arena = np.zeros(self.arena_bytes + 8, dtype=np.uint8)
+        self.results = (Result * max(self.n, 1))()
+
+    def free(self):
+        if self._p:
+            self._h._L.wfm_free_sequences(self._h._p, self._p)
+            self._p = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Handle:
+    """One handle per GPU (wfm_create)."""
+
+    def __init__(self, device=0):
+        self._L = load()
+        p = C.c_void_p()
+        rc = self._L.wfm_create(device, C.byref(p))
+        if rc != 0:
+            raise WfmError(f"wfm_create(device={device}) failed with {rc}: no usable gfx950 device "
+                           "(there is no CPU fallback)")
+        self._p = p
+
+    def close(self):
+        if self._p:
+            self._L.wfm_destroy(self._p)
+            self._p = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def last_error(self):
+        return self._L.wfm_last_error(self._p).decode()
+
+    def device_name(self):
+        buf = C.create_string_buffer(256)
+        self._L.wfm_device_name(self._p, buf, 256)
+        return buf.value.decode()
+
+    def stats(self):
+        st = Stats()
+        self._L.wfm_get_stats(self._p, C.byref(st))
+        return st
+
+    def upload(self, items):
+        return SeqSet(self, items)
+
+    def align_resident(self, seqset, pen=None, collect=True):
+        pn = Penalties(*(pen or DEFAULT_PEN))
+        rc = self._L.wfm_align_resident(self._p, C.byref(pn), seqset._p, seqset.results,
+                                        seqset.arena.ctypes.data, seqset.arena_bytes)
+        if rc < 0:
+            raise WfmError(f"wfm_align_resident failed ({rc}): {self.last_error()}")
+        if not collect:
+            return rc
+        return self._collect(seqset)
+
+    @staticmethod
+    def _collect(seqset):
+        out = []
+        a = seqset.arena
+        for i in range(seqset.n):
+            r = seqset.results[i]
+            ops = a[r.ops_off:r.ops_off + r.ops_len].tobytes() if r.status == 0 else None
+            out.append(AlignResult(r.status, r.score, ops, r.n_runs, r.cells))
+        return out
+
+    def align(self, items, pen=None):
+        """items: list of (pattern, text[, mode, pbf, pef, tbf, tef]). Returns [AlignResult]."""
+        probs, keep, n = _make_problems(items)
+        pn = Penalties(*(pen or DEFAULT_PEN))
+        nbytes = self._L.wfm_align_arena_bytes(probs, n)
+        arena = np.zeros(nbytes + 8, dtype=np.uint8)
+        res = (Result * max(n, 1))()
+        rc = self._L.wfm_align_batch(self._p, C.byref(pn), probs, n, res, arena.ctypes.data, nbytes)
+        if rc < 0:
+            raise WfmError(f"wfm_align_batch failed ({rc}): {self.last_error()}")
+        out = []
+        for i in range(n):
+            r = res[i]
+            ops = arena[r.ops_off:r.ops_off + r.ops_len].tobytes() if r.status == 0 else None
+            out.append(AlignResult(r.status, r.score, ops, r.n_runs, r.cells))
+        return out
+
+    # ---- map path ----
+    def hash_kmers(self, seq: bytes, k: int):
+        n = max(len(seq) - k + 1, 0)
+        hashes = np.zeros(n, dtype=np.uint64)
+        strand = np.zeros(n, dtype=np.int8)
+        buf = np.frombuffer(seq, dtype=np.uint8)
+        rc = self._L.wfm_hash_kmers(self._p, buf.ctypes.data, len(seq), k, hashes.ctypes.data, strand.ctypes.data)
+        if rc < 0:
+            raise WfmError(f"wfm_hash_kmers failed ({rc}): {self.last_error()}")
+        return hashes, strand
+
+    def sketch_fragments(self, seq: bytes, frag_off, frag_len, k: int, s: int, seq_id: int = 0):
+        frag_off = np.ascontiguousarray(frag_off, dtype=np.int64)
+        frag_len = np.ascontiguousarray(frag_len, dtype=np.int32)
+        n = len(frag_off)
+        out = np.zeros(n * s, dtype=MINMER_DTYPE)
+        cnt = np.zeros(n, dtype=np.int32)
+        buf = np.frombuffer(seq, dtype=np.uint8)
+        rc = self._L.wfm_sketch_fragments(self._p, buf.ctypes.data, len(seq), frag_off.ctypes.data,
+                                          frag_len.ctypes.data, n, k, s, seq_id, out.ctypes.data, cnt.ctypes.data)
+        if rc < 0:
+            raise WfmError(f"wfm_sketch_fragments failed ({rc}): {self.last_error()}")
+        return [out[i * s:i * s + cnt[i]] for i in range(n)]

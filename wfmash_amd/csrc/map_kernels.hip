@@ -1,0 +1,308 @@
+// map_kernels.hip -- mashmap3 sketching kernels for gfx950 (map path, SURVEY 8a m1,m2,m5).
+//
+//   normalize_kernel        makeUpperCaseAndValidDNA   (commonFunc.hpp:132-142)
+//   kmer_hash_kernel        getHash fwd + revcomp, canonical min, strand
+//                           (commonFunc.hpp:173-182, murmur3.h:226-302, seed 42)
+//   sketch_fragments_kernel sketchSequence: bottom-s distinct canonical hashes of
+//                           one fragment per workgroup (commonFunc.hpp:218-323)
+//
+// HBM-bound byte/integer work: 1 B/base read; k-mer words come from L1/L2 via
+// unaligned 8-byte loads of the normalised buffer; per-fragment selection is a
+// bitonic sort of (hash,pos) in LDS.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/wfmash_hip.h"
+#include "wfa_handle.h"
+
+namespace wfm {
+
+__device__ __forceinline__ uint64_t ld8(const uint8_t* p) {
+  uint64_t v;
+  __builtin_memcpy(&v, p, 8);
+  return v;
+}
+__device__ __forceinline__ uint64_t rotl64(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
+__device__ __forceinline__ uint64_t fmix64(uint64_t k) {
+  k ^= k >> 33; k *= 0xff51afd7ed558ccdULL; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ULL; k ^= k >> 33;
+  return k;
+}
+
+// MurmurHash3_x64_128 (low 64 bits) of a key of len <= 32 bytes held
+// little-endian in w[0..3] with bytes >= len zeroed.  murmur3.h:226-302.
+__device__ __forceinline__ uint64_t murmur3_x64_lo(const uint64_t w[4], int len, uint32_t seed) {
+  uint64_t h1 = seed, h2 = seed;
+  const uint64_t c1 = 0x87c37b91114253d5ULL, c2 = 0x4cf5ad432745937fULL;
+  const int nblocks = len >> 4;
+  for (int i = 0; i < nblocks; ++i) {
+    uint64_t k1 = w[2 * i], k2 = w[2 * i + 1];
+    k1 *= c1; k1 = rotl64(k1, 31); k1 *= c2; h1 ^= k1;
+    h1 = rotl64(h1, 27); h1 += h2; h1 = h1 * 5 + 0x52dce729;
+    k2 *= c2; k2 = rotl64(k2, 33); k2 *= c1; h2 ^= k2;
+    h2 = rotl64(h2, 31); h2 += h1; h2 = h2 * 5 + 0x38495ab5;
+  }
+  const int tail = len & 15;
+  if (tail) {
+    uint64_t k1 = nblocks == 0 ? w[0] : w[2], k2 = nblocks == 0 ? w[1] : w[3];
+    if (tail > 8) { k2 *= c2; k2 = rotl64(k2, 33); k2 *= c1; h2 ^= k2; }
+    k1 *= c1; k1 = rotl64(k1, 31); k1 *= c2; h1 ^= k1;
+  }
+  h1 ^= (uint64_t)len; h2 ^= (uint64_t)len;
+  h1 += h2; h2 += h1;
+  h1 = fmix64(h1); h2 = fmix64(h2);
+  h1 += h2;
+  return h1;
+}
+
+__device__ __forceinline__ uint8_t norm_base(uint8_t c) {
+  if (c > 96 && c < 123) c -= 32;
+  return (c == 'A' || c == 'C' || c == 'G' || c == 'T') ? c : (uint8_t)'N';
+}
+
+// byte j of a k-mer held in w[]
+__device__ __forceinline__ uint32_t kbyte(const uint64_t w[4], int j) { return (uint32_t)(w[j >> 3] >> ((j & 7) * 8)) & 0xffu; }
+
+// Loads the k-mer at p (k <= 32) into fw[], builds its reverse complement in
+// rc[] (commonFunc.hpp:74-83).  Returns false if it contains an N.
+__device__ __forceinline__ bool load_kmer(const uint8_t* p, int k, uint64_t fw[4], uint64_t rc[4]) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int rem = k - 8 * q;
+    uint64_t v = rem > 0 ? ld8(p + 8 * q) : 0ull;
+    if (rem > 0 && rem < 8) v &= (~0ull) >> (64 - 8 * rem);
+    fw[q] = v;
+    rc[q] = 0;
+  }
+  bool ok = true;
+  const uint32_t lut = (uint32_t)'A' | ((uint32_t)'C' << 8) | ((uint32_t)'T' << 16) | ((uint32_t)'G' << 24);
+  for (int j = 0; j < k; ++j) {
+    const uint32_t b = kbyte(fw, j);
+    ok = ok && (b != 'N');
+    const uint32_t code = ((b >> 1) & 3u) ^ 2u;  // A0 C1 T2 G3 ; complement = ^2
+    const uint64_t cb = (lut >> (8 * code)) & 0xffu;
+    const int d = k - 1 - j;
+    rc[d >> 3] |= cb << ((d & 7) * 8);
+  }
+  return ok;
+}
+
+__global__ void normalize_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, int64_t n) {
+  const int64_t i0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 16;
+  if (i0 + 16 <= n) {
+    uint4 v = *reinterpret_cast<const uint4*>(in + i0);
+    uint32_t* w = reinterpret_cast<uint32_t*>(&v);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      uint32_t x = w[q], y = 0;
+#pragma unroll
+      for (int b = 0; b < 4; ++b) y |= (uint32_t)norm_base((uint8_t)(x >> (8 * b))) << (8 * b);
+      w[q] = y;
+    }
+    *reinterpret_cast<uint4*>(out + i0) = v;
+  } else {
+    for (int64_t i = i0; i < n; ++i) out[i] = norm_base(in[i]);
+  }
+}
+
+__global__ void kmer_hash_kernel(const uint8_t* __restrict__ seq /*normalised, padded*/, int64_t nk, int k,
+                                 uint64_t* __restrict__ hash, int8_t* __restrict__ strand) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nk; i += (int64_t)gridDim.x * blockDim.x) {
+    uint64_t fw[4], rc[4];
+    const bool ok = load_kmer(seq + i, k, fw, rc);
+    uint64_t h = ~0ull;
+    int8_t st = 0;
+    if (ok) {
+      const uint64_t hf = murmur3_x64_lo(fw, k, 42u), hb = murmur3_x64_lo(rc, k, 42u);
+      if (hf != hb) { h = hf < hb ? hf : hb; st = hf < hb ? 1 : -1; }
+    }
+    hash[i] = h;
+    strand[i] = st;
+  }
+}
+
+// One workgroup per fragment.  LDS: key[npow2] (u64) + pv[npow2] (u32: pos<<1 | isRev).
+__global__ __launch_bounds__(256) void sketch_fragments_kernel(const uint8_t* __restrict__ seq, const int64_t* __restrict__ frag_off,
+                                                               const int32_t* __restrict__ frag_len, int k, int s, int32_t seq_id,
+                                                               int npow2, wfm_minmer_t* __restrict__ out, int32_t* __restrict__ out_count) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  uint64_t* key = reinterpret_cast<uint64_t*>(smem);
+  uint32_t* pv = reinterpret_cast<uint32_t*>(smem + (size_t)npow2 * 8);
+  int* ssum = reinterpret_cast<int*>(smem + (size_t)npow2 * 12);          // [s] strand sums
+  int* sbase = ssum + s;                                                  // [4] wave scan totals + running base
+  const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const uint8_t* p = seq + frag_off[f];
+  const int len = frag_len[f];
+  const int nk = len - k + 1;
+  for (int i = tid; i < npow2; i += blockDim.x) {
+    uint64_t h = ~0ull; uint32_t v = 0xffffffffu;
+    if (i < nk) {
+      uint64_t fw[4], rc[4];
+      if (load_kmer(p + i, k, fw, rc)) {
+        const uint64_t hf = murmur3_x64_lo(fw, k, 42u), hb = murmur3_x64_lo(rc, k, 42u);
+        if (hf != hb) { h = hf < hb ? hf : hb; v = ((uint32_t)i << 1) | (hf < hb ? 0u : 1u); }
+      }
+    }
+    key[i] = h; pv[i] = v;
+  }
+  for (int i = tid; i < s; i += blockDim.x) ssum[i] = 0;
+  if (tid < 8) sbase[tid] = 0;
+  __syncthreads();
+  // bitonic sort ascending by (key, pv)
+  for (int size = 2; size <= npow2; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      for (int t = tid; t < (npow2 >> 1); t += blockDim.x) {
+        const int lo = 2 * t - (t & (stride - 1));
+        const int hi = lo + stride;
+        const bool asc = ((lo & size) == 0);
+        const uint64_t ka = key[lo], kb = key[hi];
+        const uint32_t va = pv[lo], vb = pv[hi];
+        const bool gt = (ka > kb) || (ka == kb && va > vb);
+        if (gt == asc) { key[lo] = kb; key[hi] = ka; pv[lo] = vb; pv[hi] = va; }
+      }
+      __syncthreads();
+    }
+  }
+  // distinct rank of every run head (ordered block scan over chunks of blockDim)
+  int running = 0;
+  for (int i0 = 0; i0 < npow2; i0 += blockDim.x) {
+    const int i = i0 + tid;
+    const uint64_t ki = key[i];
+    const bool valid = ki != ~0ull || pv[i] != 0xffffffffu;
+    const bool head = valid && (i == 0 || key[i - 1] != ki);
+    const unsigned long long m = __ballot(head);
+    const int pre = __popcll(m & ((1ull << lane) - 1ull));
+    if (lane == 0) sbase[wid] = __popcll(m);
+    __syncthreads();
+    int woff = 0, tot = 0;
+    for (int w2 = 0; w2 < 4; ++w2) { const int x = sbase[w2]; if (w2 < wid) woff += x; tot += x; }
+    // rank of the run this element belongs to = (#heads at or before i) - 1
+    const int heads_incl = running + woff + pre + (head ? 1 : 0);
+    const int r = heads_incl - 1;
+    if (valid && r < s) {
+      const bool tail = (i + 1 >= npow2) || key[i + 1] != ki;
+      wfm_minmer_t* o = out + (size_t)f * s + r;
+      if (head) { o->hash = ki; o->wpos = (int64_t)(pv[i] >> 1); o->seqId = seq_id; o->pad_ = 0; }
+      if (tail) o->wpos_end = (int64_t)(pv[i] >> 1);
+      atomicAdd(&ssum[r], (pv[i] & 1u) ? -1 : 1);
+    }
+    running += tot;
+    __syncthreads();
+  }
+  const int cnt = min(running, s);
+  for (int r = tid; r < cnt; r += blockDim.x) {
+    const int v = ssum[r];
+    out[(size_t)f * s + r].strand = (int16_t)(v > 0 ? 1 : (v == 0 ? 0 : -1));  // FWD=1, AMBIG=0, REV=-1
+  }
+  if (tid == 0) out_count[f] = cnt;
+}
+
+}  // namespace wfm
+
+using namespace wfm;
+
+#define HIPCHK(h, call)                                                                 \
+  do {                                                                                  \
+    hipError_t e_ = (call);                                                             \
+    if (e_ != hipSuccess) {                                                             \
+      wfm_set_error((h), std::string(#call) + ": " + hipGetErrorString(e_));            \
+      return WFM_E_HIP;                                                                 \
+    }                                                                                   \
+  } while (0)
+
+namespace {
+struct Scoped {
+  std::vector<void*> ptrs;
+  ~Scoped() { for (void* p : ptrs) if (p) (void)hipFree(p); }
+  template <typename T> hipError_t alloc(T** p, size_t bytes) {
+    hipError_t e = hipMalloc((void**)p, bytes ? bytes : 16);
+    if (e == hipSuccess) ptrs.push_back(*p);
+    return e;
+  }
+};
+
+// uploads seq and returns a normalised, 64-byte padded device copy
+int upload_normalised(wfm_handle_t* h, Scoped& sc, const char* seq, int64_t len, uint8_t** d_norm) {
+  uint8_t* d_raw = nullptr;
+  const size_t padded = (size_t)len + 64;
+  HIPCHK(h, sc.alloc(&d_raw, padded));
+  HIPCHK(h, sc.alloc(d_norm, padded));
+  hipStream_t st = wfm_stream(h);
+  HIPCHK(h, hipMemsetAsync(*d_norm, 'N', padded, st));
+  HIPCHK(h, hipMemcpyAsync(d_raw, seq, (size_t)len, hipMemcpyHostToDevice, st));
+  const int64_t nthreads = (len + 15) / 16;
+  const int blocks = (int)((nthreads + 255) / 256);
+  if (blocks > 0) hipLaunchKernelGGL(normalize_kernel, dim3(blocks), dim3(256), 0, st, d_raw, *d_norm, len);
+  HIPCHK(h, hipGetLastError());
+  return WFM_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int wfm_hash_kmers(wfm_handle_t* h, const char* seq, int64_t len, int k, uint64_t* hash, int8_t* strand) {
+  if (!h || !seq || !hash || !strand || len < 0) return WFM_E_ARG;
+  if (k < 1 || k > 32) { wfm_set_error(h, "k must be in 1..32"); return WFM_E_UNSUPPORTED; }
+  const int64_t nk = len - k + 1;
+  if (nk <= 0) return WFM_OK;
+  HIPCHK(h, hipSetDevice(wfm_device(h)));
+  Scoped sc;
+  uint8_t* d_norm = nullptr;
+  int rc = upload_normalised(h, sc, seq, len, &d_norm);
+  if (rc != WFM_OK) return rc;
+  uint64_t* d_hash = nullptr; int8_t* d_st = nullptr;
+  HIPCHK(h, sc.alloc(&d_hash, (size_t)nk * 8));
+  HIPCHK(h, sc.alloc(&d_st, (size_t)nk));
+  hipStream_t st = wfm_stream(h);
+  const int blocks = (int)std::min<int64_t>((nk + 255) / 256, 256 * 8);
+  hipLaunchKernelGGL(kmer_hash_kernel, dim3(blocks), dim3(256), 0, st, d_norm, nk, k, d_hash, d_st);
+  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, hipMemcpyAsync(hash, d_hash, (size_t)nk * 8, hipMemcpyDeviceToHost, st));
+  HIPCHK(h, hipMemcpyAsync(strand, d_st, (size_t)nk, hipMemcpyDeviceToHost, st));
+  HIPCHK(h, hipStreamSynchronize(st));
+  return WFM_OK;
+}
+
+int wfm_sketch_fragments(wfm_handle_t* h, const char* seq, int64_t seq_len, const int64_t* frag_off,
+                         const int32_t* frag_len, size_t n, int k, int s, int32_t seq_id,
+                         wfm_minmer_t* out, int32_t* out_count) {
+  if (!h || !seq || (n && (!frag_off || !frag_len || !out || !out_count)) || seq_len < 0) return WFM_E_ARG;
+  if (k < 1 || k > 32 || s < 1) { wfm_set_error(h, "k must be in 1..32 and s >= 1"); return WFM_E_UNSUPPORTED; }
+  if (n == 0) return WFM_OK;
+  int maxk = 1;
+  for (size_t i = 0; i < n; ++i) {
+    if (frag_off[i] < 0 || frag_len[i] < 0 || frag_off[i] + frag_len[i] > seq_len) { wfm_set_error(h, "fragment out of range"); return WFM_E_ARG; }
+    maxk = std::max(maxk, frag_len[i] - k + 1);
+  }
+  int npow2 = 512;
+  while (npow2 < maxk) npow2 <<= 1;
+  const size_t lds = (size_t)npow2 * 12 + (size_t)s * 4 + 64;
+  if (lds > 160 * 1024) { wfm_set_error(h, "fragment too long for the LDS sort (max 8192 k-mers)"); return WFM_E_UNSUPPORTED; }
+  HIPCHK(h, hipSetDevice(wfm_device(h)));
+  Scoped sc;
+  uint8_t* d_norm = nullptr;
+  int rc = upload_normalised(h, sc, seq, seq_len, &d_norm);
+  if (rc != WFM_OK) return rc;
+  int64_t* d_off = nullptr; int32_t* d_len = nullptr; wfm_minmer_t* d_out = nullptr; int32_t* d_cnt = nullptr;
+  HIPCHK(h, sc.alloc(&d_off, n * 8));
+  HIPCHK(h, sc.alloc(&d_len, n * 4));
+  HIPCHK(h, sc.alloc(&d_out, n * (size_t)s * sizeof(wfm_minmer_t)));
+  HIPCHK(h, sc.alloc(&d_cnt, n * 4));
+  hipStream_t st = wfm_stream(h);
+  HIPCHK(h, hipMemcpyAsync(d_off, frag_off, n * 8, hipMemcpyHostToDevice, st));
+  HIPCHK(h, hipMemcpyAsync(d_len, frag_len, n * 4, hipMemcpyHostToDevice, st));
+  HIPCHK(h, hipMemsetAsync(d_out, 0, n * (size_t)s * sizeof(wfm_minmer_t), st));
+  if (lds > 64 * 1024) {
+    HIPCHK(h, hipFuncSetAttribute((const void*)sketch_fragments_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  }
+  hipLaunchKernelGGL(sketch_fragments_kernel, dim3((unsigned)n), dim3(256), lds, st, d_norm, d_off, d_len, k, s, seq_id, npow2, d_out, d_cnt);
+  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, hipMemcpyAsync(out, d_out, n * (size_t)s * sizeof(wfm_minmer_t), hipMemcpyDeviceToHost, st));
+  HIPCHK(h, hipMemcpyAsync(out_count, d_cnt, n * 4, hipMemcpyDeviceToHost, st));
+  HIPCHK(h, hipStreamSynchronize(st));
+  return WFM_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,72 @@
+// wfa_device.h -- job descriptors shared by the HIP kernels and the host driver.
+#ifndef WFM_WFA_DEVICE_H_
+#define WFM_WFA_DEVICE_H_
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace wfm {
+
+constexpr int WF_NULL = -(1 << 30);
+constexpr int RING = 32;  // rows kept per component; must be >= score scope
+constexpr int RMASK = RING - 1;
+
+// wavefront components (same numbering as oracle/wfa2p.h)
+enum { C_M = 0, C_I1 = 1, C_I2 = 2, C_D1 = 3, C_D2 = 4 };
+// RLE op codes: entry = (len << 2) | op ; 0 = empty slot
+enum { OP_M = 0, OP_X = 1, OP_I = 2, OP_D = 3 };
+// backtrace decision byte: bits 0-2 = M source component, bits 3-6 = "came by extension"
+enum { BT_I1_EXT = 8, BT_I2_EXT = 16, BT_D1_EXT = 32, BT_D2_EXT = 64 };
+
+constexpr int WFM_DEV_UNREACHABLE = -300;
+constexpr int WFM_DEV_OVERFLOW = -2;  // base job exceeded its score budget (smax)
+
+struct DevPen { int x, o1, e1, o2, e2; };
+
+struct BpJob {
+  int64_t p_fwd, t_fwd, p_rev, t_rev;  // byte offsets of the sub-range starts in the sequence buffer
+  int64_t ring_off;                    // int32 element offset of this job's ring
+  int32_t pl, tl;
+  int32_t comp_begin, comp_end;
+  int32_t width;                       // row stride = pl + tl + 3
+  int32_t pad_;
+};
+
+struct BpResult {
+  int32_t status;  // 0 breakpoint found; 1 end reached at score 0; <0 error
+  int32_t score, score_fwd, score_rev, k_fwd, off_fwd, comp;
+  int32_t steps;
+  uint64_t cells;
+};
+
+struct BaseJob {
+  int64_t p_off, t_off;  // byte offsets of the (forward) sub-range starts
+  int64_t pre_off;       // int32 element offset: pre[(smax+1)][width]
+  int64_t bt_off;        // byte offset: bt[(smax+1)][width]
+  int64_t ring_off;      // int32 element offset: ring[5][RING][width]
+  int64_t rle_end;       // exclusive end of this job's slot in the RLE buffer
+  int32_t pl, tl;
+  int32_t comp_begin, comp_end;
+  int32_t endsfree, pbf, pef, tbf, tef;
+  int32_t smax, kmin, width;
+  int32_t type;          // 0 WFA; 1 all-D (tl == 0); 2 all-I (pl == 0)
+  int32_t pad_;
+};
+
+struct BaseResult {
+  int32_t status;  // 0 ok; WFM_DEV_OVERFLOW; <0 error
+  int32_t score;
+  int32_t nruns;
+  int32_t pad_;
+  uint64_t cells;
+};
+
+void launch_bp(const uint8_t* seq, int32_t* ring, const BpJob* jobs, BpResult* res, int njobs, int threads,
+               DevPen pen, int scope, hipStream_t st);
+void launch_base(const uint8_t* seq, int32_t* a32, uint8_t* a8, uint32_t* rle, const BaseJob* jobs, BaseResult* res,
+                 int njobs, DevPen pen, hipStream_t st);
+void launch_compact(const uint32_t* rle, const int64_t* off, const int64_t* cap, uint32_t* out, unsigned long long* total,
+                    int64_t* out_start, int32_t* out_count, int nprob, hipStream_t st);
+
+}  // namespace wfm
+#endif

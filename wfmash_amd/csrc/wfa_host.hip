@@ -1,0 +1,575 @@
+// wfa_host.hip -- host driver + C ABI of the align path (see include/wfmash_hip.h).
+//
+// Restates the control flow WFA2-lib runs on the CPU for
+// WFAlignerGapAffine2Pieces::alignEnd2End(MemoryUltralow) (wflign.cpp:136-148):
+// recursive BiWFA -- find breakpoint, split, recurse; sub-problems whose
+// remaining score is <= 250 (or trivially empty) go to the unidirectional base
+// aligner -- but breadth-first: every recursion level of every problem of the
+// batch is ONE launch of wfa_bp_kernel plus ONE launch of wfa_base_kernel.
+// Ends-free patches (wflign.cpp:280-305,368-397) are base jobs directly.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <climits>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/wfmash_hip.h"
+#include "wfa_device.h"
+
+namespace {
+
+using namespace wfm;
+
+constexpr int BIALIGN_FALLBACK_MIN_SCORE = 250;   // WFA2-lib WF_BIALIGN_FALLBACK_MIN_SCORE
+constexpr int BIALIGN_FALLBACK_MIN_LENGTH = 100;  // WFA2-lib WF_BIALIGN_FALLBACK_MIN_LENGTH
+constexpr int SEQ_PAD = 16;
+
+#define HIPCHK(h, call)                                                                 \
+  do {                                                                                  \
+    hipError_t e_ = (call);                                                             \
+    if (e_ != hipSuccess) {                                                             \
+      (h)->err = std::string(#call) + ": " + hipGetErrorString(e_);                     \
+      return WFM_E_HIP;                                                                 \
+    }                                                                                   \
+  } while (0)
+
+template <typename T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t cap = 0;  // elements
+  int ensure(size_t n) {
+    if (n <= cap) return 0;
+    if (p) (void)hipFree(p);
+    p = nullptr; cap = 0;
+    size_t want = n + n / 8 + 64;
+    if (hipMalloc((void**)&p, want * sizeof(T)) != hipSuccess) {
+      if (hipMalloc((void**)&p, n * sizeof(T)) != hipSuccess) { p = nullptr; return -1; }
+      want = n;
+    }
+    cap = want;
+    return 0;
+  }
+  void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+struct ProbMeta {
+  int64_t p_fwd, t_fwd, p_rev, t_rev;  // offsets into device sequence buffer
+  int32_t plen, tlen;
+  int32_t mode, pbf, pef, tbf, tef;
+  int64_t rle_off;  // start of this problem's RLE slot range
+};
+
+struct Node {
+  int32_t prob;
+  int32_t pb, pl, tb, tl;
+  int32_t cb, ce;
+  int32_t score_rem;  // INT_MAX at the root
+  int32_t smax;       // base jobs: score budget (0 = derive)
+  int32_t endsfree;
+};
+
+}  // namespace
+
+struct wfm_seqset {
+  uint8_t* d_seq = nullptr;
+  size_t bytes = 0;
+  std::vector<ProbMeta> meta;
+  int64_t rle_total = 0;
+  uint64_t seq_bases = 0;
+};
+
+struct wfm_handle {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
+  std::string err;
+  std::string name;
+  size_t mem_budget = 0;
+  wfm_stats_t stats{};
+  DevBuf<int32_t> ring;      // breakpoint rings
+  DevBuf<int32_t> base32;    // base: pre + rings
+  DevBuf<uint8_t> base8;     // base: bt
+  DevBuf<uint32_t> rle, rle_out;
+  DevBuf<BpJob> bpjobs;
+  DevBuf<BpResult> bpres;
+  DevBuf<BaseJob> bsjobs;
+  DevBuf<BaseResult> bsres;
+  DevBuf<int64_t> i64a, i64b, i64c;
+  DevBuf<int32_t> i32a;
+  DevBuf<unsigned long long> total;
+};
+
+namespace {
+
+inline int gapcost(const wfm_penalties_t& p, int L) {
+  if (L <= 0) return 0;
+  return std::min(p.o1 + p.e1 * L, p.o2 + p.e2 * L);
+}
+
+int validate_pen(const wfm_penalties_t* pen, int* scope) {
+  if (!pen) return WFM_E_ARG;
+  if (pen->x <= 0 || pen->e1 <= 0 || pen->e2 <= 0 || pen->o1 < 0 || pen->o2 < 0) return WFM_E_UNSUPPORTED;
+  const int sc = std::max(pen->x, std::max(pen->o1 + pen->e1, pen->o2 + pen->e2)) + 1;
+  if (sc > RING) return WFM_E_UNSUPPORTED;
+  *scope = sc;
+  return WFM_OK;
+}
+
+struct LevelTimer {
+  double bp_ms = 0, base_ms = 0;
+};
+
+// Runs all base jobs of `nodes` (chunked to the memory budget); appends
+// overflowed nodes (with a doubled budget) to `retry`.
+int run_base_jobs(wfm_handle* h, wfm_seqset* S, const wfm_penalties_t& pen, const std::vector<Node>& nodes,
+                  std::vector<Node>& retry, std::vector<int32_t>& prob_status, std::vector<uint64_t>& prob_cells,
+                  LevelTimer& tm) {
+  if (nodes.empty()) return WFM_OK;
+  const DevPen dp{pen.x, pen.o1, pen.e1, pen.o2, pen.e2};
+  size_t i0 = 0;
+  std::vector<BaseJob> jobs;
+  std::vector<BaseResult> res;
+  while (i0 < nodes.size()) {
+    jobs.clear();
+    size_t n32 = 0, n8 = 0;
+    size_t i = i0;
+    for (; i < nodes.size(); ++i) {
+      const Node& nd = nodes[i];
+      const ProbMeta& pm = S->meta[nd.prob];
+      BaseJob j{};
+      j.p_off = pm.p_fwd + nd.pb;
+      j.t_off = pm.t_fwd + nd.tb;
+      j.pl = nd.pl; j.tl = nd.tl;
+      j.comp_begin = nd.cb; j.comp_end = nd.ce;
+      j.endsfree = nd.endsfree;
+      j.pbf = pm.pbf; j.pef = pm.pef; j.tbf = pm.tbf; j.tef = pm.tef;
+      j.rle_end = pm.rle_off + nd.pb + nd.tb + nd.pl + nd.tl;
+      j.pad_ = (int32_t)i;
+      if (nd.tl == 0 || nd.pl == 0) {
+        j.type = nd.tl == 0 ? 1 : 2;
+        if (nd.tl == 0 && nd.pl == 0) { j.type = 1; }
+        jobs.push_back(j);
+        continue;
+      }
+      j.type = 0;
+      j.smax = nd.smax;
+      int kmin, kmax;
+      if (nd.endsfree) {
+        kmin = std::max(-nd.pl, -pm.pbf - nd.smax);
+        kmax = std::min(nd.tl, pm.tbf + nd.smax);
+      } else {
+        kmin = std::max(-nd.pl, -nd.smax);
+        kmax = std::min(nd.tl, nd.smax);
+      }
+      j.kmin = kmin;
+      j.width = kmax - kmin + 1;
+      const size_t rows = (size_t)nd.smax + 1;
+      const size_t need32 = rows * (size_t)j.width + (size_t)5 * RING * (size_t)j.width;
+      const size_t need8 = rows * (size_t)j.width;
+      if (!jobs.empty() && (n32 + need32) * 4 + (n8 + need8) > h->mem_budget) break;
+      if (need32 * 4 + need8 > h->mem_budget) {  // a single job beyond the budget
+        prob_status[nd.prob] = WFM_ST_OOM;
+        continue;
+      }
+      j.pre_off = (int64_t)n32;
+      j.ring_off = (int64_t)(n32 + rows * (size_t)j.width);
+      j.bt_off = (int64_t)n8;
+      n32 += need32; n8 += need8;
+      jobs.push_back(j);
+    }
+    const size_t chunk_end = i;
+    if (!jobs.empty()) {
+      if (h->base32.ensure(n32 + 16) || h->base8.ensure(n8 + 16) || h->bsjobs.ensure(jobs.size()) || h->bsres.ensure(jobs.size())) {
+        h->err = "out of device memory (base arena)";
+        return WFM_E_NOMEM;
+      }
+      HIPCHK(h, hipMemcpyAsync(h->bsjobs.p, jobs.data(), jobs.size() * sizeof(BaseJob), hipMemcpyHostToDevice, h->stream));
+      HIPCHK(h, hipEventRecord(h->ev2, h->stream));
+      launch_base(S->d_seq, h->base32.p, h->base8.p, h->rle.p, h->bsjobs.p, h->bsres.p, (int)jobs.size(), dp, h->stream);
+      HIPCHK(h, hipGetLastError());
+      HIPCHK(h, hipEventRecord(h->ev3, h->stream));
+      res.resize(jobs.size());
+      HIPCHK(h, hipMemcpyAsync(res.data(), h->bsres.p, jobs.size() * sizeof(BaseResult), hipMemcpyDeviceToHost, h->stream));
+      HIPCHK(h, hipStreamSynchronize(h->stream));
+      float ms = 0;
+      HIPCHK(h, hipEventElapsedTime(&ms, h->ev2, h->ev3));
+      tm.base_ms += ms;
+      h->stats.base_launches++;
+      h->stats.base_jobs += (uint32_t)jobs.size();
+      for (size_t q = 0; q < jobs.size(); ++q) {
+        const Node& nd = nodes[(size_t)jobs[q].pad_];
+        const BaseResult& r = res[q];
+        prob_cells[nd.prob] += r.cells;
+        if (r.status == WFM_DEV_OVERFLOW) {
+          Node again = nd;
+          const int64_t bound = (int64_t)gapcost(pen, nd.pl) + gapcost(pen, nd.tl) + 8;
+          if (nd.smax >= bound) { prob_status[nd.prob] = WFM_ST_UNREACHABLE; continue; }
+          again.smax = (int32_t)std::min<int64_t>((int64_t)nd.smax * 2 + 32, bound);
+          retry.push_back(again);
+        } else if (r.status != 0) {
+          prob_status[nd.prob] = WFM_ST_UNREACHABLE;
+        }
+      }
+    }
+    i0 = chunk_end;
+  }
+  return WFM_OK;
+}
+
+int align_resident_impl(wfm_handle* h, const wfm_penalties_t* pen, wfm_seqset* S, wfm_result_t* out,
+                        char* ops_arena, size_t arena_bytes) {
+  int scope = 0;
+  int rc = validate_pen(pen, &scope);
+  if (rc != WFM_OK) { h->err = "unsupported penalties"; return rc; }
+  const auto t_start = std::chrono::steady_clock::now();
+  HIPCHK(h, hipSetDevice(h->device));
+  const size_t n = S->meta.size();
+  h->stats = wfm_stats_t{};
+  if (n == 0) return 0;
+  const DevPen dp{pen->x, pen->o1, pen->e1, pen->o2, pen->e2};
+
+  std::vector<int32_t> prob_status(n, WFM_ST_OK);
+  std::vector<uint64_t> prob_cells(n, 0);
+
+  // RLE slot buffer (zero = empty)
+  if (h->rle.ensure((size_t)S->rle_total + 16) || h->rle_out.ensure((size_t)S->rle_total + 16)) {
+    h->err = "out of device memory (rle)"; return WFM_E_NOMEM;
+  }
+  HIPCHK(h, hipMemsetAsync(h->rle.p, 0, ((size_t)S->rle_total + 16) * sizeof(uint32_t), h->stream));
+
+  // roots
+  std::vector<Node> bp_nodes, base_nodes, next_bp, retry;
+  for (size_t i = 0; i < n; ++i) {
+    const ProbMeta& pm = S->meta[i];
+    Node nd{};
+    nd.prob = (int32_t)i; nd.pb = 0; nd.pl = pm.plen; nd.tb = 0; nd.tl = pm.tlen;
+    nd.cb = C_M; nd.ce = C_M; nd.score_rem = INT_MAX; nd.endsfree = 0;
+    const int64_t bound = (int64_t)gapcost(*pen, pm.plen) + gapcost(*pen, pm.tlen) + 8;
+    if (pm.mode == WFM_MODE_ENDSFREE) {
+      nd.endsfree = 1;
+      // ends-free score is bounded by the cheaper all-gap alignment; start small, double on overflow
+      nd.smax = (int32_t)std::min<int64_t>(bound, 256);
+      base_nodes.push_back(nd);
+    } else if (pm.mode == WFM_MODE_END2END_UNI || std::max(pm.plen, pm.tlen) <= BIALIGN_FALLBACK_MIN_LENGTH ||
+               pm.plen == 0 || pm.tlen == 0) {
+      nd.smax = (int32_t)std::min<int64_t>(bound, 256);
+      base_nodes.push_back(nd);
+    } else {
+      bp_nodes.push_back(nd);
+    }
+  }
+
+  LevelTimer tm;
+  std::vector<BpJob> jobs;
+  std::vector<BpResult> res;
+  uint32_t level = 0;
+  while (!bp_nodes.empty() || !base_nodes.empty()) {
+    ++level;
+    // ---- breakpoint jobs of this level (chunked to the memory budget) ----
+    next_bp.clear();
+    size_t i0 = 0;
+    while (i0 < bp_nodes.size()) {
+      jobs.clear();
+      size_t ring_elems = 0;
+      size_t i = i0;
+      int maxw = 0;
+      for (; i < bp_nodes.size(); ++i) {
+        const Node& nd = bp_nodes[i];
+        const ProbMeta& pm = S->meta[nd.prob];
+        const size_t width = (size_t)nd.pl + nd.tl + 3;
+        const size_t need = width * 2 * 5 * RING;
+        if (!jobs.empty() && (ring_elems + need) * 4 > h->mem_budget) break;
+        if (need * 4 > h->mem_budget) { prob_status[nd.prob] = WFM_ST_OOM; continue; }
+        BpJob j{};
+        j.p_fwd = pm.p_fwd + nd.pb;
+        j.t_fwd = pm.t_fwd + nd.tb;
+        j.p_rev = pm.p_rev + (pm.plen - nd.pb - nd.pl);
+        j.t_rev = pm.t_rev + (pm.tlen - nd.tb - nd.tl);
+        j.ring_off = (int64_t)ring_elems;
+        j.pl = nd.pl; j.tl = nd.tl;
+        j.comp_begin = nd.cb; j.comp_end = nd.ce;
+        j.width = (int32_t)width;
+        j.pad_ = (int32_t)i;  // node index
+        ring_elems += need;
+        maxw = std::max(maxw, (int)width);
+        jobs.push_back(j);
+      }
+      const size_t chunk_end = i;
+      if (!jobs.empty()) {
+        if (h->ring.ensure(ring_elems + 16) || h->bpjobs.ensure(jobs.size()) || h->bpres.ensure(jobs.size())) {
+          h->err = "out of device memory (ring arena)"; return WFM_E_NOMEM;
+        }
+        // workgroup size: wide wavefronts want all 16 waves of a CU
+        int threads = 1024;
+        if (maxw <= 1024) threads = 256;
+        else if (maxw <= 8192) threads = 512;
+        HIPCHK(h, hipMemcpyAsync(h->bpjobs.p, jobs.data(), jobs.size() * sizeof(BpJob), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipEventRecord(h->ev0, h->stream));
+        launch_bp(S->d_seq, h->ring.p, h->bpjobs.p, h->bpres.p, (int)jobs.size(), threads, dp, scope, h->stream);
+        HIPCHK(h, hipGetLastError());
+        HIPCHK(h, hipEventRecord(h->ev1, h->stream));
+        res.resize(jobs.size());
+        HIPCHK(h, hipMemcpyAsync(res.data(), h->bpres.p, jobs.size() * sizeof(BpResult), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        float ms = 0;
+        HIPCHK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
+        tm.bp_ms += ms;
+        h->stats.bp_launches++;
+        h->stats.bp_jobs += (uint32_t)jobs.size();
+        for (size_t q = 0; q < jobs.size(); ++q) {
+          const Node& nd = bp_nodes[(size_t)jobs[q].pad_];
+          const BpResult& r = res[q];
+          prob_cells[nd.prob] += r.cells;
+          if (r.status == 1) {  // end reached at score 0 -> base aligner
+            Node b = nd; b.smax = 0; base_nodes.push_back(b);
+          } else if (r.status != 0) {
+            prob_status[nd.prob] = WFM_ST_UNREACHABLE;
+          } else {
+            const int bp_h = r.off_fwd, bp_v = r.off_fwd - r.k_fwd;
+            if (bp_h < 0 || bp_v < 0 || bp_h > nd.tl || bp_v > nd.pl) { prob_status[nd.prob] = WFM_ST_UNREACHABLE; continue; }
+            Node a{}, b{};
+            a.prob = nd.prob; a.pb = nd.pb; a.pl = bp_v; a.tb = nd.tb; a.tl = bp_h;
+            a.cb = nd.cb; a.ce = r.comp; a.score_rem = r.score_fwd;
+            b.prob = nd.prob; b.pb = nd.pb + bp_v; b.pl = nd.pl - bp_v; b.tb = nd.tb + bp_h; b.tl = nd.tl - bp_h;
+            b.cb = r.comp; b.ce = nd.ce; b.score_rem = r.score_rev;
+            for (Node* c : {&a, &b}) {
+              if (c->pl == 0 || c->tl == 0) { c->smax = 0; base_nodes.push_back(*c); }
+              else if (c->score_rem <= BIALIGN_FALLBACK_MIN_SCORE) { c->smax = std::max(c->score_rem, 0); base_nodes.push_back(*c); }
+              else next_bp.push_back(*c);
+            }
+          }
+        }
+      }
+      i0 = chunk_end;
+    }
+    bp_nodes.swap(next_bp);
+    // ---- base jobs collected so far (incl. retries with a larger budget) ----
+    while (!base_nodes.empty()) {
+      retry.clear();
+      rc = run_base_jobs(h, S, *pen, base_nodes, retry, prob_status, prob_cells, tm);
+      if (rc != WFM_OK) return rc;
+      base_nodes.swap(retry);
+    }
+  }
+  h->stats.levels = level;
+
+  // ---- gather RLE pieces ----
+  std::vector<int64_t> poff(n), pcap(n);
+  for (size_t i = 0; i < n; ++i) { poff[i] = S->meta[i].rle_off; pcap[i] = (int64_t)S->meta[i].plen + S->meta[i].tlen; }
+  if (h->i64a.ensure(n) || h->i64b.ensure(n) || h->i64c.ensure(n) || h->i32a.ensure(n) || h->total.ensure(1)) {
+    h->err = "out of device memory"; return WFM_E_NOMEM;
+  }
+  HIPCHK(h, hipMemcpyAsync(h->i64a.p, poff.data(), n * sizeof(int64_t), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipMemcpyAsync(h->i64b.p, pcap.data(), n * sizeof(int64_t), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipMemsetAsync(h->total.p, 0, sizeof(unsigned long long), h->stream));
+  launch_compact(h->rle.p, h->i64a.p, h->i64b.p, h->rle_out.p, h->total.p, h->i64c.p, h->i32a.p, (int)n, h->stream);
+  HIPCHK(h, hipGetLastError());
+  std::vector<int64_t> ostart(n);
+  std::vector<int32_t> ocount(n);
+  unsigned long long total = 0;
+  HIPCHK(h, hipMemcpyAsync(ostart.data(), h->i64c.p, n * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipMemcpyAsync(ocount.data(), h->i32a.p, n * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipMemcpyAsync(&total, h->total.p, sizeof(total), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  std::vector<uint32_t> runs((size_t)total + 1);
+  if (total) HIPCHK(h, hipMemcpy(runs.data(), h->rle_out.p, (size_t)total * sizeof(uint32_t), hipMemcpyDeviceToHost));
+
+  // ---- expand to op strings ----
+  static const char opc[4] = {'M', 'X', 'I', 'D'};
+  size_t arena_pos = 0;
+  int failed = 0;
+  uint64_t cells_total = 0;
+  for (size_t i = 0; i < n; ++i) {
+    wfm_result_t& r = out[i];
+    r.status = prob_status[i];
+    r.cells = prob_cells[i];
+    cells_total += prob_cells[i];
+    r.ops_off = arena_pos; r.ops_len = 0; r.n_runs = 0; r.score = -1;
+    if (r.status != WFM_ST_OK) { ++failed; continue; }
+    const uint32_t* e = runs.data() + ostart[i];
+    const int cnt = ocount[i];
+    int64_t score = 0;
+    uint64_t pc = 0, tc = 0;
+    uint32_t nruns = 0;
+    size_t pos = arena_pos;
+    int k = 0;
+    while (k < cnt) {
+      const int op = (int)(e[k] & 3u);
+      uint64_t len = e[k] >> 2;
+      int k2 = k + 1;
+      while (k2 < cnt && (int)(e[k2] & 3u) == op) { len += e[k2] >> 2; ++k2; }
+      if (pos + len > arena_bytes) { h->err = "ops arena too small"; return WFM_E_ARENA; }
+      memset(ops_arena + pos, opc[op], (size_t)len);
+      pos += (size_t)len;
+      ++nruns;
+      if (op == OP_X) { score += (int64_t)len * pen->x; pc += len; tc += len; }
+      else if (op == OP_M) { pc += len; tc += len; }
+      else {
+        score += std::min<int64_t>(pen->o1 + (int64_t)len * pen->e1, pen->o2 + (int64_t)len * pen->e2);
+        if (op == OP_I) tc += len; else pc += len;
+      }
+      k = k2;
+    }
+    if (pc != (uint64_t)S->meta[i].plen || tc != (uint64_t)S->meta[i].tlen) {
+      r.status = WFM_ST_UNREACHABLE;  // internal inconsistency: never report a broken CIGAR as ok
+      ++failed;
+      continue;
+    }
+    r.ops_len = (uint32_t)(pos - arena_pos);
+    r.n_runs = nruns;
+    r.score = (int32_t)score;
+    arena_pos = pos;
+  }
+  h->stats.cells = cells_total;
+  h->stats.bytes_algorithmic = 48ull * cells_total + S->seq_bases;
+  h->stats.ms_breakpoint = tm.bp_ms;
+  h->stats.ms_base = tm.base_ms;
+  h->stats.ms_kernels = tm.bp_ms + tm.base_ms;
+  h->stats.ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
+  return failed;
+}
+
+}  // namespace
+
+extern "C" {
+
+int wfm_create(int device, wfm_handle_t** out) {
+  if (!out) return WFM_E_ARG;
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return WFM_E_NODEVICE;
+  if (device < 0 || device >= ndev) return WFM_E_ARG;
+  if (hipSetDevice(device) != hipSuccess) return WFM_E_HIP;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) != hipSuccess) return WFM_E_HIP;
+  wfm_handle* h = new wfm_handle();
+  h->device = device;
+  h->name = std::string(prop.name) + " (" + prop.gcnArchName + ")";
+  if (hipStreamCreate(&h->stream) != hipSuccess) { delete h; return WFM_E_HIP; }
+  (void)hipEventCreate(&h->ev0); (void)hipEventCreate(&h->ev1); (void)hipEventCreate(&h->ev2); (void)hipEventCreate(&h->ev3);
+  size_t fr = 0, tot = 0;
+  if (hipMemGetInfo(&fr, &tot) != hipSuccess) { fr = (size_t)16 << 30; }
+  h->mem_budget = (size_t)((double)fr * 0.40);
+  const char* env = getenv("WFM_MEM_BUDGET_MB");
+  if (env) h->mem_budget = (size_t)atoll(env) << 20;
+  *out = h;
+  return WFM_OK;
+}
+
+void wfm_destroy(wfm_handle_t* h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  h->ring.release(); h->base32.release(); h->base8.release(); h->rle.release(); h->rle_out.release();
+  h->bpjobs.release(); h->bpres.release(); h->bsjobs.release(); h->bsres.release();
+  h->i64a.release(); h->i64b.release(); h->i64c.release(); h->i32a.release(); h->total.release();
+  if (h->ev0) (void)hipEventDestroy(h->ev0);
+  if (h->ev1) (void)hipEventDestroy(h->ev1);
+  if (h->ev2) (void)hipEventDestroy(h->ev2);
+  if (h->ev3) (void)hipEventDestroy(h->ev3);
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+}
+
+const char* wfm_last_error(const wfm_handle_t* h) { return h ? h->err.c_str() : "null handle"; }
+
+int wfm_device_name(const wfm_handle_t* h, char* buf, size_t buflen) {
+  if (!h || !buf || !buflen) return WFM_E_ARG;
+  snprintf(buf, buflen, "%s", h->name.c_str());
+  return WFM_OK;
+}
+
+size_t wfm_align_arena_bytes(const wfm_problem_t* problems, size_t n) {
+  size_t t = 0;
+  for (size_t i = 0; i < n; ++i) t += (size_t)problems[i].plen + (size_t)problems[i].tlen + 1;
+  return t;
+}
+
+int wfm_upload_sequences(wfm_handle_t* h, const wfm_problem_t* problems, size_t n, wfm_seqset_t** out) {
+  if (!h || !out || (n && !problems)) return WFM_E_ARG;
+  *out = nullptr;
+  HIPCHK(h, hipSetDevice(h->device));
+  wfm_seqset* S = new wfm_seqset();
+  S->meta.resize(n);
+  size_t bytes = SEQ_PAD;
+  int64_t rle = 0;
+  for (size_t i = 0; i < n; ++i) {
+    const wfm_problem_t& p = problems[i];
+    if (p.plen < 0 || p.tlen < 0 || (int64_t)p.plen + p.tlen > (1 << 29) || (p.plen && !p.pattern) || (p.tlen && !p.text)) {
+      delete S; h->err = "bad problem"; return WFM_E_ARG;
+    }
+    ProbMeta& m = S->meta[i];
+    m.plen = p.plen; m.tlen = p.tlen; m.mode = p.mode;
+    m.pbf = std::min(std::max(p.pattern_begin_free, 0), p.plen); m.pef = std::min(std::max(p.pattern_end_free, 0), p.plen);
+    m.tbf = std::min(std::max(p.text_begin_free, 0), p.tlen);    m.tef = std::min(std::max(p.text_end_free, 0), p.tlen);
+    if (p.mode != WFM_MODE_ENDSFREE) { m.pbf = m.pef = m.tbf = m.tef = 0; }
+    m.p_fwd = (int64_t)bytes; bytes += (size_t)p.plen + SEQ_PAD;
+    m.t_fwd = (int64_t)bytes; bytes += (size_t)p.tlen + SEQ_PAD;
+    const bool need_rev = (p.mode == WFM_MODE_END2END_BIWFA);
+    if (need_rev) {
+      m.p_rev = (int64_t)bytes; bytes += (size_t)p.plen + SEQ_PAD;
+      m.t_rev = (int64_t)bytes; bytes += (size_t)p.tlen + SEQ_PAD;
+    } else { m.p_rev = m.p_fwd; m.t_rev = m.t_fwd; }
+    m.rle_off = rle; rle += (int64_t)p.plen + p.tlen + 1;
+    S->seq_bases += (uint64_t)p.plen + (uint64_t)p.tlen;
+  }
+  bytes += SEQ_PAD;
+  std::vector<uint8_t> host(bytes, 0);
+  for (size_t i = 0; i < n; ++i) {
+    const wfm_problem_t& p = problems[i];
+    const ProbMeta& m = S->meta[i];
+    if (p.plen) memcpy(host.data() + m.p_fwd, p.pattern, (size_t)p.plen);
+    if (p.tlen) memcpy(host.data() + m.t_fwd, p.text, (size_t)p.tlen);
+    if (p.mode == WFM_MODE_END2END_BIWFA) {
+      for (int q = 0; q < p.plen; ++q) host[(size_t)m.p_rev + q] = (uint8_t)p.pattern[p.plen - 1 - q];
+      for (int q = 0; q < p.tlen; ++q) host[(size_t)m.t_rev + q] = (uint8_t)p.text[p.tlen - 1 - q];
+    }
+  }
+  if (hipMalloc((void**)&S->d_seq, bytes) != hipSuccess) { delete S; h->err = "out of device memory (sequences)"; return WFM_E_NOMEM; }
+  S->bytes = bytes;
+  S->rle_total = rle;
+  hipError_t e = hipMemcpy(S->d_seq, host.data(), bytes, hipMemcpyHostToDevice);
+  if (e != hipSuccess) { (void)hipFree(S->d_seq); delete S; h->err = hipGetErrorString(e); return WFM_E_HIP; }
+  *out = S;
+  return WFM_OK;
+}
+
+void wfm_free_sequences(wfm_handle_t* h, wfm_seqset_t* s) {
+  if (!s) return;
+  if (h) (void)hipSetDevice(h->device);
+  if (s->d_seq) (void)hipFree(s->d_seq);
+  delete s;
+}
+
+int wfm_align_resident(wfm_handle_t* h, const wfm_penalties_t* pen, wfm_seqset_t* s, wfm_result_t* out,
+                       char* ops_arena, size_t arena_bytes) {
+  if (!h || !s || !out || (!ops_arena && arena_bytes)) return WFM_E_ARG;
+  return align_resident_impl(h, pen, s, out, ops_arena, arena_bytes);
+}
+
+int wfm_align_batch(wfm_handle_t* h, const wfm_penalties_t* pen, const wfm_problem_t* problems, size_t n,
+                    wfm_result_t* out, char* ops_arena, size_t arena_bytes) {
+  if (!h) return WFM_E_ARG;
+  wfm_seqset_t* S = nullptr;
+  int rc = wfm_upload_sequences(h, problems, n, &S);
+  if (rc != WFM_OK) return rc;
+  rc = wfm_align_resident(h, pen, S, out, ops_arena, arena_bytes);
+  wfm_free_sequences(h, S);
+  return rc;
+}
+
+int wfm_get_stats(const wfm_handle_t* h, wfm_stats_t* out) {
+  if (!h || !out) return WFM_E_ARG;
+  *out = h->stats;
+  return WFM_OK;
+}
+
+}  // extern "C"
+
+#include "wfa_handle.h"
+hipStream_t wfm_stream(wfm_handle_t* h) { return h->stream; }
+int wfm_device(const wfm_handle_t* h) { return h->device; }
+void wfm_set_error(wfm_handle_t* h, const std::string& msg) { h->err = msg; }

@@ -1,0 +1,637 @@
+// wfa_kernels.hip -- gap-affine 2-piece wavefront alignment kernels for gfx950.
+//
+// Replaces the WFA2-lib calls made at wflign.cpp:136-148 (alignEnd2End,
+// MemoryUltralow = BiWFA), :280-305 and :368-397 (alignEndsFree, MemoryMed).
+// One alignment (sub-)problem per workgroup; wavefront offsets live in a
+// per-job ring in HBM/L2 ([dir][component][32 rows][diagonal], diagonals
+// contiguous -> coalesced), row ranges in LDS, wave-64 shuffles for the
+// per-step reductions.  Integer DP: no MFMA.
+//
+//   wfa_bp_kernel    BiWFA breakpoint search (forward + reverse score-only
+//                    wavefronts, 26-score scope kept in a 32-row ring)
+//   wfa_base_kernel  unidirectional WFA with per-cell backtrace decisions
+//                    (BiWFA leaves, ends-free patches, short sequences)
+//   rle_compact_kernel  gathers the leaves' run-length CIGAR pieces
+//
+// Conventions: pattern -> v, text -> h, k = h - v, offset = h, NULL = -2^30.
+// Every out-of-bounds cell (h>tlen or v>plen) is nulled in ALL components;
+// this is result-equivalent to WFA2-lib (which nulls only M and trims ends):
+// an out-of-bounds I/D offset can only feed out-of-bounds cells.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "wfa_device.h"
+
+namespace wfm {
+
+__device__ __forceinline__ uint64_t load8(const uint8_t* p) {
+  uint64_t v;
+  __builtin_memcpy(&v, p, 8);
+  return v;
+}
+
+// longest common extension of P[v..) and T[h..), bounded by the sub-problem ends
+__device__ __forceinline__ int lce_bounded(const uint8_t* P, const uint8_t* T, int v, int h, int pl, int tl) {
+  const int maxn = min(pl - v, tl - h);
+  const uint8_t* a = P + v;
+  const uint8_t* b = T + h;
+  int n = 0;
+  while (n < maxn) {
+    const uint64_t x = load8(a + n) ^ load8(b + n);
+    if (x) {
+      n += (int)(__builtin_ctzll(x) >> 3);
+      break;
+    }
+    n += 8;
+  }
+  return min(n, maxn);
+}
+
+struct Src {
+  const int32_t* p;  // p[k] addresses diagonal k
+  int lo, hi;
+};
+
+__device__ __forceinline__ int ldk(const Src& r, int k) {
+  return (k >= r.lo && k <= r.hi) ? r.p[k] : WF_NULL;
+}
+
+__device__ __forceinline__ int valid_or_null(int off, int k, unsigned pl, unsigned tl) {
+  const unsigned h = (unsigned)off, v = (unsigned)(off - k);
+  return (h <= tl && v <= pl) ? off : WF_NULL;
+}
+
+__device__ __forceinline__ int wave_max(int x) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) x = max(x, __shfl_xor(x, d, 64));
+  return x;
+}
+
+__device__ __forceinline__ int imin3(int a, int b, int c) { return min(a, min(b, c)); }
+__device__ __forceinline__ int imax3(int a, int b, int c) { return max(a, max(b, c)); }
+
+// ---------------------------------------------------------------------------
+// BiWFA breakpoint kernel
+// ---------------------------------------------------------------------------
+struct BpCtx {
+  const uint8_t* P[2];
+  const uint8_t* T[2];
+  int32_t* ring;  // job ring base, already offset so that [row*width + k] works with +pl+1 applied
+  int64_t width;
+  int pl, tl;
+  DevPen pen;
+};
+
+__device__ __forceinline__ int32_t* bp_row(const BpCtx& c, int dir, int comp, int s) {
+  return c.ring + ((int64_t)((dir * 5 + comp) * RING + (s & RMASK))) * c.width;
+}
+
+__device__ __forceinline__ Src bp_src(const BpCtx& c, int dir, int comp, int s, const int (*s_lo)[RING], const int (*s_hi)[RING]) {
+  Src r;
+  if (s < 0) {
+    r.p = c.ring; r.lo = 1; r.hi = 0;
+  } else {
+    r.p = bp_row(c, dir, comp, s);
+    r.lo = s_lo[dir][s & RMASK];
+    r.hi = s_hi[dir][s & RMASK];
+  }
+  return r;
+}
+
+// Computes + extends row s of direction dir.  Returns #cells of the row (uniform).
+// Per-thread max antidiagonal is accumulated into mak.
+__device__ __forceinline__ int bp_compute_row(const BpCtx& c, int dir, int s, int (*s_lo)[RING], int (*s_hi)[RING], int& mak) {
+  const DevPen& pn = c.pen;
+  const Src mx  = bp_src(c, dir, C_M,  s - pn.x, s_lo, s_hi);
+  const Src mo1 = bp_src(c, dir, C_M,  s - pn.o1 - pn.e1, s_lo, s_hi);
+  const Src mo2 = bp_src(c, dir, C_M,  s - pn.o2 - pn.e2, s_lo, s_hi);
+  const Src i1  = bp_src(c, dir, C_I1, s - pn.e1, s_lo, s_hi);
+  const Src d1  = bp_src(c, dir, C_D1, s - pn.e1, s_lo, s_hi);
+  const Src i2  = bp_src(c, dir, C_I2, s - pn.e2, s_lo, s_hi);
+  const Src d2  = bp_src(c, dir, C_D2, s - pn.e2, s_lo, s_hi);
+  int lo = INT32_MAX, hi = INT32_MIN;
+  if (mx.lo <= mx.hi)   { lo = min(lo, mx.lo);      hi = max(hi, mx.hi); }
+  if (mo1.lo <= mo1.hi) { lo = min(lo, mo1.lo - 1); hi = max(hi, mo1.hi + 1); }
+  if (mo2.lo <= mo2.hi) { lo = min(lo, mo2.lo - 1); hi = max(hi, mo2.hi + 1); }
+  if (i1.lo <= i1.hi)   { lo = min(lo, i1.lo - 1);  hi = max(hi, i1.hi + 1); }
+  if (i2.lo <= i2.hi)   { lo = min(lo, i2.lo - 1);  hi = max(hi, i2.hi + 1); }
+  lo = max(lo, -c.pl);
+  hi = min(hi, c.tl);
+  const bool valid = (lo <= hi);
+  if (threadIdx.x == 0) {
+    s_lo[dir][s & RMASK] = valid ? lo : 1;
+    s_hi[dir][s & RMASK] = valid ? hi : 0;
+  }
+  if (!valid) return 0;
+  int32_t* om  = bp_row(c, dir, C_M, s);
+  int32_t* oi1 = bp_row(c, dir, C_I1, s);
+  int32_t* oi2 = bp_row(c, dir, C_I2, s);
+  int32_t* od1 = bp_row(c, dir, C_D1, s);
+  int32_t* od2 = bp_row(c, dir, C_D2, s);
+  const unsigned upl = (unsigned)c.pl, utl = (unsigned)c.tl;
+  const uint8_t* P = c.P[dir];
+  const uint8_t* T = c.T[dir];
+  for (int k = lo + (int)threadIdx.x; k <= hi; k += (int)blockDim.x) {
+    const int m1a = ldk(mo1, k - 1), m1b = ldk(mo1, k + 1);
+    const int m2a = ldk(mo2, k - 1), m2b = ldk(mo2, k + 1);
+    int ins1 = max(m1a, ldk(i1, k - 1)) + 1;
+    int ins2 = max(m2a, ldk(i2, k - 1)) + 1;
+    int del1 = max(m1b, ldk(d1, k + 1));
+    int del2 = max(m2b, ldk(d2, k + 1));
+    int mis  = ldk(mx, k) + 1;
+    ins1 = valid_or_null(ins1, k, upl, utl);
+    ins2 = valid_or_null(ins2, k, upl, utl);
+    del1 = valid_or_null(del1, k, upl, utl);
+    del2 = valid_or_null(del2, k, upl, utl);
+    mis  = valid_or_null(mis, k, upl, utl);
+    int m = max(imax3(ins1, ins2, mis), max(del1, del2));
+    if (m >= 0) {
+      m += lce_bounded(P, T, m - k, m, c.pl, c.tl);
+      mak = max(mak, 2 * m - k);
+    }
+    oi1[k] = ins1; oi2[k] = ins2; od1[k] = del1; od2[k] = del2; om[k] = m;
+  }
+  return hi - lo + 1;
+}
+
+// wavefront_bialign_overlap, data-parallel part: for every (i, comp) whose
+// breakpoint score would beat `best`, find the smallest k0 with
+// off0[k0] + off1[k1] >= tl.  Results in s_mink[i*5+comp].
+__device__ __forceinline__ void bp_overlap_scan(const BpCtx& c, int d0, int s0, int s1, int best,
+                                                const int (*s_lo)[RING], const int (*s_hi)[RING], int* s_mink, int scope) {
+  const int d1 = d0 ^ 1;
+  const int lo0 = s_lo[d0][s0 & RMASK], hi0 = s_hi[d0][s0 & RMASK];
+  if (lo0 > hi0) return;
+  const int kinv = c.tl - c.pl;
+  const int32_t* r0[5];
+#pragma unroll
+  for (int cc = 0; cc < 5; ++cc) r0[cc] = bp_row(c, d0, cc, s0);
+  for (int k0 = lo0 + (int)threadIdx.x; k0 <= hi0; k0 += (int)blockDim.x) {
+    const int k1 = kinv - k0;
+    int o0[5];
+#pragma unroll
+    for (int cc = 0; cc < 5; ++cc) o0[cc] = r0[cc][k0];
+    for (int i = 0; i < scope; ++i) {
+      const int si = s1 - i;
+      if (si < 0) break;
+      if (s0 + si - c.pen.o2 >= best) continue;
+      const int lo1 = s_lo[d1][si & RMASK], hi1 = s_hi[d1][si & RMASK];
+      if (k1 < lo1 || k1 > hi1) continue;
+#pragma unroll
+      for (int cc = 0; cc < 5; ++cc) {
+        const int gop = (cc == C_M) ? 0 : ((cc == C_I1 || cc == C_D1) ? c.pen.o1 : c.pen.o2);
+        if (s0 + si - gop >= best) continue;
+        if (o0[cc] < 0) continue;
+        const int o1 = bp_row(c, d1, cc, si)[k1];
+        if (o0[cc] + o1 >= c.tl) atomicMin(&s_mink[i * 5 + cc], k0);
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(1024) void wfa_bp_kernel(const uint8_t* __restrict__ seq, int32_t* __restrict__ ring_arena,
+                                                      const BpJob* __restrict__ jobs, BpResult* __restrict__ results,
+                                                      DevPen pen, int scope) {
+  const BpJob J = jobs[blockIdx.x];
+  __shared__ int s_lo[2][RING];
+  __shared__ int s_hi[2][RING];
+  __shared__ int s_mak[3][2];
+  __shared__ int s_mink[RING * 5];
+  __shared__ int s_bp[8];  // score, score_fwd, score_rev, k_fwd, off_fwd, comp
+
+  BpCtx c;
+  c.P[0] = seq + J.p_fwd; c.T[0] = seq + J.t_fwd;
+  c.P[1] = seq + J.p_rev; c.T[1] = seq + J.t_rev;
+  c.width = J.width;
+  c.ring = ring_arena + J.ring_off + (J.pl + 1);
+  c.pl = J.pl; c.tl = J.tl;
+  c.pen = pen;
+  const int tid = threadIdx.x;
+  const int A = J.pl + J.tl - 1;  // max_antidiagonal
+  uint64_t cells = 0;
+
+  // ---- init rows 0 (wavefront_unialign_init, end2end) ----
+  if (tid < 2 * RING) { s_lo[tid / RING][tid % RING] = 1; s_hi[tid / RING][tid % RING] = 0; }
+  if (tid < 6) ((int*)s_mak)[tid] = 0;
+  __syncthreads();
+  int end_reached = 0;
+  if (tid < 2) {
+    const int d = tid;
+    const int cb = d == 0 ? J.comp_begin : J.comp_end;
+    int m0 = WF_NULL, mak = 0;
+    for (int cc = 1; cc < 5; ++cc) bp_row(c, d, cc, 0)[0] = (cc == cb) ? 0 : WF_NULL;
+    if (cb == C_M) {
+      m0 = lce_bounded(c.P[d], c.T[d], 0, 0, c.pl, c.tl);
+      mak = 2 * m0;
+    }
+    bp_row(c, d, C_M, 0)[0] = m0;
+    s_lo[d][0] = 0; s_hi[d][0] = 0;
+    s_mak[0][d] = mak;
+    // termination at score 0 (identical sequences): only possible for M/M forms
+    const int ce = d == 0 ? J.comp_end : J.comp_begin;
+    if (c.pl == c.tl && ((ce == C_M && m0 >= c.tl))) s_bp[6 + d] = 1; else s_bp[6 + d] = 0;
+  }
+  __syncthreads();
+  int fmax = s_mak[0][0], rmax = s_mak[0][1];
+  end_reached = s_bp[6] | s_bp[7];
+  if (end_reached) {
+    if (tid == 0) {
+      BpResult r; r.status = 1; r.score = 0; r.score_fwd = 0; r.score_rev = 0; r.k_fwd = 0; r.off_fwd = 0; r.comp = 0; r.steps = 0; r.cells = 2;
+      results[blockIdx.x] = r;
+    }
+    return;
+  }
+  cells = 2;
+  const int64_t max_steps = (int64_t)(pen.o1 + pen.o2) * 4 + (int64_t)(J.pl + J.tl + 2) * max(pen.x, max(pen.e1, pen.e2)) * 2 + 256;
+  int sf = 0, sr = 0;
+  int last_fwd = 0;
+  int status = 0;
+  int buf = 0;
+
+  // ---- phase 1: advance both directions until the antidiagonals meet ----
+  // (the reference alternates forward, reverse; both rows of a round are
+  //  computed here in one pass and the checks replayed in the same order)
+  for (;;) {
+    if (fmax + rmax >= A) break;
+    buf = (buf + 1) % 3;
+    if (tid == 0) { s_mak[(buf + 1) % 3][0] = 0; s_mak[(buf + 1) % 3][1] = 0; }
+    int makf = 0, makr = 0;
+    const int nf = bp_compute_row(c, 0, sf + 1, s_lo, s_hi, makf);
+    const int nr = bp_compute_row(c, 1, sr + 1, s_lo, s_hi, makr);
+    makf = wave_max(makf);
+    makr = wave_max(makr);
+    if ((tid & 63) == 0) {
+      if (makf > 0) atomicMax(&s_mak[buf][0], makf);
+      if (makr > 0) atomicMax(&s_mak[buf][1], makr);
+    }
+    __syncthreads();
+    ++sf; cells += (uint64_t)nf;
+    fmax = max(fmax, s_mak[buf][0]);
+    last_fwd = 1;
+    if (fmax + rmax >= A) break;  // reverse row sr+1 stays speculative; recomputed in phase 2
+    ++sr; cells += (uint64_t)nr;
+    rmax = max(rmax, s_mak[buf][1]);
+    last_fwd = 0;
+    if ((int64_t)sf + sr > max_steps) { status = WFM_DEV_UNREACHABLE; break; }
+  }
+
+  // ---- phase 2: overlap detection (wavefront_bialign_find_breakpoint, 2nd loop) ----
+  int best = INT32_MAX;
+  if (status == 0) {
+    const int gopen = max(pen.o1, pen.o2);
+    for (;;) {
+      int d0;  // direction whose newest wavefront is tested, then the OTHER one advances
+      if (last_fwd) {
+        const int min_sr = (sr > scope - 1) ? sr - (scope - 1) : 0;
+        if (sf + min_sr - gopen >= best) break;
+        d0 = 0;
+      } else {
+        const int min_sf = (sf > scope - 1) ? sf - (scope - 1) : 0;
+        if (min_sf + sr - gopen >= best) break;
+        d0 = 1;
+      }
+      const int s0 = d0 == 0 ? sf : sr;
+      const int s1 = d0 == 0 ? sr : sf;
+      // overlap(a_d0 new row s0, other direction rows s1..s1-scope+1)
+      const bool m0_valid = s_lo[d0][s0 & RMASK] <= s_hi[d0][s0 & RMASK];
+      if (m0_valid) {
+        for (int i = tid; i < RING * 5; i += blockDim.x) s_mink[i] = INT32_MAX;
+        __syncthreads();
+        bp_overlap_scan(c, d0, s0, s1, best, s_lo, s_hi, s_mink, scope);
+        __syncthreads();
+        if (tid == 0) {
+          int b = best;
+          const int order[5] = {C_D2, C_I2, C_D1, C_I1, C_M};
+          for (int i = 0; i < scope; ++i) {
+            const int si = s1 - i;
+            if (si < 0) break;
+            for (int oi = 0; oi < 5; ++oi) {
+              const int cc = order[oi];
+              const int gop = (cc == C_M) ? 0 : ((cc == C_I1 || cc == C_D1) ? pen.o1 : pen.o2);
+              // nested `continue`s of wavefront_bialign_overlap: a failed test skips the rest of this i
+              if ((oi == 0 || oi == 2 || oi == 4) && s0 + si - gop >= b) break;
+              const int k0 = s_mink[i * 5 + cc];
+              if (k0 == INT32_MAX) continue;
+              if (s0 + si - gop >= b) continue;
+              const int k1 = (c.tl - c.pl) - k0;
+              const int o0 = bp_row(c, d0, cc, s0)[k0];
+              const int o1 = bp_row(c, d0 ^ 1, cc, si)[k1];
+              b = s0 + si - gop;
+              s_bp[0] = b;
+              if (d0 == 0) { s_bp[1] = s0; s_bp[2] = si; s_bp[3] = k0; s_bp[4] = o0; }
+              else         { s_bp[1] = si; s_bp[2] = s0; s_bp[3] = k1; s_bp[4] = o1; }
+              s_bp[5] = cc;
+            }
+          }
+          s_bp[6] = b;
+        }
+        __syncthreads();
+        best = s_bp[6];
+      }
+      // advance the other direction
+      int mak = 0;
+      if (d0 == 0) { ++sr; cells += (uint64_t)bp_compute_row(c, 1, sr, s_lo, s_hi, mak); last_fwd = 0; }
+      else         { ++sf; cells += (uint64_t)bp_compute_row(c, 0, sf, s_lo, s_hi, mak); last_fwd = 1; }
+      __syncthreads();
+      if (d0 == 1 && (int64_t)sf + sr > max_steps && best == INT32_MAX) { status = WFM_DEV_UNREACHABLE; break; }
+    }
+  }
+  if (tid == 0) {
+    BpResult r;
+    r.status = status;
+    if (status == 0 && best == INT32_MAX) r.status = WFM_DEV_UNREACHABLE;
+    r.score = best; r.score_fwd = s_bp[1]; r.score_rev = s_bp[2]; r.k_fwd = s_bp[3]; r.off_fwd = s_bp[4]; r.comp = s_bp[5];
+    r.steps = sf + sr;
+    r.cells = cells;
+    results[blockIdx.x] = r;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Base kernel: unidirectional WFA with per-cell backtrace decisions
+// ---------------------------------------------------------------------------
+struct BaseCtx {
+  const uint8_t* P;
+  const uint8_t* T;
+  int32_t* ring;  // [5][RING][width], indexable by k (kmin applied)
+  int32_t* pre;   // [(smax+1)][width] pre-extend M offsets, indexable by k
+  uint8_t* bt;    // [(smax+1)][width]
+  int64_t width;
+  int pl, tl, kmin, kmax;
+  DevPen pen;
+};
+
+__device__ __forceinline__ int32_t* bs_row(const BaseCtx& c, int comp, int s) {
+  return c.ring + ((int64_t)(comp * RING + (s & RMASK))) * c.width;
+}
+__device__ __forceinline__ Src bs_src(const BaseCtx& c, int comp, int s, const int* s_lo, const int* s_hi) {
+  Src r;
+  if (s < 0) { r.p = c.ring; r.lo = 1; r.hi = 0; }
+  else { r.p = bs_row(c, comp, s); r.lo = s_lo[s & RMASK]; r.hi = s_hi[s & RMASK]; }
+  return r;
+}
+
+struct RleWriter {
+  uint32_t* base;  // entries are written at base[-1], base[-2], ...
+  int n;
+  int cur_op;
+  uint32_t cur_len;
+  __device__ void push(int op, int len) {
+    if (len <= 0) return;
+    if (op == cur_op) { cur_len += (uint32_t)len; return; }
+    flush();
+    cur_op = op; cur_len = (uint32_t)len;
+  }
+  __device__ void flush() {
+    if (cur_len) { ++n; base[-n] = (cur_len << 2) | (uint32_t)cur_op; }
+    cur_len = 0; cur_op = -1;
+  }
+};
+
+__global__ __launch_bounds__(256) void wfa_base_kernel(const uint8_t* __restrict__ seq, int32_t* __restrict__ arena32,
+                                                       uint8_t* __restrict__ arena8, uint32_t* __restrict__ rle,
+                                                       const BaseJob* __restrict__ jobs, BaseResult* __restrict__ results,
+                                                       DevPen pen) {
+  const BaseJob J = jobs[blockIdx.x];
+  const int tid = threadIdx.x;
+  if (J.type != 0) {  // trivial: all-D or all-I (wavefront_bialign_alignment trivial cases)
+    if (tid == 0) {
+      BaseResult r; r.status = 0; r.cells = 0; r.nruns = 0; r.score = 0;
+      const int len = J.type == 1 ? J.pl : J.tl;
+      if (len > 0) { rle[J.rle_end - 1] = ((uint32_t)len << 2) | (uint32_t)(J.type == 1 ? OP_D : OP_I); r.nruns = 1; }
+      results[blockIdx.x] = r;
+    }
+    return;
+  }
+  __shared__ int s_lo[RING];
+  __shared__ int s_hi[RING];
+  __shared__ int s_done;  // end2end: 1 when reached
+  __shared__ int s_endk;  // ends-free: min k satisfying the end condition
+
+  BaseCtx c;
+  c.P = seq + J.p_off; c.T = seq + J.t_off;
+  c.width = J.width;
+  c.ring = arena32 + J.ring_off - J.kmin;
+  c.pre = arena32 + J.pre_off - J.kmin;
+  c.bt = arena8 + J.bt_off - J.kmin;
+  c.pl = J.pl; c.tl = J.tl; c.kmin = J.kmin; c.kmax = J.kmin + J.width - 1;
+  c.pen = pen;
+  const unsigned upl = (unsigned)c.pl, utl = (unsigned)c.tl;
+  const int k_end = c.tl - c.pl;
+  uint64_t cells = 0;
+
+  if (tid < RING) { s_lo[tid] = 1; s_hi[tid] = 0; }
+  if (tid == 0) { s_done = 0; s_endk = INT32_MAX; }
+  __syncthreads();
+
+  // ---- row 0 ----
+  int lo0, hi0;
+  if (J.endsfree) { lo0 = max(-J.pbf, c.kmin); hi0 = min(J.tbf, c.kmax); }
+  else { lo0 = 0; hi0 = 0; }
+  for (int k = lo0 + tid; k <= hi0; k += blockDim.x) {
+    int m = WF_NULL;
+    int vi1 = WF_NULL, vi2 = WF_NULL, vd1 = WF_NULL, vd2 = WF_NULL;
+    if (J.endsfree) m = k > 0 ? k : 0;
+    else {
+      if (J.comp_begin == C_M) m = 0;
+      vi1 = J.comp_begin == C_I1 ? 0 : WF_NULL;
+      vi2 = J.comp_begin == C_I2 ? 0 : WF_NULL;
+      vd1 = J.comp_begin == C_D1 ? 0 : WF_NULL;
+      vd2 = J.comp_begin == C_D2 ? 0 : WF_NULL;
+    }
+    c.pre[k] = m; c.bt[k] = 0;
+    if (m >= 0) {
+      m += lce_bounded(c.P, c.T, m - k, m, c.pl, c.tl);
+      if (J.endsfree) {
+        const int h = m, v = m - k;
+        if ((h >= c.tl && c.pl - v <= J.pef) || (v >= c.pl && c.tl - h <= J.tef)) atomicMin(&s_endk, k);
+      } else if (k == k_end && J.comp_end == C_M && m >= c.tl) s_done = 1;
+    }
+    bs_row(c, C_M, 0)[k] = m;
+    bs_row(c, C_I1, 0)[k] = vi1; bs_row(c, C_I2, 0)[k] = vi2;
+    bs_row(c, C_D1, 0)[k] = vd1; bs_row(c, C_D2, 0)[k] = vd2;
+  }
+  if (tid == 0) { s_lo[0] = lo0; s_hi[0] = hi0; }
+  cells += (uint64_t)(hi0 - lo0 + 1);
+  __syncthreads();
+
+  int s = 0;
+  int status = 0;
+  bool done = J.endsfree ? (s_endk != INT32_MAX) : (s_done != 0);
+  while (!done) {
+    ++s;
+    if (s > J.smax) { status = WFM_DEV_OVERFLOW; break; }
+    const DevPen& pn = c.pen;
+    const Src mx  = bs_src(c, C_M,  s - pn.x, s_lo, s_hi);
+    const Src mo1 = bs_src(c, C_M,  s - pn.o1 - pn.e1, s_lo, s_hi);
+    const Src mo2 = bs_src(c, C_M,  s - pn.o2 - pn.e2, s_lo, s_hi);
+    const Src i1  = bs_src(c, C_I1, s - pn.e1, s_lo, s_hi);
+    const Src d1  = bs_src(c, C_D1, s - pn.e1, s_lo, s_hi);
+    const Src i2  = bs_src(c, C_I2, s - pn.e2, s_lo, s_hi);
+    const Src d2  = bs_src(c, C_D2, s - pn.e2, s_lo, s_hi);
+    int lo = INT32_MAX, hi = INT32_MIN;
+    if (mx.lo <= mx.hi)   { lo = min(lo, mx.lo);      hi = max(hi, mx.hi); }
+    if (mo1.lo <= mo1.hi) { lo = min(lo, mo1.lo - 1); hi = max(hi, mo1.hi + 1); }
+    if (mo2.lo <= mo2.hi) { lo = min(lo, mo2.lo - 1); hi = max(hi, mo2.hi + 1); }
+    if (i1.lo <= i1.hi)   { lo = min(lo, i1.lo - 1);  hi = max(hi, i1.hi + 1); }
+    if (i2.lo <= i2.hi)   { lo = min(lo, i2.lo - 1);  hi = max(hi, i2.hi + 1); }
+    lo = max(lo, max(-c.pl, c.kmin));
+    hi = min(hi, min(c.tl, c.kmax));
+    const bool valid = lo <= hi;
+    if (tid == 0) { s_lo[s & RMASK] = valid ? lo : 1; s_hi[s & RMASK] = valid ? hi : 0; }
+    if (valid) {
+      int32_t* om = bs_row(c, C_M, s);
+      int32_t* oi1 = bs_row(c, C_I1, s);
+      int32_t* oi2 = bs_row(c, C_I2, s);
+      int32_t* od1 = bs_row(c, C_D1, s);
+      int32_t* od2 = bs_row(c, C_D2, s);
+      int32_t* pre = c.pre + (int64_t)s * c.width;
+      uint8_t* bt = c.bt + (int64_t)s * c.width;
+      for (int k = lo + tid; k <= hi; k += blockDim.x) {
+        const int m1a = ldk(mo1, k - 1), m1b = ldk(mo1, k + 1);
+        const int m2a = ldk(mo2, k - 1), m2b = ldk(mo2, k + 1);
+        const int e_i1 = ldk(i1, k - 1), e_i2 = ldk(i2, k - 1);
+        const int e_d1 = ldk(d1, k + 1), e_d2 = ldk(d2, k + 1);
+        unsigned bits = 0;
+        // ext wins ties (WFA2-lib: ext type > open type; piggyback: ext >= open)
+        if (e_i1 >= m1a) bits |= BT_I1_EXT;
+        if (e_i2 >= m2a) bits |= BT_I2_EXT;
+        if (e_d1 >= m1b) bits |= BT_D1_EXT;
+        if (e_d2 >= m2b) bits |= BT_D2_EXT;
+        int ins1 = valid_or_null(max(m1a, e_i1) + 1, k, upl, utl);
+        int ins2 = valid_or_null(max(m2a, e_i2) + 1, k, upl, utl);
+        int del1 = valid_or_null(max(m1b, e_d1), k, upl, utl);
+        int del2 = valid_or_null(max(m2b, e_d2), k, upl, utl);
+        int mis  = valid_or_null(ldk(mx, k) + 1, k, upl, utl);
+        // M source priority on equal offsets: mismatch > D2 > D1 > I2 > I1
+        int m = ins1; unsigned src = C_I1;
+        if (ins2 >= m) { m = ins2; src = C_I2; }
+        if (del1 >= m) { m = del1; src = C_D1; }
+        if (del2 >= m) { m = del2; src = C_D2; }
+        if (mis >= m)  { m = mis;  src = C_M; }
+        pre[k] = m;
+        bt[k] = (uint8_t)(bits | src);
+        if (m >= 0) {
+          m += lce_bounded(c.P, c.T, m - k, m, c.pl, c.tl);
+          if (J.endsfree) {
+            const int h = m, v = m - k;
+            if ((h >= c.tl && c.pl - v <= J.pef) || (v >= c.pl && c.tl - h <= J.tef)) atomicMin(&s_endk, k);
+          }
+        }
+        if (!J.endsfree && k == k_end) {
+          const int ev = J.comp_end == C_M ? m : (J.comp_end == C_I1 ? ins1 : (J.comp_end == C_I2 ? ins2 : (J.comp_end == C_D1 ? del1 : del2)));
+          if (ev >= c.tl) s_done = 1;
+        }
+        oi1[k] = ins1; oi2[k] = ins2; od1[k] = del1; od2[k] = del2; om[k] = m;
+      }
+      cells += (uint64_t)(hi - lo + 1);
+    }
+    __syncthreads();
+    done = J.endsfree ? (s_endk != INT32_MAX) : (s_done != 0);
+  }
+
+  // ---- backtrace (wavefront_backtrace_affine), one lane ----
+  if (tid == 0) {
+    BaseResult r; r.status = status; r.score = s; r.nruns = 0; r.cells = cells;
+    if (status == 0) {
+      RleWriter w; w.base = rle + J.rle_end; w.n = 0; w.cur_op = -1; w.cur_len = 0;
+      int comp = J.endsfree ? C_M : J.comp_end;
+      int k = J.endsfree ? s_endk : k_end;
+      int off = J.endsfree ? bs_row(c, C_M, s)[k] : c.tl;
+      int sc = s;
+      int h = off, v = off - k;
+      if (comp == C_M) {
+        if (v < c.pl) w.push(OP_D, c.pl - v);
+        if (h < c.tl) w.push(OP_I, c.tl - h);
+      }
+      const DevPen& pn = c.pen;
+      while (v > 0 && h > 0 && sc > 0) {
+        const unsigned b = c.bt[(int64_t)sc * c.width + k];
+        unsigned src;
+        if (comp == C_M) {
+          const int pre = c.pre[(int64_t)sc * c.width + k];
+          w.push(OP_M, off - pre);
+          off = pre; v = off - k; h = off;
+          if (v <= 0 || h <= 0) break;
+          src = b & 7u;
+        } else {
+          src = (unsigned)comp;
+        }
+        if (src == C_M) { sc -= pn.x; comp = C_M; w.push(OP_X, 1); --off; }
+        else if (src == C_I1) { if (b & BT_I1_EXT) { sc -= pn.e1; comp = C_I1; } else { sc -= pn.o1 + pn.e1; comp = C_M; } w.push(OP_I, 1); --k; --off; }
+        else if (src == C_I2) { if (b & BT_I2_EXT) { sc -= pn.e2; comp = C_I2; } else { sc -= pn.o2 + pn.e2; comp = C_M; } w.push(OP_I, 1); --k; --off; }
+        else if (src == C_D1) { if (b & BT_D1_EXT) { sc -= pn.e1; comp = C_D1; } else { sc -= pn.o1 + pn.e1; comp = C_M; } w.push(OP_D, 1); ++k; }
+        else { if (b & BT_D2_EXT) { sc -= pn.e2; comp = C_D2; } else { sc -= pn.o2 + pn.e2; comp = C_M; } w.push(OP_D, 1); ++k; }
+        v = off - k; h = off;
+      }
+      if (comp == C_M && v > 0 && h > 0) { const int nm = min(v, h); w.push(OP_M, nm); v -= nm; h -= nm; }
+      if (v > 0) w.push(OP_D, v);
+      if (h > 0) w.push(OP_I, h);
+      w.flush();
+      r.nruns = w.n;
+    }
+    results[blockIdx.x] = r;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// RLE compaction: one workgroup per problem; keeps slot order
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void rle_compact_kernel(const uint32_t* __restrict__ rle, const int64_t* __restrict__ prob_off,
+                                                          const int64_t* __restrict__ prob_cap, uint32_t* __restrict__ out,
+                                                          unsigned long long* __restrict__ total, int64_t* __restrict__ out_start,
+                                                          int32_t* __restrict__ out_count) {
+  const int64_t base = prob_off[blockIdx.x];
+  const int64_t cap = prob_cap[blockIdx.x];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  __shared__ int s_w[4];
+  __shared__ long long s_start;
+  __shared__ int s_cnt;
+  if (tid == 0) s_cnt = 0;
+  __syncthreads();
+  int cnt = 0;
+  for (int64_t i = tid; i < cap; i += blockDim.x) cnt += rle[base + i] != 0;
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) cnt += __shfl_xor(cnt, d, 64);
+  if (lane == 0 && cnt) atomicAdd(&s_cnt, cnt);
+  __syncthreads();
+  if (tid == 0) {
+    s_start = (long long)atomicAdd(total, (unsigned long long)s_cnt);
+    out_start[blockIdx.x] = s_start;
+    out_count[blockIdx.x] = s_cnt;
+  }
+  __syncthreads();
+  int64_t wbase = s_start;
+  for (int64_t i0 = 0; i0 < cap; i0 += blockDim.x) {
+    const int64_t i = i0 + tid;
+    const uint32_t e = i < cap ? rle[base + i] : 0u;
+    const unsigned long long mask = __ballot(e != 0);
+    const int pre = __popcll(mask & ((1ull << lane) - 1ull));
+    if (lane == 0) s_w[wid] = __popcll(mask);
+    __syncthreads();
+    int woff = 0, tot = 0;
+#pragma unroll
+    for (int w2 = 0; w2 < 4; ++w2) { const int x = s_w[w2]; if (w2 < wid) woff += x; tot += x; }
+    if (e) out[wbase + woff + pre] = e;
+    wbase += tot;
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------
+// host-callable launchers
+// ---------------------------------------------------------------------------
+void launch_bp(const uint8_t* seq, int32_t* ring, const BpJob* jobs, BpResult* res, int njobs, int threads,
+               DevPen pen, int scope, hipStream_t st) {
+  hipLaunchKernelGGL(wfa_bp_kernel, dim3(njobs), dim3(threads), 0, st, seq, ring, jobs, res, pen, scope);
+}
+void launch_base(const uint8_t* seq, int32_t* a32, uint8_t* a8, uint32_t* rle, const BaseJob* jobs, BaseResult* res,
+                 int njobs, DevPen pen, hipStream_t st) {
+  hipLaunchKernelGGL(wfa_base_kernel, dim3(njobs), dim3(256), 0, st, seq, a32, a8, rle, jobs, res, pen);
+}
+void launch_compact(const uint32_t* rle, const int64_t* off, const int64_t* cap, uint32_t* out, unsigned long long* total,
+                    int64_t* out_start, int32_t* out_count, int nprob, hipStream_t st) {
+  hipLaunchKernelGGL(rle_compact_kernel, dim3(nprob), dim3(256), 0, st, rle, off, cap, out, total, out_start, out_count);
+}
+
+}  // namespace wfm
