@@ -89,6 +89,8 @@ typedef struct {
   uint32_t levels;           /* BiWFA recursion levels executed                   */
   uint32_t bp_jobs, base_jobs;
   uint32_t bp_launches, base_launches;
+  uint64_t cells_bp;         /* cells computed by wfa_bp_kernel launches          */
+  uint64_t cells_base;       /* cells computed by wfa_base_kernel launches        */
 } wfm_stats_t;
 
 int  wfm_create(int device, wfm_handle_t** out);

@@ -1,0 +1,163 @@
+"""GPU parity tests of the align path: libwfmash_hip.so (through the C ABI)
+against the CPU oracle on the same seeded inputs.  Bit-exact on op strings."""
+import random
+
+import pytest
+
+from wfmash_amd import capi, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _pairs(seed, n, lens, rates):
+    rng = random.Random(seed)
+    out = []
+    for i in range(n):
+        L = rng.choice(lens)
+        p = synth.random_dna(seed * 1000 + i, L)
+        t = synth.mutate(p, rng.choice(rates), seed * 7919 + i) if L else b""
+        r = rng.random()
+        if r < 0.08:
+            t = synth.random_dna(seed * 31 + i, rng.randrange(0, 400))
+        elif r < 0.12:
+            t = b""
+        elif r < 0.16:
+            p = b""
+        out.append((p, t))
+    return out
+
+
+def _check_batch(gpu, oracle, items, pen=None):
+    res = gpu.align(items, pen)
+    n_bad = 0
+    for (p, t), r in zip(items, res):
+        rc, ops, sc, _ = oracle.align_biwfa(p, t, pen)
+        assert rc == 0
+        assert r.status == 0, (len(p), len(t), r.status)
+        assert r.score == sc
+        if r.ops != ops:
+            n_bad += 1
+    assert n_bad == 0, f"{n_bad}/{len(items)} CIGARs differ from the oracle"
+
+
+def test_biwfa_matches_oracle_small(gpu, oracle):
+    items = _pairs(1, 300, [0, 1, 2, 3, 15, 64, 99, 100, 101, 130, 256, 400, 777], [0.0, 0.01, 0.05, 0.15, 0.35])
+    _check_batch(gpu, oracle, items)
+
+
+def test_biwfa_matches_oracle_medium(gpu, oracle):
+    items = _pairs(2, 96, [1000, 2500, 5000, 9000], [0.01, 0.05, 0.1, 0.2])
+    _check_batch(gpu, oracle, items)
+
+
+def test_biwfa_skewed_shapes(gpu, oracle):
+    """Very unequal lengths: deep D/I components, breakpoints inside long gaps."""
+    rng = random.Random(9)
+    items = []
+    for i in range(60):
+        a = synth.random_dna(4000 + i, rng.choice([120, 600, 3000]))
+        b = synth.random_dna(5000 + i, rng.choice([120, 150, 2000]))
+        core = synth.random_dna(6000 + i, rng.choice([200, 1500]))
+        items.append((a + core + b, synth.mutate(core, 0.05, 70 + i)))
+        items.append((synth.mutate(core, 0.1, 170 + i), b + core + a))
+    _check_batch(gpu, oracle, items)
+
+
+def test_biwfa_low_complexity(gpu, oracle):
+    """Homopolymers / tandem repeats create many equal-score paths: exercises every tie-break."""
+    rng = random.Random(4)
+    items = []
+    for i in range(80):
+        unit = synth.random_dna(900 + i, rng.choice([1, 2, 3, 7]))
+        n = rng.choice([150, 700, 2500])
+        p = (unit * (n // len(unit) + 1))[:n]
+        t = synth.mutate(p, rng.choice([0.02, 0.1]), 333 + i)
+        if rng.random() < 0.5:
+            t = (unit * 400)[:max(1, n + rng.randrange(-100, 100))]
+        items.append((p, t))
+    _check_batch(gpu, oracle, items)
+
+
+def test_biwfa_with_N_runs(gpu, oracle):
+    items = []
+    for i in range(20):
+        p = bytearray(synth.random_dna(40 + i, 3000))
+        p[1000:1300] = b"N" * 300
+        t = bytearray(synth.mutate(bytes(p), 0.05, 400 + i))
+        items.append((bytes(p), bytes(t)))
+    _check_batch(gpu, oracle, items)
+
+
+def test_custom_penalties(gpu, oracle):
+    items = _pairs(5, 40, [80, 300, 2000], [0.05, 0.2])
+    _check_batch(gpu, oracle, items, pen=(4, 6, 2, 12, 1))
+    _check_batch(gpu, oracle, items, pen=(3, 4, 1, 10, 1))
+
+
+def test_unsupported_penalties_fail_loudly(gpu):
+    with pytest.raises(capi.WfmError):
+        gpu.align([(b"ACGT" * 50, b"ACGA" * 50)], pen=(5, 8, 2, 60, 1))  # scope 62 > 32-row ring
+
+
+def test_endsfree_patches_match_oracle(gpu, oracle):
+    """Head / tail patch forms exactly as do_biwfa_alignment issues them (wflign.cpp:300-305, 392-397)."""
+    rng = random.Random(6)
+    items, exp = [], []
+    for i in range(120):
+        p = synth.random_dna(700 + i, rng.choice([5, 60, 130, 400, 1500]))
+        t = synth.mutate(p, rng.choice([0.0, 0.05, 0.2, 0.5]), 800 + i)
+        if rng.random() < 0.4:
+            t = synth.random_dna(70 + i, rng.randrange(1, 60)) + t
+        if rng.random() < 0.4:
+            p = synth.random_dna(90 + i, rng.randrange(1, 60)) + p
+        if not t:
+            t = b"A"
+        for args in ((len(p), 0, len(t), 0), (0, len(p), 0, len(t))):
+            items.append((p, t, capi.WFM_MODE_ENDSFREE, args[0], args[1], args[2], args[3]))
+            exp.append(oracle.align_endsfree(p, args[0], args[1], t, args[2], args[3]))
+    res = gpu.align(items)
+    bad = 0
+    for it, r, (rc, ops, sc, _) in zip(items, res, exp):
+        assert rc == 0 and r.status == 0
+        bad += r.ops != ops
+    assert bad == 0, f"{bad}/{len(items)} ends-free CIGARs differ"
+
+
+def test_uni_mode_matches_oracle(gpu, oracle):
+    items = [(p, t, capi.WFM_MODE_END2END_UNI) for p, t in _pairs(8, 40, [50, 300, 1200], [0.02, 0.1, 0.3])]
+    res = gpu.align(items)
+    for (p, t, _), r in zip(items, res):
+        rc, ops, sc, _ = oracle.align_uni(p, t)
+        assert rc == 0 and r.status == 0 and r.ops == ops and r.score == sc
+
+
+def test_c3_sized_pairs_properties(gpu, oracle):
+    """BASELINE.json configs[2] at full size (8 of the 64 pairs here): CIGAR valid,
+    implied score == reported score, and bit-identical to the oracle."""
+    pairs = synth.pairs("C3", n_pairs=8)
+    res = gpu.align(pairs)
+    ops_cpu, scores, _, failed = oracle.align_batch_biwfa([p for p, _ in pairs], [q for _, q in pairs])
+    assert failed == 0
+    for (p, t), r, oc, sc in zip(pairs, res, ops_cpu, scores):
+        assert r.status == 0
+        assert oracle.ops_check(r.ops, p, t) == 0
+        assert oracle.ops_score(r.ops) == r.score == int(sc)
+        assert r.ops == oc
+
+
+def test_memory_budget_chunking(oracle, monkeypatch):
+    """A tiny device-memory budget forces the level loop to run in chunks; results must not change."""
+    monkeypatch.setenv("WFM_MEM_BUDGET_MB", "24")
+    h = capi.Handle(0)
+    try:
+        items = _pairs(12, 24, [3000, 6000], [0.05, 0.1])
+        _check_batch(h, oracle, items)
+    finally:
+        h.close()
+
+
+def test_repeated_calls_reuse_handle(gpu, oracle):
+    items = _pairs(13, 10, [500, 2000], [0.05])
+    a = gpu.align(items)
+    b = gpu.align(items)
+    assert [r.ops for r in a] == [r.ops for r in b]

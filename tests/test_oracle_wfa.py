@@ -1,0 +1,146 @@
+"""CPU tests: the WFA oracle (oracle/wfa2p.c) against an independent O(nm) DP.
+
+The reference holds no golden vector at the WFA2-lib boundary (SURVEY.md 8c:
+"parity unpinned"), so the oracle is pinned by (i) optimal score == 5-state DP,
+(ii) pafcheck-style CIGAR validity, (iii) CIGAR-implied score == optimal score.
+"""
+import random
+
+import pytest
+
+from wfmash_amd import synth
+
+
+def _rand_pairs(seed, n, lens, rates):
+    rng = random.Random(seed)
+    out = []
+    for i in range(n):
+        L = rng.choice(lens)
+        p = synth.random_dna(seed * 1000 + i, L)
+        t = synth.mutate(p, rng.choice(rates), seed * 7919 + i) if L else b""
+        if rng.random() < 0.15:
+            t = synth.random_dna(seed * 31 + i, rng.randrange(0, 200))
+        out.append((p, t))
+    return out
+
+
+def test_uni_and_biwfa_scores_match_dp(oracle):
+    for p, t in _rand_pairs(11, 120, [0, 1, 2, 7, 40, 100, 101, 160, 420, 900], [0.0, 0.02, 0.1, 0.3]):
+        dp = oracle.dp_score(p, t)
+        rc, ops, sc, _ = oracle.align_uni(p, t)
+        assert rc == 0 and sc == dp
+        assert oracle.ops_check(ops, p, t) == 0
+        assert oracle.ops_score(ops) == dp
+        rc, ops2, sc2, _ = oracle.align_biwfa(p, t)
+        assert rc == 0 and sc2 == dp
+        assert oracle.ops_check(ops2, p, t) == 0
+
+
+def test_biwfa_recursion_is_exercised(oracle):
+    p = synth.random_dna(5, 6000)
+    t = synth.mutate(p, 0.1, 55)
+    rc, ops, sc, st = oracle.align_biwfa(p, t)
+    assert rc == 0
+    assert st.bialign_calls >= 3 and st.base_calls >= 4 and st.max_depth >= 2
+    assert sc == oracle.dp_score(p, t)
+    assert oracle.ops_check(ops, p, t) == 0
+
+
+def test_endsfree_scores_match_dp(oracle):
+    rng = random.Random(3)
+    for i in range(80):
+        p = synth.random_dna(300 + i, rng.choice([1, 20, 150, 400]))
+        t = synth.mutate(p, rng.choice([0.0, 0.05, 0.2]), 900 + i)
+        if rng.random() < 0.4:
+            t = synth.random_dna(77 + i, rng.randrange(1, 40)) + t
+        if rng.random() < 0.4:
+            p = synth.random_dna(99 + i, rng.randrange(1, 40)) + p
+        if not t:
+            continue
+        for args in ((len(p), 0, len(t), 0), (0, len(p), 0, len(t))):  # head / tail patch forms (wflign.cpp:300-305, 392-397)
+            dp = oracle.dp_score_endsfree(p, t, *args)
+            rc, ops, sc, _ = oracle.align_endsfree(p, args[0], args[1], t, args[2], args[3])
+            assert rc == 0 and sc == dp
+            assert oracle.ops_check(ops, p, t) == 0
+
+
+def test_component_halves_concatenate(oracle):
+    """A BiWFA breakpoint splits the problem into two halves whose component-
+    constrained alignments concatenate to an optimal alignment."""
+    p = synth.random_dna(8, 3000)
+    t = synth.mutate(p, 0.08, 88)
+    rc, bp, _ = oracle.find_breakpoint(p, t)
+    assert rc == 0
+    dp = oracle.dp_score(p, t)
+    assert bp.score == dp
+    h, v = bp.offset_forward, bp.offset_forward - bp.k_forward
+    rc0, ops0, _, _ = oracle.align_comp(p[:v], t[:h], 0, bp.component)
+    rc1, ops1, _, _ = oracle.align_comp(p[v:], t[h:], bp.component, 0)
+    assert rc0 == 0 and rc1 == 0
+    ops = ops0 + ops1
+    assert oracle.ops_check(ops, p, t) == 0
+    assert oracle.ops_score(ops) == dp
+
+
+def test_custom_penalties(oracle):
+    pen = (4, 6, 2, 12, 1)
+    for p, t in _rand_pairs(21, 30, [50, 300, 700], [0.05, 0.2]):
+        rc, ops, sc, _ = oracle.align_biwfa(p, t, pen)
+        assert rc == 0 and sc == oracle.dp_score(p, t, pen)
+
+
+def test_legacy_reads_fixture_is_plausible(oracle):
+    """test/data/regression/reads.255bps.paf predates the current writer (its
+    CIGARs start/end with indels); it cannot be a byte-exact golden, but the
+    alignment score of our oracle must not be worse than the legacy CIGAR's."""
+    import gzip
+    import os
+    here = os.path.dirname(__file__)
+    fa = os.path.join(here, "golden", "reads.255bps.fa.gz")
+    paf = os.path.join(here, "golden", "reads.255bps.paf")
+    if not (os.path.exists(fa) and os.path.exists(paf)):
+        pytest.skip("fixture not present")
+    seqs = {}
+    name = None
+    for line in gzip.open(fa, "rt"):
+        line = line.strip()
+        if line.startswith(">"):
+            name = line[1:].split()[0]
+            seqs[name] = ""
+        elif name:
+            seqs[name] += line.upper()
+    import re
+    n = 0
+    for line in open(paf):
+        f = line.rstrip("\n").split("\t")
+        q, qs, qe, strand, tname, ts, te = f[0], int(f[2]), int(f[3]), f[4], f[5], int(f[7]), int(f[8])
+        cg = [x for x in f if x.startswith("cg:Z:")][0][5:]
+        if strand != "+":
+            continue
+        query = seqs[q][qs:qe].encode()
+        target = seqs[tname][ts:te].encode()
+        legacy_ops = b"".join((b"M" if op in "=M" else op.encode()) * int(cnt) for cnt, op in re.findall(r"(\d+)([=XIDM])", cg))
+        # legacy "M"/"=" may hide mismatches: re-derive X from the sequences
+        v = h = 0
+        fixed = bytearray()
+        for op in legacy_ops:
+            c = chr(op)
+            if c == "M":
+                fixed.append(ord("M") if target[v] == query[h] else ord("X"))
+                v += 1
+                h += 1
+            elif c == "X":
+                fixed.append(op)
+                v += 1
+                h += 1
+            elif c == "I":
+                fixed.append(op)
+                h += 1
+            else:
+                fixed.append(op)
+                v += 1
+        assert v == len(target) and h == len(query)
+        rc, ops, sc, _ = oracle.align_biwfa(target, query)
+        assert rc == 0 and sc <= oracle.ops_score(bytes(fixed))
+        n += 1
+    assert n >= 1

@@ -50,7 +50,8 @@ class Stats(C.Structure):
                 ("ms_kernels", C.c_double), ("ms_breakpoint", C.c_double),
                 ("ms_base", C.c_double), ("ms_total", C.c_double),
                 ("levels", C.c_uint32), ("bp_jobs", C.c_uint32), ("base_jobs", C.c_uint32),
-                ("bp_launches", C.c_uint32), ("base_launches", C.c_uint32)]
+                ("bp_launches", C.c_uint32), ("base_launches", C.c_uint32),
+                ("cells_bp", C.c_uint64), ("cells_base", C.c_uint64)]
 
 
 class Minmer(C.Structure):

@@ -204,6 +204,7 @@ int run_base_jobs(wfm_handle* h, wfm_seqset* S, const wfm_penalties_t& pen, cons
         const Node& nd = nodes[(size_t)jobs[q].pad_];
         const BaseResult& r = res[q];
         prob_cells[nd.prob] += r.cells;
+        h->stats.cells_base += r.cells;
         if (r.status == WFM_DEV_OVERFLOW) {
           Node again = nd;
           const int64_t bound = (int64_t)gapcost(pen, nd.pl) + gapcost(pen, nd.tl) + 8;
@@ -324,6 +325,7 @@ int align_resident_impl(wfm_handle* h, const wfm_penalties_t* pen, wfm_seqset* S
           const Node& nd = bp_nodes[(size_t)jobs[q].pad_];
           const BpResult& r = res[q];
           prob_cells[nd.prob] += r.cells;
+          h->stats.cells_bp += r.cells;
           if (r.status == 1) {  // end reached at score 0 -> base aligner
             Node b = nd; b.smax = 0; base_nodes.push_back(b);
           } else if (r.status != 0) {
