@@ -28,8 +28,8 @@ struct BpJob {
   int64_t ring_off;                    // int32 element offset of this job's ring
   int32_t pl, tl;
   int32_t comp_begin, comp_end;
-  int32_t width;                       // row stride = pl + tl + 3
-  int32_t pad_;
+  int32_t width;                       // row stride = round4(pl + tl + 9)
+  int32_t koff;                        // column = k + koff (multiple of 4; normally pl + 4)
 };
 
 struct BpResult {
@@ -37,6 +37,9 @@ struct BpResult {
   int32_t score, score_fwd, score_rev, k_fwd, off_fwd, comp;
   int32_t steps;
   uint64_t cells;
+  int32_t steps_p1;            // steps spent before the antidiagonals met
+  uint32_t ticks_p1, ticks_p2; // wall_clock64 ticks (100 MHz) per phase
+  int32_t pad_;
 };
 
 struct BaseJob {

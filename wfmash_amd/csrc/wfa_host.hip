@@ -20,6 +20,9 @@
 #include "../../include/wfmash_hip.h"
 #include "wfa_device.h"
 
+#ifdef WFM_PROFILE_SECTIONS
+namespace wfm { void read_sections(long long* out); }
+#endif
 namespace {
 
 using namespace wfm;
@@ -266,6 +269,7 @@ int align_resident_impl(wfm_handle* h, const wfm_penalties_t* pen, wfm_seqset* S
 
   LevelTimer tm;
   std::vector<BpJob> jobs;
+  std::vector<int32_t> node_of;
   std::vector<BpResult> res;
   uint32_t level = 0;
   while (!bp_nodes.empty() || !base_nodes.empty()) {
@@ -275,13 +279,16 @@ int align_resident_impl(wfm_handle* h, const wfm_penalties_t* pen, wfm_seqset* S
     size_t i0 = 0;
     while (i0 < bp_nodes.size()) {
       jobs.clear();
+      node_of.clear();
       size_t ring_elems = 0;
       size_t i = i0;
       int maxw = 0;
       for (; i < bp_nodes.size(); ++i) {
         const Node& nd = bp_nodes[i];
         const ProbMeta& pm = S->meta[nd.prob];
-        const size_t width = (size_t)nd.pl + nd.tl + 3;
+        size_t width = ((size_t)nd.pl + nd.tl + 9 + 3) & ~(size_t)3;  // columns 4 .. pl+tl+4, 16-byte chunks
+        int koff = nd.pl + 4;
+        if (getenv("WFM_EXP_WIDTH")) { const size_t w = (size_t)atoll(getenv("WFM_EXP_WIDTH")); if (w < width) { width = w; koff = (int)(w / 2) & ~3; } }
         const size_t need = width * 2 * 5 * RING;
         if (!jobs.empty() && (ring_elems + need) * 4 > h->mem_budget) break;
         if (need * 4 > h->mem_budget) { prob_status[nd.prob] = WFM_ST_OOM; continue; }
@@ -294,7 +301,8 @@ int align_resident_impl(wfm_handle* h, const wfm_penalties_t* pen, wfm_seqset* S
         j.pl = nd.pl; j.tl = nd.tl;
         j.comp_begin = nd.cb; j.comp_end = nd.ce;
         j.width = (int32_t)width;
-        j.pad_ = (int32_t)i;  // node index
+        j.koff = koff;
+        node_of.push_back((int32_t)i);
         ring_elems += need;
         maxw = std::max(maxw, (int)width);
         jobs.push_back(j);
@@ -321,8 +329,17 @@ int align_resident_impl(wfm_handle* h, const wfm_penalties_t* pen, wfm_seqset* S
         tm.bp_ms += ms;
         h->stats.bp_launches++;
         h->stats.bp_jobs += (uint32_t)jobs.size();
+#ifdef WFM_PROFILE_SECTIONS
+        { long long sc[8]; wfm::read_sections(sc); fprintf(stderr, "[wfm] sections block0 thread0 (cycles): load+compute %lld, extend %lld, store-issue %lld | rows %lld, reduce %lld, barrier %lld | steps %lld\n", sc[0], sc[1], sc[2], sc[3], sc[4], sc[5], sc[6]); }
+#endif
+        if (getenv("WFM_DEBUG")) {
+          uint64_t c = 0; double t1 = 0, t2 = 0; int64_t st1 = 0, st = 0; uint32_t m1 = 0, m2 = 0;
+          for (const BpResult& r : res) { c += r.cells; t1 += r.ticks_p1; t2 += r.ticks_p2; st1 += r.steps_p1; st += r.steps; m1 = std::max(m1, r.ticks_p1); m2 = std::max(m2, r.ticks_p2); }
+          fprintf(stderr, "[wfm] level %u: %zu bp jobs, %d thr, %.3f ms, cells %.3e, avg steps p1 %.0f p2 %.0f, avg ms p1 %.3f p2 %.3f, max ms p1 %.3f p2 %.3f\n", level, jobs.size(), threads, ms,
+                  (double)c, (double)st1 / jobs.size(), (double)(st - st1) / jobs.size(), t1 / jobs.size() / 1e5, t2 / jobs.size() / 1e5, m1 / 1e5, m2 / 1e5);
+        }
         for (size_t q = 0; q < jobs.size(); ++q) {
-          const Node& nd = bp_nodes[(size_t)jobs[q].pad_];
+          const Node& nd = bp_nodes[(size_t)node_of[q]];
           const BpResult& r = res[q];
           prob_cells[nd.prob] += r.cells;
           h->stats.cells_bp += r.cells;

@@ -24,6 +24,15 @@
 
 namespace wfm {
 
+#ifdef WFM_PROFILE_SECTIONS
+__device__ long long g_sec[8];
+#define SEC_T(v) const long long v = clock64(); asm volatile("" ::: "memory")
+#define SEC_ADD(i, a, b) sec[i] += (b) - (a)
+#else
+#define SEC_T(v)
+#define SEC_ADD(i, a, b)
+#endif
+
 __device__ __forceinline__ uint64_t load8(const uint8_t* p) {
   uint64_t v;
   __builtin_memcpy(&v, p, 8);
@@ -78,7 +87,7 @@ struct BpCtx {
   const uint8_t* T[2];
   int32_t* ring;  // job ring base, already offset so that [row*width + k] works with +pl+1 applied
   int64_t width;
-  int pl, tl;
+  int pl, tl, koff;
   DevPen pen;
 };
 
@@ -98,23 +107,125 @@ __device__ __forceinline__ Src bp_src(const BpCtx& c, int dir, int comp, int s, 
   return r;
 }
 
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef v4i v4i_u __attribute__((aligned(4)));
+
+// source row for the vector path: p[k] addresses diagonal k; a cell k is live iff
+// (unsigned)(k - lo) <= span.  Dead rows: lo = INT32_MIN/2, span = 0.
+struct VSrc {
+  const int32_t* p;
+  int lo;
+  unsigned span;
+};
+
+__device__ __forceinline__ VSrc bp_vsrc(const BpCtx& c, int dir, int comp, int s, const int (*s_lo)[RING], const int (*s_hi)[RING]) {
+  VSrc r;
+  r.p = bp_row(c, dir, comp, s);  // always a mapped address of this job's ring
+  int lo = 1, hi = 0;
+  if (s >= 0) { lo = s_lo[dir][s & RMASK]; hi = s_hi[dir][s & RMASK]; }
+  if (lo <= hi) { r.lo = lo; r.span = (unsigned)(hi - lo); }
+  else { r.lo = INT32_MIN / 2; r.span = 0u; }
+  return r;
+}
+
+template <bool MASK>
+__device__ __forceinline__ v4i ld4(const VSrc& r, int kb) {
+  v4i v = *reinterpret_cast<const v4i_u*>(r.p + kb);
+  if (MASK) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = ((unsigned)(kb + j - r.lo) <= r.span) ? v[j] : WF_NULL;
+  }
+  return v;
+}
+
+// 4 consecutive diagonals k0..k0+3 (one 16-byte column chunk) per thread.
+template <bool MASK>
+__device__ __forceinline__ void bp_cells4(const BpCtx& c, const uint8_t* P, const uint8_t* T, int k0, int lo, int hi,
+                                          const VSrc& mx, const VSrc& mo1, const VSrc& mo2, const VSrc& i1, const VSrc& d1,
+                                          const VSrc& i2, const VSrc& d2, int32_t* om, int32_t* oi1, int32_t* oi2,
+                                          int32_t* od1, int32_t* od2, int& mak, long long* sec) {
+  SEC_T(t0);
+  const unsigned upl = (unsigned)c.pl, utl = (unsigned)c.tl;
+  const v4i a1 = ld4<MASK>(mo1, k0 - 1), b1 = ld4<MASK>(mo1, k0 + 1);
+  const v4i a2 = ld4<MASK>(mo2, k0 - 1), b2 = ld4<MASK>(mo2, k0 + 1);
+  const v4i vi1 = ld4<MASK>(i1, k0 - 1), vd1 = ld4<MASK>(d1, k0 + 1);
+  const v4i vi2 = ld4<MASK>(i2, k0 - 1), vd2 = ld4<MASK>(d2, k0 + 1);
+  const v4i vmx = ld4<MASK>(mx, k0);
+  v4i ins1, ins2, del1, del2, m;
+  uint64_t x[4];
+  int maxn[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int k = k0 + j;
+    ins1[j] = valid_or_null(max(a1[j], vi1[j]) + 1, k, upl, utl);
+    ins2[j] = valid_or_null(max(a2[j], vi2[j]) + 1, k, upl, utl);
+    del1[j] = valid_or_null(max(b1[j], vd1[j]), k, upl, utl);
+    del2[j] = valid_or_null(max(b2[j], vd2[j]), k, upl, utl);
+    const int mis = valid_or_null(vmx[j] + 1, k, upl, utl);
+    int mm = max(imax3(ins1[j], ins2[j], mis), max(del1[j], del2[j]));
+    if (k < lo || k > hi) mm = WF_NULL;  // edge chunk: cells outside the row are dead
+    m[j] = mm;
+    // first 8 bases of the extension for all four cells (independent loads)
+    x[j] = 0; maxn[j] = 0;
+    if (mm >= 0) {
+      maxn[j] = min(c.pl - (mm - k), c.tl - mm);
+      x[j] = load8(P + (mm - k)) ^ load8(T + mm);
+    }
+  }
+  SEC_T(t1);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    if (m[j] >= 0) {
+      const int k = k0 + j;
+      int n;
+      if (x[j]) n = (int)(__builtin_ctzll(x[j]) >> 3);
+      else {
+        n = 8;
+        const uint8_t* a = P + (m[j] - k);
+        const uint8_t* b = T + m[j];
+        while (n < maxn[j]) {
+          const uint64_t y = load8(a + n) ^ load8(b + n);
+          if (y) { n += (int)(__builtin_ctzll(y) >> 3); break; }
+          n += 8;
+        }
+      }
+      m[j] += min(n, maxn[j]);
+      mak = max(mak, 2 * m[j] - k);
+    }
+  }
+  SEC_T(t2);
+  *reinterpret_cast<v4i*>(oi1 + k0) = ins1;
+  *reinterpret_cast<v4i*>(oi2 + k0) = ins2;
+  *reinterpret_cast<v4i*>(od1 + k0) = del1;
+  *reinterpret_cast<v4i*>(od2 + k0) = del2;
+  *reinterpret_cast<v4i*>(om + k0) = m;
+  SEC_T(t3);
+  SEC_ADD(0, t0, t1); SEC_ADD(1, t1, t2); SEC_ADD(2, t2, t3);
+}
+
 // Computes + extends row s of direction dir.  Returns #cells of the row (uniform).
 // Per-thread max antidiagonal is accumulated into mak.
-__device__ __forceinline__ int bp_compute_row(const BpCtx& c, int dir, int s, int (*s_lo)[RING], int (*s_hi)[RING], int& mak) {
+__device__ __forceinline__ int bp_compute_row(const BpCtx& c, int dir, int s, int (*s_lo)[RING], int (*s_hi)[RING], int& mak, long long* sec) {
   const DevPen& pn = c.pen;
-  const Src mx  = bp_src(c, dir, C_M,  s - pn.x, s_lo, s_hi);
-  const Src mo1 = bp_src(c, dir, C_M,  s - pn.o1 - pn.e1, s_lo, s_hi);
-  const Src mo2 = bp_src(c, dir, C_M,  s - pn.o2 - pn.e2, s_lo, s_hi);
-  const Src i1  = bp_src(c, dir, C_I1, s - pn.e1, s_lo, s_hi);
-  const Src d1  = bp_src(c, dir, C_D1, s - pn.e1, s_lo, s_hi);
-  const Src i2  = bp_src(c, dir, C_I2, s - pn.e2, s_lo, s_hi);
-  const Src d2  = bp_src(c, dir, C_D2, s - pn.e2, s_lo, s_hi);
+  const VSrc mx  = bp_vsrc(c, dir, C_M,  s - pn.x, s_lo, s_hi);
+  const VSrc mo1 = bp_vsrc(c, dir, C_M,  s - pn.o1 - pn.e1, s_lo, s_hi);
+  const VSrc mo2 = bp_vsrc(c, dir, C_M,  s - pn.o2 - pn.e2, s_lo, s_hi);
+  const VSrc i1  = bp_vsrc(c, dir, C_I1, s - pn.e1, s_lo, s_hi);
+  const VSrc d1  = bp_vsrc(c, dir, C_D1, s - pn.e1, s_lo, s_hi);
+  const VSrc i2  = bp_vsrc(c, dir, C_I2, s - pn.e2, s_lo, s_hi);
+  const VSrc d2  = bp_vsrc(c, dir, C_D2, s - pn.e2, s_lo, s_hi);
   int lo = INT32_MAX, hi = INT32_MIN;
-  if (mx.lo <= mx.hi)   { lo = min(lo, mx.lo);      hi = max(hi, mx.hi); }
-  if (mo1.lo <= mo1.hi) { lo = min(lo, mo1.lo - 1); hi = max(hi, mo1.hi + 1); }
-  if (mo2.lo <= mo2.hi) { lo = min(lo, mo2.lo - 1); hi = max(hi, mo2.hi + 1); }
-  if (i1.lo <= i1.hi)   { lo = min(lo, i1.lo - 1);  hi = max(hi, i1.hi + 1); }
-  if (i2.lo <= i2.hi)   { lo = min(lo, i2.lo - 1);  hi = max(hi, i2.hi + 1); }
+  // interior = diagonals whose k-1..k+1 neighbourhood is live in EVERY source row
+  int in_lo = INT32_MIN, in_hi = INT32_MAX;
+  bool all_live = true;
+#define ROW_RANGE(r, dl, dh)                                                               \
+  if ((r).span != 0u || (r).lo != INT32_MIN / 2) {                                         \
+    lo = min(lo, (r).lo + (dl)); hi = max(hi, (r).lo + (int)(r).span + (dh));              \
+    in_lo = max(in_lo, (r).lo); in_hi = min(in_hi, (r).lo + (int)(r).span);                \
+  } else all_live = false;
+  ROW_RANGE(mx, 0, 0) ROW_RANGE(mo1, -1, 1) ROW_RANGE(mo2, -1, 1) ROW_RANGE(i1, -1, 1) ROW_RANGE(i2, -1, 1)
+#undef ROW_RANGE
+  if (d1.span == 0u && d1.lo == INT32_MIN / 2) all_live = false;
   lo = max(lo, -c.pl);
   hi = min(hi, c.tl);
   const bool valid = (lo <= hi);
@@ -128,28 +239,17 @@ __device__ __forceinline__ int bp_compute_row(const BpCtx& c, int dir, int s, in
   int32_t* oi2 = bp_row(c, dir, C_I2, s);
   int32_t* od1 = bp_row(c, dir, C_D1, s);
   int32_t* od2 = bp_row(c, dir, C_D2, s);
-  const unsigned upl = (unsigned)c.pl, utl = (unsigned)c.tl;
   const uint8_t* P = c.P[dir];
   const uint8_t* T = c.T[dir];
-  for (int k = lo + (int)threadIdx.x; k <= hi; k += (int)blockDim.x) {
-    const int m1a = ldk(mo1, k - 1), m1b = ldk(mo1, k + 1);
-    const int m2a = ldk(mo2, k - 1), m2b = ldk(mo2, k + 1);
-    int ins1 = max(m1a, ldk(i1, k - 1)) + 1;
-    int ins2 = max(m2a, ldk(i2, k - 1)) + 1;
-    int del1 = max(m1b, ldk(d1, k + 1));
-    int del2 = max(m2b, ldk(d2, k + 1));
-    int mis  = ldk(mx, k) + 1;
-    ins1 = valid_or_null(ins1, k, upl, utl);
-    ins2 = valid_or_null(ins2, k, upl, utl);
-    del1 = valid_or_null(del1, k, upl, utl);
-    del2 = valid_or_null(del2, k, upl, utl);
-    mis  = valid_or_null(mis, k, upl, utl);
-    int m = max(imax3(ins1, ins2, mis), max(del1, del2));
-    if (m >= 0) {
-      m += lce_bounded(P, T, m - k, m, c.pl, c.tl);
-      mak = max(mak, 2 * m - k);
-    }
-    oi1[k] = ins1; oi2[k] = ins2; od1[k] = del1; od2[k] = del2; om[k] = m;
+  const int koff = c.koff;  // column = k + koff, multiple-of-4 columns are 16-byte aligned
+  const int c_lo = (lo + koff) >> 2, c_hi = (hi + koff) >> 2;
+  for (int ch = c_lo + (int)threadIdx.x; ch <= c_hi; ch += (int)blockDim.x) {
+    const int k0 = (ch << 2) - koff;
+    // loads touch k0-1 .. k0+4
+    if (all_live && k0 - 1 >= in_lo && k0 + 4 <= in_hi)
+      bp_cells4<false>(c, P, T, k0, lo, hi, mx, mo1, mo2, i1, d1, i2, d2, om, oi1, oi2, od1, od2, mak, sec);
+    else
+      bp_cells4<true>(c, P, T, k0, lo, hi, mx, mo1, mo2, i1, d1, i2, d2, om, oi1, oi2, od1, od2, mak, sec);
   }
   return hi - lo + 1;
 }
@@ -203,7 +303,8 @@ __global__ __launch_bounds__(1024) void wfa_bp_kernel(const uint8_t* __restrict_
   c.P[0] = seq + J.p_fwd; c.T[0] = seq + J.t_fwd;
   c.P[1] = seq + J.p_rev; c.T[1] = seq + J.t_rev;
   c.width = J.width;
-  c.ring = ring_arena + J.ring_off + (J.pl + 1);
+  c.koff = J.koff;  // columns start at 4: chunk 0 is never touched, so k0-1 loads stay inside the row
+  c.ring = ring_arena + J.ring_off + c.koff;
   c.pl = J.pl; c.tl = J.tl;
   c.pen = pen;
   const int tid = threadIdx.x;
@@ -237,6 +338,7 @@ __global__ __launch_bounds__(1024) void wfa_bp_kernel(const uint8_t* __restrict_
   if (end_reached) {
     if (tid == 0) {
       BpResult r; r.status = 1; r.score = 0; r.score_fwd = 0; r.score_rev = 0; r.k_fwd = 0; r.off_fwd = 0; r.comp = 0; r.steps = 0; r.cells = 2;
+      r.steps_p1 = 0; r.ticks_p1 = 0; r.ticks_p2 = 0; r.pad_ = 0;
       results[blockIdx.x] = r;
     }
     return;
@@ -247,6 +349,9 @@ __global__ __launch_bounds__(1024) void wfa_bp_kernel(const uint8_t* __restrict_
   int last_fwd = 0;
   int status = 0;
   int buf = 0;
+  const long long t_begin = wall_clock64();
+  long long sec[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  (void)sec;
 
   // ---- phase 1: advance both directions until the antidiagonals meet ----
   // (the reference alternates forward, reverse; both rows of a round are
@@ -256,15 +361,20 @@ __global__ __launch_bounds__(1024) void wfa_bp_kernel(const uint8_t* __restrict_
     buf = (buf + 1) % 3;
     if (tid == 0) { s_mak[(buf + 1) % 3][0] = 0; s_mak[(buf + 1) % 3][1] = 0; }
     int makf = 0, makr = 0;
-    const int nf = bp_compute_row(c, 0, sf + 1, s_lo, s_hi, makf);
-    const int nr = bp_compute_row(c, 1, sr + 1, s_lo, s_hi, makr);
+    SEC_T(ta);
+    const int nf = bp_compute_row(c, 0, sf + 1, s_lo, s_hi, makf, sec);
+    const int nr = bp_compute_row(c, 1, sr + 1, s_lo, s_hi, makr, sec);
+    SEC_T(tb);
     makf = wave_max(makf);
     makr = wave_max(makr);
     if ((tid & 63) == 0) {
       if (makf > 0) atomicMax(&s_mak[buf][0], makf);
       if (makr > 0) atomicMax(&s_mak[buf][1], makr);
     }
+    SEC_T(tc);
     __syncthreads();
+    SEC_T(td);
+    SEC_ADD(3, ta, tb); SEC_ADD(4, tb, tc); SEC_ADD(5, tc, td);
     ++sf; cells += (uint64_t)nf;
     fmax = max(fmax, s_mak[buf][0]);
     last_fwd = 1;
@@ -277,6 +387,11 @@ __global__ __launch_bounds__(1024) void wfa_bp_kernel(const uint8_t* __restrict_
 
   // ---- phase 2: overlap detection (wavefront_bialign_find_breakpoint, 2nd loop) ----
   int best = INT32_MAX;
+  const long long t_mid = wall_clock64();
+#ifdef WFM_PROFILE_SECTIONS
+  if (tid == 0 && blockIdx.x == 0) { for (int q = 0; q < 6; ++q) g_sec[q] = sec[q]; g_sec[6] = sf + sr; }
+#endif
+  const int steps_p1 = sf + sr;
   if (status == 0) {
     const int gopen = max(pen.o1, pen.o2);
     for (;;) {
@@ -330,8 +445,8 @@ __global__ __launch_bounds__(1024) void wfa_bp_kernel(const uint8_t* __restrict_
       }
       // advance the other direction
       int mak = 0;
-      if (d0 == 0) { ++sr; cells += (uint64_t)bp_compute_row(c, 1, sr, s_lo, s_hi, mak); last_fwd = 0; }
-      else         { ++sf; cells += (uint64_t)bp_compute_row(c, 0, sf, s_lo, s_hi, mak); last_fwd = 1; }
+      if (d0 == 0) { ++sr; cells += (uint64_t)bp_compute_row(c, 1, sr, s_lo, s_hi, mak, sec); last_fwd = 0; }
+      else         { ++sf; cells += (uint64_t)bp_compute_row(c, 0, sf, s_lo, s_hi, mak, sec); last_fwd = 1; }
       __syncthreads();
       if (d0 == 1 && (int64_t)sf + sr > max_steps && best == INT32_MAX) { status = WFM_DEV_UNREACHABLE; break; }
     }
@@ -343,6 +458,10 @@ __global__ __launch_bounds__(1024) void wfa_bp_kernel(const uint8_t* __restrict_
     r.score = best; r.score_fwd = s_bp[1]; r.score_rev = s_bp[2]; r.k_fwd = s_bp[3]; r.off_fwd = s_bp[4]; r.comp = s_bp[5];
     r.steps = sf + sr;
     r.cells = cells;
+    r.steps_p1 = steps_p1;
+    r.ticks_p1 = (uint32_t)(t_mid - t_begin);
+    r.ticks_p2 = (uint32_t)(wall_clock64() - t_mid);
+    r.pad_ = 0;
     results[blockIdx.x] = r;
   }
 }
@@ -619,6 +738,9 @@ __global__ __launch_bounds__(256) void rle_compact_kernel(const uint32_t* __rest
 }
 
 // ---------------------------------------------------------------------------
+#ifdef WFM_PROFILE_SECTIONS
+void read_sections(long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sec), sizeof(long long) * 8); }
+#endif
 // host-callable launchers
 // ---------------------------------------------------------------------------
 void launch_bp(const uint8_t* seq, int32_t* ring, const BpJob* jobs, BpResult* res, int njobs, int threads,
