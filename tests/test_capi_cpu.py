@@ -8,10 +8,10 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _declared_symbols():
-    text = open(os.path.join(ROOT, "include", "wfmash_hip.h")).read()
+def _declared_symbols(header="wfmash_hip.h", prefix="wfm_"):
+    text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(wfm_[a-z0-9_]+)\s*\(", text)))
+    return sorted(set(re.findall(r"\b(" + prefix + r"[a-z0-9_]+)\s*\(", text)))
 
 
 def test_library_exports_every_declared_symbol():
@@ -22,6 +22,10 @@ def test_library_exports_every_declared_symbol():
     for name in decl:
         assert hasattr(L, name), f"{name} declared in include/wfmash_hip.h but not exported"
     assert sorted(capi.EXPORTS) == decl
+    host = _declared_symbols("wfmash_host.h", "wfmh_")
+    assert sorted(capi.HOST_EXPORTS) == host
+    for name in host:
+        assert hasattr(L, name), f"{name} declared in include/wfmash_host.h but not exported"
 
 
 def test_no_cpu_fallback():

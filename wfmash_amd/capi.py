@@ -262,3 +262,64 @@ class Handle:
         if rc < 0:
             raise WfmError(f"wfm_sketch_fragments failed ({rc}): {self.last_error()}")
         return [out[i * s:i * s + cnt[i]] for i in range(n)]
+
+
+# ---------------------------------------------------------------------------
+# host-side align driver (include/wfmash_host.h)
+# ---------------------------------------------------------------------------
+HOST_EXPORTS = ["wfmh_align_default_params", "wfmh_align_paf", "wfmh_test_cigar", "wfmh_free"]
+
+
+class AlignParams(C.Structure):
+    _fields_ = [("mismatch", C.c_int32), ("gap_open1", C.c_int32), ("gap_ext1", C.c_int32),
+                ("gap_open2", C.c_int32), ("gap_ext2", C.c_int32),
+                ("min_identity", C.c_float), ("min_alignment_length", C.c_uint64),
+                ("min_block_identity", C.c_float), ("target_padding", C.c_uint64),
+                ("query_padding", C.c_uint64), ("wflign_max_len_minor", C.c_uint64),
+                ("disable_chain_patching", C.c_int32)]
+
+
+class AlignSummary(C.Structure):
+    _fields_ = [("records", C.c_uint64), ("aligned_bp", C.c_uint64), ("written", C.c_uint64),
+                ("skipped", C.c_uint64), ("cells", C.c_uint64), ("ms_gpu", C.c_double), ("ms_total", C.c_double)]
+
+
+def _host():
+    L = load()
+    if not getattr(L, "_host_bound", False):
+        L.wfmh_align_default_params.restype = None
+        L.wfmh_align_default_params.argtypes = [C.POINTER(AlignParams)]
+        L.wfmh_align_paf.restype = C.c_int
+        L.wfmh_align_paf.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p,
+                                     C.POINTER(AlignParams), C.POINTER(AlignSummary)]
+        L.wfmh_test_cigar.restype = C.c_void_p
+        L.wfmh_test_cigar.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_longlong, C.c_longlong]
+        L.wfmh_free.restype = None
+        L.wfmh_free.argtypes = [C.c_void_p]
+        L._host_bound = True
+    return L
+
+
+def host_cigar_fn(fn, a=b"", b=b"", query=b"", target=b"", i0=0, i1=0) -> str:
+    """Pure host-side CIGAR helpers of wfmash_amd/host (no GPU needed)."""
+    L = _host()
+    enc = lambda x: x if isinstance(x, bytes) else x.encode()
+    p = L.wfmh_test_cigar(enc(fn), enc(a), enc(b), enc(query), enc(target), i0, i1)
+    s = C.string_at(p).decode()
+    L.wfmh_free(p)
+    return s
+
+
+def align_paf(handle, target_fasta, mapping_paf, out_paf, query_fasta=None, params=None):
+    """wfmh_align_paf: the align phase on files (mapping PAF in, aligned PAF out)."""
+    L = _host()
+    prm = AlignParams()
+    L.wfmh_align_default_params(C.byref(prm))
+    for k, v in (params or {}).items():
+        setattr(prm, k, v)
+    summ = AlignSummary()
+    rc = L.wfmh_align_paf(handle._p, target_fasta.encode(), query_fasta.encode() if query_fasta else None,
+                          mapping_paf.encode(), out_paf.encode(), C.byref(prm), C.byref(summ))
+    if rc != 0:
+        raise WfmError(f"wfmh_align_paf failed ({rc}): {handle.last_error()}")
+    return summ

@@ -1,0 +1,230 @@
+#include "aligner.hpp"
+
+#include <algorithm>
+#include <cctype>
+#include <chrono>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <sstream>
+#include <stdexcept>
+
+namespace align {
+
+namespace {
+
+std::vector<std::string> tokenize(const std::string& s) {  // whitespace split (computeAlignments.hpp:54-72)
+  std::vector<std::string> t;
+  size_t pos = 0;
+  while (pos < s.size()) {
+    while (pos < s.size() && std::isspace((unsigned char)s[pos])) ++pos;
+    if (pos >= s.size()) break;
+    const size_t st = pos;
+    while (pos < s.size() && !std::isspace((unsigned char)s[pos])) ++pos;
+    t.emplace_back(s.substr(st, pos - st));
+  }
+  return t;
+}
+
+std::vector<std::string> split(const std::string& s, char d) {  // computeAlignments.hpp:35-51
+  std::vector<std::string> r;
+  size_t pos = 0, f;
+  while ((f = s.find(d, pos)) != std::string::npos) { r.emplace_back(s.substr(pos, f - pos)); pos = f + 1; }
+  if (pos <= s.size()) r.emplace_back(s.substr(pos));
+  return r;
+}
+
+bool is_a_number(const std::string& s) {  // utils.cpp:9-11
+  return !s.empty() && s.find_first_not_of("0123456789.") == std::string::npos && std::count(s.begin(), s.end(), '.') < 2;
+}
+
+// makeUpperCaseAndValidDNA (commonFunc.hpp:132-142)
+void upper_valid_dna(std::string& s) {
+  for (auto& c : s) {
+    if (c > 96 && c < 123) c -= 32;
+    if (!(c == 'A' || c == 'C' || c == 'G' || c == 'T')) c = 'N';
+  }
+}
+
+// reverseComplement (commonFunc.hpp:74-83) on validated DNA
+std::string revcomp(const std::string& s) {
+  std::string r(s.size(), 'N');
+  for (size_t i = 0; i < s.size(); ++i) {
+    char c = s[i], o;
+    switch (c) { case 'A': o = 'T'; break; case 'C': o = 'G'; break; case 'G': o = 'C'; break; case 'T': o = 'A'; break; default: o = c; }
+    r[s.size() - 1 - i] = o;
+  }
+  return r;
+}
+
+struct Fetched {
+  MappingBoundaryRow row;
+  std::string ref;    // padded reference window
+  std::string qry;    // strand-adjusted query window
+  uint64_t ref_start = 0, ref_total = 0, q_total = 0;
+};
+
+}  // namespace
+
+Aligner::Aligner(const Parameters& p, wfm_handle_t* g) : param(p), gpu(g) {
+  if (param.refSequences.size() != 1 || param.querySequences.size() != 1)
+    throw std::runtime_error("[wfmash::align] exactly one target and one query FASTA are expected");
+  ref.reset(new wfmash_host::FastaStore(param.refSequences.front()));
+  if (param.querySequences.front() == param.refSequences.front()) query = ref.get();
+  else { query_own.reset(new wfmash_host::FastaStore(param.querySequences.front())); query = query_own.get(); }
+}
+
+void Aligner::parseMashmapRow(const std::string& line, MappingBoundaryRow& row, uint64_t target_padding, uint64_t query_padding) {
+  const auto tokens = tokenize(line);
+  if (tokens.size() < 13)
+    throw std::runtime_error("[wfmash::align::parseMashmapRow] Error! Invalid mashmap mapping record: " + line);
+  const auto idv = split(tokens[12], ':');
+  const float mm_id = (!idv.empty() && is_a_number(idv.back())) ? std::stof(idv.back()) : 0.70f;  // fixed::percentage_identity
+  int64_t chain_id = -1, chain_length = 1, chain_pos = 1;
+  if (tokens.size() > 14) {
+    const auto cv = split(tokens[14], ':');
+    if (cv.size() == 3 && cv[0] == "ch" && cv[1] == "Z") {
+      const auto parts = split(cv[2], '.');
+      if (parts.size() == 3) {  // ch:Z:id.pos.len as the mapper writes it (mappingOutput.hpp:121)
+        chain_id = std::stoll(parts[0]); chain_pos = std::stoll(parts[1]); chain_length = std::stoll(parts[2]);
+      }
+    }
+  }
+  row.qId = tokens[0];
+  row.qStartPos = std::stoll(tokens[2]);
+  row.qEndPos = std::stoll(tokens[3]);
+  row.strand = tokens[4] == "+" ? FWD : REV;
+  row.refId = tokens[5];
+  const uint64_t ref_len = std::stoull(tokens[6]);
+  row.chain_id = (int32_t)chain_id; row.chain_length = (int32_t)chain_length; row.chain_pos = (int32_t)chain_pos;
+  uint64_t rs = (uint64_t)std::stoll(tokens[7]), re = (uint64_t)std::stoll(tokens[8]);
+  uint64_t qs = (uint64_t)row.qStartPos, qe = (uint64_t)row.qEndPos;
+  const uint64_t query_len = std::stoull(tokens[1]);
+  if (target_padding > 0) {
+    rs = rs >= target_padding ? rs - target_padding : 0;
+    re = re + target_padding <= ref_len ? re + target_padding : ref_len;
+  }
+  if (query_padding > 0) {
+    // padding only at the chain ends, and only STORED for the last piece (computeAlignments.hpp:268-289)
+    if (chain_pos == 1) qs = qs >= query_padding ? qs - query_padding : 0;
+    if (chain_pos == chain_length) {
+      qe = qe + query_padding <= query_len ? qe + query_padding : query_len;
+      row.qStartPos = (int64_t)qs;
+      row.qEndPos = (int64_t)qe;
+    }
+  }
+  if (rs >= ref_len || re > ref_len)
+    throw std::runtime_error("[wfmash::align::parseMashmapRow] Error! Coordinates exceed reference length: " +
+                             std::to_string(rs) + "-" + std::to_string(re) + " (ref_len=" + std::to_string(ref_len) + ")");
+  row.rStartPos = (int64_t)rs;
+  row.rEndPos = (int64_t)re;
+  row.mashmap_estimated_identity = mm_id;
+}
+
+std::string Aligner::align_lines(const std::vector<std::string>& lines, Summary& sum) {
+  std::string out;
+  wflign::wflign_penalties_t pen;
+  pen.match = 0;
+  pen.mismatch = param.wfa_patching_mismatch_score;
+  pen.gap_opening1 = param.wfa_patching_gap_opening_score1;
+  pen.gap_extension1 = param.wfa_patching_gap_extension_score1;
+  pen.gap_opening2 = param.wfa_patching_gap_opening_score2;
+  pen.gap_extension2 = param.wfa_patching_gap_extension_score2;
+  wflign::PafParams pp;
+  pp.min_identity = param.min_identity;
+  pp.min_alignment_length = param.min_alignment_length;
+  pp.min_block_identity = param.min_block_identity;
+
+  size_t i = 0;
+  while (i < lines.size()) {
+    // ---- assemble one batch (createSeqRecord + processAlignment front half) ----
+    std::vector<Fetched> fetched;
+    uint64_t bases = 0;
+    while (i < lines.size() && fetched.size() < param.batch_records && bases < param.batch_bases) {
+      const std::string& line = lines[i++];
+      if (line.empty()) continue;
+      Fetched f;
+      try {
+        parseMashmapRow(line, f.row, param.target_padding, param.query_padding);
+        const int64_t ref_size = ref->seq_len(f.row.refId);
+        if (ref_size < 0) throw std::runtime_error("Reference sequence not found: " + f.row.refId);
+        const int64_t query_size = query->seq_len(f.row.qId);
+        if (query_size < 0) throw std::runtime_error("Query sequence not found: " + f.row.qId);
+        const uint64_t head_pad = (uint64_t)f.row.rStartPos >= param.wflign_max_len_minor ? param.wflign_max_len_minor : (uint64_t)f.row.rStartPos;
+        const uint64_t tail_pad = (uint64_t)(ref_size - f.row.rEndPos) >= param.wflign_max_len_minor ? param.wflign_max_len_minor : (uint64_t)(ref_size - f.row.rEndPos);
+        f.ref = ref->fetch(f.row.refId, f.row.rStartPos - (int64_t)head_pad, f.row.rEndPos + (int64_t)tail_pad - 1);
+        if (f.ref.empty()) throw std::runtime_error("Failed to fetch reference sequence");
+        std::string q = query->fetch(f.row.qId, f.row.qStartPos, f.row.qEndPos - 1);
+        if (q.empty()) throw std::runtime_error("Failed to fetch query sequence");
+        f.ref_start = (uint64_t)f.row.rStartPos - head_pad;
+        f.ref_total = (uint64_t)ref_size; f.q_total = (uint64_t)query_size;
+        upper_valid_dna(f.ref);
+        upper_valid_dna(q);
+        f.qry = f.row.strand == FWD ? std::move(q) : revcomp(q);
+        bases += f.ref.size() + f.qry.size();
+        fetched.push_back(std::move(f));
+      } catch (const std::exception& e) {
+        std::cerr << "[wfmash::align] Error processing record: " << e.what() << std::endl;
+        sum.skipped++;
+      }
+    }
+    if (fetched.empty()) continue;
+    std::vector<wflign::BiwfaRecord> recs(fetched.size());
+    for (size_t k = 0; k < fetched.size(); ++k) {
+      const Fetched& f = fetched[k];
+      wflign::BiwfaRecord& r = recs[k];
+      r.query_name = f.row.qId;
+      r.query = f.qry.data();
+      r.query_total_length = f.q_total;
+      r.query_offset = (uint64_t)f.row.qStartPos;
+      r.query_length = f.qry.size();
+      r.query_is_rev = f.row.strand != FWD;
+      r.target_name = f.row.refId;
+      const uint64_t skip = (uint64_t)f.row.rStartPos - f.ref_start;
+      r.target = f.ref.data() + skip;
+      r.target_total_length = f.ref_total;
+      r.target_offset = (uint64_t)f.row.rStartPos;
+      r.target_length = (uint64_t)(f.row.rEndPos - f.row.rStartPos);
+      r.target_avail = f.ref.size() - skip;
+      r.mashmap_estimated_identity = f.row.mashmap_estimated_identity;
+      r.chain_id = f.row.chain_id; r.chain_length = f.row.chain_length; r.chain_pos = f.row.chain_pos;
+    }
+    wflign::BiwfaStats st;
+    const int rc = wflign::do_biwfa_alignment_batch(gpu, recs, pen, param.disable_chain_patching, pp, &st);
+    if (rc < 0) throw std::runtime_error(std::string("[wfmash::align] GPU alignment failed: ") + wfm_last_error(gpu));
+    sum.cells += st.cells; sum.ms_gpu += st.ms_gpu;
+    for (size_t k = 0; k < recs.size(); ++k) {
+      sum.records++;
+      sum.aligned_bp += (uint64_t)(fetched[k].row.qEndPos - fetched[k].row.qStartPos);
+      if (recs[k].paf.empty()) continue;
+      // processMappingRecord re-tokenises the writer's line and joins with single tabs (computeAlignments.hpp:484-525)
+      const auto fields = tokenize(recs[k].paf);
+      std::string nl;
+      for (const auto& fld : fields) { if (!nl.empty()) nl += '\t'; nl += fld; }
+      nl += '\n';
+      out += nl;
+      sum.written++;
+    }
+  }
+  return out;
+}
+
+Summary Aligner::compute() {
+  Summary sum;
+  const auto t0 = std::chrono::steady_clock::now();
+  std::ifstream in(param.mashmapPafFile);
+  if (!in.is_open()) throw std::runtime_error("[wfmash::align] Error! Failed to open input mapping file: " + param.mashmapPafFile);
+  std::vector<std::string> lines;
+  std::string line;
+  while (std::getline(in, line)) if (!line.empty()) lines.push_back(line);
+  std::ofstream outstream(param.pafOutputFile);
+  if (!outstream.is_open()) throw std::runtime_error("[wfmash::align] Error! Failed to open output file: " + param.pafOutputFile);
+  outstream << align_lines(lines, sum);
+  outstream.close();
+  sum.ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  std::cerr << "[wfmash::align] total aligned records = " << sum.records << ", total aligned bp = " << sum.aligned_bp
+            << ", completed in " << (uint64_t)(sum.ms_total / 1000.0) << " seconds" << std::endl;
+  return sum;
+}
+
+}  // namespace align

@@ -1,0 +1,83 @@
+// aligner.hpp -- align driver above the C ABI: counterpart of align::Aligner
+// (src/align/include/computeAlignments.hpp:142-738).  Same call surface
+// (Parameters, MappingBoundaryRow, parseMashmapRow, compute) but records are
+// processed in batches so that every wflign stage is one GPU launch set instead
+// of one Taskflow task per record (computeAlignments.hpp:398-435).
+#pragma once
+
+#include <cstdint>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/wfmash_hip.h"
+#include "fasta.hpp"
+#include "wflign_hip.hpp"
+
+namespace align {
+
+enum strnd : int16_t { FWD = 1, AMBIG = 0, REV = -1 };  // skch::strnd (base_types.hpp)
+
+// align::Parameters (align_parameters.hpp:16), fields the live path reads
+struct Parameters {
+  int threads = 1;
+  float min_identity = 0;                 // parse_args.hpp:566
+  uint64_t min_alignment_length = 32;     // parse_args.hpp:572
+  float min_block_identity = 0.1f;        // parse_args.hpp:583
+  int wfa_patching_mismatch_score = 5;    // parse_args.hpp:290-294
+  int wfa_patching_gap_opening_score1 = 8;
+  int wfa_patching_gap_extension_score1 = 2;
+  int wfa_patching_gap_opening_score2 = 24;
+  int wfa_patching_gap_extension_score2 = 1;
+  uint64_t wflign_max_len_minor = 128000; // windowLength * 128, parse_args.hpp:594
+  std::vector<std::string> refSequences;
+  std::vector<std::string> querySequences;
+  std::string mashmapPafFile;
+  std::string pafOutputFile;
+  bool emit_md_tag = false;
+  bool sam_format = false;
+  bool no_seq_in_sam = false;
+  bool disable_chain_patching = false;
+  uint64_t target_padding = 1000;         // min(w, 5000), parse_args.hpp:608
+  uint64_t query_padding = 1000;          // parse_args.hpp:620
+  // batching (not in the reference): records per GPU batch are bounded by bases
+  uint64_t batch_bases = 256ull << 20;
+  size_t batch_records = 4096;
+};
+
+// MappingBoundaryRow (align_types.hpp:17)
+struct MappingBoundaryRow {
+  std::string qId, refId;
+  int64_t qStartPos = 0, qEndPos = 0, rStartPos = 0, rEndPos = 0;
+  int16_t strand = FWD;
+  float mashmap_estimated_identity = 0;
+  int32_t chain_id = -1, chain_length = 1, chain_pos = 1;
+};
+
+struct Summary {
+  uint64_t records = 0;            // "total aligned records"
+  uint64_t aligned_bp = 0;         // "total aligned bp" = sum of query spans (computeAlignments.hpp:481,528)
+  uint64_t written = 0;            // PAF lines emitted
+  uint64_t skipped = 0;            // invalid mapping rows
+  uint64_t cells = 0;
+  double ms_gpu = 0, ms_total = 0;
+};
+
+class Aligner {
+ public:
+  Aligner(const Parameters& p, wfm_handle_t* gpu);
+  // throws std::runtime_error on malformed rows (computeAlignments.hpp:199-201,292-297)
+  static void parseMashmapRow(const std::string& line, MappingBoundaryRow& row, uint64_t target_padding,
+                              uint64_t query_padding = 0);
+  Summary compute();  // reads param.mashmapPafFile, writes param.pafOutputFile
+  // Aligns mapping lines already in memory; returns the PAF text.
+  std::string align_lines(const std::vector<std::string>& lines, Summary& sum);
+
+ private:
+  const Parameters& param;
+  wfm_handle_t* gpu;
+  std::unique_ptr<wfmash_host::FastaStore> ref, query_own;
+  const wfmash_host::FastaStore* query = nullptr;
+};
+
+}  // namespace align

@@ -1,0 +1,113 @@
+// capi_host.cpp -- C entry points of the host-side align driver (include/wfmash_host.h).
+#include <exception>
+#include <iostream>
+#include <string>
+
+#include "../../include/wfmash_host.h"
+#include "../csrc/wfa_handle.h"
+#include "aligner.hpp"
+
+extern "C" {
+
+void wfmh_align_default_params(wfmh_align_params_t* p) {
+  if (!p) return;
+  p->mismatch = 5; p->gap_open1 = 8; p->gap_ext1 = 2; p->gap_open2 = 24; p->gap_ext2 = 1;
+  p->min_identity = 0.0f; p->min_alignment_length = 32; p->min_block_identity = 0.1f;
+  p->target_padding = 1000; p->query_padding = 1000; p->wflign_max_len_minor = 128000;
+  p->disable_chain_patching = 0;
+}
+
+int wfmh_align_paf(wfm_handle_t* h, const char* target_fasta, const char* query_fasta, const char* mapping_paf,
+                   const char* out_paf, const wfmh_align_params_t* params, wfmh_align_summary_t* summary) {
+  if (!h || !target_fasta || !mapping_paf || !out_paf) return WFM_E_ARG;
+  wfmh_align_params_t d;
+  wfmh_align_default_params(&d);
+  if (params) d = *params;
+  try {
+    align::Parameters ap;
+    ap.refSequences.push_back(target_fasta);
+    ap.querySequences.push_back(query_fasta ? query_fasta : target_fasta);
+    ap.mashmapPafFile = mapping_paf;
+    ap.pafOutputFile = out_paf;
+    ap.wfa_patching_mismatch_score = d.mismatch;
+    ap.wfa_patching_gap_opening_score1 = d.gap_open1;
+    ap.wfa_patching_gap_extension_score1 = d.gap_ext1;
+    ap.wfa_patching_gap_opening_score2 = d.gap_open2;
+    ap.wfa_patching_gap_extension_score2 = d.gap_ext2;
+    ap.min_identity = d.min_identity;
+    ap.min_alignment_length = d.min_alignment_length;
+    ap.min_block_identity = d.min_block_identity;
+    ap.target_padding = d.target_padding;
+    ap.query_padding = d.query_padding;
+    ap.wflign_max_len_minor = d.wflign_max_len_minor;
+    ap.disable_chain_patching = d.disable_chain_patching != 0;
+    align::Aligner aligner(ap, h);
+    const align::Summary s = aligner.compute();
+    if (summary) {
+      summary->records = s.records; summary->aligned_bp = s.aligned_bp; summary->written = s.written;
+      summary->skipped = s.skipped; summary->cells = s.cells; summary->ms_gpu = s.ms_gpu; summary->ms_total = s.ms_total;
+    }
+    return WFM_OK;
+  } catch (const std::exception& e) {
+    std::cerr << e.what() << std::endl;
+    wfm_set_error(h, e.what());
+    return WFM_E_ARG;
+  }
+}
+
+}  // extern "C"
+
+// ---- test hooks: expose the pure host-side CIGAR functions to the CPU test-suite ----
+#include <cstdlib>
+#include <cstring>
+#include <sstream>
+#include <vector>
+
+extern "C" {
+
+void wfmh_free(char* p) { free(p); }
+
+char* wfmh_test_cigar(const char* fn, const char* a, const char* b, const char* query, const char* target,
+                      long long i0, long long i1) {
+  std::string f = fn ? fn : "", sa = a ? a : "", sb = b ? b : "", q = query ? query : "", t = target ? target : "";
+  std::string r;
+  if (f == "erode") r = wflign::erode_short_matches_in_cigar(sa, (int)i0, i1 != 0);
+  else if (f == "merge") r = wflign::merge_adjacent_ops(sa, sb);
+  else if (f == "compress") r = wflign::compress_ops(sa.data(), sa.size());
+  else if (f == "swap_start") r = wflign::try_swap_start_pattern(sa, q, t, 0, 0);
+  else if (f == "swap_end") r = wflign::try_swap_end_pattern(sa, q, t, 0, 0);
+  else if (f == "head_erosion") {
+    const wflign::Erosion e = wflign::scan_head_erosion(sa);
+    r = std::to_string(e.query_eroded) + "," + std::to_string(e.target_eroded) + "," + std::to_string(e.erode_end_pos);
+  } else if (f == "tail_erosion") {
+    const wflign::Erosion e = wflign::scan_tail_erosion(wflign::parse_cigar(sa));
+    r = std::to_string(e.query_eroded) + "," + std::to_string(e.target_eroded) + "," + std::to_string(e.erode_start_idx);
+  } else if (f == "paf") {
+    // b = qname|qtotal|qoff|qlen|qrev|tname|ttotal|toff|mmid|chain_id|chain_len|chain_pos
+    std::vector<std::string> p;
+    std::stringstream ss(sb);
+    std::string item;
+    while (std::getline(ss, item, '|')) p.push_back(item);
+    if (p.size() == 12) {
+      wflign::PafParams pp;
+      wflign::write_alignment_paf(r, sa, p[0], std::stoull(p[1]), std::stoull(p[2]), std::stoull(p[3]), p[4] == "1", p[5],
+                                  std::stoull(p[6]), std::stoull(p[7]), pp, std::stof(p[8]), std::stoi(p[9]), std::stoi(p[10]),
+                                  std::stoi(p[11]));
+    }
+  } else if (f == "parse_row") {
+    try {
+      align::MappingBoundaryRow row;
+      align::Aligner::parseMashmapRow(sa, row, (uint64_t)i0, (uint64_t)i1);
+      std::ostringstream os;
+      os << row.qId << "," << row.qStartPos << "," << row.qEndPos << "," << (row.strand == align::FWD ? "+" : "-") << ","
+         << row.refId << "," << row.rStartPos << "," << row.rEndPos << "," << row.mashmap_estimated_identity << ","
+         << row.chain_id << "," << row.chain_length << "," << row.chain_pos;
+      r = os.str();
+    } catch (const std::exception& e) { r = std::string("ERROR"); }
+  }
+  char* out = (char*)malloc(r.size() + 1);
+  memcpy(out, r.c_str(), r.size() + 1);
+  return out;
+}
+
+}  // extern "C"

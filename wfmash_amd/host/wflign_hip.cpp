@@ -1,0 +1,430 @@
+// wflign_hip.cpp -- see wflign_hip.hpp.  Host-side CIGAR surgery, swizzle and PAF
+// writer of the align path, restated from the reference's behaviour; all wavefront
+// arithmetic is done on the GPU through wfm_align_batch (no CPU fallback).
+#include "wflign_hip.hpp"
+
+#include <algorithm>
+#include <cctype>
+#include <cmath>
+#include <cstring>
+#include <sstream>
+
+namespace wflign {
+
+namespace {
+inline bool is_digit(char c) { return std::isdigit(static_cast<unsigned char>(c)) != 0; }
+}  // namespace
+
+CigarOps parse_cigar(const std::string& cigar) {
+  CigarOps ops;
+  ops.reserve(cigar.size() / 2 + 1);
+  size_t i = 0;
+  while (i < cigar.size()) {
+    long long v = 0;
+    while (i < cigar.size() && is_digit(cigar[i])) { v = v * 10 + (cigar[i] - '0'); ++i; }
+    if (i >= cigar.size()) break;
+    ops.emplace_back((int)v, cigar[i++]);
+  }
+  return ops;
+}
+
+std::string cigar_to_string(const CigarOps& ops) {
+  std::string s;
+  for (const auto& o : ops) { s += std::to_string(o.first); s += o.second; }
+  return s;
+}
+
+std::string compress_ops(const char* ops, size_t n) {
+  std::string out;
+  size_t i = 0;
+  while (i < n) {
+    const char op = ops[i];
+    size_t j = i;
+    while (j < n && ops[j] == op) ++j;
+    out += std::to_string(j - i);
+    out += (op == 'M') ? '=' : op;
+    i = j;
+  }
+  return out;
+}
+
+// Concatenate two CIGARs, fusing the last op of the first with the first op of
+// the second when they are of the same type (wflign.cpp:211-238).
+std::string merge_adjacent_ops(const std::string& cigar1, const std::string& cigar2) {
+  if (cigar1.empty()) return cigar2;
+  if (cigar2.empty()) return cigar1;
+  const char op1 = cigar1.back();
+  size_t end1 = cigar1.size() - 1;  // index of op char
+  size_t start1 = end1;
+  while (start1 > 0 && is_digit(cigar1[start1 - 1])) --start1;
+  size_t pos2 = 0;
+  while (pos2 < cigar2.size() && is_digit(cigar2[pos2])) ++pos2;
+  if (pos2 >= cigar2.size()) return cigar1 + cigar2;
+  const char op2 = cigar2[pos2];
+  if (op1 == op2 && start1 < end1) {
+    const long long c1 = std::stoll(cigar1.substr(start1, end1 - start1));
+    const long long c2 = std::stoll(cigar2.substr(0, pos2));
+    return cigar1.substr(0, start1) + std::to_string(c1 + c2) + op1 + cigar2.substr(pos2 + 1);
+  }
+  return cigar1 + cigar2;
+}
+
+std::string erode_short_matches_in_cigar(const std::string& cigar, int max_match_length, bool is_head_cigar) {
+  if (cigar.length() < 6) return cigar;
+  CigarOps ops = parse_cigar(cigar);
+  if (ops.size() < 3) return cigar;
+  size_t first = 1, last = ops.size() - 1;  // candidates are ops[first .. last)
+  if (is_head_cigar) last = std::min(last, (size_t)3);
+  else first = std::max(first, ops.size() - 3);
+  bool modified = false;
+  for (size_t i = first; i < last; ++i) {
+    const char t = ops[i].second, a = ops[i - 1].second, b = ops[i + 1].second;
+    const bool is_match = (t == 'M' || t == '=' || t == 'X');
+    const bool opposite_indels = (a == 'I' && b == 'D') || (a == 'D' && b == 'I');
+    if (is_match && ops[i].first <= max_match_length && opposite_indels &&
+        ops[i - 1].first > ops[i].first && ops[i + 1].first > ops[i].first) {
+      ops[i - 1].first += ops[i].first;
+      ops[i + 1].first += ops[i].first;
+      ops[i].first = 0;
+      modified = true;
+    }
+  }
+  if (!modified) return cigar;
+  CigarOps merged;
+  merged.reserve(ops.size());
+  for (const auto& o : ops) {
+    if (o.first <= 0) continue;
+    if (!merged.empty() && merged.back().second == o.second) merged.back().first += o.first;
+    else merged.push_back(o);
+  }
+  return cigar_to_string(merged);
+}
+
+namespace {
+constexpr uint64_t MIN_PATCH_LENGTH = 128;        // wflign.cpp:169
+constexpr uint64_t MAX_ERODE_LENGTH = 4096;       // wflign.cpp:170
+constexpr int MIN_CONSECUTIVE_MATCHES = 11;       // wflign.cpp:171
+
+inline void consume(char op, int count, uint64_t& q, uint64_t& t) {
+  if (op == 'M' || op == 'X' || op == '=') { q += (uint64_t)count; t += (uint64_t)count; }
+  else if (op == 'I') q += (uint64_t)count;
+  else if (op == 'D') t += (uint64_t)count;
+}
+}  // namespace
+
+Erosion scan_head_erosion(const std::string& main_cigar) {
+  Erosion e;
+  size_t pos = 0;
+  bool found = false;
+  while (pos < main_cigar.size()) {
+    long long count = 0;
+    while (pos < main_cigar.size() && is_digit(main_cigar[pos])) { count = count * 10 + (main_cigar[pos] - '0'); ++pos; }
+    const char op = main_cigar[pos++];
+    if (op == '=' && count >= MIN_CONSECUTIVE_MATCHES) found = true;
+    if (found && e.query_eroded >= MIN_PATCH_LENGTH && e.target_eroded >= MIN_PATCH_LENGTH) break;
+    if (e.query_eroded >= MAX_ERODE_LENGTH || e.target_eroded >= MAX_ERODE_LENGTH) break;
+    consume(op, (int)count, e.query_eroded, e.target_eroded);
+    e.erode_end_pos = pos;
+  }
+  return e;
+}
+
+Erosion scan_tail_erosion(const CigarOps& ops) {
+  Erosion e;
+  e.erode_start_idx = ops.size();
+  bool found = false;
+  for (int i = (int)ops.size() - 1; i >= 0; --i) {
+    const int count = ops[i].first;
+    const char op = ops[i].second;
+    if (op == '=' && count >= MIN_CONSECUTIVE_MATCHES) found = true;
+    if (found && e.query_eroded >= MIN_PATCH_LENGTH && e.target_eroded >= MIN_PATCH_LENGTH) break;
+    if (e.query_eroded >= MAX_ERODE_LENGTH || e.target_eroded >= MAX_ERODE_LENGTH) break;
+    consume(op, count, e.query_eroded, e.target_eroded);
+    e.erode_start_idx = (size_t)i;
+  }
+  return e;
+}
+
+// ---------------------------------------------------------------------------
+// swizzle
+// ---------------------------------------------------------------------------
+namespace {
+std::string merge_cigar_ops(const std::string& cigar) {  // wflign_swizzle.cpp:7-37
+  std::string merged;
+  long long cur_count = 0;
+  char cur_op = '\0';
+  for (const auto& o : parse_cigar(cigar)) {
+    if (o.second == cur_op) cur_count += o.first;
+    else {
+      if (cur_op != '\0') { merged += std::to_string(cur_count); merged += cur_op; }
+      cur_op = o.second; cur_count = o.first;
+    }
+  }
+  if (cur_op != '\0') { merged += std::to_string(cur_count); merged += cur_op; }
+  return merged;
+}
+
+bool sequences_match(const std::string& q, const std::string& t, int64_t qs, int64_t ts, int n) {
+  if (qs < 0 || ts < 0) return false;
+  if (qs + n > (int64_t)q.size() || ts + n > (int64_t)t.size()) return false;
+  return std::memcmp(q.data() + qs, t.data() + ts, (size_t)n) == 0;
+}
+
+// accepts only CIGARs made of '=' and 'D' (wflign_swizzle.cpp:61-105)
+bool verify_eq_del_cigar(const std::string& cigar, const std::string& q, const std::string& t, int64_t qs, int64_t ts) {
+  int64_t qp = qs, tp = ts;
+  for (const auto& o : parse_cigar(cigar)) {
+    const int v = o.first;
+    if (o.second == '=') {
+      if (qp < 0 || tp < 0 || qp + v > (int64_t)q.size() || tp + v > (int64_t)t.size()) return false;
+      if (std::memcmp(q.data() + qp, t.data() + tp, (size_t)v) != 0) return false;
+      qp += v; tp += v;
+    } else if (o.second == 'D') {
+      if (tp + v > (int64_t)t.size()) return false;
+      tp += v;
+    } else {
+      return false;
+    }
+  }
+  return true;
+}
+}  // namespace
+
+std::string try_swap_start_pattern(const std::string& cigar, const std::string& query_seq, const std::string& target_seq,
+                                   int64_t query_start, int64_t target_start) {
+  // first two ops
+  size_t i = 0;
+  long long n = 0, dlen = 0;
+  while (i < cigar.size() && is_digit(cigar[i])) { n = n * 10 + (cigar[i] - '0'); ++i; }
+  if (i >= cigar.size()) return cigar;
+  const char op1 = cigar[i++];
+  while (i < cigar.size() && is_digit(cigar[i])) { dlen = dlen * 10 + (cigar[i] - '0'); ++i; }
+  if (i >= cigar.size()) return cigar;
+  const char op2 = cigar[i++];
+  if (op1 == '=' && op2 == 'D' && sequences_match(query_seq, target_seq, query_start, target_start + dlen, (int)n)) {
+    return merge_cigar_ops(std::to_string(dlen) + "D" + std::to_string(n) + "=" + cigar.substr(i));
+  }
+  return cigar;
+}
+
+std::string try_swap_end_pattern(const std::string& cigar, const std::string& query_seq, const std::string& target_seq,
+                                 int64_t query_start, int64_t target_start) {
+  const CigarOps ops = parse_cigar(cigar);
+  if (ops.size() < 2) return cigar;
+  // the reference's backwards parser also requires both ops to carry digits
+  const auto& last = ops[ops.size() - 1];
+  const auto& prev = ops[ops.size() - 2];
+  if (!(prev.second == 'D' && last.second == '=')) return cigar;
+  const int n = last.first, dlen = prev.first;
+  // alignment_end_coords counts only '=' and 'D' (wflign_swizzle.cpp:192-215)
+  int64_t end_q = query_start, end_t = target_start;
+  for (const auto& o : ops) {
+    if (o.second == '=') { end_q += o.first; end_t += o.first; }
+    else if (o.second == 'D') end_t += o.first;
+  }
+  if (!sequences_match(query_seq, target_seq, end_q - n, end_t - n - dlen, n)) return cigar;
+  // byte position where the second-to-last op starts
+  size_t p = cigar.size();
+  for (int k = 0; k < 2; ++k) {
+    --p;  // op char
+    while (p > 0 && is_digit(cigar[p - 1])) --p;
+  }
+  std::string swapped = merge_cigar_ops(cigar.substr(0, p) + std::to_string(n) + "=" + std::to_string(dlen) + "D");
+  if (!verify_eq_del_cigar(swapped, query_seq, target_seq, query_start, target_start)) return cigar;
+  return swapped;
+}
+
+// ---------------------------------------------------------------------------
+// PAF writer
+// ---------------------------------------------------------------------------
+double float2phred(double prob) {
+  if (prob == 1) return 255;
+  const double p = -10 * std::log10(prob);
+  if (p < 0 || p > 255) return 255;
+  return p;
+}
+
+namespace {
+struct CigarStats {
+  uint64_t matches = 0, mismatches = 0, insertions = 0, inserted_bp = 0, deletions = 0, deleted_bp = 0,
+           ref_len = 0, q_len = 0;
+};
+CigarStats cigar_stats(const CigarOps& ops, size_t b, size_t e) {  // process_compressed_cigar, wflign_patch.cpp:226-283
+  CigarStats s;
+  for (size_t i = b; i < e; ++i) {
+    const uint64_t len = (uint64_t)ops[i].first;
+    switch (ops[i].second) {
+      case 'M': case '=': s.matches += len; s.ref_len += len; s.q_len += len; break;
+      case 'X': s.mismatches += len; s.ref_len += len; s.q_len += len; break;
+      case 'I': s.insertions++; s.inserted_bp += len; s.q_len += len; break;
+      case 'D': s.deletions++; s.deleted_bp += len; s.ref_len += len; break;
+      default: break;
+    }
+  }
+  return s;
+}
+}  // namespace
+
+bool write_alignment_paf(std::string& out, const std::string& cigar_str, const std::string& query_name,
+                         uint64_t query_total_length, uint64_t query_offset, uint64_t query_length, bool query_is_rev,
+                         const std::string& target_name, uint64_t target_total_length, uint64_t target_offset,
+                         const PafParams& pp, float mashmap_estimated_identity, int32_t chain_id, int32_t chain_length,
+                         int32_t chain_pos) {
+  if (cigar_str.empty()) return false;
+  const CigarOps ops = parse_cigar(cigar_str);
+  // trim_indels (wflign_patch.cpp:139-223): strip leading / trailing I and D runs, shifting the coordinates
+  size_t b = 0, e = ops.size();
+  uint64_t new_ref_start = target_offset, new_query_start = query_offset;
+  while (b < e && (ops[b].second == 'I' || ops[b].second == 'D')) {
+    if (ops[b].second == 'I') new_query_start += (uint64_t)ops[b].first; else new_ref_start += (uint64_t)ops[b].first;
+    ++b;
+  }
+  if (b < e) while (e > b && (ops[e - 1].second == 'I' || ops[e - 1].second == 'D')) --e;
+  const CigarStats s = cigar_stats(ops, b, e);
+  if (b >= e) return false;
+  const double gap_compressed_identity = (double)s.matches / (double)(s.matches + s.mismatches + s.insertions + s.deletions);
+  const double block_identity = (double)s.matches / (double)(s.matches + s.mismatches + s.inserted_bp + s.deleted_bp);
+  if (!(gap_compressed_identity >= pp.min_identity && s.q_len >= pp.min_alignment_length && block_identity >= pp.min_block_identity))
+    return false;
+  uint64_t q_start, q_end;
+  if (query_is_rev) {
+    q_start = query_offset + (query_length - (new_query_start - query_offset) - s.q_len);
+    q_end = query_offset + (query_length - (new_query_start - query_offset));
+  } else {
+    q_start = new_query_start;
+    q_end = new_query_start + s.q_len;
+  }
+  const uint64_t aln_ref_pos = new_ref_start - target_offset;
+  std::ostringstream os;  // default iostream formatting = the reference's (6 significant digits)
+  os << query_name << "\t" << query_total_length << "\t" << q_start << "\t" << q_end << "\t"
+     << (query_is_rev ? "-" : "+") << "\t" << target_name << "\t" << target_total_length << "\t"
+     << target_offset + aln_ref_pos << "\t" << target_offset + aln_ref_pos + s.ref_len << "\t"
+     << s.matches << "\t" << std::max(s.ref_len, s.q_len) << "\t" << std::round(float2phred(1.0 - block_identity)) << "\t"
+     << "gi:f:" << gap_compressed_identity << "\t" << "bi:f:" << block_identity << "\t"
+     << "md:f:" << mashmap_estimated_identity << "\t";
+  if (chain_length > 0) os << "ch:Z:" << chain_id << "." << chain_length << "." << chain_pos << "\t";  // id.LENGTH.pos, wflign_patch.cpp:2708
+  os << "cg:Z:";
+  for (size_t i = b; i < e; ++i) os << ops[i].first << ops[i].second;
+  os << "\t";
+  out += os.str();
+  return true;
+}
+
+// ---------------------------------------------------------------------------
+// batch pipeline
+// ---------------------------------------------------------------------------
+namespace {
+struct GpuBatch {
+  std::vector<wfm_problem_t> probs;
+  std::vector<wfm_result_t> res;
+  std::vector<char> arena;
+  int run(wfm_handle_t* h, const wfm_penalties_t& pen, BiwfaStats* st) {
+    res.assign(probs.size(), wfm_result_t{});
+    if (probs.empty()) return 0;
+    arena.resize(wfm_align_arena_bytes(probs.data(), probs.size()) + 8);
+    const int rc = wfm_align_batch(h, &pen, probs.data(), probs.size(), res.data(), arena.data(), arena.size());
+    if (rc >= 0 && st) {
+      wfm_stats_t s;
+      if (wfm_get_stats(h, &s) == WFM_OK) { st->cells += s.cells; st->ms_gpu += s.ms_kernels; }
+    }
+    return rc;
+  }
+  std::string cigar(size_t i) const { return compress_ops(arena.data() + res[i].ops_off, res[i].ops_len); }
+};
+}  // namespace
+
+int do_biwfa_alignment_batch(wfm_handle_t* h, std::vector<BiwfaRecord>& recs, const wflign_penalties_t& penalties,
+                             bool disable_chain_patching, const PafParams& pp, BiwfaStats* stats) {
+  const wfm_penalties_t pen{penalties.mismatch, penalties.gap_opening1, penalties.gap_extension1,
+                            penalties.gap_opening2, penalties.gap_extension2};
+  GpuBatch g;
+  // ---- stage 1: main end-to-end BiWFA (wflign.cpp:136-165) ----
+  g.probs.reserve(recs.size());
+  for (const auto& r : recs) {
+    wfm_problem_t p{};
+    p.pattern = r.target; p.plen = (int32_t)r.target_length;
+    p.text = r.query; p.tlen = (int32_t)r.query_length;
+    p.mode = WFM_MODE_END2END_BIWFA;
+    g.probs.push_back(p);
+  }
+  int rc = g.run(h, pen, stats);
+  if (rc < 0) return rc;
+  for (size_t i = 0; i < recs.size(); ++i) {
+    recs[i].ok = (g.res[i].status == 0);  // status != 0: the reference drops the record silently (wflign.cpp:150-152)
+    recs[i].score = g.res[i].score;
+    recs[i].paf.clear();
+    if (recs[i].ok) recs[i].cigar = g.cigar(i);
+    else if (stats) stats->main_failed++;
+  }
+  if (!disable_chain_patching) {
+    // ---- stage 2: head patches (wflign.cpp:241-320) ----
+    std::vector<size_t> owner;
+    std::vector<Erosion> ero;
+    g.probs.clear();
+    for (size_t i = 0; i < recs.size(); ++i) {
+      if (!recs[i].ok) continue;
+      const Erosion e = scan_head_erosion(recs[i].cigar);
+      if (e.query_eroded > 3 || e.target_eroded > 3) {
+        wfm_problem_t p{};
+        p.pattern = recs[i].target; p.plen = (int32_t)e.target_eroded;
+        p.text = recs[i].query; p.tlen = (int32_t)e.query_eroded;
+        p.mode = WFM_MODE_ENDSFREE;
+        p.pattern_begin_free = (int32_t)e.target_eroded; p.pattern_end_free = 0;
+        p.text_begin_free = (int32_t)e.query_eroded; p.text_end_free = 0;
+        g.probs.push_back(p); owner.push_back(i); ero.push_back(e);
+      }
+    }
+    rc = g.run(h, pen, stats);
+    if (rc < 0) return rc;
+    for (size_t j = 0; j < owner.size(); ++j) {
+      if (g.res[j].status != 0) continue;
+      BiwfaRecord& r = recs[owner[j]];
+      std::string head = erode_short_matches_in_cigar(g.cigar(j), 3, true);
+      r.cigar = merge_adjacent_ops(head, r.cigar.substr(ero[j].erode_end_pos));
+      if (stats) stats->head_patches++;
+    }
+    // ---- stage 3: tail patches (wflign.cpp:323-418), on the head-patched CIGAR ----
+    owner.clear(); ero.clear(); g.probs.clear();
+    std::vector<CigarOps> parsed;
+    for (size_t i = 0; i < recs.size(); ++i) {
+      if (!recs[i].ok) continue;
+      CigarOps ops = parse_cigar(recs[i].cigar);
+      const Erosion e = scan_tail_erosion(ops);
+      if (e.query_eroded > 3 || e.target_eroded > 3) {
+        wfm_problem_t p{};
+        p.pattern = recs[i].target + recs[i].target_length - e.target_eroded; p.plen = (int32_t)e.target_eroded;
+        p.text = recs[i].query + recs[i].query_length - e.query_eroded; p.tlen = (int32_t)e.query_eroded;
+        p.mode = WFM_MODE_ENDSFREE;
+        p.pattern_begin_free = 0; p.pattern_end_free = (int32_t)e.target_eroded;
+        p.text_begin_free = 0; p.text_end_free = (int32_t)e.query_eroded;
+        g.probs.push_back(p); owner.push_back(i); ero.push_back(e); parsed.push_back(std::move(ops));
+      }
+    }
+    rc = g.run(h, pen, stats);
+    if (rc < 0) return rc;
+    for (size_t j = 0; j < owner.size(); ++j) {
+      if (g.res[j].status != 0) continue;
+      BiwfaRecord& r = recs[owner[j]];
+      std::string tail = erode_short_matches_in_cigar(g.cigar(j), 3, false);
+      CigarOps keep(parsed[j].begin(), parsed[j].begin() + (long)ero[j].erode_start_idx);
+      r.cigar = merge_adjacent_ops(cigar_to_string(keep), tail);
+      if (stats) stats->tail_patches++;
+    }
+  }
+  // ---- stage 4: swizzle + PAF (wflign.cpp:423-454) ----
+  for (auto& r : recs) {
+    if (!r.ok) continue;
+    const std::string q(r.query, r.query_length);
+    const std::string t(r.target, r.target_avail ? r.target_avail : r.target_length);
+    std::string sw = try_swap_start_pattern(r.cigar, q, t, 0, 0);
+    if (sw != r.cigar) r.cigar = sw;
+    sw = try_swap_end_pattern(r.cigar, q, t, 0, 0);
+    if (sw != r.cigar) r.cigar = sw;
+    write_alignment_paf(r.paf, r.cigar, r.query_name, r.query_total_length, r.query_offset, r.query_length,
+                        r.query_is_rev, r.target_name, r.target_total_length, r.target_offset, pp,
+                        r.mashmap_estimated_identity, r.chain_id, r.chain_length, r.chain_pos);
+  }
+  return 0;
+}
+
+}  // namespace wflign
