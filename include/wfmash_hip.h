@@ -91,6 +91,9 @@ typedef struct {
   uint32_t bp_launches, base_launches;
   uint64_t cells_bp;         /* cells computed by wfa_bp_kernel launches          */
   uint64_t cells_base;       /* cells computed by wfa_base_kernel launches        */
+  uint64_t cells_tile;       /* part of cells_bp computed by wfa_tile_kernel      */
+  double   ms_tile;          /* part of ms_breakpoint spent in wfa_tile_kernel    */
+  uint32_t tile_launches, tile_tasks;
 } wfm_stats_t;
 
 int  wfm_create(int device, wfm_handle_t** out);

@@ -51,7 +51,9 @@ class Stats(C.Structure):
                 ("ms_base", C.c_double), ("ms_total", C.c_double),
                 ("levels", C.c_uint32), ("bp_jobs", C.c_uint32), ("base_jobs", C.c_uint32),
                 ("bp_launches", C.c_uint32), ("base_launches", C.c_uint32),
-                ("cells_bp", C.c_uint64), ("cells_base", C.c_uint64)]
+                ("cells_bp", C.c_uint64), ("cells_base", C.c_uint64),
+                ("cells_tile", C.c_uint64), ("ms_tile", C.c_double),
+                ("tile_launches", C.c_uint32), ("tile_tasks", C.c_uint32)]
 
 
 class Minmer(C.Structure):

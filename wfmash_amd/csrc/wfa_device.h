@@ -30,6 +30,30 @@ struct BpJob {
   int32_t comp_begin, comp_end;
   int32_t width;                       // row stride = round4(pl + tl + 9)
   int32_t koff;                        // column = k + koff (multiple of 4; normally pl + 4)
+  int32_t resume_s;                    // -1: start at score 0; >= 0: both directions resume at this score
+  int32_t fmax0, rmax0;                // running max antidiagonals at resume_s
+  int32_t pad_;
+};
+
+// ---- time-tiled phase 1 (wfa_tile_kernel) ----
+// A block advances every active job by T scores.  A tile owns `core` diagonals of one
+// direction of one job, loads core + 2T columns of the snapshot (scope M rows, e1 rows of
+// I1/D1, e2 rows of I2/D2) into LDS, runs T steps there (trapezoid: the computed region
+// shrinks by one column per side per step) and writes the last `scope` rows of all five
+// components of its core back.  Row ranges are closed-form: score s covers
+// diagonals [max(-pl,-s), min(tl,s)].
+struct TileJob {
+  int64_t p_fwd, t_fwd, p_rev, t_rev;
+  int64_t ring_in, ring_out;           // int32 element offsets of the two snapshot rings
+  int32_t pl, tl;
+  int32_t comp_begin, comp_end;
+  int32_t width, koff;
+  int32_t s0;                          // snapshot score of ring_in
+  int32_t pad_;
+};
+struct TileTask {
+  int32_t job, dir;
+  int32_t core_lo, core_hi;            // inclusive diagonal range owned by this tile
 };
 
 struct BpResult {
@@ -66,6 +90,9 @@ struct BaseResult {
 
 void launch_bp(const uint8_t* seq, int32_t* ring, const BpJob* jobs, BpResult* res, int njobs, int threads,
                DevPen pen, int scope, hipStream_t st);
+void launch_tile_init(const uint8_t* seq, int32_t* ring, const TileJob* jobs, int32_t* mak0, int njobs, hipStream_t st);
+void launch_tile(const uint8_t* seq, int32_t* ring, const TileJob* jobs, const TileTask* tasks, int32_t* mak, int ntasks,
+                 int threads, int T, int Wt, size_t lds_bytes, DevPen pen, int scope, hipStream_t st);
 void launch_base(const uint8_t* seq, int32_t* a32, uint8_t* a8, uint32_t* rle, const BaseJob* jobs, BaseResult* res,
                  int njobs, DevPen pen, hipStream_t st);
 void launch_compact(const uint32_t* rle, const int64_t* off, const int64_t* cap, uint32_t* out, unsigned long long* total,

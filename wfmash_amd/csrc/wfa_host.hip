@@ -29,7 +29,7 @@ using namespace wfm;
 
 constexpr int BIALIGN_FALLBACK_MIN_SCORE = 250;   // WFA2-lib WF_BIALIGN_FALLBACK_MIN_SCORE
 constexpr int BIALIGN_FALLBACK_MIN_LENGTH = 100;  // WFA2-lib WF_BIALIGN_FALLBACK_MIN_LENGTH
-constexpr int SEQ_PAD = 16;
+constexpr int SEQ_PAD = 64;  // extension reads up to 40 bytes past a sub-range end
 
 #define HIPCHK(h, call)                                                                 \
   do {                                                                                  \
@@ -98,6 +98,9 @@ struct wfm_handle {
   DevBuf<uint8_t> base8;     // base: bt
   DevBuf<uint32_t> rle, rle_out;
   DevBuf<BpJob> bpjobs;
+  DevBuf<TileJob> tilejobs;
+  DevBuf<TileTask> tiletasks;
+  DevBuf<int32_t> tilemak;
   DevBuf<BpResult> bpres;
   DevBuf<BaseJob> bsjobs;
   DevBuf<BaseResult> bsres;
@@ -123,7 +126,7 @@ int validate_pen(const wfm_penalties_t* pen, int* scope) {
 }
 
 struct LevelTimer {
-  double bp_ms = 0, base_ms = 0;
+  double bp_ms = 0, base_ms = 0, tile_ms = 0;
 };
 
 // Runs all base jobs of `nodes` (chunked to the memory budget); appends
@@ -224,6 +227,132 @@ int run_base_jobs(wfm_handle* h, wfm_seqset* S, const wfm_penalties_t& pen, cons
   return WFM_OK;
 }
 
+
+struct TileCfg {
+  int T = 64, Wt = 1024, threads = 512;
+  int min_len = 6000, min_score = 512;
+  bool enabled = true;
+};
+
+TileCfg tile_cfg(const wfm_penalties_t& pen, int scope) {
+  TileCfg c;
+  if (const char* e = getenv("WFM_TILE")) c.enabled = atoi(e) != 0;
+  if (const char* e = getenv("WFM_TILE_T")) c.T = atoi(e);
+  if (const char* e = getenv("WFM_TILE_W")) c.Wt = atoi(e);
+  if (const char* e = getenv("WFM_TILE_THREADS")) c.threads = atoi(e);
+  if (const char* e = getenv("WFM_TILE_MIN_LEN")) c.min_len = atoi(e);
+  if (const char* e = getenv("WFM_TILE_MIN_SCORE")) c.min_score = atoi(e);
+  c.T = std::max(c.T, RING);  // the output snapshot needs `scope` rows of the block itself
+  const size_t rows = (size_t)scope + 2 * (pen.e1 + 1) + 2 * (pen.e2 + 1);
+  while ((rows * c.Wt + c.T + 1) * 4 > 160 * 1024 && c.Wt > 4 * c.T) c.Wt -= 64;
+  if (c.Wt < 4 * c.T) c.enabled = false;
+  return c;
+}
+
+// Advances the jobs listed in `tiled` (indices into jobs) in blocks of T scores with the
+// time-tiled kernel until their forward/reverse antidiagonals meet inside a block; then
+// leaves them positioned at the last snapshot for wfa_bp_kernel (resume_s/fmax0/rmax0/ring_off).
+int run_tiled_phase(wfm_handle* h, wfm_seqset* S, const DevPen& dp, int scope, const TileCfg& cfg,
+                    std::vector<BpJob>& jobs, const std::vector<int>& tiled, const std::vector<int64_t>& ring2,
+                    double& tile_ms, uint64_t& tile_cells, uint32_t level) {
+  const size_t n = tiled.size();
+  if (n == 0) return WFM_OK;
+  const int T = cfg.T, core = cfg.Wt - 2 * cfg.T;
+  std::vector<TileJob> tj(n);
+  std::vector<int> fmax(n, 0), rmax(n, 0);
+  std::vector<char> active(n, 1);
+  for (size_t i = 0; i < n; ++i) {
+    const BpJob& j = jobs[(size_t)tiled[i]];
+    TileJob& t = tj[i];
+    t.p_fwd = j.p_fwd; t.t_fwd = j.t_fwd; t.p_rev = j.p_rev; t.t_rev = j.t_rev;
+    t.ring_in = j.ring_off; t.ring_out = ring2[i];
+    t.pl = j.pl; t.tl = j.tl; t.comp_begin = j.comp_begin; t.comp_end = j.comp_end;
+    t.width = j.width; t.koff = j.koff; t.s0 = 0; t.pad_ = 0;
+  }
+  if (h->tilejobs.ensure(n) || h->tilemak.ensure(n * 2 * (size_t)std::max(T, 2))) { h->err = "out of device memory (tiles)"; return WFM_E_NOMEM; }
+  HIPCHK(h, hipMemcpyAsync(h->tilejobs.p, tj.data(), n * sizeof(TileJob), hipMemcpyHostToDevice, h->stream));
+  launch_tile_init(S->d_seq, h->ring.p, h->tilejobs.p, h->tilemak.p, (int)n, h->stream);
+  HIPCHK(h, hipGetLastError());
+  std::vector<int32_t> mak(n * 2 * (size_t)std::max(T, 2));
+  HIPCHK(h, hipMemcpyAsync(mak.data(), h->tilemak.p, n * 4 * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  size_t n_active = 0;
+  for (size_t i = 0; i < n; ++i) {
+    fmax[i] = mak[(i * 2 + 0) * 2]; rmax[i] = mak[(i * 2 + 1) * 2];
+    const bool ended = mak[(i * 2 + 0) * 2 + 1] || mak[(i * 2 + 1) * 2 + 1];
+    const int A = tj[i].pl + tj[i].tl - 1;
+    if (ended || fmax[i] + rmax[i] >= A) active[i] = 0;  // wfa_bp_kernel handles it from score 0
+    n_active += active[i];
+  }
+  const size_t lds = ((size_t)(scope + 2 * (dp.e1 + 1) + 2 * (dp.e2 + 1)) * cfg.Wt + T + 1) * 4;
+  std::vector<TileTask> tasks;
+  uint32_t blocks = 0;
+  while (n_active) {
+    tasks.clear();
+    for (size_t i = 0; i < n; ++i) {
+      if (!active[i]) continue;
+      const int s1 = tj[i].s0 + T;
+      const int L = std::max(-tj[i].pl, -s1), R = std::min(tj[i].tl, s1);
+      for (int d = 0; d < 2; ++d)
+        for (int c = L; c <= R; c += core) tasks.push_back(TileTask{(int32_t)i, d, c, std::min(R, c + core - 1)});
+      for (int t = 1; t <= T; ++t) {
+        const int sc = tj[i].s0 + t;
+        tile_cells += 2ull * (uint64_t)(std::min(tj[i].tl, sc) - std::max(-tj[i].pl, -sc) + 1);
+      }
+    }
+    if (h->tiletasks.ensure(tasks.size())) { h->err = "out of device memory (tile tasks)"; return WFM_E_NOMEM; }
+    HIPCHK(h, hipMemcpyAsync(h->tilejobs.p, tj.data(), n * sizeof(TileJob), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->tiletasks.p, tasks.data(), tasks.size() * sizeof(TileTask), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemsetAsync(h->tilemak.p, 0, n * 2 * (size_t)T * sizeof(int32_t), h->stream));
+    HIPCHK(h, hipEventRecord(h->ev0, h->stream));
+    launch_tile(S->d_seq, h->ring.p, h->tilejobs.p, h->tiletasks.p, h->tilemak.p, (int)tasks.size(), cfg.threads, T, cfg.Wt, lds, dp, scope, h->stream);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipEventRecord(h->ev1, h->stream));
+    HIPCHK(h, hipMemcpyAsync(mak.data(), h->tilemak.p, n * 2 * (size_t)T * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    float ms = 0;
+    HIPCHK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    tile_ms += ms;
+    ++blocks;
+#ifdef WFM_PROFILE_SECTIONS
+    if (blocks % 32 == 1) { long long sc[8]; wfm::read_sections(sc); fprintf(stderr, "[wfm] tile block %u (%zu tasks, %.3f ms): block0 thread0 cycles: lds+compute %lld, extend %lld | step body %lld, barrier wait %lld | total steps loop %lld\n", blocks, tasks.size(), ms, sc[0], sc[1], sc[2], sc[3], sc[5]); }
+#endif
+    h->stats.tile_launches++;
+    h->stats.tile_tasks += (uint32_t)tasks.size();
+    for (size_t i = 0; i < n; ++i) {
+      if (!active[i]) continue;
+      const int A = tj[i].pl + tj[i].tl - 1;
+      const int32_t* mf = &mak[(i * 2 + 0) * (size_t)T];
+      const int32_t* mr = &mak[(i * 2 + 1) * (size_t)T];
+      int fm = fmax[i], rm = rmax[i];
+      bool term = false;
+      // replay of the alternating forward / reverse checks of wavefront_bialign_find_breakpoint
+      for (int t = 0; t < T && !term; ++t) {
+        fm = std::max(fm, mf[t]);
+        if (fm + rm >= A) { term = true; break; }
+        rm = std::max(rm, mr[t]);
+        if (fm + rm >= A) term = true;
+      }
+      const int64_t max_steps = (int64_t)(dp.o1 + dp.o2) * 4 + (int64_t)(tj[i].pl + tj[i].tl + 2) * std::max(dp.x, std::max(dp.e1, dp.e2)) * 2 + 256;
+      if (term || 2 * (int64_t)(tj[i].s0 + T) > max_steps) {
+        active[i] = 0; --n_active;  // the block containing the meeting point is redone step by step by wfa_bp_kernel
+      } else {
+        fmax[i] = fm; rmax[i] = rm;
+        tj[i].s0 += T;
+        std::swap(tj[i].ring_in, tj[i].ring_out);
+      }
+    }
+  }
+  for (size_t i = 0; i < n; ++i) {
+    BpJob& j = jobs[(size_t)tiled[i]];
+    j.ring_off = tj[i].ring_in;
+    j.resume_s = tj[i].s0;
+    j.fmax0 = fmax[i]; j.rmax0 = rmax[i];
+  }
+  if (getenv("WFM_DEBUG")) fprintf(stderr, "[wfm] level %u: tiled %zu jobs, %u blocks of %d scores (Wt %d), %.3f ms\n", level, n, blocks, T, cfg.Wt, tile_ms);
+  return WFM_OK;
+}
+
 int align_resident_impl(wfm_handle* h, const wfm_penalties_t* pen, wfm_seqset* S, wfm_result_t* out,
                         char* ops_arena, size_t arena_bytes) {
   int scope = 0;
@@ -269,6 +398,10 @@ int align_resident_impl(wfm_handle* h, const wfm_penalties_t* pen, wfm_seqset* S
 
   LevelTimer tm;
   std::vector<BpJob> jobs;
+  std::vector<int> tiled;
+  std::vector<int64_t> ring2;
+  const TileCfg tcfg = tile_cfg(*pen, scope);
+  uint64_t tile_cells_level = 0;
   std::vector<int32_t> node_of;
   std::vector<BpResult> res;
   uint32_t level = 0;
@@ -283,13 +416,17 @@ int align_resident_impl(wfm_handle* h, const wfm_penalties_t* pen, wfm_seqset* S
       size_t ring_elems = 0;
       size_t i = i0;
       int maxw = 0;
+      tiled.clear(); ring2.clear();
       for (; i < bp_nodes.size(); ++i) {
         const Node& nd = bp_nodes[i];
         const ProbMeta& pm = S->meta[nd.prob];
         size_t width = ((size_t)nd.pl + nd.tl + 9 + 3) & ~(size_t)3;  // columns 4 .. pl+tl+4, 16-byte chunks
         int koff = nd.pl + 4;
         if (getenv("WFM_EXP_WIDTH")) { const size_t w = (size_t)atoll(getenv("WFM_EXP_WIDTH")); if (w < width) { width = w; koff = (int)(w / 2) & ~3; } }
-        const size_t need = width * 2 * 5 * RING;
+        bool tile_it = tcfg.enabled && !getenv("WFM_EXP_WIDTH") && nd.pl + nd.tl >= tcfg.min_len &&
+                             (nd.score_rem == INT_MAX || nd.score_rem >= tcfg.min_score);
+        if (tile_it && width * 2 * 5 * RING * 2 * 4 > h->mem_budget) tile_it = false;  // two snapshot rings do not fit: step-by-step kernel
+        const size_t need = width * 2 * 5 * RING * (tile_it ? 2 : 1);
         if (!jobs.empty() && (ring_elems + need) * 4 > h->mem_budget) break;
         if (need * 4 > h->mem_budget) { prob_status[nd.prob] = WFM_ST_OOM; continue; }
         BpJob j{};
@@ -302,6 +439,8 @@ int align_resident_impl(wfm_handle* h, const wfm_penalties_t* pen, wfm_seqset* S
         j.comp_begin = nd.cb; j.comp_end = nd.ce;
         j.width = (int32_t)width;
         j.koff = koff;
+        j.resume_s = -1; j.fmax0 = 0; j.rmax0 = 0;
+        if (tile_it) { tiled.push_back((int)jobs.size()); ring2.push_back((int64_t)(ring_elems + need / 2)); }
         node_of.push_back((int32_t)i);
         ring_elems += need;
         maxw = std::max(maxw, (int)width);
@@ -311,6 +450,15 @@ int align_resident_impl(wfm_handle* h, const wfm_penalties_t* pen, wfm_seqset* S
       if (!jobs.empty()) {
         if (h->ring.ensure(ring_elems + 16) || h->bpjobs.ensure(jobs.size()) || h->bpres.ensure(jobs.size())) {
           h->err = "out of device memory (ring arena)"; return WFM_E_NOMEM;
+        }
+        {
+          double tms = 0; uint64_t tcells = 0;
+          rc = run_tiled_phase(h, S, dp, scope, tcfg, jobs, tiled, ring2, tms, tcells, level);
+          if (rc != WFM_OK) return rc;
+          tm.bp_ms += tms; tm.tile_ms += tms;
+          h->stats.cells_bp += tcells; h->stats.cells_tile += tcells;
+          for (size_t q = 0; q < tiled.size(); ++q) (void)q;
+          tile_cells_level = tcells;
         }
         // workgroup size: wide wavefronts want all 16 waves of a CU
         int threads = 1024;
@@ -443,9 +591,11 @@ int align_resident_impl(wfm_handle* h, const wfm_penalties_t* pen, wfm_seqset* S
     r.score = (int32_t)score;
     arena_pos = pos;
   }
+  cells_total += h->stats.cells_tile;
   h->stats.cells = cells_total;
   h->stats.bytes_algorithmic = 48ull * cells_total + S->seq_bases;
   h->stats.ms_breakpoint = tm.bp_ms;
+  h->stats.ms_tile = tm.tile_ms;
   h->stats.ms_base = tm.base_ms;
   h->stats.ms_kernels = tm.bp_ms + tm.base_ms;
   h->stats.ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
@@ -483,6 +633,7 @@ void wfm_destroy(wfm_handle_t* h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
   h->ring.release(); h->base32.release(); h->base8.release(); h->rle.release(); h->rle_out.release();
+  h->tilejobs.release(); h->tiletasks.release(); h->tilemak.release();
   h->bpjobs.release(); h->bpres.release(); h->bsjobs.release(); h->bsres.release();
   h->i64a.release(); h->i64b.release(); h->i64c.release(); h->i32a.release(); h->total.release();
   if (h->ev0) (void)hipEventDestroy(h->ev0);

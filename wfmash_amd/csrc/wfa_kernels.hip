@@ -65,9 +65,42 @@ __device__ __forceinline__ int ldk(const Src& r, int k) {
   return (k >= r.lo && k <= r.hi) ? r.p[k] : WF_NULL;
 }
 
+// Extension with at most two dependent memory round trips for runs up to 40 bases:
+// 8 bytes first (ends almost every cell), then 32 bytes at once.
+__device__ __forceinline__ int lce_bounded2(const uint8_t* P, const uint8_t* T, int v, int h, int pl, int tl) {
+  const int maxn = min(pl - v, tl - h);
+  if (maxn <= 0) return 0;
+  const uint8_t* a = P + v;
+  const uint8_t* b = T + h;
+  uint64_t x = load8(a) ^ load8(b);
+  if (x) return min((int)(__builtin_ctzll(x) >> 3), maxn);
+  int n = 8;
+  while (n < maxn) {
+    const uint64_t x0 = load8(a + n) ^ load8(b + n), x1 = load8(a + n + 8) ^ load8(b + n + 8);
+    const uint64_t x2 = load8(a + n + 16) ^ load8(b + n + 16), x3 = load8(a + n + 24) ^ load8(b + n + 24);
+    if (x0) { n += (int)(__builtin_ctzll(x0) >> 3); break; }
+    if (x1) { n += 8 + (int)(__builtin_ctzll(x1) >> 3); break; }
+    if (x2) { n += 16 + (int)(__builtin_ctzll(x2) >> 3); break; }
+    if (x3) { n += 24 + (int)(__builtin_ctzll(x3) >> 3); break; }
+    n += 32;
+  }
+  return min(n, maxn);
+}
+
 __device__ __forceinline__ int valid_or_null(int off, int k, unsigned pl, unsigned tl) {
   const unsigned h = (unsigned)off, v = (unsigned)(off - k);
   return (h <= tl && v <= pl) ? off : WF_NULL;
+}
+
+// wave-64 max of non-negative values with DPP row shifts / broadcasts (result valid in lane 63)
+__device__ __forceinline__ int wave_max_dpp63(int x) {
+  x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false));  // row_shr:1
+  x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false));  // row_shr:2
+  x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false));  // row_shr:4
+  x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false));  // row_shr:8
+  x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false));  // row_bcast:15
+  x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false));  // row_bcast:31
+  return x;
 }
 
 __device__ __forceinline__ int wave_max(int x) {
@@ -257,36 +290,107 @@ __device__ __forceinline__ int bp_compute_row(const BpCtx& c, int dir, int s, in
 // wavefront_bialign_overlap, data-parallel part: for every (i, comp) whose
 // breakpoint score would beat `best`, find the smallest k0 with
 // off0[k0] + off1[k1] >= tl.  Results in s_mink[i*5+comp].
+// Per-row, per-component maximum offset (0 if the row holds no live cell): an upper
+// bound that lets the overlap test skip every (score, component) pair whose rows cannot
+// reach off0 + off1 >= tl anywhere.  Pure pruning: results are unchanged.
+__device__ __forceinline__ void bp_row_maxima(const BpCtx& c, int d, int s, const int (*s_lo)[RING], const int (*s_hi)[RING],
+                                              int (*s_rmax)[RING][5]) {
+  const int lo = s_lo[d][s & RMASK], hi = s_hi[d][s & RMASK];
+  int mx[5] = {0, 0, 0, 0, 0};
+  if (lo <= hi) {
+#pragma unroll
+    for (int cc = 0; cc < 5; ++cc) {
+      const int32_t* r = bp_row(c, d, cc, s);
+      for (int k = lo + (int)threadIdx.x; k <= hi; k += (int)blockDim.x) mx[cc] = max(mx[cc], r[k]);
+    }
+  }
+#pragma unroll
+  for (int cc = 0; cc < 5; ++cc) {
+    const int v = wave_max_dpp63(mx[cc]);
+    if ((threadIdx.x & 63) == 63 && v > 0) atomicMax(&s_rmax[d][s & RMASK][cc], v);
+  }
+}
+
+__device__ __forceinline__ int bp_gap_open(const DevPen& pn, int cc) {
+  return (cc == C_M) ? 0 : ((cc == C_I1 || cc == C_D1) ? pn.o1 : pn.o2);
+}
+
+// wavefront_bialign_overlap, data-parallel part: for every (i, comp) whose
+// breakpoint score would beat `best`, find the smallest k0 with
+// off0[k0] + off1[k1] >= tl.  Results in s_mink[i*5+comp].
 __device__ __forceinline__ void bp_overlap_scan(const BpCtx& c, int d0, int s0, int s1, int best,
-                                                const int (*s_lo)[RING], const int (*s_hi)[RING], int* s_mink, int scope) {
+                                                const int (*s_lo)[RING], const int (*s_hi)[RING], int* s_mink, int scope,
+                                                const int (*s_rmax)[RING][5]) {
   const int d1 = d0 ^ 1;
   const int lo0 = s_lo[d0][s0 & RMASK], hi0 = s_hi[d0][s0 & RMASK];
   if (lo0 > hi0) return;
   const int kinv = c.tl - c.pl;
+  // uniform candidate masks: bit cc of act[i] set iff pair (i, cc) can still produce a better breakpoint
+  unsigned act_lo = 0, act_hi = 0;  // 5 bits per i, i < 32 -> 160 bits in 3 words; keep two 64-bit halves
+  unsigned long long m0 = 0, m1 = 0, m2 = 0;
+  int klo = INT32_MAX, khi = INT32_MIN;
+  for (int i = 0; i < scope; ++i) {
+    const int si = s1 - i;
+    if (si < 0) break;
+    if (s0 + si - c.pen.o2 >= best) continue;
+    const int lo1 = s_lo[d1][si & RMASK], hi1 = s_hi[d1][si & RMASK];
+    if (lo1 > hi1) continue;
+    unsigned bits = 0;
+#pragma unroll
+    for (int cc = 0; cc < 5; ++cc) {
+      if (s0 + si - bp_gap_open(c.pen, cc) >= best) continue;
+      if (s_rmax[d0][s0 & RMASK][cc] + s_rmax[d1][si & RMASK][cc] < c.tl) continue;
+      bits |= 1u << cc;
+    }
+    if (!bits) continue;
+    klo = min(klo, kinv - hi1); khi = max(khi, kinv - lo1);
+    const int sh = i * 5;
+    if (sh < 60) m0 |= (unsigned long long)bits << sh;
+    else if (sh < 120) m1 |= (unsigned long long)bits << (sh - 60);
+    else m2 |= (unsigned long long)bits << (sh - 120);
+  }
+  (void)act_lo; (void)act_hi;
+  if (!(m0 | m1 | m2)) return;
+  klo = max(klo, lo0); khi = min(khi, hi0);
   const int32_t* r0[5];
 #pragma unroll
   for (int cc = 0; cc < 5; ++cc) r0[cc] = bp_row(c, d0, cc, s0);
-  for (int k0 = lo0 + (int)threadIdx.x; k0 <= hi0; k0 += (int)blockDim.x) {
+  for (int k0 = klo + (int)threadIdx.x; k0 <= khi; k0 += (int)blockDim.x) {
     const int k1 = kinv - k0;
     int o0[5];
 #pragma unroll
     for (int cc = 0; cc < 5; ++cc) o0[cc] = r0[cc][k0];
     for (int i = 0; i < scope; ++i) {
+      const int sh = i * 5;
+      const unsigned bits = (unsigned)((sh < 60 ? m0 >> sh : (sh < 120 ? m1 >> (sh - 60) : m2 >> (sh - 120))) & 31ull);
+      if (!bits) continue;
       const int si = s1 - i;
-      if (si < 0) break;
-      if (s0 + si - c.pen.o2 >= best) continue;
       const int lo1 = s_lo[d1][si & RMASK], hi1 = s_hi[d1][si & RMASK];
       if (k1 < lo1 || k1 > hi1) continue;
 #pragma unroll
       for (int cc = 0; cc < 5; ++cc) {
-        const int gop = (cc == C_M) ? 0 : ((cc == C_I1 || cc == C_D1) ? c.pen.o1 : c.pen.o2);
-        if (s0 + si - gop >= best) continue;
+        if (!(bits & (1u << cc))) continue;
         if (o0[cc] < 0) continue;
         const int o1 = bp_row(c, d1, cc, si)[k1];
         if (o0[cc] + o1 >= c.tl) atomicMin(&s_mink[i * 5 + cc], k0);
       }
     }
   }
+}
+
+// Row 0 of one direction (wavefront_unialign_init, end2end): the begin component holds
+// offset 0 at k = 0, M is extended.  Returns 1 if the alignment already ends at score 0.
+__device__ __forceinline__ int bp_init_row0(const BpCtx& c, int d, int cb, int ce, int& mak) {
+  int m0 = WF_NULL;
+  mak = 0;
+  for (int cc = 1; cc < 5; ++cc) bp_row(c, d, cc, 0)[0] = (cc == cb) ? 0 : WF_NULL;
+  if (cb == C_M) {
+    m0 = lce_bounded(c.P[d], c.T[d], 0, 0, c.pl, c.tl);
+    mak = 2 * m0;
+  }
+  bp_row(c, d, C_M, 0)[0] = m0;
+  // termination at score 0 (identical sequences): only possible for M/M forms
+  return (c.pl == c.tl && ce == C_M && m0 >= c.tl) ? 1 : 0;
 }
 
 __global__ __launch_bounds__(1024) void wfa_bp_kernel(const uint8_t* __restrict__ seq, int32_t* __restrict__ ring_arena,
@@ -298,6 +402,7 @@ __global__ __launch_bounds__(1024) void wfa_bp_kernel(const uint8_t* __restrict_
   __shared__ int s_mak[3][2];
   __shared__ int s_mink[RING * 5];
   __shared__ int s_bp[8];  // score, score_fwd, score_rev, k_fwd, off_fwd, comp
+  __shared__ int s_rmax[2][RING][5];
 
   BpCtx c;
   c.P[0] = seq + J.p_fwd; c.T[0] = seq + J.t_fwd;
@@ -311,26 +416,23 @@ __global__ __launch_bounds__(1024) void wfa_bp_kernel(const uint8_t* __restrict_
   const int A = J.pl + J.tl - 1;  // max_antidiagonal
   uint64_t cells = 0;
 
-  // ---- init rows 0 (wavefront_unialign_init, end2end) ----
+  // ---- init rows 0 (wavefront_unialign_init, end2end), or resume from a tiled snapshot ----
   if (tid < 2 * RING) { s_lo[tid / RING][tid % RING] = 1; s_hi[tid / RING][tid % RING] = 0; }
   if (tid < 6) ((int*)s_mak)[tid] = 0;
   __syncthreads();
   int end_reached = 0;
-  if (tid < 2) {
-    const int d = tid;
-    const int cb = d == 0 ? J.comp_begin : J.comp_end;
-    int m0 = WF_NULL, mak = 0;
-    for (int cc = 1; cc < 5; ++cc) bp_row(c, d, cc, 0)[0] = (cc == cb) ? 0 : WF_NULL;
-    if (cb == C_M) {
-      m0 = lce_bounded(c.P[d], c.T[d], 0, 0, c.pl, c.tl);
-      mak = 2 * m0;
+  if (J.resume_s >= 0) {
+    if (tid < 2 * RING) {
+      const int d = tid / RING, sc = J.resume_s - (tid % RING);
+      if (sc >= 0) { s_lo[d][sc & RMASK] = max(-J.pl, -sc); s_hi[d][sc & RMASK] = min(J.tl, sc); }
     }
-    bp_row(c, d, C_M, 0)[0] = m0;
+    if (tid == 0) { s_mak[0][0] = J.fmax0; s_mak[0][1] = J.rmax0; s_bp[6] = 0; s_bp[7] = 0; }
+  } else if (tid < 2) {
+    const int d = tid;
+    int mak = 0;
+    s_bp[6 + d] = bp_init_row0(c, d, d == 0 ? J.comp_begin : J.comp_end, d == 0 ? J.comp_end : J.comp_begin, mak);
     s_lo[d][0] = 0; s_hi[d][0] = 0;
     s_mak[0][d] = mak;
-    // termination at score 0 (identical sequences): only possible for M/M forms
-    const int ce = d == 0 ? J.comp_end : J.comp_begin;
-    if (c.pl == c.tl && ((ce == C_M && m0 >= c.tl))) s_bp[6 + d] = 1; else s_bp[6 + d] = 0;
   }
   __syncthreads();
   int fmax = s_mak[0][0], rmax = s_mak[0][1];
@@ -343,9 +445,9 @@ __global__ __launch_bounds__(1024) void wfa_bp_kernel(const uint8_t* __restrict_
     }
     return;
   }
-  cells = 2;
+  cells = J.resume_s >= 0 ? 0 : 2;
   const int64_t max_steps = (int64_t)(pen.o1 + pen.o2) * 4 + (int64_t)(J.pl + J.tl + 2) * max(pen.x, max(pen.e1, pen.e2)) * 2 + 256;
-  int sf = 0, sr = 0;
+  int sf = max(J.resume_s, 0), sr = sf;
   int last_fwd = 0;
   int status = 0;
   int buf = 0;
@@ -394,6 +496,14 @@ __global__ __launch_bounds__(1024) void wfa_bp_kernel(const uint8_t* __restrict_
   const int steps_p1 = sf + sr;
   if (status == 0) {
     const int gopen = max(pen.o1, pen.o2);
+    // row maxima of the `scope` newest rows of both directions (phase 1 does not track them)
+    for (int i = tid; i < 2 * RING * 5; i += blockDim.x) ((int*)s_rmax)[i] = 0;
+    __syncthreads();
+    for (int i = 0; i < scope; ++i) {
+      if (sf - i >= 0) bp_row_maxima(c, 0, sf - i, s_lo, s_hi, s_rmax);
+      if (sr - i >= 0) bp_row_maxima(c, 1, sr - i, s_lo, s_hi, s_rmax);
+    }
+    __syncthreads();
     for (;;) {
       int d0;  // direction whose newest wavefront is tested, then the OTHER one advances
       if (last_fwd) {
@@ -412,7 +522,7 @@ __global__ __launch_bounds__(1024) void wfa_bp_kernel(const uint8_t* __restrict_
       if (m0_valid) {
         for (int i = tid; i < RING * 5; i += blockDim.x) s_mink[i] = INT32_MAX;
         __syncthreads();
-        bp_overlap_scan(c, d0, s0, s1, best, s_lo, s_hi, s_mink, scope);
+        bp_overlap_scan(c, d0, s0, s1, best, s_lo, s_hi, s_mink, scope, s_rmax);
         __syncthreads();
         if (tid == 0) {
           int b = best;
@@ -445,8 +555,11 @@ __global__ __launch_bounds__(1024) void wfa_bp_kernel(const uint8_t* __restrict_
       }
       // advance the other direction
       int mak = 0;
+      if (tid < 5) s_rmax[d0 ^ 1][((d0 == 0 ? sr : sf) + 1) & RMASK][tid] = 0;
       if (d0 == 0) { ++sr; cells += (uint64_t)bp_compute_row(c, 1, sr, s_lo, s_hi, mak, sec); last_fwd = 0; }
       else         { ++sf; cells += (uint64_t)bp_compute_row(c, 0, sf, s_lo, s_hi, mak, sec); last_fwd = 1; }
+      __syncthreads();
+      bp_row_maxima(c, d0 ^ 1, d0 == 0 ? sr : sf, s_lo, s_hi, s_rmax);
       __syncthreads();
       if (d0 == 1 && (int64_t)sf + sr > max_steps && best == INT32_MAX) { status = WFM_DEV_UNREACHABLE; break; }
     }
@@ -738,6 +851,172 @@ __global__ __launch_bounds__(256) void rle_compact_kernel(const uint32_t* __rest
 }
 
 // ---------------------------------------------------------------------------
+// ---------------------------------------------------------------------------
+// Time-tiled phase 1 (see TileJob in wfa_device.h)
+// ---------------------------------------------------------------------------
+// unconditional LDS read, range applied by select (every local column k-1..k+1 is inside the tile row)
+__device__ __forceinline__ int sel_rng(int v, int k, int lo, int hi) { return (k >= lo && k <= hi) ? v : WF_NULL; }
+__device__ __forceinline__ int rng_lo(int pl, int s) { return max(-pl, -s); }
+__device__ __forceinline__ int rng_hi(int tl, int s) { return min(tl, s); }
+
+__global__ void wfa_tile_init_kernel(const uint8_t* __restrict__ seq, int32_t* __restrict__ ring_arena,
+                                     const TileJob* __restrict__ jobs, int32_t* __restrict__ mak0, int njobs) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= njobs * 2) return;
+  const TileJob J = jobs[i >> 1];
+  const int d = i & 1;
+  BpCtx c;
+  c.P[0] = seq + J.p_fwd; c.T[0] = seq + J.t_fwd;
+  c.P[1] = seq + J.p_rev; c.T[1] = seq + J.t_rev;
+  c.width = J.width; c.koff = J.koff;
+  c.ring = ring_arena + J.ring_in + c.koff;
+  c.pl = J.pl; c.tl = J.tl;
+  int mak = 0;
+  const int end = bp_init_row0(c, d, d == 0 ? J.comp_begin : J.comp_end, d == 0 ? J.comp_end : J.comp_begin, mak);
+  mak0[i * 2 + 0] = mak;
+  mak0[i * 2 + 1] = end;
+}
+
+// LDS rows: M[scope][Wt], I1[e1+1][Wt], D1[e1+1][Wt], I2[e2+1][Wt], D2[e2+1][Wt], mak[T+1]
+__global__ __launch_bounds__(1024) void wfa_tile_kernel(const uint8_t* __restrict__ seq, int32_t* __restrict__ ring_arena,
+                                                       const TileJob* __restrict__ jobs, const TileTask* __restrict__ tasks,
+                                                       int32_t* __restrict__ mak_out, int T, int Wt, DevPen pen, int scope) {
+  extern __shared__ __attribute__((aligned(16))) int lds[];
+  const TileTask tk = tasks[blockIdx.x];
+  const TileJob J = jobs[tk.job];
+  const int dir = tk.dir, tid = threadIdx.x, NT = blockDim.x;
+  const int n1 = pen.e1 + 1, n2 = pen.e2 + 1;
+  int* sM = lds;
+  int* sI1 = sM + scope * Wt;
+  int* sD1 = sI1 + n1 * Wt;
+  int* sI2 = sD1 + n1 * Wt;
+  int* sD2 = sI2 + n2 * Wt;
+  int* sMak = sD2 + n2 * Wt;
+  const uint8_t* P = seq + (dir == 0 ? J.p_fwd : J.p_rev);
+  const uint8_t* Tx = seq + (dir == 0 ? J.t_fwd : J.t_rev);
+  const int pl = J.pl, tl = J.tl, s0 = J.s0;
+  const unsigned upl = (unsigned)pl, utl = (unsigned)tl;
+  const int kA = tk.core_lo - T;  // diagonal of local column 0
+  const int64_t width = J.width;
+  const int32_t* rin = ring_arena + J.ring_in + J.koff + (int64_t)dir * 5 * RING * width;
+  int32_t* rout = ring_arena + J.ring_out + J.koff + (int64_t)dir * 5 * RING * width;
+  const int ncol = tk.core_hi + T - kA + 1;  // <= Wt
+
+  // ---- load the snapshot (rows <= s0): row loop uniform, columns across threads ----
+  for (int row = 0; row < scope + 2 * pen.e1 + 2 * pen.e2; ++row) {
+    int comp, sc, slot, r = row;
+    int* dst;
+    if (r < scope) { comp = C_M; sc = s0 - r; slot = ((sc % scope) + scope) % scope; dst = sM; }
+    else if ((r -= scope) < pen.e1) { comp = C_I1; sc = s0 - r; slot = ((sc % n1) + n1) % n1; dst = sI1; }
+    else if ((r -= pen.e1) < pen.e1) { comp = C_D1; sc = s0 - r; slot = ((sc % n1) + n1) % n1; dst = sD1; }
+    else if ((r -= pen.e1) < pen.e2) { comp = C_I2; sc = s0 - r; slot = ((sc % n2) + n2) % n2; dst = sI2; }
+    else { r -= pen.e2; comp = C_D2; sc = s0 - r; slot = ((sc % n2) + n2) % n2; dst = sD2; }
+    const int lo = sc >= 0 ? rng_lo(pl, sc) : 1, hi = sc >= 0 ? rng_hi(tl, sc) : 0;
+    const int32_t* src = rin + ((int64_t)(comp * RING + (sc & RMASK))) * width;
+    for (int j = tid; j < Wt; j += NT) {
+      const int k = kA + j;
+      dst[slot * Wt + j] = (j < ncol && k >= lo && k <= hi) ? src[k] : WF_NULL;
+    }
+  }
+  for (int t = tid; t <= T; t += NT) sMak[t] = 0;
+  __syncthreads();
+#ifdef WFM_PROFILE_SECTIONS
+  long long sec[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const long long t_start = clock64();
+#endif
+
+  // ---- T steps inside LDS ----
+  int curM = ((s0 % scope) + scope) % scope, cur1 = ((s0 % n1) + n1) % n1, cur2 = ((s0 % n2) + n2) % n2;
+  for (int t = 1; t <= T; ++t) {
+    const int s = s0 + t;
+    curM = curM + 1 == scope ? 0 : curM + 1;
+    cur1 = cur1 + 1 == n1 ? 0 : cur1 + 1;
+    cur2 = cur2 + 1 == n2 ? 0 : cur2 + 1;
+    const int sx = s - pen.x, so1 = s - pen.o1 - pen.e1, so2 = s - pen.o2 - pen.e2, se1 = s - pen.e1, se2 = s - pen.e2;
+    // closed-form ranges of the source rows (dead rows: lo > hi)
+    const int lx = sx >= 0 ? rng_lo(pl, sx) : 1, hx = sx >= 0 ? rng_hi(tl, sx) : 0;
+    const int l1 = so1 >= 0 ? rng_lo(pl, so1) : 1, h1 = so1 >= 0 ? rng_hi(tl, so1) : 0;
+    const int l2 = so2 >= 0 ? rng_lo(pl, so2) : 1, h2 = so2 >= 0 ? rng_hi(tl, so2) : 0;
+    const int le1 = se1 >= 0 ? rng_lo(pl, se1) : 1, he1 = se1 >= 0 ? rng_hi(tl, se1) : 0;
+    const int le2 = se2 >= 0 ? rng_lo(pl, se2) : 1, he2 = se2 >= 0 ? rng_hi(tl, se2) : 0;
+    // ring slots: (s - d) mod n == cur - d (+ n if negative), all look-backs d < n
+    int qx = curM - pen.x; if (qx < 0) qx += scope;
+    int q1 = curM - pen.o1 - pen.e1; if (q1 < 0) q1 += scope;
+    int q2 = curM - pen.o2 - pen.e2; if (q2 < 0) q2 += scope;
+    int qe1 = cur1 - pen.e1; if (qe1 < 0) qe1 += n1;
+    int qe2 = cur2 - pen.e2; if (qe2 < 0) qe2 += n2;
+    const int* mX = sM + qx * Wt - kA;
+    const int* mO1 = sM + q1 * Wt - kA;
+    const int* mO2 = sM + q2 * Wt - kA;
+    const int* rI1 = sI1 + qe1 * Wt - kA;
+    const int* rD1 = sD1 + qe1 * Wt - kA;
+    const int* rI2 = sI2 + qe2 * Wt - kA;
+    const int* rD2 = sD2 + qe2 * Wt - kA;
+    int* oM = sM + curM * Wt - kA;
+    int* oI1 = sI1 + cur1 * Wt - kA;
+    int* oD1 = sD1 + cur1 * Wt - kA;
+    int* oI2 = sI2 + cur2 * Wt - kA;
+    int* oD2 = sD2 + cur2 * Wt - kA;
+    const int klo = max(kA + t, rng_lo(pl, s)), khi = min(tk.core_hi + T - t, rng_hi(tl, s));
+    const bool stream = (t > T - scope);  // the last `scope` rows of I/D go to the output snapshot
+    int32_t* gI1 = rout + ((int64_t)(C_I1 * RING + (s & RMASK))) * width;
+    int32_t* gI2 = rout + ((int64_t)(C_I2 * RING + (s & RMASK))) * width;
+    int32_t* gD1 = rout + ((int64_t)(C_D1 * RING + (s & RMASK))) * width;
+    int32_t* gD2 = rout + ((int64_t)(C_D2 * RING + (s & RMASK))) * width;
+    int mak = 0;
+    SEC_T(ta);
+    for (int k = klo + tid; k <= khi; k += NT) {
+      SEC_T(t0);
+#define LDSV(p, kk, lo_, hi_) sel_rng((p)[kk], kk, lo_, hi_)
+      const int m1a = LDSV(mO1, k - 1, l1, h1), m1b = LDSV(mO1, k + 1, l1, h1);
+      const int m2a = LDSV(mO2, k - 1, l2, h2), m2b = LDSV(mO2, k + 1, l2, h2);
+      int ins1 = max(m1a, LDSV(rI1, k - 1, le1, he1)) + 1;
+      int ins2 = max(m2a, LDSV(rI2, k - 1, le2, he2)) + 1;
+      int del1 = max(m1b, LDSV(rD1, k + 1, le1, he1));
+      int del2 = max(m2b, LDSV(rD2, k + 1, le2, he2));
+      int mis = LDSV(mX, k, lx, hx) + 1;
+#undef LDSV
+      ins1 = valid_or_null(ins1, k, upl, utl);
+      ins2 = valid_or_null(ins2, k, upl, utl);
+      del1 = valid_or_null(del1, k, upl, utl);
+      del2 = valid_or_null(del2, k, upl, utl);
+      mis = valid_or_null(mis, k, upl, utl);
+      int m = max(imax3(ins1, ins2, mis), max(del1, del2));
+      asm volatile("" :: "v"(m));
+      SEC_T(t1);
+      if (m >= 0) {
+        m += lce_bounded2(P, Tx, m - k, m, pl, tl);
+        mak = max(mak, 2 * m - k);
+      }
+      asm volatile("" :: "v"(m));
+      SEC_T(t2);
+      SEC_ADD(0, t0, t1); SEC_ADD(1, t1, t2);
+      oI1[k] = ins1; oI2[k] = ins2; oD1[k] = del1; oD2[k] = del2; oM[k] = m;
+      if (stream && k >= tk.core_lo && k <= tk.core_hi) { gI1[k] = ins1; gI2[k] = ins2; gD1[k] = del1; gD2[k] = del2; }
+    }
+    mak = wave_max_dpp63(mak);
+    if ((tid & 63) == 63 && mak > 0) atomicMax(&sMak[t], mak);
+    SEC_T(tb);
+    __syncthreads();
+    SEC_T(tc);
+    SEC_ADD(2, ta, tb); SEC_ADD(3, tb, tc);
+  }
+#ifdef WFM_PROFILE_SECTIONS
+  if (tid == 0 && blockIdx.x == 0) { g_sec[0] = sec[0]; g_sec[1] = sec[1]; g_sec[2] = sec[2]; g_sec[3] = sec[3]; g_sec[4] = t_start - 0; g_sec[5] = clock64() - t_start; g_sec[6] = T; }
+#endif
+  // ---- write the last `scope` M rows of the core, and the per-step antidiagonal maxima ----
+  const int ncore = tk.core_hi - tk.core_lo + 1;
+  for (int idx = tid; idx < scope * ncore; idx += NT) {
+    const int r = idx / ncore;
+    const int k = tk.core_lo + (idx - r * ncore);
+    const int sc = s0 + T - r;
+    if (sc < 0 || k < rng_lo(pl, sc) || k > rng_hi(tl, sc)) continue;
+    rout[((int64_t)(C_M * RING + (sc & RMASK))) * width + k] = sM[(sc % scope) * Wt + (k - kA)];
+  }
+  int32_t* mk = mak_out + ((int64_t)tk.job * 2 + dir) * T;
+  for (int t = 1 + tid; t <= T; t += NT) if (sMak[t] > 0) atomicMax(&mk[t - 1], sMak[t]);
+}
+
 #ifdef WFM_PROFILE_SECTIONS
 void read_sections(long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sec), sizeof(long long) * 8); }
 #endif
@@ -746,6 +1025,18 @@ void read_sections(long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g
 void launch_bp(const uint8_t* seq, int32_t* ring, const BpJob* jobs, BpResult* res, int njobs, int threads,
                DevPen pen, int scope, hipStream_t st) {
   hipLaunchKernelGGL(wfa_bp_kernel, dim3(njobs), dim3(threads), 0, st, seq, ring, jobs, res, pen, scope);
+}
+void launch_tile_init(const uint8_t* seq, int32_t* ring, const TileJob* jobs, int32_t* mak0, int njobs, hipStream_t st) {
+  hipLaunchKernelGGL(wfa_tile_init_kernel, dim3((njobs * 2 + 63) / 64), dim3(64), 0, st, seq, ring, jobs, mak0, njobs);
+}
+void launch_tile(const uint8_t* seq, int32_t* ring, const TileJob* jobs, const TileTask* tasks, int32_t* mak, int ntasks,
+                 int threads, int T, int Wt, size_t lds_bytes, DevPen pen, int scope, hipStream_t st) {
+  static size_t configured = 0;
+  if (lds_bytes > configured) {
+    (void)hipFuncSetAttribute((const void*)wfa_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    configured = lds_bytes;
+  }
+  hipLaunchKernelGGL(wfa_tile_kernel, dim3(ntasks), dim3(threads), lds_bytes, st, seq, ring, jobs, tasks, mak, T, Wt, pen, scope);
 }
 void launch_base(const uint8_t* seq, int32_t* a32, uint8_t* a8, uint32_t* rle, const BaseJob* jobs, BaseResult* res,
                  int njobs, DevPen pen, hipStream_t st) {
