@@ -161,3 +161,29 @@ def test_repeated_calls_reuse_handle(gpu, oracle):
     a = gpu.align(items)
     b = gpu.align(items)
     assert [r.ops for r in a] == [r.ops for r in b]
+
+
+def test_tiled_kernels_agree_with_step_kernel(oracle, monkeypatch):
+    """Phase 1 has three implementations (step kernel, LDS time tiles, register time tiles).
+    On multi-tile wavefronts (C3-sized pairs) all three must give identical op strings, and
+    those must be optimal (score == oracle).  Regression for the 26-row snapshot depth."""
+    pairs = synth.pairs("C3", n_pairs=24)[8:24]
+    got = {}
+    for name, env in (("step", {"WFM_TILE": "0"}), ("lds", {"WFM_TILE_REG": "0"}), ("reg", {}),
+                      ("reg_small", {"WFM_TILE_THREADS": "256", "WFM_TILE_T": "32"})):
+        for k in ("WFM_TILE", "WFM_TILE_REG", "WFM_TILE_THREADS", "WFM_TILE_T"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        h = capi.Handle(0)
+        try:
+            got[name] = h.align(pairs)
+        finally:
+            h.close()
+    for name in ("lds", "reg", "reg_small"):
+        bad = [i for i in range(len(pairs)) if got[name][i].ops != got["step"][i].ops]
+        assert not bad, (name, bad)
+    ops_cpu, scores, _, failed = oracle.align_batch_biwfa([p for p, _ in pairs[:4]], [q for _, q in pairs[:4]])
+    assert failed == 0
+    for i in range(4):
+        assert got["reg"][i].ops == ops_cpu[i]

@@ -232,6 +232,8 @@ struct TileCfg {
   int T = 64, Wt = 1024, threads = 512;
   int min_len = 6000, min_score = 512;
   bool enabled = true;
+  bool reg = false;  // register-resident tile kernel (default penalty lags only)
+  int C = 2;
 };
 
 TileCfg tile_cfg(const wfm_penalties_t& pen, int scope) {
@@ -243,6 +245,14 @@ TileCfg tile_cfg(const wfm_penalties_t& pen, int scope) {
   if (const char* e = getenv("WFM_TILE_MIN_LEN")) c.min_len = atoi(e);
   if (const char* e = getenv("WFM_TILE_MIN_SCORE")) c.min_score = atoi(e);
   c.T = std::max(c.T, RING);  // the output snapshot needs `scope` rows of the block itself
+  const bool dflt = pen.x == 5 && pen.o1 + pen.e1 == 10 && pen.o2 + pen.e2 == 25 && pen.e1 == 2 && pen.e2 == 1;
+  c.reg = dflt && !(getenv("WFM_TILE_REG") && atoi(getenv("WFM_TILE_REG")) == 0);
+  if (c.reg) {
+    if (!getenv("WFM_TILE_THREADS")) c.threads = 1024;
+    if (const char* e = getenv("WFM_TILE_C")) c.C = atoi(e) == 4 ? 4 : 2;
+    c.Wt = c.threads * c.C;
+    return c;
+  }
   const size_t rows = (size_t)scope + 2 * (pen.e1 + 1) + 2 * (pen.e2 + 1);
   while ((rows * c.Wt + c.T + 1) * 4 > 160 * 1024 && c.Wt > 4 * c.T) c.Wt -= 64;
   if (c.Wt < 4 * c.T) c.enabled = false;
@@ -305,7 +315,8 @@ int run_tiled_phase(wfm_handle* h, wfm_seqset* S, const DevPen& dp, int scope, c
     HIPCHK(h, hipMemcpyAsync(h->tiletasks.p, tasks.data(), tasks.size() * sizeof(TileTask), hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemsetAsync(h->tilemak.p, 0, n * 2 * (size_t)T * sizeof(int32_t), h->stream));
     HIPCHK(h, hipEventRecord(h->ev0, h->stream));
-    launch_tile(S->d_seq, h->ring.p, h->tilejobs.p, h->tiletasks.p, h->tilemak.p, (int)tasks.size(), cfg.threads, T, cfg.Wt, lds, dp, scope, h->stream);
+    if (cfg.reg) launch_tile_reg(S->d_seq, h->ring.p, h->tilejobs.p, h->tiletasks.p, h->tilemak.p, (int)tasks.size(), cfg.threads, T, cfg.C, h->stream);
+    else launch_tile(S->d_seq, h->ring.p, h->tilejobs.p, h->tiletasks.p, h->tilemak.p, (int)tasks.size(), cfg.threads, T, cfg.Wt, lds, dp, scope, h->stream);
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipEventRecord(h->ev1, h->stream));
     HIPCHK(h, hipMemcpyAsync(mak.data(), h->tilemak.p, n * 2 * (size_t)T * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
@@ -315,7 +326,7 @@ int run_tiled_phase(wfm_handle* h, wfm_seqset* S, const DevPen& dp, int scope, c
     tile_ms += ms;
     ++blocks;
 #ifdef WFM_PROFILE_SECTIONS
-    if (blocks % 32 == 1) { long long sc[8]; wfm::read_sections(sc); fprintf(stderr, "[wfm] tile block %u (%zu tasks, %.3f ms): block0 thread0 cycles: lds+compute %lld, extend %lld | step body %lld, barrier wait %lld | total steps loop %lld\n", blocks, tasks.size(), ms, sc[0], sc[1], sc[2], sc[3], sc[5]); }
+    if (blocks % 32 == 1) { long long sc[8]; wfm::read_sections(sc); fprintf(stderr, "[wfm] tile block %u (%zu tasks, %.3f ms): mid block thread512 cycles: lds+compute %lld, extend %lld, writes+stream %lld | setup %lld, reduce %lld, body(after setup) %lld, barrier wait %lld | total %lld\n", blocks, tasks.size(), ms, sc[0], sc[1], sc[5], sc[4], sc[6], sc[2], sc[3], sc[7]); }
 #endif
     h->stats.tile_launches++;
     h->stats.tile_tasks += (uint32_t)tasks.size();

@@ -928,6 +928,7 @@ __global__ __launch_bounds__(1024) void wfa_tile_kernel(const uint8_t* __restric
   // ---- T steps inside LDS ----
   int curM = ((s0 % scope) + scope) % scope, cur1 = ((s0 % n1) + n1) % n1, cur2 = ((s0 % n2) + n2) % n2;
   for (int t = 1; t <= T; ++t) {
+    SEC_T(tz);
     const int s = s0 + t;
     curM = curM + 1 == scope ? 0 : curM + 1;
     cur1 = cur1 + 1 == n1 ? 0 : cur1 + 1;
@@ -965,6 +966,7 @@ __global__ __launch_bounds__(1024) void wfa_tile_kernel(const uint8_t* __restric
     int32_t* gD2 = rout + ((int64_t)(C_D2 * RING + (s & RMASK))) * width;
     int mak = 0;
     SEC_T(ta);
+    SEC_ADD(4, tz, ta);
     for (int k = klo + tid; k <= khi; k += NT) {
       SEC_T(t0);
 #define LDSV(p, kk, lo_, hi_) sel_rng((p)[kk], kk, lo_, hi_)
@@ -993,16 +995,19 @@ __global__ __launch_bounds__(1024) void wfa_tile_kernel(const uint8_t* __restric
       SEC_ADD(0, t0, t1); SEC_ADD(1, t1, t2);
       oI1[k] = ins1; oI2[k] = ins2; oD1[k] = del1; oD2[k] = del2; oM[k] = m;
       if (stream && k >= tk.core_lo && k <= tk.core_hi) { gI1[k] = ins1; gI2[k] = ins2; gD1[k] = del1; gD2[k] = del2; }
+      SEC_T(t3);
+      SEC_ADD(5, t2, t3);
     }
+    SEC_T(td);
     mak = wave_max_dpp63(mak);
     if ((tid & 63) == 63 && mak > 0) atomicMax(&sMak[t], mak);
     SEC_T(tb);
     __syncthreads();
     SEC_T(tc);
-    SEC_ADD(2, ta, tb); SEC_ADD(3, tb, tc);
+    SEC_ADD(2, ta, tb); SEC_ADD(3, tb, tc); SEC_ADD(6, td, tb);
   }
 #ifdef WFM_PROFILE_SECTIONS
-  if (tid == 0 && blockIdx.x == 0) { g_sec[0] = sec[0]; g_sec[1] = sec[1]; g_sec[2] = sec[2]; g_sec[3] = sec[3]; g_sec[4] = t_start - 0; g_sec[5] = clock64() - t_start; g_sec[6] = T; }
+  if (tid == 256 && blockIdx.x == gridDim.x / 2) { for (int q = 0; q < 7; ++q) g_sec[q] = sec[q]; g_sec[7] = clock64() - t_start; }
 #endif
   // ---- write the last `scope` M rows of the core, and the per-step antidiagonal maxima ----
   const int ncore = tk.core_hi - tk.core_lo + 1;
@@ -1015,6 +1020,181 @@ __global__ __launch_bounds__(1024) void wfa_tile_kernel(const uint8_t* __restric
   }
   int32_t* mk = mak_out + ((int64_t)tk.job * 2 + dir) * T;
   for (int t = 1 + tid; t <= T; t += NT) if (sMak[t] > 0) atomicMax(&mk[t - 1], sMak[t]);
+}
+
+// ---------------------------------------------------------------------------
+// Register-resident time tile (default penalty lags only): every thread owns C consecutive
+// diagonals; the M history is a 25-deep register delay line, I/D keep e1 / e2 rows;
+// left/right neighbours come from wave shuffles, wave edges go through a tiny LDS mailbox.
+// Same contract as wfa_tile_kernel (snapshot in -> T steps -> snapshot out + per-step maxima).
+// ---------------------------------------------------------------------------
+template <int C, int LX, int LA, int LB, int E1, int E2>
+__global__ __launch_bounds__(1024) void wfa_tile_reg_kernel(const uint8_t* __restrict__ seq, int32_t* __restrict__ ring_arena,
+                                                           const TileJob* __restrict__ jobs, const TileTask* __restrict__ tasks,
+                                                           int32_t* __restrict__ mak_out, int T) {
+  constexpr int H = LB + 1;  // delay-line depth = score scope: the output snapshot must hold rows s_end-LB .. s_end
+                             // (the overlap test of the step kernel looks LB rows behind the resume score)
+  static_assert(LX <= LB && LA <= LB && E1 == 2 && E2 == 1, "lags");
+  __shared__ int s_edge[2][16][2][4];  // [parity][wave][0: lane63 -> next wave, 1: lane0 -> previous wave][value]
+  extern __shared__ __attribute__((aligned(16))) int s_makr[];  // [T + 1]
+  const TileTask tk = tasks[blockIdx.x];
+  const TileJob J = jobs[tk.job];
+  const int dir = tk.dir, tid = threadIdx.x, NT = blockDim.x, lane = tid & 63, wv = tid >> 6, nw = NT >> 6;
+  const uint8_t* P = seq + (dir == 0 ? J.p_fwd : J.p_rev);
+  const uint8_t* Tx = seq + (dir == 0 ? J.t_fwd : J.t_rev);
+  const int pl = J.pl, tl = J.tl, s0 = J.s0;
+  const int kA = tk.core_lo - T;
+  const int k0 = kA + tid * C;  // first diagonal of this thread
+  const int64_t width = J.width;
+  const int32_t* rin = ring_arena + J.ring_in + J.koff + (int64_t)dir * 5 * RING * width;
+  int32_t* rout = ring_arena + J.ring_out + J.koff + (int64_t)dir * 5 * RING * width;
+  const int kmax = tk.core_hi + T;  // last diagonal of the tile
+
+  int Mh[C][H];       // Mh[c][d] = M[s-1-d][k0+c]
+  int I1h[C][E1], D1h[C][E1], I2h[C], D2h[C];
+  // ---- snapshot load (rows <= s0), column-blocked ----
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    const int k = k0 + c;
+    const bool kin = k <= kmax;
+#pragma unroll
+    for (int d = 0; d < H; ++d) {
+      const int sc = s0 - d;
+      Mh[c][d] = (kin && sc >= 0 && k >= rng_lo(pl, sc) && k <= rng_hi(tl, sc)) ? rin[((int64_t)(C_M * RING + (sc & RMASK))) * width + k] : WF_NULL;
+    }
+#pragma unroll
+    for (int d = 0; d < E1; ++d) {
+      const int sc = s0 - d;
+      const bool ok = kin && sc >= 0 && k >= rng_lo(pl, sc) && k <= rng_hi(tl, sc);
+      I1h[c][d] = ok ? rin[((int64_t)(C_I1 * RING + (sc & RMASK))) * width + k] : WF_NULL;
+      D1h[c][d] = ok ? rin[((int64_t)(C_D1 * RING + (sc & RMASK))) * width + k] : WF_NULL;
+    }
+    {
+      const bool ok = kin && s0 >= 0 && k >= rng_lo(pl, s0) && k <= rng_hi(tl, s0);
+      I2h[c] = ok ? rin[((int64_t)(C_I2 * RING + (s0 & RMASK))) * width + k] : WF_NULL;
+      D2h[c] = ok ? rin[((int64_t)(C_D2 * RING + (s0 & RMASK))) * width + k] : WF_NULL;
+    }
+  }
+  for (int t = tid; t <= T; t += NT) s_makr[t] = 0;
+  const unsigned upl = (unsigned)pl, utl = (unsigned)tl;
+
+  for (int t = 1; t <= T; ++t) {
+    const int s = s0 + t;
+    const int par = t & 1;
+    // publish the wave-edge history values needed by the neighbouring waves in this step
+    if (lane == 63) { int* e = s_edge[par][wv][0]; e[0] = Mh[C - 1][LA - 1]; e[1] = Mh[C - 1][LB - 1]; e[2] = I1h[C - 1][E1 - 1]; e[3] = I2h[C - 1]; }
+    if (lane == 0)  { int* e = s_edge[par][wv][1]; e[0] = Mh[0][LA - 1];     e[1] = Mh[0][LB - 1];     e[2] = D1h[0][E1 - 1];     e[3] = D2h[0]; }
+    __syncthreads();
+    // left neighbour (k0 - 1) and right neighbour (k0 + C) values
+    int lM10 = __shfl_up(Mh[C - 1][LA - 1], 1, 64), lM25 = __shfl_up(Mh[C - 1][LB - 1], 1, 64);
+    int lI1 = __shfl_up(I1h[C - 1][E1 - 1], 1, 64), lI2 = __shfl_up(I2h[C - 1], 1, 64);
+    int rM10 = __shfl_down(Mh[0][LA - 1], 1, 64), rM25 = __shfl_down(Mh[0][LB - 1], 1, 64);
+    int rD1 = __shfl_down(D1h[0][E1 - 1], 1, 64), rD2 = __shfl_down(D2h[0], 1, 64);
+    if (lane == 0) {
+      if (wv > 0) { const int* e = s_edge[par][wv - 1][0]; lM10 = e[0]; lM25 = e[1]; lI1 = e[2]; lI2 = e[3]; }
+      else { lM10 = lM25 = lI1 = lI2 = WF_NULL; }
+    }
+    if (lane == 63) {
+      if (wv + 1 < nw) { const int* e = s_edge[par][wv + 1][1]; rM10 = e[0]; rM25 = e[1]; rD1 = e[2]; rD2 = e[3]; }
+      else { rM10 = rM25 = rD1 = rD2 = WF_NULL; }
+    }
+    // closed-form ranges of the source rows
+    const int sx = s - LX, sa = s - LA, sb = s - LB, se1 = s - E1, se2 = s - E2;
+    const int lx = sx >= 0 ? rng_lo(pl, sx) : 1, hx = sx >= 0 ? rng_hi(tl, sx) : 0;
+    const int la = sa >= 0 ? rng_lo(pl, sa) : 1, ha = sa >= 0 ? rng_hi(tl, sa) : 0;
+    const int lb = sb >= 0 ? rng_lo(pl, sb) : 1, hb = sb >= 0 ? rng_hi(tl, sb) : 0;
+    const int le1 = se1 >= 0 ? rng_lo(pl, se1) : 1, he1 = se1 >= 0 ? rng_hi(tl, se1) : 0;
+    const int le2 = se2 >= 0 ? rng_lo(pl, se2) : 1, he2 = se2 >= 0 ? rng_hi(tl, se2) : 0;
+    int nM[C], nI1[C], nI2[C], nD1[C], nD2[C];
+    int mak = 0;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      const int k = k0 + c;
+      const int a10 = c == 0 ? lM10 : Mh[c - 1][LA - 1], b10 = c == C - 1 ? rM10 : Mh[c + 1][LA - 1];
+      const int a25 = c == 0 ? lM25 : Mh[c - 1][LB - 1], b25 = c == C - 1 ? rM25 : Mh[c + 1][LB - 1];
+      const int i1 = c == 0 ? lI1 : I1h[c - 1][E1 - 1], d1 = c == C - 1 ? rD1 : D1h[c + 1][E1 - 1];
+      const int i2 = c == 0 ? lI2 : I2h[c - 1], d2 = c == C - 1 ? rD2 : D2h[c + 1];
+      int ins1 = max(sel_rng(a10, k - 1, la, ha), sel_rng(i1, k - 1, le1, he1)) + 1;
+      int ins2 = max(sel_rng(a25, k - 1, lb, hb), sel_rng(i2, k - 1, le2, he2)) + 1;
+      int del1 = max(sel_rng(b10, k + 1, la, ha), sel_rng(d1, k + 1, le1, he1));
+      int del2 = max(sel_rng(b25, k + 1, lb, hb), sel_rng(d2, k + 1, le2, he2));
+      int mis = sel_rng(Mh[c][LX - 1], k, lx, hx) + 1;
+      ins1 = valid_or_null(ins1, k, upl, utl);
+      ins2 = valid_or_null(ins2, k, upl, utl);
+      del1 = valid_or_null(del1, k, upl, utl);
+      del2 = valid_or_null(del2, k, upl, utl);
+      mis = valid_or_null(mis, k, upl, utl);
+      nI1[c] = ins1; nI2[c] = ins2; nD1[c] = del1; nD2[c] = del2;
+      nM[c] = max(imax3(ins1, ins2, mis), max(del1, del2));
+    }
+    // extension: first 8 bases of all C cells in flight together
+    uint64_t x[C];
+    int maxn[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      const int k = k0 + c, m = nM[c];
+      x[c] = 0; maxn[c] = 0;
+      if (m >= 0) {
+        maxn[c] = min(pl - (m - k), tl - m);
+        x[c] = load8(P + (m - k)) ^ load8(Tx + m);
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      const int k = k0 + c;
+      int m = nM[c];
+      if (m >= 0) {
+        int n;
+        if (x[c]) n = (int)(__builtin_ctzll(x[c]) >> 3);
+        else n = 8 + lce_bounded2(P, Tx, m - k + 8, m + 8, pl, tl);
+        m += min(n, maxn[c]);
+        nM[c] = m;
+        if (k >= tk.core_lo && k <= tk.core_hi && k >= rng_lo(pl, s) && k <= rng_hi(tl, s)) mak = max(mak, 2 * m - k);
+      }
+    }
+    // stream the last H rows of I/D of the core to the output snapshot
+    if (t > T - H) {
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        const int k = k0 + c;
+        if (k >= tk.core_lo && k <= tk.core_hi && k >= rng_lo(pl, s) && k <= rng_hi(tl, s)) {
+          const int64_t ro = ((int64_t)(s & RMASK)) * width + k;
+          rout[(int64_t)C_I1 * RING * width + ro] = nI1[c];
+          rout[(int64_t)C_I2 * RING * width + ro] = nI2[c];
+          rout[(int64_t)C_D1 * RING * width + ro] = nD1[c];
+          rout[(int64_t)C_D2 * RING * width + ro] = nD2[c];
+        }
+      }
+    }
+    // advance the delay lines
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+#pragma unroll
+      for (int d = H - 1; d > 0; --d) Mh[c][d] = Mh[c][d - 1];
+      Mh[c][0] = nM[c];
+#pragma unroll
+      for (int d = E1 - 1; d > 0; --d) { I1h[c][d] = I1h[c][d - 1]; D1h[c][d] = D1h[c][d - 1]; }
+      I1h[c][0] = nI1[c]; D1h[c][0] = nD1[c];
+      I2h[c] = nI2[c]; D2h[c] = nD2[c];
+    }
+    mak = wave_max_dpp63(mak);
+    if (lane == 63 && mak > 0) atomicMax(&s_makr[t], mak);
+  }
+  // ---- output snapshot: the newest H rows of M for the core ----
+  const int s_end = s0 + T;
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    const int k = k0 + c;
+    if (k < tk.core_lo || k > tk.core_hi) continue;
+#pragma unroll
+    for (int d = 0; d < H; ++d) {
+      const int sc = s_end - d;
+      if (sc >= 0 && k >= rng_lo(pl, sc) && k <= rng_hi(tl, sc)) rout[((int64_t)(C_M * RING + (sc & RMASK))) * width + k] = Mh[c][d];
+    }
+  }
+  __syncthreads();
+  int32_t* mk = mak_out + ((int64_t)tk.job * 2 + dir) * T;
+  for (int t = 1 + tid; t <= T; t += NT) if (s_makr[t] > 0) atomicMax(&mk[t - 1], s_makr[t]);
 }
 
 #ifdef WFM_PROFILE_SECTIONS
@@ -1037,6 +1217,12 @@ void launch_tile(const uint8_t* seq, int32_t* ring, const TileJob* jobs, const T
     configured = lds_bytes;
   }
   hipLaunchKernelGGL(wfa_tile_kernel, dim3(ntasks), dim3(threads), lds_bytes, st, seq, ring, jobs, tasks, mak, T, Wt, pen, scope);
+}
+void launch_tile_reg(const uint8_t* seq, int32_t* ring, const TileJob* jobs, const TileTask* tasks, int32_t* mak, int ntasks,
+                     int threads, int T, int C, hipStream_t st) {
+  const size_t lds = (size_t)(T + 1) * 4;
+  if (C == 4) hipLaunchKernelGGL((wfa_tile_reg_kernel<4, 5, 10, 25, 2, 1>), dim3(ntasks), dim3(threads), lds, st, seq, ring, jobs, tasks, mak, T);
+  else hipLaunchKernelGGL((wfa_tile_reg_kernel<2, 5, 10, 25, 2, 1>), dim3(ntasks), dim3(threads), lds, st, seq, ring, jobs, tasks, mak, T);
 }
 void launch_base(const uint8_t* seq, int32_t* a32, uint8_t* a8, uint32_t* rle, const BaseJob* jobs, BaseResult* res,
                  int njobs, DevPen pen, hipStream_t st) {
