@@ -230,7 +230,7 @@ int run_base_jobs(wfm_handle* h, wfm_seqset* S, const wfm_penalties_t& pen, cons
 
 struct TileCfg {
   int T = 64, Wt = 1024, threads = 512;
-  int min_len = 6000, min_score = 512;
+  int min_len = 600, min_score = 64;
   bool enabled = true;
   bool reg = false;  // register-resident tile kernel (default penalty lags only)
   int C = 2;
@@ -248,8 +248,9 @@ TileCfg tile_cfg(const wfm_penalties_t& pen, int scope) {
   const bool dflt = pen.x == 5 && pen.o1 + pen.e1 == 10 && pen.o2 + pen.e2 == 25 && pen.e1 == 2 && pen.e2 == 1;
   c.reg = dflt && !(getenv("WFM_TILE_REG") && atoi(getenv("WFM_TILE_REG")) == 0);
   if (c.reg) {
-    if (!getenv("WFM_TILE_THREADS")) c.threads = 1024;
+    if (!getenv("WFM_TILE_THREADS")) c.threads = 512;
     if (const char* e = getenv("WFM_TILE_C")) c.C = atoi(e) == 4 ? 4 : 2;
+    if (c.C == 4) c.threads = std::min(c.threads, 256);
     c.Wt = c.threads * c.C;
     return c;
   }

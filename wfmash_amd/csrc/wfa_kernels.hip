@@ -1028,8 +1028,8 @@ __global__ __launch_bounds__(1024) void wfa_tile_kernel(const uint8_t* __restric
 // left/right neighbours come from wave shuffles, wave edges go through a tiny LDS mailbox.
 // Same contract as wfa_tile_kernel (snapshot in -> T steps -> snapshot out + per-step maxima).
 // ---------------------------------------------------------------------------
-template <int C, int LX, int LA, int LB, int E1, int E2>
-__global__ __launch_bounds__(1024) void wfa_tile_reg_kernel(const uint8_t* __restrict__ seq, int32_t* __restrict__ ring_arena,
+template <int C, int NTMAX, int LX, int LA, int LB, int E1, int E2>
+__global__ __launch_bounds__(NTMAX) void wfa_tile_reg_kernel(const uint8_t* __restrict__ seq, int32_t* __restrict__ ring_arena,
                                                            const TileJob* __restrict__ jobs, const TileTask* __restrict__ tasks,
                                                            int32_t* __restrict__ mak_out, int T) {
   constexpr int H = LB + 1;  // delay-line depth = score scope: the output snapshot must hold rows s_end-LB .. s_end
@@ -1076,7 +1076,14 @@ __global__ __launch_bounds__(1024) void wfa_tile_reg_kernel(const uint8_t* __res
     }
   }
   for (int t = tid; t <= T; t += NT) s_makr[t] = 0;
-  const unsigned upl = (unsigned)pl, utl = (unsigned)tl;
+  unsigned hmaxu[C];
+  bool colok[C];
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    const int k = k0 + c;
+    colok[c] = (k >= -pl) && (k <= tl);
+    hmaxu[c] = colok[c] ? (unsigned)min(tl, pl + k) : 0u;
+  }
 
   for (int t = 1; t <= T; ++t) {
     const int s = s0 + t;
@@ -1107,25 +1114,36 @@ __global__ __launch_bounds__(1024) void wfa_tile_reg_kernel(const uint8_t* __res
     const int le2 = se2 >= 0 ? rng_lo(pl, se2) : 1, he2 = se2 >= 0 ? rng_hi(tl, se2) : 0;
     int nM[C], nI1[C], nI2[C], nD1[C], nD2[C];
     int mak = 0;
+    // interior threads: every neighbour k0-1 .. k0+C is live in all five source rows -> no range selects
+    const int maxlo = max(max(la, lb), imax3(le1, le2, lx)), minhi = min(min(ha, hb), imin3(he1, he2, hx));
+    const bool interior = (k0 - 1 >= maxlo) && (k0 + C <= minhi);
 #pragma unroll
     for (int c = 0; c < C; ++c) {
       const int k = k0 + c;
-      const int a10 = c == 0 ? lM10 : Mh[c - 1][LA - 1], b10 = c == C - 1 ? rM10 : Mh[c + 1][LA - 1];
-      const int a25 = c == 0 ? lM25 : Mh[c - 1][LB - 1], b25 = c == C - 1 ? rM25 : Mh[c + 1][LB - 1];
-      const int i1 = c == 0 ? lI1 : I1h[c - 1][E1 - 1], d1 = c == C - 1 ? rD1 : D1h[c + 1][E1 - 1];
-      const int i2 = c == 0 ? lI2 : I2h[c - 1], d2 = c == C - 1 ? rD2 : D2h[c + 1];
-      int ins1 = max(sel_rng(a10, k - 1, la, ha), sel_rng(i1, k - 1, le1, he1)) + 1;
-      int ins2 = max(sel_rng(a25, k - 1, lb, hb), sel_rng(i2, k - 1, le2, he2)) + 1;
-      int del1 = max(sel_rng(b10, k + 1, la, ha), sel_rng(d1, k + 1, le1, he1));
-      int del2 = max(sel_rng(b25, k + 1, lb, hb), sel_rng(d2, k + 1, le2, he2));
-      int mis = sel_rng(Mh[c][LX - 1], k, lx, hx) + 1;
-      ins1 = valid_or_null(ins1, k, upl, utl);
-      ins2 = valid_or_null(ins2, k, upl, utl);
-      del1 = valid_or_null(del1, k, upl, utl);
-      del2 = valid_or_null(del2, k, upl, utl);
-      mis = valid_or_null(mis, k, upl, utl);
+      int a10 = c == 0 ? lM10 : Mh[c - 1][LA - 1], b10 = c == C - 1 ? rM10 : Mh[c + 1][LA - 1];
+      int a25 = c == 0 ? lM25 : Mh[c - 1][LB - 1], b25 = c == C - 1 ? rM25 : Mh[c + 1][LB - 1];
+      int i1 = c == 0 ? lI1 : I1h[c - 1][E1 - 1], d1 = c == C - 1 ? rD1 : D1h[c + 1][E1 - 1];
+      int i2 = c == 0 ? lI2 : I2h[c - 1], d2 = c == C - 1 ? rD2 : D2h[c + 1];
+      int mx = Mh[c][LX - 1];
+      if (!interior) {
+        a10 = sel_rng(a10, k - 1, la, ha); i1 = sel_rng(i1, k - 1, le1, he1);
+        a25 = sel_rng(a25, k - 1, lb, hb); i2 = sel_rng(i2, k - 1, le2, he2);
+        b10 = sel_rng(b10, k + 1, la, ha); d1 = sel_rng(d1, k + 1, le1, he1);
+        b25 = sel_rng(b25, k + 1, lb, hb); d2 = sel_rng(d2, k + 1, le2, he2);
+        mx = sel_rng(mx, k, lx, hx);
+      }
+      // in-bounds <=> 0 <= offset <= min(tl, pl + k)   (h <= tl and h - k <= pl)
+      const unsigned hm = hmaxu[c];
+      int ins1 = max(a10, i1) + 1, ins2 = max(a25, i2) + 1, del1 = max(b10, d1), del2 = max(b25, d2), mis = mx + 1;
+      ins1 = (unsigned)ins1 <= hm ? ins1 : WF_NULL;
+      ins2 = (unsigned)ins2 <= hm ? ins2 : WF_NULL;
+      del1 = (unsigned)del1 <= hm ? del1 : WF_NULL;
+      del2 = (unsigned)del2 <= hm ? del2 : WF_NULL;
+      mis = (unsigned)mis <= hm ? mis : WF_NULL;
       nI1[c] = ins1; nI2[c] = ins2; nD1[c] = del1; nD2[c] = del2;
-      nM[c] = max(imax3(ins1, ins2, mis), max(del1, del2));
+      int m = max(imax3(ins1, ins2, mis), max(del1, del2));
+      // columns outside [-pl, tl] hold no cell at all (hmaxu = 0 would let offset 0 through)
+      nM[c] = colok[c] ? m : WF_NULL;
     }
     // extension: first 8 bases of all C cells in flight together
     uint64_t x[C];
@@ -1221,8 +1239,8 @@ void launch_tile(const uint8_t* seq, int32_t* ring, const TileJob* jobs, const T
 void launch_tile_reg(const uint8_t* seq, int32_t* ring, const TileJob* jobs, const TileTask* tasks, int32_t* mak, int ntasks,
                      int threads, int T, int C, hipStream_t st) {
   const size_t lds = (size_t)(T + 1) * 4;
-  if (C == 4) hipLaunchKernelGGL((wfa_tile_reg_kernel<4, 5, 10, 25, 2, 1>), dim3(ntasks), dim3(threads), lds, st, seq, ring, jobs, tasks, mak, T);
-  else hipLaunchKernelGGL((wfa_tile_reg_kernel<2, 5, 10, 25, 2, 1>), dim3(ntasks), dim3(threads), lds, st, seq, ring, jobs, tasks, mak, T);
+  if (C == 4) hipLaunchKernelGGL((wfa_tile_reg_kernel<4, 256, 5, 10, 25, 2, 1>), dim3(ntasks), dim3(threads), lds, st, seq, ring, jobs, tasks, mak, T);
+  else hipLaunchKernelGGL((wfa_tile_reg_kernel<2, 1024, 5, 10, 25, 2, 1>), dim3(ntasks), dim3(threads), lds, st, seq, ring, jobs, tasks, mak, T);
 }
 void launch_base(const uint8_t* seq, int32_t* a32, uint8_t* a8, uint32_t* rle, const BaseJob* jobs, BaseResult* res,
                  int njobs, DevPen pen, hipStream_t st) {
