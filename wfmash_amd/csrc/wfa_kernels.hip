@@ -1105,18 +1105,12 @@ __global__ __launch_bounds__(NTMAX) void wfa_tile_reg_kernel(const uint8_t* __re
       if (wv + 1 < nw) { const int* e = s_edge[par][wv + 1][1]; rM10 = e[0]; rM25 = e[1]; rD1 = e[2]; rD2 = e[3]; }
       else { rM10 = rM25 = rD1 = rD2 = WF_NULL; }
     }
-    // closed-form ranges of the source rows
-    const int sx = s - LX, sa = s - LA, sb = s - LB, se1 = s - E1, se2 = s - E2;
-    const int lx = sx >= 0 ? rng_lo(pl, sx) : 1, hx = sx >= 0 ? rng_hi(tl, sx) : 0;
-    const int la = sa >= 0 ? rng_lo(pl, sa) : 1, ha = sa >= 0 ? rng_hi(tl, sa) : 0;
-    const int lb = sb >= 0 ? rng_lo(pl, sb) : 1, hb = sb >= 0 ? rng_hi(tl, sb) : 0;
-    const int le1 = se1 >= 0 ? rng_lo(pl, se1) : 1, he1 = se1 >= 0 ? rng_hi(tl, se1) : 0;
-    const int le2 = se2 >= 0 ? rng_lo(pl, se2) : 1, he2 = se2 >= 0 ? rng_hi(tl, se2) : 0;
+    // The closed-form source ranges are nested, the oldest row (s - LB) is the narrowest:
+    // a thread whose neighbourhood k0-1 .. k0+C lies inside it needs no range select at all.
+    const int sb = s - LB;
+    const bool interior = sb >= 0 && (k0 - 1 >= rng_lo(pl, sb)) && (k0 + C <= rng_hi(tl, sb));
     int nM[C], nI1[C], nI2[C], nD1[C], nD2[C];
     int mak = 0;
-    // interior threads: every neighbour k0-1 .. k0+C is live in all five source rows -> no range selects
-    const int maxlo = max(max(la, lb), imax3(le1, le2, lx)), minhi = min(min(ha, hb), imin3(he1, he2, hx));
-    const bool interior = (k0 - 1 >= maxlo) && (k0 + C <= minhi);
 #pragma unroll
     for (int c = 0; c < C; ++c) {
       const int k = k0 + c;
@@ -1126,6 +1120,12 @@ __global__ __launch_bounds__(NTMAX) void wfa_tile_reg_kernel(const uint8_t* __re
       int i2 = c == 0 ? lI2 : I2h[c - 1], d2 = c == C - 1 ? rD2 : D2h[c + 1];
       int mx = Mh[c][LX - 1];
       if (!interior) {
+        const int sx = s - LX, sa = s - LA, se1 = s - E1, se2 = s - E2;
+        const int lx = sx >= 0 ? rng_lo(pl, sx) : 1, hx = sx >= 0 ? rng_hi(tl, sx) : 0;
+        const int la = sa >= 0 ? rng_lo(pl, sa) : 1, ha = sa >= 0 ? rng_hi(tl, sa) : 0;
+        const int lb = sb >= 0 ? rng_lo(pl, sb) : 1, hb = sb >= 0 ? rng_hi(tl, sb) : 0;
+        const int le1 = se1 >= 0 ? rng_lo(pl, se1) : 1, he1 = se1 >= 0 ? rng_hi(tl, se1) : 0;
+        const int le2 = se2 >= 0 ? rng_lo(pl, se2) : 1, he2 = se2 >= 0 ? rng_hi(tl, se2) : 0;
         a10 = sel_rng(a10, k - 1, la, ha); i1 = sel_rng(i1, k - 1, le1, he1);
         a25 = sel_rng(a25, k - 1, lb, hb); i2 = sel_rng(i2, k - 1, le2, he2);
         b10 = sel_rng(b10, k + 1, la, ha); d1 = sel_rng(d1, k + 1, le1, he1);
