@@ -27,6 +27,9 @@ typedef struct {
   uint64_t query_padding;           /* min(w,5000) = 1000 */
   uint64_t wflign_max_len_minor;    /* 128 * w = 128000 */
   int32_t  disable_chain_patching;  /* 0 */
+  int32_t  sam_format;              /* -a: SAM instead of PAF (parse_args.hpp:128) */
+  int32_t  emit_md_tag;             /* -d: MD:Z tag in SAM records (parse_args.hpp:129) */
+  int32_t  no_seq_in_sam;           /* 0 */
 } wfmh_align_params_t;
 
 typedef struct {

@@ -374,3 +374,90 @@ def align_mapping_lines(lines, ref_seqs, query_seqs, target_padding=1000, query_
         if rec is not None:
             out.append("\t".join(rec.split()))  # processMappingRecord re-tokenisation (computeAlignments.hpp:484-525)
     return out
+
+
+# ---------------------------------------------------------------------------
+# SAM writer (wflign_patch.cpp:2480-2609) and MD:Z (write_tag_and_md_string :2397-2478)
+# ---------------------------------------------------------------------------
+def md_string(cigar, target_start, target):
+    """The reference scans ops keeping a (last_op, last_len) pair: every op except the final
+    one goes through the 'previous op' branch, the final one through the closing branch."""
+    ops = []
+    for c, o in parse(cigar):
+        if ops and ops[-1][1] == o:
+            ops[-1][0] += c
+        else:
+            ops.append([c, o])
+    out = ["MD:Z:"]
+    t_off, l_md = target_start, 0
+    for i, (n, op) in enumerate(ops):
+        last = i == len(ops) - 1
+        if not last:
+            if op in "=M":
+                l_md += n
+                t_off += n
+            elif op == "X":
+                for j in range(n):
+                    out.append(f"{l_md}{chr(target[t_off + j])}")
+                    l_md = 0
+                t_off += n
+            elif op == "D":
+                out.append(f"{l_md}^" + target[t_off:t_off + n].decode())
+                l_md = 0
+                t_off += n
+        elif n:
+            if op in "=M":
+                out.append(str(n + l_md))
+            elif op == "X":
+                for j in range(n):
+                    out.append(f"{l_md}{chr(target[t_off + j])}")
+                    l_md = 0
+                out.append("0")
+            elif op == "I":
+                out.append(str(l_md))
+            elif op == "D":
+                out.append(f"{l_md}^" + target[t_off:t_off + n].decode() + "0")
+    return "".join(out)
+
+
+def write_alignment_sam(cigar, qname, qoff, q_is_rev, tname, toff, mm_id, chain_id, chain_length, chain_pos,
+                        query, target, emit_md_tag=False, no_seq=False,
+                        min_identity=0.0, min_aln_len=32, min_block_identity=np.float32(0.1)):
+    ops = parse(cigar)
+    b, e = 0, len(ops)
+    new_ref_start, new_query_start = toff, qoff
+    while b < e and ops[b][1] in "ID":
+        if ops[b][1] == "I":
+            new_query_start += ops[b][0]
+        else:
+            new_ref_start += ops[b][0]
+        b += 1
+    if b < e:
+        while e > b and ops[e - 1][1] in "ID":
+            e -= 1
+    core = ops[b:e]
+    if not core:
+        return None
+    matches = sum(c for c, o in core if o in "M=")
+    mism = sum(c for c, o in core if o == "X")
+    ins = sum(1 for c, o in core if o == "I")
+    ins_bp = sum(c for c, o in core if o == "I")
+    dele = sum(1 for c, o in core if o == "D")
+    del_bp = sum(c for c, o in core if o == "D")
+    q_len = matches + mism + ins_bp
+    gi = matches / (matches + mism + ins + dele)
+    bi = matches / (matches + mism + ins_bp + del_bp)
+    if not (gi >= float(np.float32(min_identity)) and q_len >= min_aln_len and bi >= float(np.float32(min_block_identity))):
+        return None
+    trimmed = to_str(core)
+    p0 = new_query_start - qoff
+    seq = "*" if no_seq else query[p0:p0 + q_len].decode()
+    f = [qname, "16" if q_is_rev else "0", tname, str(new_ref_start + 1), _g(float(round(float2phred(1.0 - bi)))), trimmed,
+         "*", "0", "0", seq, "*", f"NM:i:{mism + ins_bp + del_bp}", "gi:f:" + _g(gi), "bi:f:" + _g(bi),
+         "md:f:" + _g(float(np.float32(mm_id)))]
+    if chain_length > 0:
+        f.append(f"ci:i:{chain_id}")
+        f.append(f"ch:Z:{chain_id}.{chain_length}.{chain_pos}")
+    if emit_md_tag:
+        f.append(md_string(trimmed, 0, target))
+    return "\t".join(f)

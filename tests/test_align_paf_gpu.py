@@ -133,3 +133,35 @@ def test_align_paf_no_patching_and_custom_params(gpu, tmp_path):
         if rec:
             exp.append("\t".join(rec.split()))
     assert got == exp
+
+
+def test_align_sam_with_md_matches_reference_restatement(gpu, tmp_path):
+    """-a -d: SAM records with the MD:Z tag (wflign_patch.cpp:2480-2609)."""
+    fa, paf, seqs, lines = _make_case(tmp_path, 33)
+    out = str(tmp_path / "out.sam")
+    capi.align_paf(gpu, fa, paf, out, params={"sam_format": 1, "emit_md_tag": 1})
+    got = [l.rstrip("\n") for l in open(out)]
+    header = [l for l in got if l.startswith("@")]
+    body = [l for l in got if not l.startswith("@")]
+    assert len(header) == len(seqs) + 1 and header[0].startswith("@SQ\tSN:hap0#1#chr1\tLN:")
+    exp = []
+    for line in lines:
+        try:
+            row = W.parse_mashmap_row(line, 1000, 1000)
+        except ValueError:
+            continue
+        ref, qry = seqs[row["refId"]], seqs[row["qId"]]
+        tail_pad = min(len(ref) - row["rEndPos"], 128000)
+        tav = W.upper_valid_dna(ref[row["rStartPos"]:row["rEndPos"] + tail_pad])
+        tgt = tav[:row["rEndPos"] - row["rStartPos"]]
+        q = W.upper_valid_dna(qry[row["qStartPos"]:row["qEndPos"]])
+        if row["rev"]:
+            q = W.revcomp(q)
+        cg = W.do_biwfa_alignment(q, tgt, tav, None)
+        rec = W.write_alignment_sam(cg, row["qId"], row["qStartPos"], row["rev"], row["refId"], row["rStartPos"], row["mm_id"],
+                                    row["chain_id"], row["chain_length"], row["chain_pos"], q, tav, emit_md_tag=True)
+        if rec:
+            exp.append(rec)
+    assert len(body) == len(exp) and len(body) >= 20
+    for a, b in zip(body, exp):
+        assert a == b, (a[:150], b[:150])

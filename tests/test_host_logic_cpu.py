@@ -138,3 +138,16 @@ def test_parse_mashmap_row_padding_rules():
         row = W.parse_mashmap_row(ln, 1000, 1000)
         got = capi.host_cigar_fn("parse_row", ln, i0=1000, i1=1000).split(",")
         assert [str(row["qStartPos"]), str(row["qEndPos"]), str(row["rStartPos"]), str(row["rEndPos"])] == [got[1], got[2], got[5], got[6]]
+
+
+def test_md_string_matches_oracle_and_known_answers():
+    t = b"ACGTACGTACGTACGTACGTACGTACGTACGTACGTACGT"
+    # 5= 1X 4= 2D 3= : MD counts matches, names the mismatched / deleted target bases
+    assert capi.host_cigar_fn("md", "5=1X4=2D3=", target=t, i0=0) == "MD:Z:5C4^GT3"
+    assert capi.host_cigar_fn("md", "5=1X4=2D3=", target=t, i0=0) == W.md_string("5=1X4=2D3=", 0, t)
+    rng = random.Random(3)
+    for _ in range(200):
+        c = _rand_cigar(rng, rng.randrange(1, 8), maxlen=6, short_bias=False)
+        tlen = sum(n for n, o in W.parse(c) if o in "=XD")
+        tgt = bytes(rng.choice(b"ACGT") for _ in range(tlen + 4))
+        assert capi.host_cigar_fn("md", c, target=tgt, i0=0) == W.md_string(c, 0, tgt)

@@ -190,13 +190,18 @@ std::string Aligner::align_lines(const std::vector<std::string>& lines, Summary&
       r.chain_id = f.row.chain_id; r.chain_length = f.row.chain_length; r.chain_pos = f.row.chain_pos;
     }
     wflign::BiwfaStats st;
-    const int rc = wflign::do_biwfa_alignment_batch(gpu, recs, pen, param.disable_chain_patching, pp, &st);
+    wflign::OutputFormat fmt;
+    fmt.paf_format_else_sam = !param.sam_format;
+    fmt.no_seq_in_sam = param.no_seq_in_sam;
+    fmt.emit_md_tag = param.emit_md_tag;
+    const int rc = wflign::do_biwfa_alignment_batch(gpu, recs, pen, param.disable_chain_patching, pp, &st, fmt);
     if (rc < 0) throw std::runtime_error(std::string("[wfmash::align] GPU alignment failed: ") + wfm_last_error(gpu));
     sum.cells += st.cells; sum.ms_gpu += st.ms_gpu;
     for (size_t k = 0; k < recs.size(); ++k) {
       sum.records++;
       sum.aligned_bp += (uint64_t)(fetched[k].row.qEndPos - fetched[k].row.qStartPos);
       if (recs[k].paf.empty()) continue;
+      if (param.sam_format) { out += recs[k].paf; sum.written++; continue; }  // no cg:Z: field -> line passes through unchanged
       // processMappingRecord re-tokenises the writer's line and joins with single tabs (computeAlignments.hpp:484-525)
       const auto fields = tokenize(recs[k].paf);
       std::string nl;
@@ -219,6 +224,10 @@ Summary Aligner::compute() {
   while (std::getline(in, line)) if (!line.empty()) lines.push_back(line);
   std::ofstream outstream(param.pafOutputFile);
   if (!outstream.is_open()) throw std::runtime_error("[wfmash::align] Error! Failed to open output file: " + param.pafOutputFile);
+  if (param.sam_format) {  // write_sam_header (computeAlignments.hpp:725-736)
+    for (int i = 0; i < ref->nseq(); ++i) outstream << "@SQ\tSN:" << ref->name(i) << "\tLN:" << ref->sequence(i).size() << "\n";
+    outstream << "@PG\tID:wfmash\tPN:wfmash\tVN:wfmash-hip-r1\tCL:wfmash\n";
+  }
   outstream << align_lines(lines, sum);
   outstream.close();
   sum.ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();

@@ -15,6 +15,7 @@ void wfmh_align_default_params(wfmh_align_params_t* p) {
   p->min_identity = 0.0f; p->min_alignment_length = 32; p->min_block_identity = 0.1f;
   p->target_padding = 1000; p->query_padding = 1000; p->wflign_max_len_minor = 128000;
   p->disable_chain_patching = 0;
+  p->sam_format = 0; p->emit_md_tag = 0; p->no_seq_in_sam = 0;
 }
 
 int wfmh_align_paf(wfm_handle_t* h, const char* target_fasta, const char* query_fasta, const char* mapping_paf,
@@ -41,6 +42,7 @@ int wfmh_align_paf(wfm_handle_t* h, const char* target_fasta, const char* query_
     ap.query_padding = d.query_padding;
     ap.wflign_max_len_minor = d.wflign_max_len_minor;
     ap.disable_chain_patching = d.disable_chain_patching != 0;
+    ap.sam_format = d.sam_format != 0; ap.emit_md_tag = d.emit_md_tag != 0; ap.no_seq_in_sam = d.no_seq_in_sam != 0;
     align::Aligner aligner(ap, h);
     const align::Summary s = aligner.compute();
     if (summary) {
@@ -94,6 +96,8 @@ char* wfmh_test_cigar(const char* fn, const char* a, const char* b, const char* 
                                   std::stoull(p[6]), std::stoull(p[7]), pp, std::stof(p[8]), std::stoi(p[9]), std::stoi(p[10]),
                                   std::stoi(p[11]));
     }
+  } else if (f == "md") {
+    r = wflign::md_string(sa, (int)i0, t.c_str());
   } else if (f == "parse_row") {
     try {
       align::MappingBoundaryRow row;

@@ -41,6 +41,8 @@ int main(int argc, char** argv) {
     }
     else if (a == "--device") device = atoi(next("--device").c_str());
     else if (a == "--no-patching") p.disable_chain_patching = 1;
+    else if (a == "-a" || a == "--sam") p.sam_format = 1;
+    else if (a == "-d" || a == "--md-tag") p.emit_md_tag = 1;
     else if (a == "-h" || a == "--help") {
       fprintf(stderr, "usage: wfmash-hip -i mappings.paf [-o out.paf] [-g x,o1,e1,o2,e2] [-E pad] [-U pad] target.fa [query.fa]\n");
       return 0;

@@ -310,6 +310,72 @@ bool write_alignment_paf(std::string& out, const std::string& cigar_str, const s
   return true;
 }
 
+// MD:Z string (write_tag_and_md_string, wflign_patch.cpp:2397-2478): every op but the last is
+// handled by the "previous op" branch, the last one by the closing branch.
+std::string md_string(const std::string& cigar, int target_start, const char* target) {
+  std::ostringstream os;
+  os << "MD:Z:";
+  CigarOps raw = parse_cigar(cigar), ops;
+  for (const auto& o : raw) {  // consecutive equal ops are summed by the reference's scanner
+    if (!ops.empty() && ops.back().second == o.second) ops.back().first += o.first; else ops.push_back(o);
+  }
+  int t_off = target_start, l_md = 0;
+  for (size_t i = 0; i < ops.size(); ++i) {
+    const int len = ops[i].first;
+    const char op = ops[i].second;
+    const bool last = (i + 1 == ops.size());
+    if (!last) {
+      if (op == '=' || op == 'M') { l_md += len; t_off += len; }
+      else if (op == 'X') { for (int j = 0; j < len; ++j) { os << l_md << target[t_off + j]; l_md = 0; } t_off += len; }
+      else if (op == 'D') { os << l_md << "^"; for (int j = 0; j < len; ++j) os << target[t_off + j]; l_md = 0; t_off += len; }
+    } else if (len) {
+      if (op == '=' || op == 'M') os << len + l_md;
+      else if (op == 'X') { for (int j = 0; j < len; ++j) { os << l_md << target[t_off + j]; l_md = 0; } os << "0"; }
+      else if (op == 'I') os << l_md;
+      else if (op == 'D') { os << l_md << "^"; for (int j = 0; j < len; ++j) os << target[t_off + j]; os << "0"; }
+    }
+  }
+  return os.str();
+}
+
+bool write_alignment_sam(std::string& out, const std::string& cigar_str, const std::string& query_name,
+                         uint64_t query_offset, bool query_is_rev, const std::string& target_name,
+                         uint64_t target_offset, const PafParams& pp, float mashmap_estimated_identity,
+                         bool no_seq_in_sam, bool emit_md_tag, const char* query, const char* target,
+                         int32_t chain_id, int32_t chain_length, int32_t chain_pos) {
+  if (cigar_str.empty()) return false;
+  const CigarOps ops = parse_cigar(cigar_str);
+  size_t b = 0, e = ops.size();
+  uint64_t new_ref_start = target_offset, new_query_start = query_offset;
+  while (b < e && (ops[b].second == 'I' || ops[b].second == 'D')) {
+    if (ops[b].second == 'I') new_query_start += (uint64_t)ops[b].first; else new_ref_start += (uint64_t)ops[b].first;
+    ++b;
+  }
+  if (b < e) while (e > b && (ops[e - 1].second == 'I' || ops[e - 1].second == 'D')) --e;
+  if (b >= e) return false;
+  const CigarStats s = cigar_stats(ops, b, e);
+  const double gi = (double)s.matches / (double)(s.matches + s.mismatches + s.insertions + s.deletions);
+  const double bi = (double)s.matches / (double)(s.matches + s.mismatches + s.inserted_bp + s.deleted_bp);
+  if (!(gi >= pp.min_identity && s.q_len >= pp.min_alignment_length && bi >= pp.min_block_identity)) return false;
+  std::string trimmed;
+  for (size_t i = b; i < e; ++i) { trimmed += std::to_string(ops[i].first); trimmed += ops[i].second; }
+  std::ostringstream os;
+  os << query_name << "\t" << (query_is_rev ? "16" : "0") << "\t" << target_name << "\t" << new_ref_start + 1 << "\t"
+     << std::round(float2phred(1.0 - bi)) << "\t" << trimmed << "\t" << "*\t0\t0\t";
+  if (no_seq_in_sam) os << "*";
+  else os.write(query + (new_query_start - query_offset), (std::streamsize)s.q_len);
+  os << "\t*\t" << "NM:i:" << (s.mismatches + s.inserted_bp + s.deleted_bp) << "\t" << "gi:f:" << gi << "\t"
+     << "bi:f:" << bi << "\t" << "md:f:" << mashmap_estimated_identity;
+  if (chain_length > 0) {
+    os << "\tci:i:" << chain_id;
+    os << "\tch:Z:" << chain_id << "." << chain_length << "." << chain_pos;
+  }
+  if (emit_md_tag) os << "\t" << md_string(trimmed, 0, target);  // target offset 0 + aln.i (= 0), wflign_patch.cpp:2602-2604
+  os << "\n";
+  out += os.str();
+  return true;
+}
+
 // ---------------------------------------------------------------------------
 // batch pipeline
 // ---------------------------------------------------------------------------
@@ -334,7 +400,7 @@ struct GpuBatch {
 }  // namespace
 
 int do_biwfa_alignment_batch(wfm_handle_t* h, std::vector<BiwfaRecord>& recs, const wflign_penalties_t& penalties,
-                             bool disable_chain_patching, const PafParams& pp, BiwfaStats* stats) {
+                             bool disable_chain_patching, const PafParams& pp, BiwfaStats* stats, const OutputFormat& fmt) {
   const wfm_penalties_t pen{penalties.mismatch, penalties.gap_opening1, penalties.gap_extension1,
                             penalties.gap_opening2, penalties.gap_extension2};
   GpuBatch g;
@@ -420,9 +486,14 @@ int do_biwfa_alignment_batch(wfm_handle_t* h, std::vector<BiwfaRecord>& recs, co
     if (sw != r.cigar) r.cigar = sw;
     sw = try_swap_end_pattern(r.cigar, q, t, 0, 0);
     if (sw != r.cigar) r.cigar = sw;
-    write_alignment_paf(r.paf, r.cigar, r.query_name, r.query_total_length, r.query_offset, r.query_length,
-                        r.query_is_rev, r.target_name, r.target_total_length, r.target_offset, pp,
-                        r.mashmap_estimated_identity, r.chain_id, r.chain_length, r.chain_pos);
+    if (fmt.paf_format_else_sam)
+      write_alignment_paf(r.paf, r.cigar, r.query_name, r.query_total_length, r.query_offset, r.query_length,
+                          r.query_is_rev, r.target_name, r.target_total_length, r.target_offset, pp,
+                          r.mashmap_estimated_identity, r.chain_id, r.chain_length, r.chain_pos);
+    else
+      write_alignment_sam(r.paf, r.cigar, r.query_name, r.query_offset, r.query_is_rev, r.target_name, r.target_offset, pp,
+                          r.mashmap_estimated_identity, fmt.no_seq_in_sam, fmt.emit_md_tag, r.query, r.target,
+                          r.chain_id, r.chain_length, r.chain_pos);
   }
   return 0;
 }

@@ -72,6 +72,15 @@ bool write_alignment_paf(std::string& out, const std::string& cigar_str, const s
                          const PafParams& pp, float mashmap_estimated_identity, int32_t chain_id, int32_t chain_length,
                          int32_t chain_pos);
 
+// SAM record (wflign_patch.cpp:2480-2609) incl. the MD:Z tag (write_tag_and_md_string :2397-2478).
+// `query` / `target` are the strand-adjusted query window and the target window (target offset 0).
+bool write_alignment_sam(std::string& out, const std::string& cigar_str, const std::string& query_name,
+                         uint64_t query_offset, bool query_is_rev, const std::string& target_name,
+                         uint64_t target_offset, const PafParams& pp, float mashmap_estimated_identity,
+                         bool no_seq_in_sam, bool emit_md_tag, const char* query, const char* target,
+                         int32_t chain_id, int32_t chain_length, int32_t chain_pos);
+std::string md_string(const std::string& cigar, int target_start, const char* target);  // "MD:Z:..."
+
 // ---- batch form of do_biwfa_alignment (wflign.cpp:108-483) ----
 struct BiwfaRecord {
   std::string query_name;
@@ -88,7 +97,7 @@ struct BiwfaRecord {
   bool ok = false;
   int32_t score = -1;
   std::string cigar;                 // final CIGAR (after patching + swizzle)
-  std::string paf;                   // PAF line as the reference's writer emits it ("" if filtered)
+  std::string paf;                   // PAF line (or SAM line incl. newline) as the reference's writer emits it ("" if filtered)
 };
 
 struct BiwfaStats {
@@ -97,7 +106,14 @@ struct BiwfaStats {
   uint64_t main_failed = 0, head_patches = 0, tail_patches = 0;
 };
 
+struct OutputFormat {
+  bool paf_format_else_sam = true;   // wflign.cpp:434
+  bool no_seq_in_sam = false;
+  bool emit_md_tag = false;
+};
+
 int do_biwfa_alignment_batch(wfm_handle_t* h, std::vector<BiwfaRecord>& recs, const wflign_penalties_t& penalties,
-                             bool disable_chain_patching, const PafParams& pp, BiwfaStats* stats);
+                             bool disable_chain_patching, const PafParams& pp, BiwfaStats* stats,
+                             const OutputFormat& fmt = OutputFormat());
 
 }  // namespace wflign
