@@ -6,6 +6,7 @@
 #include "../../include/wfmash_host.h"
 #include "../csrc/wfa_handle.h"
 #include "aligner.hpp"
+#include "map_stats.hpp"
 
 extern "C" {
 
@@ -96,6 +97,14 @@ char* wfmh_test_cigar(const char* fn, const char* a, const char* b, const char* 
                                   std::stoull(p[6]), std::stoull(p[7]), pp, std::stof(p[8]), std::stoi(p[9]), std::stoi(p[10]),
                                   std::stoi(p[11]));
     }
+  } else if (f == "min_hits") {   // a = "s,k,identity,ci"
+    int sk = 0, k = 0; float id = 0, ci = 0;
+    if (sscanf(sa.c_str(), "%d,%d,%f,%f", &sk, &k, &id, &ci) == 4)
+      r = std::to_string(skch::Stat::estimateMinimumHits(sk, k, id)) + "," + std::to_string(skch::Stat::estimateMinimumHitsRelaxed(sk, k, id, ci));
+  } else if (f == "sketch_cutoffs") {   // a = "s,k,ANIDiff,ANIDiffConf"
+    int sk = 0, k = 0; float ad = 0, ac = 0;
+    if (sscanf(sa.c_str(), "%d,%d,%f,%f", &sk, &k, &ad, &ac) == 4)
+      for (int v : skch::Stat::sketch_cutoffs(sk, k, ad, ac)) { if (!r.empty()) r += ","; r += std::to_string(v); }
   } else if (f == "md") {
     r = wflign::md_string(sa, (int)i0, t.c_str());
   } else if (f == "parse_row") {
