@@ -151,6 +151,14 @@ int  wfm_sketch_fragments(wfm_handle_t* h, const char* seq, int64_t seq_len,
                           int k, int s, int32_t seq_id,
                           wfm_minmer_t* out, int32_t* out_count);
 
+/* addMinmers (commonFunc.hpp:440-708): winnowed minmer intervals [wpos, wpos_end) of one target
+ * sequence, sorted by (wpos, wpos_end), spans chunked to <= w.  K-mer hashing runs on the GPU,
+ * the sequential window bookkeeping on the calling host thread (one sequence per thread is the
+ * reference's parallelism, winSketch.hpp:200-239).  Returns the number of intervals (which may
+ * exceed cap; only cap are written) or a negative WFM_E_* code. */
+int64_t wfm_add_minmers(wfm_handle_t* h, const char* seq, int64_t len, int k, int w, int s, int32_t seq_id,
+                        wfm_minmer_t* out, int64_t cap);
+
 #ifdef __cplusplus
 }
 #endif

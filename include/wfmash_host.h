@@ -56,6 +56,9 @@ int wfmh_align_paf(wfm_handle_t* h, const char* target_fasta, const char* query_
 char* wfmh_test_cigar(const char* fn, const char* a, const char* b, const char* query, const char* target,
                       long long i0, long long i1);
 void  wfmh_free(char* p);
+/* host winnowing stage of wfm_add_minmers on caller-supplied canonical k-mer hashes (CPU tests) */
+int64_t wfmh_test_winnow(const char* seq, int64_t len, int k, int w, int s, int32_t seq_id,
+                         const uint64_t* hash, const int8_t* strand, wfm_minmer_t* out, int64_t cap);
 
 #ifdef __cplusplus
 }

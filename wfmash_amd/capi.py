@@ -22,7 +22,7 @@ EXPORTS = [
     "wfm_create", "wfm_destroy", "wfm_last_error", "wfm_device_name",
     "wfm_align_arena_bytes", "wfm_align_batch", "wfm_upload_sequences",
     "wfm_free_sequences", "wfm_align_resident", "wfm_get_stats",
-    "wfm_hash_kmers", "wfm_sketch_fragments",
+    "wfm_hash_kmers", "wfm_sketch_fragments", "wfm_add_minmers",
 ]
 
 
@@ -265,11 +265,23 @@ class Handle:
             raise WfmError(f"wfm_sketch_fragments failed ({rc}): {self.last_error()}")
         return [out[i * s:i * s + cnt[i]] for i in range(n)]
 
+    def add_minmers(self, seq: bytes, k: int, w: int, s: int, seq_id: int = 0):
+        """wfm_add_minmers: winnowed minmer intervals of one target sequence."""
+        cap = 4 * len(seq) + 64
+        out = np.zeros(cap, dtype=MINMER_DTYPE)
+        buf = np.frombuffer(seq, dtype=np.uint8)
+        self._L.wfm_add_minmers.restype = C.c_int64
+        self._L.wfm_add_minmers.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int32, C.c_void_p, C.c_int64]
+        n = self._L.wfm_add_minmers(self._p, buf.ctypes.data, len(seq), k, w, s, seq_id, out.ctypes.data, cap)
+        if n < 0:
+            raise WfmError(f"wfm_add_minmers failed ({n}): {self.last_error()}")
+        return out[:n]
+
 
 # ---------------------------------------------------------------------------
 # host-side align driver (include/wfmash_host.h)
 # ---------------------------------------------------------------------------
-HOST_EXPORTS = ["wfmh_align_default_params", "wfmh_align_paf", "wfmh_test_cigar", "wfmh_free"]
+HOST_EXPORTS = ["wfmh_align_default_params", "wfmh_align_paf", "wfmh_test_cigar", "wfmh_free", "wfmh_test_winnow"]
 
 
 class AlignParams(C.Structure):
@@ -326,3 +338,16 @@ def align_paf(handle, target_fasta, mapping_paf, out_paf, query_fasta=None, para
     if rc != 0:
         raise WfmError(f"wfmh_align_paf failed ({rc}): {handle.last_error()}")
     return summ
+
+
+def host_winnow(seq: bytes, k: int, w: int, s: int, seq_id: int, hashes, strands):
+    """Host winnowing stage on caller-supplied canonical k-mer hashes (no GPU needed)."""
+    L = load()
+    L.wfmh_test_winnow.restype = C.c_int64
+    L.wfmh_test_winnow.argtypes = [C.c_char_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
+    cap = 4 * len(seq) + 64
+    out = np.zeros(cap, dtype=MINMER_DTYPE)
+    hashes = np.ascontiguousarray(hashes, dtype=np.uint64)
+    strands = np.ascontiguousarray(strands, dtype=np.int8)
+    n = L.wfmh_test_winnow(seq, len(seq), k, w, s, seq_id, hashes.ctypes.data, strands.ctypes.data, out.ctypes.data, cap)
+    return out[:n]
