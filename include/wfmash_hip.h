@@ -151,6 +151,38 @@ int  wfm_sketch_fragments(wfm_handle_t* h, const char* seq, int64_t seq_len,
                           int k, int s, int32_t seq_id,
                           wfm_minmer_t* out, int32_t* out_count);
 
+/* skch::IntervalPoint (base_types.hpp:63-76), 24 bytes: endpoints of minmer intervals */
+typedef struct {
+  int64_t  pos;
+  uint64_t hash;
+  int32_t  seqId;
+  int8_t   side;      /* OPEN = 1, CLOSE = -1 (base_types.hpp:123-127) */
+  int8_t   pad_[3];
+} wfm_interval_point_t;
+
+/* Device-resident reference index: Sketch::build's index stage (winSketch.hpp:266-429).
+ * `minmers` = the minmer intervals of all target sequences concatenated in seqId order (the
+ * output of wfm_add_minmers per sequence).  max_kmer_freq as -F (parse_args.hpp:734-737;
+ * <= 1: fraction of windows, > 1: absolute count; default 0.0002). */
+typedef struct wfm_index wfm_index_t;
+typedef struct {
+  int64_t  n_windows;   /* minmer intervals given ("windows") */
+  int64_t  n_kept;      /* size of minmerIndex after the frequency filter */
+  int64_t  n_unique;    /* unique hashes in the position lookup */
+  int64_t  n_points;    /* interval points */
+  uint64_t threshold;   /* count_threshold actually used */
+  int64_t  filtered;    /* intervals dropped by the frequency filter */
+  int32_t  adjusted;    /* 1 if the over-filtering safety check raised the threshold (winSketch.hpp:326-349) */
+  int32_t  pad_;
+} wfm_index_info_t;
+int  wfm_index_build(wfm_handle_t* h, const wfm_minmer_t* minmers, int64_t n, double max_kmer_freq, wfm_index_t** out);
+void wfm_index_free(wfm_handle_t* h, wfm_index_t* ix);
+int  wfm_index_info(const wfm_index_t* ix, wfm_index_info_t* out);
+/* Copies the index back to the host (any pointer may be NULL): unique hashes ascending,
+ * n_unique+1 offsets into points, the points, and minmerIndex. */
+int  wfm_index_download(wfm_handle_t* h, const wfm_index_t* ix, uint64_t* uhash, int64_t* poff,
+                        wfm_interval_point_t* points, wfm_minmer_t* minmers);
+
 /* addMinmers (commonFunc.hpp:440-708): winnowed minmer intervals [wpos, wpos_end) of one target
  * sequence, sorted by (wpos, wpos_end), spans chunked to <= w.  K-mer hashing runs on the GPU,
  * the sequential window bookkeeping on the calling host thread (one sequence per thread is the

@@ -23,6 +23,7 @@ EXPORTS = [
     "wfm_align_arena_bytes", "wfm_align_batch", "wfm_upload_sequences",
     "wfm_free_sequences", "wfm_align_resident", "wfm_get_stats",
     "wfm_hash_kmers", "wfm_sketch_fragments", "wfm_add_minmers",
+    "wfm_index_build", "wfm_index_free", "wfm_index_info", "wfm_index_download",
 ]
 
 
@@ -59,6 +60,14 @@ class Stats(C.Structure):
 class Minmer(C.Structure):
     _fields_ = [("hash", C.c_uint64), ("wpos", C.c_int64), ("wpos_end", C.c_int64),
                 ("seqId", C.c_int32), ("strand", C.c_int16), ("pad_", C.c_int16)]
+
+
+POINT_DTYPE = np.dtype([("pos", "<i8"), ("hash", "<u8"), ("seqId", "<i4"), ("side", "i1"), ("pad_", "V3")])
+
+
+class IndexInfo(C.Structure):
+    _fields_ = [("n_windows", C.c_int64), ("n_kept", C.c_int64), ("n_unique", C.c_int64), ("n_points", C.c_int64),
+                ("threshold", C.c_uint64), ("filtered", C.c_int64), ("adjusted", C.c_int32), ("pad_", C.c_int32)]
 
 
 MINMER_DTYPE = np.dtype([("hash", "<u8"), ("wpos", "<i8"), ("wpos_end", "<i8"),
@@ -156,6 +165,38 @@ class SeqSet:
     def free(self):
         if self._p:
             self._h._L.wfm_free_sequences(self._h._p, self._p)
+            self._p = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Index:
+    def __init__(self, handle, ptr):
+        self._h, self._p = handle, ptr
+
+    def info(self):
+        inf = IndexInfo()
+        self._h._L.wfm_index_info(self._p, C.byref(inf))
+        return inf
+
+    def download(self):
+        inf = self.info()
+        uh = np.zeros(inf.n_unique, dtype=np.uint64)
+        po = np.zeros(inf.n_unique + 1, dtype=np.int64)
+        pts = np.zeros(inf.n_points, dtype=POINT_DTYPE)
+        mm = np.zeros(inf.n_kept, dtype=MINMER_DTYPE)
+        rc = self._h._L.wfm_index_download(self._h._p, self._p, uh.ctypes.data, po.ctypes.data, pts.ctypes.data, mm.ctypes.data)
+        if rc != 0:
+            raise WfmError(f"wfm_index_download failed ({rc})")
+        return uh, po, pts, mm
+
+    def free(self):
+        if self._p:
+            self._h._L.wfm_index_free(self._h._p, self._p)
             self._p = None
 
     def __del__(self):
@@ -264,6 +305,22 @@ class Handle:
         if rc < 0:
             raise WfmError(f"wfm_sketch_fragments failed ({rc}): {self.last_error()}")
         return [out[i * s:i * s + cnt[i]] for i in range(n)]
+
+    def index_build(self, minmers, max_kmer_freq=0.0002):
+        """wfm_index_build: device-resident reference index from the concatenated minmer intervals."""
+        m = np.ascontiguousarray(minmers, dtype=MINMER_DTYPE)
+        L = self._L
+        L.wfm_index_build.restype = C.c_int
+        L.wfm_index_build.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_double, C.POINTER(C.c_void_p)]
+        L.wfm_index_free.restype = None
+        L.wfm_index_free.argtypes = [C.c_void_p, C.c_void_p]
+        L.wfm_index_info.argtypes = [C.c_void_p, C.POINTER(IndexInfo)]
+        L.wfm_index_download.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        ix = C.c_void_p()
+        rc = L.wfm_index_build(self._p, m.ctypes.data, len(m), max_kmer_freq, C.byref(ix))
+        if rc != 0:
+            raise WfmError(f"wfm_index_build failed ({rc}): {self.last_error()}")
+        return Index(self, ix)
 
     def add_minmers(self, seq: bytes, k: int, w: int, s: int, seq_id: int = 0):
         """wfm_add_minmers: winnowed minmer intervals of one target sequence."""
