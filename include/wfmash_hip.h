@@ -191,6 +191,42 @@ int  wfm_index_download(wfm_handle_t* h, const wfm_index_t* ix, uint64_t* uhash,
 int64_t wfm_add_minmers(wfm_handle_t* h, const char* seq, int64_t len, int k, int w, int s, int32_t seq_id,
                         wfm_minmer_t* out, int64_t cap);
 
+/* L1 stage: getSeedIntervalPoints + computeL1CandidateRegions + doL1Mapping's group loop
+ * (mappingCore.hpp:82-301, computeMap.hpp:945-984) for a batch of query fragments against a
+ * device-resident index.  One candidate = skch::L1_candidateLocus_t (base_types.hpp:212-224)
+ * plus the fragment it belongs to; candidates come out grouped by fragment, in the reference's
+ * order within a fragment. */
+typedef struct {
+  int32_t  seqId;
+  int32_t  frag;              /* index of the query fragment in this call */
+  int64_t  rangeStartPos;
+  int64_t  rangeEndPos;
+  int32_t  intersectionSize;
+  int32_t  pad_;
+} wfm_l1_candidate_t;
+
+typedef struct {
+  int32_t  window_length;          /* Parameters::windowLength (= segment length; fragments are exactly this long) */
+  int32_t  sketch_size;            /* Parameters::sketchSize */
+  int32_t  min_hits_cached;        /* cached_minimum_hits (computeMap.hpp:155-160) */
+  int32_t  cached_segment_length;  /* cached_segment_length */
+  int32_t  skip_self, skip_prefix, lower_triangular;
+  int32_t  stage1_topANI_filter, stage2_full_scan;
+  int32_t  n_seq;                  /* number of sequences known to the SequenceIdManager */
+  const int32_t* ref_group;        /* [n_seq] idManager.getRefGroup(seqId) */
+  const int32_t* min_hits_by_qsketch; /* [sketch_size+1] Stat::estimateMinimumHitsRelaxed(q, k, ANI) for the non-cached length */
+  const int32_t* sketch_cutoffs;   /* [n_cutoffs] Stat::sketch_cutoffs table (computeMap.hpp:182-186) */
+  int32_t  n_cutoffs;
+  int32_t  pad_;
+} wfm_l1_params_t;
+
+/* qsketch: nfrag x s minmers (layout of wfm_sketch_fragments), qcount[f] of them valid.
+ * q_active[f] == 0 skips a fragment (kmerComplexity below the threshold, computeMap.hpp:951).
+ * Returns the number of candidates (may exceed cap; only cap are written) or a WFM_E_* code. */
+int64_t wfm_map_l1(wfm_handle_t* h, const wfm_index_t* ix, const wfm_minmer_t* qsketch, const int32_t* qcount,
+                   const int32_t* q_seq_id, const int32_t* q_len, const uint8_t* q_active, int64_t nfrag, int s,
+                   const wfm_l1_params_t* prm, wfm_l1_candidate_t* out, int64_t cap);
+
 #ifdef __cplusplus
 }
 #endif

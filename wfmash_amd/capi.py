@@ -24,6 +24,7 @@ EXPORTS = [
     "wfm_free_sequences", "wfm_align_resident", "wfm_get_stats",
     "wfm_hash_kmers", "wfm_sketch_fragments", "wfm_add_minmers",
     "wfm_index_build", "wfm_index_free", "wfm_index_info", "wfm_index_download",
+    "wfm_map_l1",
 ]
 
 
@@ -72,6 +73,16 @@ class IndexInfo(C.Structure):
 
 MINMER_DTYPE = np.dtype([("hash", "<u8"), ("wpos", "<i8"), ("wpos_end", "<i8"),
                          ("seqId", "<i4"), ("strand", "<i2"), ("pad_", "<i2")])
+L1_DTYPE = np.dtype([("seqId", "<i4"), ("frag", "<i4"), ("rangeStartPos", "<i8"), ("rangeEndPos", "<i8"),
+                     ("intersectionSize", "<i4"), ("pad_", "<i4")])
+
+
+class L1Params(C.Structure):
+    _fields_ = [("window_length", C.c_int32), ("sketch_size", C.c_int32), ("min_hits_cached", C.c_int32),
+                ("cached_segment_length", C.c_int32), ("skip_self", C.c_int32), ("skip_prefix", C.c_int32),
+                ("lower_triangular", C.c_int32), ("stage1_topANI_filter", C.c_int32), ("stage2_full_scan", C.c_int32),
+                ("n_seq", C.c_int32), ("ref_group", C.c_void_p), ("min_hits_by_qsketch", C.c_void_p),
+                ("sketch_cutoffs", C.c_void_p), ("n_cutoffs", C.c_int32), ("pad_", C.c_int32)]
 
 _LIB = None
 
@@ -321,6 +332,37 @@ class Handle:
         if rc != 0:
             raise WfmError(f"wfm_index_build failed ({rc}): {self.last_error()}")
         return Index(self, ix)
+
+    def map_l1(self, index, qsketch, qcount, q_seq_id, q_len, q_active, s, params, ref_group):
+        """wfm_map_l1: L1 candidate regions of a batch of query fragments.  params: the dict of oracle/map_l1.py."""
+        nfrag = len(qcount)
+        q = np.ascontiguousarray(qsketch, dtype=MINMER_DTYPE)
+        qc = np.ascontiguousarray(qcount, dtype=np.int32)
+        qs = np.ascontiguousarray(q_seq_id, dtype=np.int32)
+        ql = np.ascontiguousarray(q_len, dtype=np.int32)
+        qa = np.ascontiguousarray(q_active, dtype=np.uint8)
+        rg = np.ascontiguousarray(ref_group, dtype=np.int32)
+        mh = np.ascontiguousarray(params["min_hits_by_qsketch"], dtype=np.int32)
+        sc = np.ascontiguousarray(params["sketch_cutoffs"], dtype=np.int32)
+        assert len(q) == nfrag * s and len(mh) == params["sketch_size"] + 1
+        P = L1Params(params["window_length"], params["sketch_size"], params["min_hits_cached"], params["cached_segment_length"],
+                     int(params["skip_self"]), int(params["skip_prefix"]), int(params["lower_triangular"]),
+                     int(params["stage1_topani"]), int(params["stage2_full_scan"]), len(rg), rg.ctypes.data, mh.ctypes.data,
+                     sc.ctypes.data, len(sc), 0)
+        f = self._L.wfm_map_l1
+        f.restype = C.c_int64
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int,
+                      C.POINTER(L1Params), C.c_void_p, C.c_int64]
+        cap = 1 << 16
+        while True:
+            out = np.zeros(cap, dtype=L1_DTYPE)
+            n = f(self._p, index._p, q.ctypes.data, qc.ctypes.data, qs.ctypes.data, ql.ctypes.data, qa.ctypes.data, nfrag, s,
+                  C.byref(P), out.ctypes.data, cap)
+            if n < 0:
+                raise WfmError(f"wfm_map_l1 failed ({n}): {self.last_error()}")
+            if n <= cap:
+                return out[:n]
+            cap = int(n)
 
     def add_minmers(self, seq: bytes, k: int, w: int, s: int, seq_id: int = 0):
         """wfm_add_minmers: winnowed minmer intervals of one target sequence."""
