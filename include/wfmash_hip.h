@@ -227,6 +227,40 @@ int64_t wfm_map_l1(wfm_handle_t* h, const wfm_index_t* ix, const wfm_minmer_t* q
                    const int32_t* q_seq_id, const int32_t* q_len, const uint8_t* q_active, int64_t nfrag, int s,
                    const wfm_l1_params_t* prm, wfm_l1_candidate_t* out, int64_t cap);
 
+/* L2 stage: doL2Mapping + computeL2MappedRegions + SlideMapper (computeMap.hpp:989-1061,
+ * mappingCore.hpp:307-442, slidingMap.hpp:28-212) for a batch of L1 candidates.
+ * One mapping = skch::MappingResult (base_types.hpp:154-165), 28 bytes. */
+typedef struct {
+  uint32_t refSeqId;
+  uint32_t refStartPos;
+  uint32_t queryStartPos;      /* 0: relative to the fragment; the caller adds fragmentIndex * windowLength (computeMap.hpp:124-128) */
+  uint32_t blockLength;
+  uint32_t n_merged;
+  uint32_t conservedSketches;
+  uint16_t nucIdentity;        /* x 1e4 */
+  uint8_t  flags;              /* bit 0: reverse strand, bit 1: discard, bit 2: overlapped */
+  uint8_t  kmerComplexity;     /* x 100 */
+} wfm_mapping_t;
+
+typedef struct {
+  int32_t  window_length;
+  int32_t  sketch_size;            /* Parameters::sketchSize = S; tables below are (S+1) x (S+1), index Q.sketchSize * (S+1) + shared */
+  int32_t  stage1_topANI_filter;
+  int32_t  pad_;
+  const uint8_t*  keep_table;      /* identity test of computeMap.hpp:1018-1024 */
+  const uint16_t* ident_table;     /* MappingResult::setNucIdentity(1 - j2md(shared / Q.sketchSize)) */
+  const double*   cutoff_j;        /* [S+1] Jaccard cutoff of computeMap.hpp:1001-1004 per Q.sketchSize */
+} wfm_l2_params_t;
+
+/* q_kmer_complexity[f]: MappingResult::setKmerComplexity(Q.kmerComplexity) already scaled.
+ * Mappings come out grouped by fragment, sorted by (refSeqId, refStartPos) within a fragment
+ * (computeMap.hpp:920-921); out_frag[i] is the fragment of out[i].  Returns the number of
+ * mappings (may exceed cap; only cap are written) or a WFM_E_* code. */
+int64_t wfm_map_l2(wfm_handle_t* h, const wfm_index_t* ix, const wfm_minmer_t* qsketch, const int32_t* qcount,
+                   const int32_t* q_len, const uint8_t* q_kmer_complexity, int64_t nfrag, int s,
+                   const wfm_l1_candidate_t* cands, int64_t ncand, const wfm_l2_params_t* prm,
+                   wfm_mapping_t* out, int32_t* out_frag, int64_t cap);
+
 #ifdef __cplusplus
 }
 #endif

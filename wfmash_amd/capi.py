@@ -24,7 +24,7 @@ EXPORTS = [
     "wfm_free_sequences", "wfm_align_resident", "wfm_get_stats",
     "wfm_hash_kmers", "wfm_sketch_fragments", "wfm_add_minmers",
     "wfm_index_build", "wfm_index_free", "wfm_index_info", "wfm_index_download",
-    "wfm_map_l1",
+    "wfm_map_l1", "wfm_map_l2",
 ]
 
 
@@ -75,6 +75,16 @@ MINMER_DTYPE = np.dtype([("hash", "<u8"), ("wpos", "<i8"), ("wpos_end", "<i8"),
                          ("seqId", "<i4"), ("strand", "<i2"), ("pad_", "<i2")])
 L1_DTYPE = np.dtype([("seqId", "<i4"), ("frag", "<i4"), ("rangeStartPos", "<i8"), ("rangeEndPos", "<i8"),
                      ("intersectionSize", "<i4"), ("pad_", "<i4")])
+
+
+MAPPING_DTYPE = np.dtype([("refSeqId", "<u4"), ("refStartPos", "<u4"), ("queryStartPos", "<u4"), ("blockLength", "<u4"),
+                          ("n_merged", "<u4"), ("conservedSketches", "<u4"), ("nucIdentity", "<u2"), ("flags", "u1"),
+                          ("kmerComplexity", "u1")])
+
+
+class L2Params(C.Structure):
+    _fields_ = [("window_length", C.c_int32), ("sketch_size", C.c_int32), ("stage1_topANI_filter", C.c_int32), ("pad_", C.c_int32),
+                ("keep_table", C.c_void_p), ("ident_table", C.c_void_p), ("cutoff_j", C.c_void_p)]
 
 
 class L1Params(C.Structure):
@@ -362,6 +372,38 @@ class Handle:
                 raise WfmError(f"wfm_map_l1 failed ({n}): {self.last_error()}")
             if n <= cap:
                 return out[:n]
+            cap = int(n)
+
+    def map_l2(self, index, qsketch, qcount, q_len, q_kc, s, cands, params):
+        """wfm_map_l2: mappings (MAPPING_DTYPE) + fragment ids for a batch of L1 candidates.
+        params: dict(window_length, sketch_size, stage1_topani, keep_table, ident_table, cutoff_j)."""
+        nfrag = len(qcount)
+        q = np.ascontiguousarray(qsketch, dtype=MINMER_DTYPE)
+        qc = np.ascontiguousarray(qcount, dtype=np.int32)
+        ql = np.ascontiguousarray(q_len, dtype=np.int32)
+        kc = np.ascontiguousarray(q_kc, dtype=np.uint8)
+        cd = np.ascontiguousarray(cands, dtype=L1_DTYPE)
+        keep = np.ascontiguousarray(params["keep_table"], dtype=np.uint8)
+        ident = np.ascontiguousarray(params["ident_table"], dtype=np.uint16)
+        cut = np.ascontiguousarray(params["cutoff_j"], dtype=np.float64)
+        S1 = params["sketch_size"] + 1
+        assert keep.size == S1 * S1 and ident.size == S1 * S1 and cut.size == S1 and len(q) == nfrag * s
+        P = L2Params(params["window_length"], params["sketch_size"], int(params["stage1_topani"]), 0, keep.ctypes.data,
+                     ident.ctypes.data, cut.ctypes.data)
+        f = self._L.wfm_map_l2
+        f.restype = C.c_int64
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p,
+                      C.c_int64, C.POINTER(L2Params), C.c_void_p, C.c_void_p, C.c_int64]
+        cap = 1 << 16
+        while True:
+            out = np.zeros(cap, dtype=MAPPING_DTYPE)
+            frag = np.zeros(cap, dtype=np.int32)
+            n = f(self._p, index._p, q.ctypes.data, qc.ctypes.data, ql.ctypes.data, kc.ctypes.data, nfrag, s, cd.ctypes.data, len(cd),
+                  C.byref(P), out.ctypes.data, frag.ctypes.data, cap)
+            if n < 0:
+                raise WfmError(f"wfm_map_l2 failed ({n}): {self.last_error()}")
+            if n <= cap:
+                return out[:n], frag[:n]
             cap = int(n)
 
     def add_minmers(self, seq: bytes, k: int, w: int, s: int, seq_id: int = 0):
