@@ -261,6 +261,20 @@ int64_t wfm_map_l2(wfm_handle_t* h, const wfm_index_t* ix, const wfm_minmer_t* q
                    const wfm_l1_candidate_t* cands, int64_t ncand, const wfm_l2_params_t* prm,
                    wfm_mapping_t* out, int32_t* out_frag, int64_t cap);
 
+/* The fused per-batch map path: Map::mapSingleQueryFrag (computeMap.hpp:875-938) for nfrag
+ * fragments of window_length bases each, fragment f = seq[frag_off[f] .. +window_length) belonging
+ * to query sequence frag_seq_id[f].  Sketches, interval points and candidates never leave the
+ * device.  Output as wfm_map_l2. */
+typedef struct {
+  int32_t  kmer_size;
+  float    kmer_complexity_threshold;   /* Parameters::kmerComplexityThreshold (computeMap.hpp:951) */
+  wfm_l1_params_t l1;
+  wfm_l2_params_t l2;
+} wfm_map_params_t;
+int64_t wfm_map_fragments(wfm_handle_t* h, const wfm_index_t* ix, const char* seq, int64_t seq_len,
+                          const int64_t* frag_off, const int32_t* frag_seq_id, int64_t nfrag,
+                          const wfm_map_params_t* prm, wfm_mapping_t* out, int32_t* out_frag, int64_t cap);
+
 #ifdef __cplusplus
 }
 #endif

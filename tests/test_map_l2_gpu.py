@@ -66,3 +66,39 @@ def test_l2_high_identity_threshold_and_no_prefix_filter(gpu):
     assert 0 < len(strict) < len(loose)
     _run(gpu, seqs, group, 500, 16, 0.9, skip_self=False, skip_prefix=False)
     _run(gpu, seqs, group, 500, 16, 0.9, stage1_topani=False)
+
+
+def test_fused_map_fragments_equals_staged_path(gpu):
+    """wfm_map_fragments (device-resident sketch -> L1 -> L2) against the staged calls, which the
+    tests above pin against the restatement."""
+    seqs, group = _pangenome(19, L=20000)
+    w, s, ident = 1000, 25, 0.85
+    p1 = _params(w, s, ident)
+    mm = np.concatenate([gpu.add_minmers(sq, K, w, s, sid) for sid, sq in enumerate(seqs)])
+    ix = gpu.index_build(mm)
+    keep, idt = L2.identity_tables(s, K, ident)
+    p2 = dict(window_length=w, sketch_size=s, stage1_topani=True, keep_table=keep, ident_table=idt,
+              cutoff_j=[0.0] + [L2.cutoff_j(q, K) for q in range(1, s + 1)])
+    buf = b"".join(seqs)
+    base = np.cumsum([0] + [len(x) for x in seqs])
+    off, sid_of, sk = [], [], []
+    for sid, sq in enumerate(seqs):
+        o = _fragments(len(sq), w)
+        off += [int(base[sid]) + x for x in o]
+        sid_of += [sid] * len(o)
+        sk += gpu.sketch_fragments(sq, o, [w] * len(o), K, s, sid)
+    nfrag = len(off)
+    flat = np.zeros(nfrag * s, dtype=sk[0].dtype)
+    for f, m in enumerate(sk):
+        flat[f * s:f * s + len(m)] = m
+    qcount = [len(m) for m in sk]
+    kc = [L2.kmer_complexity(int(m["hash"][-1]), len(m), w, K)[1] for m in sk]
+    cands = gpu.map_l1(ix, flat, qcount, sid_of, [w] * nfrag, [1] * nfrag, s, p1, group)
+    exp, efrag = gpu.map_l2(ix, flat, qcount, [w] * nfrag, kc, s, cands, p2)
+    got, gfrag = gpu.map_fragments(ix, buf, off, sid_of, K, p1, p2, group)
+    assert len(got) == len(exp) > 100
+    assert (gfrag == efrag).all() and got.tobytes() == exp.tobytes()
+    # a complexity threshold above every fragment's complexity switches the whole batch off (computeMap.hpp:951)
+    none, _ = gpu.map_fragments(ix, buf, off, sid_of, K, p1, p2, group, kc_threshold=10.0)
+    assert len(none) == 0
+    ix.free()

@@ -24,7 +24,7 @@ EXPORTS = [
     "wfm_free_sequences", "wfm_align_resident", "wfm_get_stats",
     "wfm_hash_kmers", "wfm_sketch_fragments", "wfm_add_minmers",
     "wfm_index_build", "wfm_index_free", "wfm_index_info", "wfm_index_download",
-    "wfm_map_l1", "wfm_map_l2",
+    "wfm_map_l1", "wfm_map_l2", "wfm_map_fragments",
 ]
 
 
@@ -77,6 +77,10 @@ L1_DTYPE = np.dtype([("seqId", "<i4"), ("frag", "<i4"), ("rangeStartPos", "<i8")
                      ("intersectionSize", "<i4"), ("pad_", "<i4")])
 
 
+class MapParams(C.Structure):
+    pass  # fields set after L1Params / L2Params are defined
+
+
 MAPPING_DTYPE = np.dtype([("refSeqId", "<u4"), ("refStartPos", "<u4"), ("queryStartPos", "<u4"), ("blockLength", "<u4"),
                           ("n_merged", "<u4"), ("conservedSketches", "<u4"), ("nucIdentity", "<u2"), ("flags", "u1"),
                           ("kmerComplexity", "u1")])
@@ -93,6 +97,9 @@ class L1Params(C.Structure):
                 ("lower_triangular", C.c_int32), ("stage1_topANI_filter", C.c_int32), ("stage2_full_scan", C.c_int32),
                 ("n_seq", C.c_int32), ("ref_group", C.c_void_p), ("min_hits_by_qsketch", C.c_void_p),
                 ("sketch_cutoffs", C.c_void_p), ("n_cutoffs", C.c_int32), ("pad_", C.c_int32)]
+
+
+MapParams._fields_ = [("kmer_size", C.c_int32), ("kmer_complexity_threshold", C.c_float), ("l1", L1Params), ("l2", L2Params)]
 
 _LIB = None
 
@@ -372,6 +379,41 @@ class Handle:
                 raise WfmError(f"wfm_map_l1 failed ({n}): {self.last_error()}")
             if n <= cap:
                 return out[:n]
+            cap = int(n)
+
+    def map_fragments(self, index, seq: bytes, frag_off, frag_seq_id, k, p1, p2, ref_group, kc_threshold=0.0):
+        """wfm_map_fragments: sketch -> L1 -> L2 for fragments of p1["window_length"] bases of one buffer."""
+        off = np.ascontiguousarray(frag_off, dtype=np.int64)
+        sid = np.ascontiguousarray(frag_seq_id, dtype=np.int32)
+        rg = np.ascontiguousarray(ref_group, dtype=np.int32)
+        mh = np.ascontiguousarray(p1["min_hits_by_qsketch"], dtype=np.int32)
+        sc = np.ascontiguousarray(p1["sketch_cutoffs"], dtype=np.int32)
+        keep = np.ascontiguousarray(p2["keep_table"], dtype=np.uint8)
+        ident = np.ascontiguousarray(p2["ident_table"], dtype=np.uint16)
+        cut = np.ascontiguousarray(p2["cutoff_j"], dtype=np.float64)
+        P = MapParams()
+        P.kmer_size = k
+        P.kmer_complexity_threshold = kc_threshold
+        P.l1 = L1Params(p1["window_length"], p1["sketch_size"], p1["min_hits_cached"], p1["cached_segment_length"],
+                        int(p1["skip_self"]), int(p1["skip_prefix"]), int(p1["lower_triangular"]), int(p1["stage1_topani"]),
+                        int(p1["stage2_full_scan"]), len(rg), rg.ctypes.data, mh.ctypes.data, sc.ctypes.data, len(sc), 0)
+        P.l2 = L2Params(p2["window_length"], p2["sketch_size"], int(p2["stage1_topani"]), 0, keep.ctypes.data, ident.ctypes.data,
+                        cut.ctypes.data)
+        buf = np.frombuffer(seq, dtype=np.uint8)
+        f = self._L.wfm_map_fragments
+        f.restype = C.c_int64
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(MapParams),
+                      C.c_void_p, C.c_void_p, C.c_int64]
+        cap = 1 << 16
+        while True:
+            out = np.zeros(cap, dtype=MAPPING_DTYPE)
+            frag = np.zeros(cap, dtype=np.int32)
+            n = f(self._p, index._p, buf.ctypes.data, len(seq), off.ctypes.data, sid.ctypes.data, len(off), C.byref(P),
+                  out.ctypes.data, frag.ctypes.data, cap)
+            if n < 0:
+                raise WfmError(f"wfm_map_fragments failed ({n}): {self.last_error()}")
+            if n <= cap:
+                return out[:n], frag[:n]
             cap = int(n)
 
     def map_l2(self, index, qsketch, qcount, q_len, q_kc, s, cands, params):

@@ -1,0 +1,41 @@
+// map_device.h -- device-pointer entry points of the map stages, shared by the per-stage C ABI
+// wrappers and the fused wfm_map_fragments path (map_fragments.hip).
+#ifndef WFM_MAP_DEVICE_H_
+#define WFM_MAP_DEVICE_H_
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "../../include/wfmash_hip.h"
+#include "wfa_handle.h"
+
+// device allocations that live until the owning call returns
+struct MapScratch {
+  std::vector<void*> p;
+  MapScratch() = default;
+  MapScratch(const MapScratch&) = delete;
+  MapScratch& operator=(const MapScratch&) = delete;
+  ~MapScratch() { for (void* q : p) if (q) (void)hipFree(q); }
+  template <typename T> hipError_t alloc(T** out, size_t n) {
+    hipError_t e = hipMalloc((void**)out, std::max<size_t>(n, 1) * sizeof(T));
+    if (e == hipSuccess) p.push_back(*out);
+    return e;
+  }
+};
+
+// sketchSequence of n fragments of one host buffer; results stay on the device (n x s minmers + counts)
+int map_sketch_device(wfm_handle_t* h, MapScratch& sc, const char* seq, int64_t seq_len, const int64_t* frag_off,
+                      const int32_t* frag_len, size_t n, int k, int s, int32_t seq_id, wfm_minmer_t** d_out, int32_t** d_cnt);
+
+// L1 on device-resident sketches; prm's tables are host pointers.  *d_cands is owned by sc.
+int map_l1_device(wfm_handle_t* h, MapScratch& sc, const wfm_index_t* ix, const wfm_minmer_t* d_q, const int32_t* d_qcount,
+                  const int32_t* d_qseq, const int32_t* d_qlen, const uint8_t* d_active, int64_t nfrag, int s,
+                  const wfm_l1_params_t* prm, wfm_l1_candidate_t** d_cands, int64_t* ncand);
+
+// L2 on device-resident sketches and candidates.  *d_out / *d_frag are owned by sc.
+int map_l2_device(wfm_handle_t* h, MapScratch& sc, const wfm_index_t* ix, const wfm_minmer_t* d_q, const int32_t* d_qcount,
+                  const int32_t* d_qlen, const uint8_t* d_kc, int64_t nfrag, int s, const wfm_l1_candidate_t* d_cands,
+                  int64_t ncand, const wfm_l2_params_t* prm, wfm_mapping_t** d_out, int32_t** d_frag, int64_t* n_out);
+#endif

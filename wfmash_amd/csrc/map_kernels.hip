@@ -17,6 +17,7 @@
 
 #include "../../include/wfmash_hip.h"
 #include "wfa_handle.h"
+#include "map_device.h"
 
 namespace wfm {
 
@@ -240,6 +241,42 @@ int upload_normalised(wfm_handle_t* h, Scoped& sc, const char* seq, int64_t len,
 }
 }  // namespace
 
+int map_sketch_device(wfm_handle_t* h, MapScratch& ms, const char* seq, int64_t seq_len, const int64_t* frag_off,
+                      const int32_t* frag_len, size_t n, int k, int s, int32_t seq_id, wfm_minmer_t** d_out_p, int32_t** d_cnt_p) {
+  if (k < 1 || k > 32 || s < 1) { wfm_set_error(h, "k must be in 1..32 and s >= 1"); return WFM_E_UNSUPPORTED; }
+  int maxk = 1;
+  for (size_t i = 0; i < n; ++i) {
+    if (frag_off[i] < 0 || frag_len[i] < 0 || frag_off[i] + frag_len[i] > seq_len) { wfm_set_error(h, "fragment out of range"); return WFM_E_ARG; }
+    maxk = std::max(maxk, frag_len[i] - k + 1);
+  }
+  int npow2 = 512;
+  while (npow2 < maxk) npow2 <<= 1;
+  const size_t lds = (size_t)npow2 * 12 + (size_t)s * 4 + 64;
+  if (lds > 160 * 1024) { wfm_set_error(h, "fragment too long for the LDS sort (max 8192 k-mers)"); return WFM_E_UNSUPPORTED; }
+  HIPCHK(h, hipSetDevice(wfm_device(h)));
+  Scoped sc;  // the raw / normalised sequence copies are only needed until the sketch kernel has run
+  uint8_t* d_norm = nullptr;
+  int rc = upload_normalised(h, sc, seq, seq_len, &d_norm);
+  if (rc != WFM_OK) return rc;
+  int64_t* d_off = nullptr; int32_t* d_len = nullptr; wfm_minmer_t* d_out = nullptr; int32_t* d_cnt = nullptr;
+  HIPCHK(h, sc.alloc(&d_off, n * 8));
+  HIPCHK(h, sc.alloc(&d_len, n * 4));
+  HIPCHK(h, ms.alloc(&d_out, n * (size_t)s));
+  HIPCHK(h, ms.alloc(&d_cnt, n));
+  hipStream_t st = wfm_stream(h);
+  HIPCHK(h, hipMemcpyAsync(d_off, frag_off, n * 8, hipMemcpyHostToDevice, st));
+  HIPCHK(h, hipMemcpyAsync(d_len, frag_len, n * 4, hipMemcpyHostToDevice, st));
+  HIPCHK(h, hipMemsetAsync(d_out, 0, n * (size_t)s * sizeof(wfm_minmer_t), st));
+  if (lds > 64 * 1024) {
+    HIPCHK(h, hipFuncSetAttribute((const void*)sketch_fragments_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  }
+  hipLaunchKernelGGL(sketch_fragments_kernel, dim3((unsigned)n), dim3(256), lds, st, d_norm, d_off, d_len, k, s, seq_id, npow2, d_out, d_cnt);
+  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, hipStreamSynchronize(st));  // d_norm / d_off / d_len are released on return
+  *d_out_p = d_out; *d_cnt_p = d_cnt;
+  return WFM_OK;
+}
+
 extern "C" {
 
 int wfm_hash_kmers(wfm_handle_t* h, const char* seq, int64_t len, int k, uint64_t* hash, int8_t* strand) {
@@ -269,36 +306,12 @@ int wfm_sketch_fragments(wfm_handle_t* h, const char* seq, int64_t seq_len, cons
                          const int32_t* frag_len, size_t n, int k, int s, int32_t seq_id,
                          wfm_minmer_t* out, int32_t* out_count) {
   if (!h || !seq || (n && (!frag_off || !frag_len || !out || !out_count)) || seq_len < 0) return WFM_E_ARG;
-  if (k < 1 || k > 32 || s < 1) { wfm_set_error(h, "k must be in 1..32 and s >= 1"); return WFM_E_UNSUPPORTED; }
   if (n == 0) return WFM_OK;
-  int maxk = 1;
-  for (size_t i = 0; i < n; ++i) {
-    if (frag_off[i] < 0 || frag_len[i] < 0 || frag_off[i] + frag_len[i] > seq_len) { wfm_set_error(h, "fragment out of range"); return WFM_E_ARG; }
-    maxk = std::max(maxk, frag_len[i] - k + 1);
-  }
-  int npow2 = 512;
-  while (npow2 < maxk) npow2 <<= 1;
-  const size_t lds = (size_t)npow2 * 12 + (size_t)s * 4 + 64;
-  if (lds > 160 * 1024) { wfm_set_error(h, "fragment too long for the LDS sort (max 8192 k-mers)"); return WFM_E_UNSUPPORTED; }
-  HIPCHK(h, hipSetDevice(wfm_device(h)));
-  Scoped sc;
-  uint8_t* d_norm = nullptr;
-  int rc = upload_normalised(h, sc, seq, seq_len, &d_norm);
+  MapScratch sc;
+  wfm_minmer_t* d_out = nullptr; int32_t* d_cnt = nullptr;
+  const int rc = map_sketch_device(h, sc, seq, seq_len, frag_off, frag_len, n, k, s, seq_id, &d_out, &d_cnt);
   if (rc != WFM_OK) return rc;
-  int64_t* d_off = nullptr; int32_t* d_len = nullptr; wfm_minmer_t* d_out = nullptr; int32_t* d_cnt = nullptr;
-  HIPCHK(h, sc.alloc(&d_off, n * 8));
-  HIPCHK(h, sc.alloc(&d_len, n * 4));
-  HIPCHK(h, sc.alloc(&d_out, n * (size_t)s * sizeof(wfm_minmer_t)));
-  HIPCHK(h, sc.alloc(&d_cnt, n * 4));
   hipStream_t st = wfm_stream(h);
-  HIPCHK(h, hipMemcpyAsync(d_off, frag_off, n * 8, hipMemcpyHostToDevice, st));
-  HIPCHK(h, hipMemcpyAsync(d_len, frag_len, n * 4, hipMemcpyHostToDevice, st));
-  HIPCHK(h, hipMemsetAsync(d_out, 0, n * (size_t)s * sizeof(wfm_minmer_t), st));
-  if (lds > 64 * 1024) {
-    HIPCHK(h, hipFuncSetAttribute((const void*)sketch_fragments_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  }
-  hipLaunchKernelGGL(sketch_fragments_kernel, dim3((unsigned)n), dim3(256), lds, st, d_norm, d_off, d_len, k, s, seq_id, npow2, d_out, d_cnt);
-  HIPCHK(h, hipGetLastError());
   HIPCHK(h, hipMemcpyAsync(out, d_out, n * (size_t)s * sizeof(wfm_minmer_t), hipMemcpyDeviceToHost, st));
   HIPCHK(h, hipMemcpyAsync(out_count, d_cnt, n * 4, hipMemcpyDeviceToHost, st));
   HIPCHK(h, hipStreamSynchronize(st));

@@ -28,6 +28,7 @@
 
 #include "../../include/wfmash_hip.h"
 #include "wfa_handle.h"
+#include "map_device.h"
 
 const uint64_t* wfm_index_uhash(const wfm_index_t* ix);
 const int64_t* wfm_index_poff(const wfm_index_t* ix);
@@ -45,15 +46,7 @@ namespace {
     }                                                                                   \
   } while (0)
 
-struct Scratch {
-  std::vector<void*> p;
-  ~Scratch() { for (void* q : p) if (q) (void)hipFree(q); }
-  template <typename T> hipError_t alloc(T** out, size_t n) {
-    hipError_t e = hipMalloc((void**)out, std::max<size_t>(n, 1) * sizeof(T));
-    if (e == hipSuccess) p.push_back(*out);
-    return e;
-  }
-};
+using Scratch = MapScratch;
 
 constexpr int POS_BITS = 41;  // pos < 2^41, seqId < 2^22
 __device__ __forceinline__ uint64_t pack_key(int32_t seq, int64_t pos, int side) {
@@ -229,35 +222,24 @@ int exclusive_scan_u64(wfm_handle_t* h, Scratch& sc, const T* in, uint64_t* out,
 
 }  // namespace
 
-extern "C" int64_t wfm_map_l1(wfm_handle_t* h, const wfm_index_t* ix, const wfm_minmer_t* qsketch, const int32_t* qcount,
-                              const int32_t* q_seq_id, const int32_t* q_len, const uint8_t* q_active, int64_t nfrag, int s,
-                              const wfm_l1_params_t* prm, wfm_l1_candidate_t* out, int64_t cap) {
-  if (!h || !ix || !prm || (nfrag && (!qsketch || !qcount || !q_seq_id || !q_len || !q_active)) || nfrag < 0 || s < 1) return WFM_E_ARG;
-  if (!prm->ref_group || !prm->min_hits_by_qsketch || !prm->sketch_cutoffs || prm->n_cutoffs < 1) return WFM_E_ARG;
-  for (int64_t f = 0; f < nfrag; ++f)
-    if (q_active[f] && qcount[f] > 0 && q_len[f] != prm->window_length) { wfm_set_error(h, "wfm_map_l1: fragments must be window_length long"); return WFM_E_UNSUPPORTED; }
-  if (nfrag == 0) return 0;
-  HIPCHK(h, hipSetDevice(wfm_device(h)));
+int map_l1_device(wfm_handle_t* h, MapScratch& sc, const wfm_index_t* ix, const wfm_minmer_t* d_q, const int32_t* d_qcount,
+                  const int32_t* d_qseq, const int32_t* d_qlen, const uint8_t* d_act, int64_t nfrag, int s,
+                  const wfm_l1_params_t* prm, wfm_l1_candidate_t** d_cands, int64_t* ncand) {
+  *d_cands = nullptr; *ncand = 0;
+  if (nfrag == 0) return WFM_OK;
   hipStream_t st = wfm_stream(h);
-  Scratch sc;
   DevParams P;
   P.w = prm->window_length; P.sketch_size = prm->sketch_size; P.min_hits_cached = prm->min_hits_cached;
   P.cached_segment_length = prm->cached_segment_length;
   P.skip_self = prm->skip_self; P.skip_prefix = prm->skip_prefix; P.lower_triangular = prm->lower_triangular;
   P.stage1_topani = prm->stage1_topANI_filter; P.stage2_full_scan = prm->stage2_full_scan;
   P.n_cutoffs = prm->n_cutoffs; P.n_seq = prm->n_seq;
-  P.cutoff_div = std::max(1.0, (double)prm->sketch_size / 1000.0);
-  wfm_minmer_t* d_q = nullptr; int32_t *d_qcount = nullptr, *d_qseq = nullptr, *d_qlen = nullptr, *d_group = nullptr, *d_minhits = nullptr, *d_cut = nullptr, *d_slot = nullptr;
-  uint8_t* d_act = nullptr; uint32_t *d_cap = nullptr, *d_cnt = nullptr, *d_ocount = nullptr; uint64_t *d_off = nullptr, *d_ooff = nullptr;
+  P.cutoff_div = std::max(1.0, (double)prm->sketch_size / 1000.0);  // fixed::ss_table_max
+  int32_t *d_group = nullptr, *d_minhits = nullptr, *d_cut = nullptr, *d_slot = nullptr;
+  uint32_t *d_cap = nullptr, *d_cnt = nullptr, *d_ocount = nullptr; uint64_t *d_off = nullptr, *d_ooff = nullptr;
 #define ALLOC(p, n) do { if (sc.alloc(&(p), (size_t)(n)) != hipSuccess) { wfm_set_error(h, "out of device memory (L1)"); return WFM_E_NOMEM; } } while (0)
-  ALLOC(d_q, nfrag * s); ALLOC(d_qcount, nfrag); ALLOC(d_qseq, nfrag); ALLOC(d_qlen, nfrag); ALLOC(d_act, nfrag);
   ALLOC(d_group, prm->n_seq); ALLOC(d_minhits, prm->sketch_size + 1); ALLOC(d_cut, prm->n_cutoffs); ALLOC(d_slot, nfrag * s);
   ALLOC(d_cap, nfrag); ALLOC(d_cnt, nfrag); ALLOC(d_ocount, nfrag); ALLOC(d_off, nfrag + 1); ALLOC(d_ooff, nfrag + 1);
-  HIPCHK(h, hipMemcpyAsync(d_q, qsketch, (size_t)nfrag * s * sizeof(wfm_minmer_t), hipMemcpyHostToDevice, st));
-  HIPCHK(h, hipMemcpyAsync(d_qcount, qcount, (size_t)nfrag * 4, hipMemcpyHostToDevice, st));
-  HIPCHK(h, hipMemcpyAsync(d_qseq, q_seq_id, (size_t)nfrag * 4, hipMemcpyHostToDevice, st));
-  HIPCHK(h, hipMemcpyAsync(d_qlen, q_len, (size_t)nfrag * 4, hipMemcpyHostToDevice, st));
-  HIPCHK(h, hipMemcpyAsync(d_act, q_active, (size_t)nfrag, hipMemcpyHostToDevice, st));
   HIPCHK(h, hipMemcpyAsync(d_group, prm->ref_group, (size_t)prm->n_seq * 4, hipMemcpyHostToDevice, st));
   HIPCHK(h, hipMemcpyAsync(d_minhits, prm->min_hits_by_qsketch, (size_t)(prm->sketch_size + 1) * 4, hipMemcpyHostToDevice, st));
   HIPCHK(h, hipMemcpyAsync(d_cut, prm->sketch_cutoffs, (size_t)prm->n_cutoffs * 4, hipMemcpyHostToDevice, st));
@@ -298,15 +280,44 @@ extern "C" int64_t wfm_map_l1(wfm_handle_t* h, const wfm_index_t* ix, const wfm_
   HIPCHK(h, hipMemcpyAsync(&lc2, d_ocount + (nfrag - 1), 4, hipMemcpyDeviceToHost, st));
   HIPCHK(h, hipStreamSynchronize(st));
   const int64_t n_out = (int64_t)(lo2 + lc2);
-  if (n_out > 0 && out && cap > 0) {
+  if (n_out > 0) {
     wfm_l1_candidate_t* d_out = nullptr;
     ALLOC(d_out, n_out);
     hipLaunchKernelGGL(l1_sweep_kernel, g, b, 0, st, d_keys2, d_off, d_cnt, d_qcount, d_qlen, d_act, d_group, d_minhits, d_cut, nfrag, P,
                        d_ocount, d_ooff, d_out);
     HIPCHK(h, hipGetLastError());
-    HIPCHK(h, hipMemcpyAsync(out, d_out, (size_t)std::min(n_out, cap) * sizeof(wfm_l1_candidate_t), hipMemcpyDeviceToHost, st));
-    HIPCHK(h, hipStreamSynchronize(st));
+    *d_cands = d_out;
   }
 #undef ALLOC
+  *ncand = n_out;
+  return WFM_OK;
+}
+
+extern "C" int64_t wfm_map_l1(wfm_handle_t* h, const wfm_index_t* ix, const wfm_minmer_t* qsketch, const int32_t* qcount,
+                              const int32_t* q_seq_id, const int32_t* q_len, const uint8_t* q_active, int64_t nfrag, int s,
+                              const wfm_l1_params_t* prm, wfm_l1_candidate_t* out, int64_t cap) {
+  if (!h || !ix || !prm || (nfrag && (!qsketch || !qcount || !q_seq_id || !q_len || !q_active)) || nfrag < 0 || s < 1) return WFM_E_ARG;
+  if (!prm->ref_group || !prm->min_hits_by_qsketch || !prm->sketch_cutoffs || prm->n_cutoffs < 1) return WFM_E_ARG;
+  for (int64_t f = 0; f < nfrag; ++f)
+    if (q_active[f] && qcount[f] > 0 && q_len[f] != prm->window_length) { wfm_set_error(h, "wfm_map_l1: fragments must be window_length long"); return WFM_E_UNSUPPORTED; }
+  if (nfrag == 0) return 0;
+  HIPCHK(h, hipSetDevice(wfm_device(h)));
+  hipStream_t st = wfm_stream(h);
+  MapScratch sc;
+  wfm_minmer_t* d_q = nullptr; int32_t *d_qcount = nullptr, *d_qseq = nullptr, *d_qlen = nullptr; uint8_t* d_act = nullptr;
+  if (sc.alloc(&d_q, (size_t)nfrag * s) != hipSuccess || sc.alloc(&d_qcount, nfrag) != hipSuccess || sc.alloc(&d_qseq, nfrag) != hipSuccess ||
+      sc.alloc(&d_qlen, nfrag) != hipSuccess || sc.alloc(&d_act, nfrag) != hipSuccess) { wfm_set_error(h, "out of device memory (L1)"); return WFM_E_NOMEM; }
+  HIPCHK(h, hipMemcpyAsync(d_q, qsketch, (size_t)nfrag * s * sizeof(wfm_minmer_t), hipMemcpyHostToDevice, st));
+  HIPCHK(h, hipMemcpyAsync(d_qcount, qcount, (size_t)nfrag * 4, hipMemcpyHostToDevice, st));
+  HIPCHK(h, hipMemcpyAsync(d_qseq, q_seq_id, (size_t)nfrag * 4, hipMemcpyHostToDevice, st));
+  HIPCHK(h, hipMemcpyAsync(d_qlen, q_len, (size_t)nfrag * 4, hipMemcpyHostToDevice, st));
+  HIPCHK(h, hipMemcpyAsync(d_act, q_active, (size_t)nfrag, hipMemcpyHostToDevice, st));
+  wfm_l1_candidate_t* d_out = nullptr; int64_t n_out = 0;
+  const int rc = map_l1_device(h, sc, ix, d_q, d_qcount, d_qseq, d_qlen, d_act, nfrag, s, prm, &d_out, &n_out);
+  if (rc != WFM_OK) return rc;
+  if (n_out > 0 && out && cap > 0) {
+    HIPCHK(h, hipMemcpyAsync(out, d_out, (size_t)std::min(n_out, cap) * sizeof(wfm_l1_candidate_t), hipMemcpyDeviceToHost, st));
+  }
+  HIPCHK(h, hipStreamSynchronize(st));
   return n_out;
 }

@@ -27,6 +27,7 @@
 
 #include "../../include/wfmash_hip.h"
 #include "wfa_handle.h"
+#include "map_device.h"
 
 const wfm_minmer_t* wfm_index_minmers(const wfm_index_t* ix);
 int64_t wfm_index_n_kept(const wfm_index_t* ix);
@@ -42,15 +43,7 @@ namespace {
     }                                                                                   \
   } while (0)
 
-struct Scratch {
-  std::vector<void*> p;
-  ~Scratch() { for (void* q : p) if (q) (void)hipFree(q); }
-  template <typename T> hipError_t alloc(T** out, size_t n) {
-    hipError_t e = hipMalloc((void**)out, std::max<size_t>(n, 1) * sizeof(T));
-    if (e == hipSuccess) p.push_back(*out);
-    return e;
-  }
-};
+using Scratch = MapScratch;
 
 struct Slot { uint32_t nbi; int16_t vote; uint8_t active; int8_t qstrand; };  // slidingMapContainerValueType minus the hash
 struct HeapEnt { int64_t wpos_end; int64_t idx; };
@@ -314,37 +307,23 @@ int total_of(wfm_handle_t* h, const uint64_t* d_off, const uint32_t* d_cnt, int6
 
 }  // namespace
 
-extern "C" int64_t wfm_map_l2(wfm_handle_t* h, const wfm_index_t* ix, const wfm_minmer_t* qsketch, const int32_t* qcount, const int32_t* q_len,
-                              const uint8_t* q_kmer_complexity, int64_t nfrag, int s, const wfm_l1_candidate_t* cands, int64_t ncand,
-                              const wfm_l2_params_t* prm, wfm_mapping_t* out, int32_t* out_frag, int64_t cap) {
-  if (!h || !ix || !prm || nfrag < 0 || ncand < 0 || s < 1 || (nfrag && (!qsketch || !qcount || !q_len || !q_kmer_complexity)) || (ncand && !cands))
-    return WFM_E_ARG;
-  if (!prm->keep_table || !prm->ident_table || !prm->cutoff_j || prm->sketch_size < 1 || s > prm->sketch_size) return WFM_E_ARG;
-  for (int64_t c = 0; c < ncand; ++c) {
-    if (cands[c].frag < 0 || cands[c].frag >= nfrag) return WFM_E_ARG;
-    if (q_len[cands[c].frag] != prm->window_length) { wfm_set_error(h, "wfm_map_l2: fragments must be window_length long"); return WFM_E_UNSUPPORTED; }
-  }
-  if (ncand == 0) return 0;
-  HIPCHK(h, hipSetDevice(wfm_device(h)));
+int map_l2_device(wfm_handle_t* h, MapScratch& sc, const wfm_index_t* ix, const wfm_minmer_t* d_q, const int32_t* d_qcount,
+                  const int32_t* d_qlen, const uint8_t* d_kc, int64_t nfrag, int s, const wfm_l1_candidate_t* d_cand,
+                  int64_t ncand, const wfm_l2_params_t* prm, wfm_mapping_t** d_out_p, int32_t** d_frag_p, int64_t* n_out_p) {
+  *d_out_p = nullptr; *d_frag_p = nullptr; *n_out_p = 0;
+  (void)nfrag;
+  if (ncand == 0) return WFM_OK;
   hipStream_t st = wfm_stream(h);
-  Scratch sc;
   const int S1 = prm->sketch_size + 1;
   DevParams P{prm->window_length, prm->sketch_size, prm->stage1_topANI_filter};
 #define ALLOC(p, n) do { if (sc.alloc(&(p), (size_t)(n)) != hipSuccess) { wfm_set_error(h, "out of device memory (L2)"); return WFM_E_NOMEM; } } while (0)
-  wfm_minmer_t* d_q = nullptr; int32_t *d_qcount = nullptr, *d_qlen = nullptr; uint8_t *d_kc = nullptr, *d_keep = nullptr; uint16_t* d_ident = nullptr;
-  double* d_cut = nullptr; wfm_l1_candidate_t* d_cand = nullptr; int64_t* d_lo = nullptr;
+  uint8_t* d_keep = nullptr; uint16_t* d_ident = nullptr; double* d_cut = nullptr; int64_t* d_lo = nullptr;
   uint32_t *d_hcap = nullptr, *d_lcap = nullptr, *d_nloci = nullptr, *d_nkeep = nullptr; uint64_t *d_hoff = nullptr, *d_loff = nullptr, *d_ooff = nullptr;
-  ALLOC(d_q, nfrag * s); ALLOC(d_qcount, nfrag); ALLOC(d_qlen, nfrag); ALLOC(d_kc, nfrag); ALLOC(d_keep, S1 * S1); ALLOC(d_ident, S1 * S1);
-  ALLOC(d_cut, S1); ALLOC(d_cand, ncand); ALLOC(d_lo, ncand); ALLOC(d_hcap, ncand); ALLOC(d_lcap, ncand); ALLOC(d_nloci, ncand); ALLOC(d_nkeep, ncand);
-  ALLOC(d_hoff, ncand); ALLOC(d_loff, ncand); ALLOC(d_ooff, ncand);
-  HIPCHK(h, hipMemcpyAsync(d_q, qsketch, (size_t)nfrag * s * sizeof(wfm_minmer_t), hipMemcpyHostToDevice, st));
-  HIPCHK(h, hipMemcpyAsync(d_qcount, qcount, (size_t)nfrag * 4, hipMemcpyHostToDevice, st));
-  HIPCHK(h, hipMemcpyAsync(d_qlen, q_len, (size_t)nfrag * 4, hipMemcpyHostToDevice, st));
-  HIPCHK(h, hipMemcpyAsync(d_kc, q_kmer_complexity, (size_t)nfrag, hipMemcpyHostToDevice, st));
+  ALLOC(d_keep, S1 * S1); ALLOC(d_ident, S1 * S1); ALLOC(d_cut, S1); ALLOC(d_lo, ncand); ALLOC(d_hcap, ncand); ALLOC(d_lcap, ncand);
+  ALLOC(d_nloci, ncand); ALLOC(d_nkeep, ncand); ALLOC(d_hoff, ncand); ALLOC(d_loff, ncand); ALLOC(d_ooff, ncand);
   HIPCHK(h, hipMemcpyAsync(d_keep, prm->keep_table, (size_t)S1 * S1, hipMemcpyHostToDevice, st));
   HIPCHK(h, hipMemcpyAsync(d_ident, prm->ident_table, (size_t)S1 * S1 * 2, hipMemcpyHostToDevice, st));
   HIPCHK(h, hipMemcpyAsync(d_cut, prm->cutoff_j, (size_t)S1 * 8, hipMemcpyHostToDevice, st));
-  HIPCHK(h, hipMemcpyAsync(d_cand, cands, (size_t)ncand * sizeof(wfm_l1_candidate_t), hipMemcpyHostToDevice, st));
   const wfm_minmer_t* mi = wfm_index_minmers(ix);
   const int64_t n_mi = wfm_index_n_kept(ix);
   const dim3 g((unsigned)((ncand + 63) / 64)), b(64);
@@ -365,17 +344,49 @@ extern "C" int64_t wfm_map_l2(wfm_handle_t* h, const wfm_index_t* ix, const wfm_
   if (rc != WFM_OK) return rc;
   uint64_t n_out = 0;
   if ((rc = total_of(h, d_ooff, d_nkeep, ncand, st, &n_out)) != WFM_OK) return rc;
-  if (n_out > 0 && out && out_frag && cap > 0) {
+  if (n_out > 0) {
     wfm_mapping_t* d_out = nullptr; int32_t* d_ofrag = nullptr;
     ALLOC(d_out, n_out); ALLOC(d_ofrag, n_out);
     hipLaunchKernelGGL(l2_emit_kernel, g, b, 0, st, d_cand, ncand, d_qcount, d_qlen, d_kc, d_loff, d_loci, d_nloci, d_ooff, d_keep, d_ident, P,
                        d_out, d_ofrag);
     HIPCHK(h, hipGetLastError());
-    const size_t n_copy = (size_t)std::min<int64_t>((int64_t)n_out, cap);
-    HIPCHK(h, hipMemcpyAsync(out, d_out, n_copy * sizeof(wfm_mapping_t), hipMemcpyDeviceToHost, st));
-    HIPCHK(h, hipMemcpyAsync(out_frag, d_ofrag, n_copy * 4, hipMemcpyDeviceToHost, st));
-    HIPCHK(h, hipStreamSynchronize(st));
+    *d_out_p = d_out; *d_frag_p = d_ofrag;
   }
 #undef ALLOC
-  return (int64_t)n_out;
+  *n_out_p = (int64_t)n_out;
+  return WFM_OK;
+}
+
+extern "C" int64_t wfm_map_l2(wfm_handle_t* h, const wfm_index_t* ix, const wfm_minmer_t* qsketch, const int32_t* qcount, const int32_t* q_len,
+                              const uint8_t* q_kmer_complexity, int64_t nfrag, int s, const wfm_l1_candidate_t* cands, int64_t ncand,
+                              const wfm_l2_params_t* prm, wfm_mapping_t* out, int32_t* out_frag, int64_t cap) {
+  if (!h || !ix || !prm || nfrag < 0 || ncand < 0 || s < 1 || (nfrag && (!qsketch || !qcount || !q_len || !q_kmer_complexity)) || (ncand && !cands))
+    return WFM_E_ARG;
+  if (!prm->keep_table || !prm->ident_table || !prm->cutoff_j || prm->sketch_size < 1 || s > prm->sketch_size) return WFM_E_ARG;
+  for (int64_t c = 0; c < ncand; ++c) {
+    if (cands[c].frag < 0 || cands[c].frag >= nfrag) return WFM_E_ARG;
+    if (q_len[cands[c].frag] != prm->window_length) { wfm_set_error(h, "wfm_map_l2: fragments must be window_length long"); return WFM_E_UNSUPPORTED; }
+  }
+  if (ncand == 0) return 0;
+  HIPCHK(h, hipSetDevice(wfm_device(h)));
+  hipStream_t st = wfm_stream(h);
+  MapScratch sc;
+  wfm_minmer_t* d_q = nullptr; int32_t *d_qcount = nullptr, *d_qlen = nullptr; uint8_t* d_kc = nullptr; wfm_l1_candidate_t* d_cand = nullptr;
+  if (sc.alloc(&d_q, (size_t)nfrag * s) != hipSuccess || sc.alloc(&d_qcount, nfrag) != hipSuccess || sc.alloc(&d_qlen, nfrag) != hipSuccess ||
+      sc.alloc(&d_kc, nfrag) != hipSuccess || sc.alloc(&d_cand, ncand) != hipSuccess) { wfm_set_error(h, "out of device memory (L2)"); return WFM_E_NOMEM; }
+  HIPCHK(h, hipMemcpyAsync(d_q, qsketch, (size_t)nfrag * s * sizeof(wfm_minmer_t), hipMemcpyHostToDevice, st));
+  HIPCHK(h, hipMemcpyAsync(d_qcount, qcount, (size_t)nfrag * 4, hipMemcpyHostToDevice, st));
+  HIPCHK(h, hipMemcpyAsync(d_qlen, q_len, (size_t)nfrag * 4, hipMemcpyHostToDevice, st));
+  HIPCHK(h, hipMemcpyAsync(d_kc, q_kmer_complexity, (size_t)nfrag, hipMemcpyHostToDevice, st));
+  HIPCHK(h, hipMemcpyAsync(d_cand, cands, (size_t)ncand * sizeof(wfm_l1_candidate_t), hipMemcpyHostToDevice, st));
+  wfm_mapping_t* d_out = nullptr; int32_t* d_ofrag = nullptr; int64_t n_out = 0;
+  const int rc = map_l2_device(h, sc, ix, d_q, d_qcount, d_qlen, d_kc, nfrag, s, d_cand, ncand, prm, &d_out, &d_ofrag, &n_out);
+  if (rc != WFM_OK) return rc;
+  if (n_out > 0 && out && out_frag && cap > 0) {
+    const size_t n_copy = (size_t)std::min<int64_t>(n_out, cap);
+    HIPCHK(h, hipMemcpyAsync(out, d_out, n_copy * sizeof(wfm_mapping_t), hipMemcpyDeviceToHost, st));
+    HIPCHK(h, hipMemcpyAsync(out_frag, d_ofrag, n_copy * 4, hipMemcpyDeviceToHost, st));
+  }
+  HIPCHK(h, hipStreamSynchronize(st));
+  return n_out;
 }
