@@ -60,6 +60,57 @@ void  wfmh_free(char* p);
 int64_t wfmh_test_winnow(const char* seq, int64_t len, int k, int w, int s, int32_t seq_id,
                          const uint64_t* hash, const int8_t* strand, wfm_minmer_t* out, int64_t cap);
 
+/* ---- map phase (skch::Map, src/map/include/computeMap.hpp) ---- */
+
+/* skch::Parameters as set up by parse_args.hpp; wfmh_map_default_params fills the defaults
+ * (file:line of each default in wfmash_amd/host/map_types.hpp). */
+typedef struct {
+  int32_t  kmer_size;                 /* -k 15 */
+  int64_t  window_length;             /* -w / segment length, 1000 */
+  int64_t  block_length;              /* -l 0 */
+  int64_t  chain_gap;                 /* -c 2000 */
+  uint64_t max_mapping_length;        /* -P 50000 */
+  float    percentage_identity;       /* -p as a fraction; 0.70 unless estimated */
+  int32_t  sketch_size;               /* -s; 0 = derive from identity (parse_args.hpp:642-644) */
+  int32_t  filter_mode;               /* 1 map (default), 2 one-to-one, 3 none */
+  uint32_t num_mappings_for_segment;  /* -n; UINT32_MAX = inf (default) */
+  uint32_t num_mappings_for_scaffold; /* 1 */
+  int32_t  drop_rand;                 /* 0 */
+  int32_t  split;                     /* 1 */
+  int32_t  merge_mappings;            /* 1 */
+  int32_t  skip_self;                 /* 1 */
+  int32_t  skip_prefix;               /* 1 */
+  int32_t  lower_triangular;          /* 0 */
+  char     prefix_delim;              /* '#' */
+  int32_t  filter_length_mismatches;  /* 1 */
+  uint64_t sparsity_hash_threshold;   /* UINT64_MAX */
+  double   overlap_threshold;         /* 0.95 */
+  double   scaffold_overlap_threshold;/* 0.5 */
+  int64_t  scaffold_max_deviation;    /* 100000 */
+  int64_t  scaffold_gap;              /* 100000 */
+  int64_t  scaffold_min_length;       /* 10000 */
+  int32_t  legacy_output;             /* 0 */
+  int32_t  minimum_hits;              /* 3 */
+  double   max_kmer_freq;             /* 0.0002 */
+  int64_t  index_by_size;             /* -b; INT64_MAX */
+  float    kmer_complexity_threshold; /* 0 */
+  int32_t  stage1_topani_filter;      /* 1 */
+  int32_t  stage2_full_scan;          /* 1 */
+  float    ani_diff, ani_diff_conf;   /* 0.0, 0.999 */
+  double   hg_numerator;              /* 1.0 */
+  int32_t  threads;                   /* 1 */
+} wfmh_map_params_t;
+
+void wfmh_map_default_params(wfmh_map_params_t* p);
+
+/* Test hook for the host-side post-processing of one query's mappings (CPU tests): runs
+ * mappingBoundarySanityCheck + Map::filterSubsetMappings + reportReadMappings
+ * (stage "subset"), or filterByGroup on the reference axis as the one-to-one pass does
+ * (stage "onetoone"), on caller-supplied MappingResults and returns the mapping PAF text
+ * (malloc'd; wfmh_free).  fasta: the file whose .fai (or the FASTA itself) defines the sequences. */
+char* wfmh_test_filter(const char* stage, const wfm_mapping_t* maps, int64_t n, const char* fasta,
+                       const char* query_name, const wfmh_map_params_t* prm);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,76 @@
+"""CPU tests of the host-side map post-processing: chaining/merging, weak
+mapping filter, plane sweeps, scaffold filter and the mapping-PAF writer of wfmash_amd/host against
+(a) golden output of the reference's own code (tests/golden/filter_golden.json.gz, made by
+tests/golden/make_filter_golden.py from oracle/_ref/libref_filter.so) and (b) that library live
+when it is present."""
+import gzip
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import pyfilter
+from tests import filter_cases as FC
+from wfmash_amd import capi
+
+GOLDEN = json.loads(gzip.open(os.path.join(os.path.dirname(__file__), "golden", "filter_golden.json.gz")).read())
+
+
+@pytest.fixture(scope="module")
+def fai(tmp_path_factory):
+    return FC.write_fai(str(tmp_path_factory.mktemp("fai")))
+
+
+def test_default_params_match_parse_args():
+    p = capi.map_default_params()
+    assert (p.kmer_size, p.window_length, p.chain_gap, p.max_mapping_length) == (15, 1000, 2000, 50000)
+    assert p.num_mappings_for_segment == 0xFFFFFFFF and p.num_mappings_for_scaffold == 1 and p.filter_mode == 1
+    assert (p.scaffold_gap, p.scaffold_max_deviation, p.scaffold_min_length) == (100000, 100000, 10000)
+    assert p.prefix_delim == b"#" and p.skip_prefix == 1 and p.skip_self == 1 and p.minimum_hits == 3
+    assert abs(p.overlap_threshold - 0.95) < 1e-12 and abs(p.max_kmer_freq - 0.0002) < 1e-12
+
+
+@pytest.mark.parametrize("case", FC.CASES, ids=[c[0] for c in FC.CASES])
+def test_filter_subset_matches_reference_golden(fai, case):
+    name, query, seed, over = case
+    m = FC.make_mappings(name, query, seed, over)
+    P = capi.map_default_params(**over)
+    got = capi.host_filter("subset", m, fai, query, P)
+    assert got == GOLDEN[name]["subset"]
+    if "onetoone" in GOLDEN[name]:
+        assert capi.host_filter("onetoone", m, fai, query, P) == GOLDEN[name]["onetoone"]
+
+
+def test_golden_is_not_trivial():
+    n_lines = {k: len(v["subset"].splitlines()) for k, v in GOLDEN.items()}
+    assert sum(1 for v in n_lines.values() if v > 10) >= 18
+    assert n_lines["defaults"] > n_lines["n1"] > 0 and n_lines["no_merge"] > n_lines["defaults"]
+    first = GOLDEN["defaults"]["subset"].splitlines()[0].split("\t")
+    assert len(first) == 15 and first[12].startswith("id:f:") and first[14].startswith("ch:Z:")
+
+
+@pytest.mark.skipif(not pyfilter.have_ref(), reason="oracle/_ref/libref_filter.so not built (needs /root/reference)")
+def test_filter_subset_matches_reference_live(fai):
+    """fresh seeds (not in the golden file) through the reference's own code, side by side"""
+    total = 0
+    for seed in range(100, 112):
+        for over in ({}, {"num_mappings_for_segment": 2, "overlap_threshold": 0.7}, {"chain_gap": 8000, "block_length": 3000}):
+            m = FC.make_mappings("live", "A#2#c1", seed, over)
+            P = capi.map_default_params(**over)
+            exp = pyfilter.ref_filter("subset", m, fai, "A#2#c1", P)
+            assert capi.host_filter("subset", m, fai, "A#2#c1", P) == exp
+            assert capi.host_filter("onetoone", m, fai, "A#2#c1", P) == pyfilter.ref_filter("onetoone", m, fai, "A#2#c1", P)
+            total += len(exp.splitlines())
+    assert total > 1000
+
+
+def test_sequence_id_manager_groups(fai, tmp_path):
+    """ids follow the .fai order, groups the sorted names up to the LAST delimiter (sequenceIds.hpp:286-338)."""
+    # a mapping onto every target prints its name and length through the id manager
+    m = np.array([(t, 10, 0, 1000, 1, 10, 9000, 0, 90) for t in range(len(FC.NAMES))], dtype=FC.MAPPING_DTYPE)
+    P = capi.map_default_params(scaffold_gap=0, filter_mode=3, merge_mappings=0)
+    out = capi.host_filter("subset", m, fai, "A#1#c1", P).splitlines()
+    assert [(l.split("\t")[5], int(l.split("\t")[6])) for l in out] == FC.NAMES
+    with pytest.raises(capi.WfmError):
+        capi.host_filter("subset", m, fai, "absent_sequence_name", P)

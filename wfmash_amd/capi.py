@@ -464,7 +464,54 @@ class Handle:
 # ---------------------------------------------------------------------------
 # host-side align driver (include/wfmash_host.h)
 # ---------------------------------------------------------------------------
-HOST_EXPORTS = ["wfmh_align_default_params", "wfmh_align_paf", "wfmh_test_cigar", "wfmh_free", "wfmh_test_winnow"]
+HOST_EXPORTS = ["wfmh_align_default_params", "wfmh_align_paf", "wfmh_test_cigar", "wfmh_free", "wfmh_test_winnow",
+                "wfmh_map_default_params", "wfmh_test_filter"]
+
+
+class MapHostParams(C.Structure):
+    """wfmh_map_params_t (include/wfmash_host.h)"""
+    _fields_ = [("kmer_size", C.c_int32), ("window_length", C.c_int64), ("block_length", C.c_int64), ("chain_gap", C.c_int64),
+                ("max_mapping_length", C.c_uint64), ("percentage_identity", C.c_float), ("sketch_size", C.c_int32),
+                ("filter_mode", C.c_int32), ("num_mappings_for_segment", C.c_uint32), ("num_mappings_for_scaffold", C.c_uint32),
+                ("drop_rand", C.c_int32), ("split", C.c_int32), ("merge_mappings", C.c_int32), ("skip_self", C.c_int32),
+                ("skip_prefix", C.c_int32), ("lower_triangular", C.c_int32), ("prefix_delim", C.c_char),
+                ("filter_length_mismatches", C.c_int32), ("sparsity_hash_threshold", C.c_uint64), ("overlap_threshold", C.c_double),
+                ("scaffold_overlap_threshold", C.c_double), ("scaffold_max_deviation", C.c_int64), ("scaffold_gap", C.c_int64),
+                ("scaffold_min_length", C.c_int64), ("legacy_output", C.c_int32), ("minimum_hits", C.c_int32),
+                ("max_kmer_freq", C.c_double), ("index_by_size", C.c_int64), ("kmer_complexity_threshold", C.c_float),
+                ("stage1_topani_filter", C.c_int32), ("stage2_full_scan", C.c_int32), ("ani_diff", C.c_float),
+                ("ani_diff_conf", C.c_float), ("hg_numerator", C.c_double), ("threads", C.c_int32)]
+
+
+def map_default_params(**over) -> MapHostParams:
+    L = load()
+    p = MapHostParams()
+    L.wfmh_map_default_params.restype = None
+    L.wfmh_map_default_params.argtypes = [C.POINTER(MapHostParams)]
+    L.wfmh_map_default_params(C.byref(p))
+    for k, v in over.items():
+        if k == "prefix_delim" and isinstance(v, str):
+            v = v.encode()
+        setattr(p, k, v)
+    return p
+
+
+def host_filter(stage: str, mappings, fasta: str, query_name: str, params: MapHostParams) -> str:
+    """wfmh_test_filter: the host-side post-processing on caller-supplied MappingResults (no GPU needed)."""
+    L = load()
+    m = np.ascontiguousarray(mappings, dtype=MAPPING_DTYPE)
+    L.wfmh_test_filter.restype = C.c_void_p
+    L.wfmh_test_filter.argtypes = [C.c_char_p, C.c_void_p, C.c_int64, C.c_char_p, C.c_char_p, C.POINTER(MapHostParams)]
+    L.wfmh_free.restype = None
+    L.wfmh_free.argtypes = [C.c_void_p]
+    p = L.wfmh_test_filter(stage.encode(), m.ctypes.data, len(m), fasta.encode(), query_name.encode(), C.byref(params))
+    if not p:
+        raise WfmError("wfmh_test_filter failed")
+    s = C.string_at(p).decode()
+    L.wfmh_free(p)
+    if s.startswith("ERROR: "):
+        raise WfmError(s)
+    return s
 
 
 class AlignParams(C.Structure):

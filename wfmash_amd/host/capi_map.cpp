@@ -1,0 +1,136 @@
+// capi_map.cpp -- C entry points of the map phase's host side (include/wfmash_host.h).
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+#include <sstream>
+#include <string>
+
+#include "../../include/wfmash_host.h"
+#include "capi_map.hpp"
+#include "map_filter.hpp"
+#include "sequence_ids.hpp"
+
+namespace wfmash_host {
+
+skch::Parameters to_parameters(const wfmh_map_params_t& c) {
+  skch::Parameters p;
+  p.kmerSize = c.kmer_size;
+  p.windowLength = c.window_length;
+  p.block_length = c.block_length;
+  p.chain_gap = c.chain_gap;
+  p.max_mapping_length = c.max_mapping_length;
+  p.percentageIdentity = c.percentage_identity;
+  p.sketchSize = c.sketch_size;
+  p.filterMode = c.filter_mode;
+  p.numMappingsForSegment = c.num_mappings_for_segment;
+  p.numMappingsForScaffold = c.num_mappings_for_scaffold;
+  p.dropRand = c.drop_rand != 0;
+  p.split = c.split != 0;
+  p.mergeMappings = c.merge_mappings != 0;
+  p.skip_self = c.skip_self != 0;
+  p.skip_prefix = c.skip_prefix != 0;
+  p.lower_triangular = c.lower_triangular != 0;
+  p.prefix_delim = c.prefix_delim;
+  p.filterLengthMismatches = c.filter_length_mismatches != 0;
+  p.sparsity_hash_threshold = c.sparsity_hash_threshold;
+  p.overlap_threshold = c.overlap_threshold;
+  p.scaffold_overlap_threshold = c.scaffold_overlap_threshold;
+  p.scaffold_max_deviation = c.scaffold_max_deviation;
+  p.scaffold_gap = c.scaffold_gap;
+  p.scaffold_min_length = c.scaffold_min_length;
+  p.legacy_output = c.legacy_output != 0;
+  p.minimum_hits = c.minimum_hits;
+  p.max_kmer_freq = c.max_kmer_freq;
+  p.index_by_size = c.index_by_size;
+  p.kmerComplexityThreshold = c.kmer_complexity_threshold;
+  p.stage1_topANI_filter = c.stage1_topani_filter != 0;
+  p.stage2_full_scan = c.stage2_full_scan != 0;
+  p.ANIDiff = c.ani_diff;
+  p.ANIDiffConf = c.ani_diff_conf;
+  p.hgNumerator = c.hg_numerator;
+  p.threads = c.threads;
+  return p;
+}
+
+}  // namespace wfmash_host
+
+extern "C" {
+
+void wfmh_map_default_params(wfmh_map_params_t* c) {
+  if (!c) return;
+  const skch::Parameters p;  // the defaults live in one place (map_types.hpp)
+  std::memset(c, 0, sizeof(*c));
+  c->kmer_size = p.kmerSize;
+  c->window_length = p.windowLength;
+  c->block_length = p.block_length;
+  c->chain_gap = p.chain_gap;
+  c->max_mapping_length = p.max_mapping_length;
+  c->percentage_identity = p.percentageIdentity;
+  c->sketch_size = p.sketchSize;
+  c->filter_mode = p.filterMode;
+  c->num_mappings_for_segment = p.numMappingsForSegment;
+  c->num_mappings_for_scaffold = p.numMappingsForScaffold;
+  c->drop_rand = p.dropRand;
+  c->split = p.split;
+  c->merge_mappings = p.mergeMappings;
+  c->skip_self = p.skip_self;
+  c->skip_prefix = p.skip_prefix;
+  c->lower_triangular = p.lower_triangular;
+  c->prefix_delim = p.prefix_delim;
+  c->filter_length_mismatches = p.filterLengthMismatches;
+  c->sparsity_hash_threshold = p.sparsity_hash_threshold;
+  c->overlap_threshold = p.overlap_threshold;
+  c->scaffold_overlap_threshold = p.scaffold_overlap_threshold;
+  c->scaffold_max_deviation = p.scaffold_max_deviation;
+  c->scaffold_gap = p.scaffold_gap;
+  c->scaffold_min_length = p.scaffold_min_length;
+  c->legacy_output = p.legacy_output;
+  c->minimum_hits = p.minimum_hits;
+  c->max_kmer_freq = p.max_kmer_freq;
+  c->index_by_size = p.index_by_size;
+  c->kmer_complexity_threshold = p.kmerComplexityThreshold;
+  c->stage1_topani_filter = p.stage1_topANI_filter;
+  c->stage2_full_scan = p.stage2_full_scan;
+  c->ani_diff = p.ANIDiff;
+  c->ani_diff_conf = p.ANIDiffConf;
+  c->hg_numerator = p.hgNumerator;
+  c->threads = p.threads;
+}
+
+char* wfmh_test_filter(const char* stage, const wfm_mapping_t* maps, int64_t n, const char* fasta, const char* query_name,
+                       const wfmh_map_params_t* prm) {
+  if (!stage || !fasta || !query_name || !prm || n < 0 || (n && !maps)) return nullptr;
+  std::string text;
+  try {
+    const skch::Parameters p = wfmash_host::to_parameters(*prm);
+    const std::string delim = p.prefix_delim ? std::string(1, p.prefix_delim) : std::string();
+    const skch::SequenceIdManager ids({std::string(fasta)}, {std::string(fasta)}, {}, {std::string()}, delim);
+    skch::MappingResultsVector_t v((size_t)n);
+    if (n) std::memcpy(v.data(), maps, (size_t)n * sizeof(wfm_mapping_t));
+    const skch::seqno_t qid = ids.getSequenceId(query_name);
+    const skch::offset_t qlen = ids.getSequenceLength(qid);
+    std::ostringstream os;
+    const std::string st(stage);
+    if (st == "subset") {
+      skch::MappingOutput::mappingBoundarySanityCheck(qlen, v, ids);
+      skch::FilteredMappingsResult r = skch::filterSubsetMappings(v, p, ids, qlen);
+      const bool merged = p.mergeMappings && p.split;
+      skch::MappingOutput::reportReadMappings(merged ? r.mergedMappings : r.nonMergedMappings, merged ? r.mergedChainInfo : r.nonMergedChainInfo,
+                                              query_name, os, ids, p, qlen);
+    } else if (st == "onetoone") {
+      skch::MappingResultsVector_t kept;
+      skch::MappingFilterUtils::filterByGroup(v, kept, p.numMappingsForSegment - 1, true, ids, p);
+      skch::MappingOutput::reportReadMappings(kept, query_name, os, ids, p, qlen);
+    } else {
+      return nullptr;
+    }
+    text = os.str();
+  } catch (const std::exception& e) {
+    text = std::string("ERROR: ") + e.what();
+  }
+  char* out = (char*)malloc(text.size() + 1);
+  if (out) std::memcpy(out, text.c_str(), text.size() + 1);
+  return out;
+}
+
+}  // extern "C"

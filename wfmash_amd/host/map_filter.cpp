@@ -1,0 +1,582 @@
+#include "map_filter.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <limits>
+#include <map>
+#include <numeric>
+#include <set>
+#include <tuple>
+
+namespace skch {
+
+// ---------------------------------------------------------------------------------------------
+// plane sweeps (filter.hpp)
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+// The two sweeps differ only in the axis they run along.
+struct QueryAxis {
+  static double score(const MappingResultsVector_t& v, int x) {
+    if (v[x].blockLength <= 0 || v[x].blockNucIdentity() <= 0) return std::numeric_limits<double>::lowest();
+    return v[x].blockNucIdentity() * std::log(static_cast<double>(v[x].blockLength));
+  }
+  // strict "ranks before": higher score, then larger query start, then larger refSeqId
+  static bool before(const MappingResultsVector_t& v, int x, int y) {
+    const double xs = score(v, x), ys = score(v, y);
+    return std::tie(xs, v[x].queryStartPos, v[x].refSeqId) > std::tie(ys, v[y].queryStartPos, v[y].refSeqId);
+  }
+  static double overlap(const MappingResultsVector_t& v, int x, int y) {
+    const offset_t b = std::max(v[x].queryStartPos, v[y].queryStartPos);
+    const offset_t e = std::min(v[x].queryEndPos(), v[y].queryEndPos());
+    const offset_t ov = std::max(0, static_cast<int>(e - b));
+    const offset_t xl = v[x].queryEndPos() - v[x].queryStartPos, yl = v[y].queryEndPos() - v[y].queryStartPos;
+    return static_cast<double>(ov) / std::min(xl, yl);
+  }
+};
+
+struct RefAxis {
+  static double score(const MappingResultsVector_t& v, int x) { return v[x].blockNucIdentity() * log(v[x].blockLength); }
+  static bool before(const MappingResultsVector_t& v, int x, int y) {
+    const double xs = score(v, x), ys = score(v, y);
+    return std::tie(xs, v[x].refStartPos) > std::tie(ys, v[y].refStartPos);
+  }
+  static double overlap(const MappingResultsVector_t& v, int x, int y) {
+    const offset_t b = std::max(v[x].refStartPos, v[y].refStartPos);
+    const offset_t e = std::min(v[x].refEndPos(), v[y].refEndPos());
+    const offset_t ov = std::max(0, static_cast<int>(e - b));
+    const offset_t xl = v[x].refEndPos() - v[x].refStartPos, yl = v[y].refEndPos() - v[y].refStartPos;
+    return static_cast<double>(ov) / std::min(xl, yl);
+  }
+};
+
+// Sweep-line status: the mappings crossing the current position, ranked by Axis::before.  It is a
+// std::set on purpose: two mappings that compare equivalent collapse into one entry, and erasing
+// one erases whichever is stored -- behaviour the output depends on.
+template <class Axis>
+class SweepLine {
+ public:
+  explicit SweepLine(MappingResultsVector_t& v) : v_(v), live_(Rank{&v}) {}
+  void enter(int i) { live_.insert(i); }
+  void leave(int i) { live_.erase(i); }
+
+  // Helper::markGood (filter.hpp:95-165, :381-447)
+  void markGood(int secondaryToKeep, bool dropRand, double overlapThreshold) {
+    auto it = live_.begin();
+    const auto top = live_.begin();
+    int kept = 0;
+    for (; it != live_.end(); ++it) {
+      const bool worse_or_seen = Axis::score(v_, *top) > Axis::score(v_, *it) || !v_[*it].discard();
+      if (worse_or_seen && kept > secondaryToKeep) break;
+      v_[*it].setDiscard(false);
+      ++kept;
+    }
+    const auto first_unkept = it;
+    if (overlapThreshold < 1.0) {
+      for (; it != live_.end(); ++it) {
+        if (it == live_.begin()) continue;
+        for (auto k = live_.begin(); k != first_unkept; ++k) {
+          if (Axis::overlap(v_, *it, *k) > overlapThreshold) {
+            v_[*it].setOverlapped(true);
+            v_[*it].setDiscard(true);
+            break;
+          }
+        }
+      }
+    }
+    if (kept > secondaryToKeep && dropRand) {
+      // ties beyond the quota: keep the ones with the largest (score, hash, address)
+      std::vector<std::tuple<double, size_t, MappingResult*>> tied;
+      for (int i : live_)
+        if (!v_[i].discard()) tied.emplace_back(Axis::score(v_, i), v_[i].hash(), &v_[i]);
+      std::sort(tied.begin(), tied.end(), std::greater<>{});
+      for (auto& t : tied) std::get<2>(t)->setDiscard(true);
+      kept = 0;
+      for (auto& t : tied) {
+        if (kept > secondaryToKeep) break;
+        std::get<2>(t)->setDiscard(false);
+        ++kept;
+      }
+    }
+  }
+
+ private:
+  struct Rank {
+    const MappingResultsVector_t* v;
+    bool operator()(int x, int y) const { return Axis::before(*v, x, y); }
+  };
+  MappingResultsVector_t& v_;
+  std::set<int, Rank> live_;
+};
+
+}  // namespace
+
+namespace Filter {
+namespace query {
+
+void filterMappings(MappingResultsVector_t& readMappings, int secondaryToKeep, bool dropRand, double overlapThreshold) {
+  if (readMappings.size() <= 1) return;
+  for (auto& e : readMappings) { e.setDiscard(true); e.setOverlapped(false); }
+  SweepLine<QueryAxis> line(readMappings);
+  // (position, BEGIN/END, mapping).  The reference's schedule also carries 2N value-initialised
+  // records (filter.hpp:194); they sort first and erase mapping 0 from a still empty status.
+  typedef std::tuple<offset_t, int, int> Event;
+  std::vector<Event> events;
+  events.reserve(2 * readMappings.size());
+  for (int i = 0; i < (int)readMappings.size(); ++i) {
+    events.emplace_back(readMappings[i].queryStartPos, (int)event::BEGIN, i);
+    events.emplace_back(readMappings[i].queryEndPos(), (int)event::END, i);
+  }
+  std::sort(events.begin(), events.end());
+  for (size_t a = 0; a < events.size();) {
+    size_t b = a;
+    while (b < events.size() && std::get<0>(events[b]) == std::get<0>(events[a])) ++b;
+    for (size_t k = a; k < b; ++k) {
+      if (std::get<1>(events[k]) == event::BEGIN) line.enter(std::get<2>(events[k]));
+      else line.leave(std::get<2>(events[k]));
+    }
+    line.markGood(secondaryToKeep, dropRand, overlapThreshold);
+    a = b;
+  }
+  readMappings.erase(std::remove_if(readMappings.begin(), readMappings.end(), [](const MappingResult& e) { return e.discard() || e.overlapped(); }),
+                     readMappings.end());
+}
+
+}  // namespace query
+
+namespace ref {
+
+void filterMappings(MappingResultsVector_t& readMappings, const SequenceIdManager& idManager, uint16_t secondaryToKeep, bool dropRand,
+                    double overlapThreshold) {
+  if (readMappings.size() <= 1) return;
+  for (auto& e : readMappings) e.setDiscard(true);
+  SweepLine<RefAxis> line(readMappings);
+  typedef std::tuple<seqno_t, offset_t, int, int> Event;  // (ref sequence, offset, BEGIN/END, mapping)
+  std::vector<Event> events;
+  events.reserve(2 * readMappings.size());
+  for (int i = 0; i < (int)readMappings.size(); ++i) {
+    const MappingResult& m = readMappings[i];
+    events.emplace_back((seqno_t)m.refSeqId, (offset_t)m.refStartPos, (int)event::BEGIN, i);
+    // the END event sits one base past the mapping, rolling over into the next sequence (filter.hpp:455-468)
+    seqno_t s = (seqno_t)m.refSeqId;
+    offset_t o = m.refEndPos();
+    if (o == idManager.getSequenceLength(s) - 1) { s += 1; o = 0; } else { o += 1; }
+    events.emplace_back(s, o, (int)event::END, i);
+  }
+  std::sort(events.begin(), events.end());
+  for (size_t a = 0; a < events.size();) {
+    size_t b = a;
+    while (b < events.size() && std::get<0>(events[b]) == std::get<0>(events[a]) && std::get<1>(events[b]) == std::get<1>(events[a])) ++b;
+    for (size_t k = a; k < b; ++k) {
+      if (std::get<2>(events[k]) == event::BEGIN) line.enter(std::get<3>(events[k]));
+      else line.leave(std::get<3>(events[k]));
+    }
+    line.markGood(secondaryToKeep, dropRand, overlapThreshold);
+    a = b;
+  }
+  readMappings.erase(std::remove_if(readMappings.begin(), readMappings.end(), [](const MappingResult& e) { return e.discard(); }), readMappings.end());
+}
+
+}  // namespace ref
+}  // namespace Filter
+
+// ---------------------------------------------------------------------------------------------
+// MappingFilterUtils (mappingFilter.hpp)
+// ---------------------------------------------------------------------------------------------
+void MappingFilterUtils::filterWeakMappings(MappingResultsVector_t& readMappings, int64_t min_count, const Parameters& param,
+                                            const SequenceIdManager& idManager, offset_t queryLen) {
+  auto weak = [&](const MappingResult& e) {
+    const bool at_boundary = e.queryStartPos < param.windowLength || e.queryEndPos() > queryLen - param.windowLength ||
+                             e.refStartPos < param.windowLength ||
+                             e.refEndPos() > idManager.getSequenceLength(e.refSeqId) - param.windowLength;
+    // mappings touching a sequence end only need half the length / half the segment count
+    if (at_boundary) return e.blockLength < param.block_length / 2 || e.n_merged < min_count / 2;
+    return e.blockLength < param.block_length || e.n_merged < min_count;
+  };
+  readMappings.erase(std::remove_if(readMappings.begin(), readMappings.end(), weak), readMappings.end());
+}
+
+void MappingFilterUtils::filterFalseHighIdentity(MappingResultsVector_t& readMappings, const Parameters& param) {
+  auto mismatched = [&](const MappingResult& e) {
+    const int64_t q_l = (int64_t)e.queryEndPos() - (int64_t)e.queryStartPos;
+    const int64_t r_l = (int64_t)e.refEndPos() - (int64_t)e.refStartPos;
+    const uint64_t delta = std::abs(r_l - q_l);
+    const double len_id_bound = (1.0 - (double)delta / (((double)q_l + r_l) / 2));
+    return len_id_bound < std::min(0.7, std::pow((double)param.percentageIdentity, 3.0));  // pow(float, int) is double pow under g++
+  };
+  readMappings.erase(std::remove_if(readMappings.begin(), readMappings.end(), mismatched), readMappings.end());
+}
+
+void MappingFilterUtils::sparsifyMappings(MappingResultsVector_t& readMappings, const Parameters& param) {
+  if (param.sparsity_hash_threshold == std::numeric_limits<uint64_t>::max()) return;
+  readMappings.erase(std::remove_if(readMappings.begin(), readMappings.end(),
+                                    [&](const MappingResult& e) { return e.hash() > param.sparsity_hash_threshold; }),
+                     readMappings.end());
+}
+
+void MappingFilterUtils::filterByGroup(MappingResultsVector_t& unfilteredMappings, MappingResultsVector_t& filteredMappings, int n_mappings,
+                                       bool filter_ref, const SequenceIdManager& idManager, const Parameters& param) {
+  filteredMappings.reserve(unfilteredMappings.size());
+  std::sort(unfilteredMappings.begin(), unfilteredMappings.end(), [](const MappingResult& a, const MappingResult& b) {
+    return std::tie(a.refSeqId, a.refStartPos) < std::tie(b.refSeqId, b.refStartPos);
+  });
+  if (param.filterMode == filter::MAP || param.filterMode == filter::ONETOONE) {
+    // one sweep per run of consecutive target sequences of the same group (all of them without -Y)
+    size_t lo = 0;
+    while (lo < unfilteredMappings.size()) {
+      size_t hi = unfilteredMappings.size();
+      if (param.skip_prefix) {
+        const int g = idManager.getRefGroup(unfilteredMappings[lo].refSeqId);
+        hi = lo;
+        while (hi < unfilteredMappings.size() && idManager.getRefGroup(unfilteredMappings[hi].refSeqId) == g) ++hi;
+      }
+      MappingResultsVector_t run(unfilteredMappings.begin() + lo, unfilteredMappings.begin() + hi);
+      std::sort(run.begin(), run.end(), [](const MappingResult& a, const MappingResult& b) {
+        return std::tie(a.queryStartPos, a.refSeqId, a.refStartPos) < std::tie(b.queryStartPos, b.refSeqId, b.refStartPos);
+      });
+      if (filter_ref) Filter::ref::filterMappings(run, idManager, n_mappings, param.dropRand, param.overlap_threshold);
+      else Filter::query::filterMappings(run, n_mappings, param.dropRand, param.overlap_threshold);
+      filteredMappings.insert(filteredMappings.end(), run.begin(), run.end());
+      lo = hi;
+    }
+  }
+  std::sort(filteredMappings.begin(), filteredMappings.end(), [](const MappingResult& a, const MappingResult& b) {
+    const auto as = a.strand(), bs = b.strand();
+    return std::tie(a.queryStartPos, a.refSeqId, a.refStartPos, as) < std::tie(b.queryStartPos, b.refSeqId, b.refStartPos, bs);
+  });
+}
+
+namespace {
+
+// union by rank; equal ranks attach the larger id under the smaller (common/dset64.hpp:87-119).
+// The representative ends up as a sort key, so the tie rule is part of the output.
+class ChainSets {
+ public:
+  explicit ChainSets(size_t n) : parent_(n), rank_(n, 0) { std::iota(parent_.begin(), parent_.end(), (uint64_t)0); }
+  uint64_t find(uint64_t x) {
+    while (parent_[x] != x) {
+      parent_[x] = parent_[parent_[x]];
+      x = parent_[x];
+    }
+    return x;
+  }
+  void unite(uint64_t a, uint64_t b) {
+    a = find(a); b = find(b);
+    if (a == b) return;
+    if (rank_[a] > rank_[b] || (rank_[a] == rank_[b] && a < b)) std::swap(a, b);
+    parent_[a] = b;  // a: lower rank, or equal rank and larger id
+    if (rank_[a] == rank_[b]) ++rank_[b];
+  }
+
+ private:
+  std::vector<uint64_t> parent_;
+  std::vector<uint64_t> rank_;
+};
+
+template <typename T>
+std::vector<T> permuted(const std::vector<T>& in, const std::vector<uint32_t>& p) {
+  std::vector<T> out(in.size());
+  for (size_t i = 0; i < p.size(); ++i) out[i] = in[p[i]];
+  return out;
+}
+
+// Steps 1-4 of mergeMappingsInRange[WithChains] (mappingFilter.hpp:402-498, :593-675): sorts
+// readMappings into chains and returns each mapping's chain representative.
+std::vector<offset_t> chain_mappings(MappingResultsVector_t& readMappings, int max_dist, const Parameters& param) {
+  const size_t n = readMappings.size();
+  std::vector<offset_t> chainOf(n);
+  std::iota(chainOf.begin(), chainOf.end(), (offset_t)0);
+  std::vector<double> linkScore(n, std::numeric_limits<double>::max());
+  std::vector<int64_t> linkFrom(n, std::numeric_limits<int64_t>::min());
+
+  std::vector<uint32_t> p(n);
+  std::iota(p.begin(), p.end(), 0u);
+  std::sort(p.begin(), p.end(), [&](uint32_t i, uint32_t j) {
+    const MappingResult &a = readMappings[i], &b = readMappings[j];
+    const auto as = a.strand(), bs = b.strand();
+    return std::tie(a.refSeqId, as, a.queryStartPos, a.refStartPos) < std::tie(b.refSeqId, bs, b.queryStartPos, b.refStartPos);
+  });
+  readMappings = permuted(readMappings, p);
+  chainOf = permuted(chainOf, p);
+
+  ChainSets sets(n);
+  for (size_t lo = 0; lo < n;) {
+    size_t hi = lo + 1;
+    while (hi < n && readMappings[hi].refSeqId == readMappings[lo].refSeqId && readMappings[hi].strand() == readMappings[lo].strand()) ++hi;
+    // within one (target, strand) run every mapping links to its closest admissible successor
+    for (size_t i = lo; i < hi; ++i) {
+      if (linkScore[i] != std::numeric_limits<double>::max()) sets.unite(chainOf[i], linkFrom[i]);
+      double best = std::numeric_limits<double>::max();
+      size_t best_j = hi;
+      const MappingResult& a = readMappings[i];
+      for (size_t j = i + 1; j < hi; ++j) {
+        const MappingResult& b = readMappings[j];
+        if (b.queryStartPos > a.queryEndPos() + max_dist) break;
+        int64_t q_dist = b.queryStartPos - a.queryEndPos();
+        if (q_dist < 0) q_dist = 0;
+        const int64_t r_dist = (a.strand() == strnd::FWD) ? (b.refStartPos - a.refEndPos()) : (a.refStartPos - b.refEndPos());
+        if (q_dist <= max_dist && r_dist >= -param.windowLength / 5 && r_dist <= max_dist) {
+          const double d2 = (double)q_dist * q_dist + (double)r_dist * r_dist;
+          if (d2 < best && d2 < linkScore[j]) { best = d2; best_j = j; }
+        }
+      }
+      if (best_j != hi) { linkScore[best_j] = best; linkFrom[best_j] = chainOf[i]; }
+    }
+    lo = hi;
+  }
+  for (size_t i = 0; i < n; ++i)
+    if (linkScore[i] != std::numeric_limits<double>::max()) sets.unite(chainOf[i], linkFrom[i]);
+  for (size_t i = 0; i < n; ++i) chainOf[i] = (offset_t)sets.find(chainOf[i]);
+
+  std::iota(p.begin(), p.end(), 0u);
+  std::sort(p.begin(), p.end(), [&](uint32_t i, uint32_t j) {
+    return std::tie(chainOf[i], readMappings[i].queryStartPos, readMappings[i].refStartPos) <
+           std::tie(chainOf[j], readMappings[j].queryStartPos, readMappings[j].refStartPos);
+  });
+  readMappings = permuted(readMappings, p);
+  chainOf = permuted(chainOf, p);
+  return chainOf;
+}
+
+// one merged record for members [first, last] of a chain (mappingFilter.hpp:536-562)
+MappingResult merge_span(const MappingResultsVector_t& m, size_t first, size_t last) {
+  MappingResult merged = m[first];
+  const uint32_t q_start = m[first].queryStartPos;
+  const uint32_t q_end = m[last].queryEndPos();
+  uint32_t r_start = m[first].refStartPos;
+  uint32_t r_end = m[last].refEndPos();
+  double total_id = 0, total_comp = 0;
+  uint32_t total_conserved = 0;
+  for (size_t k = first; k <= last; ++k) {
+    total_id += m[k].getNucIdentity();
+    total_comp += m[k].getKmerComplexity();
+    total_conserved += m[k].conservedSketches;
+    if (merged.strand() == strnd::REV) {
+      r_start = std::min(r_start, m[k].refStartPos);
+      r_end = std::max(r_end, (uint32_t)m[k].refEndPos());
+    }
+  }
+  merged.queryStartPos = q_start;
+  merged.refStartPos = (merged.strand() == strnd::FWD) ? r_start : m[last].refStartPos;
+  merged.blockLength = std::max(q_end - q_start, r_end - r_start);
+  merged.n_merged = (uint32_t)(last - first + 1);
+  merged.setNucIdentity(total_id / merged.n_merged);
+  merged.setKmerComplexity(total_comp / merged.n_merged);
+  merged.conservedSketches = total_conserved;
+  return merged;
+}
+
+// walks the chains of a chain-sorted vector, splitting each at max_mapping_length
+template <class Emit>
+void for_each_merged_span(const MappingResultsVector_t& m, const std::vector<offset_t>& chainOf, const Parameters& param, Emit emit) {
+  for (size_t i = 0; i < m.size();) {
+    size_t j = i;
+    while (j + 1 < m.size() && chainOf[j + 1] == chainOf[i]) ++j;
+    for (size_t first = i; first <= j;) {
+      size_t last = first;
+      while (last + 1 <= j) {
+        const offset_t query_span = m[last + 1].queryEndPos() - m[first].queryStartPos;
+        const offset_t ref_span = m[last + 1].refEndPos() - m[first].refStartPos;
+        if (std::max(query_span, ref_span) >= param.max_mapping_length) break;  // int64 against uint64, as the reference
+        ++last;
+      }
+      emit(i, j, first, last);
+      first = last + 1;
+    }
+    i = j + 1;
+  }
+}
+
+}  // namespace
+
+MappingsWithChains MappingFilterUtils::mergeMappingsInRangeWithChains(MappingResultsVector_t& readMappings, int max_dist, const Parameters& param) {
+  MappingsWithChains result;
+  if (!param.split || readMappings.size() < 2) {
+    result.mappings = readMappings;
+    result.chainInfo.resize(readMappings.size());
+    for (size_t i = 0; i < readMappings.size(); ++i) result.chainInfo[i] = {static_cast<uint32_t>(i), 1, 1};
+    return result;
+  }
+  const std::vector<offset_t> chainOf = chain_mappings(readMappings, max_dist, param);
+  std::map<uint32_t, uint32_t> denseId;  // representative -> sequential chain id
+  uint32_t nextId = 0;
+  uint32_t chainId = 0;
+  uint16_t chainPos = 1;
+  size_t current = (size_t)-1;
+  for_each_merged_span(readMappings, chainOf, param, [&](size_t i, size_t j, size_t first, size_t last) {
+    if (i != current) {
+      current = i;
+      auto it = denseId.find((uint32_t)chainOf[i]);
+      if (it == denseId.end()) it = denseId.emplace((uint32_t)chainOf[i], nextId++).first;
+      chainId = it->second;
+      chainPos = 1;
+    }
+    const uint16_t chainLen = (uint16_t)(j - i + 1);
+    result.mappings.push_back(merge_span(readMappings, first, last));
+    result.chainInfo.push_back({chainId, chainPos++, chainLen});
+  });
+  return result;
+}
+
+MappingResultsVector_t MappingFilterUtils::mergeMappingsInRange(MappingResultsVector_t& readMappings, int max_dist, const Parameters& param) {
+  if (!param.split || readMappings.size() < 2) return readMappings;
+  const std::vector<offset_t> chainOf = chain_mappings(readMappings, max_dist, param);
+  MappingResultsVector_t out;
+  for_each_merged_span(readMappings, chainOf, param,
+                       [&](size_t, size_t, size_t first, size_t last) { out.push_back(merge_span(readMappings, first, last)); });
+  return out;
+}
+
+namespace {
+
+// exact nearest-anchor distance in the (query midpoint, target midpoint) plane.  The reference
+// walks a KD-tree (mappingFilter.hpp:45-127); only the minimum distance is used, so anchors are
+// kept sorted by x and scanned outwards until |dx| alone exceeds the best distance.
+class AnchorIndex {
+ public:
+  explicit AnchorIndex(const MappingResultsVector_t& anchors) {
+    pts_.reserve(anchors.size());
+    for (const auto& m : anchors) pts_.push_back({m.queryStartPos + m.blockLength * 0.5f, m.refStartPos + m.blockLength * 0.5f});
+    std::sort(pts_.begin(), pts_.end(), [](const P& a, const P& b) { return a.x < b.x; });
+  }
+  float nearest(float x, float y) const {
+    if (pts_.empty()) return std::numeric_limits<float>::infinity();
+    float best = std::numeric_limits<float>::infinity();
+    const size_t mid = std::lower_bound(pts_.begin(), pts_.end(), x, [](const P& a, float v) { return a.x < v; }) - pts_.begin();
+    for (size_t i = mid; i < pts_.size(); ++i) {
+      if (std::abs(x - pts_[i].x) > best) break;
+      best = std::min(best, dist(pts_[i], x, y));
+    }
+    for (size_t i = mid; i-- > 0;) {
+      if (std::abs(x - pts_[i].x) > best) break;
+      best = std::min(best, dist(pts_[i], x, y));
+    }
+    return best;
+  }
+
+ private:
+  struct P { float x, y; };
+  static float dist(const P& a, float x, float y) { return std::sqrt((a.x - x) * (a.x - x) + (a.y - y) * (a.y - y)); }
+  std::vector<P> pts_;
+};
+
+}  // namespace
+
+void MappingFilterUtils::filterByScaffolds(MappingResultsVector_t& readMappings, const Parameters& param, const SequenceIdManager& idManager) {
+  if (param.scaffold_gap <= 0) return;
+  // scaffolds: chains formed with the (much larger) scaffold gap, long enough, and surviving a
+  // plane sweep of their own
+  MappingResultsVector_t work = readMappings;
+  const MappingResultsVector_t originals = work;
+  MappingResultsVector_t scaffolds = mergeMappingsInRange(work, (int)param.scaffold_gap, param);
+  scaffolds.erase(std::remove_if(scaffolds.begin(), scaffolds.end(),
+                                 [&](const MappingResult& m) { return m.blockLength < param.scaffold_min_length; }),
+                  scaffolds.end());
+  if (!scaffolds.empty() && (param.filterMode == filter::MAP || param.filterMode == filter::ONETOONE)) {
+    MappingResultsVector_t kept;
+    Parameters sweep = param;
+    sweep.overlap_threshold = param.scaffold_overlap_threshold;
+    filterByGroup(scaffolds, kept, param.numMappingsForScaffold - 1, false, idManager, sweep);
+    scaffolds = std::move(kept);
+  }
+  // anchors: the original mappings lying inside a scaffold
+  MappingResultsVector_t anchors;
+  for (const auto& chain : scaffolds)
+    for (const auto& orig : originals)
+      if (orig.refSeqId == chain.refSeqId && orig.strand() == chain.strand() && orig.queryStartPos >= chain.queryStartPos &&
+          orig.queryEndPos() <= chain.queryEndPos() && orig.refStartPos >= chain.refStartPos && orig.refEndPos() <= chain.refEndPos())
+        anchors.push_back(orig);
+  if (readMappings.empty()) return;
+  if (anchors.empty()) { readMappings.clear(); return; }
+  const AnchorIndex index(anchors);
+  const float max_dist = static_cast<float>(param.scaffold_max_deviation);
+  MappingResultsVector_t keepers;
+  for (const auto& m : readMappings)
+    if (index.nearest(m.queryStartPos + m.blockLength * 0.5f, m.refStartPos + m.blockLength * 0.5f) <= max_dist) keepers.push_back(m);
+  readMappings = std::move(keepers);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Map::filterSubsetMappings (computeMap.hpp:1076-1165)
+// ---------------------------------------------------------------------------------------------
+FilteredMappingsResult filterSubsetMappings(MappingResultsVector_t& mappings, const Parameters& param, const SequenceIdManager& idManager,
+                                            offset_t queryLen) {
+  FilteredMappingsResult result;
+  if (mappings.empty()) return result;
+  MappingsWithChains chained = MappingFilterUtils::mergeMappingsInRangeWithChains(mappings, (int)param.chain_gap, param);
+  MappingResultsVector_t& merged = chained.mappings;
+  if (param.mergeMappings && param.split) {
+    MappingFilterUtils::filterWeakMappings(merged, (int64_t)std::floor(param.block_length / param.windowLength), param, idManager, queryLen);
+    if (param.filterMode == filter::MAP || param.filterMode == filter::ONETOONE) {
+      MappingResultsVector_t kept;
+      // -n inf: uint32 max - 1 lands in an int as -2 (SURVEY 8a parity hazards)
+      MappingFilterUtils::filterByGroup(merged, kept, param.numMappingsForSegment - 1, false, idManager, param);
+      merged = std::move(kept);
+    }
+    if (param.filterLengthMismatches) MappingFilterUtils::filterFalseHighIdentity(merged, param);
+    MappingFilterUtils::sparsifyMappings(merged, param);
+    MappingFilterUtils::filterByScaffolds(merged, param, idManager);
+  } else {
+    if (param.filterMode == filter::MAP || param.filterMode == filter::ONETOONE) {
+      MappingResultsVector_t kept;
+      MappingFilterUtils::filterByGroup(mappings, kept, param.numMappingsForSegment - 1, false, idManager, param);
+      mappings = std::move(kept);
+    }
+    MappingFilterUtils::filterByScaffolds(mappings, param, idManager);
+  }
+  result.nonMergedMappings = std::move(mappings);
+  result.mergedMappings = std::move(merged);
+  result.nonMergedChainInfo.resize(result.nonMergedMappings.size());
+  for (size_t i = 0; i < result.nonMergedMappings.size(); ++i) result.nonMergedChainInfo[i] = {static_cast<uint32_t>(i), 1, 1};
+  result.mergedChainInfo = std::move(chained.chainInfo);
+  return result;
+}
+
+// ---------------------------------------------------------------------------------------------
+// MappingOutput (mappingOutput.hpp)
+// ---------------------------------------------------------------------------------------------
+void MappingOutput::mappingBoundarySanityCheck(offset_t queryLen, MappingResultsVector_t& readMappings, const SequenceIdManager& idManager) {
+  for (auto& e : readMappings) {
+    const offset_t refLen = idManager.getSequenceLength(e.refSeqId);
+    if (e.refStartPos >= refLen) e.refStartPos = refLen - 1;
+    if (e.refEndPos() < e.refStartPos) e.blockLength = 0;
+    if (e.refEndPos() >= refLen) e.blockLength = refLen - 1 - e.refStartPos;
+    if (e.queryStartPos >= queryLen) e.queryStartPos = queryLen;
+    if (e.queryEndPos() < e.queryStartPos) e.blockLength = 0;
+    if (e.queryEndPos() >= queryLen) e.blockLength = queryLen - e.queryStartPos;
+  }
+}
+
+void MappingOutput::reportReadMappings(MappingResultsVector_t& readMappings, const ChainInfoVector_t& chainInfo, const std::string& queryName,
+                                       std::ostream& outstrm, const SequenceIdManager& idManager, const Parameters& param, offset_t queryLen) {
+  std::vector<size_t> order(readMappings.size());
+  std::iota(order.begin(), order.end(), (size_t)0);
+  std::sort(order.begin(), order.end(), [&](size_t a, size_t b) { return readMappings[a].queryStartPos < readMappings[b].queryStartPos; });
+  const std::string sep = param.legacy_output ? " " : "\t";
+  for (size_t idx : order) {
+    const MappingResult& e = readMappings[idx];
+    const ChainInfo& chain = chainInfo[idx];
+    const float fakeMapQ = e.getNucIdentity() == 1 ? 255 : std::round(-10.0 * std::log10(1 - (e.getNucIdentity())));
+    outstrm << queryName << sep << queryLen << sep << e.queryStartPos << sep << e.queryEndPos() - (param.legacy_output ? 1 : 0) << sep
+            << (e.strand() == strnd::FWD ? "+" : "-") << sep << idManager.getSequenceName(e.refSeqId) << sep
+            << idManager.getSequenceLength(e.refSeqId) << sep << e.refStartPos << sep << e.refEndPos() - (param.legacy_output ? 1 : 0);
+    if (!param.legacy_output) {
+      outstrm << sep << e.conservedSketches << sep << e.blockLength << sep << fakeMapQ << sep << "id:f:" << e.getNucIdentity() << sep
+              << "kc:f:" << e.getKmerComplexity();
+      if (!param.mergeMappings) outstrm << sep << "jc:f:" << 0.0;
+      else outstrm << sep << "ch:Z:" << chain.chainId << "." << chain.chainPos << "." << chain.chainLen;
+    } else {
+      outstrm << sep << e.nucIdentity * 100.0;
+    }
+    outstrm << "\n";
+  }
+}
+
+void MappingOutput::reportReadMappings(MappingResultsVector_t& readMappings, const std::string& queryName, std::ostream& outstrm,
+                                       const SequenceIdManager& idManager, const Parameters& param, offset_t queryLen) {
+  ChainInfoVector_t own(readMappings.size());
+  for (size_t i = 0; i < readMappings.size(); ++i) own[i] = {static_cast<uint32_t>(i), 1, 1};
+  reportReadMappings(readMappings, own, queryName, outstrm, idManager, param, queryLen);
+}
+
+}  // namespace skch

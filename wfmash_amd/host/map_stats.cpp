@@ -16,7 +16,9 @@ float j2md(float j, int k) {
 
 float md2j(float d, int k) {
   const float sim = 1 - d;
-  const float jaccard = std::pow(sim, k) / (2 - std::pow(sim, k));  // pow(float,int) promotes to double (map_stats.hpp:77)
+  // std::pow(float, int) promotes both to double under g++ (map_stats.hpp:77); spelled out because hipcc adds a float overload
+  const double sk = std::pow((double)sim, (double)k);
+  const float jaccard = sk / (2 - sk);
   return jaccard;
 }
 
