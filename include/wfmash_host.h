@@ -103,6 +103,24 @@ typedef struct {
 
 void wfmh_map_default_params(wfmh_map_params_t* p);
 
+typedef struct {
+  uint64_t targets, queries, subsets;
+  uint64_t target_bp, query_bp;
+  uint64_t index_windows;   /* minmer intervals indexed (all subsets) */
+  uint64_t fragments;       /* query fragments mapped (all subsets) */
+  uint64_t l2_mappings;     /* MappingResults produced by the GPU stages */
+  uint64_t written;         /* mapping PAF records written */
+  double   ms_index, ms_map, ms_filter, ms_total;
+} wfmh_map_summary_t;
+
+/* The map phase on files: replaces skch::Map's constructor + mapQuery()
+ * (src/map/include/computeMap.hpp:147-230, :329-872).  Reads the FASTA files (query_fasta NULL or
+ * equal to target_fasta = all-vs-all), indexes the targets on the GPU, maps every query fragment
+ * (sketch, L1, L2 on the GPU), post-processes per query on the host and writes the approximate
+ * mapping PAF (the -m / -i hand-off file, parse_args.hpp:781-811).  Returns 0 or WFM_E_*. */
+int wfmh_map(wfm_handle_t* h, const char* target_fasta, const char* query_fasta, const char* out_paf,
+             const wfmh_map_params_t* params, wfmh_map_summary_t* summary);
+
 /* Test hook for the host-side post-processing of one query's mappings (CPU tests): runs
  * mappingBoundarySanityCheck + Map::filterSubsetMappings + reportReadMappings
  * (stage "subset"), or filterByGroup on the reference axis as the one-to-one pass does

@@ -1,0 +1,102 @@
+"""GPU end-to-end test of the map phase on files (wfmh_map: index + sketch + L1 + L2 on the GPU,
+post-processing on the host) against the stage oracles strung together (oracle/map_pipeline.py)
+and the reference's own filter/output code where it is built.  The mapping PAF must be
+byte-identical."""
+import os
+
+import pytest
+
+from oracle import map_pipeline as MP
+from oracle import pyfilter, pymap
+from oracle import wflign_host as W
+from wfmash_amd import capi, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _write_fasta(path, seqs, width=70):
+    with open(path, "w") as f, open(path + ".fai", "w") as fai:
+        off = 0
+        for name, s in seqs:
+            hdr = f">{name}\n"
+            f.write(hdr)
+            off += len(hdr)
+            fai.write(f"{name}\t{len(s)}\t{off}\t{width}\t{width + 1}\n")
+            t = s.decode()
+            for i in range(0, len(t), width):
+                f.write(t[i:i + width] + "\n")
+            off += len(t) + (len(t) + width - 1) // width
+
+
+def _pangenome(seed, L=30000):
+    base = synth.random_dna(seed, L)
+    unit = synth.random_dna(seed + 1, 900)
+    base = base[:L // 3] + unit + base[L // 3:L // 3 + 4000] + unit + base[L // 3 + 4000:]
+    seqs = []
+    for g, gname in enumerate(["HG01", "HG02", "HG03"]):
+        for hap in (1, 2):
+            s = synth.mutate(base, 0.01 + 0.015 * g, seed * 100 + g * 10 + hap)
+            if g == 1 and hap == 2:
+                s = W.revcomp(s)
+            if g == 2 and hap == 1:  # a large deletion and lower-case soft masking
+                s = s[:8000] + s[12500:20000].lower() + s[20000:]
+            seqs.append((f"{gname}#{hap}#chr1", s))
+    seqs.append(("tiny#1#x", synth.random_dna(seed + 9, 700)))       # shorter than a window: never indexed, never mapped
+    seqs.append(("other#1#chr2", synth.random_dna(seed + 7, 6500)))  # unrelated
+    return seqs
+
+
+def _expected(seqs, fa, P, pct, **kw):
+    add = None if pymap.have_ref() else kw.pop("add_minmers")
+    kw.pop("add_minmers", None)
+    maps, group, S = MP.map_queries(seqs, pct, add_minmers=add, **kw)
+    flt = pyfilter.ref_filter if pyfilter.have_ref() else capi.host_filter
+    return "".join(flt("subset", maps[q], fa, seqs[q][0], P) for q in range(len(seqs))), maps, S
+
+
+@pytest.mark.parametrize("over", [{}, {"num_mappings_for_segment": 1, "chain_gap": 5000}, {"merge_mappings": 0, "scaffold_gap": 0}],
+                         ids=["defaults", "n1_c5k", "no_merge"])
+def test_map_paf_matches_stage_oracles(gpu, tmp_path, over):
+    seqs = _pangenome(41)
+    fa = str(tmp_path / "pan.fa")
+    _write_fasta(fa, seqs)
+    pct = 0.85
+    P = capi.map_default_params(percentage_identity=pct, **over)
+    out = str(tmp_path / "map.paf")
+    summ = capi.map_paf(gpu, fa, out, params=P)
+    got = open(out).read()
+    S = MP.sketch_size(pct, 1000, 15)
+    exp, maps, S2 = _expected(seqs, fa, P, pct, add_minmers=lambda sq, sid: gpu.add_minmers(sq, 15, 1000, S, sid))
+    assert S == S2 == 49
+    assert summ.queries == len(seqs) and summ.targets == len(seqs) and summ.subsets == 1
+    assert summ.l2_mappings == sum(len(m) for m in maps.values()) > 300
+    assert got == exp
+    assert summ.written == len(got.splitlines()) > 10
+    # self and same-haplotype-group targets are never reported (-Y '#' default), the unrelated sequence maps nowhere
+    for line in got.splitlines():
+        f = line.split("\t")
+        assert f[0].rsplit("#", 1)[0] != f[5].rsplit("#", 1)[0]
+        assert "other" not in f[0] and "other" not in f[5] and "tiny" not in line
+
+
+def test_map_paf_target_subsets_and_query_file(gpu, tmp_path):
+    """-b style target batching (one index per subset) and a separate query file."""
+    seqs = _pangenome(43, L=20000)
+    fa = str(tmp_path / "t.fa")
+    _write_fasta(fa, seqs)
+    qfa = str(tmp_path / "q.fa")
+    queries = [("sample#1#ctg", synth.mutate(seqs[0][1][3000:17000], 0.03, 99))]
+    _write_fasta(qfa, queries)
+    P = capi.map_default_params(percentage_identity=0.85, index_by_size=45000)
+    out = str(tmp_path / "m.paf")
+    summ = capi.map_paf(gpu, fa, out, query_fasta=qfa, params=P)
+    assert summ.subsets >= 3 and summ.queries == 1 and summ.targets == len(seqs)
+    lines = open(out).read().splitlines()
+    assert len(lines) >= 6
+    hit = {l.split("\t")[5] for l in lines}
+    assert {f"HG0{g}#{h}#chr1" for g in (1, 2, 3) for h in (1, 2)} <= hit
+    for l in lines:
+        f = l.split("\t")
+        # the query was cut from this haplotype at 3000 (the end-anchored last fragment is reported at nfrag*w, computeMap.hpp:124-128)
+        if f[5] == "HG01#1#chr1" and int(f[2]) < 13000:
+            assert f[4] == "+" and abs((int(f[7]) - int(f[2])) - 3000) < 400

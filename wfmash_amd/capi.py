@@ -465,7 +465,27 @@ class Handle:
 # host-side align driver (include/wfmash_host.h)
 # ---------------------------------------------------------------------------
 HOST_EXPORTS = ["wfmh_align_default_params", "wfmh_align_paf", "wfmh_test_cigar", "wfmh_free", "wfmh_test_winnow",
-                "wfmh_map_default_params", "wfmh_test_filter"]
+                "wfmh_map_default_params", "wfmh_test_filter", "wfmh_map"]
+
+
+class MapSummary(C.Structure):
+    _fields_ = [("targets", C.c_uint64), ("queries", C.c_uint64), ("subsets", C.c_uint64), ("target_bp", C.c_uint64),
+                ("query_bp", C.c_uint64), ("index_windows", C.c_uint64), ("fragments", C.c_uint64), ("l2_mappings", C.c_uint64),
+                ("written", C.c_uint64), ("ms_index", C.c_double), ("ms_map", C.c_double), ("ms_filter", C.c_double),
+                ("ms_total", C.c_double)]
+
+
+def map_paf(handle, target_fasta: str, out_paf: str, query_fasta: str = None, params=None) -> "MapSummary":
+    """wfmh_map: the map phase on files (FASTA -> approximate mapping PAF)."""
+    L = load()
+    L.wfmh_map.restype = C.c_int
+    L.wfmh_map.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_void_p, C.POINTER(MapSummary)]
+    s = MapSummary()
+    rc = L.wfmh_map(handle._p, target_fasta.encode(), query_fasta.encode() if query_fasta else None, out_paf.encode(),
+                    C.byref(params) if params is not None else None, C.byref(s))
+    if rc != 0:
+        raise WfmError(f"wfmh_map failed ({rc}): {handle.last_error()}")
+    return s
 
 
 class MapHostParams(C.Structure):

@@ -6,8 +6,10 @@
 #include <string>
 
 #include "../../include/wfmash_host.h"
+#include "../csrc/wfa_handle.h"
 #include "capi_map.hpp"
 #include "map_filter.hpp"
+#include "mapper.hpp"
 #include "sequence_ids.hpp"
 
 namespace wfmash_host {
@@ -95,6 +97,32 @@ void wfmh_map_default_params(wfmh_map_params_t* c) {
   c->ani_diff_conf = p.ANIDiffConf;
   c->hg_numerator = p.hgNumerator;
   c->threads = p.threads;
+}
+
+int wfmh_map(wfm_handle_t* h, const char* target_fasta, const char* query_fasta, const char* out_paf, const wfmh_map_params_t* params,
+             wfmh_map_summary_t* summary) {
+  if (!h || !target_fasta || !out_paf) return WFM_E_ARG;
+  try {
+    wfmh_map_params_t def;
+    wfmh_map_default_params(&def);
+    skch::Parameters p = wfmash_host::to_parameters(params ? *params : def);
+    p.refSequences = {std::string(target_fasta)};
+    p.querySequences = {std::string(query_fasta ? query_fasta : target_fasta)};
+    p.outFileName = out_paf;
+    skch::Map mapper(p, h);
+    skch::MapSummary s;
+    const int rc = mapper.mapQuery(&s);
+    if (summary) {
+      summary->targets = s.targets; summary->queries = s.queries; summary->subsets = s.subsets;
+      summary->target_bp = s.target_bp; summary->query_bp = s.query_bp; summary->index_windows = s.index_windows;
+      summary->fragments = s.fragments; summary->l2_mappings = s.l2_mappings; summary->written = s.written;
+      summary->ms_index = s.ms_index; summary->ms_map = s.ms_map; summary->ms_filter = s.ms_filter; summary->ms_total = s.ms_total;
+    }
+    return rc;
+  } catch (const std::exception& e) {
+    wfm_set_error(h, e.what());
+    return WFM_E_ARG;
+  }
 }
 
 char* wfmh_test_filter(const char* stage, const wfm_mapping_t* maps, int64_t n, const char* fasta, const char* query_name,

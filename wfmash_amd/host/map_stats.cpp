@@ -120,5 +120,31 @@ std::vector<int> sketch_cutoffs(int sketchSize, int kmerSize, float ANIDiff, flo
   return cutoffs;
 }
 
+// Jaccard cutoff of the best-first L2 loop for a query sketch of qs minmers (computeMap.hpp:1001-1004)
+double l2_cutoff_j(int qs, int k, float ANIDiff, double hgNumerator) {
+  const double jaccardSimilarity = hgNumerator / qs;
+  const double mash_dist = j2md(jaccardSimilarity, k);
+  const double cutoff_ani = std::max(0.0, (1 - mash_dist) - ANIDiff);
+  return md2j(1 - cutoff_ani, k);
+}
+
+// identity test and scaled identity of an L2 locus with `shared` of qs sketch elements
+// (computeMap.hpp:1018-1036); index qs * (S + 1) + shared
+void l2_identity_tables(int S, int k, float percentageIdentity, bool keep_low_pct_id, float ci, std::vector<uint8_t>& keep,
+                        std::vector<uint16_t>& ident) {
+  keep.assign((size_t)(S + 1) * (S + 1), 0);
+  ident.assign((size_t)(S + 1) * (S + 1), 0);
+  for (int qs = 1; qs <= S; ++qs) {
+    for (int shared = 0; shared <= qs; ++shared) {
+      const float mash_dist = j2md(1.0 * shared / qs, k);
+      const float nucIdentity = (1 - mash_dist);
+      const float nucIdentityUpperBound = 1 - md_lower_bound(mash_dist, qs, k, ci);
+      const size_t t = (size_t)qs * (S + 1) + shared;
+      keep[t] = ((keep_low_pct_id && nucIdentityUpperBound >= percentageIdentity) || nucIdentity >= percentageIdentity) ? 1 : 0;
+      ident[t] = static_cast<uint16_t>(roundf(nucIdentity * 10000.0f));  // MappingResult::setNucIdentity
+    }
+  }
+}
+
 }  // namespace Stat
 }  // namespace skch

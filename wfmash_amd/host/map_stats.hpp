@@ -8,6 +8,7 @@
 // feed integer thresholds.
 #pragma once
 
+#include <cstdint>
 #include <vector>
 
 namespace skch {
@@ -23,6 +24,10 @@ int estimateMinimumHits(int s, int k, float perc_identity);
 int estimateMinimumHitsRelaxed(int s, int k, float perc_identity, float confidence_interval);
 // Map::setProbs: sketchCutoffs[cmax], cmax = 0 .. min(s, 1000)
 std::vector<int> sketch_cutoffs(int sketchSize, int kmerSize, float ANIDiff, float ANIDiffConf);
+// per-(Q.sketchSize, shared) tables the L2 kernels take (computeMap.hpp:1001-1004, :1018-1036)
+double l2_cutoff_j(int qs, int k, float ANIDiff, double hgNumerator);
+void l2_identity_tables(int S, int k, float percentageIdentity, bool keep_low_pct_id, float ci, std::vector<uint8_t>& keep,
+                        std::vector<uint16_t>& ident);
 
 }  // namespace Stat
 }  // namespace skch

@@ -1,0 +1,277 @@
+#include "mapper.hpp"
+
+#include <algorithm>
+#include <chrono>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <map>
+#include <sstream>
+#include <stdexcept>
+#include <unordered_map>
+
+#include "../csrc/wfa_handle.h"
+#include "fasta.hpp"
+#include "map_filter.hpp"
+#include "map_stats.hpp"
+
+namespace skch {
+
+namespace {
+
+constexpr float kConfidenceInterval = 0.95f;  // fixed::confidence_interval (map_parameters.hpp:125)
+constexpr int64_t kBatchBases = 256ll << 20;  // query bases per wfm_map_fragments call
+
+double now_ms() {
+  return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// all FASTA files of a run, loaded once; name -> sequence
+class SequenceSource {
+ public:
+  void add(const std::string& path) {
+    if (stores_.count(path)) return;
+    stores_.emplace(path, std::make_unique<wfmash_host::FastaStore>(path));
+    order_.push_back(path);
+  }
+  // the first file holding `name`, restricted to `files`
+  const std::string* find(const std::vector<std::string>& files, const std::string& name) const {
+    for (const auto& f : files) {
+      const auto& st = *stores_.at(f);
+      for (int i = 0; i < st.nseq(); ++i)
+        if (st.name(i) == name) return &st.sequence(i);
+    }
+    return nullptr;
+  }
+
+ private:
+  std::unordered_map<std::string, std::unique_ptr<wfmash_host::FastaStore>> stores_;
+  std::vector<std::string> order_;
+};
+
+struct DeviceTables {
+  std::vector<int32_t> ref_group, min_hits, cutoffs;
+  std::vector<uint8_t> keep;
+  std::vector<uint16_t> ident;
+  std::vector<double> cutoff_j;
+  wfm_map_params_t prm;
+};
+
+}  // namespace
+
+Map::Map(const Parameters& p, wfm_handle_t* h) : param_(p), h_(h) {
+  if (param_.querySequences.empty()) param_.querySequences = param_.refSequences;  // all-vs-all
+  if (param_.sketchSize <= 0) {
+    const double md = 1 - param_.percentageIdentity;
+    const double dens = 0.02 * (1 + (md / 0.1));
+    param_.sketchSize = dens * (param_.windowLength - param_.kmerSize);
+  }
+  if (param_.sketchSize < 1 || param_.sketchSize > param_.windowLength) throw std::runtime_error("sketch size must be in 1..window size");
+  idManager_ = std::make_unique<SequenceIdManager>(param_.querySequences, param_.refSequences, param_.query_prefix,
+                                                   std::vector<std::string>{param_.target_prefix}, std::string(1, param_.prefix_delim),
+                                                   param_.query_list, param_.target_list);
+  cached_minimum_hits_ = std::max(param_.minimum_hits, Stat::estimateMinimumHitsRelaxed(param_.sketchSize, param_.kmerSize,
+                                                                                         param_.percentageIdentity, kConfidenceInterval));
+}
+
+int Map::mapQuery(MapSummary* summary) {
+  MapSummary sum;
+  const double t_begin = now_ms();
+  const Parameters& P = param_;
+  const SequenceIdManager& ids = *idManager_;
+  const int S = P.sketchSize, k = P.kmerSize;
+  const int64_t w = P.windowLength;
+
+  // names as Map's constructor selects them (computeMap.hpp:162-190)
+  std::vector<std::string> queryNames, targetNames;
+  for (const auto& n : ids.getQuerySequenceNames()) {
+    bool ok = P.query_prefix.empty();
+    for (const auto& pre : P.query_prefix) ok = ok || n.compare(0, pre.size(), pre) == 0;
+    if (ok) queryNames.push_back(n);
+  }
+  for (const auto& n : ids.getTargetSequenceNames())
+    if (P.target_prefix.empty() || n.compare(0, P.target_prefix.size(), P.target_prefix) == 0) targetNames.push_back(n);
+
+  SequenceSource src;
+  for (const auto& f : P.refSequences) src.add(f);
+  for (const auto& f : P.querySequences) src.add(f);
+
+  // thresholds and tables the kernels take
+  DeviceTables T;
+  T.ref_group = ids.refGroupTable();
+  T.min_hits.assign((size_t)S + 1, 0);
+  for (int q = 1; q <= S; ++q)
+    T.min_hits[q] = std::max(P.minimum_hits, Stat::estimateMinimumHitsRelaxed(q, k, P.percentageIdentity, kConfidenceInterval));
+  if (P.stage1_topANI_filter) {
+    const std::vector<int> c = Stat::sketch_cutoffs(S, k, P.ANIDiff, P.ANIDiffConf);
+    T.cutoffs.assign(c.begin(), c.end());
+  } else {
+    T.cutoffs.assign((size_t)std::min<double>(S, 1000.0) + 1, 1);
+  }
+  Stat::l2_identity_tables(S, k, P.percentageIdentity, P.keep_low_pct_id, kConfidenceInterval, T.keep, T.ident);
+  T.cutoff_j.assign((size_t)S + 1, 0.0);
+  for (int q = 1; q <= S; ++q) T.cutoff_j[q] = Stat::l2_cutoff_j(q, k, P.ANIDiff, P.hgNumerator);
+  std::memset(&T.prm, 0, sizeof(T.prm));
+  T.prm.kmer_size = k;
+  T.prm.kmer_complexity_threshold = P.kmerComplexityThreshold;
+  wfm_l1_params_t& l1 = T.prm.l1;
+  l1.window_length = (int32_t)w; l1.sketch_size = S; l1.min_hits_cached = cached_minimum_hits_; l1.cached_segment_length = (int32_t)w;
+  l1.skip_self = P.skip_self; l1.skip_prefix = P.skip_prefix; l1.lower_triangular = P.lower_triangular;
+  l1.stage1_topANI_filter = P.stage1_topANI_filter; l1.stage2_full_scan = P.stage2_full_scan;
+  l1.n_seq = (int32_t)T.ref_group.size(); l1.ref_group = T.ref_group.data(); l1.min_hits_by_qsketch = T.min_hits.data();
+  l1.sketch_cutoffs = T.cutoffs.data(); l1.n_cutoffs = (int32_t)T.cutoffs.size();
+  wfm_l2_params_t& l2 = T.prm.l2;
+  l2.window_length = (int32_t)w; l2.sketch_size = S; l2.stage1_topANI_filter = P.stage1_topANI_filter;
+  l2.keep_table = T.keep.data(); l2.ident_table = T.ident.data(); l2.cutoff_j = T.cutoff_j.data();
+
+  // createTargetSubsets (computeMap.hpp:295-327)
+  std::vector<std::vector<std::string>> subsets;
+  {
+    const int64_t batch = P.index_by_size > 0 ? P.index_by_size : 5000000;
+    std::vector<std::string> cur;
+    uint64_t cur_size = 0;
+    for (size_t i = 0; i < targetNames.size(); ++i) {
+      cur.push_back(targetNames[i]);
+      cur_size += ids.getSequenceLength(ids.getSequenceId(targetNames[i]));
+      if (cur_size >= (uint64_t)batch || i + 1 == targetNames.size()) { subsets.push_back(cur); cur.clear(); cur_size = 0; }
+    }
+  }
+  sum.targets = targetNames.size();
+  sum.queries = queryNames.size();
+  sum.subsets = subsets.size();
+  for (const auto& n : targetNames) sum.target_bp += ids.getSequenceLength(ids.getSequenceId(n));
+  for (const auto& n : queryNames) sum.query_bp += ids.getSequenceLength(ids.getSequenceId(n));
+
+  const bool to_stdout = P.outFileName == "/dev/stdout" || P.outFileName == "-";
+  std::ofstream file;
+  if (!to_stdout) {
+    file.open(P.outFileName);
+    if (!file.is_open()) { wfm_set_error(h_, "cannot open output file " + P.outFileName); return WFM_E_ARG; }
+  }
+  std::ostream& out = to_stdout ? static_cast<std::ostream&>(std::cout) : file;
+  std::map<seqno_t, MappingResultsVector_t> combined;  // one-to-one mode: everything is held back
+
+  for (const auto& subset : subsets) {
+    // ---- index of this subset (Sketch::build)
+    double t0 = now_ms();
+    std::vector<wfm_minmer_t> minmers;
+    for (const auto& name : subset) {
+      const std::string* seq = src.find(P.refSequences, name);
+      if (!seq) { wfm_set_error(h_, "target sequence not found in FASTA: " + name); return WFM_E_ARG; }
+      if ((int64_t)seq->size() < w) continue;  // "skipping short sequence" (winSketch.hpp:216-229)
+      std::vector<wfm_minmer_t> buf(4 * seq->size() / std::max<int64_t>(1, w / S / 2 + 1) + 1024);
+      int64_t n = wfm_add_minmers(h_, seq->data(), (int64_t)seq->size(), k, (int)w, S, ids.getSequenceId(name), buf.data(), (int64_t)buf.size());
+      if (n > (int64_t)buf.size()) {
+        buf.resize((size_t)n);
+        n = wfm_add_minmers(h_, seq->data(), (int64_t)seq->size(), k, (int)w, S, ids.getSequenceId(name), buf.data(), (int64_t)buf.size());
+      }
+      if (n < 0) return (int)n;
+      minmers.insert(minmers.end(), buf.begin(), buf.begin() + n);
+    }
+    sum.index_windows += minmers.size();
+    wfm_index_t* ix = nullptr;
+    if (!minmers.empty()) {
+      const int rc = wfm_index_build(h_, minmers.data(), (int64_t)minmers.size(), P.max_kmer_freq, &ix);
+      if (rc != WFM_OK) return rc;
+    }
+    std::vector<wfm_minmer_t>().swap(minmers);
+    sum.ms_index += now_ms() - t0;
+
+    // ---- queries, in batches of whole sequences
+    size_t qi = 0;
+    while (qi < queryNames.size()) {
+      t0 = now_ms();
+      struct BatchQuery { std::string name; seqno_t id; offset_t len; int64_t base; int64_t first_frag; int nfrag; };
+      std::vector<BatchQuery> bq;
+      std::string buffer;
+      std::vector<int64_t> frag_off;
+      std::vector<int32_t> frag_seq;
+      while (qi < queryNames.size() && ((int64_t)buffer.size() < kBatchBases || bq.empty())) {
+        const std::string& name = queryNames[qi++];
+        const std::string* seq = src.find(P.querySequences, name);
+        if (!seq || seq->empty()) continue;  // "not found or empty, skipping" (computeMap.hpp:534-537)
+        BatchQuery q{name, ids.getSequenceId(name), (offset_t)seq->size(), (int64_t)buffer.size(), (int64_t)frag_off.size(), 0};
+        const int whole = (int)(q.len / w);
+        for (int i = 0; i < whole; ++i) frag_off.push_back(q.base + (int64_t)i * w);
+        q.nfrag = whole;
+        if (whole >= 1 && q.len % w != 0) { frag_off.push_back(q.base + q.len - w); q.nfrag++; }  // anchored at the end
+        frag_seq.insert(frag_seq.end(), (size_t)q.nfrag, q.id);
+        buffer += *seq;
+        bq.push_back(std::move(q));
+      }
+      std::vector<wfm_mapping_t> maps;
+      std::vector<int32_t> mfrag;
+      if (ix && !frag_off.empty()) {
+        int64_t cap = std::max<int64_t>(1 << 16, (int64_t)frag_off.size() * 8);
+        for (;;) {
+          maps.resize((size_t)cap); mfrag.resize((size_t)cap);
+          const int64_t n = wfm_map_fragments(h_, ix, buffer.data(), (int64_t)buffer.size(), frag_off.data(), frag_seq.data(),
+                                              (int64_t)frag_off.size(), &T.prm, maps.data(), mfrag.data(), cap);
+          if (n < 0) { wfm_index_free(h_, ix); return (int)n; }
+          if (n <= cap) { maps.resize((size_t)n); mfrag.resize((size_t)n); break; }
+          cap = n;
+        }
+      }
+      sum.fragments += frag_off.size();
+      sum.l2_mappings += maps.size();
+      sum.ms_map += now_ms() - t0;
+
+      // ---- per query: boundary check, filters, output (processFragment :124-128; query task :634-688)
+      t0 = now_ms();
+      size_t m = 0;
+      for (const auto& q : bq) {
+        MappingResultsVector_t results;
+        while (m < maps.size() && mfrag[m] < q.first_frag + q.nfrag) {
+          MappingResult r;
+          std::memcpy(&r, &maps[m], sizeof(r));
+          r.queryStartPos += (uint32_t)((mfrag[m] - q.first_frag) * w);  // fragmentIndex * windowLength, also for the anchored one
+          results.push_back(r);
+          ++m;
+        }
+        MappingOutput::mappingBoundarySanityCheck(q.len, results, ids);
+        FilteredMappingsResult fr = filterSubsetMappings(results, P, ids, q.len);
+        const bool merged = P.mergeMappings && P.split;
+        MappingResultsVector_t& keep = merged ? fr.mergedMappings : fr.nonMergedMappings;
+        const ChainInfoVector_t& chains = merged ? fr.mergedChainInfo : fr.nonMergedChainInfo;
+        if (P.filterMode == filter::ONETOONE) {
+          auto& dst = combined[q.id];
+          dst.insert(dst.end(), keep.begin(), keep.end());
+        } else {
+          MappingOutput::reportReadMappings(keep, chains, q.name, out, ids, P, q.len);
+          sum.written += keep.size();
+        }
+      }
+      out.flush();
+      sum.ms_filter += now_ms() - t0;
+    }
+    if (ix) wfm_index_free(h_, ix);
+  }
+
+  if (P.filterMode == filter::ONETOONE) {
+    // final reference-axis pass (computeMap.hpp:790-866).  The reference walks unordered maps here;
+    // ids ascending is used instead, which fixes the order of the output records.
+    const double t0 = now_ms();
+    std::map<seqno_t, MappingResultsVector_t> byTarget, final_;
+    for (auto& [qid, v] : combined)
+      for (auto& r : v) byTarget[(seqno_t)r.refSeqId].push_back(r);
+    for (auto& [tid, v] : byTarget) {
+      MappingResultsVector_t kept;
+      MappingFilterUtils::filterByGroup(v, kept, P.numMappingsForSegment - 1, true, ids, P);
+      for (const auto& r : kept)
+        for (auto& [qid, orig] : combined)
+          for (const auto& o : orig)
+            if (o.refSeqId == r.refSeqId && o.refStartPos == r.refStartPos && o.queryStartPos == r.queryStartPos) { final_[qid].push_back(r); break; }
+    }
+    for (auto& [qid, v] : final_) {
+      MappingOutput::reportReadMappings(v, ids.getSequenceName(qid), out, ids, P, ids.getSequenceLength(qid));
+      sum.written += v.size();
+    }
+    out.flush();
+    sum.ms_filter += now_ms() - t0;
+  }
+  sum.ms_total = now_ms() - t_begin;
+  if (summary) *summary = sum;
+  return WFM_OK;
+}
+
+}  // namespace skch
