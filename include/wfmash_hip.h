@@ -191,6 +191,12 @@ int  wfm_index_download(wfm_handle_t* h, const wfm_index_t* ix, uint64_t* uhash,
 int64_t wfm_add_minmers(wfm_handle_t* h, const char* seq, int64_t len, int k, int w, int s, int32_t seq_id,
                         wfm_minmer_t* out, int64_t cap);
 
+/* MinHash of one whole sequence for the ANI estimate (estimate_identity_for_groups,
+ * src/map/include/map_stats.hpp:325-822; StreamingMinHash, streamingMinHash.hpp:35-135): the
+ * sketch_size smallest canonical k-mer hashes, duplicates included, ascending.  Returns how many
+ * were written (< sketch_size for short or N-rich sequences) or a WFM_E_* code. */
+int64_t wfm_minhash_sketch(wfm_handle_t* h, const char* seq, int64_t len, int k, int sketch_size, uint64_t* out);
+
 /* L1 stage: getSeedIntervalPoints + computeL1CandidateRegions + doL1Mapping's group loop
  * (mappingCore.hpp:82-301, computeMap.hpp:945-984) for a batch of query fragments against a
  * device-resident index.  One candidate = skch::L1_candidateLocus_t (base_types.hpp:212-224)

@@ -99,6 +99,10 @@ typedef struct {
   float    ani_diff, ani_diff_conf;   /* 0.0, 0.999 */
   double   hg_numerator;              /* 1.0 */
   int32_t  threads;                   /* 1 */
+  int32_t  auto_pct_identity;         /* 1: estimate the identity from the data, -p aniN[+-adj] (parse_args.hpp:341-395);
+                                         0: use percentage_identity as given */
+  int32_t  ani_percentile;            /* 50 */
+  float    ani_adjustment;            /* -2.0 (percent) */
 } wfmh_map_params_t;
 
 void wfmh_map_default_params(wfmh_map_params_t* p);
@@ -110,6 +114,8 @@ typedef struct {
   uint64_t fragments;       /* query fragments mapped (all subsets) */
   uint64_t l2_mappings;     /* MappingResults produced by the GPU stages */
   uint64_t written;         /* mapping PAF records written */
+  float    percentage_identity;  /* the threshold used (estimated when auto_pct_identity) */
+  int32_t  sketch_size;          /* the sketch size used */
   double   ms_index, ms_map, ms_filter, ms_total;
 } wfmh_map_summary_t;
 

@@ -1,0 +1,49 @@
+"""GPU parity tests of the automatic identity estimate: wfm_minhash_sketch against
+the StreamingMinHash restatement, and the threshold + sketch size wfmh_map derives from it."""
+import numpy as np
+import pytest
+
+from oracle import map_ani as ANI
+from oracle import map_pipeline as MP
+from wfmash_amd import capi, synth
+from tests.test_map_paf_gpu import _pangenome, _write_fasta
+
+pytestmark = pytest.mark.gpu
+
+
+def test_minhash_sketch_matches_restatement(gpu):
+    base = synth.random_dna(77, 60000)
+    cases = {
+        "plain": base,
+        "lower_and_iupac": base[:20000].lower() + b"RYKM" + base[20000:40000] + b"N" * 500 + base[40000:],
+        "ambiguous_head": base[:7] + b"N" + base[8:30000],          # arms the counter for k-mers 0..20
+        "repeat": synth.random_dna(5, 300) * 150,                    # duplicates fill the sketch
+        "short": base[:2000],                                        # fewer k-mers than the sketch holds
+        "tiny": base[:20],                                           # shorter than k
+        "all_n": b"N" * 3000,
+    }
+    for name, sq in cases.items():
+        got = gpu.minhash_sketch(sq)
+        exp = ANI.minhash_sketch(sq)
+        assert len(got) == len(exp), name
+        assert (got == exp).all(), name
+    assert len(gpu.minhash_sketch(cases["repeat"])) == 4096 and len(set(gpu.minhash_sketch(cases["repeat"]).tolist())) < 400
+    small = gpu.minhash_sketch(base, k=15, sketch_size=64)
+    assert (small == ANI.minhash_sketch(base, 15, 64)).all()
+
+
+def test_auto_identity_drives_threshold_and_sketch_size(gpu, tmp_path):
+    seqs = _pangenome(51)
+    fa = str(tmp_path / "pan.fa")
+    _write_fasta(fa, seqs)
+    names = [n for n, _ in seqs]
+    groups = MP.ref_groups(names)
+    for pctl, adj in ((50, -2.0), (25, 0.0)):
+        exp = ANI.estimate_identity([s for _, s in seqs], groups, pctl, adj)
+        P = capi.map_default_params(ani_percentile=pctl, ani_adjustment=adj)
+        assert P.auto_pct_identity == 1
+        summ = capi.map_paf(gpu, fa, str(tmp_path / f"m{pctl}.paf"), params=P)
+        assert summ.percentage_identity == np.float32(exp)
+        assert 0.90 < summ.percentage_identity < 1.0
+        assert summ.sketch_size == MP.sketch_size(np.float32(exp), 1000, 15)
+        assert summ.written > 5

@@ -61,7 +61,7 @@ def test_map_paf_matches_stage_oracles(gpu, tmp_path, over):
     fa = str(tmp_path / "pan.fa")
     _write_fasta(fa, seqs)
     pct = 0.85
-    P = capi.map_default_params(percentage_identity=pct, **over)
+    P = capi.map_default_params(percentage_identity=pct, auto_pct_identity=0, **over)
     out = str(tmp_path / "map.paf")
     summ = capi.map_paf(gpu, fa, out, params=P)
     got = open(out).read()
@@ -87,7 +87,7 @@ def test_map_paf_target_subsets_and_query_file(gpu, tmp_path):
     qfa = str(tmp_path / "q.fa")
     queries = [("sample#1#ctg", synth.mutate(seqs[0][1][3000:17000], 0.03, 99))]
     _write_fasta(qfa, queries)
-    P = capi.map_default_params(percentage_identity=0.85, index_by_size=45000)
+    P = capi.map_default_params(percentage_identity=0.85, auto_pct_identity=0, index_by_size=45000)
     out = str(tmp_path / "m.paf")
     summ = capi.map_paf(gpu, fa, out, query_fasta=qfa, params=P)
     assert summ.subsets >= 3 and summ.queries == 1 and summ.targets == len(seqs)

@@ -24,7 +24,7 @@ EXPORTS = [
     "wfm_free_sequences", "wfm_align_resident", "wfm_get_stats",
     "wfm_hash_kmers", "wfm_sketch_fragments", "wfm_add_minmers",
     "wfm_index_build", "wfm_index_free", "wfm_index_info", "wfm_index_download",
-    "wfm_map_l1", "wfm_map_l2", "wfm_map_fragments",
+    "wfm_map_l1", "wfm_map_l2", "wfm_map_fragments", "wfm_minhash_sketch",
 ]
 
 
@@ -416,6 +416,18 @@ class Handle:
                 return out[:n], frag[:n]
             cap = int(n)
 
+    def minhash_sketch(self, seq: bytes, k: int = 21, sketch_size: int = 4096):
+        """wfm_minhash_sketch: bottom-sketch_size canonical k-mer hashes (with multiplicity) of one sequence."""
+        out = np.zeros(sketch_size, dtype=np.uint64)
+        buf = np.frombuffer(seq, dtype=np.uint8)
+        f = self._L.wfm_minhash_sketch
+        f.restype = C.c_int64
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p]
+        n = f(self._p, buf.ctypes.data, len(seq), k, sketch_size, out.ctypes.data)
+        if n < 0:
+            raise WfmError(f"wfm_minhash_sketch failed ({n}): {self.last_error()}")
+        return out[:n]
+
     def map_l2(self, index, qsketch, qcount, q_len, q_kc, s, cands, params):
         """wfm_map_l2: mappings (MAPPING_DTYPE) + fragment ids for a batch of L1 candidates.
         params: dict(window_length, sketch_size, stage1_topani, keep_table, ident_table, cutoff_j)."""
@@ -471,7 +483,7 @@ HOST_EXPORTS = ["wfmh_align_default_params", "wfmh_align_paf", "wfmh_test_cigar"
 class MapSummary(C.Structure):
     _fields_ = [("targets", C.c_uint64), ("queries", C.c_uint64), ("subsets", C.c_uint64), ("target_bp", C.c_uint64),
                 ("query_bp", C.c_uint64), ("index_windows", C.c_uint64), ("fragments", C.c_uint64), ("l2_mappings", C.c_uint64),
-                ("written", C.c_uint64), ("ms_index", C.c_double), ("ms_map", C.c_double), ("ms_filter", C.c_double),
+                ("written", C.c_uint64), ("percentage_identity", C.c_float), ("sketch_size", C.c_int32), ("ms_index", C.c_double), ("ms_map", C.c_double), ("ms_filter", C.c_double),
                 ("ms_total", C.c_double)]
 
 
@@ -500,7 +512,8 @@ class MapHostParams(C.Structure):
                 ("scaffold_min_length", C.c_int64), ("legacy_output", C.c_int32), ("minimum_hits", C.c_int32),
                 ("max_kmer_freq", C.c_double), ("index_by_size", C.c_int64), ("kmer_complexity_threshold", C.c_float),
                 ("stage1_topani_filter", C.c_int32), ("stage2_full_scan", C.c_int32), ("ani_diff", C.c_float),
-                ("ani_diff_conf", C.c_float), ("hg_numerator", C.c_double), ("threads", C.c_int32)]
+                ("ani_diff_conf", C.c_float), ("hg_numerator", C.c_double), ("threads", C.c_int32),
+                ("auto_pct_identity", C.c_int32), ("ani_percentile", C.c_int32), ("ani_adjustment", C.c_float)]
 
 
 def map_default_params(**over) -> MapHostParams:

@@ -12,6 +12,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <cstring>  // rocprim's texture iterator calls host memset
+
+#include <rocprim/rocprim.hpp>
+
 #include <string>
 #include <vector>
 
@@ -300,6 +304,49 @@ int wfm_hash_kmers(wfm_handle_t* h, const char* seq, int64_t len, int k, uint64_
   HIPCHK(h, hipMemcpyAsync(strand, d_st, (size_t)nk, hipMemcpyDeviceToHost, st));
   HIPCHK(h, hipStreamSynchronize(st));
   return WFM_OK;
+}
+
+// Bottom-`sketch_size` MinHash of one sequence as StreamingMinHash keeps it (streamingMinHash.hpp:90-100):
+// the smallest canonical hashes WITH multiplicity of all k-mers free of non-ACGT bases whose two
+// strands hash differently (map_stats.hpp:569-616).  An ambiguous base among the first k bases
+// blanks k-mers 0..k-1 (the counter is armed with k there, :574-580).  One hashing pass + one
+// device radix sort.
+int64_t wfm_minhash_sketch(wfm_handle_t* h, const char* seq, int64_t len, int k, int sketch_size, uint64_t* out) {
+  if (!h || !seq || len < 0 || sketch_size < 1 || !out) return WFM_E_ARG;
+  if (k < 1 || k > 32) { wfm_set_error(h, "k must be in 1..32"); return WFM_E_UNSUPPORTED; }
+  const int64_t nk = len - k + 1;
+  if (nk <= 0) return 0;
+  HIPCHK(h, hipSetDevice(wfm_device(h)));
+  Scoped sc;
+  uint8_t* d_norm = nullptr;
+  int rc = upload_normalised(h, sc, seq, len, &d_norm);
+  if (rc != WFM_OK) return rc;
+  uint64_t *d_hash = nullptr, *d_sorted = nullptr; int8_t* d_st = nullptr;
+  HIPCHK(h, sc.alloc(&d_hash, (size_t)nk * 8));
+  HIPCHK(h, sc.alloc(&d_sorted, (size_t)nk * 8));
+  HIPCHK(h, sc.alloc(&d_st, (size_t)nk));
+  hipStream_t st = wfm_stream(h);
+  const int blocks = (int)std::min<int64_t>((nk + 255) / 256, 256 * 8);
+  hipLaunchKernelGGL(kmer_hash_kernel, dim3(blocks), dim3(256), 0, st, d_norm, nk, k, d_hash, d_st);
+  HIPCHK(h, hipGetLastError());
+  bool head_ambiguous = false;
+  for (int j = 0; j < k && j < len; ++j) {
+    char c = seq[j];
+    if (c > 96 && c < 123) c -= 32;
+    if (c != 'A' && c != 'C' && c != 'G' && c != 'T') { head_ambiguous = true; break; }
+  }
+  if (head_ambiguous) HIPCHK(h, hipMemsetAsync(d_hash, 0xff, (size_t)std::min<int64_t>(k, nk) * 8, st));
+  size_t tmp = 0;
+  HIPCHK(h, rocprim::radix_sort_keys(nullptr, tmp, d_hash, d_sorted, (size_t)nk, 0, 64, st));
+  char* d_tmp = nullptr;
+  HIPCHK(h, sc.alloc(&d_tmp, tmp));
+  HIPCHK(h, rocprim::radix_sort_keys(d_tmp, tmp, d_hash, d_sorted, (size_t)nk, 0, 64, st));
+  const int64_t n = std::min<int64_t>(sketch_size, nk);
+  HIPCHK(h, hipMemcpyAsync(out, d_sorted, (size_t)n * 8, hipMemcpyDeviceToHost, st));
+  HIPCHK(h, hipStreamSynchronize(st));
+  int64_t valid = n;
+  while (valid > 0 && out[valid - 1] == ~0ull) --valid;  // invalid k-mers sort last
+  return valid;
 }
 
 int wfm_sketch_fragments(wfm_handle_t* h, const char* seq, int64_t seq_len, const int64_t* frag_off,

@@ -1,0 +1,105 @@
+#include "ani_estimate.hpp"
+
+#include <algorithm>
+#include <map>
+#include <memory>
+#include <string>
+#include <stdexcept>
+#include <unordered_map>
+#include <utility>
+#include <vector>
+
+#include "fasta.hpp"
+#include "map_stats.hpp"
+
+namespace skch {
+namespace Stat {
+
+namespace {
+constexpr int kEstimationK = 21;             // map_stats.hpp:328
+constexpr int kEstimationSketchSize = 4096;  // map_stats.hpp:330
+constexpr double kFallbackIdentity = 0.70;   // fixed::percentage_identity
+
+// StreamingMinHash keeps the smallest values with their multiplicity, so pooling is a multiset
+// union cut back to the sketch size.
+void pool(std::vector<hash_t>& group, const std::vector<hash_t>& add) {
+  group.insert(group.end(), add.begin(), add.end());
+  std::sort(group.begin(), group.end());
+  if (group.size() > (size_t)kEstimationSketchSize) group.resize(kEstimationSketchSize);
+}
+}  // namespace
+
+double estimate_identity_for_groups(const Parameters& params, const SequenceIdManager& idManager, wfm_handle_t* h) {
+  struct Role { std::string file; bool is_query = false, is_target = false; };
+  std::map<std::string, Role> roles;  // the reference walks a hash map here; the result does not depend on the order
+  std::unordered_map<std::string, std::unique_ptr<wfmash_host::FastaStore>> stores;
+  auto open = [&](const std::string& file) -> wfmash_host::FastaStore& {
+    auto it = stores.find(file);
+    if (it == stores.end()) it = stores.emplace(file, std::make_unique<wfmash_host::FastaStore>(file)).first;
+    return *it->second;
+  };
+  auto known = [&](const std::string& name) {
+    try { return idManager.getSequenceName(idManager.getSequenceId(name)) == name; } catch (const std::exception&) { return false; }
+  };
+  for (const auto& file : params.querySequences) {
+    auto& fa = open(file);
+    for (int i = 0; i < fa.nseq(); ++i)
+      if (known(fa.name(i))) { Role& r = roles[fa.name(i)]; r.file = file; r.is_query = true; }
+  }
+  for (const auto& file : params.refSequences) {
+    auto& fa = open(file);
+    for (int i = 0; i < fa.nseq(); ++i)
+      if (known(fa.name(i))) { Role& r = roles[fa.name(i)]; if (r.file.empty()) r.file = file; r.is_target = true; }
+  }
+  std::map<int, std::vector<hash_t>> query_groups, target_groups;
+  for (const auto& [name, role] : roles) {
+    const int g = idManager.getRefGroup(idManager.getSequenceId(name));
+    if (role.is_query) query_groups[g];
+    if (role.is_target) target_groups[g];
+  }
+  int query_seq_count = 0, target_seq_count = 0;
+  std::vector<hash_t> sketch((size_t)kEstimationSketchSize);
+  for (const auto& [name, role] : roles) {
+    const wfmash_host::FastaStore& fa = open(role.file);
+    const int64_t len = fa.seq_len(name);
+    if (len <= 0) continue;  // "not found or empty, skipping"
+    const std::string seq = fa.fetch(name, 0, len - 1);
+    const int64_t n = wfm_minhash_sketch(h, seq.data(), (int64_t)seq.size(), kEstimationK, kEstimationSketchSize, sketch.data());
+    if (n < 0) throw std::runtime_error(std::string("wfm_minhash_sketch failed: ") + wfm_last_error(h));
+    const std::vector<hash_t> s(sketch.begin(), sketch.begin() + n);
+    const int g = idManager.getRefGroup(idManager.getSequenceId(name));
+    if (role.is_query) { pool(query_groups[g], s); ++query_seq_count; }
+    if (role.is_target) { pool(target_groups[g], s); ++target_seq_count; }
+  }
+  if (query_seq_count == 0 || target_seq_count == 0) return kFallbackIdentity;
+
+  std::vector<double> anis;
+  for (const auto& [qg, qs] : query_groups) {
+    for (const auto& [tg, ts] : target_groups) {
+      // same-group pairs are skipped; (A,B) and (B,A) are both taken: the reference's self-mode test
+      // compares the addresses of two different members and never holds (map_stats.hpp:712-715)
+      if (qg == tg || qs.empty() || ts.empty()) continue;
+      size_t shared = 0, i = 0, j = 0;
+      while (i < qs.size() && j < ts.size()) {
+        if (qs[i] == ts[j]) { ++shared; ++i; ++j; }
+        else if (qs[i] < ts[j]) ++i;
+        else ++j;
+      }
+      if (shared == 0) continue;
+      const double jaccard = static_cast<double>(shared) / std::min(qs.size(), ts.size());
+      const double mash_dist = j2md(jaccard, kEstimationK);
+      anis.push_back(1.0 - mash_dist);
+    }
+  }
+  if (anis.empty()) return kFallbackIdentity;
+  std::sort(anis.begin(), anis.end());
+  size_t idx = (params.ani_percentile * anis.size()) / 100;
+  if (idx >= anis.size()) idx = anis.size() - 1;
+  double adjusted = anis[idx] + (params.ani_adjustment / 100.0);
+  if (adjusted < 0.0) adjusted = 0.0;
+  if (adjusted > 1.0) adjusted = 1.0;
+  return adjusted;
+}
+
+}  // namespace Stat
+}  // namespace skch

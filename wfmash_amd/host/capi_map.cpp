@@ -7,6 +7,7 @@
 
 #include "../../include/wfmash_host.h"
 #include "../csrc/wfa_handle.h"
+#include "ani_estimate.hpp"
 #include "capi_map.hpp"
 #include "map_filter.hpp"
 #include "mapper.hpp"
@@ -51,6 +52,9 @@ skch::Parameters to_parameters(const wfmh_map_params_t& c) {
   p.ANIDiffConf = c.ani_diff_conf;
   p.hgNumerator = c.hg_numerator;
   p.threads = c.threads;
+  p.auto_pct_identity = c.auto_pct_identity != 0;
+  p.ani_percentile = c.ani_percentile;
+  p.ani_adjustment = c.ani_adjustment;
   return p;
 }
 
@@ -97,6 +101,9 @@ void wfmh_map_default_params(wfmh_map_params_t* c) {
   c->ani_diff_conf = p.ANIDiffConf;
   c->hg_numerator = p.hgNumerator;
   c->threads = p.threads;
+  c->auto_pct_identity = p.auto_pct_identity;
+  c->ani_percentile = p.ani_percentile;
+  c->ani_adjustment = p.ani_adjustment;
 }
 
 int wfmh_map(wfm_handle_t* h, const char* target_fasta, const char* query_fasta, const char* out_paf, const wfmh_map_params_t* params,
@@ -109,6 +116,14 @@ int wfmh_map(wfm_handle_t* h, const char* target_fasta, const char* query_fasta,
     p.refSequences = {std::string(target_fasta)};
     p.querySequences = {std::string(query_fasta ? query_fasta : target_fasta)};
     p.outFileName = out_paf;
+    if (p.auto_pct_identity) {
+      // main.cpp:72-128: estimate, then derive the sketch size from the estimate unless -s was given
+      std::vector<std::string> target_prefix_vec;
+      if (!p.target_prefix.empty()) target_prefix_vec.push_back(p.target_prefix);
+      const skch::SequenceIdManager ids(p.querySequences, p.refSequences, p.query_prefix, target_prefix_vec,
+                                        std::string(1, p.prefix_delim), p.query_list, p.target_list);
+      p.percentageIdentity = skch::Stat::estimate_identity_for_groups(p, ids, h);
+    }
     skch::Map mapper(p, h);
     skch::MapSummary s;
     const int rc = mapper.mapQuery(&s);
@@ -116,6 +131,8 @@ int wfmh_map(wfm_handle_t* h, const char* target_fasta, const char* query_fasta,
       summary->targets = s.targets; summary->queries = s.queries; summary->subsets = s.subsets;
       summary->target_bp = s.target_bp; summary->query_bp = s.query_bp; summary->index_windows = s.index_windows;
       summary->fragments = s.fragments; summary->l2_mappings = s.l2_mappings; summary->written = s.written;
+      summary->percentage_identity = mapper.parameters().percentageIdentity;
+      summary->sketch_size = mapper.parameters().sketchSize;
       summary->ms_index = s.ms_index; summary->ms_map = s.ms_map; summary->ms_filter = s.ms_filter; summary->ms_total = s.ms_total;
     }
     return rc;

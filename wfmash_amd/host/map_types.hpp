@@ -119,6 +119,9 @@ struct Parameters {
   int64_t index_by_size = std::numeric_limits<int64_t>::max();  // :766-768
   int minimum_hits = 3;                    // :729-731
   double max_kmer_freq = 0.0002;           // :735-737
+  bool auto_pct_identity = true;           // -p ani50-2 (:41-43, :392-395); an explicit -p switches it off
+  int ani_percentile = 50;
+  float ani_adjustment = -2.0f;
   std::vector<std::string> refSequences, querySequences;
   std::string target_list, target_prefix, query_list;
   std::vector<std::string> query_prefix;
