@@ -191,6 +191,14 @@ int  wfm_index_download(wfm_handle_t* h, const wfm_index_t* ix, uint64_t* uhash,
 int64_t wfm_add_minmers(wfm_handle_t* h, const char* seq, int64_t len, int k, int w, int s, int32_t seq_id,
                         wfm_minmer_t* out, int64_t cap);
 
+/* wfm_add_minmers for nseq sequences: the GPU hashes one sequence after the other while `threads`
+ * host workers winnow the ones already hashed (one sequence per worker = the reference's
+ * ThreadPool, winSketch.hpp:200-239).  out receives the intervals of all sequences concatenated
+ * in input order, counts[i] (optional) the number of sequence i.  Returns the total (may exceed
+ * cap; only cap are written) or a WFM_E_* code. */
+int64_t wfm_add_minmers_multi(wfm_handle_t* h, const char* const* seqs, const int64_t* lens, const int32_t* seq_ids,
+                              int64_t nseq, int k, int w, int s, int threads, wfm_minmer_t* out, int64_t cap, int64_t* counts);
+
 /* MinHash of one whole sequence for the ANI estimate (estimate_identity_for_groups,
  * src/map/include/map_stats.hpp:325-822; StreamingMinHash, streamingMinHash.hpp:35-135): the
  * sketch_size smallest canonical k-mer hashes, duplicates included, ascending.  Returns how many

@@ -100,3 +100,44 @@ def test_map_paf_target_subsets_and_query_file(gpu, tmp_path):
         # the query was cut from this haplotype at 3000 (the end-anchored last fragment is reported at nfrag*w, computeMap.hpp:124-128)
         if f[5] == "HG01#1#chr1" and int(f[2]) < 13000:
             assert f[4] == "+" and abs((int(f[7]) - int(f[2])) - 3000) < 400
+
+
+def test_cli_map_then_align_equals_two_phase_run(gpu, tmp_path):
+    """wfmash-hip target.fa == wfmash-hip -m | wfmash-hip -i (the reference's two-phase restart), and every
+    record is a valid base-level alignment of the FASTA (pafcheck-style)."""
+    import subprocess
+    cli = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "wfmash_amd", "wfmash-hip")
+    seqs = _pangenome(47, L=24000)
+    fa = str(tmp_path / "pan.fa")
+    _write_fasta(fa, seqs)
+    one, m, two = str(tmp_path / "one.paf"), str(tmp_path / "m.paf"), str(tmp_path / "two.paf")
+    subprocess.check_call([cli, "-p", "85", "-t", "4", "--out", one, fa], cwd=str(tmp_path))
+    subprocess.check_call([cli, "-m", "-p", "85", "--out", m, fa], cwd=str(tmp_path))
+    subprocess.check_call([cli, "-i", m, "--out", two, fa], cwd=str(tmp_path))
+    a, b = open(one).read(), open(two).read()
+    assert a == b and len(a.splitlines()) >= 10
+    assert not [f for f in os.listdir(tmp_path) if f.startswith("wfmash-")]  # the hand-off file is removed
+    by_name = dict(seqs)
+    for line in a.splitlines():
+        f = line.split("\t")
+        qs, qe, strand, ts, te = int(f[2]), int(f[3]), f[4], int(f[7]), int(f[8])
+        cg = [x for x in f if x.startswith("cg:Z:")][0][5:]
+        qseq = W.upper_valid_dna(by_name[f[0]][qs:qe])
+        if strand == "-":
+            qseq = W.revcomp(qseq)
+        tseq = W.upper_valid_dna(by_name[f[5]][ts:te])
+        qi = ti = 0
+        for n, op in W.parse(cg):
+            if op == "=":
+                assert qseq[qi:qi + n] == tseq[ti:ti + n]
+                qi += n; ti += n
+            elif op == "X":
+                qi += n; ti += n
+            elif op == "I":
+                qi += n
+            else:
+                ti += n
+        assert qi == len(qseq) and ti == len(tseq)
+    # auto identity (the default -p ani50-2) runs end to end too
+    subprocess.check_call([cli, "-m", "--out", str(tmp_path / "auto.paf"), fa], cwd=str(tmp_path))
+    assert len(open(tmp_path / "auto.paf").read().splitlines()) >= 6

@@ -24,7 +24,7 @@ EXPORTS = [
     "wfm_free_sequences", "wfm_align_resident", "wfm_get_stats",
     "wfm_hash_kmers", "wfm_sketch_fragments", "wfm_add_minmers",
     "wfm_index_build", "wfm_index_free", "wfm_index_info", "wfm_index_download",
-    "wfm_map_l1", "wfm_map_l2", "wfm_map_fragments", "wfm_minhash_sketch",
+    "wfm_map_l1", "wfm_map_l2", "wfm_map_fragments", "wfm_minhash_sketch", "wfm_add_minmers_multi",
 ]
 
 

@@ -1,6 +1,7 @@
 #include "mapper.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstring>
 #include <fstream>
@@ -8,6 +9,7 @@
 #include <map>
 #include <sstream>
 #include <stdexcept>
+#include <thread>
 #include <unordered_map>
 
 #include "../csrc/wfa_handle.h"
@@ -155,18 +157,29 @@ int Map::mapQuery(MapSummary* summary) {
     // ---- index of this subset (Sketch::build)
     double t0 = now_ms();
     std::vector<wfm_minmer_t> minmers;
-    for (const auto& name : subset) {
-      const std::string* seq = src.find(P.refSequences, name);
-      if (!seq) { wfm_set_error(h_, "target sequence not found in FASTA: " + name); return WFM_E_ARG; }
-      if ((int64_t)seq->size() < w) continue;  // "skipping short sequence" (winSketch.hpp:216-229)
-      std::vector<wfm_minmer_t> buf(4 * seq->size() / std::max<int64_t>(1, w / S / 2 + 1) + 1024);
-      int64_t n = wfm_add_minmers(h_, seq->data(), (int64_t)seq->size(), k, (int)w, S, ids.getSequenceId(name), buf.data(), (int64_t)buf.size());
-      if (n > (int64_t)buf.size()) {
-        buf.resize((size_t)n);
-        n = wfm_add_minmers(h_, seq->data(), (int64_t)seq->size(), k, (int)w, S, ids.getSequenceId(name), buf.data(), (int64_t)buf.size());
+    {
+      std::vector<const char*> sp;
+      std::vector<int64_t> sl;
+      std::vector<int32_t> si;
+      int64_t bases = 0;
+      for (const auto& name : subset) {
+        const std::string* seq = src.find(P.refSequences, name);
+        if (!seq) { wfm_set_error(h_, "target sequence not found in FASTA: " + name); return WFM_E_ARG; }
+        if ((int64_t)seq->size() < w) continue;  // "skipping short sequence" (winSketch.hpp:216-229)
+        sp.push_back(seq->data()); sl.push_back((int64_t)seq->size()); si.push_back(ids.getSequenceId(name));
+        bases += (int64_t)seq->size();
+      }
+      // about 2 s / w intervals per base; grown on demand
+      minmers.resize((size_t)(bases / std::max<int64_t>(1, w) * S * 3 + 4096));
+      int64_t n = wfm_add_minmers_multi(h_, sp.data(), sl.data(), si.data(), (int64_t)sp.size(), k, (int)w, S, P.threads, minmers.data(),
+                                        (int64_t)minmers.size(), nullptr);
+      if (n > (int64_t)minmers.size()) {
+        minmers.resize((size_t)n);
+        n = wfm_add_minmers_multi(h_, sp.data(), sl.data(), si.data(), (int64_t)sp.size(), k, (int)w, S, P.threads, minmers.data(),
+                                  (int64_t)minmers.size(), nullptr);
       }
       if (n < 0) return (int)n;
-      minmers.insert(minmers.end(), buf.begin(), buf.begin() + n);
+      minmers.resize((size_t)n);
     }
     sum.index_windows += minmers.size();
     wfm_index_t* ix = nullptr;
@@ -218,27 +231,56 @@ int Map::mapQuery(MapSummary* summary) {
 
       // ---- per query: boundary check, filters, output (processFragment :124-128; query task :634-688)
       t0 = now_ms();
-      size_t m = 0;
-      for (const auto& q : bq) {
-        MappingResultsVector_t results;
-        while (m < maps.size() && mfrag[m] < q.first_frag + q.nfrag) {
-          MappingResult r;
-          std::memcpy(&r, &maps[m], sizeof(r));
-          r.queryStartPos += (uint32_t)((mfrag[m] - q.first_frag) * w);  // fragmentIndex * windowLength, also for the anchored one
-          results.push_back(r);
-          ++m;
+      // queries are independent here (the reference runs one Taskflow task per query); results are
+      // written in query order afterwards
+      std::vector<size_t> first_map(bq.size() + 1, maps.size());
+      {
+        size_t m = 0;
+        for (size_t qn = 0; qn < bq.size(); ++qn) {
+          first_map[qn] = m;
+          while (m < maps.size() && mfrag[m] < bq[qn].first_frag + bq[qn].nfrag) ++m;
         }
-        MappingOutput::mappingBoundarySanityCheck(q.len, results, ids);
-        FilteredMappingsResult fr = filterSubsetMappings(results, P, ids, q.len);
-        const bool merged = P.mergeMappings && P.split;
-        MappingResultsVector_t& keep = merged ? fr.mergedMappings : fr.nonMergedMappings;
-        const ChainInfoVector_t& chains = merged ? fr.mergedChainInfo : fr.nonMergedChainInfo;
+      }
+      struct QueryOut { MappingResultsVector_t keep; std::string text; };
+      std::vector<QueryOut> qout(bq.size());
+      std::atomic<size_t> next{0};
+      auto work = [&]() {
+        for (size_t qn; (qn = next.fetch_add(1)) < bq.size();) {
+          const BatchQuery& q = bq[qn];
+          MappingResultsVector_t results;
+          for (size_t m = first_map[qn]; m < first_map[qn + 1]; ++m) {
+            MappingResult r;
+            std::memcpy(&r, &maps[m], sizeof(r));
+            r.queryStartPos += (uint32_t)((mfrag[m] - q.first_frag) * w);  // fragmentIndex * windowLength, also for the anchored one
+            results.push_back(r);
+          }
+          MappingOutput::mappingBoundarySanityCheck(q.len, results, ids);
+          FilteredMappingsResult fr = filterSubsetMappings(results, P, ids, q.len);
+          const bool merged = P.mergeMappings && P.split;
+          MappingResultsVector_t& keep = merged ? fr.mergedMappings : fr.nonMergedMappings;
+          const ChainInfoVector_t& chains = merged ? fr.mergedChainInfo : fr.nonMergedChainInfo;
+          if (P.filterMode != filter::ONETOONE) {
+            std::ostringstream os;
+            MappingOutput::reportReadMappings(keep, chains, q.name, os, ids, P, q.len);
+            qout[qn].text = os.str();
+          }
+          qout[qn].keep = std::move(keep);
+        }
+      };
+      {
+        const int nt = (int)std::min<size_t>((size_t)std::max(1, P.threads), bq.size());
+        std::vector<std::thread> pool;
+        for (int t = 1; t < nt; ++t) pool.emplace_back(work);
+        work();
+        for (auto& t : pool) t.join();
+      }
+      for (size_t qn = 0; qn < bq.size(); ++qn) {
         if (P.filterMode == filter::ONETOONE) {
-          auto& dst = combined[q.id];
-          dst.insert(dst.end(), keep.begin(), keep.end());
+          auto& dst = combined[bq[qn].id];
+          dst.insert(dst.end(), qout[qn].keep.begin(), qout[qn].keep.end());
         } else {
-          MappingOutput::reportReadMappings(keep, chains, q.name, out, ids, P, q.len);
-          sum.written += keep.size();
+          out << qout[qn].text;
+          sum.written += qout[qn].keep.size();
         }
       }
       out.flush();

@@ -14,9 +14,14 @@
 //   pool      lazy min-heap (hash, pos) of window k-mers that are not in the sketch
 #include <algorithm>
 #include <cmath>
+#include <condition_variable>
 #include <cstring>
 #include <deque>
 #include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <thread>
 #include <tuple>
 #include <vector>
 
@@ -222,6 +227,93 @@ extern "C" int64_t wfm_add_minmers(wfm_handle_t* h, const char* seq, int64_t len
   const int64_t n = (int64_t)res.size();
   for (int64_t i = 0; i < n && i < cap; ++i) out[i] = res[(size_t)i];
   return n;
+}
+
+// Many sequences at once: the calling thread feeds the GPU (one hashing pass per sequence) while
+// `threads` host workers winnow the sequences already hashed -- one sequence per worker, the
+// reference's own parallelism (winSketch.hpp:200-239, ThreadPool over buildHelper).  Output is the
+// concatenation in input order, whatever order the workers finish in.
+extern "C" int64_t wfm_add_minmers_multi(wfm_handle_t* h, const char* const* seqs, const int64_t* lens, const int32_t* seq_ids, int64_t nseq,
+                                         int k, int w, int s, int threads, wfm_minmer_t* out, int64_t cap, int64_t* counts) {
+  if (!h || nseq < 0 || (nseq && (!seqs || !lens || !seq_ids)) || (cap && !out)) return WFM_E_ARG;
+  if (k < 1 || k > 32 || w < k || s < 1) { wfm_set_error(h, "need 1 <= k <= 32, w >= k, s >= 1"); return WFM_E_UNSUPPORTED; }
+  struct Job {
+    int64_t idx;
+    std::string norm;
+    std::vector<uint64_t> hash;
+    std::vector<int8_t> strand;
+  };
+  std::vector<std::vector<wfm_minmer_t>> results((size_t)nseq);
+  std::deque<std::unique_ptr<Job>> queue;
+  std::mutex mu;
+  std::condition_variable cv_work, cv_room;
+  bool done = false;
+  int64_t inflight_bases = 0;
+  const int64_t max_inflight = 1ll << 31;  // ~2 Gbp of hashed-but-not-winnowed sequence (9 B/base of hashes)
+  const int nthreads = std::max(1, threads);
+  std::vector<std::thread> pool;
+  for (int t = 0; t < nthreads; ++t) {
+    pool.emplace_back([&]() {
+      for (;;) {
+        std::unique_ptr<Job> job;
+        {
+          std::unique_lock<std::mutex> lk(mu);
+          cv_work.wait(lk, [&] { return done || !queue.empty(); });
+          if (queue.empty()) return;
+          job = std::move(queue.front());
+          queue.pop_front();
+        }
+        const int64_t len = (int64_t)job->norm.size();
+        for (auto& c : job->norm) {  // makeUpperCaseAndValidDNA (commonFunc.hpp:132-142)
+          if (c > 96 && c < 123) c -= 32;
+          if (!(c == 'A' || c == 'C' || c == 'G' || c == 'T')) c = 'N';
+        }
+        winnow(job->norm.data(), len, k, w, s, seq_ids[job->idx], job->hash.data(), job->strand.data(), results[(size_t)job->idx]);
+        {
+          std::lock_guard<std::mutex> lk(mu);
+          inflight_bases -= len;
+        }
+        cv_room.notify_one();
+      }
+    });
+  }
+  int rc = WFM_OK;
+  for (int64_t i = 0; i < nseq && rc == WFM_OK; ++i) {
+    const int64_t len = lens[i];
+    if (!seqs[i] || len < 0) { rc = WFM_E_ARG; break; }
+    if (len < k) continue;
+    auto job = std::make_unique<Job>();
+    job->idx = i;
+    const int64_t nk = len - k + 1;
+    job->hash.resize((size_t)nk);
+    job->strand.resize((size_t)nk);
+    rc = wfm_hash_kmers(h, seqs[i], len, k, job->hash.data(), job->strand.data());
+    if (rc != WFM_OK) break;
+    job->norm.assign(seqs[i], (size_t)len);  // upper-cased / N-masked by the worker
+    {
+      std::unique_lock<std::mutex> lk(mu);
+      cv_room.wait(lk, [&] { return inflight_bases == 0 || inflight_bases + len <= max_inflight; });
+      inflight_bases += len;
+      queue.push_back(std::move(job));
+    }
+    cv_work.notify_one();
+  }
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    done = true;
+  }
+  cv_work.notify_all();
+  for (auto& t : pool) t.join();
+  if (rc != WFM_OK) return rc;
+  int64_t total = 0;
+  for (int64_t i = 0; i < nseq; ++i) {
+    const auto& r = results[(size_t)i];
+    if (counts) counts[i] = (int64_t)r.size();
+    for (size_t j = 0; j < r.size(); ++j)
+      if (total + (int64_t)j < cap) out[total + (int64_t)j] = r[j];
+    total += (int64_t)r.size();
+  }
+  return total;
 }
 
 // Test hook (CPU test-suite): the host winnowing stage on caller-supplied k-mer hashes.
