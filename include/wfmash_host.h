@@ -103,6 +103,11 @@ typedef struct {
                                          0: use percentage_identity as given */
   int32_t  ani_percentile;            /* 50 */
   float    ani_adjustment;            /* -2.0 (percent) */
+  /* sequence selection (parse_args.hpp:112-115); NULL = unset */
+  const char* target_prefix;          /* -T: only targets whose name starts with this */
+  const char* target_list;            /* -R: file with target names */
+  const char* query_prefix;           /* -Q: comma-separated name prefixes */
+  const char* query_list;             /* -A: file with query names (also how ranks shard the queries) */
 } wfmh_map_params_t;
 
 void wfmh_map_default_params(wfmh_map_params_t* p);

@@ -56,3 +56,50 @@ def test_gather_bytes_two_ranks():
     # every record exactly once
     seen = sorted(int(x.split(b":")[0][3:]) for part in out for x in part.split(b"|"))
     assert seen == list(range(40))
+
+
+# ---- map path: queries sharded over ranks, text gathered and re-ordered on rank 0 ----
+
+_QUERIES = [(f"s{i}#1#c", 1000 * ((i * 37) % 11 + 1)) for i in range(9)]
+
+
+def _fake_map(names):
+    """stands in for wfmh_map on a query list: a query-dependent number of records per query"""
+    return "".join(f"{n}\t{dict(_QUERIES)[n]}\t{j}\trest\n" for n in names for j in range(len(n) % 3 + (dict(_QUERIES)[n] // 4000)))
+
+
+def _map_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from wfmash_amd.dist import map_sharded
+    names = [n for n, _ in _QUERIES]
+    out = map_sharded(_fake_map, names, [l for _, l in _QUERIES], dist)
+    if rank == 0:
+        q.put(out)
+    else:
+        assert out is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_map_sharded_two_ranks_reproduces_single_process_order():
+    from wfmash_amd.dist import map_sharded, shard_queries
+    names = [n for n, _ in _QUERIES]
+    single = map_sharded(_fake_map, names, [l for _, l in _QUERIES], None)
+    assert single == _fake_map(names)
+    shards = shard_queries([l for _, l in _QUERIES], 2)
+    assert sorted(shards[0] + shards[1]) == list(range(len(names))) and shards[0] and shards[1]
+    loads = [sum(_QUERIES[i][1] for i in s) for s in shards]
+    assert abs(loads[0] - loads[1]) <= max(l for _, l in _QUERIES)
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_map_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert out == single

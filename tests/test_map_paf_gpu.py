@@ -141,3 +141,30 @@ def test_cli_map_then_align_equals_two_phase_run(gpu, tmp_path):
     # auto identity (the default -p ani50-2) runs end to end too
     subprocess.check_call([cli, "-m", "--out", str(tmp_path / "auto.paf"), fa], cwd=str(tmp_path))
     assert len(open(tmp_path / "auto.paf").read().splitlines()) >= 6
+
+
+def test_query_sharding_reproduces_single_run(gpu, tmp_path):
+    """the multi-GPU map path: every rank indexes all targets and maps its shard of the queries
+    (-A query list); merging the per-rank texts gives the single-GPU output.  Ranks are run one after
+    the other on the one GPU here."""
+    from wfmash_amd import dist as D
+    seqs = _pangenome(53, L=20000)
+    fa = str(tmp_path / "pan.fa")
+    _write_fasta(fa, seqs)
+    names = [n for n, _ in seqs]
+    lens = [len(s) for _, s in seqs]
+    single = str(tmp_path / "single.paf")
+    capi.map_paf(gpu, fa, single, params=capi.map_default_params(percentage_identity=0.85, auto_pct_identity=0))
+
+    def map_fn(mine):
+        lst = str(tmp_path / f"q{abs(hash(tuple(mine))) % 10**8}.txt")
+        with open(lst, "w") as f:
+            f.write("\n".join(mine) + "\n")
+        out = lst + ".paf"
+        capi.map_paf(gpu, fa, out, params=capi.map_default_params(percentage_identity=0.85, auto_pct_identity=0, query_list=lst))
+        return open(out).read()
+
+    shards = D.shard_queries(lens, 3)
+    texts = [map_fn([names[i] for i in sh]) for sh in shards]
+    assert D.merge_query_blocks(texts, names) == open(single).read()
+    assert sum(1 for t in texts if t) >= 2

@@ -513,7 +513,8 @@ class MapHostParams(C.Structure):
                 ("max_kmer_freq", C.c_double), ("index_by_size", C.c_int64), ("kmer_complexity_threshold", C.c_float),
                 ("stage1_topani_filter", C.c_int32), ("stage2_full_scan", C.c_int32), ("ani_diff", C.c_float),
                 ("ani_diff_conf", C.c_float), ("hg_numerator", C.c_double), ("threads", C.c_int32),
-                ("auto_pct_identity", C.c_int32), ("ani_percentile", C.c_int32), ("ani_adjustment", C.c_float)]
+                ("auto_pct_identity", C.c_int32), ("ani_percentile", C.c_int32), ("ani_adjustment", C.c_float),
+                ("target_prefix", C.c_char_p), ("target_list", C.c_char_p), ("query_prefix", C.c_char_p), ("query_list", C.c_char_p)]
 
 
 def map_default_params(**over) -> MapHostParams:
@@ -523,7 +524,7 @@ def map_default_params(**over) -> MapHostParams:
     L.wfmh_map_default_params.argtypes = [C.POINTER(MapHostParams)]
     L.wfmh_map_default_params(C.byref(p))
     for k, v in over.items():
-        if k == "prefix_delim" and isinstance(v, str):
+        if isinstance(v, str):
             v = v.encode()
         setattr(p, k, v)
     return p

@@ -49,3 +49,46 @@ def gather_bytes(payload: torch.Tensor, dist, dst=0):
         return [recv[r][:sizes[r]] for r in range(world)]
     dist.gather(buf, gather_list=None, dst=dst)
     return None
+
+
+# ---- map path: the queries shard, the target index is replicated on every rank ----
+
+def shard_queries(lengths, world_size):
+    """Query sequences are independent units of the map phase (one Taskflow task per query,
+    computeMap.hpp:527-688): greedy longest-first onto the least-loaded rank, weight = sequence
+    length (mapping cost is linear in the number of fragments)."""
+    return shard_records([float(x) for x in lengths], world_size)
+
+
+def merge_query_blocks(rank_texts, query_order):
+    """Reassembles the single-GPU record order from per-rank mapping PAF texts: a rank prints the
+    records of one query as one consecutive block (reportReadMappings runs once per query), and the
+    single-GPU run prints the blocks in query order.  query_order: all query names in file order."""
+    blocks = {}
+    for text in rank_texts:
+        for line in text.splitlines(keepends=True):
+            blocks.setdefault(line.split("\t", 1)[0], []).append(line)
+    return "".join("".join(blocks.get(q, [])) for q in query_order)
+
+
+def map_sharded(map_fn, query_names, query_lengths, dist=None, device=None):
+    """Runs the map phase with the queries sharded over the ranks of `dist` (None = single process).
+
+    map_fn(names) -> mapping PAF text of those queries against ALL targets (e.g. a closure over
+    capi.map_paf with a -A style query list; every rank builds the same target index).  No
+    data-path collective: the only exchange is the gather of the PAF text to rank 0, which returns
+    the text in single-GPU record order; other ranks return None."""
+    world = dist.get_world_size() if dist is not None else 1
+    rank = dist.get_rank() if dist is not None else 0
+    shards = shard_queries(query_lengths, world)
+    mine = [query_names[i] for i in shards[rank]]
+    text = map_fn(mine) if mine else ""
+    if dist is None:
+        return merge_query_blocks([text], query_names)
+    payload = torch.frombuffer(bytearray(text.encode()), dtype=torch.uint8) if text else torch.zeros(0, dtype=torch.uint8)
+    if device is not None:
+        payload = payload.to(device)
+    parts = gather_bytes(payload, dist, dst=0)
+    if parts is None:
+        return None
+    return merge_query_blocks([bytes(p.cpu().numpy().tobytes()).decode() for p in parts], query_names)

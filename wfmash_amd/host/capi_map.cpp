@@ -55,6 +55,13 @@ skch::Parameters to_parameters(const wfmh_map_params_t& c) {
   p.auto_pct_identity = c.auto_pct_identity != 0;
   p.ani_percentile = c.ani_percentile;
   p.ani_adjustment = c.ani_adjustment;
+  if (c.target_prefix) p.target_prefix = c.target_prefix;
+  if (c.target_list) p.target_list = c.target_list;
+  if (c.query_list) p.query_list = c.query_list;
+  if (c.query_prefix) {  // CommonFunc::split(args::get(query_prefix), ',') (parse_args.hpp:204)
+    std::stringstream ss(c.query_prefix);
+    for (std::string tok; std::getline(ss, tok, ',');) p.query_prefix.push_back(tok);
+  }
   return p;
 }
 

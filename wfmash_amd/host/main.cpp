@@ -115,6 +115,10 @@ int main(int argc, char** argv) {
     }
     else if (a == "--scaffold-overlap") mp.scaffold_overlap_threshold = atof(next("--scaffold-overlap").c_str());
     else if (a == "-Y" || a == "--group-prefix") { const std::string v = next("-Y"); mp.prefix_delim = v.empty() ? '\0' : v[0]; mp.skip_prefix = mp.prefix_delim != '\0'; }
+    else if (a == "-T" || a == "--target-prefix") mp.target_prefix = argv[(next("-T"), i)];
+    else if (a == "-R" || a == "--target-list") mp.target_list = argv[(next("-R"), i)];
+    else if (a == "-Q" || a == "--query-prefix") mp.query_prefix = argv[(next("-Q"), i)];
+    else if (a == "-A" || a == "--query-list") mp.query_list = argv[(next("-A"), i)];
     else if (a == "-X" || a == "--self-maps") mp.skip_self = 0;
     else if (a == "-L" || a == "--lower-triangular") mp.lower_triangular = 1;
     // ---- alignment (parse_args.hpp:119-129)
