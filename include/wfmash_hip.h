@@ -20,7 +20,14 @@
  *                              (MurmurHash3_x64_128 seed 42, src/common/murmur3.h:226-302)
  *     wfm_sketch_fragments  <- CommonFunc::sketchSequence, commonFunc.hpp:218-323
  *                              via MappingCore::getSeedHits, mappingCore.hpp:62-76
- *     wfm_add_minmers       <- CommonFunc::addMinmers, commonFunc.hpp:440-708
+ *     wfm_add_minmers[_multi] <- CommonFunc::addMinmers, commonFunc.hpp:440-708
+ *     wfm_index_build       <- Sketch::build (index stage), winSketch.hpp:266-429
+ *     wfm_map_l1            <- getSeedIntervalPoints + computeL1CandidateRegions, mappingCore.hpp:82-301
+ *     wfm_map_l2            <- computeL2MappedRegions + SlideMapper + doL2Mapping,
+ *                              mappingCore.hpp:307-442, slidingMap.hpp:28-212, computeMap.hpp:989-1061
+ *     wfm_map_fragments     <- Map::mapSingleQueryFrag for a whole batch, computeMap.hpp:875-938
+ *     wfm_minhash_sketch    <- StreamingMinHash over one sequence (ANI estimate), map_stats.hpp:569-616
+ *   (file-level drivers of both phases: include/wfmash_host.h)
  *
  * All pointers are HOST memory unless stated; the library owns every device
  * buffer.  No torch types.  A handle is bound to one GPU and is not

@@ -433,9 +433,8 @@ int align_resident_impl(wfm_handle* h, const wfm_penalties_t* pen, wfm_seqset* S
         const Node& nd = bp_nodes[i];
         const ProbMeta& pm = S->meta[nd.prob];
         size_t width = ((size_t)nd.pl + nd.tl + 9 + 3) & ~(size_t)3;  // columns 4 .. pl+tl+4, 16-byte chunks
-        int koff = nd.pl + 4;
-        if (getenv("WFM_EXP_WIDTH")) { const size_t w = (size_t)atoll(getenv("WFM_EXP_WIDTH")); if (w < width) { width = w; koff = (int)(w / 2) & ~3; } }
-        bool tile_it = tcfg.enabled && !getenv("WFM_EXP_WIDTH") && nd.pl + nd.tl >= tcfg.min_len &&
+        const int koff = nd.pl + 4;
+        bool tile_it = tcfg.enabled && nd.pl + nd.tl >= tcfg.min_len &&
                              (nd.score_rem == INT_MAX || nd.score_rem >= tcfg.min_score);
         if (tile_it && width * 2 * 5 * RING * 2 * 4 > h->mem_budget) tile_it = false;  // two snapshot rings do not fit: step-by-step kernel
         const size_t need = width * 2 * 5 * RING * (tile_it ? 2 : 1);

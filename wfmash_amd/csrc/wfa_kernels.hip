@@ -172,11 +172,11 @@ __device__ __forceinline__ v4i ld4(const VSrc& r, int kb) {
 }
 
 // 4 consecutive diagonals k0..k0+3 (one 16-byte column chunk) per thread.
-template <bool MASK>
+template <bool MASK, bool TRACK>
 __device__ __forceinline__ void bp_cells4(const BpCtx& c, const uint8_t* P, const uint8_t* T, int k0, int lo, int hi,
                                           const VSrc& mx, const VSrc& mo1, const VSrc& mo2, const VSrc& i1, const VSrc& d1,
                                           const VSrc& i2, const VSrc& d2, int32_t* om, int32_t* oi1, int32_t* oi2,
-                                          int32_t* od1, int32_t* od2, int& mak, long long* sec) {
+                                          int32_t* od1, int32_t* od2, int& mak, int* cmax, long long* sec) {
   SEC_T(t0);
   const unsigned upl = (unsigned)c.pl, utl = (unsigned)c.tl;
   const v4i a1 = ld4<MASK>(mo1, k0 - 1), b1 = ld4<MASK>(mo1, k0 + 1);
@@ -226,6 +226,15 @@ __device__ __forceinline__ void bp_cells4(const BpCtx& c, const uint8_t* P, cons
       mak = max(mak, 2 * m[j] - k);
     }
   }
+  if (TRACK) {  // per-component row maxima for the phase-2 overlap pruning, while the cells are in registers
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (k0 + j >= lo && k0 + j <= hi) {
+        cmax[C_M] = max(cmax[C_M], m[j]); cmax[C_I1] = max(cmax[C_I1], ins1[j]); cmax[C_I2] = max(cmax[C_I2], ins2[j]);
+        cmax[C_D1] = max(cmax[C_D1], del1[j]); cmax[C_D2] = max(cmax[C_D2], del2[j]);
+      }
+    }
+  }
   SEC_T(t2);
   *reinterpret_cast<v4i*>(oi1 + k0) = ins1;
   *reinterpret_cast<v4i*>(oi2 + k0) = ins2;
@@ -238,7 +247,9 @@ __device__ __forceinline__ void bp_cells4(const BpCtx& c, const uint8_t* P, cons
 
 // Computes + extends row s of direction dir.  Returns #cells of the row (uniform).
 // Per-thread max antidiagonal is accumulated into mak.
-__device__ __forceinline__ int bp_compute_row(const BpCtx& c, int dir, int s, int (*s_lo)[RING], int (*s_hi)[RING], int& mak, long long* sec) {
+template <bool TRACK = false>
+__device__ __forceinline__ int bp_compute_row(const BpCtx& c, int dir, int s, int (*s_lo)[RING], int (*s_hi)[RING], int& mak, long long* sec,
+                                              int* cmax = nullptr) {
   const DevPen& pn = c.pen;
   const VSrc mx  = bp_vsrc(c, dir, C_M,  s - pn.x, s_lo, s_hi);
   const VSrc mo1 = bp_vsrc(c, dir, C_M,  s - pn.o1 - pn.e1, s_lo, s_hi);
@@ -280,9 +291,9 @@ __device__ __forceinline__ int bp_compute_row(const BpCtx& c, int dir, int s, in
     const int k0 = (ch << 2) - koff;
     // loads touch k0-1 .. k0+4
     if (all_live && k0 - 1 >= in_lo && k0 + 4 <= in_hi)
-      bp_cells4<false>(c, P, T, k0, lo, hi, mx, mo1, mo2, i1, d1, i2, d2, om, oi1, oi2, od1, od2, mak, sec);
+      bp_cells4<false, TRACK>(c, P, T, k0, lo, hi, mx, mo1, mo2, i1, d1, i2, d2, om, oi1, oi2, od1, od2, mak, cmax, sec);
     else
-      bp_cells4<true>(c, P, T, k0, lo, hi, mx, mo1, mo2, i1, d1, i2, d2, om, oi1, oi2, od1, od2, mak, sec);
+      bp_cells4<true, TRACK>(c, P, T, k0, lo, hi, mx, mo1, mo2, i1, d1, i2, d2, om, oi1, oi2, od1, od2, mak, cmax, sec);
   }
   return hi - lo + 1;
 }
@@ -329,6 +340,7 @@ __device__ __forceinline__ void bp_overlap_scan(const BpCtx& c, int d0, int s0, 
   unsigned act_lo = 0, act_hi = 0;  // 5 bits per i, i < 32 -> 160 bits in 3 words; keep two 64-bit halves
   unsigned long long m0 = 0, m1 = 0, m2 = 0;
   int klo = INT32_MAX, khi = INT32_MIN;
+  int rm1[5] = {0, 0, 0, 0, 0};  // largest opposite-direction offset any active row holds, per component
   for (int i = 0; i < scope; ++i) {
     const int si = s1 - i;
     if (si < 0) break;
@@ -343,6 +355,9 @@ __device__ __forceinline__ void bp_overlap_scan(const BpCtx& c, int d0, int s0, 
       bits |= 1u << cc;
     }
     if (!bits) continue;
+#pragma unroll
+    for (int cc = 0; cc < 5; ++cc)
+      if (bits & (1u << cc)) rm1[cc] = max(rm1[cc], s_rmax[d1][si & RMASK][cc]);
     klo = min(klo, kinv - hi1); khi = max(khi, kinv - lo1);
     const int sh = i * 5;
     if (sh < 60) m0 |= (unsigned long long)bits << sh;
@@ -358,8 +373,13 @@ __device__ __forceinline__ void bp_overlap_scan(const BpCtx& c, int d0, int s0, 
   for (int k0 = klo + (int)threadIdx.x; k0 <= khi; k0 += (int)blockDim.x) {
     const int k1 = kinv - k0;
     int o0[5];
+    bool reach = false;  // can this diagonal meet ANY active opposite row?  (most diagonals cannot: pure pruning)
 #pragma unroll
-    for (int cc = 0; cc < 5; ++cc) o0[cc] = r0[cc][k0];
+    for (int cc = 0; cc < 5; ++cc) {
+      o0[cc] = r0[cc][k0];
+      reach = reach || (o0[cc] >= 0 && o0[cc] + rm1[cc] >= c.tl);
+    }
+    if (!reach) continue;
     for (int i = 0; i < scope; ++i) {
       const int sh = i * 5;
       const unsigned bits = (unsigned)((sh < 60 ? m0 >> sh : (sh < 120 ? m1 >> (sh - 60) : m2 >> (sh - 120))) & 31ull);
@@ -370,7 +390,7 @@ __device__ __forceinline__ void bp_overlap_scan(const BpCtx& c, int d0, int s0, 
 #pragma unroll
       for (int cc = 0; cc < 5; ++cc) {
         if (!(bits & (1u << cc))) continue;
-        if (o0[cc] < 0) continue;
+        if (o0[cc] < 0 || o0[cc] + s_rmax[d1][si & RMASK][cc] < c.tl) continue;
         const int o1 = bp_row(c, d1, cc, si)[k1];
         if (o0[cc] + o1 >= c.tl) atomicMin(&s_mink[i * 5 + cc], k0);
       }
@@ -419,6 +439,7 @@ __global__ __launch_bounds__(1024) void wfa_bp_kernel(const uint8_t* __restrict_
   // ---- init rows 0 (wavefront_unialign_init, end2end), or resume from a tiled snapshot ----
   if (tid < 2 * RING) { s_lo[tid / RING][tid % RING] = 1; s_hi[tid / RING][tid % RING] = 0; }
   if (tid < 6) ((int*)s_mak)[tid] = 0;
+  for (int i = tid; i < 2 * RING * 5; i += blockDim.x) ((int*)s_rmax)[i] = 0;
   __syncthreads();
   int end_reached = 0;
   if (J.resume_s >= 0) {
@@ -462,16 +483,28 @@ __global__ __launch_bounds__(1024) void wfa_bp_kernel(const uint8_t* __restrict_
     if (fmax + rmax >= A) break;
     buf = (buf + 1) % 3;
     if (tid == 0) { s_mak[(buf + 1) % 3][0] = 0; s_mak[(buf + 1) % 3][1] = 0; }
+    // per-component row maxima (phase-2 pruning) ride along: the slots of the rows computed NEXT
+    // round are cleared now, one barrier ahead of the atomics that fill them
+    if (tid < 10) s_rmax[tid / 5][((tid < 5 ? sf : sr) + 2) & RMASK][tid % 5] = 0;
     int makf = 0, makr = 0;
+    int cmf[5] = {0, 0, 0, 0, 0}, cmr[5] = {0, 0, 0, 0, 0};
     SEC_T(ta);
-    const int nf = bp_compute_row(c, 0, sf + 1, s_lo, s_hi, makf, sec);
-    const int nr = bp_compute_row(c, 1, sr + 1, s_lo, s_hi, makr, sec);
+    const int nf = bp_compute_row<true>(c, 0, sf + 1, s_lo, s_hi, makf, sec, cmf);
+    const int nr = bp_compute_row<true>(c, 1, sr + 1, s_lo, s_hi, makr, sec, cmr);
     SEC_T(tb);
     makf = wave_max(makf);
     makr = wave_max(makr);
     if ((tid & 63) == 0) {
       if (makf > 0) atomicMax(&s_mak[buf][0], makf);
       if (makr > 0) atomicMax(&s_mak[buf][1], makr);
+    }
+#pragma unroll
+    for (int cc = 0; cc < 5; ++cc) {
+      const int vf = wave_max_dpp63(cmf[cc]), vr = wave_max_dpp63(cmr[cc]);
+      if ((tid & 63) == 63) {
+        if (vf > 0) atomicMax(&s_rmax[0][(sf + 1) & RMASK][cc], vf);
+        if (vr > 0) atomicMax(&s_rmax[1][(sr + 1) & RMASK][cc], vr);
+      }
     }
     SEC_T(tc);
     __syncthreads();
@@ -496,12 +529,12 @@ __global__ __launch_bounds__(1024) void wfa_bp_kernel(const uint8_t* __restrict_
   const int steps_p1 = sf + sr;
   if (status == 0) {
     const int gopen = max(pen.o1, pen.o2);
-    // row maxima of the `scope` newest rows of both directions (phase 1 does not track them)
-    for (int i = tid; i < 2 * RING * 5; i += blockDim.x) ((int*)s_rmax)[i] = 0;
-    __syncthreads();
+    // row maxima of the `scope` newest rows of both directions: rows computed by this kernel
+    // already have theirs; rows taken over from a tile snapshot (or row 0) are scanned here
+    const int own_from = max(J.resume_s, 0) + 1;
     for (int i = 0; i < scope; ++i) {
-      if (sf - i >= 0) bp_row_maxima(c, 0, sf - i, s_lo, s_hi, s_rmax);
-      if (sr - i >= 0) bp_row_maxima(c, 1, sr - i, s_lo, s_hi, s_rmax);
+      if (sf - i >= 0 && sf - i < own_from) bp_row_maxima(c, 0, sf - i, s_lo, s_hi, s_rmax);
+      if (sr - i >= 0 && sr - i < own_from) bp_row_maxima(c, 1, sr - i, s_lo, s_hi, s_rmax);
     }
     __syncthreads();
     for (;;) {
@@ -556,10 +589,18 @@ __global__ __launch_bounds__(1024) void wfa_bp_kernel(const uint8_t* __restrict_
       // advance the other direction
       int mak = 0;
       if (tid < 5) s_rmax[d0 ^ 1][((d0 == 0 ? sr : sf) + 1) & RMASK][tid] = 0;
-      if (d0 == 0) { ++sr; cells += (uint64_t)bp_compute_row(c, 1, sr, s_lo, s_hi, mak, sec); last_fwd = 0; }
-      else         { ++sf; cells += (uint64_t)bp_compute_row(c, 0, sf, s_lo, s_hi, mak, sec); last_fwd = 1; }
-      __syncthreads();
-      bp_row_maxima(c, d0 ^ 1, d0 == 0 ? sr : sf, s_lo, s_hi, s_rmax);
+      __syncthreads();  // the clear must not race with the atomics of faster waves below
+      int cmax[5] = {0, 0, 0, 0, 0};
+      if (d0 == 0) { ++sr; cells += (uint64_t)bp_compute_row<true>(c, 1, sr, s_lo, s_hi, mak, sec, cmax); last_fwd = 0; }
+      else         { ++sf; cells += (uint64_t)bp_compute_row<true>(c, 0, sf, s_lo, s_hi, mak, sec, cmax); last_fwd = 1; }
+      {  // row maxima of the new row straight from the registers that computed it
+        const int sn = d0 == 0 ? sr : sf;
+#pragma unroll
+        for (int cc = 0; cc < 5; ++cc) {
+          const int v = wave_max_dpp63(cmax[cc]);
+          if ((tid & 63) == 63 && v > 0) atomicMax(&s_rmax[d0 ^ 1][sn & RMASK][cc], v);
+        }
+      }
       __syncthreads();
       if (d0 == 1 && (int64_t)sf + sr > max_steps && best == INT32_MAX) { status = WFM_DEV_UNREACHABLE; break; }
     }
