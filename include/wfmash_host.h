@@ -60,6 +60,13 @@ void  wfmh_free(char* p);
 int64_t wfmh_test_winnow(const char* seq, int64_t len, int k, int w, int s, int32_t seq_id,
                          const uint64_t* hash, const int8_t* strand, wfm_minmer_t* out, int64_t cap);
 
+/* the same through speculative chunks of chunk_len k-mers (how wfm_add_minmers_multi spreads one
+ * long sequence over its workers); *replays = chunks whose speculation failed and were replayed
+ * from the previous chunk's state, -1 = the sequence fell back to one stream */
+int64_t wfmh_test_winnow_chunked(const char* seq, int64_t len, int k, int w, int s, int32_t seq_id,
+                                 const uint64_t* hash, const int8_t* strand, int64_t chunk_len,
+                                 wfm_minmer_t* out, int64_t cap, int* replays);
+
 /* ---- map phase (skch::Map, src/map/include/computeMap.hpp) ---- */
 
 /* skch::Parameters as set up by parse_args.hpp; wfmh_map_default_params fills the defaults

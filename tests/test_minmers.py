@@ -78,3 +78,56 @@ def test_add_minmers_gpu_equals_cpu_stage_on_long_sequence(gpu):
     exp = _cpu_winnow(seq, 15, 1000, 39, 0)
     assert len(got) == len(exp) > 5000
     assert (got == exp).all()
+
+
+# ---- speculative chunked winnowing == one stream ----
+
+def _chunk_cases():
+    from wfmash_amd import synth
+    base = synth.random_dna(901, 60000)
+    unit7 = synth.random_dna(902, 7)
+    unit400 = synth.random_dna(903, 400)
+    yield "random", base
+    yield "n_runs", base[:9000] + b"N" * 1500 + base[9000:20000] + b"n" + base[20000:31000] + b"N" * 40 + base[31000:]
+    yield "n_at_boundaries", base[:4990] + b"NNNNNNNNNNNNNNNNNNNN" + base[5010:9999] + b"N" + base[10000:]
+    yield "microsatellite", base[:8000] + unit7 * 3000 + base[8000:20000]                 # fewer than s distinct k-mers per window
+    yield "tandem_repeat", base[:5000] + unit400 * 60 + base[5000:15000]                  # the same hashes stay in the sketch for 24 kb
+    yield "palindromes", base[:3000] + (b"ACGT" * 2000) + base[3000:9000]
+    yield "low_then_n", (b"A" * 5000) + b"N" * 100 + base[:12000] + (b"AC" * 4000)
+
+
+def test_chunked_winnowing_equals_single_stream():
+    import numpy as np
+    from oracle import pymap
+    from wfmash_amd import capi
+    total_replays = 0
+    for name, seq in _chunk_cases():
+        for (k, w, s) in ((15, 1000, 39), (15, 500, 16), (19, 256, 5)):
+            h, st = pymap.hash_kmers(capi_norm(seq), k)
+            one = capi.host_winnow(seq, k, w, s, 3, h, st)
+            for chunk in (4 * w + 17, 10000, 25000):
+                got, replays = capi.host_winnow_chunked(seq, k, w, s, 3, h, st, chunk)
+                assert replays >= 0, (name, k, w, s, chunk, "fell back to one stream: an expired pool entry took part in a refill")
+                assert len(got) == len(one) and got.tobytes() == one.tobytes(), (name, k, w, s, chunk, replays)
+                total_replays += replays
+    # the speculation is expected to hold almost everywhere (replays are legal, just slow)
+    assert total_replays <= 6, total_replays
+
+
+def capi_norm(seq: bytes) -> bytes:
+    """upper-case / N-mask as the hashing kernel does (the oracle hashes what it is given)"""
+    up = seq.upper()
+    return bytes(c if c in b"ACGT" else ord("N") for c in up)
+
+
+@pytest.mark.gpu
+def test_add_minmers_multi_threaded_chunks_equal_single_calls(gpu, monkeypatch):
+    """the production path: GPU hashing + worker pool + speculative chunks (chunk size shrunk so that
+    every sequence is cut several times) against one wfm_add_minmers call per sequence"""
+    seqs = [s for _, s in _chunk_cases()]
+    single = [gpu.add_minmers(sq, 15, 256, 12, i) for i, sq in enumerate(seqs)]
+    monkeypatch.setenv("WFM_WINNOW_CHUNK", str(64 * 256))
+    multi = gpu.add_minmers_multi(seqs, 15, 256, 12, threads=8)
+    assert len(multi) == len(single)
+    for a, b in zip(multi, single):
+        assert len(a) == len(b) and a.tobytes() == b.tobytes()

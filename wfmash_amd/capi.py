@@ -460,6 +460,27 @@ class Handle:
                 return out[:n], frag[:n]
             cap = int(n)
 
+    def add_minmers_multi(self, seqs, k: int, w: int, s: int, seq_ids=None, threads: int = 1):
+        """wfm_add_minmers_multi: minmer intervals of several sequences (GPU hashing, threaded host winnowing);
+        returns one array per sequence."""
+        n = len(seqs)
+        ids = np.ascontiguousarray(seq_ids if seq_ids is not None else range(n), dtype=np.int32)
+        bufs = [np.frombuffer(x, dtype=np.uint8) for x in seqs]
+        ptrs = (C.c_void_p * n)(*[b.ctypes.data for b in bufs])
+        lens = np.array([len(x) for x in seqs], dtype=np.int64)
+        cap = 4 * int(lens.sum()) + 64
+        out = np.zeros(cap, dtype=MINMER_DTYPE)
+        counts = np.zeros(n, dtype=np.int64)
+        f = self._L.wfm_add_minmers_multi
+        f.restype = C.c_int64
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int64,
+                      C.c_void_p]
+        tot = f(self._p, ptrs, lens.ctypes.data, ids.ctypes.data, n, k, w, s, threads, out.ctypes.data, cap, counts.ctypes.data)
+        if tot < 0:
+            raise WfmError(f"wfm_add_minmers_multi failed ({tot}): {self.last_error()}")
+        offs = np.concatenate([[0], np.cumsum(counts)])
+        return [out[offs[i]:offs[i + 1]] for i in range(n)]
+
     def add_minmers(self, seq: bytes, k: int, w: int, s: int, seq_id: int = 0):
         """wfm_add_minmers: winnowed minmer intervals of one target sequence."""
         cap = 4 * len(seq) + 64
@@ -477,7 +498,7 @@ class Handle:
 # host-side align driver (include/wfmash_host.h)
 # ---------------------------------------------------------------------------
 HOST_EXPORTS = ["wfmh_align_default_params", "wfmh_align_paf", "wfmh_test_cigar", "wfmh_free", "wfmh_test_winnow",
-                "wfmh_map_default_params", "wfmh_test_filter", "wfmh_map"]
+                "wfmh_map_default_params", "wfmh_test_filter", "wfmh_map", "wfmh_test_winnow_chunked"]
 
 
 class MapSummary(C.Structure):
@@ -615,3 +636,20 @@ def host_winnow(seq: bytes, k: int, w: int, s: int, seq_id: int, hashes, strands
     strands = np.ascontiguousarray(strands, dtype=np.int8)
     n = L.wfmh_test_winnow(seq, len(seq), k, w, s, seq_id, hashes.ctypes.data, strands.ctypes.data, out.ctypes.data, cap)
     return out[:n]
+
+
+def host_winnow_chunked(seq: bytes, k: int, w: int, s: int, seq_id: int, hashes, strands, chunk_len: int):
+    """The speculative chunked form of the host winnowing (single thread); returns (minmers, replays).
+    replays = chunks whose speculation failed and were replayed; -1 = fell back to one stream."""
+    L = load()
+    f = L.wfmh_test_winnow_chunked
+    f.restype = C.c_int64
+    f.argtypes = [C.c_char_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
+                  C.POINTER(C.c_int)]
+    cap = 4 * len(seq) + 64
+    out = np.zeros(cap, dtype=MINMER_DTYPE)
+    hashes = np.ascontiguousarray(hashes, dtype=np.uint64)
+    strands = np.ascontiguousarray(strands, dtype=np.int8)
+    rep = C.c_int(0)
+    n = f(seq, len(seq), k, w, s, seq_id, hashes.ctypes.data, strands.ctypes.data, chunk_len, out.ctypes.data, cap, C.byref(rep))
+    return out[:n], rep.value

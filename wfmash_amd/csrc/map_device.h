@@ -38,4 +38,18 @@ int map_l1_device(wfm_handle_t* h, MapScratch& sc, const wfm_index_t* ix, const 
 int map_l2_device(wfm_handle_t* h, MapScratch& sc, const wfm_index_t* ix, const wfm_minmer_t* d_q, const int32_t* d_qcount,
                   const int32_t* d_qlen, const uint8_t* d_kc, int64_t nfrag, int s, const wfm_l1_candidate_t* d_cands,
                   int64_t ncand, const wfm_l2_params_t* prm, wfm_mapping_t** d_out, int32_t** d_frag, int64_t* n_out);
+
+// One sequence normalised and hashed on the device, left there so that host threads can pull the
+// slices they work on in parallel (each through its own per-thread stream).
+struct MapHashedSeq {
+  uint8_t* d_norm = nullptr;   // upper-cased / N-masked bases
+  uint64_t* d_hash = nullptr;  // canonical hash per k-mer start (~0 = invalid)
+  int8_t* d_strand = nullptr;  // +1 / -1 / 0 (contains N or palindromic)
+  int64_t len = 0, nk = 0;
+  int device = 0;
+};
+int map_hash_sequence_device(wfm_handle_t* h, const char* seq, int64_t len, int k, MapHashedSeq* out);
+void map_hashed_free(MapHashedSeq* s);
+int map_hashed_fetch(const MapHashedSeq* s, int64_t from, int64_t to, int64_t base_from, int64_t base_to, uint64_t* hash, int8_t* strand,
+                     char* norm);
 #endif

@@ -281,9 +281,62 @@ int map_sketch_device(wfm_handle_t* h, MapScratch& ms, const char* seq, int64_t 
   return WFM_OK;
 }
 
-extern "C" {
+// ---- hashed sequence kept on the device; host threads fetch slices concurrently (minmers.cpp) ----
+int map_hash_sequence_device(wfm_handle_t* h, const char* seq, int64_t len, int k, MapHashedSeq* out) {
+  out->d_norm = nullptr; out->d_hash = nullptr; out->d_strand = nullptr; out->len = len; out->nk = len - k + 1; out->device = wfm_device(h);
+  if (out->nk <= 0) return WFM_OK;
+  HIPCHK(h, hipSetDevice(wfm_device(h)));
+  hipStream_t st = wfm_stream(h);
+  const size_t padded = (size_t)len + 64;
+  uint8_t* d_raw = nullptr;
+  auto fail = [&](hipError_t e, const char* what) {
+    if (d_raw) (void)hipFree(d_raw);
+    map_hashed_free(out);
+    wfm_set_error(h, std::string(what) + ": " + hipGetErrorString(e));
+    return e == hipErrorOutOfMemory ? WFM_E_NOMEM : WFM_E_HIP;
+  };
+  hipError_t e;
+  if ((e = hipMalloc((void**)&d_raw, padded)) != hipSuccess) return fail(e, "hipMalloc");
+  if ((e = hipMalloc((void**)&out->d_norm, padded)) != hipSuccess) return fail(e, "hipMalloc");
+  if ((e = hipMalloc((void**)&out->d_hash, (size_t)out->nk * 8)) != hipSuccess) return fail(e, "hipMalloc");
+  if ((e = hipMalloc((void**)&out->d_strand, (size_t)out->nk)) != hipSuccess) return fail(e, "hipMalloc");
+  if ((e = hipMemsetAsync(out->d_norm, 'N', padded, st)) != hipSuccess) return fail(e, "hipMemsetAsync");
+  if ((e = hipMemcpyAsync(d_raw, seq, (size_t)len, hipMemcpyHostToDevice, st)) != hipSuccess) return fail(e, "hipMemcpyAsync");
+  const int64_t nthreads = (len + 15) / 16;
+  hipLaunchKernelGGL(normalize_kernel, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, st, d_raw, out->d_norm, len);
+  const int blocks = (int)std::min<int64_t>((out->nk + 255) / 256, 256 * 8);
+  hipLaunchKernelGGL(kmer_hash_kernel, dim3(blocks), dim3(256), 0, st, out->d_norm, out->nk, k, out->d_hash, out->d_strand);
+  if ((e = hipGetLastError()) != hipSuccess) return fail(e, "kernel launch");
+  if ((e = hipStreamSynchronize(st)) != hipSuccess) return fail(e, "hipStreamSynchronize");
+  (void)hipFree(d_raw);
+  return WFM_OK;
+}
 
-int wfm_hash_kmers(wfm_handle_t* h, const char* seq, int64_t len, int k, uint64_t* hash, int8_t* strand) {
+void map_hashed_free(MapHashedSeq* s) {
+  (void)hipSetDevice(s->device);
+  if (s->d_norm) (void)hipFree(s->d_norm);
+  if (s->d_hash) (void)hipFree(s->d_hash);
+  if (s->d_strand) (void)hipFree(s->d_strand);
+  s->d_norm = nullptr; s->d_hash = nullptr; s->d_strand = nullptr;
+}
+
+// k-mer starts [from, to) and bases [base_from, base_to), into the host arrays at the same indices.
+// Fastest into host memory that is already resident (a copy into fresh pages is bound by page faults).
+int map_hashed_fetch(const MapHashedSeq* s, int64_t from, int64_t to, int64_t base_from, int64_t base_to, uint64_t* hash, int8_t* strand,
+                     char* norm) {
+  if (hipSetDevice(s->device) != hipSuccess) return WFM_E_HIP;
+  if (to > from) {
+    if (hipMemcpy(hash + from, s->d_hash + from, (size_t)(to - from) * 8, hipMemcpyDeviceToHost) != hipSuccess) return WFM_E_HIP;
+    if (hipMemcpy(strand + from, s->d_strand + from, (size_t)(to - from), hipMemcpyDeviceToHost) != hipSuccess) return WFM_E_HIP;
+  }
+  if (base_to > base_from && hipMemcpy(norm + base_from, s->d_norm + base_from, (size_t)(base_to - base_from), hipMemcpyDeviceToHost) != hipSuccess)
+    return WFM_E_HIP;
+  return WFM_OK;
+}
+
+// wfm_hash_kmers; norm_out (optional, len bytes) receives the upper-cased / N-masked sequence the
+// hashes were computed from, for callers that go on working on the host (minmers.cpp)
+int wfm_hash_kmers_norm(wfm_handle_t* h, const char* seq, int64_t len, int k, uint64_t* hash, int8_t* strand, char* norm_out) {
   if (!h || !seq || !hash || !strand || len < 0) return WFM_E_ARG;
   if (k < 1 || k > 32) { wfm_set_error(h, "k must be in 1..32"); return WFM_E_UNSUPPORTED; }
   const int64_t nk = len - k + 1;
@@ -302,8 +355,15 @@ int wfm_hash_kmers(wfm_handle_t* h, const char* seq, int64_t len, int k, uint64_
   HIPCHK(h, hipGetLastError());
   HIPCHK(h, hipMemcpyAsync(hash, d_hash, (size_t)nk * 8, hipMemcpyDeviceToHost, st));
   HIPCHK(h, hipMemcpyAsync(strand, d_st, (size_t)nk, hipMemcpyDeviceToHost, st));
+  if (norm_out) HIPCHK(h, hipMemcpyAsync(norm_out, d_norm, (size_t)len, hipMemcpyDeviceToHost, st));
   HIPCHK(h, hipStreamSynchronize(st));
   return WFM_OK;
+}
+
+extern "C" {
+
+int wfm_hash_kmers(wfm_handle_t* h, const char* seq, int64_t len, int k, uint64_t* hash, int8_t* strand) {
+  return wfm_hash_kmers_norm(h, seq, len, k, hash, strand, nullptr);
 }
 
 // Bottom-`sketch_size` MinHash of one sequence as StreamingMinHash keeps it (streamingMinHash.hpp:90-100):

@@ -309,10 +309,25 @@ __device__ __forceinline__ void bp_row_maxima(const BpCtx& c, int d, int s, cons
   const int lo = s_lo[d][s & RMASK], hi = s_hi[d][s & RMASK];
   int mx[5] = {0, 0, 0, 0, 0};
   if (lo <= hi) {
+    // 16-byte column chunks, the five components of a chunk in flight together; cells outside
+    // [lo, hi] are masked (they may hold stale values of an older row)
+    const int koff = c.koff;
+    const int c_lo = (lo + koff) >> 2, c_hi = (hi + koff) >> 2;
+    const int32_t* r[5];
 #pragma unroll
-    for (int cc = 0; cc < 5; ++cc) {
-      const int32_t* r = bp_row(c, d, cc, s);
-      for (int k = lo + (int)threadIdx.x; k <= hi; k += (int)blockDim.x) mx[cc] = max(mx[cc], r[k]);
+    for (int cc = 0; cc < 5; ++cc) r[cc] = bp_row(c, d, cc, s);
+    for (int ch = c_lo + (int)threadIdx.x; ch <= c_hi; ch += (int)blockDim.x) {
+      const int k0 = (ch << 2) - koff;
+      v4i v[5];
+#pragma unroll
+      for (int cc = 0; cc < 5; ++cc) v[cc] = *reinterpret_cast<const v4i_u*>(r[cc] + k0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (k0 + j >= lo && k0 + j <= hi) {
+#pragma unroll
+          for (int cc = 0; cc < 5; ++cc) mx[cc] = max(mx[cc], v[cc][j]);
+        }
+      }
     }
   }
 #pragma unroll
@@ -370,29 +385,40 @@ __device__ __forceinline__ void bp_overlap_scan(const BpCtx& c, int d0, int s0, 
   const int32_t* r0[5];
 #pragma unroll
   for (int cc = 0; cc < 5; ++cc) r0[cc] = bp_row(c, d0, cc, s0);
-  for (int k0 = klo + (int)threadIdx.x; k0 <= khi; k0 += (int)blockDim.x) {
-    const int k1 = kinv - k0;
-    int o0[5];
-    bool reach = false;  // can this diagonal meet ANY active opposite row?  (most diagonals cannot: pure pruning)
+  // 16-byte chunks of the new row, five components in flight together
+  const int c_lo = (klo + c.koff) >> 2, c_hi = (khi + c.koff) >> 2;
+  for (int ch = c_lo + (int)threadIdx.x; ch <= c_hi; ch += (int)blockDim.x) {
+    const int kb = (ch << 2) - c.koff;
+    v4i v[5];
 #pragma unroll
-    for (int cc = 0; cc < 5; ++cc) {
-      o0[cc] = r0[cc][k0];
-      reach = reach || (o0[cc] >= 0 && o0[cc] + rm1[cc] >= c.tl);
-    }
-    if (!reach) continue;
-    for (int i = 0; i < scope; ++i) {
-      const int sh = i * 5;
-      const unsigned bits = (unsigned)((sh < 60 ? m0 >> sh : (sh < 120 ? m1 >> (sh - 60) : m2 >> (sh - 120))) & 31ull);
-      if (!bits) continue;
-      const int si = s1 - i;
-      const int lo1 = s_lo[d1][si & RMASK], hi1 = s_hi[d1][si & RMASK];
-      if (k1 < lo1 || k1 > hi1) continue;
+    for (int cc = 0; cc < 5; ++cc) v[cc] = *reinterpret_cast<const v4i_u*>(r0[cc] + kb);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int k0 = kb + j;
+      if (k0 < klo || k0 > khi) continue;
+      const int k1 = kinv - k0;
+      int o0[5];
+      bool reach = false;  // can this diagonal meet ANY active opposite row?  (most diagonals cannot: pure pruning)
 #pragma unroll
       for (int cc = 0; cc < 5; ++cc) {
-        if (!(bits & (1u << cc))) continue;
-        if (o0[cc] < 0 || o0[cc] + s_rmax[d1][si & RMASK][cc] < c.tl) continue;
-        const int o1 = bp_row(c, d1, cc, si)[k1];
-        if (o0[cc] + o1 >= c.tl) atomicMin(&s_mink[i * 5 + cc], k0);
+        o0[cc] = v[cc][j];
+        reach = reach || (o0[cc] >= 0 && o0[cc] + rm1[cc] >= c.tl);
+      }
+      if (!reach) continue;
+      for (int i = 0; i < scope; ++i) {
+        const int sh = i * 5;
+        const unsigned bits = (unsigned)((sh < 60 ? m0 >> sh : (sh < 120 ? m1 >> (sh - 60) : m2 >> (sh - 120))) & 31ull);
+        if (!bits) continue;
+        const int si = s1 - i;
+        const int lo1 = s_lo[d1][si & RMASK], hi1 = s_hi[d1][si & RMASK];
+        if (k1 < lo1 || k1 > hi1) continue;
+#pragma unroll
+        for (int cc = 0; cc < 5; ++cc) {
+          if (!(bits & (1u << cc))) continue;
+          if (o0[cc] < 0 || o0[cc] + s_rmax[d1][si & RMASK][cc] < c.tl) continue;
+          const int o1 = bp_row(c, d1, cc, si)[k1];
+          if (o0[cc] + o1 >= c.tl) atomicMin(&s_mink[i * 5 + cc], k0);
+        }
       }
     }
   }

@@ -215,7 +215,9 @@ int Map::mapQuery(MapSummary* summary) {
       std::vector<wfm_mapping_t> maps;
       std::vector<int32_t> mfrag;
       if (ix && !frag_off.empty()) {
-        int64_t cap = std::max<int64_t>(1 << 16, (int64_t)frag_off.size() * 8);
+        // a fragment of a pangenome maps about once per target haplotype; a too small buffer costs a
+        // second pass over the batch, so be generous
+        int64_t cap = (int64_t)frag_off.size() * std::min<int64_t>(256, std::max<int64_t>(16, 2 * (int64_t)subset.size())) + (1 << 16);
         for (;;) {
           maps.resize((size_t)cap); mfrag.resize((size_t)cap);
           const int64_t n = wfm_map_fragments(h_, ix, buffer.data(), (int64_t)buffer.size(), frag_off.data(), frag_seq.data(),
