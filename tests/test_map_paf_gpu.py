@@ -168,3 +168,28 @@ def test_query_sharding_reproduces_single_run(gpu, tmp_path):
     texts = [map_fn([names[i] for i in sh]) for sh in shards]
     assert D.merge_query_blocks(texts, names) == open(single).read()
     assert sum(1 for t in texts if t) >= 2
+
+
+def test_filter_modes_end_to_end(gpu, tmp_path):
+    """one-to-one (-o), no filter (-f) and lower-triangular (-L) runs against the default run"""
+    seqs = _pangenome(59, L=20000)
+    fa = str(tmp_path / "pan.fa")
+    _write_fasta(fa, seqs)
+    order = {n: i for i, (n, _) in enumerate(seqs)}
+
+    def run(tag, **over):
+        out = str(tmp_path / f"{tag}.paf")
+        capi.map_paf(gpu, fa, out, params=capi.map_default_params(percentage_identity=0.85, auto_pct_identity=0, **over))
+        return [tuple(l.split("\t")[:12]) for l in open(out).read().splitlines()]
+
+    base = run("base")
+    o2o = run("o2o", filter_mode=2)
+    none = run("none", filter_mode=3)
+    lt = run("lt", lower_triangular=1)
+    # each mode only removes records of the weaker one.  (The one-to-one pass re-attributes the kept mappings to queries
+    # by coordinates, computeMap.hpp:823-838, so haplotypes with coincident coordinates can receive a record twice.)
+    # so only the mapping itself (coordinates, strand, target, counts), not the query it is printed under, is a base record
+    assert o2o and len(base) <= len(none) and set(base) <= set(none)
+    assert {r[2:] for r in o2o} <= {r[2:] for r in base}
+    assert lt and all(order[r[0]] > order[r[5]] for r in lt)
+    assert {(r[0], r[5]) for r in lt} <= {(r[0], r[5]) for r in none}

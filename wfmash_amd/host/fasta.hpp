@@ -25,6 +25,8 @@ class FastaStore {
   // to the sequence; empty string if absent.
   std::string fetch(const std::string& name, int64_t start, int64_t end_inclusive) const;
   const std::string& sequence(int i) const { return seqs_[i]; }
+  // index of `name`, -1 if absent
+  int find(const std::string& name) const { auto it = index_.find(name); return it == index_.end() ? -1 : it->second; }
 
  private:
   std::vector<std::string> names_;

@@ -40,8 +40,8 @@ class SequenceSource {
   const std::string* find(const std::vector<std::string>& files, const std::string& name) const {
     for (const auto& f : files) {
       const auto& st = *stores_.at(f);
-      for (int i = 0; i < st.nseq(); ++i)
-        if (st.name(i) == name) return &st.sequence(i);
+      const int i = st.find(name);
+      if (i >= 0) return &st.sequence(i);
     }
     return nullptr;
   }
