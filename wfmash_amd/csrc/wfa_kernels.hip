@@ -19,6 +19,7 @@
 // an out-of-bounds I/D offset can only feed out-of-bounds cells.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 #include "wfa_device.h"
 
@@ -1099,9 +1100,13 @@ template <int C, int NTMAX, int LX, int LA, int LB, int E1, int E2>
 __global__ __launch_bounds__(NTMAX) void wfa_tile_reg_kernel(const uint8_t* __restrict__ seq, int32_t* __restrict__ ring_arena,
                                                            const TileJob* __restrict__ jobs, const TileTask* __restrict__ tasks,
                                                            int32_t* __restrict__ mak_out, int T) {
-  constexpr int H = LB + 1;  // delay-line depth = score scope: the output snapshot must hold rows s_end-LB .. s_end
+  constexpr int H = LB + 1;  // rows of M the output snapshot must hold: s_end-LB .. s_end
                              // (the overlap test of the step kernel looks LB rows behind the resume score)
-  static_assert(LX <= LB && LA <= LB && E1 == 2 && E2 == 1, "lags");
+  // The default lags x = 5, o1+e1 = 10, o2+e2 = 25 are all multiples of 5: a step only ever reads M rows of
+  // its own residue class (s mod 5).  The M history is therefore kept as 5 delay lines of depth 6 per
+  // diagonal and a step shifts ONE of them (6 moves) instead of a 26-deep line (25 moves).
+  constexpr int NCL = 5, DEP = 6;
+  static_assert(LX == 5 && LA == 10 && LB == 25 && E1 == 2 && E2 == 1, "lags");
   __shared__ int s_edge[2][16][2][4];  // [parity][wave][0: lane63 -> next wave, 1: lane0 -> previous wave][value]
   extern __shared__ __attribute__((aligned(16))) int s_makr[];  // [T + 1]
   const TileTask tk = tasks[blockIdx.x];
@@ -1117,7 +1122,8 @@ __global__ __launch_bounds__(NTMAX) void wfa_tile_reg_kernel(const uint8_t* __re
   int32_t* rout = ring_arena + J.ring_out + J.koff + (int64_t)dir * 5 * RING * width;
   const int kmax = tk.core_hi + T;  // last diagonal of the tile
 
-  int Mh[C][H];       // Mh[c][d] = M[s-1-d][k0+c]
+  // Mh[c][r][e] = M[sr - 5 e][k0+c], sr = the newest score <= current with (sr - s0) mod 5 == r
+  int Mh[C][NCL][DEP];
   int I1h[C][E1], D1h[C][E1], I2h[C], D2h[C];
   // ---- snapshot load (rows <= s0), column-blocked ----
 #pragma unroll
@@ -1125,9 +1131,14 @@ __global__ __launch_bounds__(NTMAX) void wfa_tile_reg_kernel(const uint8_t* __re
     const int k = k0 + c;
     const bool kin = k <= kmax;
 #pragma unroll
+    for (int r = 0; r < NCL; ++r)
+#pragma unroll
+      for (int e = 0; e < DEP; ++e) Mh[c][r][e] = WF_NULL;
+#pragma unroll
     for (int d = 0; d < H; ++d) {
       const int sc = s0 - d;
-      Mh[c][d] = (kin && sc >= 0 && k >= rng_lo(pl, sc) && k <= rng_hi(tl, sc)) ? rin[((int64_t)(C_M * RING + (sc & RMASK))) * width + k] : WF_NULL;
+      const int v = (kin && sc >= 0 && k >= rng_lo(pl, sc) && k <= rng_hi(tl, sc)) ? rin[((int64_t)(C_M * RING + (sc & RMASK))) * width + k] : WF_NULL;
+      Mh[c][(NCL - d % NCL) % NCL][d / NCL] = v;  // row s0-d: class (-d mod 5), the (d/5)-th newest of its class
     }
 #pragma unroll
     for (int d = 0; d < E1; ++d) {
@@ -1152,17 +1163,23 @@ __global__ __launch_bounds__(NTMAX) void wfa_tile_reg_kernel(const uint8_t* __re
     hmaxu[c] = colok[c] ? (unsigned)min(tl, pl + k) : 0u;
   }
 
-  for (int t = 1; t <= T; ++t) {
+  for (int tb = 0; tb < T; tb += NCL) {
+#pragma unroll
+  for (int jj = 1; jj <= NCL; ++jj) {
+    const int t = tb + jj;
+    if (t > T) break;
+    const int cl = jj % NCL;  // residue class of this step's score: compile time after unrolling
     const int s = s0 + t;
     const int par = t & 1;
+    // rows this step reads from its class: [0] = s-5, [1] = s-10, [4] = s-25
     // publish the wave-edge history values needed by the neighbouring waves in this step
-    if (lane == 63) { int* e = s_edge[par][wv][0]; e[0] = Mh[C - 1][LA - 1]; e[1] = Mh[C - 1][LB - 1]; e[2] = I1h[C - 1][E1 - 1]; e[3] = I2h[C - 1]; }
-    if (lane == 0)  { int* e = s_edge[par][wv][1]; e[0] = Mh[0][LA - 1];     e[1] = Mh[0][LB - 1];     e[2] = D1h[0][E1 - 1];     e[3] = D2h[0]; }
+    if (lane == 63) { int* e = s_edge[par][wv][0]; e[0] = Mh[C - 1][cl][1]; e[1] = Mh[C - 1][cl][4]; e[2] = I1h[C - 1][E1 - 1]; e[3] = I2h[C - 1]; }
+    if (lane == 0)  { int* e = s_edge[par][wv][1]; e[0] = Mh[0][cl][1];     e[1] = Mh[0][cl][4];     e[2] = D1h[0][E1 - 1];     e[3] = D2h[0]; }
     __syncthreads();
     // left neighbour (k0 - 1) and right neighbour (k0 + C) values
-    int lM10 = __shfl_up(Mh[C - 1][LA - 1], 1, 64), lM25 = __shfl_up(Mh[C - 1][LB - 1], 1, 64);
+    int lM10 = __shfl_up(Mh[C - 1][cl][1], 1, 64), lM25 = __shfl_up(Mh[C - 1][cl][4], 1, 64);
     int lI1 = __shfl_up(I1h[C - 1][E1 - 1], 1, 64), lI2 = __shfl_up(I2h[C - 1], 1, 64);
-    int rM10 = __shfl_down(Mh[0][LA - 1], 1, 64), rM25 = __shfl_down(Mh[0][LB - 1], 1, 64);
+    int rM10 = __shfl_down(Mh[0][cl][1], 1, 64), rM25 = __shfl_down(Mh[0][cl][4], 1, 64);
     int rD1 = __shfl_down(D1h[0][E1 - 1], 1, 64), rD2 = __shfl_down(D2h[0], 1, 64);
     if (lane == 0) {
       if (wv > 0) { const int* e = s_edge[par][wv - 1][0]; lM10 = e[0]; lM25 = e[1]; lI1 = e[2]; lI2 = e[3]; }
@@ -1181,11 +1198,11 @@ __global__ __launch_bounds__(NTMAX) void wfa_tile_reg_kernel(const uint8_t* __re
 #pragma unroll
     for (int c = 0; c < C; ++c) {
       const int k = k0 + c;
-      int a10 = c == 0 ? lM10 : Mh[c - 1][LA - 1], b10 = c == C - 1 ? rM10 : Mh[c + 1][LA - 1];
-      int a25 = c == 0 ? lM25 : Mh[c - 1][LB - 1], b25 = c == C - 1 ? rM25 : Mh[c + 1][LB - 1];
+      int a10 = c == 0 ? lM10 : Mh[c - 1][cl][1], b10 = c == C - 1 ? rM10 : Mh[c + 1][cl][1];
+      int a25 = c == 0 ? lM25 : Mh[c - 1][cl][4], b25 = c == C - 1 ? rM25 : Mh[c + 1][cl][4];
       int i1 = c == 0 ? lI1 : I1h[c - 1][E1 - 1], d1 = c == C - 1 ? rD1 : D1h[c + 1][E1 - 1];
       int i2 = c == 0 ? lI2 : I2h[c - 1], d2 = c == C - 1 ? rD2 : D2h[c + 1];
-      int mx = Mh[c][LX - 1];
+      int mx = Mh[c][cl][0];
       if (!interior) {
         const int sx = s - LX, sa = s - LA, se1 = s - E1, se2 = s - E2;
         const int lx = sx >= 0 ? rng_lo(pl, sx) : 1, hx = sx >= 0 ? rng_hi(tl, sx) : 0;
@@ -1251,12 +1268,12 @@ __global__ __launch_bounds__(NTMAX) void wfa_tile_reg_kernel(const uint8_t* __re
         }
       }
     }
-    // advance the delay lines
+    // advance the delay line of this step's class only
 #pragma unroll
     for (int c = 0; c < C; ++c) {
 #pragma unroll
-      for (int d = H - 1; d > 0; --d) Mh[c][d] = Mh[c][d - 1];
-      Mh[c][0] = nM[c];
+      for (int e = DEP - 1; e > 0; --e) Mh[c][cl][e] = Mh[c][cl][e - 1];
+      Mh[c][cl][0] = nM[c];
 #pragma unroll
       for (int d = E1 - 1; d > 0; --d) { I1h[c][d] = I1h[c][d - 1]; D1h[c][d] = D1h[c][d - 1]; }
       I1h[c][0] = nI1[c]; D1h[c][0] = nD1[c];
@@ -1265,17 +1282,33 @@ __global__ __launch_bounds__(NTMAX) void wfa_tile_reg_kernel(const uint8_t* __re
     mak = wave_max_dpp63(mak);
     if (lane == 63 && mak > 0) atomicMax(&s_makr[t], mak);
   }
+  }
   // ---- output snapshot: the newest H rows of M for the core ----
+  // row s_end - d lives in class (T - d) mod 5 at depth (d - (T - class) mod 5) / 5; T mod 5 is uniform, one
+  // compile-time variant per value keeps the history in registers
   const int s_end = s0 + T;
+  auto write_rows = [&](auto TR) {
+    constexpr int tr = decltype(TR)::value;  // T mod 5
 #pragma unroll
-  for (int c = 0; c < C; ++c) {
-    const int k = k0 + c;
-    if (k < tk.core_lo || k > tk.core_hi) continue;
+    for (int c = 0; c < C; ++c) {
+      const int k = k0 + c;
+      if (k < tk.core_lo || k > tk.core_hi) continue;
 #pragma unroll
-    for (int d = 0; d < H; ++d) {
-      const int sc = s_end - d;
-      if (sc >= 0 && k >= rng_lo(pl, sc) && k <= rng_hi(tl, sc)) rout[((int64_t)(C_M * RING + (sc & RMASK))) * width + k] = Mh[c][d];
+      for (int d = 0; d < H; ++d) {
+        const int r = ((tr - d) % NCL + NCL) % NCL;        // class of row s_end - d
+        const int back = ((tr - r) % NCL + NCL) % NCL;     // s_end - (newest score of class r)
+        const int e = (d - back) / NCL;
+        const int sc = s_end - d;
+        if (sc >= 0 && k >= rng_lo(pl, sc) && k <= rng_hi(tl, sc)) rout[((int64_t)(C_M * RING + (sc & RMASK))) * width + k] = Mh[c][r][e];
+      }
     }
+  };
+  switch (T % NCL) {
+    case 0: write_rows(std::integral_constant<int, 0>{}); break;
+    case 1: write_rows(std::integral_constant<int, 1>{}); break;
+    case 2: write_rows(std::integral_constant<int, 2>{}); break;
+    case 3: write_rows(std::integral_constant<int, 3>{}); break;
+    default: write_rows(std::integral_constant<int, 4>{}); break;
   }
   __syncthreads();
   int32_t* mk = mak_out + ((int64_t)tk.job * 2 + dir) * T;
