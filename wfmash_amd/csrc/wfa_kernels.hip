@@ -1096,6 +1096,38 @@ __global__ __launch_bounds__(1024) void wfa_tile_kernel(const uint8_t* __restric
 // left/right neighbours come from wave shuffles, wave edges go through a tiny LDS mailbox.
 // Same contract as wfa_tile_kernel (snapshot in -> T steps -> snapshot out + per-step maxima).
 // ---------------------------------------------------------------------------
+// ---- sequence windows in LDS (register tile kernel) ----
+// The extension is a chain of dependent loads (8 bases, compare, next 8 ...); from L2 that chain is the
+// longest stall of a score step.  A tile only touches a few kilobases of either sequence during its T
+// steps (offsets never decrease and fall off by ~5 bases per diagonal away from the furthest one), so a
+// window of each sequence is staged in LDS once per tile; anything outside it still comes from global.
+constexpr int SEQ_WIN = 8192;  // bytes per window
+__device__ __forceinline__ uint64_t lds_load8(const uint32_t* win, unsigned off) {
+  const uint32_t* w = win + (off >> 2);
+  const unsigned sh = (off & 3u) * 8u;
+  const uint32_t w0 = w[0], w1 = w[1], w2 = w[2];
+  const uint32_t lo = __builtin_amdgcn_alignbit(w1, w0, sh), hi = __builtin_amdgcn_alignbit(w2, w1, sh);
+  return ((uint64_t)hi << 32) | lo;
+}
+// 8 bases of P[v..) xor T[h..)
+__device__ __forceinline__ uint64_t win_xor8(const uint8_t* P, const uint8_t* T, const uint32_t* winP, const uint32_t* winT, int v, int h,
+                                             int wP0, int wT0) {
+  const unsigned ov = (unsigned)(v - wP0), oh = (unsigned)(h - wT0);
+  if (ov <= (unsigned)(SEQ_WIN - 8) && oh <= (unsigned)(SEQ_WIN - 8)) return lds_load8(winP, ov) ^ lds_load8(winT, oh);
+  return load8(P + v) ^ load8(T + h);
+}
+// longest common extension from (v, h) on, at most maxn
+__device__ __forceinline__ int win_lce(const uint8_t* P, const uint8_t* T, const uint32_t* winP, const uint32_t* winT, int v, int h, int maxn,
+                                       int wP0, int wT0) {
+  int n = 0;
+  while (n < maxn) {
+    const uint64_t x = win_xor8(P, T, winP, winT, v + n, h + n, wP0, wT0);
+    if (x) { n += (int)(__builtin_ctzll(x) >> 3); break; }
+    n += 8;
+  }
+  return min(n, maxn);
+}
+
 template <int C, int NTMAX, int LX, int LA, int LB, int E1, int E2>
 __global__ __launch_bounds__(NTMAX) void wfa_tile_reg_kernel(const uint8_t* __restrict__ seq, int32_t* __restrict__ ring_arena,
                                                            const TileJob* __restrict__ jobs, const TileTask* __restrict__ tasks,
@@ -1108,10 +1140,13 @@ __global__ __launch_bounds__(NTMAX) void wfa_tile_reg_kernel(const uint8_t* __re
   constexpr int NCL = 5, DEP = 6;
   static_assert(LX == 5 && LA == 10 && LB == 25 && E1 == 2 && E2 == 1, "lags");
   __shared__ int s_edge[2][16][2][4];  // [parity][wave][0: lane63 -> next wave, 1: lane0 -> previous wave][value]
+  __shared__ __attribute__((aligned(16))) uint32_t s_winP[SEQ_WIN / 4 + 4], s_winT[SEQ_WIN / 4 + 4];
+  __shared__ int s_wlo[2];
   extern __shared__ __attribute__((aligned(16))) int s_makr[];  // [T + 1]
   const TileTask tk = tasks[blockIdx.x];
   const TileJob J = jobs[tk.job];
   const int dir = tk.dir, tid = threadIdx.x, NT = blockDim.x, lane = tid & 63, wv = tid >> 6, nw = NT >> 6;
+  if (tid < 2) s_wlo[tid] = INT32_MAX;
   const uint8_t* P = seq + (dir == 0 ? J.p_fwd : J.p_rev);
   const uint8_t* Tx = seq + (dir == 0 ? J.t_fwd : J.t_rev);
   const int pl = J.pl, tl = J.tl, s0 = J.s0;
@@ -1162,6 +1197,38 @@ __global__ __launch_bounds__(NTMAX) void wfa_tile_reg_kernel(const uint8_t* __re
     colok[c] = (k >= -pl) && (k <= tl);
     hmaxu[c] = colok[c] ? (unsigned)min(tl, pl + k) : 0u;
   }
+  // ---- sequence windows: every offset this tile will ever extend from is >= the smallest live offset of
+  // its history (a cell's text offset h and pattern offset v = h - k never fall below its source's)
+  {
+    int hlo = INT32_MAX, vlo = INT32_MAX;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      const int k = k0 + c;
+      int lo = INT32_MAX;
+#pragma unroll
+      for (int r = 0; r < NCL; ++r)
+#pragma unroll
+        for (int e = 0; e < DEP; ++e) lo = min(lo, Mh[c][r][e] >= 0 ? Mh[c][r][e] : INT32_MAX);
+#pragma unroll
+      for (int d = 0; d < E1; ++d) { lo = min(lo, I1h[c][d] >= 0 ? I1h[c][d] : INT32_MAX); lo = min(lo, D1h[c][d] >= 0 ? D1h[c][d] : INT32_MAX); }
+      lo = min(lo, I2h[c] >= 0 ? I2h[c] : INT32_MAX);
+      lo = min(lo, D2h[c] >= 0 ? D2h[c] : INT32_MAX);
+      if (lo != INT32_MAX) { hlo = min(hlo, lo); vlo = min(vlo, lo - k); }
+    }
+    __syncthreads();  // s_wlo initialised
+    if (hlo != INT32_MAX) { atomicMin(&s_wlo[0], hlo); atomicMin(&s_wlo[1], max(vlo, 0)); }
+    __syncthreads();
+  }
+  const int wT0 = s_wlo[0] == INT32_MAX ? 0 : (s_wlo[0] & ~7), wP0 = s_wlo[1] == INT32_MAX ? 0 : (s_wlo[1] & ~7);
+  for (int i = tid; i < SEQ_WIN / 8 + 1; i += NT) {
+    // sequences are padded by 64 readable bytes past their end (SEQ_PAD); beyond that the window holds zeros,
+    // which is harmless: extensions are cut at the sequence ends
+    const int bt = wT0 + 8 * i, bp = wP0 + 8 * i;
+    const uint64_t vt = bt + 8 <= tl + 64 ? load8(Tx + bt) : 0ull, vp = bp + 8 <= pl + 64 ? load8(P + bp) : 0ull;
+    s_winT[2 * i] = (uint32_t)vt; s_winT[2 * i + 1] = (uint32_t)(vt >> 32);
+    s_winP[2 * i] = (uint32_t)vp; s_winP[2 * i + 1] = (uint32_t)(vp >> 32);
+  }
+  __syncthreads();
 
   for (int tb = 0; tb < T; tb += NCL) {
 #pragma unroll
@@ -1238,7 +1305,7 @@ __global__ __launch_bounds__(NTMAX) void wfa_tile_reg_kernel(const uint8_t* __re
       x[c] = 0; maxn[c] = 0;
       if (m >= 0) {
         maxn[c] = min(pl - (m - k), tl - m);
-        x[c] = load8(P + (m - k)) ^ load8(Tx + m);
+        x[c] = win_xor8(P, Tx, s_winP, s_winT, m - k, m, wP0, wT0);
       }
     }
 #pragma unroll
@@ -1248,7 +1315,7 @@ __global__ __launch_bounds__(NTMAX) void wfa_tile_reg_kernel(const uint8_t* __re
       if (m >= 0) {
         int n;
         if (x[c]) n = (int)(__builtin_ctzll(x[c]) >> 3);
-        else n = 8 + lce_bounded2(P, Tx, m - k + 8, m + 8, pl, tl);
+        else n = 8 + win_lce(P, Tx, s_winP, s_winT, m - k + 8, m + 8, maxn[c] - 8, wP0, wT0);
         m += min(n, maxn[c]);
         nM[c] = m;
         if (k >= tk.core_lo && k <= tk.core_hi && k >= rng_lo(pl, s) && k <= rng_hi(tl, s)) mak = max(mak, 2 * m - k);
