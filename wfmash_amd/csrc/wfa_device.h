@@ -49,11 +49,15 @@ struct TileJob {
   int32_t comp_begin, comp_end;
   int32_t width, koff;
   int32_t s0;                          // snapshot score of ring_in
+  int32_t active;                      // 0: the meeting point lies in the block after s0 (or the job is over): tiles exit
+  int32_t fmax, rmax;                  // running maximum antidiagonals of the two directions up to s0
+  int32_t nblocks;                     // tile blocks executed so far (incl. the one that found the meeting point)
   int32_t pad_;
 };
 struct TileTask {
   int32_t job, dir;
-  int32_t core_lo, core_hi;            // inclusive diagonal range owned by this tile
+  int32_t core_lo, core_hi;            // in memory: (tile index, tile width); the kernels turn it into the inclusive
+                                       // diagonal range owned by the tile for the block at hand
 };
 
 struct BpResult {
@@ -93,6 +97,7 @@ void launch_bp(const uint8_t* seq, int32_t* ring, const BpJob* jobs, BpResult* r
 void launch_tile_init(const uint8_t* seq, int32_t* ring, const TileJob* jobs, int32_t* mak0, int njobs, hipStream_t st);
 void launch_tile(const uint8_t* seq, int32_t* ring, const TileJob* jobs, const TileTask* tasks, int32_t* mak, int ntasks,
                  int threads, int T, int Wt, size_t lds_bytes, DevPen pen, int scope, hipStream_t st);
+void launch_tile_advance(TileJob* jobs, int32_t* mak, int njobs, int T, DevPen pen, hipStream_t st);
 void launch_tile_reg(const uint8_t* seq, int32_t* ring, const TileJob* jobs, const TileTask* tasks, int32_t* mak, int ntasks,
                      int threads, int T, int C, hipStream_t st);
 void launch_base(const uint8_t* seq, int32_t* a32, uint8_t* a8, uint32_t* rle, const BaseJob* jobs, BaseResult* res,

@@ -89,6 +89,7 @@ struct wfm_handle {
   int device = 0;
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
+  std::vector<hipEvent_t> tile_ev;  // start/stop pairs for the tile blocks of one chunk
   std::string err;
   std::string name;
   size_t mem_budget = 0;
@@ -229,6 +230,7 @@ int run_base_jobs(wfm_handle* h, wfm_seqset* S, const wfm_penalties_t& pen, cons
 
 
 struct TileCfg {
+  int chunk = 2;  // tile blocks launched back to back between two looks of the host (WFM_TILE_CHUNK); more only adds idle tiles
   int T = 64, Wt = 1024, threads = 512;
   int min_len = 600, min_score = 64;
   bool enabled = true;
@@ -250,6 +252,7 @@ TileCfg tile_cfg(const wfm_penalties_t& pen, int scope) {
   if (c.reg) {
     if (!getenv("WFM_TILE_THREADS")) c.threads = 512;
     if (const char* e = getenv("WFM_TILE_C")) c.C = atoi(e) == 4 ? 4 : 2;
+    if (const char* e = getenv("WFM_TILE_CHUNK")) c.chunk = std::max(1, atoi(e));
     if (c.C == 4) c.threads = std::min(c.threads, 256);
     c.Wt = c.threads * c.C;
     return c;
@@ -278,7 +281,7 @@ int run_tiled_phase(wfm_handle* h, wfm_seqset* S, const DevPen& dp, int scope, c
     t.p_fwd = j.p_fwd; t.t_fwd = j.t_fwd; t.p_rev = j.p_rev; t.t_rev = j.t_rev;
     t.ring_in = j.ring_off; t.ring_out = ring2[i];
     t.pl = j.pl; t.tl = j.tl; t.comp_begin = j.comp_begin; t.comp_end = j.comp_end;
-    t.width = j.width; t.koff = j.koff; t.s0 = 0; t.pad_ = 0;
+    t.width = j.width; t.koff = j.koff; t.s0 = 0; t.active = 1; t.fmax = 0; t.rmax = 0; t.nblocks = 0; t.pad_ = 0;
   }
   if (h->tilejobs.ensure(n) || h->tilemak.ensure(n * 2 * (size_t)std::max(T, 2))) { h->err = "out of device memory (tiles)"; return WFM_E_NOMEM; }
   HIPCHK(h, hipMemcpyAsync(h->tilejobs.p, tj.data(), n * sizeof(TileJob), hipMemcpyHostToDevice, h->stream));
@@ -294,64 +297,63 @@ int run_tiled_phase(wfm_handle* h, wfm_seqset* S, const DevPen& dp, int scope, c
     const int A = tj[i].pl + tj[i].tl - 1;
     if (ended || fmax[i] + rmax[i] >= A) active[i] = 0;  // wfa_bp_kernel handles it from score 0
     n_active += active[i];
+    tj[i].active = active[i]; tj[i].fmax = fmax[i]; tj[i].rmax = rmax[i]; tj[i].nblocks = 0;
   }
   const size_t lds = ((size_t)(scope + 2 * (dp.e1 + 1) + 2 * (dp.e2 + 1)) * cfg.Wt + T + 1) * 4;
-  std::vector<TileTask> tasks;
   uint32_t blocks = 0;
-  while (n_active) {
-    tasks.clear();
-    for (size_t i = 0; i < n; ++i) {
-      if (!active[i]) continue;
-      const int s1 = tj[i].s0 + T;
-      const int L = std::max(-tj[i].pl, -s1), R = std::min(tj[i].tl, s1);
-      for (int d = 0; d < 2; ++d)
-        for (int c = L; c <= R; c += core) tasks.push_back(TileTask{(int32_t)i, d, c, std::min(R, c + core - 1)});
-      for (int t = 1; t <= T; ++t) {
-        const int sc = tj[i].s0 + t;
-        tile_cells += 2ull * (uint64_t)(std::min(tj[i].tl, sc) - std::max(-tj[i].pl, -sc) + 1);
-      }
-    }
-    if (h->tiletasks.ensure(tasks.size())) { h->err = "out of device memory (tile tasks)"; return WFM_E_NOMEM; }
+  if (n_active) {
+    // The per-job state lives on the device and a tiny kernel between two blocks replays the termination
+    // checks, so the host only looks every `chunk` blocks.  The task list is built per chunk for the widest
+    // range the chunk can reach; a block's tiles outside its current range, and all tiles of jobs that
+    // finished earlier in the chunk, exit at once.
+    std::vector<TileTask> tasks;
     HIPCHK(h, hipMemcpyAsync(h->tilejobs.p, tj.data(), n * sizeof(TileJob), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipMemcpyAsync(h->tiletasks.p, tasks.data(), tasks.size() * sizeof(TileTask), hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemsetAsync(h->tilemak.p, 0, n * 2 * (size_t)T * sizeof(int32_t), h->stream));
-    HIPCHK(h, hipEventRecord(h->ev0, h->stream));
-    if (cfg.reg) launch_tile_reg(S->d_seq, h->ring.p, h->tilejobs.p, h->tiletasks.p, h->tilemak.p, (int)tasks.size(), cfg.threads, T, cfg.C, h->stream);
-    else launch_tile(S->d_seq, h->ring.p, h->tilejobs.p, h->tiletasks.p, h->tilemak.p, (int)tasks.size(), cfg.threads, T, cfg.Wt, lds, dp, scope, h->stream);
-    HIPCHK(h, hipGetLastError());
-    HIPCHK(h, hipEventRecord(h->ev1, h->stream));
-    HIPCHK(h, hipMemcpyAsync(mak.data(), h->tilemak.p, n * 2 * (size_t)T * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    float ms = 0;
-    HIPCHK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
-    tile_ms += ms;
-    ++blocks;
-#ifdef WFM_PROFILE_SECTIONS
-    if (blocks % 32 == 1) { long long sc[8]; wfm::read_sections(sc); fprintf(stderr, "[wfm] tile block %u (%zu tasks, %.3f ms): mid block thread512 cycles: lds+compute %lld, extend %lld, writes+stream %lld | setup %lld, reduce %lld, body(after setup) %lld, barrier wait %lld | total %lld\n", blocks, tasks.size(), ms, sc[0], sc[1], sc[5], sc[4], sc[6], sc[2], sc[3], sc[7]); }
-#endif
-    h->stats.tile_launches++;
-    h->stats.tile_tasks += (uint32_t)tasks.size();
-    for (size_t i = 0; i < n; ++i) {
-      if (!active[i]) continue;
-      const int A = tj[i].pl + tj[i].tl - 1;
-      const int32_t* mf = &mak[(i * 2 + 0) * (size_t)T];
-      const int32_t* mr = &mak[(i * 2 + 1) * (size_t)T];
-      int fm = fmax[i], rm = rmax[i];
-      bool term = false;
-      // replay of the alternating forward / reverse checks of wavefront_bialign_find_breakpoint
-      for (int t = 0; t < T && !term; ++t) {
-        fm = std::max(fm, mf[t]);
-        if (fm + rm >= A) { term = true; break; }
-        rm = std::max(rm, mr[t]);
-        if (fm + rm >= A) term = true;
+    const int chunk = std::max(1, std::min(cfg.chunk, (int)h->tile_ev.size() / 2));
+    std::vector<TileJob> got(n);
+    while (n_active) {
+      // as many tiles of `core` diagonals per job and direction as the last block of this chunk can need
+      tasks.clear();
+      for (size_t i = 0; i < n; ++i) {
+        if (!active[i]) continue;
+        const int reach = tj[i].s0 + chunk * T;
+        const int L = std::max(-tj[i].pl, -reach), R = std::min(tj[i].tl, reach);
+        const int ntiles = (R - L + core) / core;
+        for (int d = 0; d < 2; ++d)
+          for (int t = 0; t < ntiles; ++t) tasks.push_back(TileTask{(int32_t)i, d, t, core});  // (tile index, tile width): the kernel places it
       }
-      const int64_t max_steps = (int64_t)(dp.o1 + dp.o2) * 4 + (int64_t)(tj[i].pl + tj[i].tl + 2) * std::max(dp.x, std::max(dp.e1, dp.e2)) * 2 + 256;
-      if (term || 2 * (int64_t)(tj[i].s0 + T) > max_steps) {
-        active[i] = 0; --n_active;  // the block containing the meeting point is redone step by step by wfa_bp_kernel
-      } else {
-        fmax[i] = fm; rmax[i] = rm;
-        tj[i].s0 += T;
-        std::swap(tj[i].ring_in, tj[i].ring_out);
+      if (h->tiletasks.ensure(tasks.size())) { h->err = "out of device memory (tile tasks)"; return WFM_E_NOMEM; }
+      HIPCHK(h, hipMemcpyAsync(h->tiletasks.p, tasks.data(), tasks.size() * sizeof(TileTask), hipMemcpyHostToDevice, h->stream));
+      for (int b = 0; b < chunk; ++b) {
+        HIPCHK(h, hipEventRecord(h->tile_ev[2 * b], h->stream));
+        if (cfg.reg) launch_tile_reg(S->d_seq, h->ring.p, h->tilejobs.p, h->tiletasks.p, h->tilemak.p, (int)tasks.size(), cfg.threads, T, cfg.C, h->stream);
+        else launch_tile(S->d_seq, h->ring.p, h->tilejobs.p, h->tiletasks.p, h->tilemak.p, (int)tasks.size(), cfg.threads, T, cfg.Wt, lds, dp, scope, h->stream);
+        HIPCHK(h, hipEventRecord(h->tile_ev[2 * b + 1], h->stream));
+        launch_tile_advance(h->tilejobs.p, h->tilemak.p, (int)n, T, dp, h->stream);
+      }
+      HIPCHK(h, hipGetLastError());
+      HIPCHK(h, hipMemcpyAsync(got.data(), h->tilejobs.p, n * sizeof(TileJob), hipMemcpyDeviceToHost, h->stream));
+      HIPCHK(h, hipStreamSynchronize(h->stream));
+      for (int b = 0; b < chunk; ++b) {
+        float ms = 0;
+        HIPCHK(h, hipEventElapsedTime(&ms, h->tile_ev[2 * b], h->tile_ev[2 * b + 1]));
+        tile_ms += ms;
+      }
+      blocks += (uint32_t)chunk;
+      h->stats.tile_launches += (uint32_t)chunk;
+      h->stats.tile_tasks += (uint32_t)(tasks.size() * (size_t)chunk);
+      n_active = 0;
+      for (size_t i = 0; i < n; ++i) {
+        // cells of the blocks this job ran since the last look (the block that found the meeting point included)
+        for (int bl = tj[i].nblocks; bl < got[i].nblocks; ++bl)
+          for (int t = 1; t <= T; ++t) {
+            const int sc = bl * T + t;
+            tile_cells += 2ull * (uint64_t)(std::min(tj[i].tl, sc) - std::max(-tj[i].pl, -sc) + 1);
+          }
+        tj[i] = got[i];
+        active[i] = (char)(got[i].active != 0);
+        fmax[i] = got[i].fmax; rmax[i] = got[i].rmax;
+        n_active += active[i];
       }
     }
   }
@@ -409,6 +411,7 @@ int align_resident_impl(wfm_handle* h, const wfm_penalties_t* pen, wfm_seqset* S
   }
 
   LevelTimer tm;
+  double wall_tile = 0, wall_base = 0;
   std::vector<BpJob> jobs;
   std::vector<int> tiled;
   std::vector<int64_t> ring2;
@@ -466,7 +469,9 @@ int align_resident_impl(wfm_handle* h, const wfm_penalties_t* pen, wfm_seqset* S
         }
         {
           double tms = 0; uint64_t tcells = 0;
+          const auto tw0 = std::chrono::steady_clock::now();
           rc = run_tiled_phase(h, S, dp, scope, tcfg, jobs, tiled, ring2, tms, tcells, level);
+          wall_tile += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tw0).count();
           if (rc != WFM_OK) return rc;
           tm.bp_ms += tms; tm.tile_ms += tms;
           h->stats.cells_bp += tcells; h->stats.cells_tile += tcells;
@@ -530,12 +535,15 @@ int align_resident_impl(wfm_handle* h, const wfm_penalties_t* pen, wfm_seqset* S
     // ---- base jobs collected so far (incl. retries with a larger budget) ----
     while (!base_nodes.empty()) {
       retry.clear();
+      const auto tb0 = std::chrono::steady_clock::now();
       rc = run_base_jobs(h, S, *pen, base_nodes, retry, prob_status, prob_cells, tm);
+      wall_base += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tb0).count();
       if (rc != WFM_OK) return rc;
       base_nodes.swap(retry);
     }
   }
   h->stats.levels = level;
+  const auto t_levels = std::chrono::steady_clock::now();
 
   // ---- gather RLE pieces ----
   std::vector<int64_t> poff(n), pcap(n);
@@ -612,6 +620,10 @@ int align_resident_impl(wfm_handle* h, const wfm_penalties_t* pen, wfm_seqset* S
   h->stats.ms_base = tm.base_ms;
   h->stats.ms_kernels = tm.bp_ms + tm.base_ms;
   h->stats.ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
+  if (getenv("WFM_DEBUG"))
+    fprintf(stderr, "[wfm] wall: total %.2f ms | levels %.2f (tile phase %.2f incl. kernels %.2f; base phase %.2f incl. kernels %.2f; bp kernels %.2f) | gather+expand %.2f\n",
+            h->stats.ms_total, std::chrono::duration<double, std::milli>(t_levels - t_start).count(), wall_tile, tm.tile_ms, wall_base, tm.base_ms,
+            tm.bp_ms - tm.tile_ms, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_levels).count());
   return failed;
 }
 
@@ -633,6 +645,8 @@ int wfm_create(int device, wfm_handle_t** out) {
   h->name = std::string(prop.name) + " (" + prop.gcnArchName + ")";
   if (hipStreamCreate(&h->stream) != hipSuccess) { delete h; return WFM_E_HIP; }
   (void)hipEventCreate(&h->ev0); (void)hipEventCreate(&h->ev1); (void)hipEventCreate(&h->ev2); (void)hipEventCreate(&h->ev3);
+  h->tile_ev.resize(64);
+  for (auto& e : h->tile_ev) (void)hipEventCreate(&e);
   size_t fr = 0, tot = 0;
   if (hipMemGetInfo(&fr, &tot) != hipSuccess) { fr = (size_t)16 << 30; }
   h->mem_budget = (size_t)((double)fr * 0.40);
@@ -653,6 +667,7 @@ void wfm_destroy(wfm_handle_t* h) {
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   if (h->ev2) (void)hipEventDestroy(h->ev2);
   if (h->ev3) (void)hipEventDestroy(h->ev3);
+  for (auto& e : h->tile_ev) if (e) (void)hipEventDestroy(e);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
 }

@@ -950,8 +950,18 @@ __global__ __launch_bounds__(1024) void wfa_tile_kernel(const uint8_t* __restric
                                                        const TileJob* __restrict__ jobs, const TileTask* __restrict__ tasks,
                                                        int32_t* __restrict__ mak_out, int T, int Wt, DevPen pen, int scope) {
   extern __shared__ __attribute__((aligned(16))) int lds[];
-  const TileTask tk = tasks[blockIdx.x];
+  TileTask tk = tasks[blockIdx.x];
   const TileJob J = jobs[tk.job];
+  if (!J.active) return;
+  {  // tasks carry (tile index, tile width): this block's diagonal range [-s1, s1], clipped to the problem, is cut
+     // into tiles from its own left end, so every tile but the last is full
+    const int s1 = J.s0 + T;
+    const int L = max(-J.pl, -s1), R = min(J.tl, s1);
+    const int idx = tk.core_lo, core = tk.core_hi;
+    tk.core_lo = L + idx * core;
+    tk.core_hi = min(R, tk.core_lo + core - 1);
+    if (tk.core_lo > R) return;
+  }
   const int dir = tk.dir, tid = threadIdx.x, NT = blockDim.x;
   const int n1 = pen.e1 + 1, n2 = pen.e2 + 1;
   int* sM = lds;
@@ -1143,8 +1153,18 @@ __global__ __launch_bounds__(NTMAX) void wfa_tile_reg_kernel(const uint8_t* __re
   __shared__ __attribute__((aligned(16))) uint32_t s_winP[SEQ_WIN / 4 + 4], s_winT[SEQ_WIN / 4 + 4];
   __shared__ int s_wlo[2];
   extern __shared__ __attribute__((aligned(16))) int s_makr[];  // [T + 1]
-  const TileTask tk = tasks[blockIdx.x];
+  TileTask tk = tasks[blockIdx.x];
   const TileJob J = jobs[tk.job];
+  if (!J.active) return;
+  {  // tasks carry (tile index, tile width): this block's diagonal range [-s1, s1], clipped to the problem, is cut
+     // into tiles from its own left end, so every tile but the last is full
+    const int s1 = J.s0 + T;
+    const int L = max(-J.pl, -s1), R = min(J.tl, s1);
+    const int idx = tk.core_lo, core = tk.core_hi;
+    tk.core_lo = L + idx * core;
+    tk.core_hi = min(R, tk.core_lo + core - 1);
+    if (tk.core_lo > R) return;
+  }
   const int dir = tk.dir, tid = threadIdx.x, NT = blockDim.x, lane = tid & 63, wv = tid >> 6, nw = NT >> 6;
   if (tid < 2) s_wlo[tid] = INT32_MAX;
   const uint8_t* P = seq + (dir == 0 ? J.p_fwd : J.p_rev);
@@ -1382,6 +1402,39 @@ __global__ __launch_bounds__(NTMAX) void wfa_tile_reg_kernel(const uint8_t* __re
   for (int t = 1 + tid; t <= T; t += NT) if (s_makr[t] > 0) atomicMax(&mk[t - 1], s_makr[t]);
 }
 
+// Between two tile blocks: one lane per job replays the alternating forward / reverse checks of
+// wavefront_bialign_find_breakpoint over the T per-score maxima of the block just computed.  A job whose
+// wavefronts met inside the block (or that ran out of steps) goes inactive with its state still at the
+// block's START -- wfa_bp_kernel redoes that block step by step; the others move on to the next block.
+__global__ void wfa_tile_advance_kernel(TileJob* __restrict__ jobs, int32_t* __restrict__ mak, int njobs, int T, DevPen pen) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= njobs) return;
+  TileJob J = jobs[i];
+  if (!J.active) return;
+  int32_t* mf = mak + ((int64_t)i * 2 + 0) * T;
+  int32_t* mr = mak + ((int64_t)i * 2 + 1) * T;
+  const int A = J.pl + J.tl - 1;
+  int fm = J.fmax, rm = J.rmax;
+  bool term = false;
+  for (int t = 0; t < T && !term; ++t) {
+    fm = max(fm, mf[t]);
+    if (fm + rm >= A) { term = true; break; }
+    rm = max(rm, mr[t]);
+    if (fm + rm >= A) term = true;
+  }
+  for (int t = 0; t < T; ++t) { mf[t] = 0; mr[t] = 0; }
+  const int64_t max_steps = (int64_t)(pen.o1 + pen.o2) * 4 + (int64_t)(J.pl + J.tl + 2) * max(pen.x, max(pen.e1, pen.e2)) * 2 + 256;
+  J.nblocks += 1;
+  if (term || 2 * (int64_t)(J.s0 + T) > max_steps) {
+    J.active = 0;
+  } else {
+    J.fmax = fm; J.rmax = rm;
+    J.s0 += T;
+    const int64_t t = J.ring_in; J.ring_in = J.ring_out; J.ring_out = t;
+  }
+  jobs[i] = J;
+}
+
 #ifdef WFM_PROFILE_SECTIONS
 void read_sections(long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sec), sizeof(long long) * 8); }
 #endif
@@ -1402,6 +1455,9 @@ void launch_tile(const uint8_t* seq, int32_t* ring, const TileJob* jobs, const T
     configured = lds_bytes;
   }
   hipLaunchKernelGGL(wfa_tile_kernel, dim3(ntasks), dim3(threads), lds_bytes, st, seq, ring, jobs, tasks, mak, T, Wt, pen, scope);
+}
+void launch_tile_advance(TileJob* jobs, int32_t* mak, int njobs, int T, DevPen pen, hipStream_t st) {
+  hipLaunchKernelGGL(wfa_tile_advance_kernel, dim3((njobs + 63) / 64), dim3(64), 0, st, jobs, mak, njobs, T, pen);
 }
 void launch_tile_reg(const uint8_t* seq, int32_t* ring, const TileJob* jobs, const TileTask* tasks, int32_t* mak, int ntasks,
                      int threads, int T, int C, hipStream_t st) {
