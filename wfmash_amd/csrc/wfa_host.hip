@@ -231,7 +231,7 @@ int run_base_jobs(wfm_handle* h, wfm_seqset* S, const wfm_penalties_t& pen, cons
 
 struct TileCfg {
   int chunk = 2;  // tile blocks launched back to back between two looks of the host (WFM_TILE_CHUNK); more only adds idle tiles
-  int T = 64, Wt = 1024, threads = 512;
+  int T = 100, Wt = 1024, threads = 512;  // T: scores per tile block (measured optimum 96-100 on C3: halo 2T of 1024 columns vs per-tile snapshot cost)
   int min_len = 600, min_score = 64;
   bool enabled = true;
   bool reg = false;  // register-resident tile kernel (default penalty lags only)
