@@ -230,6 +230,8 @@ int run_base_jobs(wfm_handle* h, wfm_seqset* S, const wfm_penalties_t& pen, cons
 
 
 struct TileCfg {
+  int T_refine = 0;   // optional second pass over the block that holds the meeting point, in finer blocks (WFM_TILE_T_REFINE;
+                      // measured neutral on C3: what the step kernel saves, the small tiles cost)
   int chunk = 2;  // tile blocks launched back to back between two looks of the host (WFM_TILE_CHUNK); more only adds idle tiles
   int T = 100, Wt = 1024, threads = 512;  // T: scores per tile block (measured optimum 96-100 on C3: halo 2T of 1024 columns vs per-tile snapshot cost)
   int min_len = 600, min_score = 64;
@@ -242,11 +244,13 @@ TileCfg tile_cfg(const wfm_penalties_t& pen, int scope) {
   TileCfg c;
   if (const char* e = getenv("WFM_TILE")) c.enabled = atoi(e) != 0;
   if (const char* e = getenv("WFM_TILE_T")) c.T = atoi(e);
+  if (const char* e = getenv("WFM_TILE_T_REFINE")) c.T_refine = atoi(e);
   if (const char* e = getenv("WFM_TILE_W")) c.Wt = atoi(e);
   if (const char* e = getenv("WFM_TILE_THREADS")) c.threads = atoi(e);
   if (const char* e = getenv("WFM_TILE_MIN_LEN")) c.min_len = atoi(e);
   if (const char* e = getenv("WFM_TILE_MIN_SCORE")) c.min_score = atoi(e);
   c.T = std::max(c.T, RING);  // the output snapshot needs `scope` rows of the block itself
+  if (c.T_refine > 0) c.T_refine = std::max(c.T_refine, RING);
   const bool dflt = pen.x == 5 && pen.o1 + pen.e1 == 10 && pen.o2 + pen.e2 == 25 && pen.e1 == 2 && pen.e2 == 1;
   c.reg = dflt && !(getenv("WFM_TILE_REG") && atoi(getenv("WFM_TILE_REG")) == 0);
   if (c.reg) {
@@ -266,12 +270,14 @@ TileCfg tile_cfg(const wfm_penalties_t& pen, int scope) {
 // Advances the jobs listed in `tiled` (indices into jobs) in blocks of T scores with the
 // time-tiled kernel until their forward/reverse antidiagonals meet inside a block; then
 // leaves them positioned at the last snapshot for wfa_bp_kernel (resume_s/fmax0/rmax0/ring_off).
-int run_tiled_phase(wfm_handle* h, wfm_seqset* S, const DevPen& dp, int scope, const TileCfg& cfg,
-                    std::vector<BpJob>& jobs, const std::vector<int>& tiled, const std::vector<int64_t>& ring2,
+// With `refine` the jobs continue from where a coarser pass left them (blocks of T scores again, T smaller),
+// so that the step-by-step kernel has at most the finer T steps to redo.
+int run_tiled_phase(wfm_handle* h, wfm_seqset* S, const DevPen& dp, int scope, const TileCfg& cfg, int T, bool refine,
+                    std::vector<BpJob>& jobs, const std::vector<int>& tiled, std::vector<int64_t>& ring2,
                     double& tile_ms, uint64_t& tile_cells, uint32_t level) {
   const size_t n = tiled.size();
   if (n == 0) return WFM_OK;
-  const int T = cfg.T, core = cfg.Wt - 2 * cfg.T;
+  const int core = cfg.Wt - 2 * T;
   std::vector<TileJob> tj(n);
   std::vector<int> fmax(n, 0), rmax(n, 0);
   std::vector<char> active(n, 1);
@@ -284,20 +290,33 @@ int run_tiled_phase(wfm_handle* h, wfm_seqset* S, const DevPen& dp, int scope, c
     t.width = j.width; t.koff = j.koff; t.s0 = 0; t.active = 1; t.fmax = 0; t.rmax = 0; t.nblocks = 0; t.pad_ = 0;
   }
   if (h->tilejobs.ensure(n) || h->tilemak.ensure(n * 2 * (size_t)std::max(T, 2))) { h->err = "out of device memory (tiles)"; return WFM_E_NOMEM; }
-  HIPCHK(h, hipMemcpyAsync(h->tilejobs.p, tj.data(), n * sizeof(TileJob), hipMemcpyHostToDevice, h->stream));
-  launch_tile_init(S->d_seq, h->ring.p, h->tilejobs.p, h->tilemak.p, (int)n, h->stream);
-  HIPCHK(h, hipGetLastError());
-  std::vector<int32_t> mak(n * 2 * (size_t)std::max(T, 2));
-  HIPCHK(h, hipMemcpyAsync(mak.data(), h->tilemak.p, n * 4 * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
-  HIPCHK(h, hipStreamSynchronize(h->stream));
   size_t n_active = 0;
-  for (size_t i = 0; i < n; ++i) {
-    fmax[i] = mak[(i * 2 + 0) * 2]; rmax[i] = mak[(i * 2 + 1) * 2];
-    const bool ended = mak[(i * 2 + 0) * 2 + 1] || mak[(i * 2 + 1) * 2 + 1];
-    const int A = tj[i].pl + tj[i].tl - 1;
-    if (ended || fmax[i] + rmax[i] >= A) active[i] = 0;  // wfa_bp_kernel handles it from score 0
-    n_active += active[i];
-    tj[i].active = active[i]; tj[i].fmax = fmax[i]; tj[i].rmax = rmax[i]; tj[i].nblocks = 0;
+  std::vector<int> s_begin(n, 0);  // score the jobs start this pass at
+  if (!refine) {
+    HIPCHK(h, hipMemcpyAsync(h->tilejobs.p, tj.data(), n * sizeof(TileJob), hipMemcpyHostToDevice, h->stream));
+    launch_tile_init(S->d_seq, h->ring.p, h->tilejobs.p, h->tilemak.p, (int)n, h->stream);
+    HIPCHK(h, hipGetLastError());
+    std::vector<int32_t> mak(n * 4);
+    HIPCHK(h, hipMemcpyAsync(mak.data(), h->tilemak.p, n * 4 * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    for (size_t i = 0; i < n; ++i) {
+      fmax[i] = mak[(i * 2 + 0) * 2]; rmax[i] = mak[(i * 2 + 1) * 2];
+      const bool ended = mak[(i * 2 + 0) * 2 + 1] || mak[(i * 2 + 1) * 2 + 1];
+      const int A = tj[i].pl + tj[i].tl - 1;
+      if (ended || fmax[i] + rmax[i] >= A) active[i] = 0;  // wfa_bp_kernel handles it from score 0
+      n_active += active[i];
+      tj[i].active = active[i]; tj[i].fmax = fmax[i]; tj[i].rmax = rmax[i]; tj[i].nblocks = 0;
+    }
+  } else {
+    for (size_t i = 0; i < n; ++i) {
+      const BpJob& j = jobs[(size_t)tiled[i]];
+      const int A = tj[i].pl + tj[i].tl - 1;
+      fmax[i] = j.fmax0; rmax[i] = j.rmax0;
+      s_begin[i] = j.resume_s;
+      active[i] = (char)(fmax[i] + rmax[i] < A);  // jobs that were over before their first block stay where they are
+      n_active += active[i];
+      tj[i].s0 = j.resume_s; tj[i].active = active[i]; tj[i].fmax = fmax[i]; tj[i].rmax = rmax[i]; tj[i].nblocks = 0;
+    }
   }
   const size_t lds = ((size_t)(scope + 2 * (dp.e1 + 1) + 2 * (dp.e2 + 1)) * cfg.Wt + T + 1) * 4;
   uint32_t blocks = 0;
@@ -347,7 +366,7 @@ int run_tiled_phase(wfm_handle* h, wfm_seqset* S, const DevPen& dp, int scope, c
         // cells of the blocks this job ran since the last look (the block that found the meeting point included)
         for (int bl = tj[i].nblocks; bl < got[i].nblocks; ++bl)
           for (int t = 1; t <= T; ++t) {
-            const int sc = bl * T + t;
+            const int sc = s_begin[i] + bl * T + t;
             tile_cells += 2ull * (uint64_t)(std::min(tj[i].tl, sc) - std::max(-tj[i].pl, -sc) + 1);
           }
         tj[i] = got[i];
@@ -360,6 +379,7 @@ int run_tiled_phase(wfm_handle* h, wfm_seqset* S, const DevPen& dp, int scope, c
   for (size_t i = 0; i < n; ++i) {
     BpJob& j = jobs[(size_t)tiled[i]];
     j.ring_off = tj[i].ring_in;
+    ring2[i] = tj[i].ring_out;
     j.resume_s = tj[i].s0;
     j.fmax0 = fmax[i]; j.rmax0 = rmax[i];
   }
@@ -470,7 +490,9 @@ int align_resident_impl(wfm_handle* h, const wfm_penalties_t* pen, wfm_seqset* S
         {
           double tms = 0; uint64_t tcells = 0;
           const auto tw0 = std::chrono::steady_clock::now();
-          rc = run_tiled_phase(h, S, dp, scope, tcfg, jobs, tiled, ring2, tms, tcells, level);
+          rc = run_tiled_phase(h, S, dp, scope, tcfg, tcfg.T, false, jobs, tiled, ring2, tms, tcells, level);
+          if (rc == WFM_OK && tcfg.T_refine > 0 && tcfg.T_refine < tcfg.T)
+            rc = run_tiled_phase(h, S, dp, scope, tcfg, tcfg.T_refine, true, jobs, tiled, ring2, tms, tcells, level);
           wall_tile += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tw0).count();
           if (rc != WFM_OK) return rc;
           tm.bp_ms += tms; tm.tile_ms += tms;
