@@ -30,9 +30,13 @@ struct BpJob {
   int32_t comp_begin, comp_end;
   int32_t width;                       // row stride = round4(pl + tl + 9)
   int32_t koff;                        // column = k + koff (multiple of 4; normally pl + 4)
-  int32_t resume_s;                    // -1: start at score 0; >= 0: both directions resume at this score
-  int32_t fmax0, rmax0;                // running max antidiagonals at resume_s
+  int32_t resume_s;                    // -1: start at score 0; >= 0: the forward direction resumes at this score
+  int32_t fmax0, rmax0;                // running max antidiagonals at the resume point
   int32_t pad_;
+  // resume_sr >= 0: the snapshot is the exact meeting point found by the tile kernels -- forward at resume_s,
+  // reverse at resume_sr (= resume_s or resume_s - 1), phase 1 is over; -1: both directions resume at resume_s
+  int32_t resume_sr;
+  int32_t last_fwd;                    // with resume_sr >= 0: 1 if the forward step was the last one taken
 };
 
 // ---- time-tiled phase 1 (wfa_tile_kernel) ----
@@ -52,6 +56,9 @@ struct TileJob {
   int32_t active;                      // 0: the meeting point lies in the block after s0 (or the job is over): tiles exit
   int32_t fmax, rmax;                  // running maximum antidiagonals of the two directions up to s0
   int32_t nblocks;                     // tile blocks executed so far (incl. the one that found the meeting point)
+  int32_t mode;                        // 0: full blocks; 1: next block stops exactly at the meeting point; 2: stopped there
+  int32_t tf, tr;                      // mode >= 1: steps of the forward / reverse direction inside the block after s0
+  int32_t last_fwd;                    // mode >= 1: 1 if the forward check ended phase 1 (reverse is one step behind)
   int32_t pad_;
 };
 struct TileTask {
@@ -97,7 +104,7 @@ void launch_bp(const uint8_t* seq, int32_t* ring, const BpJob* jobs, BpResult* r
 void launch_tile_init(const uint8_t* seq, int32_t* ring, const TileJob* jobs, int32_t* mak0, int njobs, hipStream_t st);
 void launch_tile(const uint8_t* seq, int32_t* ring, const TileJob* jobs, const TileTask* tasks, int32_t* mak, int ntasks,
                  int threads, int T, int Wt, size_t lds_bytes, DevPen pen, int scope, hipStream_t st);
-void launch_tile_advance(TileJob* jobs, int32_t* mak, int njobs, int T, DevPen pen, hipStream_t st);
+void launch_tile_advance(TileJob* jobs, int32_t* mak, int njobs, int T, DevPen pen, int exact, hipStream_t st);
 void launch_tile_reg(const uint8_t* seq, int32_t* ring, const TileJob* jobs, const TileTask* tasks, int32_t* mak, int ntasks,
                      int threads, int T, int C, hipStream_t st);
 void launch_base(const uint8_t* seq, int32_t* a32, uint8_t* a8, uint32_t* rle, const BaseJob* jobs, BaseResult* res,

@@ -230,6 +230,8 @@ int run_base_jobs(wfm_handle* h, wfm_seqset* S, const wfm_penalties_t& pen, cons
 
 
 struct TileCfg {
+  bool exact = true;  // register tiles: re-run the block that holds the meeting point up to that point only, so the step
+                      // kernel starts at phase 2 (WFM_TILE_EXACT=0: it redoes the block step by step instead)
   int T_refine = 0;   // optional second pass over the block that holds the meeting point, in finer blocks (WFM_TILE_T_REFINE;
                       // measured neutral on C3: what the step kernel saves, the small tiles cost)
   int chunk = 2;  // tile blocks launched back to back between two looks of the host (WFM_TILE_CHUNK); more only adds idle tiles
@@ -245,6 +247,7 @@ TileCfg tile_cfg(const wfm_penalties_t& pen, int scope) {
   if (const char* e = getenv("WFM_TILE")) c.enabled = atoi(e) != 0;
   if (const char* e = getenv("WFM_TILE_T")) c.T = atoi(e);
   if (const char* e = getenv("WFM_TILE_T_REFINE")) c.T_refine = atoi(e);
+  if (const char* e = getenv("WFM_TILE_EXACT")) c.exact = atoi(e) != 0;
   if (const char* e = getenv("WFM_TILE_W")) c.Wt = atoi(e);
   if (const char* e = getenv("WFM_TILE_THREADS")) c.threads = atoi(e);
   if (const char* e = getenv("WFM_TILE_MIN_LEN")) c.min_len = atoi(e);
@@ -287,7 +290,7 @@ int run_tiled_phase(wfm_handle* h, wfm_seqset* S, const DevPen& dp, int scope, c
     t.p_fwd = j.p_fwd; t.t_fwd = j.t_fwd; t.p_rev = j.p_rev; t.t_rev = j.t_rev;
     t.ring_in = j.ring_off; t.ring_out = ring2[i];
     t.pl = j.pl; t.tl = j.tl; t.comp_begin = j.comp_begin; t.comp_end = j.comp_end;
-    t.width = j.width; t.koff = j.koff; t.s0 = 0; t.active = 1; t.fmax = 0; t.rmax = 0; t.nblocks = 0; t.pad_ = 0;
+    t.width = j.width; t.koff = j.koff; t.s0 = 0; t.active = 1; t.fmax = 0; t.rmax = 0; t.nblocks = 0; t.mode = 0; t.tf = 0; t.tr = 0; t.last_fwd = 0; t.pad_ = 0;
   }
   if (h->tilejobs.ensure(n) || h->tilemak.ensure(n * 2 * (size_t)std::max(T, 2))) { h->err = "out of device memory (tiles)"; return WFM_E_NOMEM; }
   size_t n_active = 0;
@@ -348,7 +351,7 @@ int run_tiled_phase(wfm_handle* h, wfm_seqset* S, const DevPen& dp, int scope, c
         if (cfg.reg) launch_tile_reg(S->d_seq, h->ring.p, h->tilejobs.p, h->tiletasks.p, h->tilemak.p, (int)tasks.size(), cfg.threads, T, cfg.C, h->stream);
         else launch_tile(S->d_seq, h->ring.p, h->tilejobs.p, h->tiletasks.p, h->tilemak.p, (int)tasks.size(), cfg.threads, T, cfg.Wt, lds, dp, scope, h->stream);
         HIPCHK(h, hipEventRecord(h->tile_ev[2 * b + 1], h->stream));
-        launch_tile_advance(h->tilejobs.p, h->tilemak.p, (int)n, T, dp, h->stream);
+        launch_tile_advance(h->tilejobs.p, h->tilemak.p, (int)n, T, dp, (cfg.reg && cfg.exact) ? 1 : 0, h->stream);
       }
       HIPCHK(h, hipGetLastError());
       HIPCHK(h, hipMemcpyAsync(got.data(), h->tilejobs.p, n * sizeof(TileJob), hipMemcpyDeviceToHost, h->stream));
@@ -364,11 +367,17 @@ int run_tiled_phase(wfm_handle* h, wfm_seqset* S, const DevPen& dp, int scope, c
       n_active = 0;
       for (size_t i = 0; i < n; ++i) {
         // cells of the blocks this job ran since the last look (the block that found the meeting point included)
-        for (int bl = tj[i].nblocks; bl < got[i].nblocks; ++bl)
-          for (int t = 1; t <= T; ++t) {
-            const int sc = s_begin[i] + bl * T + t;
-            tile_cells += 2ull * (uint64_t)(std::min(tj[i].tl, sc) - std::max(-tj[i].pl, -sc) + 1);
+        for (int bl = tj[i].nblocks; bl < got[i].nblocks; ++bl) {
+          const bool last_exact = got[i].mode == 2 && bl == got[i].nblocks - 1;  // the block that stopped at the meeting point
+          const int base = s_begin[i] + (last_exact ? bl - 1 : bl) * T;          // it re-ran the block before it
+          for (int d = 0; d < 2; ++d) {
+            const int steps = last_exact ? (d == 0 ? got[i].tf : got[i].tr) : T;
+            for (int t = 1; t <= steps; ++t) {
+              const int sc = base + t;
+              tile_cells += (uint64_t)(std::min(tj[i].tl, sc) - std::max(-tj[i].pl, -sc) + 1);
+            }
           }
+        }
         tj[i] = got[i];
         active[i] = (char)(got[i].active != 0);
         fmax[i] = got[i].fmax; rmax[i] = got[i].rmax;
@@ -381,6 +390,12 @@ int run_tiled_phase(wfm_handle* h, wfm_seqset* S, const DevPen& dp, int scope, c
     j.ring_off = tj[i].ring_in;
     ring2[i] = tj[i].ring_out;
     j.resume_s = tj[i].s0;
+    j.resume_sr = -1; j.last_fwd = 0;
+    if (tj[i].mode == 2) {  // stopped exactly at the meeting point: the step kernel goes straight to phase 2
+      j.resume_s = tj[i].s0 + tj[i].tf;
+      j.resume_sr = tj[i].s0 + tj[i].tr;
+      j.last_fwd = tj[i].last_fwd;
+    }
     j.fmax0 = fmax[i]; j.rmax0 = rmax[i];
   }
   if (getenv("WFM_DEBUG")) fprintf(stderr, "[wfm] level %u: tiled %zu jobs, %u blocks of %d scores (Wt %d), %.3f ms\n", level, n, blocks, T, cfg.Wt, tile_ms);
@@ -473,7 +488,7 @@ int align_resident_impl(wfm_handle* h, const wfm_penalties_t* pen, wfm_seqset* S
         j.comp_begin = nd.cb; j.comp_end = nd.ce;
         j.width = (int32_t)width;
         j.koff = koff;
-        j.resume_s = -1; j.fmax0 = 0; j.rmax0 = 0;
+        j.resume_s = -1; j.resume_sr = -1; j.last_fwd = 0; j.fmax0 = 0; j.rmax0 = 0;
         if (tile_it) { tiled.push_back((int)jobs.size()); ring2.push_back((int64_t)(ring_elems + need / 2)); }
         node_of.push_back((int32_t)i);
         ring_elems += need;
@@ -491,7 +506,7 @@ int align_resident_impl(wfm_handle* h, const wfm_penalties_t* pen, wfm_seqset* S
           double tms = 0; uint64_t tcells = 0;
           const auto tw0 = std::chrono::steady_clock::now();
           rc = run_tiled_phase(h, S, dp, scope, tcfg, tcfg.T, false, jobs, tiled, ring2, tms, tcells, level);
-          if (rc == WFM_OK && tcfg.T_refine > 0 && tcfg.T_refine < tcfg.T)
+          if (rc == WFM_OK && tcfg.T_refine > 0 && tcfg.T_refine < tcfg.T && !(tcfg.reg && tcfg.exact))
             rc = run_tiled_phase(h, S, dp, scope, tcfg, tcfg.T_refine, true, jobs, tiled, ring2, tms, tcells, level);
           wall_tile += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tw0).count();
           if (rc != WFM_OK) return rc;

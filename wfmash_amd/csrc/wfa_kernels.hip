@@ -469,9 +469,11 @@ __global__ __launch_bounds__(1024) void wfa_bp_kernel(const uint8_t* __restrict_
   for (int i = tid; i < 2 * RING * 5; i += blockDim.x) ((int*)s_rmax)[i] = 0;
   __syncthreads();
   int end_reached = 0;
+  const bool exact = J.resume_s >= 0 && J.resume_sr >= 0;  // the snapshot IS the meeting point: phase 1 is over
+  const int rs_f = J.resume_s, rs_r = exact ? J.resume_sr : J.resume_s;
   if (J.resume_s >= 0) {
     if (tid < 2 * RING) {
-      const int d = tid / RING, sc = J.resume_s - (tid % RING);
+      const int d = tid / RING, sc = (d == 0 ? rs_f : rs_r) - (tid % RING);
       if (sc >= 0) { s_lo[d][sc & RMASK] = max(-J.pl, -sc); s_hi[d][sc & RMASK] = min(J.tl, sc); }
     }
     if (tid == 0) { s_mak[0][0] = J.fmax0; s_mak[0][1] = J.rmax0; s_bp[6] = 0; s_bp[7] = 0; }
@@ -495,8 +497,8 @@ __global__ __launch_bounds__(1024) void wfa_bp_kernel(const uint8_t* __restrict_
   }
   cells = J.resume_s >= 0 ? 0 : 2;
   const int64_t max_steps = (int64_t)(pen.o1 + pen.o2) * 4 + (int64_t)(J.pl + J.tl + 2) * max(pen.x, max(pen.e1, pen.e2)) * 2 + 256;
-  int sf = max(J.resume_s, 0), sr = sf;
-  int last_fwd = 0;
+  int sf = max(rs_f, 0), sr = max(rs_r, 0);
+  int last_fwd = exact ? J.last_fwd : 0;
   int status = 0;
   int buf = 0;
   const long long t_begin = wall_clock64();
@@ -558,10 +560,10 @@ __global__ __launch_bounds__(1024) void wfa_bp_kernel(const uint8_t* __restrict_
     const int gopen = max(pen.o1, pen.o2);
     // row maxima of the `scope` newest rows of both directions: rows computed by this kernel
     // already have theirs; rows taken over from a tile snapshot (or row 0) are scanned here
-    const int own_from = max(J.resume_s, 0) + 1;
+    const int own_f = max(rs_f, 0) + 1, own_r = max(rs_r, 0) + 1;
     for (int i = 0; i < scope; ++i) {
-      if (sf - i >= 0 && sf - i < own_from) bp_row_maxima(c, 0, sf - i, s_lo, s_hi, s_rmax);
-      if (sr - i >= 0 && sr - i < own_from) bp_row_maxima(c, 1, sr - i, s_lo, s_hi, s_rmax);
+      if (sf - i >= 0 && sf - i < own_f) bp_row_maxima(c, 0, sf - i, s_lo, s_hi, s_rmax);
+      if (sr - i >= 0 && sr - i < own_r) bp_row_maxima(c, 1, sr - i, s_lo, s_hi, s_rmax);
     }
     __syncthreads();
     for (;;) {
@@ -1176,6 +1178,8 @@ __global__ __launch_bounds__(NTMAX) void wfa_tile_reg_kernel(const uint8_t* __re
   const int32_t* rin = ring_arena + J.ring_in + J.koff + (int64_t)dir * 5 * RING * width;
   int32_t* rout = ring_arena + J.ring_out + J.koff + (int64_t)dir * 5 * RING * width;
   const int kmax = tk.core_hi + T;  // last diagonal of the tile
+  // a job whose meeting point is known runs its last block only up to it (per direction)
+  const int Tn = J.mode == 1 ? (dir == 0 ? J.tf : J.tr) : T;
 
   // Mh[c][r][e] = M[sr - 5 e][k0+c], sr = the newest score <= current with (sr - s0) mod 5 == r
   int Mh[C][NCL][DEP];
@@ -1250,11 +1254,11 @@ __global__ __launch_bounds__(NTMAX) void wfa_tile_reg_kernel(const uint8_t* __re
   }
   __syncthreads();
 
-  for (int tb = 0; tb < T; tb += NCL) {
+  for (int tb = 0; tb < Tn; tb += NCL) {
 #pragma unroll
   for (int jj = 1; jj <= NCL; ++jj) {
     const int t = tb + jj;
-    if (t > T) break;
+    if (t > Tn) break;
     const int cl = jj % NCL;  // residue class of this step's score: compile time after unrolling
     const int s = s0 + t;
     const int par = t & 1;
@@ -1342,7 +1346,7 @@ __global__ __launch_bounds__(NTMAX) void wfa_tile_reg_kernel(const uint8_t* __re
       }
     }
     // stream the last H rows of I/D of the core to the output snapshot
-    if (t > T - H) {
+    if (t > Tn - H) {
 #pragma unroll
       for (int c = 0; c < C; ++c) {
         const int k = k0 + c;
@@ -1373,7 +1377,24 @@ __global__ __launch_bounds__(NTMAX) void wfa_tile_reg_kernel(const uint8_t* __re
   // ---- output snapshot: the newest H rows of M for the core ----
   // row s_end - d lives in class (T - d) mod 5 at depth (d - (T - class) mod 5) / 5; T mod 5 is uniform, one
   // compile-time variant per value keeps the history in registers
-  const int s_end = s0 + T;
+  const int s_end = s0 + Tn;
+  if (Tn < H) {
+    // a short last block: the I/D rows of scores <= s0 that the step kernel still looks at live in the input ring
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      const int k = k0 + c;
+      if (k < tk.core_lo || k > tk.core_hi) continue;
+      for (int d = Tn; d < H; ++d) {
+        const int sc = s_end - d;
+        if (sc < 0 || k < rng_lo(pl, sc) || k > rng_hi(tl, sc)) continue;
+        const int64_t ro = ((int64_t)(sc & RMASK)) * width + k;
+        rout[(int64_t)C_I1 * RING * width + ro] = rin[(int64_t)C_I1 * RING * width + ro];
+        rout[(int64_t)C_I2 * RING * width + ro] = rin[(int64_t)C_I2 * RING * width + ro];
+        rout[(int64_t)C_D1 * RING * width + ro] = rin[(int64_t)C_D1 * RING * width + ro];
+        rout[(int64_t)C_D2 * RING * width + ro] = rin[(int64_t)C_D2 * RING * width + ro];
+      }
+    }
+  }
   auto write_rows = [&](auto TR) {
     constexpr int tr = decltype(TR)::value;  // T mod 5
 #pragma unroll
@@ -1390,7 +1411,7 @@ __global__ __launch_bounds__(NTMAX) void wfa_tile_reg_kernel(const uint8_t* __re
       }
     }
   };
-  switch (T % NCL) {
+  switch (Tn % NCL) {
     case 0: write_rows(std::integral_constant<int, 0>{}); break;
     case 1: write_rows(std::integral_constant<int, 1>{}); break;
     case 2: write_rows(std::integral_constant<int, 2>{}); break;
@@ -1406,26 +1427,39 @@ __global__ __launch_bounds__(NTMAX) void wfa_tile_reg_kernel(const uint8_t* __re
 // wavefront_bialign_find_breakpoint over the T per-score maxima of the block just computed.  A job whose
 // wavefronts met inside the block (or that ran out of steps) goes inactive with its state still at the
 // block's START -- wfa_bp_kernel redoes that block step by step; the others move on to the next block.
-__global__ void wfa_tile_advance_kernel(TileJob* __restrict__ jobs, int32_t* __restrict__ mak, int njobs, int T, DevPen pen) {
+__global__ void wfa_tile_advance_kernel(TileJob* __restrict__ jobs, int32_t* __restrict__ mak, int njobs, int T, DevPen pen, int exact) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= njobs) return;
   TileJob J = jobs[i];
   if (!J.active) return;
   int32_t* mf = mak + ((int64_t)i * 2 + 0) * T;
   int32_t* mr = mak + ((int64_t)i * 2 + 1) * T;
+  if (J.mode == 1) {
+    // the block that stops at the meeting point has run: its output ring is the snapshot the step kernel starts phase 2 from
+    for (int t = 0; t < T; ++t) { mf[t] = 0; mr[t] = 0; }
+    const int64_t t = J.ring_in; J.ring_in = J.ring_out; J.ring_out = t;
+    J.mode = 2; J.active = 0; J.nblocks += 1;
+    jobs[i] = J;
+    return;
+  }
   const int A = J.pl + J.tl - 1;
   int fm = J.fmax, rm = J.rmax;
+  int tf = 0, tr = 0, last_fwd = 0;
   bool term = false;
   for (int t = 0; t < T && !term; ++t) {
-    fm = max(fm, mf[t]);
-    if (fm + rm >= A) { term = true; break; }
-    rm = max(rm, mr[t]);
+    fm = max(fm, mf[t]); tf = t + 1;
+    if (fm + rm >= A) { term = true; last_fwd = 1; break; }
+    rm = max(rm, mr[t]); tr = t + 1;
     if (fm + rm >= A) term = true;
   }
   for (int t = 0; t < T; ++t) { mf[t] = 0; mr[t] = 0; }
   const int64_t max_steps = (int64_t)(pen.o1 + pen.o2) * 4 + (int64_t)(J.pl + J.tl + 2) * max(pen.x, max(pen.e1, pen.e2)) * 2 + 256;
   J.nblocks += 1;
-  if (term || 2 * (int64_t)(J.s0 + T) > max_steps) {
+  if (term && exact) {
+    // redo this block, but only up to the meeting point (forward tf steps, reverse tr): same input ring
+    J.mode = 1; J.tf = tf; J.tr = tr; J.last_fwd = last_fwd;
+    J.fmax = fm; J.rmax = rm;
+  } else if (term || 2 * (int64_t)(J.s0 + T) > max_steps) {
     J.active = 0;
   } else {
     J.fmax = fm; J.rmax = rm;
@@ -1456,8 +1490,8 @@ void launch_tile(const uint8_t* seq, int32_t* ring, const TileJob* jobs, const T
   }
   hipLaunchKernelGGL(wfa_tile_kernel, dim3(ntasks), dim3(threads), lds_bytes, st, seq, ring, jobs, tasks, mak, T, Wt, pen, scope);
 }
-void launch_tile_advance(TileJob* jobs, int32_t* mak, int njobs, int T, DevPen pen, hipStream_t st) {
-  hipLaunchKernelGGL(wfa_tile_advance_kernel, dim3((njobs + 63) / 64), dim3(64), 0, st, jobs, mak, njobs, T, pen);
+void launch_tile_advance(TileJob* jobs, int32_t* mak, int njobs, int T, DevPen pen, int exact, hipStream_t st) {
+  hipLaunchKernelGGL(wfa_tile_advance_kernel, dim3((njobs + 63) / 64), dim3(64), 0, st, jobs, mak, njobs, T, pen, exact);
 }
 void launch_tile_reg(const uint8_t* seq, int32_t* ring, const TileJob* jobs, const TileTask* tasks, int32_t* mak, int ntasks,
                      int threads, int T, int C, hipStream_t st) {
