@@ -1427,8 +1427,10 @@ __global__ __launch_bounds__(NTMAX) void wfa_tile_reg_kernel(const uint8_t* __re
 // wavefront_bialign_find_breakpoint over the T per-score maxima of the block just computed.  A job whose
 // wavefronts met inside the block (or that ran out of steps) goes inactive with its state still at the
 // block's START -- wfa_bp_kernel redoes that block step by step; the others move on to the next block.
-__global__ void wfa_tile_advance_kernel(TileJob* __restrict__ jobs, int32_t* __restrict__ mak, int njobs, int T, DevPen pen, int exact) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+// one wave per job: the T per-score maxima are read once, prefix maxima replace the sequential replay
+__global__ __launch_bounds__(64) void wfa_tile_advance_kernel(TileJob* __restrict__ jobs, int32_t* __restrict__ mak, int njobs, int T, DevPen pen,
+                                                              int exact) {
+  const int i = blockIdx.x, lane = threadIdx.x;
   if (i >= njobs) return;
   TileJob J = jobs[i];
   if (!J.active) return;
@@ -1436,23 +1438,44 @@ __global__ void wfa_tile_advance_kernel(TileJob* __restrict__ jobs, int32_t* __r
   int32_t* mr = mak + ((int64_t)i * 2 + 1) * T;
   if (J.mode == 1) {
     // the block that stops at the meeting point has run: its output ring is the snapshot the step kernel starts phase 2 from
-    for (int t = 0; t < T; ++t) { mf[t] = 0; mr[t] = 0; }
-    const int64_t t = J.ring_in; J.ring_in = J.ring_out; J.ring_out = t;
-    J.mode = 2; J.active = 0; J.nblocks += 1;
-    jobs[i] = J;
+    for (int t = lane; t < T; t += 64) { mf[t] = 0; mr[t] = 0; }
+    if (lane == 0) {
+      const int64_t t = J.ring_in; J.ring_in = J.ring_out; J.ring_out = t;
+      J.mode = 2; J.active = 0; J.nblocks += 1;
+      jobs[i] = J;
+    }
     return;
   }
   const int A = J.pl + J.tl - 1;
-  int fm = J.fmax, rm = J.rmax;
+  int fm = J.fmax, rm = J.rmax;  // running maxima before the chunk of 64 scores at hand (uniform)
   int tf = 0, tr = 0, last_fwd = 0;
   bool term = false;
-  for (int t = 0; t < T && !term; ++t) {
-    fm = max(fm, mf[t]); tf = t + 1;
-    if (fm + rm >= A) { term = true; last_fwd = 1; break; }
-    rm = max(rm, mr[t]); tr = t + 1;
-    if (fm + rm >= A) term = true;
+  for (int base = 0; base < T && !term; base += 64) {
+    const int t = base + lane;
+    const int vf = t < T ? mf[t] : 0, vr = t < T ? mr[t] : 0;
+    int pf = vf, pr = vr;  // inclusive prefix maxima over the lanes
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int uf = __shfl_up(pf, d, 64), ur = __shfl_up(pr, d, 64);
+      if (lane >= d) { pf = max(pf, uf); pr = max(pr, ur); }
+    }
+    int er = __shfl_up(pr, 1, 64);  // exclusive prefix maximum of the reverse direction
+    if (lane == 0) er = 0;
+    const int fm_t = max(fm, pf), rm_t = max(rm, pr), rm_before = max(rm, er);
+    // the reference alternates: forward step t, check, reverse step t, check
+    const bool hit_f = t < T && fm_t + rm_before >= A, hit_r = t < T && fm_t + rm_t >= A;
+    const unsigned long long bf = __ballot(hit_f), br = __ballot(hit_r);
+    if (bf | br) {
+      const int lf = bf ? __builtin_ctzll(bf) : 64, lr = br ? __builtin_ctzll(br) : 64;
+      term = true;
+      if (lf <= lr) { last_fwd = 1; tf = base + lf + 1; tr = base + lf; fm = __shfl(fm_t, lf, 64); rm = __shfl(rm_before, lf, 64); }
+      else { last_fwd = 0; tf = tr = base + lr + 1; fm = __shfl(fm_t, lr, 64); rm = __shfl(rm_t, lr, 64); }
+    } else {
+      fm = __shfl(fm_t, 63, 64); rm = __shfl(rm_t, 63, 64);
+    }
   }
-  for (int t = 0; t < T; ++t) { mf[t] = 0; mr[t] = 0; }
+  for (int t = lane; t < T; t += 64) { mf[t] = 0; mr[t] = 0; }
+  if (lane != 0) return;
   const int64_t max_steps = (int64_t)(pen.o1 + pen.o2) * 4 + (int64_t)(J.pl + J.tl + 2) * max(pen.x, max(pen.e1, pen.e2)) * 2 + 256;
   J.nblocks += 1;
   if (term && exact) {
@@ -1491,7 +1514,7 @@ void launch_tile(const uint8_t* seq, int32_t* ring, const TileJob* jobs, const T
   hipLaunchKernelGGL(wfa_tile_kernel, dim3(ntasks), dim3(threads), lds_bytes, st, seq, ring, jobs, tasks, mak, T, Wt, pen, scope);
 }
 void launch_tile_advance(TileJob* jobs, int32_t* mak, int njobs, int T, DevPen pen, int exact, hipStream_t st) {
-  hipLaunchKernelGGL(wfa_tile_advance_kernel, dim3((njobs + 63) / 64), dim3(64), 0, st, jobs, mak, njobs, T, pen, exact);
+  hipLaunchKernelGGL(wfa_tile_advance_kernel, dim3(njobs), dim3(64), 0, st, jobs, mak, njobs, T, pen, exact);
 }
 void launch_tile_reg(const uint8_t* seq, int32_t* ring, const TileJob* jobs, const TileTask* tasks, int32_t* mak, int ntasks,
                      int threads, int T, int C, hipStream_t st) {
