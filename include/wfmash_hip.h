@@ -101,6 +101,10 @@ typedef struct {
   uint64_t cells_tile;       /* part of cells_bp computed by wfa_tile_kernel      */
   double   ms_tile;          /* part of ms_breakpoint spent in wfa_tile_kernel    */
   uint32_t tile_launches, tile_tasks;
+  double   ms_tile_busy;     /* time during which at least one tile kernel launch was running: equals ms_tile unless
+                              * the two halves of a batch ran their tile kernels side by side on two streams */
+  uint32_t streams;          /* 1, or 2 when the batch was split into two concurrently processed halves */
+  uint32_t pad_;
 } wfm_stats_t;
 
 int  wfm_create(int device, wfm_handle_t** out);

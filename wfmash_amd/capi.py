@@ -55,7 +55,8 @@ class Stats(C.Structure):
                 ("bp_launches", C.c_uint32), ("base_launches", C.c_uint32),
                 ("cells_bp", C.c_uint64), ("cells_base", C.c_uint64),
                 ("cells_tile", C.c_uint64), ("ms_tile", C.c_double),
-                ("tile_launches", C.c_uint32), ("tile_tasks", C.c_uint32)]
+                ("tile_launches", C.c_uint32), ("tile_tasks", C.c_uint32),
+                ("ms_tile_busy", C.c_double), ("streams", C.c_uint32), ("pad_", C.c_uint32)]
 
 
 class Minmer(C.Structure):

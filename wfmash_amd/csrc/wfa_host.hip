@@ -15,6 +15,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/wfmash_hip.h"
@@ -90,6 +91,10 @@ struct wfm_handle {
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
   std::vector<hipEvent_t> tile_ev;  // start/stop pairs for the tile blocks of one chunk
+  wfm_handle* peer = nullptr;       // second context for the other half of a batch (created on first use)
+  hipEvent_t ev_base = nullptr;     // time origin of the call (shared by the two halves)
+  hipEvent_t call_base = nullptr;   // the origin this call measures against
+  std::vector<std::pair<float, float>> tile_iv;  // (start, end) of every tile kernel launch of the call, ms after call_base
   std::string err;
   std::string name;
   size_t mem_budget = 0;
@@ -360,6 +365,11 @@ int run_tiled_phase(wfm_handle* h, wfm_seqset* S, const DevPen& dp, int scope, c
         float ms = 0;
         HIPCHK(h, hipEventElapsedTime(&ms, h->tile_ev[2 * b], h->tile_ev[2 * b + 1]));
         tile_ms += ms;
+        if (h->call_base) {
+          float t0 = 0;
+          HIPCHK(h, hipEventElapsedTime(&t0, h->call_base, h->tile_ev[2 * b]));
+          h->tile_iv.emplace_back(t0, t0 + ms);
+        }
       }
       blocks += (uint32_t)chunk;
       h->stats.tile_launches += (uint32_t)chunk;
@@ -402,20 +412,21 @@ int run_tiled_phase(wfm_handle* h, wfm_seqset* S, const DevPen& dp, int scope, c
   return WFM_OK;
 }
 
-int align_resident_impl(wfm_handle* h, const wfm_penalties_t* pen, wfm_seqset* S, wfm_result_t* out,
-                        char* ops_arena, size_t arena_bytes) {
+// Aligns problems [first, last) of S; their op strings go to ops_arena from byte arena_base on.
+int align_resident_impl(wfm_handle* h, const wfm_penalties_t* pen, wfm_seqset* S, size_t first, size_t last, wfm_result_t* out,
+                        char* ops_arena, size_t arena_bytes, size_t arena_base) {
   int scope = 0;
   int rc = validate_pen(pen, &scope);
   if (rc != WFM_OK) { h->err = "unsupported penalties"; return rc; }
   const auto t_start = std::chrono::steady_clock::now();
   HIPCHK(h, hipSetDevice(h->device));
-  const size_t n = S->meta.size();
+  const size_t n = last - first;
   h->stats = wfm_stats_t{};
   if (n == 0) return 0;
   const DevPen dp{pen->x, pen->o1, pen->e1, pen->o2, pen->e2};
 
-  std::vector<int32_t> prob_status(n, WFM_ST_OK);
-  std::vector<uint64_t> prob_cells(n, 0);
+  std::vector<int32_t> prob_status(S->meta.size(), WFM_ST_OK);  // indexed by problem id
+  std::vector<uint64_t> prob_cells(S->meta.size(), 0);
 
   // RLE slot buffer (zero = empty)
   if (h->rle.ensure((size_t)S->rle_total + 16) || h->rle_out.ensure((size_t)S->rle_total + 16)) {
@@ -425,7 +436,7 @@ int align_resident_impl(wfm_handle* h, const wfm_penalties_t* pen, wfm_seqset* S
 
   // roots
   std::vector<Node> bp_nodes, base_nodes, next_bp, retry;
-  for (size_t i = 0; i < n; ++i) {
+  for (size_t i = first; i < last; ++i) {
     const ProbMeta& pm = S->meta[i];
     Node nd{};
     nd.prob = (int32_t)i; nd.pb = 0; nd.pl = pm.plen; nd.tb = 0; nd.tl = pm.tlen;
@@ -584,7 +595,7 @@ int align_resident_impl(wfm_handle* h, const wfm_penalties_t* pen, wfm_seqset* S
 
   // ---- gather RLE pieces ----
   std::vector<int64_t> poff(n), pcap(n);
-  for (size_t i = 0; i < n; ++i) { poff[i] = S->meta[i].rle_off; pcap[i] = (int64_t)S->meta[i].plen + S->meta[i].tlen; }
+  for (size_t i = 0; i < n; ++i) { poff[i] = S->meta[first + i].rle_off; pcap[i] = (int64_t)S->meta[first + i].plen + S->meta[first + i].tlen; }
   if (h->i64a.ensure(n) || h->i64b.ensure(n) || h->i64c.ensure(n) || h->i32a.ensure(n) || h->total.ensure(1)) {
     h->err = "out of device memory"; return WFM_E_NOMEM;
   }
@@ -605,14 +616,15 @@ int align_resident_impl(wfm_handle* h, const wfm_penalties_t* pen, wfm_seqset* S
 
   // ---- expand to op strings ----
   static const char opc[4] = {'M', 'X', 'I', 'D'};
-  size_t arena_pos = 0;
+  size_t arena_pos = arena_base;
   int failed = 0;
   uint64_t cells_total = 0;
   for (size_t i = 0; i < n; ++i) {
-    wfm_result_t& r = out[i];
-    r.status = prob_status[i];
-    r.cells = prob_cells[i];
-    cells_total += prob_cells[i];
+    const size_t gi = first + i;  // problem id
+    wfm_result_t& r = out[gi];
+    r.status = prob_status[gi];
+    r.cells = prob_cells[gi];
+    cells_total += prob_cells[gi];
     r.ops_off = arena_pos; r.ops_len = 0; r.n_runs = 0; r.score = -1;
     if (r.status != WFM_ST_OK) { ++failed; continue; }
     const uint32_t* e = runs.data() + ostart[i];
@@ -639,7 +651,7 @@ int align_resident_impl(wfm_handle* h, const wfm_penalties_t* pen, wfm_seqset* S
       }
       k = k2;
     }
-    if (pc != (uint64_t)S->meta[i].plen || tc != (uint64_t)S->meta[i].tlen) {
+    if (pc != (uint64_t)S->meta[gi].plen || tc != (uint64_t)S->meta[gi].tlen) {
       r.status = WFM_ST_UNREACHABLE;  // internal inconsistency: never report a broken CIGAR as ok
       ++failed;
       continue;
@@ -651,7 +663,9 @@ int align_resident_impl(wfm_handle* h, const wfm_penalties_t* pen, wfm_seqset* S
   }
   cells_total += h->stats.cells_tile;
   h->stats.cells = cells_total;
-  h->stats.bytes_algorithmic = 48ull * cells_total + S->seq_bases;
+  uint64_t range_bases = 0;
+  for (size_t i = first; i < last; ++i) range_bases += (uint64_t)S->meta[i].plen + (uint64_t)S->meta[i].tlen;
+  h->stats.bytes_algorithmic = 48ull * cells_total + range_bases;
   h->stats.ms_breakpoint = tm.bp_ms;
   h->stats.ms_tile = tm.tile_ms;
   h->stats.ms_base = tm.base_ms;
@@ -684,6 +698,7 @@ int wfm_create(int device, wfm_handle_t** out) {
   (void)hipEventCreate(&h->ev0); (void)hipEventCreate(&h->ev1); (void)hipEventCreate(&h->ev2); (void)hipEventCreate(&h->ev3);
   h->tile_ev.resize(64);
   for (auto& e : h->tile_ev) (void)hipEventCreate(&e);
+  (void)hipEventCreate(&h->ev_base);
   size_t fr = 0, tot = 0;
   if (hipMemGetInfo(&fr, &tot) != hipSuccess) { fr = (size_t)16 << 30; }
   h->mem_budget = (size_t)((double)fr * 0.40);
@@ -695,6 +710,7 @@ int wfm_create(int device, wfm_handle_t** out) {
 
 void wfm_destroy(wfm_handle_t* h) {
   if (!h) return;
+  if (h->peer) { wfm_destroy(h->peer); h->peer = nullptr; }
   (void)hipSetDevice(h->device);
   h->ring.release(); h->base32.release(); h->base8.release(); h->rle.release(); h->rle_out.release();
   h->tilejobs.release(); h->tiletasks.release(); h->tilemak.release();
@@ -705,6 +721,7 @@ void wfm_destroy(wfm_handle_t* h) {
   if (h->ev2) (void)hipEventDestroy(h->ev2);
   if (h->ev3) (void)hipEventDestroy(h->ev3);
   for (auto& e : h->tile_ev) if (e) (void)hipEventDestroy(e);
+  if (h->ev_base) (void)hipEventDestroy(h->ev_base);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
 }
@@ -782,7 +799,69 @@ void wfm_free_sequences(wfm_handle_t* h, wfm_seqset_t* s) {
 int wfm_align_resident(wfm_handle_t* h, const wfm_penalties_t* pen, wfm_seqset_t* s, wfm_result_t* out,
                        char* ops_arena, size_t arena_bytes) {
   if (!h || !s || !out || (!ops_arena && arena_bytes)) return WFM_E_ARG;
-  return align_resident_impl(h, pen, s, out, ops_arena, arena_bytes);
+  const size_t n = s->meta.size();
+  static const bool overlap = !(getenv("WFM_OVERLAP") && atoi(getenv("WFM_OVERLAP")) == 0);
+  if (hipSetDevice(h->device) != hipSuccess || hipEventRecord(h->ev_base, h->stream) != hipSuccess ||
+      hipEventSynchronize(h->ev_base) != hipSuccess) { h->err = "hipEventRecord failed"; return WFM_E_HIP; }
+  h->call_base = h->ev_base;
+  h->tile_iv.clear();
+  auto busy_ms = [](std::vector<std::pair<float, float>> iv) {  // length of the union of the intervals
+    std::sort(iv.begin(), iv.end());
+    double total = 0, lo = 0, hi = -1;
+    for (const auto& x : iv) {
+      if (x.first > hi) { if (hi > lo) total += hi - lo; lo = x.first; hi = x.second; }
+      else hi = std::max<double>(hi, x.second);
+    }
+    if (hi > lo) total += hi - lo;
+    return total;
+  };
+  if (!overlap || n < 8) {
+    const int rc = align_resident_impl(h, pen, s, 0, n, out, ops_arena, arena_bytes, 0);
+    h->stats.ms_tile_busy = busy_ms(h->tile_iv);
+    h->stats.streams = 1;
+    return rc;
+  }
+  // Two halves of the batch side by side, each with its own stream and arenas (a peer handle on the same
+  // device) and its own host thread: while one half sits in the few-workgroup levels of the step kernel or
+  // waits for the host, the other half's tiles fill the machine.  Problems are independent, the halves only
+  // share the (read-only) sequences and the caller's output buffers.
+  if (!h->peer) {
+    wfm_handle_t* p = nullptr;
+    const int rc = wfm_create(h->device, &p);
+    if (rc != WFM_OK) return align_resident_impl(h, pen, s, 0, n, out, ops_arena, arena_bytes, 0);
+    h->peer = p;
+  }
+  // balance the halves by sum of (plen + tlen)^2 (WFA cost), contiguous split
+  std::vector<double> cost(n + 1, 0.0);
+  for (size_t i = 0; i < n; ++i) {
+    const double l = (double)s->meta[i].plen + (double)s->meta[i].tlen;
+    cost[i + 1] = cost[i] + l * l;
+  }
+  size_t mid = 1;
+  while (mid + 1 < n && cost[mid] < cost[n] / 2) ++mid;
+  size_t base_b = 0;
+  for (size_t i = 0; i < mid; ++i) base_b += (size_t)s->meta[i].plen + (size_t)s->meta[i].tlen + 1;
+  const auto t0 = std::chrono::steady_clock::now();
+  int rc_b = 0;
+  h->peer->call_base = h->ev_base;
+  h->peer->tile_iv.clear();
+  std::thread tb([&] { rc_b = align_resident_impl(h->peer, pen, s, mid, n, out, ops_arena, arena_bytes, base_b); });
+  const int rc_a = align_resident_impl(h, pen, s, 0, mid, out, ops_arena, arena_bytes, 0);
+  tb.join();
+  if (rc_b < 0) h->err = h->peer->err;
+  if (rc_a < 0 || rc_b < 0) return rc_a < 0 ? rc_a : rc_b;
+  const wfm_stats_t& b = h->peer->stats;
+  wfm_stats_t& a = h->stats;
+  a.cells += b.cells; a.bytes_algorithmic += b.bytes_algorithmic; a.ms_kernels += b.ms_kernels; a.ms_breakpoint += b.ms_breakpoint;
+  a.ms_base += b.ms_base; a.levels = std::max(a.levels, b.levels); a.bp_jobs += b.bp_jobs; a.base_jobs += b.base_jobs;
+  a.bp_launches += b.bp_launches; a.base_launches += b.base_launches; a.cells_bp += b.cells_bp; a.cells_base += b.cells_base;
+  a.cells_tile += b.cells_tile; a.ms_tile += b.ms_tile; a.tile_launches += b.tile_launches; a.tile_tasks += b.tile_tasks;
+  a.ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  std::vector<std::pair<float, float>> iv = h->tile_iv;
+  iv.insert(iv.end(), h->peer->tile_iv.begin(), h->peer->tile_iv.end());
+  a.ms_tile_busy = busy_ms(iv);
+  a.streams = 2;
+  return rc_a + rc_b;
 }
 
 int wfm_align_batch(wfm_handle_t* h, const wfm_penalties_t* pen, const wfm_problem_t* problems, size_t n,
