@@ -138,7 +138,7 @@ def main():
         peak = 8000.0
         traffic = None  # HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/)
         try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r1d_traffic.json")))
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r1e_traffic.json")))
             if tj.get("kernel") == dom and args.config == "C3" and args.pairs == 64:
                 traffic = tj["traffic_bytes_per_launch"]
         except (OSError, ValueError, KeyError):
