@@ -91,13 +91,14 @@ struct wfm_handle {
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
   std::vector<hipEvent_t> tile_ev;  // start/stop pairs for the tile blocks of one chunk
-  wfm_handle* peer = nullptr;       // second context for the other half of a batch (created on first use)
+  std::vector<wfm_handle*> peers;   // further contexts for the other parts of a batch (created on first use)
   hipEvent_t ev_base = nullptr;     // time origin of the call (shared by the two halves)
   hipEvent_t call_base = nullptr;   // the origin this call measures against
   std::vector<std::pair<float, float>> tile_iv;  // (start, end) of every tile kernel launch of the call, ms after call_base
   std::string err;
   std::string name;
-  size_t mem_budget = 0;
+  size_t mem_budget = 0;       // arena budget in force for the call at hand
+  size_t mem_budget_full = 0;  // the handle's whole budget (40 % of free HBM at creation, or WFM_MEM_BUDGET_MB)
   wfm_stats_t stats{};
   DevBuf<int32_t> ring;      // breakpoint rings
   DevBuf<int32_t> base32;    // base: pre + rings
@@ -704,13 +705,15 @@ int wfm_create(int device, wfm_handle_t** out) {
   h->mem_budget = (size_t)((double)fr * 0.40);
   const char* env = getenv("WFM_MEM_BUDGET_MB");
   if (env) h->mem_budget = (size_t)atoll(env) << 20;
+  h->mem_budget_full = h->mem_budget;
   *out = h;
   return WFM_OK;
 }
 
 void wfm_destroy(wfm_handle_t* h) {
   if (!h) return;
-  if (h->peer) { wfm_destroy(h->peer); h->peer = nullptr; }
+  for (wfm_handle* p : h->peers) wfm_destroy(p);
+  h->peers.clear();
   (void)hipSetDevice(h->device);
   h->ring.release(); h->base32.release(); h->base8.release(); h->rle.release(); h->rle_out.release();
   h->tilejobs.release(); h->tiletasks.release(); h->tilemak.release();
@@ -815,53 +818,81 @@ int wfm_align_resident(wfm_handle_t* h, const wfm_penalties_t* pen, wfm_seqset_t
     if (hi > lo) total += hi - lo;
     return total;
   };
+  h->mem_budget = h->mem_budget_full;
   if (!overlap || n < 8) {
     const int rc = align_resident_impl(h, pen, s, 0, n, out, ops_arena, arena_bytes, 0);
     h->stats.ms_tile_busy = busy_ms(h->tile_iv);
     h->stats.streams = 1;
     return rc;
   }
-  // Two halves of the batch side by side, each with its own stream and arenas (a peer handle on the same
-  // device) and its own host thread: while one half sits in the few-workgroup levels of the step kernel or
-  // waits for the host, the other half's tiles fill the machine.  Problems are independent, the halves only
-  // share the (read-only) sequences and the caller's output buffers.
-  if (!h->peer) {
-    wfm_handle_t* p = nullptr;
-    const int rc = wfm_create(h->device, &p);
-    if (rc != WFM_OK) return align_resident_impl(h, pen, s, 0, n, out, ops_arena, arena_bytes, 0);
-    h->peer = p;
+  // Parts of the batch side by side, each with its own stream and arenas (peer handles on the same device)
+  // and its own host thread: while one part sits in the few-workgroup levels of the step kernel or waits for
+  // the host, the other parts' tiles fill the machine.  Problems are independent, the parts only share the
+  // (read-only) sequences and the caller's output buffers.
+  static const int want = [] { const char* e = getenv("WFM_STREAMS"); return e ? std::max(1, std::min(8, atoi(e))) : 3; }();  // measured: 2 -> 124, 3 -> 120, 4 -> 160 ms on C3
+  // every part needs room for its own arenas: no split below 256 MB per part
+  const size_t parts = std::min<size_t>(std::min<size_t>((size_t)want, n / 4), h->mem_budget_full >> 28);
+  if (parts < 2) {
+    const int rc = align_resident_impl(h, pen, s, 0, n, out, ops_arena, arena_bytes, 0);
+    h->stats.ms_tile_busy = busy_ms(h->tile_iv);
+    h->stats.streams = 1;
+    return rc;
   }
-  // balance the halves by sum of (plen + tlen)^2 (WFA cost), contiguous split
+  while (h->peers.size() + 1 < parts) {
+    wfm_handle_t* p = nullptr;
+    if (wfm_create(h->device, &p) != WFM_OK) break;
+    h->peers.push_back(p);
+  }
+  const size_t np = h->peers.size() + 1;
+  h->mem_budget = h->mem_budget_full / np;  // the parts share the primary handle's budget
+  for (wfm_handle* pk : h->peers) pk->mem_budget = h->mem_budget;
+  // contiguous parts of equal WFA cost, sum of (plen + tlen)^2
   std::vector<double> cost(n + 1, 0.0);
   for (size_t i = 0; i < n; ++i) {
     const double l = (double)s->meta[i].plen + (double)s->meta[i].tlen;
     cost[i + 1] = cost[i] + l * l;
   }
-  size_t mid = 1;
-  while (mid + 1 < n && cost[mid] < cost[n] / 2) ++mid;
-  size_t base_b = 0;
-  for (size_t i = 0; i < mid; ++i) base_b += (size_t)s->meta[i].plen + (size_t)s->meta[i].tlen + 1;
+  std::vector<size_t> cut(np + 1, n);
+  cut[0] = 0;
+  for (size_t k = 1, i = 0; k < np; ++k) {
+    while (i < n && cost[i] < cost[n] * (double)k / (double)np) ++i;
+    cut[k] = std::min(std::max(i, cut[k - 1] + 1), n - (np - k));
+  }
+  std::vector<size_t> base(np, 0);
+  for (size_t k = 1; k < np; ++k) {
+    base[k] = base[k - 1];
+    for (size_t i = cut[k - 1]; i < cut[k]; ++i) base[k] += (size_t)s->meta[i].plen + (size_t)s->meta[i].tlen + 1;
+  }
   const auto t0 = std::chrono::steady_clock::now();
-  int rc_b = 0;
-  h->peer->call_base = h->ev_base;
-  h->peer->tile_iv.clear();
-  std::thread tb([&] { rc_b = align_resident_impl(h->peer, pen, s, mid, n, out, ops_arena, arena_bytes, base_b); });
-  const int rc_a = align_resident_impl(h, pen, s, 0, mid, out, ops_arena, arena_bytes, 0);
-  tb.join();
-  if (rc_b < 0) h->err = h->peer->err;
-  if (rc_a < 0 || rc_b < 0) return rc_a < 0 ? rc_a : rc_b;
-  const wfm_stats_t& b = h->peer->stats;
+  std::vector<int> rcs(np, 0);
+  std::vector<std::thread> th;
+  for (size_t k = 1; k < np; ++k) {
+    wfm_handle* pk = h->peers[k - 1];
+    pk->call_base = h->ev_base;
+    pk->tile_iv.clear();
+    th.emplace_back([&, k, pk] { rcs[k] = align_resident_impl(pk, pen, s, cut[k], cut[k + 1], out, ops_arena, arena_bytes, base[k]); });
+  }
+  rcs[0] = align_resident_impl(h, pen, s, cut[0], cut[1], out, ops_arena, arena_bytes, 0);
+  for (auto& t : th) t.join();
+  int failed = 0;
+  for (size_t k = 0; k < np; ++k) {
+    if (rcs[k] < 0) { if (k) h->err = h->peers[k - 1]->err; return rcs[k]; }
+    failed += rcs[k];
+  }
   wfm_stats_t& a = h->stats;
-  a.cells += b.cells; a.bytes_algorithmic += b.bytes_algorithmic; a.ms_kernels += b.ms_kernels; a.ms_breakpoint += b.ms_breakpoint;
-  a.ms_base += b.ms_base; a.levels = std::max(a.levels, b.levels); a.bp_jobs += b.bp_jobs; a.base_jobs += b.base_jobs;
-  a.bp_launches += b.bp_launches; a.base_launches += b.base_launches; a.cells_bp += b.cells_bp; a.cells_base += b.cells_base;
-  a.cells_tile += b.cells_tile; a.ms_tile += b.ms_tile; a.tile_launches += b.tile_launches; a.tile_tasks += b.tile_tasks;
-  a.ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   std::vector<std::pair<float, float>> iv = h->tile_iv;
-  iv.insert(iv.end(), h->peer->tile_iv.begin(), h->peer->tile_iv.end());
+  for (size_t k = 1; k < np; ++k) {
+    const wfm_stats_t& b = h->peers[k - 1]->stats;
+    a.cells += b.cells; a.bytes_algorithmic += b.bytes_algorithmic; a.ms_kernels += b.ms_kernels; a.ms_breakpoint += b.ms_breakpoint;
+    a.ms_base += b.ms_base; a.levels = std::max(a.levels, b.levels); a.bp_jobs += b.bp_jobs; a.base_jobs += b.base_jobs;
+    a.bp_launches += b.bp_launches; a.base_launches += b.base_launches; a.cells_bp += b.cells_bp; a.cells_base += b.cells_base;
+    a.cells_tile += b.cells_tile; a.ms_tile += b.ms_tile; a.tile_launches += b.tile_launches; a.tile_tasks += b.tile_tasks;
+    iv.insert(iv.end(), h->peers[k - 1]->tile_iv.begin(), h->peers[k - 1]->tile_iv.end());
+  }
+  a.ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   a.ms_tile_busy = busy_ms(iv);
-  a.streams = 2;
-  return rc_a + rc_b;
+  a.streams = (uint32_t)np;
+  return failed;
 }
 
 int wfm_align_batch(wfm_handle_t* h, const wfm_penalties_t* pen, const wfm_problem_t* problems, size_t n,
