@@ -79,7 +79,7 @@ extern "C" int64_t wfm_map_fragments(wfm_handle_t* h, const wfm_index_t* ix, con
   std::vector<uint8_t> act((size_t)nfrag), kc((size_t)nfrag);
   for (int64_t f = 0; f < nfrag; ++f) {
     if (cnt[f] == 0) { act[f] = 0; kc[f] = 0; continue; }
-    const double max_hash_01 = (long double)(last[f]) / std::numeric_limits<uint64_t>::max();
+    const double max_hash_01 = (long double)(last[f]) / (long double)std::numeric_limits<uint64_t>::max();  // host pass: x87 long double
     const float complexity = (double(cnt[f]) / max_hash_01) / ((w - k + 1) * 2);
     act[f] = !(complexity < prm->kmer_complexity_threshold);
     kc[f] = (uint8_t)(int)roundf(complexity * 100.0f);  // MappingResult::setKmerComplexity
