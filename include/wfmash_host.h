@@ -147,6 +147,13 @@ int wfmh_map(wfm_handle_t* h, const char* target_fasta, const char* query_fasta,
 char* wfmh_test_filter(const char* stage, const wfm_mapping_t* maps, int64_t n, const char* fasta,
                        const char* query_name, const wfmh_map_params_t* prm);
 
+/* Test hook for the FASTA reader that stands in for faigz/htslib (src/common/faigz.h:221-505;
+ * random access through .fai, and .gzi for BGZF).  name == NULL: "indexed|in-memory" + one
+ * "name\tlength" line per sequence in file order.  Otherwise bases [start, end_inclusive] of `name`
+ * (faidx_reader_fetch_seq's convention); whole != 0 loads the sequence first, as the map driver does.
+ * malloc'd, wfmh_free; "ERROR: ..." on failure. */
+char* wfmh_test_fasta(const char* path, const char* name, int64_t start, int64_t end_inclusive, int whole);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,133 @@
+"""One rank's share of config C4 (8 haplotypes of a chr1-sized backbone, `-Y '#'`, 8 GPUs) on ONE GPU:
+every rank builds the index of all haplotypes and maps the queries dist.shard_queries gives it, so
+rank r of 8 is a complete dry run of what each GPU of the node does (no exchange step
+besides the gather of PAF text).
+
+The haplotypes are synthetic (real chr1 is not available): one random backbone, per haplotype 0.1 % SNPs,
+0.01 % short indels and 20 structural variants of 10-100 kb (deletion / duplication / inversion).  The
+generator is vectorised numpy (seeded), not the splitmix64 one of C3: 2 Gbp have to be made in seconds.
+
+Usage: python scripts/c4_rank.py [--haps 8] [--mbp 248.956422] [--rank 0] [--world 8] [--pct 0 (auto)]
+Prints one JSON line: sizes, stage times, records written, peak host RSS."""
+import argparse
+import json
+import os
+import resource
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from wfmash_amd import capi, dist  # noqa: E402
+
+ACGT = np.frombuffer(b"ACGT", dtype=np.uint8)
+COMP = np.zeros(256, dtype=np.uint8)
+COMP[ACGT] = np.frombuffer(b"TGCA", dtype=np.uint8)
+
+
+def haplotype(base: np.ndarray, seed: int) -> np.ndarray:
+    rng = np.random.default_rng(seed)
+    s = base.copy()
+    n = len(s)
+    # SNPs: a different base at 0.1 % of the positions
+    pos = rng.integers(0, n, n // 1000)
+    code = np.searchsorted(ACGT, s[pos])  # ACGT is sorted
+    s[pos] = ACGT[(code + rng.integers(1, 4, len(pos))) % 4]
+    # short indels, 0.01 %: half deletions, half insertions of 1 + Geometric(0.5) bases
+    m = n // 10000
+    pos = np.unique(rng.integers(0, n, m))
+    ln = rng.geometric(0.5, len(pos))
+    is_del = rng.random(len(pos)) < 0.5
+    keep = np.ones(n, dtype=bool)
+    for p, l in zip(pos[is_del], ln[is_del]):
+        keep[p:p + l] = False
+    ins_pos = np.repeat(pos[~is_del], ln[~is_del])
+    ins_val = ACGT[rng.integers(0, 4, len(ins_pos))]
+    # np.insert indexes into the ORIGINAL array; deleted bases are removed afterwards through `keep`
+    keep = np.insert(keep, ins_pos, True)
+    s = np.insert(s, ins_pos, ins_val)[keep]
+    # 20 structural variants
+    for _ in range(20):
+        l = int(rng.integers(10_000, 100_001))
+        p = int(rng.integers(0, len(s) - l))
+        kind = int(rng.integers(0, 3))
+        if kind == 0:
+            s = np.concatenate([s[:p], s[p + l:]])
+        elif kind == 1:
+            s = np.concatenate([s[:p + l], s[p:p + l], s[p + l:]])
+        else:
+            s[p:p + l] = COMP[s[p:p + l]][::-1]
+    return s
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--haps", type=int, default=8)
+    ap.add_argument("--mbp", type=float, default=248.956422)
+    ap.add_argument("--rank", type=int, default=0)
+    ap.add_argument("--world", type=int, default=8)
+    ap.add_argument("--pct", type=float, default=0.0, help="identity threshold as a fraction; 0 = estimate (ani50-2)")
+    ap.add_argument("--keep", default="")
+    a = ap.parse_args()
+
+    d = a.keep or tempfile.mkdtemp()
+    fa = os.path.join(d, "c4.fa")
+    t0 = time.time()
+    L = int(a.mbp * 1e6)
+    base = ACGT[np.random.default_rng(0xC4).integers(0, 4, L, dtype=np.uint8)]
+    names, lengths = [], []
+    with open(fa, "wb") as f, open(fa + ".fai", "w") as fai:
+        for h in range(a.haps):
+            s = haplotype(base, 0xC400 + h)
+            name = f"hap{h + 1}#1#chr1"
+            hdr = f">{name}\n".encode()
+            off = f.tell() + len(hdr)
+            f.write(hdr)
+            s.tofile(f)
+            f.write(b"\n")
+            fai.write(f"{name}\t{len(s)}\t{off}\t{len(s)}\t{len(s) + 1}\n")
+            names.append(name)
+            lengths.append(len(s))
+    del base
+    t_gen = time.time() - t0
+
+    mine = [names[i] for i in dist.shard_queries(lengths, a.world)[a.rank]]
+    qlist = os.path.join(d, f"queries.rank{a.rank}.txt")
+    with open(qlist, "w") as f:
+        f.write("\n".join(mine) + "\n")
+    threads = os.cpu_count() or 1
+    over = dict(threads=threads, query_list=qlist)
+    if a.pct:
+        over.update(percentage_identity=a.pct, auto_pct_identity=0)
+    P = capi.map_default_params(**over)
+    h = capi.Handle(0)
+    out = os.path.join(d, f"rank{a.rank}.paf")
+    t0 = time.time()
+    s = capi.map_paf(h, fa, out, params=P)
+    wall = time.time() - t0
+    h.close()
+    # sanity of the output: every record lies inside its sequences and no query maps to its own haplotype
+    bad = 0
+    span = 0
+    ln = dict(zip(names, lengths))
+    with open(out) as f:
+        for line in f:
+            c = line.split("\t")
+            qs, qe, ts, te = int(c[2]), int(c[3]), int(c[7]), int(c[8])
+            span += qe - qs
+            if not (0 <= qs < qe <= ln[c[0]] and 0 <= ts < te <= ln[c[5]]) or c[0].split("#")[0] == c[5].split("#")[0]:
+                bad += 1
+    print(json.dumps({"config": f"C4 rank {a.rank} of {a.world}", "haps": a.haps, "target_bp": int(s.target_bp), "query_bp": int(s.query_bp),
+                      "queries": mine, "threads": threads, "gen_s": round(t_gen, 1), "wall_s": round(wall, 2),
+                      "pct": round(float(s.percentage_identity), 4), "sketch": s.sketch_size, "windows": int(s.index_windows),
+                      "fragments": int(s.fragments), "l2_mappings": int(s.l2_mappings), "written": int(s.written), "bad_records": bad,
+                      "query_span_mapped_per_target": round(span / max(1, int(s.query_bp)) / max(1, a.haps - 1), 4),
+                      "ms_index": round(s.ms_index), "ms_map": round(s.ms_map), "ms_filter": round(s.ms_filter), "ms_total": round(s.ms_total),
+                      "query_mbp_per_s": round(s.query_bp / 1e6 / (s.ms_total / 1e3), 2),
+                      "peak_rss_gb": round(resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1e6, 1)}))
+
+
+if __name__ == "__main__":
+    main()

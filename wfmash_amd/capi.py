@@ -499,7 +499,7 @@ class Handle:
 # host-side align driver (include/wfmash_host.h)
 # ---------------------------------------------------------------------------
 HOST_EXPORTS = ["wfmh_align_default_params", "wfmh_align_paf", "wfmh_test_cigar", "wfmh_free", "wfmh_test_winnow",
-                "wfmh_map_default_params", "wfmh_test_filter", "wfmh_map", "wfmh_test_winnow_chunked"]
+                "wfmh_map_default_params", "wfmh_test_filter", "wfmh_map", "wfmh_test_winnow_chunked", "wfmh_test_fasta"]
 
 
 class MapSummary(C.Structure):
@@ -550,6 +550,24 @@ def map_default_params(**over) -> MapHostParams:
             v = v.encode()
         setattr(p, k, v)
     return p
+
+
+def host_fasta(path: str, name: str = None, start: int = 0, end_inclusive: int = -1, whole: bool = False) -> str:
+    """wfmh_test_fasta: the FASTA reader (random access through .fai/.gzi, or in-memory); no GPU needed.
+    name None -> 'indexed|in-memory' and the name/length table."""
+    L = load()
+    L.wfmh_test_fasta.restype = C.c_void_p
+    L.wfmh_test_fasta.argtypes = [C.c_char_p, C.c_char_p, C.c_int64, C.c_int64, C.c_int]
+    L.wfmh_free.restype = None
+    L.wfmh_free.argtypes = [C.c_void_p]
+    p = L.wfmh_test_fasta(path.encode(), name.encode() if name is not None else None, start, end_inclusive, int(whole))
+    if not p:
+        raise WfmError("wfmh_test_fasta failed")
+    s = C.string_at(p).decode()
+    L.wfmh_free(p)
+    if s.startswith("ERROR: "):
+        raise WfmError(s)
+    return s
 
 
 def host_filter(stage: str, mappings, fasta: str, query_name: str, params: MapHostParams) -> str:

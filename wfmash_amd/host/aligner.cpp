@@ -225,7 +225,7 @@ Summary Aligner::compute() {
   std::ofstream outstream(param.pafOutputFile);
   if (!outstream.is_open()) throw std::runtime_error("[wfmash::align] Error! Failed to open output file: " + param.pafOutputFile);
   if (param.sam_format) {  // write_sam_header (computeAlignments.hpp:725-736)
-    for (int i = 0; i < ref->nseq(); ++i) outstream << "@SQ\tSN:" << ref->name(i) << "\tLN:" << ref->sequence(i).size() << "\n";
+    for (int i = 0; i < ref->nseq(); ++i) outstream << "@SQ\tSN:" << ref->name(i) << "\tLN:" << ref->length(i) << "\n";
     outstream << "@PG\tID:wfmash\tPN:wfmash\tVN:wfmash-hip-r1\tCL:wfmash\n";
   }
   outstream << align_lines(lines, sum);

@@ -6,6 +6,7 @@
 #include "../../include/wfmash_host.h"
 #include "../csrc/wfa_handle.h"
 #include "aligner.hpp"
+#include "fasta.hpp"
 #include "map_stats.hpp"
 
 extern "C" {
@@ -120,6 +121,33 @@ char* wfmh_test_cigar(const char* fn, const char* a, const char* b, const char* 
   }
   char* out = (char*)malloc(r.size() + 1);
   memcpy(out, r.c_str(), r.size() + 1);
+  return out;
+}
+
+char* wfmh_test_fasta(const char* path, const char* name, int64_t start, int64_t end_inclusive, int whole) {
+  std::string r;
+  try {
+    wfmash_host::FastaStore fa(path ? path : "");
+    if (!name) {
+      std::ostringstream os;
+      os << (fa.indexed() ? "indexed" : "in-memory") << "\n";
+      for (int i = 0; i < fa.nseq(); ++i) os << fa.name(i) << "\t" << fa.length(i) << "\n";
+      r = os.str();
+    } else {
+      const int i = fa.find(name);
+      if (i < 0) r = "ERROR: no such sequence";
+      else {
+        if (whole) fa.preload({i}, 2);
+        r = fa.fetch(name, start, end_inclusive);
+      }
+    }
+  } catch (const std::exception& e) {
+    r = std::string("ERROR: ") + e.what();
+  }
+  char* out = (char*)malloc(r.size() + 1);
+  if (!out) return nullptr;
+  memcpy(out, r.data(), r.size());
+  out[r.size()] = 0;
   return out;
 }
 

@@ -1,12 +1,155 @@
 #include "fasta.hpp"
 
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <zlib.h>
 
+#include <algorithm>
+#include <atomic>
+#include <cstring>
+#include <fstream>
+#include <sstream>
 #include <stdexcept>
+#include <thread>
 
 namespace wfmash_host {
 
-FastaStore::FastaStore(const std::string& path) {
+namespace {
+
+void pread_all(int fd, void* dst, size_t n, int64_t off, const std::string& path) {
+  char* p = static_cast<char*>(dst);
+  while (n > 0) {
+    const ssize_t r = pread(fd, p, n, (off_t)off);
+    if (r <= 0) throw std::runtime_error("short read from " + path + " (stale .fai/.gzi?)");
+    p += r; n -= (size_t)r; off += r;
+  }
+}
+
+uint16_t le16(const unsigned char* p) { return (uint16_t)(p[0] | (p[1] << 8)); }
+uint32_t le32(const unsigned char* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
+uint64_t le64(const unsigned char* p) { return (uint64_t)le32(p) | ((uint64_t)le32(p + 4) << 32); }
+
+// A BGZF block is a gzip member whose extra field carries the subfield 'B','C' = total block size - 1
+// (SAM specification, section 4.1).  Returns the block size and where the deflate data begins; 0 if the
+// bytes at `off` are not a BGZF block header.
+int64_t bgzf_block_size(int fd, int64_t off, int64_t file_size, int* data_begin) {
+  unsigned char h[12];
+  if (off + 12 > file_size) return 0;
+  if (pread(fd, h, 12, (off_t)off) != 12) return 0;
+  if (h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || !(h[3] & 4)) return 0;
+  const int xlen = le16(h + 10);
+  if (off + 12 + xlen > file_size) return 0;
+  std::vector<unsigned char> x((size_t)xlen);
+  if (xlen && pread(fd, x.data(), (size_t)xlen, (off_t)(off + 12)) != xlen) return 0;
+  for (int p = 0; p + 4 <= xlen;) {
+    const int slen = le16(x.data() + p + 2);
+    if (x[(size_t)p] == 'B' && x[(size_t)p + 1] == 'C' && slen == 2 && p + 6 <= xlen) {
+      if (data_begin) *data_begin = 12 + xlen;
+      return (int64_t)le16(x.data() + p + 4) + 1;
+    }
+    p += 4 + slen;
+  }
+  return 0;
+}
+
+}  // namespace
+
+FastaStore::FastaStore(const std::string& path) : path_(path) {
+  if (!open_indexed(path)) load_stream(path);
+  for (size_t i = 0; i < names_.size(); ++i) index_.emplace(names_[i], (int)i);  // the first of equal names wins, as in faidx
+}
+
+FastaStore::~FastaStore() {
+  if (fd_ >= 0) close(fd_);
+}
+
+bool FastaStore::open_indexed(const std::string& path) {
+  std::ifstream fai(path + ".fai");
+  if (!fai.is_open()) return false;
+  const int fd = open(path.c_str(), O_RDONLY);
+  if (fd < 0) throw std::runtime_error("cannot open FASTA: " + path);
+  struct stat sb;
+  if (fstat(fd, &sb) != 0) { close(fd); throw std::runtime_error("cannot stat FASTA: " + path); }
+  const int64_t file_size = (int64_t)sb.st_size;
+  unsigned char magic[2] = {0, 0};
+  const bool gz = file_size >= 2 && pread(fd, magic, 2, 0) == 2 && magic[0] == 0x1f && magic[1] == 0x8b;
+  if (gz) {
+    int db = 0;
+    if (bgzf_block_size(fd, 0, file_size, &db) == 0) { close(fd); return false; }  // plain gzip: no random access, stream it
+    // block table: <path>.gzi = u64 count, then (compressed offset, uncompressed offset) of every block but the first
+    std::ifstream gzi(path + ".gzi", std::ios::binary);
+    bool have = false;
+    if (gzi.is_open()) {
+      unsigned char b[16];
+      if (gzi.read(reinterpret_cast<char*>(b), 8)) {
+        const uint64_t n = le64(b);
+        block_coff_.assign(1, 0); block_uoff_.assign(1, 0);
+        have = true;
+        for (uint64_t i = 0; i < n; ++i) {
+          if (!gzi.read(reinterpret_cast<char*>(b), 16)) { have = false; break; }
+          block_coff_.push_back((int64_t)le64(b)); block_uoff_.push_back((int64_t)le64(b + 8));
+        }
+        if (have && (block_coff_.back() >= file_size || !std::is_sorted(block_coff_.begin(), block_coff_.end()))) have = false;
+      }
+    }
+    if (have) {
+      // the text ends after the last data block; an index may or may not list the empty EOF block
+      int64_t off = block_coff_.back(), uoff = block_uoff_.back();
+      while (off < file_size) {
+        const int64_t bs = bgzf_block_size(fd, off, file_size, nullptr);
+        if (bs == 0) { close(fd); throw std::runtime_error("corrupt BGZF block in " + path); }
+        unsigned char t[4];
+        pread_all(fd, t, 4, off + bs - 4, path);
+        off += bs;
+        uoff += le32(t);
+        if (off < file_size) { block_coff_.push_back(off); block_uoff_.push_back(uoff); }
+      }
+      text_size_ = uoff;
+    } else {
+      block_coff_.clear(); block_uoff_.clear();
+      int64_t off = 0, uoff = 0;
+      while (off < file_size) {
+        const int64_t bs = bgzf_block_size(fd, off, file_size, nullptr);
+        if (bs == 0) { close(fd); throw std::runtime_error("corrupt BGZF block in " + path); }
+        unsigned char t[4];
+        pread_all(fd, t, 4, off + bs - 4, path);
+        block_coff_.push_back(off); block_uoff_.push_back(uoff);
+        off += bs;
+        uoff += le32(t);
+      }
+      text_size_ = uoff;
+    }
+    bgzf_ = true;
+  } else {
+    text_size_ = file_size;
+  }
+  std::string line;
+  while (std::getline(fai, line)) {
+    if (line.empty()) continue;
+    std::istringstream is(line);
+    std::string name;
+    int64_t len = 0;
+    FaiEntry e{0, 0, 0};
+    std::getline(is, name, '\t');
+    if (!(is >> len >> e.offset >> e.line_bases >> e.line_width) || len < 0 || e.offset < 0 || e.line_width < e.line_bases ||
+        (len > 0 && e.line_bases <= 0)) {
+      close(fd);
+      throw std::runtime_error("malformed line in " + path + ".fai: " + line);
+    }
+    if (len > 0) {
+      const int64_t last = e.offset + (len - 1) / e.line_bases * e.line_width + (len - 1) % e.line_bases;
+      if (last >= text_size_) { close(fd); throw std::runtime_error(path + ".fai does not match the FASTA (sequence " + name + " ends past the file)"); }
+    }
+    names_.push_back(name); lens_.push_back(len); fai_.push_back(e);
+  }
+  fd_ = fd;
+  seqs_.resize(names_.size());
+  once_.reset(new std::once_flag[names_.size()]);
+  return true;
+}
+
+void FastaStore::load_stream(const std::string& path) {
   gzFile f = gzopen(path.c_str(), "rb");
   if (!f) throw std::runtime_error("cannot open FASTA: " + path);
   gzbuffer(f, 1 << 20);
@@ -16,46 +159,156 @@ FastaStore::FastaStore(const std::string& path) {
   std::string header;
   int n;
   while ((n = gzread(f, buf.data(), (unsigned)buf.size())) > 0) {
-    for (int i = 0; i < n; ++i) {
-      const char c = buf[i];
+    int i = 0;
+    while (i < n) {
       if (in_header) {
-        if (c == '\n') {
+        const char* nl = static_cast<const char*>(memchr(buf.data() + i, '\n', (size_t)(n - i)));
+        const int e = nl ? (int)(nl - buf.data()) : n;
+        header.append(buf.data() + i, (size_t)(e - i));
+        i = e;
+        if (nl) {
+          ++i;
           in_header = false;
           // name = header up to the first whitespace (faidx convention)
-          size_t e = 0;
-          while (e < header.size() && header[e] != ' ' && header[e] != '\t' && header[e] != '\r') ++e;
-          names_.push_back(header.substr(0, e));
+          size_t w = 0;
+          while (w < header.size() && header[w] != ' ' && header[w] != '\t' && header[w] != '\r') ++w;
+          names_.push_back(header.substr(0, w));
           seqs_.emplace_back();
           cur = &seqs_.back();
           header.clear();
-        } else {
-          header.push_back(c);
         }
-      } else if (c == '>') {
+      } else if (buf[(size_t)i] == '>') {
         in_header = true;
-      } else if (c != '\n' && c != '\r') {
-        if (cur) cur->push_back(c);
+        ++i;
+      } else {
+        // a run of sequence bytes up to the end of the line
+        const char* nl = static_cast<const char*>(memchr(buf.data() + i, '\n', (size_t)(n - i)));
+        int e = nl ? (int)(nl - buf.data()) : n;
+        int stop = e;
+        if (stop > i && buf[(size_t)stop - 1] == '\r') --stop;
+        if (cur && stop > i) cur->append(buf.data() + i, (size_t)(stop - i));
+        i = nl ? e + 1 : n;
       }
     }
   }
   gzclose(f);
-  for (size_t i = 0; i < names_.size(); ++i) index_.emplace(names_[i], (int)i);
+  for (const auto& s : seqs_) lens_.push_back((int64_t)s.size());
+}
+
+void FastaStore::read_text(int64_t off, int64_t n, char* dst) const {
+  if (n <= 0) return;
+  if (off < 0 || off + n > text_size_) throw std::runtime_error("read past the end of " + path_);
+  if (!bgzf_) { pread_all(fd_, dst, (size_t)n, off, path_); return; }
+  size_t b = (size_t)(std::upper_bound(block_uoff_.begin(), block_uoff_.end(), off) - block_uoff_.begin()) - 1;
+  std::vector<unsigned char> comp, plain;
+  struct stat sb;
+  fstat(fd_, &sb);
+  while (n > 0) {
+    if (b >= block_coff_.size()) throw std::runtime_error("BGZF block table of " + path_ + " is too short");
+    int db = 0;
+    const int64_t bs = bgzf_block_size(fd_, block_coff_[b], (int64_t)sb.st_size, &db);
+    if (bs == 0) throw std::runtime_error("corrupt BGZF block in " + path_);
+    comp.resize((size_t)bs);
+    pread_all(fd_, comp.data(), (size_t)bs, block_coff_[b], path_);
+    const uint32_t isize = le32(comp.data() + bs - 4);
+    plain.resize(isize);
+    if (isize) {
+      z_stream zs;
+      memset(&zs, 0, sizeof(zs));
+      if (inflateInit2(&zs, -15) != Z_OK) throw std::runtime_error("zlib inflateInit2 failed");
+      zs.next_in = comp.data() + db;
+      zs.avail_in = (uInt)(bs - db - 8);
+      zs.next_out = plain.data();
+      zs.avail_out = isize;
+      const int zr = inflate(&zs, Z_FINISH);
+      inflateEnd(&zs);
+      if (zr != Z_STREAM_END || zs.total_out != isize) throw std::runtime_error("corrupt BGZF block in " + path_);
+    }
+    const int64_t in_block = off - block_uoff_[b];
+    const int64_t take = std::min<int64_t>(n, (int64_t)isize - in_block);
+    if (take > 0) {
+      memcpy(dst, plain.data() + in_block, (size_t)take);
+      dst += take; off += take; n -= take;
+    }
+    ++b;
+  }
+}
+
+void FastaStore::read_bases(int i, int64_t start, int64_t end, std::string& out) const {
+  if (start >= end) return;
+  const FaiEntry& e = fai_[(size_t)i];
+  const int64_t first = e.offset + start / e.line_bases * e.line_width + start % e.line_bases;
+  const int64_t last = e.offset + (end - 1) / e.line_bases * e.line_width + (end - 1) % e.line_bases;  // inclusive
+  // in slices, so that a chromosome does not need a second buffer of its size
+  const int64_t slice = 64ll << 20;
+  std::vector<char> buf;
+  out.reserve(out.size() + (size_t)(end - start));
+  for (int64_t off = first; off <= last; off += slice) {
+    const int64_t n = std::min(slice, last + 1 - off);
+    buf.resize((size_t)n);
+    read_text(off, n, buf.data());
+    // keep the bytes whose position within its line is < line_bases
+    int64_t col = (off - e.offset) % e.line_width;
+    int64_t p = 0;
+    while (p < n) {
+      if (col < e.line_bases) {
+        const int64_t run = std::min(e.line_bases - col, n - p);
+        out.append(buf.data() + p, (size_t)run);
+        p += run; col += run;
+      } else {
+        const int64_t skip = std::min(e.line_width - col, n - p);
+        p += skip; col += skip;
+      }
+      if (col == e.line_width) col = 0;
+    }
+  }
 }
 
 int64_t FastaStore::seq_len(const std::string& name) const {
   auto it = index_.find(name);
-  return it == index_.end() ? -1 : (int64_t)seqs_[it->second].size();
+  return it == index_.end() ? -1 : lens_[(size_t)it->second];
+}
+
+const std::string& FastaStore::sequence(int i) const {
+  if (fd_ >= 0)
+    std::call_once(once_[(size_t)i], [&] {
+      std::string s;
+      read_bases(i, 0, lens_[(size_t)i], s);
+      seqs_[(size_t)i] = std::move(s);
+    });
+  return seqs_[(size_t)i];
+}
+
+void FastaStore::preload(const std::vector<int>& which, int threads) const {
+  if (fd_ < 0) return;
+  std::vector<int> todo = which;
+  if (todo.empty())
+    for (int i = 0; i < nseq(); ++i) todo.push_back(i);
+  // longest first
+  std::sort(todo.begin(), todo.end(), [&](int a, int b) { return lens_[(size_t)a] > lens_[(size_t)b]; });
+  std::atomic<size_t> next{0};
+  auto work = [&] {
+    for (size_t j; (j = next.fetch_add(1)) < todo.size();) sequence(todo[j]);
+  };
+  const int nt = (int)std::min<size_t>((size_t)std::max(1, threads), todo.size());
+  std::vector<std::thread> pool;
+  for (int t = 1; t < nt; ++t) pool.emplace_back(work);
+  work();
+  for (auto& t : pool) t.join();
 }
 
 std::string FastaStore::fetch(const std::string& name, int64_t start, int64_t end_inclusive) const {
   auto it = index_.find(name);
   if (it == index_.end()) return std::string();
-  const std::string& s = seqs_[it->second];
+  const int i = it->second;
   if (start < 0) start = 0;
   int64_t end = end_inclusive + 1;
-  if (end > (int64_t)s.size()) end = (int64_t)s.size();
+  if (end > lens_[(size_t)i]) end = lens_[(size_t)i];
   if (start >= end) return std::string();
-  return s.substr((size_t)start, (size_t)(end - start));
+  if (fd_ < 0 || !seqs_[(size_t)i].empty()) return seqs_[(size_t)i].substr((size_t)start, (size_t)(end - start));
+  std::string out;
+  read_bases(i, start, end, out);
+  return out;
 }
 
 }  // namespace wfmash_host

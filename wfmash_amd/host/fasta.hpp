@@ -1,13 +1,23 @@
-// fasta.hpp -- in-memory FASTA store used by the align driver.
+// fasta.hpp -- FASTA access for the map and align drivers.
 //
-// Replaces the reference's faigz/htslib random access (src/common/faigz.h:221-505,
-// faidx_meta_load / faidx_reader_fetch_seq) for the hot path's needs: sequence
-// names in file order, lengths, and substring fetches.  Plain and gzip/bgzip
-// FASTA are read through zlib (a BGZF file is a series of gzip members).
-// Random access through .fai/.gzi without loading the file is SURVEY 8(f) "next".
+// Replaces the reference's faigz/htslib layer (src/common/faigz.h:221-505: faidx_meta_load,
+// faidx_meta_seq_len, faidx_reader_fetch_seq) with what the hot path needs: sequence names in
+// file order, lengths, and substring fetches.
+//
+// Two modes, chosen per file:
+//  * indexed -- `<path>.fai` exists and the file is plain text or BGZF: nothing is read up front.
+//    fetch() is true random access (pread of the lines that hold the range; for BGZF the blocks
+//    that hold it, found through `<path>.gzi` or, without one, a scan of the block headers);
+//    sequence(i) loads one whole sequence on first use, thread-safe, so callers can load many
+//    side by side (preload()).
+//  * in-memory -- no .fai, or a gzip stream that is not BGZF: the file is read once through zlib.
+//    (htslib would build the .fai here, FAI_CREATE; this reader does not write next to its inputs.)
+// Both modes return identical bytes; tests/test_fasta_cpu.py holds them against each other.
 #pragma once
 
 #include <cstdint>
+#include <memory>
+#include <mutex>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -16,22 +26,48 @@ namespace wfmash_host {
 
 class FastaStore {
  public:
-  // Throws std::runtime_error if the file cannot be read.
+  // Throws std::runtime_error if the file (or a present but unusable index) cannot be read.
   explicit FastaStore(const std::string& path);
+  ~FastaStore();
+  FastaStore(const FastaStore&) = delete;
+  FastaStore& operator=(const FastaStore&) = delete;
+
   int nseq() const { return (int)names_.size(); }
   const std::string& name(int i) const { return names_[i]; }
+  int64_t length(int i) const { return lens_[i]; }
   int64_t seq_len(const std::string& name) const;  // -1 if absent (faidx_meta_seq_len)
   // Bases [start, end_inclusive] of `name` (faigz uses an inclusive end), clamped
   // to the sequence; empty string if absent.
   std::string fetch(const std::string& name, int64_t start, int64_t end_inclusive) const;
-  const std::string& sequence(int i) const { return seqs_[i]; }
+  // The whole sequence; in indexed mode it is read on first use and kept.
+  const std::string& sequence(int i) const;
+  // Reads the listed sequences (all if empty) with up to `threads` readers.
+  void preload(const std::vector<int>& which, int threads) const;
   // index of `name`, -1 if absent
   int find(const std::string& name) const { auto it = index_.find(name); return it == index_.end() ? -1 : it->second; }
+  bool indexed() const { return fd_ >= 0; }
 
  private:
+  struct FaiEntry { int64_t offset, line_bases, line_width; };
+  void load_stream(const std::string& path);
+  bool open_indexed(const std::string& path);
+  // bytes [off, off+n) of the uncompressed file
+  void read_text(int64_t off, int64_t n, char* dst) const;
+  // bases [start, end) of sequence i appended to out
+  void read_bases(int i, int64_t start, int64_t end, std::string& out) const;
+
+  std::string path_;
   std::vector<std::string> names_;
-  std::vector<std::string> seqs_;
+  std::vector<int64_t> lens_;
   std::unordered_map<std::string, int> index_;
+  mutable std::vector<std::string> seqs_;
+  // indexed mode
+  int fd_ = -1;
+  bool bgzf_ = false;
+  std::vector<FaiEntry> fai_;
+  std::vector<int64_t> block_coff_, block_uoff_;  // BGZF: start of each block in the file / in the text
+  int64_t text_size_ = 0;
+  mutable std::unique_ptr<std::once_flag[]> once_;
 };
 
 }  // namespace wfmash_host

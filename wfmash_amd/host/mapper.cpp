@@ -45,6 +45,19 @@ class SequenceSource {
     }
     return nullptr;
   }
+  // indexed files: read the sequences find() will be asked for, side by side
+  void preload(const std::vector<std::string>& files, const std::vector<std::string>& names, int threads) const {
+    std::unordered_map<std::string, bool> seen;
+    for (const auto& f : files) {
+      const auto& st = *stores_.at(f);
+      std::vector<int> which;
+      for (const auto& n : names) {
+        const int i = st.find(n);
+        if (i >= 0 && !seen[n]) { which.push_back(i); seen[n] = true; }
+      }
+      if (!which.empty()) st.preload(which, threads);
+    }
+  }
 
  private:
   std::unordered_map<std::string, std::unique_ptr<wfmash_host::FastaStore>> stores_;
@@ -97,6 +110,8 @@ int Map::mapQuery(MapSummary* summary) {
   SequenceSource src;
   for (const auto& f : P.refSequences) src.add(f);
   for (const auto& f : P.querySequences) src.add(f);
+  src.preload(P.refSequences, targetNames, P.threads);
+  src.preload(P.querySequences, queryNames, P.threads);
 
   // thresholds and tables the kernels take
   DeviceTables T;

@@ -44,7 +44,7 @@ void SequenceIdManager::readIndex(const std::string& fasta, const std::vector<st
     }
   } else {
     wfmash_host::FastaStore fa(fasta);  // throws when unreadable
-    for (int i = 0; i < fa.nseq(); ++i) entries.emplace_back(fa.name(i), (offset_t)fa.sequence(i).size());
+    for (int i = 0; i < fa.nseq(); ++i) entries.emplace_back(fa.name(i), (offset_t)fa.length(i));
   }
   for (const auto& e : entries) {
     const bool prefix_ok = prefixes.empty() || std::any_of(prefixes.begin(), prefixes.end(), [&](const std::string& p) { return starts_with(e.first, p); });
