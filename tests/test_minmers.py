@@ -131,3 +131,30 @@ def test_add_minmers_multi_threaded_chunks_equal_single_calls(gpu, monkeypatch):
     assert len(multi) == len(single)
     for a, b in zip(multi, single):
         assert len(a) == len(b) and a.tobytes() == b.tobytes()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("force", ["1", "2"])
+def test_add_minmers_streamed_replay_paths(force):
+    """failed speculations (1) and the one-stream fall-back (2) fetch their k-mers again from the device:
+    forced for every chunk, in a fresh process (the switch is read once), the output must not change"""
+    import subprocess
+    import sys
+    code = (
+        "import sys; sys.path.insert(0, '.'); sys.path.insert(0, 'tests')\n"
+        "from wfmash_amd import capi\n"
+        "from test_minmers import _chunk_cases\n"
+        "import os\n"
+        "h = capi.Handle(0)\n"
+        "seqs = [s for _, s in _chunk_cases()]\n"
+        "single = [h.add_minmers(sq, 15, 256, 12, i) for i, sq in enumerate(seqs)]\n"
+        "multi = h.add_minmers_multi(seqs, 15, 256, 12, threads=8)\n"
+        "assert all(a.tobytes() == b.tobytes() for a, b in zip(multi, single))\n"
+        "print('same', sum(len(a) for a in multi))\n")
+    env = dict(os.environ, WFM_WINNOW_CHUNK=str(64 * 256), WFM_WINNOW_FORCE=force, WFM_DEBUG="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0 and "same" in r.stdout, r.stderr[-2000:]
+    streamed = [l for l in r.stderr.splitlines() if "streamed through the pinned ring" in l]
+    assert len(streamed) == 1, r.stderr[-2000:]
+    if force == "1":
+        assert "(0 replayed)" not in streamed[0], streamed[0]

@@ -52,4 +52,24 @@ int map_hash_sequence_device(wfm_handle_t* h, const char* seq, int64_t len, int 
 void map_hashed_free(MapHashedSeq* s);
 int map_hashed_fetch(const MapHashedSeq* s, int64_t from, int64_t to, int64_t base_from, int64_t base_to, uint64_t* hash, int8_t* strand,
                      char* norm);
+
+// Pinned staging ring for streaming hashed slices to host workers (minmers.cpp): a slot receives
+//   uint64 hash[to-from] | int8 strand[to-from] | char norm[base_to-base_from]
+// by asynchronous copies on the ring's own stream; map_stage_wait blocks the calling thread until the
+// slot's copies have landed.  The ring is kept with the handle and reused by later calls.
+struct MapStage {
+  int device = 0;
+  int nslots = 0;
+  size_t slot_bytes = 0;
+  char* base = nullptr;
+  hipStream_t stream = nullptr;
+  std::vector<hipEvent_t> ev;
+  char* slot(int i) const { return base + (size_t)i * slot_bytes; }
+};
+inline size_t map_stage_bytes(int64_t nkmers, int64_t nbases) { return (size_t)nkmers * 9 + (size_t)nbases; }
+int map_stage_acquire(wfm_handle_t* h, size_t slot_bytes, int nslots, MapStage** out);
+int map_stage_copy(MapStage* st, int slot, const MapHashedSeq* s, int64_t from, int64_t to, int64_t base_from, int64_t base_to);
+int map_stage_wait(MapStage* st, int slot);
+// the same layout, synchronously, into ordinary memory (the rare replays)
+int map_hashed_fetch_packed(const MapHashedSeq* s, int64_t from, int64_t to, int64_t base_from, int64_t base_to, char* dst);
 #endif

@@ -334,6 +334,68 @@ int map_hashed_fetch(const MapHashedSeq* s, int64_t from, int64_t to, int64_t ba
   return WFM_OK;
 }
 
+namespace {
+void map_stage_destroy(void* p) {
+  MapStage* st = static_cast<MapStage*>(p);
+  (void)hipSetDevice(st->device);
+  for (hipEvent_t e : st->ev) if (e) (void)hipEventDestroy(e);
+  if (st->stream) (void)hipStreamDestroy(st->stream);
+  if (st->base) (void)hipHostFree(st->base);
+  delete st;
+}
+}  // namespace
+
+int map_stage_acquire(wfm_handle_t* h, size_t slot_bytes, int nslots, MapStage** out) {
+  MapStage* st = static_cast<MapStage*>(wfm_attachment(h));
+  if (st && st->slot_bytes >= slot_bytes && st->nslots >= nslots) { *out = st; return WFM_OK; }
+  HIPCHK(h, hipSetDevice(wfm_device(h)));
+  st = new MapStage();
+  st->device = wfm_device(h);
+  st->nslots = nslots;
+  st->slot_bytes = (slot_bytes + 4095) & ~(size_t)4095;
+  hipError_t e = hipHostMalloc((void**)&st->base, st->slot_bytes * (size_t)nslots, hipHostMallocDefault);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&st->stream, hipStreamNonBlocking);
+  st->ev.assign((size_t)nslots, nullptr);
+  for (int i = 0; i < nslots && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&st->ev[(size_t)i], hipEventDisableTiming);
+  if (e != hipSuccess) {
+    map_stage_destroy(st);
+    wfm_set_error(h, std::string("pinned staging ring: ") + hipGetErrorString(e));
+    return e == hipErrorOutOfMemory ? WFM_E_NOMEM : WFM_E_HIP;
+  }
+  wfm_set_attachment(h, st, map_stage_destroy);  // replaces (and frees) a smaller ring
+  *out = st;
+  return WFM_OK;
+}
+
+int map_stage_copy(MapStage* st, int slot, const MapHashedSeq* s, int64_t from, int64_t to, int64_t base_from, int64_t base_to) {
+  const size_t nk = (size_t)std::max<int64_t>(0, to - from), nb = (size_t)std::max<int64_t>(0, base_to - base_from);
+  if (slot < 0 || slot >= st->nslots || nk * 9 + nb > st->slot_bytes) return WFM_E_ARG;
+  if (hipSetDevice(st->device) != hipSuccess) return WFM_E_HIP;
+  char* dst = st->slot(slot);
+  if (nk) {
+    if (hipMemcpyAsync(dst, s->d_hash + from, nk * 8, hipMemcpyDeviceToHost, st->stream) != hipSuccess) return WFM_E_HIP;
+    if (hipMemcpyAsync(dst + nk * 8, s->d_strand + from, nk, hipMemcpyDeviceToHost, st->stream) != hipSuccess) return WFM_E_HIP;
+  }
+  if (nb && hipMemcpyAsync(dst + nk * 9, s->d_norm + base_from, nb, hipMemcpyDeviceToHost, st->stream) != hipSuccess) return WFM_E_HIP;
+  return hipEventRecord(st->ev[(size_t)slot], st->stream) == hipSuccess ? WFM_OK : WFM_E_HIP;
+}
+
+int map_stage_wait(MapStage* st, int slot) {
+  if (hipSetDevice(st->device) != hipSuccess) return WFM_E_HIP;
+  return hipEventSynchronize(st->ev[(size_t)slot]) == hipSuccess ? WFM_OK : WFM_E_HIP;
+}
+
+int map_hashed_fetch_packed(const MapHashedSeq* s, int64_t from, int64_t to, int64_t base_from, int64_t base_to, char* dst) {
+  if (hipSetDevice(s->device) != hipSuccess) return WFM_E_HIP;
+  const size_t nk = (size_t)std::max<int64_t>(0, to - from), nb = (size_t)std::max<int64_t>(0, base_to - base_from);
+  if (nk) {
+    if (hipMemcpy(dst, s->d_hash + from, nk * 8, hipMemcpyDeviceToHost) != hipSuccess) return WFM_E_HIP;
+    if (hipMemcpy(dst + nk * 8, s->d_strand + from, nk, hipMemcpyDeviceToHost) != hipSuccess) return WFM_E_HIP;
+  }
+  if (nb && hipMemcpy(dst + nk * 9, s->d_norm + base_from, nb, hipMemcpyDeviceToHost) != hipSuccess) return WFM_E_HIP;
+  return WFM_OK;
+}
+
 // wfm_hash_kmers; norm_out (optional, len bytes) receives the upper-cased / N-masked sequence the
 // hashes were computed from, for callers that go on working on the host (minmers.cpp)
 int wfm_hash_kmers_norm(wfm_handle_t* h, const char* seq, int64_t len, int k, uint64_t* hash, int8_t* strand, char* norm_out) {

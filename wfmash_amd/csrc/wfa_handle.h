@@ -8,4 +8,7 @@
 hipStream_t wfm_stream(wfm_handle_t* h);
 int wfm_device(const wfm_handle_t* h);
 void wfm_set_error(wfm_handle_t* h, const std::string& msg);
+// one object another translation unit keeps with the handle; destroyed with it
+void* wfm_attachment(wfm_handle_t* h);
+void wfm_set_attachment(wfm_handle_t* h, void* p, void (*destroy)(void*));
 #endif

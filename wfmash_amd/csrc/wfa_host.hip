@@ -114,6 +114,8 @@ struct wfm_handle {
   DevBuf<int64_t> i64a, i64b, i64c;
   DevBuf<int32_t> i32a;
   DevBuf<unsigned long long> total;
+  void* attachment = nullptr;  // owned by another translation unit (map_kernels.hip: the pinned staging ring)
+  void (*attachment_free)(void*) = nullptr;
 };
 
 namespace {
@@ -725,6 +727,7 @@ void wfm_destroy(wfm_handle_t* h) {
   if (h->ev3) (void)hipEventDestroy(h->ev3);
   for (auto& e : h->tile_ev) if (e) (void)hipEventDestroy(e);
   if (h->ev_base) (void)hipEventDestroy(h->ev_base);
+  if (h->attachment && h->attachment_free) h->attachment_free(h->attachment);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
 }
@@ -918,3 +921,9 @@ int wfm_get_stats(const wfm_handle_t* h, wfm_stats_t* out) {
 hipStream_t wfm_stream(wfm_handle_t* h) { return h->stream; }
 int wfm_device(const wfm_handle_t* h) { return h->device; }
 void wfm_set_error(wfm_handle_t* h, const std::string& msg) { h->err = msg; }
+void* wfm_attachment(wfm_handle_t* h) { return h->attachment; }
+void wfm_set_attachment(wfm_handle_t* h, void* p, void (*destroy)(void*)) {
+  if (h->attachment && h->attachment_free && h->attachment != p) h->attachment_free(h->attachment);
+  h->attachment = p;
+  h->attachment_free = destroy;
+}

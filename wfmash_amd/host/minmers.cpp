@@ -18,6 +18,12 @@
 // popped, it can never be chosen -- see advance().)  Intervals that are open across a boundary
 // get their true start from the previous chunk when the chunks are stitched.
 //
+// Data movement.  The hashes of a sequence (10 B per base with strands and the normalised bases) stay
+// on the device; a streaming thread copies them chunk by chunk into a small ring of pinned slots
+// (asynchronous, link speed), a worker takes a slot's bytes into its own reused buffer and winnows from
+// there.  The host never holds whole-sequence arrays -- that form (20 GB of fresh pages for 2 Gbp, a
+// pageable copy at a few GB/s) used to be most of the index time.  A replay fetches its chunk again.
+//
 // State (names follow the roles, not the reference's identifiers):
 //   arrivals  every valid k-mer still inside (or lingering behind) the window, arrival order
 //   sketch    ordered map hash -> open interval + occurrences: the <= s smallest hashes
@@ -89,20 +95,30 @@ inline bool pool_after(const PoolItem& a, const PoolItem& b) {  // min-heap on (
 
 constexpr int64_t kUnknownStart = std::numeric_limits<int64_t>::min();  // start of an interval opened before the chunk
 
-// seq: upper-cased / N-masked bases; hash/strand: canonical hash and strand per k-mer start as
+// What a stream reads of its sequence: k-mer starts [kmer0, ...) and bases [base0, ...).
+// norm: upper-cased / N-masked bases; hash/strand: canonical hash and strand per k-mer start as
 // wfm_hash_kmers returns them (strand 0 = contains N or palindromic).
+struct Slice {
+  const uint64_t* hash = nullptr;
+  const int8_t* strand = nullptr;
+  const char* norm = nullptr;
+  int64_t kmer0 = 0, base0 = 0;
+};
+
 class Winnower {
  public:
-  Winnower(const char* seq, int64_t len, int k, int w, int s, int32_t seq_id, const uint64_t* hash, const int8_t* strand)
-      : seq_(seq), len_(len), k_(k), w_(w), s_(s), seq_id_(seq_id), dev_hash_(hash), dev_strand_(strand), rc_((size_t)k) {}
+  Winnower(const Slice& d, int64_t len, int k, int w, int s, int32_t seq_id)
+      : d_(d), len_(len), k_(k), w_(w), s_(s), seq_id_(seq_id), rc_((size_t)k) {}
 
   std::vector<wfm_minmer_t> out;  // raw interval records in emission order
 
   // the stream for k-mer starts [from, to)
   void advance(int64_t from, int64_t to) {
     const int k = k_, w = w_, s = s_;
-    const char* seq = seq_;
+    const int64_t k0 = d_.kmer0, b0 = d_.base0;
+    const char* norm = d_.norm;
     for (int64_t i = from; i < to; ++i) {
+      const char* seq = norm + (i - b0);  // the k-mer's bases: seq[0..k)
       const int64_t win = i + k - w;  // id of the window that ends with this k-mer
       if (pool_.size() > (size_t)2 * (size_t)w) {
         pool_.erase(std::remove_if(pool_.begin(), pool_.end(), [win](const PoolItem& p) { return p.pos < win; }), pool_.end());
@@ -112,17 +128,17 @@ class Winnower {
       // (NOTE: no initial scan, commonFunc.hpp:473: an N inside the first k-1 bases of the sequence
       //  is only seen when it is the LAST base of a k-mer)
       uint64_t hf_min; int16_t strand; bool asym;
-      if (dev_strand_[i] != 0) { hf_min = dev_hash_[i]; strand = dev_strand_[i]; asym = true; }
+      if (d_.strand[i - k0] != 0) { hf_min = d_.hash[i - k0]; strand = d_.strand[i - k0]; asym = true; }
       else {
         bool has_n = false;
-        for (int j = 0; j < k; ++j) has_n |= seq[i + j] == 'N';
+        for (int j = 0; j < k; ++j) has_n |= seq[j] == 'N';
         if (!has_n) { asym = false; hf_min = 0; strand = 0; }  // hashFwd == hashBwd
         else {
           for (int j = 0; j < k; ++j) {
-            const char c = seq[i + j];
+            const char c = seq[j];
             rc_[(size_t)(k - 1 - j)] = (uint8_t)(c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : c == 'T' ? 'A' : c);
           }
-          const uint64_t hf = murmur_lo((const uint8_t*)seq + i, k, 42u), hb = murmur_lo(rc_.data(), k, 42u);
+          const uint64_t hf = murmur_lo((const uint8_t*)seq, k, 42u), hb = murmur_lo(rc_.data(), k, 42u);
           asym = hf != hb; hf_min = std::min(hf, hb); strand = hf < hb ? 1 : -1;
         }
       }
@@ -152,7 +168,7 @@ class Winnower {
         }
         arrivals_.pop_front();
       }
-      if (seq[i + k - 1] == 'N') ambig_ = k;
+      if (seq[k - 1] == 'N') ambig_ = k;
       if (asym && ambig_ == 0) {
         arrivals_.emplace_back(hf_min, strand, i);
         auto it = sketch_.find(hf_min);
@@ -266,12 +282,10 @@ class Winnower {
   }
 
  private:
-  const char* seq_;
+  Slice d_;
   int64_t len_;
   int k_, w_, s_;
   int32_t seq_id_;
-  const uint64_t* dev_hash_;
-  const int8_t* dev_strand_;
   std::deque<std::tuple<uint64_t, int16_t, int64_t>> arrivals_;
   std::map<uint64_t, Open> sketch_;
   std::vector<PoolItem> pool_;
@@ -312,7 +326,7 @@ void normalise(char* p, int64_t n) {  // makeUpperCaseAndValidDNA (commonFunc.hp
 // the whole sequence as one stream
 void winnow(const char* seq, int64_t len, int k, int w, int s, int32_t seq_id, const uint64_t* hash, const int8_t* strand,
             std::vector<wfm_minmer_t>& out) {
-  Winnower W(seq, len, k, w, s, seq_id, hash, strand);
+  Winnower W(Slice{hash, strand, seq, 0, 0}, len, k, w, s, seq_id);
   W.advance(0, len - k + 1);
   W.flush_end();
   out = std::move(W.out);
@@ -325,6 +339,8 @@ struct SeqJob {
   int32_t seq_id = 0;
   int64_t len = 0, nk = 0;
   int k = 0, w = 0, s = 0;
+  // whole-sequence host arrays: only when the sequence is winnowed from ordinary memory (one stream
+  // per sequence, the test hooks, the fall-back in stitch()); the streamed form never holds them
   std::unique_ptr<char[]> norm;
   std::unique_ptr<uint64_t[]> hash;
   std::unique_ptr<int8_t[]> strand;
@@ -333,30 +349,22 @@ struct SeqJob {
   std::vector<Winnower::Live> started_from;             // live state chunk j began with (j >= 1)
   std::atomic<int> pending{0};
   int replays = 0;
+  int fetch_rc = WFM_OK;
   std::vector<wfm_minmer_t> result;
-  // The hashes stay on the device until the host arrays are resident: a device-to-host copy into
-  // freshly allocated memory spends its time in page faults, not on PCIe, so the workers first-touch
-  // the arrays slice by slice in parallel and the feeding thread then copies at link speed.
-  MapHashedSeq dev;
+  MapHashedSeq dev;          // the hashed sequence on the device: the source of every slice
   bool on_device = false;
-  std::atomic<int> touched{0};
 
-  // chunk j's slice of the host arrays: k-mer starts [bounds[j], bounds[j+1]) and the bases from k-1
-  // past its first k-mer start to k-1 past its last (chunk 0 from base 0): every byte has one writer
-  void touch(size_t j) {
-    const size_t n = bounds.size() - 1;
-    const int64_t base_from = j == 0 ? 0 : bounds[j] + k - 1;
-    const int64_t base_to = j + 1 == n ? len : bounds[j + 1] + k - 1;
-    memset(hash.get() + bounds[j], 0, (size_t)(bounds[j + 1] - bounds[j]) * 8);
-    memset(strand.get() + bounds[j], 0, (size_t)(bounds[j + 1] - bounds[j]));
-    if (base_to > base_from) memset(norm.get() + base_from, 0, (size_t)(base_to - base_from));
-    touched.fetch_add(1, std::memory_order_release);
+  Slice whole() const { return Slice{hash.get(), strand.get(), norm.get(), 0, 0}; }
+  int64_t warm_from(size_t j) const { return j > 0 ? std::max<int64_t>(0, bounds[j] - 2 * (int64_t)w) : 0; }
+  // what chunk j reads: k-mer starts [kf, kt) (two windows of warm-up first) and their bases [kf, bt)
+  void chunk_range(size_t j, int64_t* kf, int64_t* kt, int64_t* bt) const {
+    *kf = warm_from(j); *kt = bounds[j + 1]; *bt = bounds[j + 1] + k - 1;
   }
 
   void plan(int64_t chunk_len) {
     bounds.assign(1, 0);
-    // a chunk must dwarf its two-window warm-up; short sequences stay one stream
-    if (chunk_len >= 64 * (int64_t)w && nk > 2 * chunk_len)
+    // a chunk must dwarf its two-window warm-up; no chunk is longer than 1.5 x chunk_len
+    if (chunk_len >= 64 * (int64_t)w && nk > chunk_len + chunk_len / 2)
       for (int64_t b = chunk_len; b + chunk_len / 2 < nk; b += chunk_len) bounds.push_back(b);
     bounds.push_back(nk);
     const size_t n = bounds.size() - 1;
@@ -364,11 +372,10 @@ struct SeqJob {
     started_from.resize(n);
     pending.store((int)n);
   }
-  void run_chunk(size_t j) {
-    const int64_t warm_from = j > 0 ? std::max<int64_t>(0, bounds[j] - 2 * (int64_t)w) : 0;
-    auto W = std::make_unique<Winnower>(norm.get(), len, k, w, s, seq_id, hash.get(), strand.get());
+  void run_chunk(size_t j, const Slice& d) {
+    auto W = std::make_unique<Winnower>(d, len, k, w, s, seq_id);
     if (j > 0) {
-      W->advance(warm_from, bounds[j]);  // warm-up: records are not this chunk's
+      W->advance(warm_from(j), bounds[j]);  // warm-up: records are not this chunk's
       W->out.clear();
       W->mark_open_unknown();
       started_from[j] = W->live_state(bounds[j]);
@@ -376,24 +383,46 @@ struct SeqJob {
     W->advance(bounds[j], bounds[j + 1]);
     chunk[j] = std::move(W);
   }
+  // the packed slice layout of map_device.h in `buf`
+  static Slice packed(const char* buf, int64_t kf, int64_t kt) {
+    const size_t n = (size_t)(kt - kf);
+    return Slice{reinterpret_cast<const uint64_t*>(buf), reinterpret_cast<const int8_t*>(buf + n * 8), buf + n * 9, kf, kf};
+  }
+  // k-mer starts [kf, kt) with their bases, from the host arrays or (streamed form) from the device
+  Slice refetch(int64_t kf, int64_t kt, std::vector<char>& buf) {
+    if (hash) return whole();
+    buf.resize(map_stage_bytes(kt - kf, kt - kf + k - 1));
+    const int rc = map_hashed_fetch_packed(&dev, kf, kt, kf, kt + k - 1, buf.data());
+    if (rc != WFM_OK) { fetch_rc = rc; memset(buf.data(), 0, buf.size()); }
+    return packed(buf.data(), kf, kt);
+  }
   // sequential: check every speculation against the state the previous chunk really reached
   void stitch() {
-    int64_t expired = 0;
+    // WFM_WINNOW_FORCE (tests): 1 = treat every speculation as failed, 2 = take the one-stream fall-back
+    static const int force = [] { const char* e = getenv("WFM_WINNOW_FORCE"); return e ? atoi(e) : 0; }();
+    int64_t expired = force == 2 ? 1 : 0;
     for (const auto& c : chunk) expired += c->expired_in_refill();
+    std::vector<char> buf;
     if (chunk.size() > 1 && expired > 0) {
       // an expired pool entry took part in a refill: the chunks' histories of expired entries differ
       // from the single stream's, so only the single stream is trusted
       chunk.clear();
       started_from.clear();
       replays = -1;
-      winnow(norm.get(), len, k, w, s, seq_id, hash.get(), strand.get(), result);
+      const Slice d = refetch(0, nk, buf);
+      Winnower W(d, len, k, w, s, seq_id);
+      W.advance(0, nk);
+      W.flush_end();
+      result = std::move(W.out);
+      finish_records(result, w);
       norm.reset(); hash.reset(); strand.reset();
       return;
     }
     for (size_t j = 1; j < chunk.size(); ++j) {
       const Winnower& prev = *chunk[j - 1];
-      if (!(started_from[j] == prev.live_state(bounds[j]))) {
-        auto R = std::make_unique<Winnower>(norm.get(), len, k, w, s, seq_id, hash.get(), strand.get());
+      if (force == 1 || !(started_from[j] == prev.live_state(bounds[j]))) {
+        const Slice d = refetch(bounds[j], bounds[j + 1], buf);
+        auto R = std::make_unique<Winnower>(d, len, k, w, s, seq_id);
         R->take_state(prev);
         R->advance(bounds[j], bounds[j + 1]);
         chunk[j] = std::move(R);
@@ -416,7 +445,7 @@ struct SeqJob {
 
 int64_t chunk_length() {
   const char* e = getenv("WFM_WINNOW_CHUNK");  // k-mers per speculative chunk; 0 = one stream per sequence
-  return e ? atoll(e) : (int64_t)1 << 20;
+  return e ? atoll(e) : (int64_t)1 << 18;
 }
 
 }  // namespace
@@ -427,25 +456,45 @@ extern "C" int64_t wfm_add_minmers(wfm_handle_t* h, const char* seq, int64_t len
   return wfm_add_minmers_multi(h, seqs, &len, &seq_id, 1, k, w, s, 1, out, cap, nullptr);
 }
 
-// Many sequences at once: the calling thread feeds the GPU (one hashing pass per sequence) while
-// `threads` host workers winnow what has been hashed -- sequences side by side (the reference's
-// ThreadPool over buildHelper, winSketch.hpp:200-239) and, within a long sequence, its
-// speculative chunks.  Output is the concatenation in input order.
+// Many sequences at once.  The calling thread hashes one sequence after the other on the GPU; the
+// hashes stay there.  A second thread streams them out chunk by chunk through a small ring of pinned
+// slots (asynchronous copies at link speed, no page faults); `threads` host workers take a slot's
+// bytes into their own reused buffer, hand the slot back and winnow the chunk -- sequences side by
+// side (the reference's ThreadPool over buildHelper, winSketch.hpp:200-239) and, within a long
+// sequence, its speculative chunks.  The host never holds more than one chunk per worker.
+// Output is the concatenation in input order.
 extern "C" int64_t wfm_add_minmers_multi(wfm_handle_t* h, const char* const* seqs, const int64_t* lens, const int32_t* seq_ids, int64_t nseq,
                                          int k, int w, int s, int threads, wfm_minmer_t* out, int64_t cap, int64_t* counts) {
   if (!h || nseq < 0 || (nseq && (!seqs || !lens || !seq_ids)) || (cap && !out)) return WFM_E_ARG;
   if (k < 1 || k > 32 || w < k || s < 1) { wfm_set_error(h, "need 1 <= k <= 32, w >= k, s >= 1"); return WFM_E_UNSUPPORTED; }
-  std::vector<std::unique_ptr<SeqJob>> jobs((size_t)nseq);
-  struct Task { SeqJob* job; size_t chunk; bool touch; };
-  std::deque<Task> queue;
-  std::mutex mu;
-  std::condition_variable cv_work, cv_room;
-  bool done = false;
-  int64_t inflight_bases = 0;
-  const int64_t max_inflight = 1ll << 31;  // ~2 Gbp of hashed-but-not-winnowed sequence (10 B/base host, 10 B/base device)
   const int nthreads = std::max(1, threads);
   const int64_t chunk_len = nthreads > 1 ? chunk_length() : 0;
+  const bool streamed = chunk_len >= 64 * (int64_t)w;  // otherwise: whole sequences through ordinary memory
+  MapStage* stage = nullptr;
+  const int64_t slot_kmers = chunk_len + chunk_len / 2 + 2 * (int64_t)w + 1;
+  const size_t slot_bytes = map_stage_bytes(slot_kmers, slot_kmers + k);
+  const int nslots = 16;
+  if (streamed) {
+    const int src = map_stage_acquire(h, slot_bytes, nslots, &stage);
+    if (src != WFM_OK) return src;
+  }
+
+  std::vector<std::unique_ptr<SeqJob>> jobs((size_t)nseq);
+  struct Task { SeqJob* job; size_t chunk; int slot; };
+  std::deque<Task> queue;       // for the workers
+  std::deque<SeqJob*> hashed;   // for the streaming thread
+  std::vector<int> free_slots;
+  for (int i = 0; i < (streamed ? stage->nslots : 0); ++i) free_slots.push_back(i);
+  std::vector<SeqJob*> stitched;  // device arrays to release (done by the calling thread)
+  std::mutex mu;
+  std::condition_variable cv_work, cv_room, cv_slot, cv_hashed;
+  bool done = false, hashed_done = false;
+  std::atomic<int> async_rc{WFM_OK};
+  int64_t inflight_bases = 0;
+  const int64_t max_inflight = 1ll << 31;  // ~2 Gbp hashed but not yet winnowed: 10 B/base on the device
+
   auto worker = [&]() {
+    std::vector<char> local;
     for (;;) {
       Task task;
       {
@@ -456,93 +505,152 @@ extern "C" int64_t wfm_add_minmers_multi(wfm_handle_t* h, const char* const* seq
         queue.pop_front();
       }
       SeqJob* J = task.job;
-      if (task.touch) { J->touch(task.chunk); continue; }
-      J->run_chunk(task.chunk);
+      Slice d = J->whole();
+      if (task.slot >= 0) {
+        int64_t kf, kt, bt;
+        J->chunk_range(task.chunk, &kf, &kt, &bt);
+        const size_t nbytes = map_stage_bytes(kt - kf, bt - kf);
+        if (local.size() < nbytes) local.resize(std::max(nbytes, stage->slot_bytes));
+        const int wrc = map_stage_wait(stage, task.slot);
+        if (wrc == WFM_OK) memcpy(local.data(), stage->slot(task.slot), nbytes);
+        else { memset(local.data(), 0, nbytes); async_rc.store(wrc); }
+        {
+          std::lock_guard<std::mutex> lk(mu);
+          free_slots.push_back(task.slot);
+        }
+        cv_slot.notify_one();
+        d = SeqJob::packed(local.data(), kf, kt);
+      }
+      J->run_chunk(task.chunk, d);
       if (J->pending.fetch_sub(1) == 1) {  // last chunk of this sequence: stitch here
         J->stitch();
+        if (J->fetch_rc != WFM_OK) async_rc.store(J->fetch_rc);
         {
           std::lock_guard<std::mutex> lk(mu);
           inflight_bases -= J->len;
+          stitched.push_back(J);
         }
         cv_room.notify_one();
       }
     }
   };
-  std::vector<std::thread> pool;
-  for (int t = 0; t < nthreads; ++t) pool.emplace_back(worker);
-  int rc = WFM_OK;
-  const auto t_start = std::chrono::steady_clock::now();
-  double ms_hash = 0, ms_copy = 0;
-  // Waves: (1) hash a wave of sequences on the GPU, results stay there; (2) the workers first-touch
-  // the host arrays, slice by slice; (3) this thread -- the only one that talks to the GPU -- copies
-  // each sequence over as soon as its arrays are resident and releases its chunks for winnowing.
-  std::vector<SeqJob*> wave;
-  int64_t wave_bases = 0;
-  const int64_t wave_limit = 1ll << 29;
-  auto release_wave = [&]() {
-    if (wave.empty()) return;
+  // streams the chunks of every hashed sequence into the ring, in order
+  auto streamer = [&]() {
+    for (;;) {
+      SeqJob* J;
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        cv_hashed.wait(lk, [&] { return hashed_done || !hashed.empty(); });
+        if (hashed.empty()) break;
+        J = hashed.front();
+        hashed.pop_front();
+      }
+      for (size_t c = 0; c + 1 < J->bounds.size(); ++c) {
+        int slot;
+        {
+          std::unique_lock<std::mutex> lk(mu);
+          cv_slot.wait(lk, [&] { return !free_slots.empty(); });
+          slot = free_slots.back();
+          free_slots.pop_back();
+        }
+        int64_t kf, kt, bt;
+        J->chunk_range(c, &kf, &kt, &bt);
+        const int crc = map_stage_copy(stage, slot, &J->dev, kf, kt, kf, bt);
+        if (crc != WFM_OK) async_rc.store(crc);  // the worker still runs (on whatever the slot holds): keeps the bookkeeping simple
+        {
+          std::lock_guard<std::mutex> lk(mu);
+          queue.push_back(Task{J, c, slot});
+        }
+        cv_work.notify_one();
+      }
+    }
     {
-      std::unique_lock<std::mutex> lk(mu);
-      cv_room.wait(lk, [&] { return inflight_bases == 0 || inflight_bases + wave_bases <= max_inflight; });
-      inflight_bases += wave_bases;
-      for (SeqJob* Jp : wave)
-        for (size_t c = 0; c + 1 < Jp->bounds.size(); ++c) queue.push_back(Task{Jp, c, true});
+      std::lock_guard<std::mutex> lk(mu);
+      done = true;
     }
     cv_work.notify_all();
-    for (SeqJob* Jp : wave) {
-      const int nchunks = (int)Jp->bounds.size() - 1;
-      while (Jp->touched.load(std::memory_order_acquire) < nchunks) std::this_thread::yield();
-      const auto t0 = std::chrono::steady_clock::now();
-      const int crc = map_hashed_fetch(&Jp->dev, 0, Jp->nk, 0, Jp->len, Jp->hash.get(), Jp->strand.get(), Jp->norm.get());
-      map_hashed_free(&Jp->dev);
-      Jp->on_device = false;
-      ms_copy += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-      if (crc != WFM_OK && rc == WFM_OK) { rc = crc; wfm_set_error(h, "device-to-host copy of k-mer hashes failed"); }
-      {
-        std::lock_guard<std::mutex> lk(mu);
-        for (int c = 0; c < nchunks; ++c) queue.push_back(Task{Jp, (size_t)c, false});  // winnowed even after an error: keeps the bookkeeping simple
-      }
-      cv_work.notify_all();
-    }
-    wave.clear();
-    wave_bases = 0;
   };
+  auto release_stitched = [&]() {
+    std::vector<SeqJob*> list;
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      list.swap(stitched);
+    }
+    for (SeqJob* J : list)
+      if (J->on_device) { map_hashed_free(&J->dev); J->on_device = false; }
+  };
+
+  std::vector<std::thread> pool;
+  for (int t = 0; t < nthreads; ++t) pool.emplace_back(worker);
+  std::thread stream_thread;
+  if (streamed) stream_thread = std::thread(streamer);
+  int rc = WFM_OK;
+  const auto t_start = std::chrono::steady_clock::now();
+  double ms_hash = 0;
   for (int64_t i = 0; i < nseq && rc == WFM_OK; ++i) {
     const int64_t len = lens[i];
     if (!seqs[i] || len < 0) { rc = WFM_E_ARG; break; }
     if (len < k) continue;
+    {
+      std::unique_lock<std::mutex> lk(mu);
+      cv_room.wait(lk, [&] { return inflight_bases == 0 || inflight_bases + len <= max_inflight; });
+      inflight_bases += len;
+    }
+    release_stitched();
     auto J = std::make_unique<SeqJob>();
     J->idx = i; J->seq_id = seq_ids[i]; J->len = len; J->nk = len - k + 1; J->k = k; J->w = w; J->s = s;
-    J->norm.reset(new char[(size_t)len]);
-    J->hash.reset(new uint64_t[(size_t)J->nk]);
-    J->strand.reset(new int8_t[(size_t)J->nk]);
     const auto t0 = std::chrono::steady_clock::now();
     rc = map_hash_sequence_device(h, seqs[i], len, k, &J->dev);  // GPU: normalise + 2 x MurmurHash3 per base
     if (rc != WFM_OK) break;
     J->on_device = true;
     ms_hash += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    J->plan(chunk_len);
-    wave.push_back(J.get());
-    wave_bases += len;
+    J->plan(streamed ? chunk_len : 0);
+    SeqJob* Jp = J.get();
     jobs[(size_t)i] = std::move(J);
-    if (wave_bases >= wave_limit) release_wave();
+    if (streamed) {
+      {
+        std::lock_guard<std::mutex> lk(mu);
+        hashed.push_back(Jp);
+      }
+      cv_hashed.notify_one();
+    } else {
+      Jp->norm.reset(new char[(size_t)len]);
+      Jp->hash.reset(new uint64_t[(size_t)Jp->nk]);
+      Jp->strand.reset(new int8_t[(size_t)Jp->nk]);
+      rc = map_hashed_fetch(&Jp->dev, 0, Jp->nk, 0, len, Jp->hash.get(), Jp->strand.get(), Jp->norm.get());
+      map_hashed_free(&Jp->dev);
+      Jp->on_device = false;
+      if (rc != WFM_OK) { wfm_set_error(h, "device-to-host copy of k-mer hashes failed"); break; }
+      {
+        std::lock_guard<std::mutex> lk(mu);
+        queue.push_back(Task{Jp, 0, -1});
+      }
+      cv_work.notify_one();
+    }
   }
-  release_wave();
   {
     std::lock_guard<std::mutex> lk(mu);
-    done = true;
+    hashed_done = true;
+    if (!streamed) done = true;
   }
+  cv_hashed.notify_all();
   cv_work.notify_all();
   const auto t_fed = std::chrono::steady_clock::now();
+  if (stream_thread.joinable()) stream_thread.join();
   for (auto& t : pool) t.join();
+  release_stitched();
+  for (auto& J : jobs)
+    if (J && J->on_device) { map_hashed_free(&J->dev); J->on_device = false; }  // after an error
   if (getenv("WFM_DEBUG")) {
     int64_t nchunks = 0, replays = 0;
     for (const auto& J : jobs)
       if (J) { nchunks += (int64_t)J->bounds.size() - 1; replays += J->replays; }
-    fprintf(stderr, "[wfm] add_minmers_multi: %lld sequences in %lld chunks (%lld replayed), %d workers: feeding %.1f ms (GPU hashing %.1f, D2H %.1f), drain %.1f ms\n",
-            (long long)nseq, (long long)nchunks, (long long)replays, nthreads, std::chrono::duration<double, std::milli>(t_fed - t_start).count(),
-            ms_hash, ms_copy, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_fed).count());
+    fprintf(stderr, "[wfm] add_minmers_multi: %lld sequences in %lld chunks (%lld replayed), %d workers, %s: hashing thread %.1f ms (GPU hashing %.1f), drain %.1f ms\n",
+            (long long)nseq, (long long)nchunks, (long long)replays, nthreads, streamed ? "streamed through the pinned ring" : "whole sequences",
+            std::chrono::duration<double, std::milli>(t_fed - t_start).count(), ms_hash,
+            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_fed).count());
   }
+  if (rc == WFM_OK && async_rc.load() != WFM_OK) { rc = async_rc.load(); wfm_set_error(h, "device-to-host streaming of k-mer hashes failed"); }
   if (rc != WFM_OK) return rc;
   int64_t total = 0;
   for (int64_t i = 0; i < nseq; ++i) {
@@ -574,7 +682,7 @@ extern "C" int64_t wfmh_test_winnow_chunked(const char* seq, int64_t len, int k,
   J.bounds.push_back(J.nk);
   J.chunk.resize(J.bounds.size() - 1);
   J.started_from.resize(J.bounds.size() - 1);
-  for (size_t c = 0; c + 1 < J.bounds.size(); ++c) J.run_chunk(c);
+  for (size_t c = 0; c + 1 < J.bounds.size(); ++c) J.run_chunk(c, J.whole());
   J.stitch();
   if (replays) *replays = J.replays;
   const int64_t n = (int64_t)J.result.size();
