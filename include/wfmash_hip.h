@@ -21,6 +21,7 @@
  *     wfm_sketch_fragments  <- CommonFunc::sketchSequence, commonFunc.hpp:218-323
  *                              via MappingCore::getSeedHits, mappingCore.hpp:62-76
  *     wfm_add_minmers[_multi] <- CommonFunc::addMinmers, commonFunc.hpp:440-708
+ *     wfm_prefilter_kmers   <- (no counterpart: the device-side thinning of addMinmers' input stream)
  *     wfm_index_build       <- Sketch::build (index stage), winSketch.hpp:266-429
  *     wfm_map_l1            <- getSeedIntervalPoints + computeL1CandidateRegions, mappingCore.hpp:82-301
  *     wfm_map_l2            <- computeL2MappedRegions + SlideMapper + doL2Mapping,
@@ -209,6 +210,14 @@ int64_t wfm_add_minmers(wfm_handle_t* h, const char* seq, int64_t len, int k, in
  * cap; only cap are written) or a WFM_E_* code. */
 int64_t wfm_add_minmers_multi(wfm_handle_t* h, const char* const* seqs, const int64_t* lens, const int32_t* seq_ids,
                               int64_t nseq, int k, int w, int s, int threads, wfm_minmer_t* out, int64_t cap, int64_t* counts);
+
+/* The k-mers of a sequence that wfm_add_minmers_multi lets its host workers see: valid k-mers whose hash
+ * is under the threshold that lets c_factor * s of a window's w-k+1 k-mers through, plus every valid k-mer of a window that may hold
+ * fewer than s distinct such hashes (wfmash_amd/csrc/map_prefilter.hip states the rule and why winnowing
+ * the kept k-mers alone reproduces addMinmers).  pos / hash / strand receive up to cap kept k-mers in
+ * ascending position; returns their number (may exceed cap) or a WFM_E_* code. */
+int64_t wfm_prefilter_kmers(wfm_handle_t* h, const char* seq, int64_t len, int k, int w, int s, double c_factor,
+                            uint32_t* pos, uint64_t* hash, int8_t* strand, int64_t cap);
 
 /* MinHash of one whole sequence for the ANI estimate (estimate_identity_for_groups,
  * src/map/include/map_stats.hpp:325-822; StreamingMinHash, streamingMinHash.hpp:35-135): the

@@ -67,6 +67,15 @@ int64_t wfmh_test_winnow_chunked(const char* seq, int64_t len, int k, int w, int
                                  const uint64_t* hash, const int8_t* strand, int64_t chunk_len,
                                  wfm_minmer_t* out, int64_t cap, int* replays);
 
+/* the same on the thinned stream wfm_add_minmers_multi feeds its workers (wfm_prefilter_kmers,
+ * wfmash_hip.h): the selection is restated on the host from its definition, with the hash threshold set to
+ * let c_factor * s of a window's w-k+1 k-mers through, and only the kept k-mers are winnowed.  kept_pos (optional)
+ * receives the kept k-mer starts, *n_kept their number. */
+int64_t wfmh_test_winnow_thinned(const char* seq, int64_t len, int k, int w, int s, int32_t seq_id,
+                                 const uint64_t* hash, const int8_t* strand, double c_factor, int64_t chunk_len,
+                                 wfm_minmer_t* out, int64_t cap, uint32_t* kept_pos, int64_t cap_kept,
+                                 int64_t* n_kept, int* replays);
+
 /* ---- map phase (skch::Map, src/map/include/computeMap.hpp) ---- */
 
 /* skch::Parameters as set up by parse_args.hpp; wfmh_map_default_params fills the defaults

@@ -114,6 +114,40 @@ def test_chunked_winnowing_equals_single_stream():
     assert total_replays <= 6, total_replays
 
 
+def _thin_cases():
+    yield from _chunk_cases()
+    rng = random.Random(99)
+    rnd = bytes(rng.choice(b"ACGT") for _ in range(30000))
+    yield "n_in_first_kmers", b"ACGNTACGTTGCA" + rnd[:20000]
+    yield "n_runs", rnd[:7000] + b"N" * 3000 + rnd[7000:9000] + b"N" * 40 + rnd[9000:20000]
+    yield "short_tandem", rnd[:6000] + (rnd[100:137] * 300) + rnd[6000:14000]
+    yield "long_period_repeat", rnd[:4000] + rnd[4000:5200] * 8 + rnd[5200:12000]
+    yield "barely_a_window", rnd[:1003]
+
+
+def test_thinned_winnowing_equals_single_stream():
+    """the stream wfm_add_minmers_multi really feeds its workers: k-mers above the hash threshold are dropped
+    unless a window may need them (selection restated on the host here; the GPU's is held against it in
+    test_prefilter_gpu_matches_host_definition).  Winnowing the kept k-mers alone must give addMinmers' records."""
+    total_kept = total = 0
+    for name, seq in _thin_cases():
+        for (k, w, s) in ((15, 1000, 39), (15, 500, 16), (19, 256, 5), (15, 1000, 78)):
+            if len(seq) < w:
+                continue
+            h, st = pymap.hash_kmers(capi_norm(seq), k)
+            one = capi.host_winnow(seq, k, w, s, 3, h, st)
+            for c_factor in (3.0, 1.5, 0.5):
+                for chunk in (0, 4 * w + 17, 25000):
+                    got, kept, replays = capi.host_winnow_thinned(seq, k, w, s, 3, h, st, c_factor, chunk)
+                    assert replays >= 0, (name, k, w, s, c_factor, chunk)
+                    assert len(got) == len(one) and got.tobytes() == one.tobytes(), (name, k, w, s, c_factor, chunk, len(kept), len(h))
+                if c_factor == 3.0 and (k, w, s) == (15, 1000, 39):
+                    total_kept += len(kept)
+                    total += len(h)
+    # the point of the exercise: most k-mers never reach the host (these cases are repeat- and N-heavy on purpose)
+    assert total_kept < 0.6 * total, (total_kept, total)
+
+
 def capi_norm(seq: bytes) -> bytes:
     """upper-case / N-mask as the hashing kernel does (the oracle hashes what it is given)"""
     up = seq.upper()
@@ -158,3 +192,18 @@ def test_add_minmers_streamed_replay_paths(force):
     assert len(streamed) == 1, r.stderr[-2000:]
     if force == "1":
         assert "(0 replayed)" not in streamed[0], streamed[0]
+
+
+@pytest.mark.gpu
+def test_prefilter_gpu_matches_host_definition(gpu):
+    """the device's selection of k-mers (scan / radix sort / window counts, map_prefilter.hip) against the
+    definition restated on the host, and hashes/strands against the hash kernel's"""
+    for name, seq in _thin_cases():
+        for (k, w, s, c) in ((15, 1000, 39, 3.0), (19, 256, 5, 1.5), (15, 500, 16, 3.0)):
+            if len(seq) < w:
+                continue
+            h, st = gpu.hash_kmers(seq, k)
+            _, kept, _ = capi.host_winnow_thinned(seq, k, w, s, 3, h, st, c, 0)
+            pos, ph, ps = gpu.prefilter_kmers(seq, k, w, s, c)
+            assert pos.tobytes() == kept.tobytes(), (name, k, w, s, c, len(pos), len(kept))
+            assert (ph == h[pos]).all() and (ps == st[pos]).all(), (name, k, w, s, c)

@@ -25,6 +25,7 @@ EXPORTS = [
     "wfm_hash_kmers", "wfm_sketch_fragments", "wfm_add_minmers",
     "wfm_index_build", "wfm_index_free", "wfm_index_info", "wfm_index_download",
     "wfm_map_l1", "wfm_map_l2", "wfm_map_fragments", "wfm_minhash_sketch", "wfm_add_minmers_multi",
+    "wfm_prefilter_kmers",
 ]
 
 
@@ -482,6 +483,21 @@ class Handle:
         offs = np.concatenate([[0], np.cumsum(counts)])
         return [out[offs[i]:offs[i + 1]] for i in range(n)]
 
+    def prefilter_kmers(self, seq: bytes, k: int, w: int, s: int, c_factor: float = 4.0):
+        """wfm_prefilter_kmers: the k-mers the host winnowing gets to see; returns (pos, hash, strand)."""
+        cap = len(seq) + 1
+        pos = np.zeros(cap, dtype=np.uint32)
+        hsh = np.zeros(cap, dtype=np.uint64)
+        st = np.zeros(cap, dtype=np.int8)
+        buf = np.frombuffer(seq, dtype=np.uint8)
+        f = self._L.wfm_prefilter_kmers
+        f.restype = C.c_int64
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
+        n = f(self._p, buf.ctypes.data, len(seq), k, w, s, c_factor, pos.ctypes.data, hsh.ctypes.data, st.ctypes.data, cap)
+        if n < 0:
+            raise WfmError(f"wfm_prefilter_kmers failed ({n}): {self.last_error()}")
+        return pos[:n], hsh[:n], st[:n]
+
     def add_minmers(self, seq: bytes, k: int, w: int, s: int, seq_id: int = 0):
         """wfm_add_minmers: winnowed minmer intervals of one target sequence."""
         cap = 4 * len(seq) + 64
@@ -499,7 +515,7 @@ class Handle:
 # host-side align driver (include/wfmash_host.h)
 # ---------------------------------------------------------------------------
 HOST_EXPORTS = ["wfmh_align_default_params", "wfmh_align_paf", "wfmh_test_cigar", "wfmh_free", "wfmh_test_winnow",
-                "wfmh_map_default_params", "wfmh_test_filter", "wfmh_map", "wfmh_test_winnow_chunked", "wfmh_test_fasta"]
+                "wfmh_map_default_params", "wfmh_test_filter", "wfmh_map", "wfmh_test_winnow_chunked", "wfmh_test_fasta", "wfmh_test_winnow_thinned"]
 
 
 class MapSummary(C.Structure):
@@ -655,6 +671,26 @@ def host_winnow(seq: bytes, k: int, w: int, s: int, seq_id: int, hashes, strands
     strands = np.ascontiguousarray(strands, dtype=np.int8)
     n = L.wfmh_test_winnow(seq, len(seq), k, w, s, seq_id, hashes.ctypes.data, strands.ctypes.data, out.ctypes.data, cap)
     return out[:n]
+
+
+def host_winnow_thinned(seq: bytes, k: int, w: int, s: int, seq_id: int, hashes, strands, c_factor: float = 4.0, chunk_len: int = 0):
+    """The chunked host winnowing on the thinned stream (selection restated on the host); returns
+    (minmers, kept positions, replays)."""
+    L = load()
+    f = L.wfmh_test_winnow_thinned
+    f.restype = C.c_int64
+    f.argtypes = [C.c_char_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int32, C.c_void_p, C.c_void_p, C.c_double, C.c_int64, C.c_void_p,
+                  C.c_int64, C.c_void_p, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int)]
+    cap = 4 * len(seq) + 64
+    out = np.zeros(cap, dtype=MINMER_DTYPE)
+    kept = np.zeros(len(seq) + 1, dtype=np.uint32)
+    hashes = np.ascontiguousarray(hashes, dtype=np.uint64)
+    strands = np.ascontiguousarray(strands, dtype=np.int8)
+    rep = C.c_int(0)
+    nk = C.c_int64(0)
+    n = f(seq, len(seq), k, w, s, seq_id, hashes.ctypes.data, strands.ctypes.data, c_factor, chunk_len, out.ctypes.data, cap,
+          kept.ctypes.data, len(kept), C.byref(nk), C.byref(rep))
+    return out[:n], kept[:nk.value], rep.value
 
 
 def host_winnow_chunked(seq: bytes, k: int, w: int, s: int, seq_id: int, hashes, strands, chunk_len: int):

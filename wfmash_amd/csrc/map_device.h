@@ -6,6 +6,7 @@
 #include <stdint.h>
 
 #include <algorithm>
+#include <cmath>
 #include <vector>
 
 #include "../../include/wfmash_hip.h"
@@ -72,4 +73,29 @@ int map_stage_copy(MapStage* st, int slot, const MapHashedSeq* s, int64_t from, 
 int map_stage_wait(MapStage* st, int slot);
 // the same layout, synchronously, into ordinary memory (the rare replays)
 int map_hashed_fetch_packed(const MapHashedSeq* s, int64_t from, int64_t to, int64_t base_from, int64_t base_to, char* dst);
+
+// The k-mers of a hashed sequence the host winnowing has to see (map_prefilter.hip), ascending positions.
+struct MapSparseSeq {
+  uint32_t* d_pos = nullptr;   // k-mer start
+  uint64_t* d_hash = nullptr;
+  int8_t* d_strand = nullptr;  // +1 / -1
+  int64_t m = 0;
+  int device = 0;
+};
+// The threshold that lets about c x s of the W k-mers of a window through.  A canonical hash is the smaller of
+// two uniform 64-bit values, so a fraction t of the hash range holds 1 - (1-t)^2 of the k-mers.
+inline uint64_t map_prefilter_tau(double c_factor, int s, int64_t W) {
+  const double share = c_factor * (double)s / (double)std::max<int64_t>(1, W);  // of the k-mers
+  if (!(share < 1.0)) return ~0ull;
+  const long double t = 1.0L - sqrtl(1.0L - (long double)share);
+  return (uint64_t)(t * 18446744073709551616.0L);
+}
+// W = k-mers per window (w - k + 1), s = sketch size, tau = hash threshold
+int map_prefilter_device(wfm_handle_t* h, const MapHashedSeq* q, int64_t W, int s, uint64_t tau, MapSparseSeq* out);
+void map_sparse_free(MapSparseSeq* s);
+// out[i] = number of kept k-mers with position < query[i] (host arrays)
+int map_sparse_lower_bound(wfm_handle_t* h, const MapSparseSeq* s, const int64_t* query, int nq, int64_t* out);
+// kept k-mers [c0, c1): uint64 hash[mc] | uint32 pos[mc] | int8 strand[mc], into a ring slot / ordinary memory
+int map_stage_copy_sparse(MapStage* st, int slot, const MapSparseSeq* s, int64_t c0, int64_t c1);
+int map_sparse_fetch_packed(const MapSparseSeq* s, int64_t c0, int64_t c1, char* dst);
 #endif

@@ -19,10 +19,13 @@
 // get their true start from the previous chunk when the chunks are stitched.
 //
 // Data movement.  The hashes of a sequence (10 B per base with strands and the normalised bases) stay
-// on the device; a streaming thread copies them chunk by chunk into a small ring of pinned slots
-// (asynchronous, link speed), a worker takes a slot's bytes into its own reused buffer and winnows from
-// there.  The host never holds whole-sequence arrays -- that form (20 GB of fresh pages for 2 Gbp, a
-// pageable copy at a few GB/s) used to be most of the index time.  A replay fetches its chunk again.
+// on the device, where the stream is first THINNED (map_prefilter.hip): a k-mer whose hash is above a
+// threshold is dropped unless a window may need it, which leaves about one k-mer in eight; the workers
+// replay only the kept ones (Winnower::advance_sparse holds the argument why that changes nothing).  A
+// streaming thread copies them chunk by chunk into a small ring of pinned slots (asynchronous, link
+// speed), a worker takes a slot's bytes into its own reused buffer and winnows from there.  The host never
+// holds whole-sequence arrays.  A replay fetches its chunk again.  One stream per sequence
+// (wfm_add_minmers, threads == 1) stays dense: the tests hold the two forms against each other.
 //
 // State (names follow the roles, not the reference's identifiers):
 //   arrivals  every valid k-mer still inside (or lingering behind) the window, arrival order
@@ -114,117 +117,25 @@ class Winnower {
 
   // the stream for k-mer starts [from, to)
   void advance(int64_t from, int64_t to) {
-    const int k = k_, w = w_, s = s_;
+    if (sp_.pos) { advance_sparse(from, to); return; }
+    const int k = k_, w = w_;
     const int64_t k0 = d_.kmer0, b0 = d_.base0;
     const char* norm = d_.norm;
     for (int64_t i = from; i < to; ++i) {
       const char* seq = norm + (i - b0);  // the k-mer's bases: seq[0..k)
       const int64_t win = i + k - w;  // id of the window that ends with this k-mer
-      if (pool_.size() > (size_t)2 * (size_t)w) {
-        pool_.erase(std::remove_if(pool_.begin(), pool_.end(), [win](const PoolItem& p) { return p.pos < win; }), pool_.end());
-        std::make_heap(pool_.begin(), pool_.end(), pool_after);
-      }
+      tidy_pool(win);
       // canonical hash: from the device, except k-mers that contain an N the reference does not notice
       // (NOTE: no initial scan, commonFunc.hpp:473: an N inside the first k-1 bases of the sequence
       //  is only seen when it is the LAST base of a k-mer)
       uint64_t hf_min; int16_t strand; bool asym;
       if (d_.strand[i - k0] != 0) { hf_min = d_.hash[i - k0]; strand = d_.strand[i - k0]; asym = true; }
-      else {
-        bool has_n = false;
-        for (int j = 0; j < k; ++j) has_n |= seq[j] == 'N';
-        if (!has_n) { asym = false; hf_min = 0; strand = 0; }  // hashFwd == hashBwd
-        else {
-          for (int j = 0; j < k; ++j) {
-            const char c = seq[j];
-            rc_[(size_t)(k - 1 - j)] = (uint8_t)(c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : c == 'T' ? 'A' : c);
-          }
-          const uint64_t hf = murmur_lo((const uint8_t*)seq, k, 42u), hb = murmur_lo(rc_.data(), k, 42u);
-          asym = hf != hb; hf_min = std::min(hf, hb); strand = hf < hb ? 1 : -1;
-        }
-      }
-      // ---- the k-mer that fell out of the window (one per iteration) ----
-      if (!arrivals_.empty() && std::get<2>(arrivals_.front()) < win) {
-        const uint64_t lh = std::get<0>(arrivals_.front());
-        const int16_t ls = std::get<1>(arrivals_.front());
-        if (!sketch_.empty() && lh <= std::prev(sketch_.end())->first) {
-          auto it = sketch_.find(lh);
-          if (it != sketch_.end()) {
-            Open& o = it->second;
-            if (o.occ.size() == 1) {
-              o.mi.wpos_end = win;
-              out.push_back(o.mi);
-              sketch_.erase(it);
-            } else {
-              if (o.mi.strand - ls == 0 || o.mi.strand == 0) {  // tally reaches or leaves zero: split the interval
-                o.mi.wpos_end = win;
-                out.push_back(o.mi);
-                o.mi.wpos = win;
-                o.mi.wpos_end = -1;
-              }
-              o.mi.strand = (int16_t)(o.mi.strand - ls);
-              if (!o.occ.empty()) o.occ.pop_front();
-            }
-          }
-        }
-        arrivals_.pop_front();
-      }
+      else asym = unnoticed_n_kmer(seq, &hf_min, &strand);
+      leave(win);
       if (seq[k - 1] == 'N') ambig_ = k;
-      if (asym && ambig_ == 0) {
-        arrivals_.emplace_back(hf_min, strand, i);
-        auto it = sketch_.find(hf_min);
-        if (it != sketch_.end()) {
-          Open& o = it->second;
-          o.occ.push_back(Occ{i, strand});
-          if (o.mi.strand + strand == 0 || o.mi.strand == 0) {
-            o.mi.wpos_end = win;
-            out.push_back(o.mi);
-            o.mi.wpos = win;
-            o.mi.wpos_end = -1;
-          }
-          o.mi.strand = (int16_t)(o.mi.strand + strand);
-        } else {
-          pool_.push_back(PoolItem{hf_min, i, strand});
-          std::push_heap(pool_.begin(), pool_.end(), pool_after);
-        }
-      }
+      if (asym && ambig_ == 0) arrive(i, win, hf_min, strand);
       if (ambig_ > 0) --ambig_;
-      // ---- keep the sketch at the s smallest hashes of the window ----
-      // Expired pool entries never get chosen: the loop below clears them off the top, after it the
-      // top is live, one step frees at most one sketch slot (one k-mer leaves per step; the swap
-      // against the largest needs a full sketch), and a sketch with two or more free slots means
-      // the pool ran empty earlier -- so the refill takes the live top and stops, or empties the pool.
-      if (win >= 0) {
-        while (!pool_.empty() && pool_.front().pos < win) { std::pop_heap(pool_.begin(), pool_.end(), pool_after); pool_.pop_back(); }
-        if (!sketch_.empty() && !pool_.empty() && sketch_.size() == (size_t)s && pool_.front().hash < std::prev(sketch_.end())->first) {
-          auto last = std::prev(sketch_.end());
-          last->second.mi.wpos_end = win;
-          out.push_back(last->second.mi);
-          for (const Occ& oc : last->second.occ) {
-            if (oc.pos > win) {  // strictly greater, as the reference (commonFunc.hpp:615)
-              pool_.push_back(PoolItem{last->first, oc.pos, oc.strand});
-              std::push_heap(pool_.begin(), pool_.end(), pool_after);
-            }
-          }
-          sketch_.erase(last);
-        }
-        while (!pool_.empty() && sketch_.size() < (size_t)s) {
-          if (pool_.front().pos < win) {  // drops ONE expired item, then takes whatever is on top (commonFunc.hpp:627-633)
-            ++expired_in_refill_;         // never expected (see above); chunked runs fall back to one stream if it happens
-            std::pop_heap(pool_.begin(), pool_.end(), pool_after);
-            pool_.pop_back();
-            if (pool_.empty()) break;  // the reference reads an empty heap here (undefined); stop instead
-          }
-          const PoolItem top = pool_.front();
-          Open& o = sketch_[top.hash];
-          o.mi = wfm_minmer_t{top.hash, win, -1, seq_id_, 0, 0};
-          while (!pool_.empty() && pool_.front().hash == top.hash) {
-            o.occ.push_back(Occ{pool_.front().pos, pool_.front().strand});
-            o.mi.strand = (int16_t)(o.mi.strand + pool_.front().strand);
-            std::pop_heap(pool_.begin(), pool_.end(), pool_after);
-            pool_.pop_back();
-          }
-        }
-      }
+      if (win >= 0) maintain(win);
     }
   }
 
@@ -282,6 +193,167 @@ class Winnower {
   }
 
  private:
+  // a k-mer the device marks invalid (strand 0): palindromic, or it contains an N.  The reference hashes the
+  // ones whose N it has not noticed; whether the k-mer then enters the stream is the ambiguity counter's call.
+  bool unnoticed_n_kmer(const char* seq, uint64_t* hf_min, int16_t* strand) {
+    const int k = k_;
+    bool has_n = false;
+    for (int j = 0; j < k; ++j) has_n |= seq[j] == 'N';
+    if (!has_n) { *hf_min = 0; *strand = 0; return false; }  // hashFwd == hashBwd
+    for (int j = 0; j < k; ++j) {
+      const char c = seq[j];
+      rc_[(size_t)(k - 1 - j)] = (uint8_t)(c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : c == 'T' ? 'A' : c);
+    }
+    const uint64_t hf = murmur_lo((const uint8_t*)seq, k, 42u), hb = murmur_lo(rc_.data(), k, 42u);
+    *hf_min = std::min(hf, hb); *strand = hf < hb ? 1 : -1;
+    return hf != hb;
+  }
+  void tidy_pool(int64_t win) {
+    if (pool_.size() > (size_t)2 * (size_t)w_) {
+      pool_.erase(std::remove_if(pool_.begin(), pool_.end(), [win](const PoolItem& p) { return p.pos < win; }), pool_.end());
+      std::make_heap(pool_.begin(), pool_.end(), pool_after);
+    }
+  }
+  // ---- the k-mer that fell out of the window (one per iteration) ----
+  void leave(int64_t win) {
+    if (!arrivals_.empty() && std::get<2>(arrivals_.front()) < win) {
+      const uint64_t lh = std::get<0>(arrivals_.front());
+      const int16_t ls = std::get<1>(arrivals_.front());
+      if (!sketch_.empty() && lh <= std::prev(sketch_.end())->first) {
+        auto it = sketch_.find(lh);
+        if (it != sketch_.end()) {
+          Open& o = it->second;
+          if (o.occ.size() == 1) {
+            o.mi.wpos_end = win;
+            out.push_back(o.mi);
+            sketch_.erase(it);
+          } else {
+            if (o.mi.strand - ls == 0 || o.mi.strand == 0) {  // tally reaches or leaves zero: split the interval
+              o.mi.wpos_end = win;
+              out.push_back(o.mi);
+              o.mi.wpos = win;
+              o.mi.wpos_end = -1;
+            }
+            o.mi.strand = (int16_t)(o.mi.strand - ls);
+            if (!o.occ.empty()) o.occ.pop_front();
+          }
+        }
+      }
+      arrivals_.pop_front();
+    }
+  }
+  // ---- a valid k-mer enters the window ----
+  void arrive(int64_t i, int64_t win, uint64_t hf_min, int16_t strand) {
+    arrivals_.emplace_back(hf_min, strand, i);
+    auto it = sketch_.find(hf_min);
+    if (it != sketch_.end()) {
+      Open& o = it->second;
+      o.occ.push_back(Occ{i, strand});
+      if (o.mi.strand + strand == 0 || o.mi.strand == 0) {
+        o.mi.wpos_end = win;
+        out.push_back(o.mi);
+        o.mi.wpos = win;
+        o.mi.wpos_end = -1;
+      }
+      o.mi.strand = (int16_t)(o.mi.strand + strand);
+    } else {
+      pool_.push_back(PoolItem{hf_min, i, strand});
+      std::push_heap(pool_.begin(), pool_.end(), pool_after);
+    }
+  }
+  // ---- keep the sketch at the s smallest hashes of the window ----
+  // Expired pool entries never get chosen: the loop below clears them off the top, after it the
+  // top is live, one step frees at most one sketch slot (one k-mer leaves per step; the swap
+  // against the largest needs a full sketch), and a sketch with two or more free slots means
+  // the pool ran empty earlier -- so the refill takes the live top and stops, or empties the pool.
+  void maintain(int64_t win) {
+    const size_t s = (size_t)s_;
+    while (!pool_.empty() && pool_.front().pos < win) { std::pop_heap(pool_.begin(), pool_.end(), pool_after); pool_.pop_back(); }
+    if (!sketch_.empty() && !pool_.empty() && sketch_.size() == s && pool_.front().hash < std::prev(sketch_.end())->first) {
+      auto last = std::prev(sketch_.end());
+      last->second.mi.wpos_end = win;
+      out.push_back(last->second.mi);
+      for (const Occ& oc : last->second.occ) {
+        if (oc.pos > win) {  // strictly greater, as the reference (commonFunc.hpp:615)
+          pool_.push_back(PoolItem{last->first, oc.pos, oc.strand});
+          std::push_heap(pool_.begin(), pool_.end(), pool_after);
+        }
+      }
+      sketch_.erase(last);
+    }
+    while (!pool_.empty() && sketch_.size() < s) {
+      if (pool_.front().pos < win) {  // drops ONE expired item, then takes whatever is on top (commonFunc.hpp:627-633)
+        ++expired_in_refill_;         // never expected (see above); chunked runs fall back to one stream if it happens
+        std::pop_heap(pool_.begin(), pool_.end(), pool_after);
+        pool_.pop_back();
+        if (pool_.empty()) break;  // the reference reads an empty heap here (undefined); stop instead
+      }
+      const PoolItem top = pool_.front();
+      Open& o = sketch_[top.hash];
+      o.mi = wfm_minmer_t{top.hash, win, -1, seq_id_, 0, 0};
+      while (!pool_.empty() && pool_.front().hash == top.hash) {
+        o.occ.push_back(Occ{pool_.front().pos, pool_.front().strand});
+        o.mi.strand = (int16_t)(o.mi.strand + pool_.front().strand);
+        std::pop_heap(pool_.begin(), pool_.end(), pool_after);
+        pool_.pop_back();
+      }
+    }
+  }
+
+  // The thinned stream (map_prefilter.hip): only the kept k-mers are known, each one valid.  What the full
+  // stream does in an iteration whose arriving and leaving k-mers were both dropped is nothing:
+  //  * a dropped k-mer x has hash > tau and every window that holds it has >= s distinct hashes <= tau, all of
+  //    them kept.  By induction over the steps the sketch of such a window is full and <= tau after maintain():
+  //    x is never found in it (arrive/leave only touch x's own hash), never beats its largest entry (the swap),
+  //    and a refill -- one free slot, after a kept k-mer left -- takes the pool's live minimum, which is kept;
+  //  * with the sketch full and the pool's live minimum >= its largest entry (true after every maintain(),
+  //    since one step adds at most one small k-mer to the pool and the swap/refill takes exactly that one),
+  //    maintain() only pops expired entries off the top, which the next call would do just as well;
+  //  * windows with fewer fresh candidates keep ALL their k-mers, so there both streams hold the same live set.
+  // So only three kinds of iterations are run: a kept k-mer arrives, a kept k-mer leaves (W steps after it
+  // arrived), and the one where the first window completes.  Expired pool entries differ between the two
+  // streams (dropped k-mers are never pooled); they are unobservable unless one takes part in a refill, which
+  // the counter catches as it does for the chunks -- the fall-back is then the FULL single stream.
+  void advance_sparse(int64_t from, int64_t to) {
+    const int64_t W = (int64_t)w_ - k_ + 1;  // a k-mer that arrived at p leaves at p + W
+    const int64_t first_full = (int64_t)w_ - k_;  // win == 0
+    size_t c = (size_t)(std::lower_bound(sp_.pos, sp_.pos + sp_.n, from, [](uint32_t p, int64_t x) { return (int64_t)p < x; }) - sp_.pos);
+    size_t e = (size_t)(std::lower_bound(extra_.begin(), extra_.end(), from, [](const PoolItem& p, int64_t x) { return p.pos < x; }) - extra_.begin());
+    const int64_t never = std::numeric_limits<int64_t>::max();
+    int64_t i = from;
+    for (;;) {
+      const int64_t ia = c < sp_.n ? (int64_t)sp_.pos[c] : never;
+      const int64_t ie = e < extra_.size() ? extra_[e].pos : never;
+      const int64_t il = arrivals_.empty() ? never : std::max(i, std::get<2>(arrivals_.front()) + W);
+      const int64_t i0 = (first_full >= i && first_full >= from) ? first_full : never;
+      i = std::min(std::min(ia, ie), std::min(il, i0));
+      if (i >= to) break;
+      const int64_t win = i + k_ - w_;
+      tidy_pool(win);
+      leave(win);
+      if (ie == i) { arrive(i, win, extra_[e].hash, extra_[e].strand); ++e; }
+      else if (ia == i) { arrive(i, win, sp_.hash[c], sp_.strand[c]); ++c; }
+      if (win >= 0) maintain(win);
+      ++i;
+    }
+  }
+
+ public:
+  // the kept k-mers of the stream (ascending positions)
+  struct Sparse { const uint32_t* pos = nullptr; const uint64_t* hash = nullptr; const int8_t* strand = nullptr; size_t n = 0; };
+  // Thinned form.  The k-mers the device cannot judge -- an N among the first k-1 bases of the sequence is not
+  // noticed by the reference (see advance()) -- are hashed here from `head` (the first 2k bases, or all).
+  Winnower(const Sparse& sp, const char* head, int64_t head_len, int64_t len, int k, int w, int s, int32_t seq_id)
+      : len_(len), k_(k), w_(w), s_(s), seq_id_(seq_id), rc_((size_t)k), sp_(sp) {
+    for (int64_t i = 0; i < k - 1 && i + k <= head_len; ++i) {
+      bool late_n = false;  // an N the reference notices: at base k-1 or later
+      for (int64_t b = std::max<int64_t>(i, k - 1); b < i + k; ++b) late_n |= head[b] == 'N';
+      uint64_t hf; int16_t st;
+      if (!late_n && unnoticed_n_kmer(head + i, &hf, &st)) extra_.push_back(PoolItem{hf, i, st});
+    }
+  }
+
+ private:
   Slice d_;
   int64_t len_;
   int k_, w_, s_;
@@ -292,6 +364,8 @@ class Winnower {
   std::vector<uint8_t> rc_;
   int ambig_ = 0;
   int64_t expired_in_refill_ = 0;
+  Sparse sp_;
+  std::vector<PoolItem> extra_;  // thinned form: the unnoticed-N k-mers at the start of the sequence
 
  public:
   int64_t expired_in_refill() const { return expired_in_refill_; }
@@ -353,6 +427,30 @@ struct SeqJob {
   std::vector<wfm_minmer_t> result;
   MapHashedSeq dev;          // the hashed sequence on the device: the source of every slice
   bool on_device = false;
+  // thinned form (map_prefilter.hip): the kept k-mers, on the device; chunk j reads [cidx_warm[j], cidx[j+1])
+  bool thinned = false;
+  MapSparseSeq sparse;
+  std::string head;                      // the first normalised bases: the k-mers the device cannot judge (Winnower)
+  std::vector<int64_t> cidx, cidx_warm;  // kept k-mers before bounds[j] / before warm_from(j)
+  std::vector<uint32_t> h_pos;           // test hook: the kept k-mers in host memory
+  std::vector<uint64_t> h_hash;
+  std::vector<int8_t> h_strand;
+
+  // what a stream reads: a dense slice or kept k-mers
+  struct View { Slice d; Winnower::Sparse sp; };
+  std::unique_ptr<Winnower> make(const View& v) const {
+    if (thinned && v.sp.pos) return std::make_unique<Winnower>(v.sp, head.data(), (int64_t)head.size(), len, k, w, s, seq_id);
+    return std::make_unique<Winnower>(v.d, len, k, w, s, seq_id);
+  }
+  // the packed kept-k-mer layout of map_device.h in `buf`
+  static Winnower::Sparse packed_sparse(const char* buf, size_t mc) {
+    Winnower::Sparse sp;
+    sp.hash = reinterpret_cast<const uint64_t*>(buf);
+    sp.pos = reinterpret_cast<const uint32_t*>(buf + mc * 8);
+    sp.strand = reinterpret_cast<const int8_t*>(buf + mc * 12);
+    sp.n = mc;
+    return sp;
+  }
 
   Slice whole() const { return Slice{hash.get(), strand.get(), norm.get(), 0, 0}; }
   int64_t warm_from(size_t j) const { return j > 0 ? std::max<int64_t>(0, bounds[j] - 2 * (int64_t)w) : 0; }
@@ -372,8 +470,8 @@ struct SeqJob {
     started_from.resize(n);
     pending.store((int)n);
   }
-  void run_chunk(size_t j, const Slice& d) {
-    auto W = std::make_unique<Winnower>(d, len, k, w, s, seq_id);
+  void run_chunk(size_t j, const View& v) {
+    auto W = make(v);
     if (j > 0) {
       W->advance(warm_from(j), bounds[j]);  // warm-up: records are not this chunk's
       W->out.clear();
@@ -395,6 +493,22 @@ struct SeqJob {
     const int rc = map_hashed_fetch_packed(&dev, kf, kt, kf, kt + k - 1, buf.data());
     if (rc != WFM_OK) { fetch_rc = rc; memset(buf.data(), 0, buf.size()); }
     return packed(buf.data(), kf, kt);
+  }
+  // what a replay of chunk j reads
+  View refetch_chunk(size_t j, std::vector<char>& buf) {
+    View v;
+    if (!thinned) { v.d = refetch(bounds[j], bounds[j + 1], buf); return v; }
+    const int64_t c0 = cidx[j], c1 = cidx[j + 1];
+    if (!h_pos.empty() || c1 == c0) {
+      static const uint32_t none = 0;
+      v.sp.pos = h_pos.empty() ? &none : h_pos.data() + c0; v.sp.hash = h_hash.data() + c0; v.sp.strand = h_strand.data() + c0; v.sp.n = (size_t)(c1 - c0);
+      return v;
+    }
+    buf.resize((size_t)(c1 - c0) * 13);
+    const int rc = map_sparse_fetch_packed(&sparse, c0, c1, buf.data());
+    if (rc != WFM_OK) { fetch_rc = rc; memset(buf.data(), 0, buf.size()); }
+    v.sp = packed_sparse(buf.data(), (size_t)(c1 - c0));
+    return v;
   }
   // sequential: check every speculation against the state the previous chunk really reached
   void stitch() {
@@ -421,8 +535,7 @@ struct SeqJob {
     for (size_t j = 1; j < chunk.size(); ++j) {
       const Winnower& prev = *chunk[j - 1];
       if (force == 1 || !(started_from[j] == prev.live_state(bounds[j]))) {
-        const Slice d = refetch(bounds[j], bounds[j + 1], buf);
-        auto R = std::make_unique<Winnower>(d, len, k, w, s, seq_id);
+        auto R = make(refetch_chunk(j, buf));
         R->take_state(prev);
         R->advance(bounds[j], bounds[j + 1]);
         chunk[j] = std::move(R);
@@ -442,6 +555,18 @@ struct SeqJob {
     norm.reset(); hash.reset(); strand.reset();
   }
 };
+
+// The hash threshold of the thinned stream: ~c x s of the W k-mers of a window stay (c = 3, WFM_PREFILTER_C);
+// 0 = no thinning (WFM_PREFILTER=0, or more than half of the k-mers would stay anyway)
+uint64_t prefilter_tau(int s, int64_t W) {
+  const char* on = getenv("WFM_PREFILTER");
+  if (on && atoi(on) == 0) return 0;
+  const char* ce = getenv("WFM_PREFILTER_C");
+  const double c = ce ? atof(ce) : 3.0;
+  const double share = c * (double)s / (double)std::max<int64_t>(1, W);
+  if (!(share > 0) || share > 0.5) return 0;
+  return map_prefilter_tau(c, s, W);
+}
 
 int64_t chunk_length() {
   const char* e = getenv("WFM_WINNOW_CHUNK");  // k-mers per speculative chunk; 0 = one stream per sequence
@@ -471,8 +596,10 @@ extern "C" int64_t wfm_add_minmers_multi(wfm_handle_t* h, const char* const* seq
   const int64_t chunk_len = nthreads > 1 ? chunk_length() : 0;
   const bool streamed = chunk_len >= 64 * (int64_t)w;  // otherwise: whole sequences through ordinary memory
   MapStage* stage = nullptr;
+  const int64_t W = (int64_t)w - k + 1;  // k-mers per window
+  const uint64_t tau = streamed ? prefilter_tau(s, W) : 0;
   const int64_t slot_kmers = chunk_len + chunk_len / 2 + 2 * (int64_t)w + 1;
-  const size_t slot_bytes = map_stage_bytes(slot_kmers, slot_kmers + k);
+  const size_t slot_bytes = std::max(map_stage_bytes(slot_kmers, slot_kmers + k), (size_t)slot_kmers * 13);
   const int nslots = 16;
   if (streamed) {
     const int src = map_stage_acquire(h, slot_bytes, nslots, &stage);
@@ -505,12 +632,14 @@ extern "C" int64_t wfm_add_minmers_multi(wfm_handle_t* h, const char* const* seq
         queue.pop_front();
       }
       SeqJob* J = task.job;
-      Slice d = J->whole();
+      SeqJob::View v;
+      v.d = J->whole();
       if (task.slot >= 0) {
         int64_t kf, kt, bt;
         J->chunk_range(task.chunk, &kf, &kt, &bt);
-        const size_t nbytes = map_stage_bytes(kt - kf, bt - kf);
-        if (local.size() < nbytes) local.resize(std::max(nbytes, stage->slot_bytes));
+        const size_t mc = J->thinned ? (size_t)(J->cidx[task.chunk + 1] - J->cidx_warm[task.chunk]) : 0;
+        const size_t nbytes = J->thinned ? mc * 13 : map_stage_bytes(kt - kf, bt - kf);
+        if (local.size() < std::max<size_t>(nbytes, 16)) local.resize(std::max(nbytes, stage->slot_bytes));
         const int wrc = map_stage_wait(stage, task.slot);
         if (wrc == WFM_OK) memcpy(local.data(), stage->slot(task.slot), nbytes);
         else { memset(local.data(), 0, nbytes); async_rc.store(wrc); }
@@ -519,9 +648,15 @@ extern "C" int64_t wfm_add_minmers_multi(wfm_handle_t* h, const char* const* seq
           free_slots.push_back(task.slot);
         }
         cv_slot.notify_one();
-        d = SeqJob::packed(local.data(), kf, kt);
+        if (J->thinned) {
+          static const uint32_t none = 0;
+          v.sp = SeqJob::packed_sparse(local.data(), mc);
+          if (mc == 0) v.sp.pos = &none;  // an empty stream is still a thinned one
+        } else {
+          v.d = SeqJob::packed(local.data(), kf, kt);
+        }
       }
-      J->run_chunk(task.chunk, d);
+      J->run_chunk(task.chunk, v);
       if (J->pending.fetch_sub(1) == 1) {  // last chunk of this sequence: stitch here
         J->stitch();
         if (J->fetch_rc != WFM_OK) async_rc.store(J->fetch_rc);
@@ -555,7 +690,8 @@ extern "C" int64_t wfm_add_minmers_multi(wfm_handle_t* h, const char* const* seq
         }
         int64_t kf, kt, bt;
         J->chunk_range(c, &kf, &kt, &bt);
-        const int crc = map_stage_copy(stage, slot, &J->dev, kf, kt, kf, bt);
+        const int crc = J->thinned ? map_stage_copy_sparse(stage, slot, &J->sparse, J->cidx_warm[c], J->cidx[c + 1])
+                                   : map_stage_copy(stage, slot, &J->dev, kf, kt, kf, bt);
         if (crc != WFM_OK) async_rc.store(crc);  // the worker still runs (on whatever the slot holds): keeps the bookkeeping simple
         {
           std::lock_guard<std::mutex> lk(mu);
@@ -576,8 +712,10 @@ extern "C" int64_t wfm_add_minmers_multi(wfm_handle_t* h, const char* const* seq
       std::lock_guard<std::mutex> lk(mu);
       list.swap(stitched);
     }
-    for (SeqJob* J : list)
+    for (SeqJob* J : list) {
       if (J->on_device) { map_hashed_free(&J->dev); J->on_device = false; }
+      map_sparse_free(&J->sparse);
+    }
   };
 
   std::vector<std::thread> pool;
@@ -586,7 +724,8 @@ extern "C" int64_t wfm_add_minmers_multi(wfm_handle_t* h, const char* const* seq
   if (streamed) stream_thread = std::thread(streamer);
   int rc = WFM_OK;
   const auto t_start = std::chrono::steady_clock::now();
-  double ms_hash = 0;
+  double ms_hash = 0, ms_thin = 0;
+  int64_t kept_kmers = 0, thinned_kmers = 0;
   for (int64_t i = 0; i < nseq && rc == WFM_OK; ++i) {
     const int64_t len = lens[i];
     if (!seqs[i] || len < 0) { rc = WFM_E_ARG; break; }
@@ -605,6 +744,26 @@ extern "C" int64_t wfm_add_minmers_multi(wfm_handle_t* h, const char* const* seq
     J->on_device = true;
     ms_hash += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     J->plan(streamed ? chunk_len : 0);
+    const auto t1 = std::chrono::steady_clock::now();
+    if (tau != 0 && J->nk >= W && J->nk < ((int64_t)1 << 32) - 1) {
+      // thin the stream on the device; the dense arrays stay there for the one-stream fall-back
+      rc = map_prefilter_device(h, &J->dev, W, s, tau, &J->sparse);
+      if (rc != WFM_OK) { map_hashed_free(&J->dev); break; }
+      J->thinned = true;
+      kept_kmers += J->sparse.m;
+      thinned_kmers += J->nk;
+      J->head.assign((size_t)std::min<int64_t>(len, 2 * (int64_t)k), 'N');
+      rc = map_hashed_fetch(&J->dev, 0, 0, 0, (int64_t)J->head.size(), nullptr, nullptr, &J->head[0]);
+      const size_t nc = J->bounds.size() - 1;
+      std::vector<int64_t> q(2 * nc + 1), r(2 * nc + 1);
+      for (size_t c = 0; c <= nc; ++c) q[c] = J->bounds[c];
+      for (size_t c = 0; c < nc; ++c) q[nc + 1 + c] = J->warm_from(c);
+      if (rc == WFM_OK) rc = map_sparse_lower_bound(h, &J->sparse, q.data(), (int)q.size(), r.data());
+      if (rc != WFM_OK) { map_hashed_free(&J->dev); map_sparse_free(&J->sparse); break; }
+      J->cidx.assign(r.begin(), r.begin() + (long)nc + 1);
+      J->cidx_warm.assign(r.begin() + (long)nc + 1, r.end());
+    }
+    ms_thin += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count();
     SeqJob* Jp = J.get();
     jobs[(size_t)i] = std::move(J);
     if (streamed) {
@@ -645,9 +804,10 @@ extern "C" int64_t wfm_add_minmers_multi(wfm_handle_t* h, const char* const* seq
     int64_t nchunks = 0, replays = 0;
     for (const auto& J : jobs)
       if (J) { nchunks += (int64_t)J->bounds.size() - 1; replays += J->replays; }
-    fprintf(stderr, "[wfm] add_minmers_multi: %lld sequences in %lld chunks (%lld replayed), %d workers, %s: hashing thread %.1f ms (GPU hashing %.1f), drain %.1f ms\n",
+    fprintf(stderr, "[wfm] add_minmers_multi: %lld sequences in %lld chunks (%lld replayed), %d workers, %s, %.1f %% of the k-mers kept: hashing thread %.1f ms (GPU hashing %.1f, thinning %.1f), drain %.1f ms\n",
             (long long)nseq, (long long)nchunks, (long long)replays, nthreads, streamed ? "streamed through the pinned ring" : "whole sequences",
-            std::chrono::duration<double, std::milli>(t_fed - t_start).count(), ms_hash,
+            thinned_kmers ? 100.0 * (double)kept_kmers / (double)thinned_kmers : 100.0,
+            std::chrono::duration<double, std::milli>(t_fed - t_start).count(), ms_hash, ms_thin,
             std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_fed).count());
   }
   if (rc == WFM_OK && async_rc.load() != WFM_OK) { rc = async_rc.load(); wfm_set_error(h, "device-to-host streaming of k-mer hashes failed"); }
@@ -682,7 +842,7 @@ extern "C" int64_t wfmh_test_winnow_chunked(const char* seq, int64_t len, int k,
   J.bounds.push_back(J.nk);
   J.chunk.resize(J.bounds.size() - 1);
   J.started_from.resize(J.bounds.size() - 1);
-  for (size_t c = 0; c + 1 < J.bounds.size(); ++c) J.run_chunk(c, J.whole());
+  for (size_t c = 0; c + 1 < J.bounds.size(); ++c) { SeqJob::View v; v.d = J.whole(); J.run_chunk(c, v); }
   J.stitch();
   if (replays) *replays = J.replays;
   const int64_t n = (int64_t)J.result.size();
@@ -701,3 +861,72 @@ extern "C" int64_t wfmh_test_winnow(const char* seq, int64_t len, int k, int w, 
   for (int64_t i = 0; i < n && i < cap; ++i) out[i] = res[(size_t)i];
   return n;
 }
+
+// Test hook (CPU test-suite): the thinned stream.  The device's selection (map_prefilter.hip) is restated
+// here from its definition -- candidates, fresh candidates, windows under the bound, their dilation -- and
+// the chunked winnowing then runs on the kept k-mers only.  kept_pos (optional, cap_kept entries) receives the
+// kept positions, *n_kept their number: the GPU test holds wfm_prefilter_kmers against them.
+extern "C" int64_t wfmh_test_winnow_thinned(const char* seq, int64_t len, int k, int w, int s, int32_t seq_id, const uint64_t* hash,
+                                            const int8_t* strand, double c_factor, int64_t chunk_len, wfm_minmer_t* out, int64_t cap,
+                                            uint32_t* kept_pos, int64_t cap_kept, int64_t* n_kept, int* replays) {
+  if (len < k) return 0;
+  SeqJob J;
+  J.seq_id = seq_id; J.len = len; J.nk = len - k + 1; J.k = k; J.w = w; J.s = s;
+  const int64_t n = J.nk, W = (int64_t)w - k + 1;
+  J.norm.reset(new char[(size_t)len]);
+  memcpy(J.norm.get(), seq, (size_t)len);
+  normalise(J.norm.get(), len);
+  J.hash.reset(new uint64_t[(size_t)n]);
+  J.strand.reset(new int8_t[(size_t)n]);
+  memcpy(J.hash.get(), hash, (size_t)n * 8);
+  memcpy(J.strand.get(), strand, (size_t)n);
+  const uint64_t tau = map_prefilter_tau(c_factor, s, W);
+  // candidates sorted by (hash, position) -> fresh flags
+  std::vector<std::pair<uint64_t, int64_t>> cand;
+  for (int64_t i = 0; i < n; ++i)
+    if (strand[i] != 0 && hash[i] <= tau) cand.emplace_back(hash[i], i);
+  std::sort(cand.begin(), cand.end());
+  std::vector<uint32_t> F((size_t)n + 1, 0), P((size_t)n + 1, 0);  // prefix sums, shifted by one
+  {
+    std::vector<uint8_t> fresh((size_t)n, 0);
+    for (size_t j = 0; j < cand.size(); ++j)
+      if (j == 0 || cand[j].first != cand[j - 1].first || cand[j].second - cand[j - 1].second >= W) fresh[(size_t)cand[j].second] = 1;
+    for (int64_t i = 0; i < n; ++i) F[(size_t)i + 1] = F[(size_t)i] + fresh[(size_t)i];
+  }
+  for (int64_t a = 0; a < n; ++a) {
+    const uint32_t under = (a + W <= n && F[(size_t)(a + W)] - F[(size_t)a] < (uint32_t)s) ? 1u : 0u;
+    P[(size_t)a + 1] = P[(size_t)a] + under;
+  }
+  for (int64_t i = 0; i < n; ++i) {
+    if (strand[i] == 0) continue;
+    const bool dense = P[(size_t)i + 1] - P[(size_t)std::max<int64_t>(0, i - W + 1)] > 0;  // a window a in (i-W, i] is under the bound
+    if (hash[i] <= tau || dense) { J.h_pos.push_back((uint32_t)i); J.h_hash.push_back(hash[i]); J.h_strand.push_back(strand[i]); }
+  }
+  if (n_kept) *n_kept = (int64_t)J.h_pos.size();
+  for (size_t i = 0; kept_pos && i < J.h_pos.size() && (int64_t)i < cap_kept; ++i) kept_pos[i] = J.h_pos[i];
+  J.thinned = true;
+  J.head.assign(J.norm.get(), (size_t)std::min<int64_t>(len, 2 * (int64_t)k));
+  J.bounds.assign(1, 0);
+  if (chunk_len > 0)
+    for (int64_t b = chunk_len; b < n; b += chunk_len) J.bounds.push_back(b);
+  J.bounds.push_back(n);
+  const size_t nc = J.bounds.size() - 1;
+  J.chunk.resize(nc);
+  J.started_from.resize(nc);
+  auto before = [&](int64_t x) { return (int64_t)(std::lower_bound(J.h_pos.begin(), J.h_pos.end(), x, [](uint32_t p, int64_t v) { return (int64_t)p < v; }) - J.h_pos.begin()); };
+  for (size_t c = 0; c <= nc; ++c) J.cidx.push_back(before(J.bounds[c]));
+  for (size_t c = 0; c < nc; ++c) J.cidx_warm.push_back(before(J.warm_from(c)));
+  static const uint32_t none = 0;
+  for (size_t c = 0; c < nc; ++c) {
+    SeqJob::View v;
+    const int64_t c0 = J.cidx_warm[c], c1 = J.cidx[c + 1];
+    v.sp.pos = J.h_pos.empty() ? &none : J.h_pos.data() + c0; v.sp.hash = J.h_hash.data() + c0; v.sp.strand = J.h_strand.data() + c0; v.sp.n = (size_t)(c1 - c0);
+    J.run_chunk(c, v);
+  }
+  J.stitch();
+  if (replays) *replays = J.replays;
+  const int64_t m = (int64_t)J.result.size();
+  for (int64_t i = 0; i < m && i < cap; ++i) out[i] = J.result[(size_t)i];
+  return m;
+}
+
