@@ -23,6 +23,7 @@
  *     wfm_add_minmers[_multi] <- CommonFunc::addMinmers, commonFunc.hpp:440-708
  *     wfm_prefilter_kmers   <- (no counterpart: the device-side thinning of addMinmers' input stream)
  *     wfm_index_build       <- Sketch::build (index stage), winSketch.hpp:266-429
+ *     wfm_index_build_sequences <- Sketch::build as a whole, winSketch.hpp:175-457
  *     wfm_map_l1            <- getSeedIntervalPoints + computeL1CandidateRegions, mappingCore.hpp:82-301
  *     wfm_map_l2            <- computeL2MappedRegions + SlideMapper + doL2Mapping,
  *                              mappingCore.hpp:307-442, slidingMap.hpp:28-212, computeMap.hpp:989-1061
@@ -210,6 +211,14 @@ int64_t wfm_add_minmers(wfm_handle_t* h, const char* seq, int64_t len, int k, in
  * cap; only cap are written) or a WFM_E_* code. */
 int64_t wfm_add_minmers_multi(wfm_handle_t* h, const char* const* seqs, const int64_t* lens, const int32_t* seq_ids,
                               int64_t nseq, int k, int w, int s, int threads, wfm_minmer_t* out, int64_t cap, int64_t* counts);
+
+/* Sketch::build in one call (winSketch.hpp:175-457): wfm_add_minmers_multi followed by wfm_index_build, with the
+ * minmer intervals going from the host workers straight to the device (no host array of all intervals).  The
+ * index equals wfm_index_build(wfm_add_minmers_multi(...)).  *n_windows (optional) receives the number of
+ * intervals; when it is 0 no index is made and *out stays NULL. */
+int wfm_index_build_sequences(wfm_handle_t* h, const char* const* seqs, const int64_t* lens, const int32_t* seq_ids,
+                              int64_t nseq, int k, int w, int s, int threads, double max_kmer_freq,
+                              wfm_index_t** out, int64_t* n_windows);
 
 /* The k-mers of a sequence that wfm_add_minmers_multi lets its host workers see: valid k-mers whose hash
  * is under the threshold that lets c_factor * s of a window's w-k+1 k-mers through, plus every valid k-mer of a window that may hold

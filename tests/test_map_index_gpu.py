@@ -39,6 +39,14 @@ def _check(gpu, seqs, k, w, s, max_freq):
         got = [[int(p["pos"]), int(p["hash"]), int(p["seqId"]), int(p["side"])] for p in pts[po[u]:po[u + 1]]]
         assert got == lookup[int(hsh)], hex(int(hsh))
     assert [(int(x["hash"]), int(x["wpos"]), int(x["wpos_end"]), int(x["seqId"]), int(x["strand"])) for x in kept] == index
+    # Sketch::build in one call: GPU hashing, thinned threaded winnowing, intervals straight to the device
+    ix2, nw = gpu.index_build_sequences(seqs, k, w, s, threads=4, max_kmer_freq=max_freq)
+    assert nw == len(mm)
+    inf2 = ix2.info()
+    assert [getattr(inf2, f) for f, _ in inf2._fields_] == [getattr(inf, f) for f, _ in inf._fields_]
+    for a, b in zip(ix2.download(), (uh, po, pts, kept)):
+        assert a.tobytes() == b.tobytes()
+    ix2.free()
     ix.free()
     return inf
 

@@ -25,7 +25,7 @@ EXPORTS = [
     "wfm_hash_kmers", "wfm_sketch_fragments", "wfm_add_minmers",
     "wfm_index_build", "wfm_index_free", "wfm_index_info", "wfm_index_download",
     "wfm_map_l1", "wfm_map_l2", "wfm_map_fragments", "wfm_minhash_sketch", "wfm_add_minmers_multi",
-    "wfm_prefilter_kmers",
+    "wfm_prefilter_kmers", "wfm_index_build_sequences",
 ]
 
 
@@ -351,6 +351,29 @@ class Handle:
         if rc != 0:
             raise WfmError(f"wfm_index_build failed ({rc}): {self.last_error()}")
         return Index(self, ix)
+
+    def index_build_sequences(self, seqs, k: int, w: int, s: int, seq_ids=None, threads: int = 1, max_kmer_freq=0.0002):
+        """wfm_index_build_sequences: Sketch::build in one call; returns (Index or None, number of minmer intervals)."""
+        n = len(seqs)
+        ids = np.ascontiguousarray(seq_ids if seq_ids is not None else range(n), dtype=np.int32)
+        bufs = [np.frombuffer(x, dtype=np.uint8) for x in seqs]
+        ptrs = (C.c_void_p * n)(*[b.ctypes.data for b in bufs])
+        lens = np.array([len(x) for x in seqs], dtype=np.int64)
+        L = self._L
+        L.wfm_index_free.restype = None
+        L.wfm_index_free.argtypes = [C.c_void_p, C.c_void_p]
+        L.wfm_index_info.argtypes = [C.c_void_p, C.POINTER(IndexInfo)]
+        L.wfm_index_download.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        f = L.wfm_index_build_sequences
+        f.restype = C.c_int
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double,
+                      C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
+        ix = C.c_void_p()
+        nw = C.c_int64(0)
+        rc = f(self._p, ptrs, lens.ctypes.data, ids.ctypes.data, n, k, w, s, threads, max_kmer_freq, C.byref(ix), C.byref(nw))
+        if rc != 0:
+            raise WfmError(f"wfm_index_build_sequences failed ({rc}): {self.last_error()}")
+        return (Index(self, ix) if ix.value else None), nw.value
 
     def map_l1(self, index, qsketch, qcount, q_seq_id, q_len, q_active, s, params, ref_group):
         """wfm_map_l1: L1 candidate regions of a batch of query fragments.  params: the dict of oracle/map_l1.py."""

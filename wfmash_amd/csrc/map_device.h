@@ -40,6 +40,9 @@ int map_l2_device(wfm_handle_t* h, MapScratch& sc, const wfm_index_t* ix, const 
                   const int32_t* d_qlen, const uint8_t* d_kc, int64_t nfrag, int s, const wfm_l1_candidate_t* d_cands,
                   int64_t ncand, const wfm_l2_params_t* prm, wfm_mapping_t** d_out, int32_t** d_frag, int64_t* n_out);
 
+// The index stage on minmer intervals that are already on the device (map_index.hip); d_minmers stays the caller's.
+int map_index_build_device(wfm_handle_t* h, const wfm_minmer_t* d_minmers, int64_t n, double max_kmer_freq, wfm_index_t** out);
+
 // One sequence normalised and hashed on the device, left there so that host threads can pull the
 // slices they work on in parallel (each through its own per-thread stream).
 struct MapHashedSeq {
@@ -48,8 +51,19 @@ struct MapHashedSeq {
   int8_t* d_strand = nullptr;  // +1 / -1 / 0 (contains N or palindromic)
   int64_t len = 0, nk = 0;
   int device = 0;
+  bool borrowed = false;       // the arrays belong to a MapHashWork: valid until it hashes the next sequence
 };
 int map_hash_sequence_device(wfm_handle_t* h, const char* seq, int64_t len, int k, MapHashedSeq* out);
+// grow-only device buffers for hashing one sequence after the other without allocating each time
+struct MapHashWork {
+  uint8_t *d_raw = nullptr, *d_norm = nullptr;
+  uint64_t* d_hash = nullptr;
+  int8_t* d_strand = nullptr;
+  size_t cap = 0;  // bases
+  int device = 0;
+};
+int map_hash_sequence_into(wfm_handle_t* h, MapHashWork* wk, const char* seq, int64_t len, int k, MapHashedSeq* out);
+void map_hash_work_free(MapHashWork* wk);
 void map_hashed_free(MapHashedSeq* s);
 int map_hashed_fetch(const MapHashedSeq* s, int64_t from, int64_t to, int64_t base_from, int64_t base_to, uint64_t* hash, int8_t* strand,
                      char* norm);
@@ -90,8 +104,15 @@ inline uint64_t map_prefilter_tau(double c_factor, int s, int64_t W) {
   const long double t = 1.0L - sqrtl(1.0L - (long double)share);
   return (uint64_t)(t * 18446744073709551616.0L);
 }
+// grow-only scratch of the thinning passes (optional: without it every call allocates and frees its own)
+struct MapThinWork {
+  struct Buf { void* p = nullptr; size_t bytes = 0; };
+  Buf a, b, ck, ck2, cp, cp2, tmp;
+  int device = 0;
+};
+void map_thin_work_free(MapThinWork* wk);
 // W = k-mers per window (w - k + 1), s = sketch size, tau = hash threshold
-int map_prefilter_device(wfm_handle_t* h, const MapHashedSeq* q, int64_t W, int s, uint64_t tau, MapSparseSeq* out);
+int map_prefilter_device(wfm_handle_t* h, const MapHashedSeq* q, int64_t W, int s, uint64_t tau, MapSparseSeq* out, MapThinWork* wk = nullptr);
 void map_sparse_free(MapSparseSeq* s);
 // out[i] = number of kept k-mers with position < query[i] (host arrays)
 int map_sparse_lower_bound(wfm_handle_t* h, const MapSparseSeq* s, const int64_t* query, int nq, int64_t* out);

@@ -12,6 +12,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>  // rocprim's texture iterator calls host memset
 
 #include <rocprim/rocprim.hpp>
@@ -22,6 +25,7 @@
 
 #include "../../include/wfmash_hip.h"
 #include "wfa_handle.h"
+#include "map_device.h"
 
 struct wfm_index {
   int device = 0;
@@ -155,21 +159,39 @@ int wfm_index_build(wfm_handle_t* h, const wfm_minmer_t* minmers, int64_t n, dou
   if (!h || !out || (n && !minmers) || n < 0 || n >= (int64_t)1 << 31) return WFM_E_ARG;
   *out = nullptr;
   HIPCHK(h, hipSetDevice(wfm_device(h)));
+  Scratch sc;
+  wfm_minmer_t* d_m = nullptr;
+  if (n > 0) {
+    if (sc.alloc(&d_m, (size_t)n) != hipSuccess) { wfm_set_error(h, "out of device memory (index build)"); return WFM_E_NOMEM; }
+    HIPCHK(h, hipMemcpyAsync(d_m, minmers, (size_t)n * sizeof(wfm_minmer_t), hipMemcpyHostToDevice, wfm_stream(h)));
+  }
+  return map_index_build_device(h, d_m, n, max_kmer_freq, out);
+}
+
+}  // extern "C"
+
+// the index of n minmer intervals that are already on the device (input order = the reference's minmerIndex order)
+int map_index_build_device(wfm_handle_t* h, const wfm_minmer_t* d_m, int64_t n, double max_kmer_freq, wfm_index_t** out) {
+  if (!h || !out || n < 0 || n >= (int64_t)1 << 31 || (n && !d_m)) return WFM_E_ARG;
+  *out = nullptr;
+  HIPCHK(h, hipSetDevice(wfm_device(h)));
   hipStream_t st = wfm_stream(h);
   wfm_index* ix = new wfm_index();
   ix->device = wfm_device(h);
   ix->n_windows = n;
   if (n == 0) { *out = ix; return WFM_OK; }
   Scratch sc;
-  wfm_minmer_t* d_m = nullptr;
   uint64_t *d_k = nullptr, *d_k2 = nullptr, *d_ghash = nullptr;
   uint32_t *d_ord = nullptr, *d_ord2 = nullptr, *d_head = nullptr, *d_gid = nullptr, *d_freq = nullptr, *d_keep = nullptr,
            *d_chead = nullptr, *d_chain = nullptr, *d_gkeep = nullptr, *d_gkeep_incl = nullptr, *d_keep_in = nullptr, *d_keep_in_incl = nullptr;
   int64_t* d_gstart = nullptr;
 #define ALLOC(p, cnt) do { if (sc.alloc(&(p), (size_t)(cnt)) != hipSuccess) { delete ix; wfm_set_error(h, "out of device memory (index build)"); return WFM_E_NOMEM; } } while (0)
-  ALLOC(d_m, n); ALLOC(d_k, n); ALLOC(d_k2, n); ALLOC(d_ord, n); ALLOC(d_ord2, n); ALLOC(d_head, n); ALLOC(d_gid, n);
+  ALLOC(d_k, n); ALLOC(d_k2, n); ALLOC(d_ord, n); ALLOC(d_ord2, n); ALLOC(d_head, n); ALLOC(d_gid, n);
   ALLOC(d_keep, n); ALLOC(d_chead, n); ALLOC(d_chain, n); ALLOC(d_keep_in, n); ALLOC(d_keep_in_incl, n);
-  HIPCHK(h, hipMemcpyAsync(d_m, minmers, (size_t)n * sizeof(wfm_minmer_t), hipMemcpyHostToDevice, st));
+  const bool dbg = getenv("WFM_DEBUG") != nullptr;
+  auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  if (dbg) fprintf(stderr, "[wfm] index_build: %.1f MB of minmers", (double)n * 32 / 1e6);
+  const double t_b = now();
   hipLaunchKernelGGL(gather_hash, grid_for(n), dim3(256), 0, st, d_m, d_k, n);
   hipLaunchKernelGGL(iota_u32, grid_for(n), dim3(256), 0, st, d_ord, n);
   {  // stable radix sort of (hash, input index)
@@ -193,6 +215,8 @@ int wfm_index_build(wfm_handle_t* h, const wfm_minmer_t* minmers, int64_t n, dou
   std::vector<uint32_t> freq((size_t)ng);
   HIPCHK(h, hipMemcpyAsync(freq.data(), d_freq, (size_t)ng * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
   HIPCHK(h, hipStreamSynchronize(st));
+  if (dbg) fprintf(stderr, ", sort+groups+freq download (%lld groups) %.1f ms", (long long)ng, now() - t_b);
+  const double t_c = now();
   const uint64_t min_occ = 10;
   uint64_t thr;
   if (max_kmer_freq <= 1.0) thr = std::max(min_occ, (uint64_t)((double)n * max_kmer_freq));
@@ -208,6 +232,8 @@ int wfm_index_build(wfm_handle_t* h, const wfm_minmer_t* minmers, int64_t n, dou
     ix->adjusted = 1;
   }
   ix->threshold = thr;
+  if (dbg) fprintf(stderr, ", threshold on host %.1f ms", now() - t_c);
+  const double t_d = now();
   HIPCHK(h, hipMemsetAsync(d_gkeep, 0, (size_t)ng * sizeof(uint32_t), st));
   hipLaunchKernelGGL(mark_keep_and_chain, grid_for(n), dim3(256), 0, st, d_m, d_ord2, d_head, d_gid, d_freq, thr, d_keep, d_chead, d_gkeep, n);
   rc = inclusive_scan<uint32_t>(h, sc, d_chead, d_chain, n, st);
@@ -234,9 +260,12 @@ int wfm_index_build(wfm_handle_t* h, const wfm_minmer_t* minmers, int64_t n, dou
   HIPCHK(h, hipGetLastError());
   HIPCHK(h, hipStreamSynchronize(st));
 #undef ALLOC
+  if (dbg) fprintf(stderr, ", emit %.1f ms\n", now() - t_d);
   *out = ix;
   return WFM_OK;
 }
+
+extern "C" {
 
 void wfm_index_free(wfm_handle_t* h, wfm_index_t* ix) {
   if (!ix) return;

@@ -312,7 +312,50 @@ int map_hash_sequence_device(wfm_handle_t* h, const char* seq, int64_t len, int 
   return WFM_OK;
 }
 
+void map_hash_work_free(MapHashWork* wk) {
+  (void)hipSetDevice(wk->device);
+  if (wk->d_raw) (void)hipFree(wk->d_raw);
+  if (wk->d_norm) (void)hipFree(wk->d_norm);
+  if (wk->d_hash) (void)hipFree(wk->d_hash);
+  if (wk->d_strand) (void)hipFree(wk->d_strand);
+  *wk = MapHashWork();
+}
+
+int map_hash_sequence_into(wfm_handle_t* h, MapHashWork* wk, const char* seq, int64_t len, int k, MapHashedSeq* out) {
+  *out = MapHashedSeq();
+  out->len = len; out->nk = len - k + 1; out->device = wfm_device(h); out->borrowed = true;
+  if (out->nk <= 0) return WFM_OK;
+  HIPCHK(h, hipSetDevice(wfm_device(h)));
+  hipStream_t st = wfm_stream(h);
+  if ((size_t)len > wk->cap) {
+    map_hash_work_free(wk);
+    wk->device = wfm_device(h);
+    const size_t cap = (size_t)len + (size_t)len / 8;  // a little room: chromosomes come in similar sizes
+    hipError_t e = hipMalloc((void**)&wk->d_raw, cap + 64);
+    if (e == hipSuccess) e = hipMalloc((void**)&wk->d_norm, cap + 64);
+    if (e == hipSuccess) e = hipMalloc((void**)&wk->d_hash, cap * 8);
+    if (e == hipSuccess) e = hipMalloc((void**)&wk->d_strand, cap);
+    if (e != hipSuccess) {
+      map_hash_work_free(wk);
+      wfm_set_error(h, std::string("hipMalloc: ") + hipGetErrorString(e));
+      return e == hipErrorOutOfMemory ? WFM_E_NOMEM : WFM_E_HIP;
+    }
+    wk->cap = cap;
+  }
+  HIPCHK(h, hipMemsetAsync(wk->d_norm + len, 'N', 64, st));  // the hash kernel reads whole words past the end
+  HIPCHK(h, hipMemcpyAsync(wk->d_raw, seq, (size_t)len, hipMemcpyHostToDevice, st));
+  const int64_t nthreads = (len + 15) / 16;
+  hipLaunchKernelGGL(normalize_kernel, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, st, wk->d_raw, wk->d_norm, len);
+  const int blocks = (int)std::min<int64_t>((out->nk + 255) / 256, 256 * 8);
+  hipLaunchKernelGGL(kmer_hash_kernel, dim3(blocks), dim3(256), 0, st, wk->d_norm, out->nk, k, wk->d_hash, wk->d_strand);
+  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, hipStreamSynchronize(st));
+  out->d_norm = wk->d_norm; out->d_hash = wk->d_hash; out->d_strand = wk->d_strand;
+  return WFM_OK;
+}
+
 void map_hashed_free(MapHashedSeq* s) {
+  if (s->borrowed) { s->d_norm = nullptr; s->d_hash = nullptr; s->d_strand = nullptr; return; }
   (void)hipSetDevice(s->device);
   if (s->d_norm) (void)hipFree(s->d_norm);
   if (s->d_hash) (void)hipFree(s->d_hash);

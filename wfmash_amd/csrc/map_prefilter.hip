@@ -94,11 +94,31 @@ __global__ void pf_lower_bound_kernel(const uint32_t* __restrict__ pos, int64_t 
   out[q] = lo;
 }
 
-int scan_u32(wfm_handle_t* h, MapScratch& sc, const uint32_t* in, uint32_t* out, int64_t n, hipStream_t st) {
+// a buffer of the caller's grow-only workspace, or (without one) an allocation that lives until the call returns
+int need(wfm_handle_t* h, MapScratch& sc, MapThinWork::Buf* slot, size_t bytes, void** out) {
+  if (!slot) {
+    char* p = nullptr;
+    HIPCHK(h, sc.alloc(&p, bytes));
+    *out = p;
+    return WFM_OK;
+  }
+  if (slot->bytes < bytes) {
+    if (slot->p) (void)hipFree(slot->p);
+    slot->p = nullptr; slot->bytes = 0;
+    const size_t want = bytes + bytes / 8;
+    HIPCHK(h, hipMalloc(&slot->p, want));
+    slot->bytes = want;
+  }
+  *out = slot->p;
+  return WFM_OK;
+}
+
+int scan_u32(wfm_handle_t* h, MapScratch& sc, MapThinWork* wk, const uint32_t* in, uint32_t* out, int64_t n, hipStream_t st) {
   size_t tmp = 0;
   HIPCHK(h, rocprim::inclusive_scan(nullptr, tmp, in, out, (size_t)n, rocprim::plus<uint32_t>(), st));
-  char* d_tmp = nullptr;
-  HIPCHK(h, sc.alloc(&d_tmp, tmp));
+  void* d_tmp = nullptr;
+  const int rc = need(h, sc, wk ? &wk->tmp : nullptr, tmp, &d_tmp);
+  if (rc != WFM_OK) return rc;
   HIPCHK(h, rocprim::inclusive_scan(d_tmp, tmp, in, out, (size_t)n, rocprim::plus<uint32_t>(), st));
   return WFM_OK;
 }
@@ -106,6 +126,14 @@ int scan_u32(wfm_handle_t* h, MapScratch& sc, const uint32_t* in, uint32_t* out,
 inline dim3 grid_for(int64_t n) { return dim3((unsigned)((n + 255) / 256)); }
 
 }  // namespace
+
+void map_thin_work_free(MapThinWork* wk) {
+  (void)hipSetDevice(wk->device);
+  for (MapThinWork::Buf* b : {&wk->a, &wk->b, &wk->ck, &wk->ck2, &wk->cp, &wk->cp2, &wk->tmp}) {
+    if (b->p) (void)hipFree(b->p);
+    b->p = nullptr; b->bytes = 0;
+  }
+}
 
 void map_sparse_free(MapSparseSeq* s) {
   (void)hipSetDevice(s->device);
@@ -115,7 +143,7 @@ void map_sparse_free(MapSparseSeq* s) {
   s->d_pos = nullptr; s->d_hash = nullptr; s->d_strand = nullptr; s->m = 0;
 }
 
-int map_prefilter_device(wfm_handle_t* h, const MapHashedSeq* q, int64_t W, int s, uint64_t tau, MapSparseSeq* out) {
+int map_prefilter_device(wfm_handle_t* h, const MapHashedSeq* q, int64_t W, int s, uint64_t tau, MapSparseSeq* out, MapThinWork* wk) {
   out->d_pos = nullptr; out->d_hash = nullptr; out->d_strand = nullptr; out->m = 0; out->device = q->device;
   const int64_t n = q->nk;
   if (n <= 0) return WFM_OK;
@@ -123,12 +151,14 @@ int map_prefilter_device(wfm_handle_t* h, const MapHashedSeq* q, int64_t W, int 
   HIPCHK(h, hipSetDevice(q->device));
   hipStream_t st = wfm_stream(h);
   MapScratch sc;
+  if (wk) wk->device = q->device;
   uint32_t *A = nullptr, *B = nullptr;
-  HIPCHK(h, sc.alloc(&A, (size_t)n));
-  HIPCHK(h, sc.alloc(&B, (size_t)n));
+  int rc = need(h, sc, wk ? &wk->a : nullptr, (size_t)n * 4, (void**)&A);
+  if (rc == WFM_OK) rc = need(h, sc, wk ? &wk->b : nullptr, (size_t)n * 4, (void**)&B);
+  if (rc != WFM_OK) return rc;
   // candidates: valid and hash <= tau
   hipLaunchKernelGGL(pf_cand_kernel, grid_for(n), dim3(256), 0, st, q->d_hash, q->d_strand, tau, A, n);
-  int rc = scan_u32(h, sc, A, B, n, st);
+  rc = scan_u32(h, sc, wk, A, B, n, st);
   if (rc != WFM_OK) return rc;
   uint32_t mc32 = 0;
   HIPCHK(h, hipMemcpyAsync(&mc32, B + (n - 1), 4, hipMemcpyDeviceToHost, st));
@@ -137,25 +167,29 @@ int map_prefilter_device(wfm_handle_t* h, const MapHashedSeq* q, int64_t W, int 
   uint64_t *ck = nullptr, *ck2 = nullptr;
   uint32_t *cp = nullptr, *cp2 = nullptr;
   if (mc > 0) {
-    HIPCHK(h, sc.alloc(&ck, (size_t)mc)); HIPCHK(h, sc.alloc(&ck2, (size_t)mc));
-    HIPCHK(h, sc.alloc(&cp, (size_t)mc)); HIPCHK(h, sc.alloc(&cp2, (size_t)mc));
+    rc = need(h, sc, wk ? &wk->ck : nullptr, (size_t)mc * 8, (void**)&ck);
+    if (rc == WFM_OK) rc = need(h, sc, wk ? &wk->ck2 : nullptr, (size_t)mc * 8, (void**)&ck2);
+    if (rc == WFM_OK) rc = need(h, sc, wk ? &wk->cp : nullptr, (size_t)mc * 4, (void**)&cp);
+    if (rc == WFM_OK) rc = need(h, sc, wk ? &wk->cp2 : nullptr, (size_t)mc * 4, (void**)&cp2);
+    if (rc != WFM_OK) return rc;
     hipLaunchKernelGGL(pf_scatter_cand_kernel, grid_for(n), dim3(256), 0, st, q->d_hash, A, B, ck, cp, n);
     size_t tmp = 0;
     HIPCHK(h, rocprim::radix_sort_pairs(nullptr, tmp, ck, ck2, cp, cp2, (size_t)mc, 0, 64, st));
-    char* d_tmp = nullptr;
-    HIPCHK(h, sc.alloc(&d_tmp, tmp));
+    void* d_tmp = nullptr;
+    rc = need(h, sc, wk ? &wk->tmp : nullptr, tmp, &d_tmp);
+    if (rc != WFM_OK) return rc;
     HIPCHK(h, rocprim::radix_sort_pairs(d_tmp, tmp, ck, ck2, cp, cp2, (size_t)mc, 0, 64, st));  // stable: positions ascend within a hash
   }
   // fresh candidates -> per-window lower bound of the distinct count
   HIPCHK(h, hipMemsetAsync(A, 0, (size_t)n * 4, st));
   if (mc > 0) hipLaunchKernelGGL(pf_fresh_kernel, grid_for(mc), dim3(256), 0, st, ck2, cp2, mc, (uint32_t)std::min<int64_t>(W, 0xffffffffll), A);
-  rc = scan_u32(h, sc, A, B, n, st);
+  rc = scan_u32(h, sc, wk, A, B, n, st);
   if (rc != WFM_OK) return rc;
   hipLaunchKernelGGL(pf_deficient_kernel, grid_for(n), dim3(256), 0, st, B, n, W, (uint32_t)s, A);
-  rc = scan_u32(h, sc, A, B, n, st);
+  rc = scan_u32(h, sc, wk, A, B, n, st);
   if (rc != WFM_OK) return rc;
   hipLaunchKernelGGL(pf_keep_kernel, grid_for(n), dim3(256), 0, st, q->d_hash, q->d_strand, tau, B, n, W, A);
-  rc = scan_u32(h, sc, A, B, n, st);
+  rc = scan_u32(h, sc, wk, A, B, n, st);
   if (rc != WFM_OK) return rc;
   uint32_t m32 = 0;
   HIPCHK(h, hipMemcpyAsync(&m32, B + (n - 1), 4, hipMemcpyDeviceToHost, st));

@@ -3,6 +3,8 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <iostream>
@@ -171,38 +173,25 @@ int Map::mapQuery(MapSummary* summary) {
   for (const auto& subset : subsets) {
     // ---- index of this subset (Sketch::build)
     double t0 = now_ms();
-    std::vector<wfm_minmer_t> minmers;
+    wfm_index_t* ix = nullptr;
     {
       std::vector<const char*> sp;
       std::vector<int64_t> sl;
       std::vector<int32_t> si;
-      int64_t bases = 0;
       for (const auto& name : subset) {
         const std::string* seq = src.find(P.refSequences, name);
         if (!seq) { wfm_set_error(h_, "target sequence not found in FASTA: " + name); return WFM_E_ARG; }
         if ((int64_t)seq->size() < w) continue;  // "skipping short sequence" (winSketch.hpp:216-229)
         sp.push_back(seq->data()); sl.push_back((int64_t)seq->size()); si.push_back(ids.getSequenceId(name));
-        bases += (int64_t)seq->size();
       }
-      // about 2 s / w intervals per base; grown on demand
-      minmers.resize((size_t)(bases / std::max<int64_t>(1, w) * S * 3 + 4096));
-      int64_t n = wfm_add_minmers_multi(h_, sp.data(), sl.data(), si.data(), (int64_t)sp.size(), k, (int)w, S, P.threads, minmers.data(),
-                                        (int64_t)minmers.size(), nullptr);
-      if (n > (int64_t)minmers.size()) {
-        minmers.resize((size_t)n);
-        n = wfm_add_minmers_multi(h_, sp.data(), sl.data(), si.data(), (int64_t)sp.size(), k, (int)w, S, P.threads, minmers.data(),
-                                  (int64_t)minmers.size(), nullptr);
-      }
-      if (n < 0) return (int)n;
-      minmers.resize((size_t)n);
-    }
-    sum.index_windows += minmers.size();
-    wfm_index_t* ix = nullptr;
-    if (!minmers.empty()) {
-      const int rc = wfm_index_build(h_, minmers.data(), (int64_t)minmers.size(), P.max_kmer_freq, &ix);
+      // minmer intervals (GPU hashing + thinning, host winnowing) and the index stage; the intervals never
+      // sit in one host array
+      int64_t n_windows = 0;
+      const int rc = wfm_index_build_sequences(h_, sp.data(), sl.data(), si.data(), (int64_t)sp.size(), k, (int)w, S, P.threads,
+                                               P.max_kmer_freq, &ix, &n_windows);
       if (rc != WFM_OK) return rc;
+      sum.index_windows += (uint64_t)n_windows;
     }
-    std::vector<wfm_minmer_t>().swap(minmers);
     sum.ms_index += now_ms() - t0;
 
     // ---- queries, in batches of whole sequences

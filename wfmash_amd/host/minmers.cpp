@@ -424,6 +424,7 @@ struct SeqJob {
   std::atomic<int> pending{0};
   int replays = 0;
   int fetch_rc = WFM_OK;
+  std::atomic<bool> stitched{false};   // result is final
   std::vector<wfm_minmer_t> result;
   MapHashedSeq dev;          // the hashed sequence on the device: the source of every slice
   bool on_device = false;
@@ -432,6 +433,9 @@ struct SeqJob {
   MapSparseSeq sparse;
   std::string head;                      // the first normalised bases: the k-mers the device cannot judge (Winnower)
   std::vector<int64_t> cidx, cidx_warm;  // kept k-mers before bounds[j] / before warm_from(j)
+  const char* raw = nullptr;             // the caller's sequence, handle and GPU lock: to hash it again if the
+  wfm_handle_t* handle = nullptr;        //   dense stream is needed after all (stitch()'s fall-back)
+  std::mutex* gpu_mu = nullptr;
   std::vector<uint32_t> h_pos;           // test hook: the kept k-mers in host memory
   std::vector<uint64_t> h_hash;
   std::vector<int8_t> h_strand;
@@ -490,6 +494,13 @@ struct SeqJob {
   Slice refetch(int64_t kf, int64_t kt, std::vector<char>& buf) {
     if (hash) return whole();
     buf.resize(map_stage_bytes(kt - kf, kt - kf + k - 1));
+    if (!on_device && raw && handle && gpu_mu) {
+      // thinned form: the dense arrays were only borrowed; hash the sequence again (the rare fall-back)
+      std::lock_guard<std::mutex> g(*gpu_mu);
+      const int hrc = map_hash_sequence_device(handle, raw, len, k, &dev);
+      if (hrc == WFM_OK) on_device = true; else fetch_rc = hrc;
+    }
+    if (!on_device) { if (fetch_rc == WFM_OK) fetch_rc = WFM_E_HIP; memset(buf.data(), 0, buf.size()); return packed(buf.data(), kf, kt); }
     const int rc = map_hashed_fetch_packed(&dev, kf, kt, kf, kt + k - 1, buf.data());
     if (rc != WFM_OK) { fetch_rc = rc; memset(buf.data(), 0, buf.size()); }
     return packed(buf.data(), kf, kt);
@@ -588,9 +599,16 @@ extern "C" int64_t wfm_add_minmers(wfm_handle_t* h, const char* seq, int64_t len
 // side (the reference's ThreadPool over buildHelper, winSketch.hpp:200-239) and, within a long
 // sequence, its speculative chunks.  The host never holds more than one chunk per worker.
 // Output is the concatenation in input order.
-extern "C" int64_t wfm_add_minmers_multi(wfm_handle_t* h, const char* const* seqs, const int64_t* lens, const int32_t* seq_ids, int64_t nseq,
-                                         int k, int w, int s, int threads, wfm_minmer_t* out, int64_t cap, int64_t* counts) {
-  if (!h || nseq < 0 || (nseq && (!seqs || !lens || !seq_ids)) || (cap && !out)) return WFM_E_ARG;
+namespace {
+// where the records of the sequences go: put() is called once per sequence, in input order, from the calling thread
+struct MinmerSink {
+  virtual ~MinmerSink() = default;
+  virtual int put(const wfm_minmer_t* recs, int64_t n) = 0;
+};
+
+int64_t add_minmers_core(wfm_handle_t* h, const char* const* seqs, const int64_t* lens, const int32_t* seq_ids, int64_t nseq,
+                         int k, int w, int s, int threads, MinmerSink& sink, int64_t* counts) {
+  if (!h || nseq < 0 || (nseq && (!seqs || !lens || !seq_ids))) return WFM_E_ARG;
   if (k < 1 || k > 32 || w < k || s < 1) { wfm_set_error(h, "need 1 <= k <= 32, w >= k, s >= 1"); return WFM_E_UNSUPPORTED; }
   const int nthreads = std::max(1, threads);
   const int64_t chunk_len = nthreads > 1 ? chunk_length() : 0;
@@ -660,6 +678,7 @@ extern "C" int64_t wfm_add_minmers_multi(wfm_handle_t* h, const char* const* seq
       if (J->pending.fetch_sub(1) == 1) {  // last chunk of this sequence: stitch here
         J->stitch();
         if (J->fetch_rc != WFM_OK) async_rc.store(J->fetch_rc);
+        J->stitched.store(true, std::memory_order_release);
         {
           std::lock_guard<std::mutex> lk(mu);
           inflight_bases -= J->len;
@@ -718,6 +737,23 @@ extern "C" int64_t wfm_add_minmers_multi(wfm_handle_t* h, const char* const* seq
     }
   };
 
+  // finished sequences leave in input order while the later ones are still being worked on
+  int64_t next_out = 0, total = 0;
+  int sink_rc = WFM_OK;
+  auto flush_ready = [&](int64_t limit) {
+    for (; next_out < limit; ++next_out) {
+      SeqJob* J = jobs[(size_t)next_out].get();
+      if (J && !J->stitched.load(std::memory_order_acquire)) break;
+      const int64_t n = J ? (int64_t)J->result.size() : 0;
+      if (counts) counts[next_out] = n;
+      if (n && sink_rc == WFM_OK) sink_rc = sink.put(J->result.data(), n);
+      total += n;
+      if (J) std::vector<wfm_minmer_t>().swap(J->result);
+    }
+  };
+  std::mutex gpu_mu;  // the handle's stream and error string: this thread, and a worker that hashes a sequence again
+  MapHashWork hash_work;
+  MapThinWork thin_work;
   std::vector<std::thread> pool;
   for (int t = 0; t < nthreads; ++t) pool.emplace_back(worker);
   std::thread stream_thread;
@@ -736,18 +772,23 @@ extern "C" int64_t wfm_add_minmers_multi(wfm_handle_t* h, const char* const* seq
       inflight_bases += len;
     }
     release_stitched();
+    flush_ready(i);
     auto J = std::make_unique<SeqJob>();
     J->idx = i; J->seq_id = seq_ids[i]; J->len = len; J->nk = len - k + 1; J->k = k; J->w = w; J->s = s;
     const auto t0 = std::chrono::steady_clock::now();
-    rc = map_hash_sequence_device(h, seqs[i], len, k, &J->dev);  // GPU: normalise + 2 x MurmurHash3 per base
+    const bool thin = tau != 0 && J->nk >= W && J->nk < ((int64_t)1 << 32) - 1;
+    std::unique_lock<std::mutex> gpu(gpu_mu);
+    // GPU: normalise + 2 x MurmurHash3 per base; the thinned form reuses one set of device buffers
+    rc = thin ? map_hash_sequence_into(h, &hash_work, seqs[i], len, k, &J->dev) : map_hash_sequence_device(h, seqs[i], len, k, &J->dev);
     if (rc != WFM_OK) break;
     J->on_device = true;
     ms_hash += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     J->plan(streamed ? chunk_len : 0);
     const auto t1 = std::chrono::steady_clock::now();
-    if (tau != 0 && J->nk >= W && J->nk < ((int64_t)1 << 32) - 1) {
-      // thin the stream on the device; the dense arrays stay there for the one-stream fall-back
-      rc = map_prefilter_device(h, &J->dev, W, s, tau, &J->sparse);
+    if (thin) {
+      // thin the stream on the device; only the kept k-mers outlive this iteration
+      J->raw = seqs[i]; J->handle = h; J->gpu_mu = &gpu_mu;
+      rc = map_prefilter_device(h, &J->dev, W, s, tau, &J->sparse, &thin_work);
       if (rc != WFM_OK) { map_hashed_free(&J->dev); break; }
       J->thinned = true;
       kept_kmers += J->sparse.m;
@@ -762,7 +803,10 @@ extern "C" int64_t wfm_add_minmers_multi(wfm_handle_t* h, const char* const* seq
       if (rc != WFM_OK) { map_hashed_free(&J->dev); map_sparse_free(&J->sparse); break; }
       J->cidx.assign(r.begin(), r.begin() + (long)nc + 1);
       J->cidx_warm.assign(r.begin() + (long)nc + 1, r.end());
+      map_hashed_free(&J->dev);  // borrowed: just forgets the pointers
+      J->on_device = false;
     }
+    gpu.unlock();
     ms_thin += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count();
     SeqJob* Jp = J.get();
     jobs[(size_t)i] = std::move(J);
@@ -799,7 +843,9 @@ extern "C" int64_t wfm_add_minmers_multi(wfm_handle_t* h, const char* const* seq
   for (auto& t : pool) t.join();
   release_stitched();
   for (auto& J : jobs)
-    if (J && J->on_device) { map_hashed_free(&J->dev); J->on_device = false; }  // after an error
+    if (J) { if (J->on_device) { map_hashed_free(&J->dev); J->on_device = false; } map_sparse_free(&J->sparse); }  // after an error
+  map_hash_work_free(&hash_work);
+  map_thin_work_free(&thin_work);
   if (getenv("WFM_DEBUG")) {
     int64_t nchunks = 0, replays = 0;
     for (const auto& J : jobs)
@@ -812,14 +858,67 @@ extern "C" int64_t wfm_add_minmers_multi(wfm_handle_t* h, const char* const* seq
   }
   if (rc == WFM_OK && async_rc.load() != WFM_OK) { rc = async_rc.load(); wfm_set_error(h, "device-to-host streaming of k-mer hashes failed"); }
   if (rc != WFM_OK) return rc;
-  int64_t total = 0;
-  for (int64_t i = 0; i < nseq; ++i) {
-    const size_t n = jobs[(size_t)i] ? jobs[(size_t)i]->result.size() : 0;
-    if (counts) counts[i] = (int64_t)n;
-    if (n && total < cap) memcpy(out + total, jobs[(size_t)i]->result.data(), (size_t)std::min<int64_t>((int64_t)n, cap - total) * sizeof(wfm_minmer_t));
-    total += (int64_t)n;
-  }
+  flush_ready(nseq);
+  if (sink_rc != WFM_OK) return sink_rc;
   return total;
+}
+
+// records into the caller's array, as far as it goes
+struct HostSink : MinmerSink {
+  wfm_minmer_t* out; int64_t cap, at = 0;
+  HostSink(wfm_minmer_t* o, int64_t c) : out(o), cap(c) {}
+  int put(const wfm_minmer_t* recs, int64_t n) override {
+    if (at < cap) memcpy(out + at, recs, (size_t)std::min(n, cap - at) * sizeof(wfm_minmer_t));
+    at += n;
+    return WFM_OK;
+  }
+};
+
+// records into one growing device array (the index is built from it without a detour through host memory)
+struct DeviceSink : MinmerSink {
+  wfm_handle_t* h;
+  wfm_minmer_t* d = nullptr;
+  int64_t cap = 0, n = 0;
+  DeviceSink(wfm_handle_t* hh, int64_t expect) : h(hh), cap(std::max<int64_t>(expect, 4096)) {}
+  ~DeviceSink() override { if (d) (void)hipFree(d); }
+  int put(const wfm_minmer_t* recs, int64_t m) override {
+    if (hipSetDevice(wfm_device(h)) != hipSuccess) return WFM_E_HIP;
+    if (!d || n + m > cap) {
+      int64_t want = d ? std::max(cap + cap / 2, n + m) : std::max(cap, m);
+      wfm_minmer_t* nd = nullptr;
+      if (hipMalloc((void**)&nd, (size_t)want * sizeof(wfm_minmer_t)) != hipSuccess) { wfm_set_error(h, "out of device memory (minmer intervals)"); return WFM_E_NOMEM; }
+      if (d && n && hipMemcpy(nd, d, (size_t)n * sizeof(wfm_minmer_t), hipMemcpyDeviceToDevice) != hipSuccess) { (void)hipFree(nd); return WFM_E_HIP; }
+      if (d) (void)hipFree(d);
+      d = nd; cap = want;
+    }
+    if (hipMemcpy(d + n, recs, (size_t)m * sizeof(wfm_minmer_t), hipMemcpyHostToDevice) != hipSuccess) { wfm_set_error(h, "upload of minmer intervals failed"); return WFM_E_HIP; }
+    n += m;
+    return WFM_OK;
+  }
+};
+}  // namespace
+
+extern "C" int64_t wfm_add_minmers_multi(wfm_handle_t* h, const char* const* seqs, const int64_t* lens, const int32_t* seq_ids, int64_t nseq,
+                                         int k, int w, int s, int threads, wfm_minmer_t* out, int64_t cap, int64_t* counts) {
+  if (cap && !out) return WFM_E_ARG;
+  HostSink sink(out, cap);
+  return add_minmers_core(h, seqs, lens, seq_ids, nseq, k, w, s, threads, sink, counts);
+}
+
+// Sketch::build in one call (winSketch.hpp:175-457): minmer intervals of all sequences, then the index stage, with
+// the intervals going from the workers straight to the device.  *n_windows (optional) = number of intervals.
+extern "C" int wfm_index_build_sequences(wfm_handle_t* h, const char* const* seqs, const int64_t* lens, const int32_t* seq_ids, int64_t nseq,
+                                         int k, int w, int s, int threads, double max_kmer_freq, wfm_index_t** out, int64_t* n_windows) {
+  if (!h || !out) return WFM_E_ARG;
+  *out = nullptr;
+  int64_t bases = 0;
+  for (int64_t i = 0; i < nseq && lens; ++i) bases += std::max<int64_t>(0, lens[i]);
+  DeviceSink sink(h, bases / std::max(1, w) * (int64_t)s * 5 / 2 + 4096);  // about 2 s / w intervals per base
+  const int64_t n = add_minmers_core(h, seqs, lens, seq_ids, nseq, k, w, s, threads, sink, nullptr);
+  if (n < 0) return (int)n;
+  if (n_windows) *n_windows = n;
+  if (n == 0) return WFM_OK;  // no index: *out stays NULL
+  return map_index_build_device(h, sink.d, n, max_kmer_freq, out);
 }
 
 // Test hook (CPU test-suite): the host winnowing stage on caller-supplied k-mer hashes.
