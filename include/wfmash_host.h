@@ -76,6 +76,10 @@ int64_t wfmh_test_winnow_thinned(const char* seq, int64_t len, int k, int w, int
                                  wfm_minmer_t* out, int64_t cap, uint32_t* kept_pos, int64_t cap_kept,
                                  int64_t* n_kept, int* replays);
 
+/* the closing sort of a sequence's records by (wpos, wpos_end) (commonFunc.hpp:696): threads == 1 is std::sort,
+ * threads > 1 the same introsort with its halves on several threads -- same result, ties included */
+void wfmh_test_sort_records(wfm_minmer_t* recs, int64_t n, int threads);
+
 /* ---- map phase (skch::Map, src/map/include/computeMap.hpp) ---- */
 
 /* skch::Parameters as set up by parse_args.hpp; wfmh_map_default_params fills the defaults

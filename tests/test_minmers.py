@@ -148,6 +148,24 @@ def test_thinned_winnowing_equals_single_stream():
     assert total_kept < 0.6 * total, (total_kept, total)
 
 
+def test_spread_sort_equals_std_sort_ties_included():
+    """records tie under the reference's (wpos, wpos_end) order and std::sort's tie order is part of the output:
+    the multi-threaded form must reproduce it exactly"""
+    rng = np.random.default_rng(5)
+    for n, span in ((300_000, 40_000), (1_500_000, 1_000_000), (700_000, 50)):
+        recs = np.zeros(n, dtype=capi.MINMER_DTYPE)
+        # nearly sorted with local disorder and many ties, like a sequence's records
+        base = np.sort(rng.integers(0, span, n))
+        recs["wpos"] = base + rng.integers(-3, 4, n)
+        recs["wpos_end"] = recs["wpos"] + rng.integers(1, 4, n)
+        recs["hash"] = rng.integers(0, 2**63, n, dtype=np.int64).astype(np.uint64)
+        recs["seqId"] = 1
+        one = capi.host_sort_records(recs, 1)
+        assert (np.diff(one["wpos"]) >= 0).all()
+        for threads in (2, 8, 16):
+            assert capi.host_sort_records(recs, threads).tobytes() == one.tobytes(), (n, span, threads)
+
+
 def capi_norm(seq: bytes) -> bytes:
     """upper-case / N-mask as the hashing kernel does (the oracle hashes what it is given)"""
     up = seq.upper()

@@ -538,7 +538,7 @@ class Handle:
 # host-side align driver (include/wfmash_host.h)
 # ---------------------------------------------------------------------------
 HOST_EXPORTS = ["wfmh_align_default_params", "wfmh_align_paf", "wfmh_test_cigar", "wfmh_free", "wfmh_test_winnow",
-                "wfmh_map_default_params", "wfmh_test_filter", "wfmh_map", "wfmh_test_winnow_chunked", "wfmh_test_fasta", "wfmh_test_winnow_thinned"]
+                "wfmh_map_default_params", "wfmh_test_filter", "wfmh_map", "wfmh_test_winnow_chunked", "wfmh_test_fasta", "wfmh_test_winnow_thinned", "wfmh_test_sort_records"]
 
 
 class MapSummary(C.Structure):
@@ -694,6 +694,16 @@ def host_winnow(seq: bytes, k: int, w: int, s: int, seq_id: int, hashes, strands
     strands = np.ascontiguousarray(strands, dtype=np.int8)
     n = L.wfmh_test_winnow(seq, len(seq), k, w, s, seq_id, hashes.ctypes.data, strands.ctypes.data, out.ctypes.data, cap)
     return out[:n]
+
+
+def host_sort_records(recs, threads: int):
+    """wfmh_test_sort_records: the closing (wpos, wpos_end) sort of a sequence's records; returns a sorted copy."""
+    L = load()
+    L.wfmh_test_sort_records.restype = None
+    L.wfmh_test_sort_records.argtypes = [C.c_void_p, C.c_int64, C.c_int]
+    a = np.array(recs, dtype=MINMER_DTYPE, copy=True)
+    L.wfmh_test_sort_records(a.ctypes.data, len(a), threads)
+    return a
 
 
 def host_winnow_thinned(seq: bytes, k: int, w: int, s: int, seq_id: int, hashes, strands, c_factor: float = 4.0, chunk_len: int = 0):

@@ -371,8 +371,42 @@ class Winnower {
   int64_t expired_in_refill() const { return expired_in_refill_; }
 };
 
+// std::sort, run by several threads, with std::sort's result to the last tie.
+// The reference orders a sequence's records by (wpos, wpos_end) alone (commonFunc.hpp:696), so where records tie
+// their order is whatever libstdc++'s introsort leaves -- and that order is part of the output.  The same routine
+// is therefore run here, only its independent halves side by side: introsort partitions, recurses into the right
+// part and loops on the left; the two parts never touch each other's elements, so handing the right part to
+// another thread changes nothing, and the closing insertion pass is the library's own.
+#if defined(__GLIBCXX__)
+template <typename It, typename Cmp>
+void introsort_loop_spread(It first, It last, long depth_limit, Cmp comp, long spawn_above) {
+  std::vector<std::thread> helpers;
+  while (last - first > (long)std::_S_threshold) {
+    if (depth_limit == 0) { std::__partial_sort(first, last, last, comp); break; }
+    --depth_limit;
+    It cut = std::__unguarded_partition_pivot(first, last, comp);
+    if (last - cut > spawn_above) helpers.emplace_back([=] { introsort_loop_spread(cut, last, depth_limit, comp, spawn_above); });
+    else std::__introsort_loop(cut, last, depth_limit, comp);
+    last = cut;
+  }
+  for (auto& t : helpers) t.join();
+}
+template <typename It, typename Compare>
+void sort_as_std(It first, It last, Compare comp, int threads) {
+  if (first == last) return;
+  const long n = last - first;
+  if (threads <= 1 || n < ((long)1 << 18)) { std::sort(first, last, comp); return; }
+  auto c = __gnu_cxx::__ops::__iter_comp_iter(comp);
+  introsort_loop_spread(first, last, std::__lg(n) * 2, c, std::max<long>(n / (2 * (long)threads), (long)1 << 15));
+  std::__final_insertion_sort(first, last, c);
+}
+#else
+template <typename It, typename Compare>
+void sort_as_std(It first, It last, Compare comp, int) { std::sort(first, last, comp); }
+#endif
+
 // strand sign, chunks of at most w windows, order, de-duplication (commonFunc.hpp:660-706)
-void finish_records(std::vector<wfm_minmer_t>& out, int w) {
+void finish_records(std::vector<wfm_minmer_t>& out, int w, int threads = 1) {
   out.erase(std::remove_if(out.begin(), out.end(), [](const wfm_minmer_t& m) { return m.wpos < 0 || m.wpos_end < 0 || m.wpos == m.wpos_end; }), out.end());
   std::vector<wfm_minmer_t> chunks;
   for (auto& m : out) {
@@ -385,7 +419,7 @@ void finish_records(std::vector<wfm_minmer_t>& out, int w) {
   }
   out.erase(std::remove_if(out.begin(), out.end(), [w](const wfm_minmer_t& m) { return m.wpos_end - m.wpos > w; }), out.end());
   out.insert(out.end(), chunks.begin(), chunks.end());
-  std::sort(out.begin(), out.end(), [](const wfm_minmer_t& l, const wfm_minmer_t& r) { return std::tie(l.wpos, l.wpos_end) < std::tie(r.wpos, r.wpos_end); });
+  sort_as_std(out.begin(), out.end(), [](const wfm_minmer_t& l, const wfm_minmer_t& r) { return std::tie(l.wpos, l.wpos_end) < std::tie(r.wpos, r.wpos_end); }, threads);
   out.erase(std::unique(out.begin(), out.end(), [](const wfm_minmer_t& l, const wfm_minmer_t& r) { return l.wpos == r.wpos && l.hash == r.hash; }), out.end());
 }
 
@@ -425,6 +459,8 @@ struct SeqJob {
   int replays = 0;
   int fetch_rc = WFM_OK;
   std::atomic<bool> stitched{false};   // result is final
+  int sort_threads = 1;                // for the closing sort of stitch()
+  double ms_stitch = 0;
   std::vector<wfm_minmer_t> result;
   MapHashedSeq dev;          // the hashed sequence on the device: the source of every slice
   bool on_device = false;
@@ -539,7 +575,7 @@ struct SeqJob {
       W.advance(0, nk);
       W.flush_end();
       result = std::move(W.out);
-      finish_records(result, w);
+      finish_records(result, w, sort_threads);
       norm.reset(); hash.reset(); strand.reset();
       return;
     }
@@ -562,7 +598,7 @@ struct SeqJob {
     for (const auto& c : chunk) result.insert(result.end(), c->out.begin(), c->out.end());
     chunk.clear();
     started_from.clear();
-    finish_records(result, w);
+    finish_records(result, w, sort_threads);
     norm.reset(); hash.reset(); strand.reset();
   }
 };
@@ -676,7 +712,9 @@ int64_t add_minmers_core(wfm_handle_t* h, const char* const* seqs, const int64_t
       }
       J->run_chunk(task.chunk, v);
       if (J->pending.fetch_sub(1) == 1) {  // last chunk of this sequence: stitch here
+        const auto ts = std::chrono::steady_clock::now();
         J->stitch();
+        J->ms_stitch = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ts).count();
         if (J->fetch_rc != WFM_OK) async_rc.store(J->fetch_rc);
         J->stitched.store(true, std::memory_order_release);
         {
@@ -775,6 +813,7 @@ int64_t add_minmers_core(wfm_handle_t* h, const char* const* seqs, const int64_t
     flush_ready(i);
     auto J = std::make_unique<SeqJob>();
     J->idx = i; J->seq_id = seq_ids[i]; J->len = len; J->nk = len - k + 1; J->k = k; J->w = w; J->s = s;
+    J->sort_threads = std::min(16, nthreads);
     const auto t0 = std::chrono::steady_clock::now();
     const bool thin = tau != 0 && J->nk >= W && J->nk < ((int64_t)1 << 32) - 1;
     std::unique_lock<std::mutex> gpu(gpu_mu);
@@ -848,13 +887,14 @@ int64_t add_minmers_core(wfm_handle_t* h, const char* const* seqs, const int64_t
   map_thin_work_free(&thin_work);
   if (getenv("WFM_DEBUG")) {
     int64_t nchunks = 0, replays = 0;
+    double stitch_max = 0;
     for (const auto& J : jobs)
-      if (J) { nchunks += (int64_t)J->bounds.size() - 1; replays += J->replays; }
-    fprintf(stderr, "[wfm] add_minmers_multi: %lld sequences in %lld chunks (%lld replayed), %d workers, %s, %.1f %% of the k-mers kept: hashing thread %.1f ms (GPU hashing %.1f, thinning %.1f), drain %.1f ms\n",
+      if (J) { nchunks += (int64_t)J->bounds.size() - 1; replays += J->replays; stitch_max = std::max(stitch_max, J->ms_stitch); }
+    fprintf(stderr, "[wfm] add_minmers_multi: %lld sequences in %lld chunks (%lld replayed), %d workers, %s, %.1f %% of the k-mers kept: hashing thread %.1f ms (GPU hashing %.1f, thinning %.1f), drain %.1f ms (longest stitch %.1f)\n",
             (long long)nseq, (long long)nchunks, (long long)replays, nthreads, streamed ? "streamed through the pinned ring" : "whole sequences",
             thinned_kmers ? 100.0 * (double)kept_kmers / (double)thinned_kmers : 100.0,
             std::chrono::duration<double, std::milli>(t_fed - t_start).count(), ms_hash, ms_thin,
-            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_fed).count());
+            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_fed).count(), stitch_max);
   }
   if (rc == WFM_OK && async_rc.load() != WFM_OK) { rc = async_rc.load(); wfm_set_error(h, "device-to-host streaming of k-mer hashes failed"); }
   if (rc != WFM_OK) return rc;
@@ -1027,5 +1067,11 @@ extern "C" int64_t wfmh_test_winnow_thinned(const char* seq, int64_t len, int k,
   const int64_t m = (int64_t)J.result.size();
   for (int64_t i = 0; i < m && i < cap; ++i) out[i] = J.result[(size_t)i];
   return m;
+}
+
+// Test hook: the closing sort of a sequence's records, as stitch() runs it (threads > 1: introsort's halves side by
+// side; 1: std::sort itself).  The two must agree to the last tie.
+extern "C" void wfmh_test_sort_records(wfm_minmer_t* recs, int64_t n, int threads) {
+  sort_as_std(recs, recs + n, [](const wfm_minmer_t& l, const wfm_minmer_t& r) { return std::tie(l.wpos, l.wpos_end) < std::tie(r.wpos, r.wpos_end); }, threads);
 }
 
