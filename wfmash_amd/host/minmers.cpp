@@ -31,6 +31,8 @@
 //   arrivals  every valid k-mer still inside (or lingering behind) the window, arrival order
 //   sketch    ordered map hash -> open interval + occurrences: the <= s smallest hashes
 //   pool      lazy min-heap (hash, pos) of window k-mers that are not in the sketch
+#include <sys/mman.h>
+
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -405,22 +407,98 @@ template <typename It, typename Compare>
 void sort_as_std(It first, It last, Compare comp, int) { std::sort(first, last, comp); }
 #endif
 
+// The records of one sequence: one allocation of the final size, 2 MB aligned and marked for huge pages (a
+// chromosome's records are hundreds of MB; with 4 kB pages the first touch of such an array is mostly page faults).
+struct RecBuf {
+  wfm_minmer_t* p = nullptr;
+  size_t n = 0;
+  RecBuf() = default;
+  RecBuf(const RecBuf&) = delete;
+  RecBuf& operator=(const RecBuf&) = delete;
+  ~RecBuf() { release(); }
+  void release() { free(p); p = nullptr; n = 0; }
+  void allocate(size_t count) {
+    release();
+    if (!count) return;
+    const size_t huge = (size_t)2 << 20, bytes = (count * sizeof(wfm_minmer_t) + huge - 1) / huge * huge;
+    p = static_cast<wfm_minmer_t*>(aligned_alloc(huge, bytes));
+    if (!p) throw std::bad_alloc();
+#ifdef MADV_HUGEPAGE
+    (void)madvise(p, bytes, MADV_HUGEPAGE);
+#endif
+    n = count;
+  }
+  void assign(const std::vector<wfm_minmer_t>& v) { allocate(v.size()); if (n) memcpy(p, v.data(), n * sizeof(wfm_minmer_t)); }
+  size_t size() const { return n; }
+  const wfm_minmer_t* data() const { return p; }
+  const wfm_minmer_t& operator[](size_t i) const { return p[i]; }
+};
+
+inline bool by_window(const wfm_minmer_t& l, const wfm_minmer_t& r) { return std::tie(l.wpos, l.wpos_end) < std::tie(r.wpos, r.wpos_end); }
+inline bool dropped_record(const wfm_minmer_t& m) { return m.wpos < 0 || m.wpos_end < 0 || m.wpos == m.wpos_end; }
+inline int16_t strand_sign(int16_t tally) { return tally < 0 ? (int16_t)-1 : (int16_t)1; }  // every non-negative tally (0 included) reads FWD (commonFunc.hpp:672)
+inline int pieces_of(const wfm_minmer_t& m, int w) { return (int)std::ceil(float(m.wpos_end - m.wpos) / float(w)); }
+
 // strand sign, chunks of at most w windows, order, de-duplication (commonFunc.hpp:660-706)
 void finish_records(std::vector<wfm_minmer_t>& out, int w, int threads = 1) {
-  out.erase(std::remove_if(out.begin(), out.end(), [](const wfm_minmer_t& m) { return m.wpos < 0 || m.wpos_end < 0 || m.wpos == m.wpos_end; }), out.end());
+  out.erase(std::remove_if(out.begin(), out.end(), dropped_record), out.end());
   std::vector<wfm_minmer_t> chunks;
   for (auto& m : out) {
-    m.strand = m.strand < 0 ? (int16_t)-1 : (int16_t)1;  // every non-negative tally (0 included) reads FWD (commonFunc.hpp:672)
+    m.strand = strand_sign(m.strand);
     if (m.wpos_end > m.wpos + w) {
-      const int n = (int)std::ceil(float(m.wpos_end - m.wpos) / float(w));
+      const int n = pieces_of(m, w);
       for (int c = 0; c < n; ++c)
         chunks.push_back(wfm_minmer_t{m.hash, m.wpos + (int64_t)c * w, std::min(m.wpos + (int64_t)c * w + w, m.wpos_end), m.seqId, m.strand, 0});
     }
   }
   out.erase(std::remove_if(out.begin(), out.end(), [w](const wfm_minmer_t& m) { return m.wpos_end - m.wpos > w; }), out.end());
   out.insert(out.end(), chunks.begin(), chunks.end());
-  sort_as_std(out.begin(), out.end(), [](const wfm_minmer_t& l, const wfm_minmer_t& r) { return std::tie(l.wpos, l.wpos_end) < std::tie(r.wpos, r.wpos_end); }, threads);
+  sort_as_std(out.begin(), out.end(), by_window, threads);
   out.erase(std::unique(out.begin(), out.end(), [](const wfm_minmer_t& l, const wfm_minmer_t& r) { return l.wpos == r.wpos && l.hash == r.hash; }), out.end());
+}
+
+// finish_records for records that sit in per-chunk lists (emission order = list after list): the array std::sort
+// sees -- the records of at most w windows in emission order, then the pieces of the longer ones in emission order
+// -- is laid out at its final size and filled by `threads` threads, each list into its own place.
+void finish_lists(const std::vector<const std::vector<wfm_minmer_t>*>& lists, int w, int threads, RecBuf& out) {
+  const size_t nl = lists.size();
+  std::vector<size_t> n_short(nl + 1, 0), n_piece(nl + 1, 0);
+  auto spread = [&](auto&& fn) {
+    std::atomic<size_t> next{0};
+    auto work = [&] { for (size_t j; (j = next.fetch_add(1)) < nl;) fn(j); };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < std::min<int>(std::max(1, threads), (int)nl); ++t) pool.emplace_back(work);
+    work();
+    for (auto& t : pool) t.join();
+  };
+  spread([&](size_t j) {
+    size_t a = 0, b = 0;
+    for (const wfm_minmer_t& m : *lists[j]) {
+      if (dropped_record(m)) continue;
+      if (m.wpos_end > m.wpos + w) b += (size_t)pieces_of(m, w); else ++a;
+    }
+    n_short[j + 1] = a; n_piece[j + 1] = b;
+  });
+  for (size_t j = 0; j < nl; ++j) { n_short[j + 1] += n_short[j]; n_piece[j + 1] += n_piece[j]; }
+  const size_t total_short = n_short[nl], total = total_short + n_piece[nl];
+  out.allocate(total);
+  spread([&](size_t j) {
+    wfm_minmer_t* a = out.p + n_short[j];
+    wfm_minmer_t* b = out.p + total_short + n_piece[j];
+    for (const wfm_minmer_t& m : *lists[j]) {
+      if (dropped_record(m)) continue;
+      const int16_t st = strand_sign(m.strand);
+      if (m.wpos_end > m.wpos + w) {
+        const int n = pieces_of(m, w);
+        for (int c = 0; c < n; ++c)
+          *b++ = wfm_minmer_t{m.hash, m.wpos + (int64_t)c * w, std::min(m.wpos + (int64_t)c * w + w, m.wpos_end), m.seqId, st, 0};
+      } else {
+        *a = m; a->strand = st; ++a;
+      }
+    }
+  });
+  sort_as_std(out.p, out.p + total, by_window, threads);
+  out.n = (size_t)(std::unique(out.p, out.p + total, [](const wfm_minmer_t& l, const wfm_minmer_t& r) { return l.wpos == r.wpos && l.hash == r.hash; }) - out.p);
 }
 
 void normalise(char* p, int64_t n) {  // makeUpperCaseAndValidDNA (commonFunc.hpp:132-142)
@@ -461,7 +539,7 @@ struct SeqJob {
   std::atomic<bool> stitched{false};   // result is final
   int sort_threads = 1;                // for the closing sort of stitch()
   double ms_stitch = 0;
-  std::vector<wfm_minmer_t> result;
+  RecBuf result;
   MapHashedSeq dev;          // the hashed sequence on the device: the source of every slice
   bool on_device = false;
   // thinned form (map_prefilter.hip): the kept k-mers, on the device; chunk j reads [cidx_warm[j], cidx[j+1])
@@ -574,8 +652,8 @@ struct SeqJob {
       Winnower W(d, len, k, w, s, seq_id);
       W.advance(0, nk);
       W.flush_end();
-      result = std::move(W.out);
-      finish_records(result, w, sort_threads);
+      finish_records(W.out, w, sort_threads);
+      result.assign(W.out);
       norm.reset(); hash.reset(); strand.reset();
       return;
     }
@@ -592,13 +670,11 @@ struct SeqJob {
       }
     }
     chunk.back()->flush_end();
-    size_t total = 0;
-    for (const auto& c : chunk) total += c->out.size();
-    result.reserve(total);
-    for (const auto& c : chunk) result.insert(result.end(), c->out.begin(), c->out.end());
+    std::vector<const std::vector<wfm_minmer_t>*> lists;
+    for (const auto& c : chunk) lists.push_back(&c->out);
+    finish_lists(lists, w, sort_threads, result);
     chunk.clear();
     started_from.clear();
-    finish_records(result, w, sort_threads);
     norm.reset(); hash.reset(); strand.reset();
   }
 };
@@ -786,7 +862,7 @@ int64_t add_minmers_core(wfm_handle_t* h, const char* const* seqs, const int64_t
       if (counts) counts[next_out] = n;
       if (n && sink_rc == WFM_OK) sink_rc = sink.put(J->result.data(), n);
       total += n;
-      if (J) std::vector<wfm_minmer_t>().swap(J->result);
+      if (J) J->result.release();
     }
   };
   std::mutex gpu_mu;  // the handle's stream and error string: this thread, and a worker that hashes a sequence again
@@ -968,6 +1044,7 @@ extern "C" int64_t wfmh_test_winnow_chunked(const char* seq, int64_t len, int k,
   if (len < k) return 0;
   SeqJob J;
   J.seq_id = seq_id; J.len = len; J.nk = len - k + 1; J.k = k; J.w = w; J.s = s;
+  J.sort_threads = 4;
   J.norm.reset(new char[(size_t)len]);
   memcpy(J.norm.get(), seq, (size_t)len);
   normalise(J.norm.get(), len);
@@ -1011,6 +1088,7 @@ extern "C" int64_t wfmh_test_winnow_thinned(const char* seq, int64_t len, int k,
   if (len < k) return 0;
   SeqJob J;
   J.seq_id = seq_id; J.len = len; J.nk = len - k + 1; J.k = k; J.w = w; J.s = s;
+  J.sort_threads = 4;
   const int64_t n = J.nk, W = (int64_t)w - k + 1;
   J.norm.reset(new char[(size_t)len]);
   memcpy(J.norm.get(), seq, (size_t)len);
