@@ -59,11 +59,19 @@ double estimate_identity_for_groups(const Parameters& params, const SequenceIdMa
   }
   int query_seq_count = 0, target_seq_count = 0;
   std::vector<hash_t> sketch((size_t)kEstimationSketchSize);
+  {  // indexed files: read the sequences side by side instead of one after the other
+    std::unordered_map<std::string, std::vector<int>> want;
+    for (const auto& [name, role] : roles) {
+      const int i = open(role.file).find(name);
+      if (i >= 0) want[role.file].push_back(i);
+    }
+    for (const auto& [file, which] : want) open(file).preload(which, params.threads);
+  }
   for (const auto& [name, role] : roles) {
     const wfmash_host::FastaStore& fa = open(role.file);
     const int64_t len = fa.seq_len(name);
     if (len <= 0) continue;  // "not found or empty, skipping"
-    const std::string seq = fa.fetch(name, 0, len - 1);
+    const std::string& seq = fa.sequence(fa.find(name));
     const int64_t n = wfm_minhash_sketch(h, seq.data(), (int64_t)seq.size(), kEstimationK, kEstimationSketchSize, sketch.data());
     if (n < 0) throw std::runtime_error(std::string("wfm_minhash_sketch failed: ") + wfm_last_error(h));
     const std::vector<hash_t> s(sketch.begin(), sketch.begin() + n);

@@ -460,8 +460,10 @@ void finish_records(std::vector<wfm_minmer_t>& out, int w, int threads = 1) {
 // finish_records for records that sit in per-chunk lists (emission order = list after list): the array std::sort
 // sees -- the records of at most w windows in emission order, then the pieces of the longer ones in emission order
 // -- is laid out at its final size and filled by `threads` threads, each list into its own place.
-void finish_lists(const std::vector<const std::vector<wfm_minmer_t>*>& lists, int w, int threads, RecBuf& out) {
+void finish_lists(const std::vector<const std::vector<wfm_minmer_t>*>& lists, int w, int threads, RecBuf& out, double* ms = nullptr) {
   const size_t nl = lists.size();
+  auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double t0 = now();
   std::vector<size_t> n_short(nl + 1, 0), n_piece(nl + 1, 0);
   auto spread = [&](auto&& fn) {
     std::atomic<size_t> next{0};
@@ -482,6 +484,7 @@ void finish_lists(const std::vector<const std::vector<wfm_minmer_t>*>& lists, in
   for (size_t j = 0; j < nl; ++j) { n_short[j + 1] += n_short[j]; n_piece[j + 1] += n_piece[j]; }
   const size_t total_short = n_short[nl], total = total_short + n_piece[nl];
   out.allocate(total);
+  const double t1 = now();
   spread([&](size_t j) {
     wfm_minmer_t* a = out.p + n_short[j];
     wfm_minmer_t* b = out.p + total_short + n_piece[j];
@@ -497,8 +500,11 @@ void finish_lists(const std::vector<const std::vector<wfm_minmer_t>*>& lists, in
       }
     }
   });
+  const double t2 = now();
   sort_as_std(out.p, out.p + total, by_window, threads);
+  const double t3 = now();
   out.n = (size_t)(std::unique(out.p, out.p + total, [](const wfm_minmer_t& l, const wfm_minmer_t& r) { return l.wpos == r.wpos && l.hash == r.hash; }) - out.p);
+  if (ms) { ms[0] = t1 - t0; ms[1] = t2 - t1; ms[2] = t3 - t2; ms[3] = now() - t3; }
 }
 
 void normalise(char* p, int64_t n) {  // makeUpperCaseAndValidDNA (commonFunc.hpp:132-142)
@@ -539,6 +545,7 @@ struct SeqJob {
   std::atomic<bool> stitched{false};   // result is final
   int sort_threads = 1;                // for the closing sort of stitch()
   double ms_stitch = 0;
+  double ms_parts[6] = {0, 0, 0, 0, 0, 0};  // compare, count, fill, sort, unique, release
   RecBuf result;
   MapHashedSeq dev;          // the hashed sequence on the device: the source of every slice
   bool on_device = false;
@@ -657,6 +664,7 @@ struct SeqJob {
       norm.reset(); hash.reset(); strand.reset();
       return;
     }
+    const auto tb = std::chrono::steady_clock::now();
     for (size_t j = 1; j < chunk.size(); ++j) {
       const Winnower& prev = *chunk[j - 1];
       if (force == 1 || !(started_from[j] == prev.live_state(bounds[j]))) {
@@ -670,11 +678,15 @@ struct SeqJob {
       }
     }
     chunk.back()->flush_end();
+    const auto tc = std::chrono::steady_clock::now();
     std::vector<const std::vector<wfm_minmer_t>*> lists;
     for (const auto& c : chunk) lists.push_back(&c->out);
-    finish_lists(lists, w, sort_threads, result);
+    finish_lists(lists, w, sort_threads, result, ms_parts + 1);
+    const auto td = std::chrono::steady_clock::now();
     chunk.clear();
     started_from.clear();
+    ms_parts[0] = std::chrono::duration<double, std::milli>(tc - tb).count();
+    ms_parts[5] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - td).count();
     norm.reset(); hash.reset(); strand.reset();
   }
 };
@@ -964,8 +976,12 @@ int64_t add_minmers_core(wfm_handle_t* h, const char* const* seqs, const int64_t
   if (getenv("WFM_DEBUG")) {
     int64_t nchunks = 0, replays = 0;
     double stitch_max = 0;
+    const SeqJob* slowest = nullptr;
     for (const auto& J : jobs)
-      if (J) { nchunks += (int64_t)J->bounds.size() - 1; replays += J->replays; stitch_max = std::max(stitch_max, J->ms_stitch); }
+      if (J) { nchunks += (int64_t)J->bounds.size() - 1; replays += J->replays; if (J->ms_stitch >= stitch_max) { stitch_max = J->ms_stitch; slowest = J.get(); } }
+    if (slowest)
+      fprintf(stderr, "[wfm] longest stitch: compare %.1f, count %.1f, fill %.1f, sort %.1f, unique %.1f, release %.1f ms\n", slowest->ms_parts[0],
+              slowest->ms_parts[1], slowest->ms_parts[2], slowest->ms_parts[3], slowest->ms_parts[4], slowest->ms_parts[5]);
     fprintf(stderr, "[wfm] add_minmers_multi: %lld sequences in %lld chunks (%lld replayed), %d workers, %s, %.1f %% of the k-mers kept: hashing thread %.1f ms (GPU hashing %.1f, thinning %.1f), drain %.1f ms (longest stitch %.1f)\n",
             (long long)nseq, (long long)nchunks, (long long)replays, nthreads, streamed ? "streamed through the pinned ring" : "whole sequences",
             thinned_kmers ? 100.0 * (double)kept_kmers / (double)thinned_kmers : 100.0,
