@@ -24,6 +24,7 @@
  *     wfm_prefilter_kmers   <- (no counterpart: the device-side thinning of addMinmers' input stream)
  *     wfm_index_build       <- Sketch::build (index stage), winSketch.hpp:266-429
  *     wfm_index_build_sequences <- Sketch::build as a whole, winSketch.hpp:175-457
+ *     wfm_index_upload / wfm_index_download <- Sketch::readIndex / writeIndex (device side), winSketch.hpp:569-866
  *     wfm_map_l1            <- getSeedIntervalPoints + computeL1CandidateRegions, mappingCore.hpp:82-301
  *     wfm_map_l2            <- computeL2MappedRegions + SlideMapper + doL2Mapping,
  *                              mappingCore.hpp:307-442, slidingMap.hpp:28-212, computeMap.hpp:989-1061
@@ -195,6 +196,13 @@ int  wfm_index_info(const wfm_index_t* ix, wfm_index_info_t* out);
  * n_unique+1 offsets into points, the points, and minmerIndex. */
 int  wfm_index_download(wfm_handle_t* h, const wfm_index_t* ix, uint64_t* uhash, int64_t* poff,
                         wfm_interval_point_t* points, wfm_minmer_t* minmers);
+
+/* The inverse of wfm_index_download: a device index from the structures of an index file (`-I`;
+ * Sketch::readIndex, winSketch.hpp:834-866, host/index_file.cpp reads the file).  uhash ascending,
+ * poff[n_unique + 1] offsets into points, minmers = minmerIndex sorted by (seqId, wpos). */
+int  wfm_index_upload(wfm_handle_t* h, const uint64_t* uhash, const int64_t* poff, int64_t n_unique,
+                      const wfm_interval_point_t* points, const wfm_minmer_t* minmers, int64_t n_kept,
+                      wfm_index_t** out);
 
 /* addMinmers (commonFunc.hpp:440-708): winnowed minmer intervals [wpos, wpos_end) of one target
  * sequence, sorted by (wpos, wpos_end), spans chunked to <= w.  K-mer hashing runs on the GPU,

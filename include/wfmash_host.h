@@ -128,6 +128,11 @@ typedef struct {
   const char* target_list;            /* -R: file with target names */
   const char* query_prefix;           /* -Q: comma-separated name prefixes */
   const char* query_list;             /* -A: file with query names (also how ranks shard the queries) */
+  /* on-disk index (parse_args.hpp:745-758; format: wfmash_amd/host/index_file.hpp) */
+  const char* index_file;             /* NULL = none */
+  int32_t  write_index;               /* 1: -W, build the index of every target subset, write it and stop;
+                                         0 with index_file set: -I, read the index instead of building it */
+  int32_t  pad_;
 } wfmh_map_params_t;
 
 void wfmh_map_default_params(wfmh_map_params_t* p);
@@ -166,6 +171,11 @@ char* wfmh_test_filter(const char* stage, const wfm_mapping_t* maps, int64_t n, 
  * (faidx_reader_fetch_seq's convention); whole != 0 loads the sequence first, as the map driver does.
  * malloc'd, wfmh_free; "ERROR: ..." on failure. */
 char* wfmh_test_fasta(const char* path, const char* name, int64_t start, int64_t end_inclusive, int whole);
+
+/* Test hook for the on-disk index format (wfmash_amd/host/index_file.hpp; no GPU needed).  op "ids": the id
+ * section alone (SequenceIdManager::exportIdMapping, sequenceIds.hpp:101-115) of fasta's sequences into out_path;
+ * op "rewrite": every sub-index of in_path is read and written again into out_path.  0, or -1 (message on stderr). */
+int wfmh_test_index_file(const char* op, const char* fasta, char prefix_delim, const char* in_path, const char* out_path);
 
 #ifdef __cplusplus
 }

@@ -30,3 +30,13 @@ def ref_filter(stage: str, mappings, fasta: str, query_name: str, params) -> str
     s = C.string_at(p).decode()
     _LIB.ref_filter_free(p)
     return s
+
+
+def ref_export_ids(fasta: str, out_path: str, prefix_delim: str = "#") -> None:
+    """the reference's SequenceIdManager::exportIdMapping for the sequences of `fasta` (its .fai)"""
+    lib = C.CDLL(_PATH)
+    lib.ref_export_ids.restype = C.c_int
+    lib.ref_export_ids.argtypes = [C.c_char_p, C.c_char, C.c_char_p]
+    if lib.ref_export_ids(fasta.encode(), (prefix_delim or "\0").encode(), out_path.encode()) != 0:
+        raise RuntimeError("ref_export_ids failed")
+

@@ -14,6 +14,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <fstream>
 #include <iomanip>
 #include <map>
 #include <sstream>
@@ -127,3 +128,16 @@ extern "C" char* ref_filter(const char* stage, const wfm_mapping_t* maps, int64_
 }
 
 extern "C" void ref_filter_free(char* p) { free(p); }
+
+// The reference's own id section of an index file (SequenceIdManager::exportIdMapping, sequenceIds.hpp:101-115)
+// for the sequences of `fasta`: pins the byte layout and the map iteration order of host/sequence_ids.cpp.
+extern "C" int ref_export_ids(const char* fasta, char prefix_delim, const char* out_path) {
+  QuietStderr quiet;
+  const std::string delim = prefix_delim ? std::string(1, prefix_delim) : std::string();
+  skch::SequenceIdManager ids({std::string(fasta)}, {std::string(fasta)}, {}, {std::string()}, delim);
+  std::ofstream out(out_path, std::ios::binary);
+  if (!out) return -1;
+  ids.exportIdMapping(out);
+  return out ? 0 : -1;
+}
+

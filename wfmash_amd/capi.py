@@ -25,7 +25,7 @@ EXPORTS = [
     "wfm_hash_kmers", "wfm_sketch_fragments", "wfm_add_minmers",
     "wfm_index_build", "wfm_index_free", "wfm_index_info", "wfm_index_download",
     "wfm_map_l1", "wfm_map_l2", "wfm_map_fragments", "wfm_minhash_sketch", "wfm_add_minmers_multi",
-    "wfm_prefilter_kmers", "wfm_index_build_sequences",
+    "wfm_prefilter_kmers", "wfm_index_build_sequences", "wfm_index_upload",
 ]
 
 
@@ -538,7 +538,7 @@ class Handle:
 # host-side align driver (include/wfmash_host.h)
 # ---------------------------------------------------------------------------
 HOST_EXPORTS = ["wfmh_align_default_params", "wfmh_align_paf", "wfmh_test_cigar", "wfmh_free", "wfmh_test_winnow",
-                "wfmh_map_default_params", "wfmh_test_filter", "wfmh_map", "wfmh_test_winnow_chunked", "wfmh_test_fasta", "wfmh_test_winnow_thinned", "wfmh_test_sort_records"]
+                "wfmh_map_default_params", "wfmh_test_filter", "wfmh_map", "wfmh_test_winnow_chunked", "wfmh_test_fasta", "wfmh_test_winnow_thinned", "wfmh_test_sort_records", "wfmh_test_index_file"]
 
 
 class MapSummary(C.Structure):
@@ -575,7 +575,8 @@ class MapHostParams(C.Structure):
                 ("stage1_topani_filter", C.c_int32), ("stage2_full_scan", C.c_int32), ("ani_diff", C.c_float),
                 ("ani_diff_conf", C.c_float), ("hg_numerator", C.c_double), ("threads", C.c_int32),
                 ("auto_pct_identity", C.c_int32), ("ani_percentile", C.c_int32), ("ani_adjustment", C.c_float),
-                ("target_prefix", C.c_char_p), ("target_list", C.c_char_p), ("query_prefix", C.c_char_p), ("query_list", C.c_char_p)]
+                ("target_prefix", C.c_char_p), ("target_list", C.c_char_p), ("query_prefix", C.c_char_p), ("query_list", C.c_char_p),
+                ("index_file", C.c_char_p), ("write_index", C.c_int32), ("pad_", C.c_int32)]
 
 
 def map_default_params(**over) -> MapHostParams:
@@ -694,6 +695,17 @@ def host_winnow(seq: bytes, k: int, w: int, s: int, seq_id: int, hashes, strands
     strands = np.ascontiguousarray(strands, dtype=np.int8)
     n = L.wfmh_test_winnow(seq, len(seq), k, w, s, seq_id, hashes.ctypes.data, strands.ctypes.data, out.ctypes.data, cap)
     return out[:n]
+
+
+def host_index_file(op: str, fasta: str, out_path: str, in_path: str = None, prefix_delim: str = "#"):
+    """wfmh_test_index_file: 'ids' (id section of fasta's sequences) or 'rewrite' (read + write every sub-index)."""
+    L = load()
+    f = L.wfmh_test_index_file
+    f.restype = C.c_int
+    f.argtypes = [C.c_char_p, C.c_char_p, C.c_char, C.c_char_p, C.c_char_p]
+    rc = f(op.encode(), fasta.encode(), (prefix_delim or "\0").encode(), in_path.encode() if in_path else None, out_path.encode())
+    if rc != 0:
+        raise WfmError(f"wfmh_test_index_file({op}) failed")
 
 
 def host_sort_records(recs, threads: int):

@@ -267,6 +267,38 @@ int map_index_build_device(wfm_handle_t* h, const wfm_minmer_t* d_m, int64_t n, 
 
 extern "C" {
 
+int wfm_index_upload(wfm_handle_t* h, const uint64_t* uhash, const int64_t* poff, int64_t n_unique, const wfm_interval_point_t* points,
+                     const wfm_minmer_t* minmers, int64_t n_kept, wfm_index_t** out) {
+  if (!h || !out || n_unique < 0 || n_kept < 0 || (n_unique && (!uhash || !poff || !points)) || (n_kept && !minmers)) return WFM_E_ARG;
+  *out = nullptr;
+  for (int64_t u = 1; u < n_unique; ++u)
+    if (uhash[u] <= uhash[u - 1]) { wfm_set_error(h, "wfm_index_upload: hashes must ascend strictly"); return WFM_E_ARG; }
+  const int64_t n_points = n_unique ? poff[n_unique] : 0;
+  if (n_unique && (poff[0] != 0 || n_points < 0)) { wfm_set_error(h, "wfm_index_upload: bad offsets"); return WFM_E_ARG; }
+  HIPCHK(h, hipSetDevice(wfm_device(h)));
+  hipStream_t st = wfm_stream(h);
+  wfm_index* ix = new wfm_index();
+  ix->device = wfm_device(h);
+  ix->n_windows = n_kept; ix->n_kept = n_kept; ix->n_unique = n_unique; ix->n_points = n_points;
+  const int64_t zero = 0;
+  if (hipMalloc((void**)&ix->d_uhash, std::max<size_t>((size_t)n_unique, 1) * 8) != hipSuccess ||
+      hipMalloc((void**)&ix->d_poff, ((size_t)n_unique + 1) * 8) != hipSuccess ||
+      hipMalloc((void**)&ix->d_points, std::max<size_t>((size_t)n_points, 1) * sizeof(wfm_interval_point_t)) != hipSuccess ||
+      hipMalloc((void**)&ix->d_minmers, std::max<size_t>((size_t)n_kept, 1) * sizeof(wfm_minmer_t)) != hipSuccess) {
+    wfm_index_free(h, ix); wfm_set_error(h, "out of device memory (index)"); return WFM_E_NOMEM;
+  }
+  hipError_t e = hipSuccess;
+  if (n_unique) e = hipMemcpyAsync(ix->d_uhash, uhash, (size_t)n_unique * 8, hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) e = n_unique ? hipMemcpyAsync(ix->d_poff, poff, ((size_t)n_unique + 1) * 8, hipMemcpyHostToDevice, st)
+                                    : hipMemcpyAsync(ix->d_poff, &zero, 8, hipMemcpyHostToDevice, st);
+  if (e == hipSuccess && n_points) e = hipMemcpyAsync(ix->d_points, points, (size_t)n_points * sizeof(wfm_interval_point_t), hipMemcpyHostToDevice, st);
+  if (e == hipSuccess && n_kept) e = hipMemcpyAsync(ix->d_minmers, minmers, (size_t)n_kept * sizeof(wfm_minmer_t), hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  if (e != hipSuccess) { wfm_index_free(h, ix); wfm_set_error(h, std::string("wfm_index_upload: ") + hipGetErrorString(e)); return WFM_E_HIP; }
+  *out = ix;
+  return WFM_OK;
+}
+
 void wfm_index_free(wfm_handle_t* h, wfm_index_t* ix) {
   if (!ix) return;
   if (h) (void)hipSetDevice(wfm_device(h));

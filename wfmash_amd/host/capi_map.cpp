@@ -1,5 +1,7 @@
 // capi_map.cpp -- C entry points of the map phase's host side (include/wfmash_host.h).
 #include <cstdlib>
+#include <fstream>
+#include <cstdio>
 #include <cstring>
 #include <limits>
 #include <sstream>
@@ -9,6 +11,7 @@
 #include "../csrc/wfa_handle.h"
 #include "ani_estimate.hpp"
 #include "capi_map.hpp"
+#include "index_file.hpp"
 #include "map_filter.hpp"
 #include "mapper.hpp"
 #include "sequence_ids.hpp"
@@ -58,6 +61,7 @@ skch::Parameters to_parameters(const wfmh_map_params_t& c) {
   if (c.target_prefix) p.target_prefix = c.target_prefix;
   if (c.target_list) p.target_list = c.target_list;
   if (c.query_list) p.query_list = c.query_list;
+  if (c.index_file) { p.indexFilename = c.index_file; p.create_index_only = c.write_index != 0; }
   if (c.query_prefix) {  // CommonFunc::split(args::get(query_prefix), ',') (parse_args.hpp:204)
     std::stringstream ss(c.query_prefix);
     for (std::string tok; std::getline(ss, tok, ',');) p.query_prefix.push_back(tok);
@@ -183,6 +187,41 @@ char* wfmh_test_filter(const char* stage, const wfm_mapping_t* maps, int64_t n, 
   char* out = (char*)malloc(text.size() + 1);
   if (out) std::memcpy(out, text.c_str(), text.size() + 1);
   return out;
+}
+
+// Test hook for the on-disk index (host/index_file.cpp; no GPU needed).  op "ids": the id section alone
+// (SequenceIdManager::exportIdMapping) of `fasta`'s sequences into out_path.  op "rewrite": every sub-index of
+// in_path is read (read_sub_index, ids imported) and written again (write_sub_index) into out_path.
+// Returns 0, or -1 with the message on stderr.
+int wfmh_test_index_file(const char* op, const char* fasta, char prefix_delim, const char* in_path, const char* out_path) {
+  if (!op || !fasta || !out_path) return -1;
+  try {
+    const std::string delim = prefix_delim ? std::string(1, prefix_delim) : std::string();
+    skch::SequenceIdManager ids({std::string(fasta)}, {std::string(fasta)}, {}, {std::string()}, delim);
+    std::ofstream out(out_path, std::ios::binary);
+    if (!out) throw std::runtime_error("cannot open the output file");
+    const std::string o(op);
+    if (o == "ids") {
+      ids.exportIdMapping(out);
+    } else if (o == "rewrite") {
+      if (!in_path) return -1;
+      std::ifstream in(in_path, std::ios::binary);
+      if (!in) throw std::runtime_error("cannot open the input file");
+      uint64_t total = 1;
+      for (uint64_t b = 0; b < total; ++b) {
+        skch::SubIndex sub;
+        skch::read_sub_index(in, sub, ids);
+        total = sub.total_batches;
+        skch::write_sub_index(out, sub, ids);
+      }
+    } else {
+      return -1;
+    }
+    return out ? 0 : -1;
+  } catch (const std::exception& e) {
+    fprintf(stderr, "wfmh_test_index_file: %s\n", e.what());
+    return -1;
+  }
 }
 
 }  // extern "C"

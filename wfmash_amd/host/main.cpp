@@ -39,6 +39,7 @@ static void usage() {
           "            -n INT|inf mappings per segment [inf]   -l INT block length [0]   -c INT chain jump [2k]   -P INT max length [50k]\n"
           "            -N no split   -M no merge   -f no filter   -o one-to-one   -O FLOAT max overlap [0.95]   -x FLOAT sparsify [1.0]\n"
           "            -H INT L1 hits [3]   -F FLOAT high-frequency filter [0.0002]   -b SIZE target batch [all]\n"
+          "            -W FILE build the index, write it and stop   -I FILE read the index from FILE\n"
           "            -S INT scaffold mass [10k]   -D INT scaffold dist [100k]   -j INT scaffold jump [100k]   -r INT per scaffold [1]\n"
           "            -Y C group delimiter [#]   -X self maps   -L lower triangular   -t INT threads [1]\n"
           "  alignment -g x,o1,e1,o2,e2 [5,8,2,24,1]   -E INT target padding   -U INT query padding   -a SAM   -d MD tag\n"
@@ -106,6 +107,8 @@ int main(int argc, char** argv) {
     else if (a == "-H" || a == "--l1-hits") mp.minimum_hits = atoi(next("-H").c_str());
     else if (a == "-F" || a == "--filter-freq") mp.max_kmer_freq = atof(next("-F").c_str());
     else if (a == "-b" || a == "--batch") mp.index_by_size = size("-b");
+    else if (a == "-W" || a == "--write-index") { mp.index_file = argv[(next("-W"), i)]; mp.write_index = 1; }
+    else if (a == "-I" || a == "--read-index") { mp.index_file = argv[(next("-I"), i)]; mp.write_index = 0; }
     else if (a == "-S" || a == "--scaffold-mass") mp.scaffold_min_length = size("-S");
     else if (a == "-D" || a == "--scaffold-dist") mp.scaffold_max_deviation = size("-D");
     else if (a == "-j" || a == "--scaffold-jump") mp.scaffold_gap = size("-j");
@@ -168,6 +171,11 @@ int main(int argc, char** argv) {
               ms.sketch_size, (unsigned long long)ms.fragments, (unsigned long long)ms.l2_mappings, (unsigned long long)ms.written, ms.ms_index,
               ms.ms_map, ms.ms_filter, ms.ms_total);
     else fprintf(stderr, "[wfmash::map] ERROR: %s\n", wfm_last_error(h));
+  }
+  if (mp.index_file && mp.write_index) {  // -W: "index construction completed", nothing else runs (computeMap.hpp:405-415)
+    if (!temp.empty()) unlink(temp.c_str());
+    wfm_destroy(h);
+    return rc == WFM_OK ? 0 : 3;
   }
   if (rc == WFM_OK && !approx_only) {
     wfmh_align_summary_t s;

@@ -117,6 +117,8 @@ struct Parameters {
   int64_t scaffold_min_length = 10000;     // :454-461
   bool legacy_output = false;
   int64_t index_by_size = std::numeric_limits<int64_t>::max();  // :766-768
+  std::string indexFilename;               // -W / -I (:745-758)
+  bool create_index_only = false;          // -W: write the index and stop
   int minimum_hits = 3;                    // :729-731
   double max_kmer_freq = 0.0002;           // :735-737
   bool auto_pct_identity = true;           // -p ani50-2 (:41-43, :392-395); an explicit -p switches it off

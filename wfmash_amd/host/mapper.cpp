@@ -16,6 +16,7 @@
 
 #include "../csrc/wfa_handle.h"
 #include "fasta.hpp"
+#include "index_file.hpp"
 #include "map_filter.hpp"
 #include "map_stats.hpp"
 
@@ -146,7 +147,14 @@ int Map::mapQuery(MapSummary* summary) {
   // createTargetSubsets (computeMap.hpp:295-327)
   std::vector<std::vector<std::string>> subsets;
   {
-    const int64_t batch = P.index_by_size > 0 ? P.index_by_size : 5000000;
+    int64_t index_by_size = P.index_by_size;
+    if (!P.indexFilename.empty() && !P.create_index_only) {
+      // "Using batch size N from index file" (computeMap.hpp:349-376)
+      int64_t bs = 0;
+      try { peek_index_file(P.indexFilename, &bs, nullptr); } catch (const std::exception& e) { wfm_set_error(h_, e.what()); return WFM_E_ARG; }
+      if (bs > 0) index_by_size = bs;
+    }
+    const int64_t batch = index_by_size > 0 ? index_by_size : 5000000;
     std::vector<std::string> cur;
     uint64_t cur_size = 0;
     for (size_t i = 0; i < targetNames.size(); ++i) {
@@ -170,11 +178,33 @@ int Map::mapQuery(MapSummary* summary) {
   std::ostream& out = to_stdout ? static_cast<std::ostream&>(std::cout) : file;
   std::map<seqno_t, MappingResultsVector_t> combined;  // one-to-one mode: everything is held back
 
+  std::ifstream index_in;   // -I: the sub-indexes are read in file order, one per subset
+  if (!P.indexFilename.empty() && !P.create_index_only) {
+    index_in.open(P.indexFilename, std::ios::binary);
+    if (!index_in) { wfm_set_error(h_, "unable to open index file for reading: " + P.indexFilename); return WFM_E_ARG; }
+  }
+  size_t subset_idx = 0;
   for (const auto& subset : subsets) {
-    // ---- index of this subset (Sketch::build)
+    // ---- index of this subset (Sketch::build, or Sketch::readIndex with -I)
     double t0 = now_ms();
     wfm_index_t* ix = nullptr;
-    {
+    const size_t this_subset = subset_idx++;
+    if (index_in.is_open()) {
+      SubIndex sub;
+      try { read_sub_index(index_in, sub, *idManager_); } catch (const std::exception& e) { wfm_set_error(h_, e.what()); return WFM_E_ARG; }
+      if (sub.windowLength != w || sub.sketchSize != S || sub.kmerSize != k) {  // readParameters (winSketch.hpp:713-737)
+        wfm_set_error(h_, "parameters of the indexed sketch differ from the current ones: index w=" + std::to_string(sub.windowLength) + " s=" +
+                              std::to_string(sub.sketchSize) + " k=" + std::to_string(sub.kmerSize));
+        return WFM_E_ARG;
+      }
+      if (sub.names != subset) std::cerr << "[wfmash::mashmap] Warning: the sequences of index subset " << this_subset + 1 << " differ from the expected targets\n";
+      if (!sub.minmers.empty()) {
+        const int rc = wfm_index_upload(h_, sub.uhash.data(), sub.poff.data(), (int64_t)sub.uhash.size(), sub.points.data(), sub.minmers.data(),
+                                        (int64_t)sub.minmers.size(), &ix);
+        if (rc != WFM_OK) return rc;
+      }
+      sum.index_windows += sub.minmers.size();
+    } else {
       std::vector<const char*> sp;
       std::vector<int64_t> sl;
       std::vector<int32_t> si;
@@ -191,6 +221,28 @@ int Map::mapQuery(MapSummary* summary) {
                                                P.max_kmer_freq, &ix, &n_windows);
       if (rc != WFM_OK) return rc;
       sum.index_windows += (uint64_t)n_windows;
+    }
+    if (P.create_index_only) {
+      // -W: write the sub-index, appended after the previous ones, and go on to the next subset (computeMap.hpp:405-415)
+      SubIndex sub;
+      sub.batch_idx = this_subset; sub.total_batches = subsets.size(); sub.batch_size = P.index_by_size;
+      sub.names = subset; sub.windowLength = w; sub.sketchSize = S; sub.kmerSize = k;
+      if (ix) {
+        wfm_index_info_t inf;
+        wfm_index_info(ix, &inf);
+        sub.uhash.resize((size_t)inf.n_unique); sub.poff.resize((size_t)inf.n_unique + 1);
+        sub.points.resize((size_t)inf.n_points); sub.minmers.resize((size_t)inf.n_kept);
+        const int rc = wfm_index_download(h_, ix, sub.uhash.data(), sub.poff.data(), sub.points.data(), sub.minmers.data());
+        wfm_index_free(h_, ix);
+        if (rc != WFM_OK) return rc;
+      } else {
+        sub.poff.assign(1, 0);
+      }
+      std::ofstream index_out(P.indexFilename, this_subset ? std::ios::binary | std::ios::app : std::ios::binary);
+      if (!index_out) { wfm_set_error(h_, "unable to open index file for writing: " + P.indexFilename); return WFM_E_ARG; }
+      try { write_sub_index(index_out, sub, ids); } catch (const std::exception& e) { wfm_set_error(h_, e.what()); return WFM_E_ARG; }
+      sum.ms_index += now_ms() - t0;
+      continue;
     }
     sum.ms_index += now_ms() - t0;
 

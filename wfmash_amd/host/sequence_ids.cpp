@@ -2,6 +2,8 @@
 
 #include <algorithm>
 #include <fstream>
+#include <istream>
+#include <ostream>
 #include <sstream>
 #include <stdexcept>
 #include <unordered_set>
@@ -68,6 +70,7 @@ seqno_t SequenceIdManager::addSequence(const std::string& name, offset_t length)
 
 void SequenceIdManager::buildRefGroups() {
   if (metadata_.empty()) throw std::runtime_error("SequenceIdManager: no sequences indexed");
+  groupKey_.clear();
   std::vector<std::pair<std::string, size_t>> order;
   order.reserve(metadata_.size());
   for (size_t i = 0; i < metadata_.size(); ++i) order.emplace_back(metadata_[i].name, i);
@@ -115,6 +118,68 @@ std::vector<int32_t> SequenceIdManager::refGroupTable() const {
   std::vector<int32_t> t(metadata_.size());
   for (size_t i = 0; i < metadata_.size(); ++i) t[i] = metadata_[i].groupId;
   return t;
+}
+
+void SequenceIdManager::exportIdMapping(std::ostream& out) const {
+  const uint64_t mapSize = idOf_.size();
+  out.write(reinterpret_cast<const char*>(&mapSize), sizeof(mapSize));
+  for (const auto& [name, id] : idOf_) {
+    const uint64_t nameLength = name.size();
+    out.write(reinterpret_cast<const char*>(&nameLength), sizeof(nameLength));
+    out.write(name.c_str(), (std::streamsize)nameLength);
+    out.write(reinterpret_cast<const char*>(&id), sizeof(id));
+  }
+  const seqno_t nextId = (seqno_t)metadata_.size();
+  out.write(reinterpret_cast<const char*>(&nextId), sizeof(nextId));
+}
+
+bool SequenceIdManager::importIdMapping(std::istream& in) {
+  uint64_t mapSize = 0;
+  in.read(reinterpret_cast<char*>(&mapSize), sizeof(mapSize));
+  if (!in || mapSize > 1000000) return false;  // the reference's sanity bound
+  std::vector<std::pair<std::string, seqno_t>> entries;
+  seqno_t maxId = 0;
+  for (uint64_t i = 0; i < mapSize; ++i) {
+    uint64_t nameLength = 0;
+    in.read(reinterpret_cast<char*>(&nameLength), sizeof(nameLength));
+    if (!in || nameLength > 10000) return false;
+    std::string name((size_t)nameLength, '\0');
+    in.read(&name[0], (std::streamsize)nameLength);
+    seqno_t id = 0;
+    in.read(reinterpret_cast<char*>(&id), sizeof(id));
+    if (!in || id < 0) return false;
+    maxId = std::max(maxId, id);
+    entries.emplace_back(std::move(name), id);
+  }
+  seqno_t indexNextId = 0;
+  in.read(reinterpret_cast<char*>(&indexNextId), sizeof(indexNextId));
+  if (!in) return false;
+  // the usual case: the run reads the files the index was made from -- nothing moves
+  bool same = entries.size() == idOf_.size();
+  for (const auto& e : entries) {
+    auto it = idOf_.find(e.first);
+    same = same && it != idOf_.end() && it->second == e.second;
+  }
+  if (same) return true;
+  const auto oldIds = idOf_;
+  const auto oldMeta = metadata_;
+  idOf_.clear();
+  targetNames_.clear();
+  metadata_.assign((size_t)std::max<seqno_t>(indexNextId, maxId + 1), ContigInfo{std::string(), 0, 0});
+  for (const auto& e : entries) {
+    idOf_[e.first] = e.second;
+    targetNames_.push_back(e.first);
+    metadata_[(size_t)e.second].name = e.first;
+    auto it = oldIds.find(e.first);
+    if (it != oldIds.end()) metadata_[(size_t)e.second].len = oldMeta[(size_t)it->second].len;
+  }
+  for (const auto& q : queryNames_) {
+    if (idOf_.count(q)) continue;
+    auto it = oldIds.find(q);
+    addSequence(q, it != oldIds.end() ? oldMeta[(size_t)it->second].len : 0);
+  }
+  buildRefGroups();
+  return true;
 }
 
 }  // namespace skch

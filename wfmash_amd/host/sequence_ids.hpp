@@ -5,10 +5,11 @@
 // of the lexicographically sorted sequence names (sequenceIds.hpp:286-338); the group key of a name
 // is the first matching user prefix, else the part before the LAST delimiter, else the whole name.
 // The .fai next to each FASTA is read when it exists; otherwise the FASTA itself is scanned
-// (the reference lets htslib create the .fai, faigz.h FAI_CREATE).  Index import/export
-// (sequenceIds.hpp:101-212) belongs to the on-disk index format, which is out of scope.
+// (the reference lets htslib create the .fai, faigz.h FAI_CREATE).  exportIdMapping / importIdMapping
+// (sequenceIds.hpp:101-212) are the id section of the on-disk index (host/index_file.cpp).
 #pragma once
 
+#include <iosfwd>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -35,6 +36,12 @@ class SequenceIdManager {
   std::string getGroupPrefix(int groupId) const;
   // groupId of every sequence id, the table the L1 kernels take
   std::vector<int32_t> refGroupTable() const;
+  // the id section of an index file: (name length, name, id) per sequence in the map's own iteration order, then
+  // the next free id (sequenceIds.hpp:101-115)
+  void exportIdMapping(std::ostream& out) const;
+  // takes names and ids from an index file; lengths of known names are kept, query sequences the file does
+  // not know get fresh ids (the reference reloads them, sequenceIds.hpp:58-99,117-212); false = malformed
+  bool importIdMapping(std::istream& in);
 
  private:
   seqno_t addSequence(const std::string& name, offset_t length);
