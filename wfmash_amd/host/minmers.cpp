@@ -950,7 +950,7 @@ int64_t add_minmers_core(wfm_handle_t* h, const char* const* seqs, const int64_t
       rc = map_hashed_fetch(&Jp->dev, 0, Jp->nk, 0, len, Jp->hash.get(), Jp->strand.get(), Jp->norm.get());
       map_hashed_free(&Jp->dev);
       Jp->on_device = false;
-      if (rc != WFM_OK) { wfm_set_error(h, "device-to-host copy of k-mer hashes failed"); break; }
+      if (rc != WFM_OK) { wfm_set_error(h, "device-to-host copy of k-mer hashes failed"); jobs[(size_t)i].reset(); break; }  // never queued: nobody will stitch it
       {
         std::lock_guard<std::mutex> lk(mu);
         queue.push_back(Task{Jp, 0, -1});
@@ -966,6 +966,16 @@ int64_t add_minmers_core(wfm_handle_t* h, const char* const* seqs, const int64_t
   cv_hashed.notify_all();
   cv_work.notify_all();
   const auto t_fed = std::chrono::steady_clock::now();
+  {  // hand the sequences on in order as their stitches finish, while the later ones are still being stitched
+    std::unique_lock<std::mutex> lk(mu);
+    while (next_out < nseq) {
+      SeqJob* J = jobs[(size_t)next_out].get();
+      if (J && !J->stitched.load(std::memory_order_acquire)) { cv_room.wait(lk); continue; }  // a worker signals after every stitch
+      lk.unlock();
+      flush_ready(next_out + 1);
+      lk.lock();
+    }
+  }
   if (stream_thread.joinable()) stream_thread.join();
   for (auto& t : pool) t.join();
   release_stitched();
