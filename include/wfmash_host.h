@@ -30,6 +30,9 @@ typedef struct {
   int32_t  sam_format;              /* -a: SAM instead of PAF (parse_args.hpp:128) */
   int32_t  emit_md_tag;             /* -d: MD:Z tag in SAM records (parse_args.hpp:129) */
   int32_t  no_seq_in_sam;           /* 0 */
+  int32_t  threads;                 /* -t: host threads for fetching sequences and for the CIGAR / PAF work of a
+                                       batch (the reference runs one Taskflow worker per record); 0 = all cores */
+  int32_t  pad_;
 } wfmh_align_params_t;
 
 typedef struct {

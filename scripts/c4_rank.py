@@ -70,6 +70,7 @@ def main():
     ap.add_argument("--world", type=int, default=8)
     ap.add_argument("--pct", type=float, default=0.0, help="identity threshold as a fraction; 0 = estimate (ani50-2)")
     ap.add_argument("--keep", default="")
+    ap.add_argument("--align", action="store_true", help="also run the align phase on the rank's mappings")
     a = ap.parse_args()
 
     d = a.keep or tempfile.mkdtemp()
@@ -107,6 +108,28 @@ def main():
     t0 = time.time()
     s = capi.map_paf(h, fa, out, params=P)
     wall = time.time() - t0
+    align = None
+    if a.align:
+        aln = os.path.join(d, f"rank{a.rank}.aln.paf")
+        t0 = time.time()
+        sa = capi.align_paf(h, fa, out, aln)
+        wall_a = time.time() - t0
+        # every record's CIGAR must span exactly its coordinates (pafcheck's rule)
+        import re
+        bad_cg = n_rec = 0
+        with open(aln) as f:
+            for line in f:
+                c = line.rstrip("\n").split("\t")
+                cg = next(x[5:] for x in c[12:] if x.startswith("cg:Z:"))
+                ql = tl = 0
+                for num, op in re.findall(r"(\d+)([=XIDM])", cg):
+                    ql += int(num) if op in "=XIM" else 0
+                    tl += int(num) if op in "=XDM" else 0
+                n_rec += 1
+                bad_cg += (ql != int(c[3]) - int(c[2])) or (tl != int(c[8]) - int(c[7]))
+        align = {"records": int(sa.records), "written": int(sa.written), "aligned_bp": int(sa.aligned_bp), "cells": int(sa.cells),
+                 "ms_gpu": round(sa.ms_gpu), "ms_total": round(sa.ms_total), "wall_s": round(wall_a, 2),
+                 "aligned_bp_per_s": round(sa.aligned_bp / (sa.ms_total / 1e3)), "cigar_span_errors": int(bad_cg), "checked": n_rec}
     h.close()
     # sanity of the output: every record starts inside its sequences, query ranges are exact and no query maps to
     # its own haplotype.  A target END may pass the sequence end by a few bases: a chain's block length is the
@@ -131,6 +154,7 @@ def main():
                       "query_span_mapped_per_target": round(span / max(1, int(s.query_bp)) / max(1, a.haps - 1), 4),
                       "ms_index": round(s.ms_index), "ms_map": round(s.ms_map), "ms_filter": round(s.ms_filter), "ms_total": round(s.ms_total),
                       "query_mbp_per_s": round(s.query_bp / 1e6 / (s.ms_total / 1e3), 2),
+                      "align": align,
                       "peak_rss_gb": round(resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1e6, 1)}))
 
 

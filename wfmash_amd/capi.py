@@ -635,7 +635,7 @@ class AlignParams(C.Structure):
                 ("min_block_identity", C.c_float), ("target_padding", C.c_uint64),
                 ("query_padding", C.c_uint64), ("wflign_max_len_minor", C.c_uint64),
                 ("disable_chain_patching", C.c_int32), ("sam_format", C.c_int32),
-                ("emit_md_tag", C.c_int32), ("no_seq_in_sam", C.c_int32)]
+                ("emit_md_tag", C.c_int32), ("no_seq_in_sam", C.c_int32), ("threads", C.c_int32), ("pad_", C.c_int32)]
 
 
 class AlignSummary(C.Structure):

@@ -1,6 +1,8 @@
 #include "aligner.hpp"
 
 #include <algorithm>
+#include <thread>
+#include <atomic>
 #include <cctype>
 #include <chrono>
 #include <cstring>
@@ -138,9 +140,10 @@ std::string Aligner::align_lines(const std::vector<std::string>& lines, Summary&
   size_t i = 0;
   while (i < lines.size()) {
     // ---- assemble one batch (createSeqRecord + processAlignment front half) ----
-    std::vector<Fetched> fetched;
+    // rows first (cheap, in order), then the sequence fetches of the whole batch on `threads` threads
+    std::vector<Fetched> rows;
     uint64_t bases = 0;
-    while (i < lines.size() && fetched.size() < param.batch_records && bases < param.batch_bases) {
+    while (i < lines.size() && rows.size() < param.batch_records && bases < param.batch_bases) {
       const std::string& line = lines[i++];
       if (line.empty()) continue;
       Fetched f;
@@ -150,23 +153,53 @@ std::string Aligner::align_lines(const std::vector<std::string>& lines, Summary&
         if (ref_size < 0) throw std::runtime_error("Reference sequence not found: " + f.row.refId);
         const int64_t query_size = query->seq_len(f.row.qId);
         if (query_size < 0) throw std::runtime_error("Query sequence not found: " + f.row.qId);
-        const uint64_t head_pad = (uint64_t)f.row.rStartPos >= param.wflign_max_len_minor ? param.wflign_max_len_minor : (uint64_t)f.row.rStartPos;
-        const uint64_t tail_pad = (uint64_t)(ref_size - f.row.rEndPos) >= param.wflign_max_len_minor ? param.wflign_max_len_minor : (uint64_t)(ref_size - f.row.rEndPos);
-        f.ref = ref->fetch(f.row.refId, f.row.rStartPos - (int64_t)head_pad, f.row.rEndPos + (int64_t)tail_pad - 1);
-        if (f.ref.empty()) throw std::runtime_error("Failed to fetch reference sequence");
-        std::string q = query->fetch(f.row.qId, f.row.qStartPos, f.row.qEndPos - 1);
-        if (q.empty()) throw std::runtime_error("Failed to fetch query sequence");
-        f.ref_start = (uint64_t)f.row.rStartPos - head_pad;
         f.ref_total = (uint64_t)ref_size; f.q_total = (uint64_t)query_size;
-        upper_valid_dna(f.ref);
-        upper_valid_dna(q);
-        f.qry = f.row.strand == FWD ? std::move(q) : revcomp(q);
-        bases += f.ref.size() + f.qry.size();
-        fetched.push_back(std::move(f));
+        bases += (uint64_t)std::max<int64_t>(0, f.row.rEndPos - f.row.rStartPos) + (uint64_t)std::max<int64_t>(0, f.row.qEndPos - f.row.qStartPos);
+        rows.push_back(std::move(f));
       } catch (const std::exception& e) {
         std::cerr << "[wfmash::align] Error processing record: " << e.what() << std::endl;
         sum.skipped++;
       }
+    }
+    std::vector<std::string> fetch_error(rows.size());
+    {
+      std::atomic<size_t> next{0};
+      auto work = [&] {
+        for (size_t k; (k = next.fetch_add(1)) < rows.size();) {
+          Fetched& f = rows[k];
+          try {
+            const int64_t ref_size = (int64_t)f.ref_total;
+            const uint64_t head_pad = (uint64_t)f.row.rStartPos >= param.wflign_max_len_minor ? param.wflign_max_len_minor : (uint64_t)f.row.rStartPos;
+            const uint64_t tail_pad = (uint64_t)(ref_size - f.row.rEndPos) >= param.wflign_max_len_minor ? param.wflign_max_len_minor : (uint64_t)(ref_size - f.row.rEndPos);
+            f.ref = ref->fetch(f.row.refId, f.row.rStartPos - (int64_t)head_pad, f.row.rEndPos + (int64_t)tail_pad - 1);
+            if (f.ref.empty()) throw std::runtime_error("Failed to fetch reference sequence");
+            std::string q = query->fetch(f.row.qId, f.row.qStartPos, f.row.qEndPos - 1);
+            if (q.empty()) throw std::runtime_error("Failed to fetch query sequence");
+            f.ref_start = (uint64_t)f.row.rStartPos - head_pad;
+            upper_valid_dna(f.ref);
+            upper_valid_dna(q);
+            f.qry = f.row.strand == FWD ? std::move(q) : revcomp(q);
+          } catch (const std::exception& e) {
+            fetch_error[k] = e.what();
+            if (fetch_error[k].empty()) fetch_error[k] = "error";
+          }
+        }
+      };
+      const int nt = (int)std::min<size_t>((size_t)std::max(1, param.threads), rows.size());
+      std::vector<std::thread> pool;
+      for (int t = 1; t < nt; ++t) pool.emplace_back(work);
+      work();
+      for (auto& t : pool) t.join();
+    }
+    std::vector<Fetched> fetched;
+    fetched.reserve(rows.size());
+    for (size_t k = 0; k < rows.size(); ++k) {
+      if (!fetch_error[k].empty()) {
+        std::cerr << "[wfmash::align] Error processing record: " << fetch_error[k] << std::endl;
+        sum.skipped++;
+        continue;
+      }
+      fetched.push_back(std::move(rows[k]));
     }
     if (fetched.empty()) continue;
     std::vector<wflign::BiwfaRecord> recs(fetched.size());
@@ -194,6 +227,7 @@ std::string Aligner::align_lines(const std::vector<std::string>& lines, Summary&
     fmt.paf_format_else_sam = !param.sam_format;
     fmt.no_seq_in_sam = param.no_seq_in_sam;
     fmt.emit_md_tag = param.emit_md_tag;
+    fmt.threads = param.threads;
     const int rc = wflign::do_biwfa_alignment_batch(gpu, recs, pen, param.disable_chain_patching, pp, &st, fmt);
     if (rc < 0) throw std::runtime_error(std::string("[wfmash::align] GPU alignment failed: ") + wfm_last_error(gpu));
     sum.cells += st.cells; sum.ms_gpu += st.ms_gpu;

@@ -1,7 +1,9 @@
 // capi_host.cpp -- C entry points of the host-side align driver (include/wfmash_host.h).
+#include <algorithm>
 #include <exception>
 #include <iostream>
 #include <string>
+#include <thread>
 
 #include "../../include/wfmash_host.h"
 #include "../csrc/wfa_handle.h"
@@ -18,6 +20,7 @@ void wfmh_align_default_params(wfmh_align_params_t* p) {
   p->target_padding = 1000; p->query_padding = 1000; p->wflign_max_len_minor = 128000;
   p->disable_chain_patching = 0;
   p->sam_format = 0; p->emit_md_tag = 0; p->no_seq_in_sam = 0;
+  p->threads = 0; p->pad_ = 0;
 }
 
 int wfmh_align_paf(wfm_handle_t* h, const char* target_fasta, const char* query_fasta, const char* mapping_paf,
@@ -45,6 +48,7 @@ int wfmh_align_paf(wfm_handle_t* h, const char* target_fasta, const char* query_
     ap.wflign_max_len_minor = d.wflign_max_len_minor;
     ap.disable_chain_patching = d.disable_chain_patching != 0;
     ap.sam_format = d.sam_format != 0; ap.emit_md_tag = d.emit_md_tag != 0; ap.no_seq_in_sam = d.no_seq_in_sam != 0;
+    ap.threads = d.threads > 0 ? d.threads : (int)std::max(1u, std::thread::hardware_concurrency());
     align::Aligner aligner(ap, h);
     const align::Summary s = aligner.compute();
     if (summary) {

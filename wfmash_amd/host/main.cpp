@@ -69,7 +69,7 @@ int main(int argc, char** argv) {
     else if (a == "-i" || a == "--align-paf") mapping_in = next("-i");
     else if (a == "--out") out = next("--out");
     else if (a == "--device") device = atoi(next("--device").c_str());
-    else if (a == "-t" || a == "--threads") mp.threads = atoi(next("-t").c_str());
+    else if (a == "-t" || a == "--threads") { mp.threads = atoi(next("-t").c_str()); ap.threads = mp.threads; }
     // ---- mapping (parse_args.hpp:71-115)
     else if (a == "-k" || a == "--kmer-size") mp.kmer_size = atoi(next("-k").c_str());
     else if (a == "-s" || a == "--sketch-size") mp.sketch_size = atoi(next("-s").c_str());

@@ -4,6 +4,8 @@
 #include "wflign_hip.hpp"
 
 #include <algorithm>
+#include <thread>
+#include <atomic>
 #include <cctype>
 #include <cmath>
 #include <cstring>
@@ -380,6 +382,20 @@ bool write_alignment_sam(std::string& out, const std::string& cigar_str, const s
 // batch pipeline
 // ---------------------------------------------------------------------------
 namespace {
+// fn(i) for i in [0, n) on up to `threads` threads; records are independent of each other (the reference runs one
+// Taskflow task per record, computeAlignments.hpp:391-435)
+template <typename F>
+void for_each_record(size_t n, int threads, F&& fn) {
+  const int nt = (int)std::min<size_t>((size_t)std::max(1, threads), n);
+  if (nt <= 1) { for (size_t i = 0; i < n; ++i) fn(i); return; }
+  std::atomic<size_t> next{0};
+  auto work = [&] { for (size_t i; (i = next.fetch_add(1)) < n;) fn(i); };
+  std::vector<std::thread> pool;
+  for (int t = 1; t < nt; ++t) pool.emplace_back(work);
+  work();
+  for (auto& t : pool) t.join();
+}
+
 struct GpuBatch {
   std::vector<wfm_problem_t> probs;
   std::vector<wfm_result_t> res;
@@ -415,21 +431,25 @@ int do_biwfa_alignment_batch(wfm_handle_t* h, std::vector<BiwfaRecord>& recs, co
   }
   int rc = g.run(h, pen, stats);
   if (rc < 0) return rc;
-  for (size_t i = 0; i < recs.size(); ++i) {
+  const int nt = fmt.threads;
+  for_each_record(recs.size(), nt, [&](size_t i) {
     recs[i].ok = (g.res[i].status == 0);  // status != 0: the reference drops the record silently (wflign.cpp:150-152)
     recs[i].score = g.res[i].score;
     recs[i].paf.clear();
     if (recs[i].ok) recs[i].cigar = g.cigar(i);
-    else if (stats) stats->main_failed++;
-  }
+  });
+  if (stats)
+    for (const auto& r : recs) stats->main_failed += !r.ok;
   if (!disable_chain_patching) {
     // ---- stage 2: head patches (wflign.cpp:241-320) ----
     std::vector<size_t> owner;
     std::vector<Erosion> ero;
     g.probs.clear();
+    std::vector<Erosion> scanned(recs.size());
+    for_each_record(recs.size(), nt, [&](size_t i) { if (recs[i].ok) scanned[i] = scan_head_erosion(recs[i].cigar); });
     for (size_t i = 0; i < recs.size(); ++i) {
       if (!recs[i].ok) continue;
-      const Erosion e = scan_head_erosion(recs[i].cigar);
+      const Erosion& e = scanned[i];
       if (e.query_eroded > 3 || e.target_eroded > 3) {
         wfm_problem_t p{};
         p.pattern = recs[i].target; p.plen = (int32_t)e.target_eroded;
@@ -442,20 +462,27 @@ int do_biwfa_alignment_batch(wfm_handle_t* h, std::vector<BiwfaRecord>& recs, co
     }
     rc = g.run(h, pen, stats);
     if (rc < 0) return rc;
-    for (size_t j = 0; j < owner.size(); ++j) {
-      if (g.res[j].status != 0) continue;
+    for_each_record(owner.size(), nt, [&](size_t j) {
+      if (g.res[j].status != 0) return;
       BiwfaRecord& r = recs[owner[j]];
       std::string head = erode_short_matches_in_cigar(g.cigar(j), 3, true);
       r.cigar = merge_adjacent_ops(head, r.cigar.substr(ero[j].erode_end_pos));
-      if (stats) stats->head_patches++;
-    }
+    });
+    if (stats)
+      for (size_t j = 0; j < owner.size(); ++j) stats->head_patches += g.res[j].status == 0;
     // ---- stage 3: tail patches (wflign.cpp:323-418), on the head-patched CIGAR ----
     owner.clear(); ero.clear(); g.probs.clear();
     std::vector<CigarOps> parsed;
+    std::vector<CigarOps> all_ops(recs.size());
+    for_each_record(recs.size(), nt, [&](size_t i) {
+      if (!recs[i].ok) return;
+      all_ops[i] = parse_cigar(recs[i].cigar);
+      scanned[i] = scan_tail_erosion(all_ops[i]);
+    });
     for (size_t i = 0; i < recs.size(); ++i) {
       if (!recs[i].ok) continue;
-      CigarOps ops = parse_cigar(recs[i].cigar);
-      const Erosion e = scan_tail_erosion(ops);
+      CigarOps& ops = all_ops[i];
+      const Erosion& e = scanned[i];
       if (e.query_eroded > 3 || e.target_eroded > 3) {
         wfm_problem_t p{};
         p.pattern = recs[i].target + recs[i].target_length - e.target_eroded; p.plen = (int32_t)e.target_eroded;
@@ -468,18 +495,20 @@ int do_biwfa_alignment_batch(wfm_handle_t* h, std::vector<BiwfaRecord>& recs, co
     }
     rc = g.run(h, pen, stats);
     if (rc < 0) return rc;
-    for (size_t j = 0; j < owner.size(); ++j) {
-      if (g.res[j].status != 0) continue;
+    for_each_record(owner.size(), nt, [&](size_t j) {
+      if (g.res[j].status != 0) return;
       BiwfaRecord& r = recs[owner[j]];
       std::string tail = erode_short_matches_in_cigar(g.cigar(j), 3, false);
       CigarOps keep(parsed[j].begin(), parsed[j].begin() + (long)ero[j].erode_start_idx);
       r.cigar = merge_adjacent_ops(cigar_to_string(keep), tail);
-      if (stats) stats->tail_patches++;
-    }
+    });
+    if (stats)
+      for (size_t j = 0; j < owner.size(); ++j) stats->tail_patches += g.res[j].status == 0;
   }
   // ---- stage 4: swizzle + PAF (wflign.cpp:423-454) ----
-  for (auto& r : recs) {
-    if (!r.ok) continue;
+  for_each_record(recs.size(), nt, [&](size_t ri) {
+    BiwfaRecord& r = recs[ri];
+    if (!r.ok) return;
     const std::string q(r.query, r.query_length);
     const std::string t(r.target, r.target_avail ? r.target_avail : r.target_length);
     std::string sw = try_swap_start_pattern(r.cigar, q, t, 0, 0);
@@ -494,7 +523,7 @@ int do_biwfa_alignment_batch(wfm_handle_t* h, std::vector<BiwfaRecord>& recs, co
       write_alignment_sam(r.paf, r.cigar, r.query_name, r.query_offset, r.query_is_rev, r.target_name, r.target_offset, pp,
                           r.mashmap_estimated_identity, fmt.no_seq_in_sam, fmt.emit_md_tag, r.query, r.target,
                           r.chain_id, r.chain_length, r.chain_pos);
-  }
+  });
   return 0;
 }
 

@@ -110,6 +110,7 @@ struct OutputFormat {
   bool paf_format_else_sam = true;   // wflign.cpp:434
   bool no_seq_in_sam = false;
   bool emit_md_tag = false;
+  int threads = 1;                   // host threads for the per-record CIGAR / PAF work of a batch
 };
 
 int do_biwfa_alignment_batch(wfm_handle_t* h, std::vector<BiwfaRecord>& recs, const wflign_penalties_t& penalties,
