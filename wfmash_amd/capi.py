@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libwfmash_hip.so")
+LIB_PATH = os.environ.get("WFM_LIB_PATH") or os.path.join(_HERE, "libwfmash_hip.so")  # WFM_LIB_PATH: A/B runs of two builds
 
 WFM_MODE_END2END_BIWFA = 0
 WFM_MODE_ENDSFREE = 1

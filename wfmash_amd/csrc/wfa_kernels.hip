@@ -1132,6 +1132,37 @@ __device__ __forceinline__ uint64_t win_xor8(const uint8_t* P, const uint8_t* T,
 __device__ __forceinline__ int win_lce(const uint8_t* P, const uint8_t* T, const uint32_t* winP, const uint32_t* winT, int v, int h, int maxn,
                                        int wP0, int wT0) {
   int n = 0;
+  // 32 bases per round: the loads of a round do not depend on each other, so a long run of matches (low
+  // divergence: hundreds of bases between two differences) costs one LDS / L2 round trip per 32 bases, not per 8
+  while (n + 32 <= maxn) {
+    const unsigned ov = (unsigned)(v + n - wP0), oh = (unsigned)(h + n - wT0);
+    uint64_t x0, x1, x2, x3;
+    if (ov <= (unsigned)(SEQ_WIN - 32) && oh <= (unsigned)(SEQ_WIN - 32)) {
+      const uint32_t* a = winP + (ov >> 2);
+      const uint32_t* b = winT + (oh >> 2);
+      const unsigned sa = (ov & 3u) * 8u, sb = (oh & 3u) * 8u;
+      uint32_t wa[9], wb[9];
+#pragma unroll
+      for (int q = 0; q < 9; ++q) { wa[q] = a[q]; wb[q] = b[q]; }
+      uint32_t d[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) d[q] = __builtin_amdgcn_alignbit(wa[q + 1], wa[q], sa) ^ __builtin_amdgcn_alignbit(wb[q + 1], wb[q], sb);
+      x0 = ((uint64_t)d[1] << 32) | d[0]; x1 = ((uint64_t)d[3] << 32) | d[2];
+      x2 = ((uint64_t)d[5] << 32) | d[4]; x3 = ((uint64_t)d[7] << 32) | d[6];
+    } else {
+      const uint8_t* pp = P + (v + n);
+      const uint8_t* tt = T + (h + n);
+      x0 = load8(pp) ^ load8(tt); x1 = load8(pp + 8) ^ load8(tt + 8);
+      x2 = load8(pp + 16) ^ load8(tt + 16); x3 = load8(pp + 24) ^ load8(tt + 24);
+    }
+    if (x0 | x1 | x2 | x3) {
+      if (x0) return n + (int)(__builtin_ctzll(x0) >> 3);
+      if (x1) return n + 8 + (int)(__builtin_ctzll(x1) >> 3);
+      if (x2) return n + 16 + (int)(__builtin_ctzll(x2) >> 3);
+      return n + 24 + (int)(__builtin_ctzll(x3) >> 3);
+    }
+    n += 32;
+  }
   while (n < maxn) {
     const uint64_t x = win_xor8(P, T, winP, winT, v + n, h + n, wP0, wT0);
     if (x) { n += (int)(__builtin_ctzll(x) >> 3); break; }
