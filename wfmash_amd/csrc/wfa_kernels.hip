@@ -40,21 +40,34 @@ __device__ __forceinline__ uint64_t load8(const uint8_t* p) {
   return v;
 }
 
+// common prefix of a[n..) and b[n..) counted from 0, at most maxn: 32 bases per round while they last (the four
+// loads of a round are independent: one memory round trip per 32 matching bases instead of per 8 -- at low
+// divergence a run of matches is hundreds of bases long), then 8 at a time.  May return more than maxn when the
+// last word read runs past it; callers cap.
+__device__ __forceinline__ int lce_from(const uint8_t* a, const uint8_t* b, int n, int maxn) {
+  while (n + 32 <= maxn) {
+    const uint64_t x0 = load8(a + n) ^ load8(b + n), x1 = load8(a + n + 8) ^ load8(b + n + 8);
+    const uint64_t x2 = load8(a + n + 16) ^ load8(b + n + 16), x3 = load8(a + n + 24) ^ load8(b + n + 24);
+    if (x0 | x1 | x2 | x3) {
+      if (x0) return n + (int)(__builtin_ctzll(x0) >> 3);
+      if (x1) return n + 8 + (int)(__builtin_ctzll(x1) >> 3);
+      if (x2) return n + 16 + (int)(__builtin_ctzll(x2) >> 3);
+      return n + 24 + (int)(__builtin_ctzll(x3) >> 3);
+    }
+    n += 32;
+  }
+  while (n < maxn) {
+    const uint64_t x = load8(a + n) ^ load8(b + n);
+    if (x) return n + (int)(__builtin_ctzll(x) >> 3);
+    n += 8;
+  }
+  return n;
+}
+
 // longest common extension of P[v..) and T[h..), bounded by the sub-problem ends
 __device__ __forceinline__ int lce_bounded(const uint8_t* P, const uint8_t* T, int v, int h, int pl, int tl) {
   const int maxn = min(pl - v, tl - h);
-  const uint8_t* a = P + v;
-  const uint8_t* b = T + h;
-  int n = 0;
-  while (n < maxn) {
-    const uint64_t x = load8(a + n) ^ load8(b + n);
-    if (x) {
-      n += (int)(__builtin_ctzll(x) >> 3);
-      break;
-    }
-    n += 8;
-  }
-  return min(n, maxn);
+  return min(lce_from(P + v, T + h, 0, maxn), maxn);
 }
 
 struct Src {
@@ -213,16 +226,7 @@ __device__ __forceinline__ void bp_cells4(const BpCtx& c, const uint8_t* P, cons
       const int k = k0 + j;
       int n;
       if (x[j]) n = (int)(__builtin_ctzll(x[j]) >> 3);
-      else {
-        n = 8;
-        const uint8_t* a = P + (m[j] - k);
-        const uint8_t* b = T + m[j];
-        while (n < maxn[j]) {
-          const uint64_t y = load8(a + n) ^ load8(b + n);
-          if (y) { n += (int)(__builtin_ctzll(y) >> 3); break; }
-          n += 8;
-        }
-      }
+      else n = lce_from(P + (m[j] - k), T + m[j], 8, maxn[j]);
       m[j] += min(n, maxn[j]);
       mak = max(mak, 2 * m[j] - k);
     }
