@@ -138,7 +138,7 @@ def main():
         peak = 8000.0
         traffic = None  # HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/)
         try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r1f_traffic.json")))
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r1g_traffic.json")))
             if tj.get("kernel") == dom and args.config == "C3" and args.pairs == 64:
                 traffic = tj["traffic_bytes_per_launch"]
         except (OSError, ValueError, KeyError):
@@ -166,7 +166,7 @@ def main():
                                  "The batch runs as up to three parts on as many streams, so launches of this kernel overlap each other: "
                                  "avg_launch_ms (what rocprofv3 shows per launch) is stretched by the sharing, the running "
                                  "time is the union of the launch intervals from HIP events; WFM_OVERLAP=0 gives the "
-                                 "exclusive figure (0.93, profiles/r1d_align.md); profiles/r1f_align.md is this configuration. The tiled kernel keeps wavefront history "
+                                 "exclusive figure (0.93, profiles/r1d_align.md); profiles/r1g_align.md is this configuration. The tiled kernel keeps wavefront history "
                                  "in registers, so real HBM traffic (traffic, per launch) is far below the algorithmic bytes"},
             "kernel_ms_per_step": {"wfa_tile_reg_kernel": ms_tile / args.steps, "wfa_bp_kernel": (ms_bp - ms_tile) / args.steps,
                                    "wfa_base_kernel": ms_base / args.steps},
