@@ -156,6 +156,42 @@ def test_memory_budget_chunking(oracle, monkeypatch):
         h.close()
 
 
+@pytest.mark.parametrize("band_root", ["4096", "200"], ids=["bands_hold", "bands_overflow"])
+def test_narrow_rings_and_their_retries(oracle, monkeypatch, capfd, band_root):
+    """When a level does not fit the memory budget, jobs get rings for the diagonals they are expected to reach only
+    (low-divergence long records); a job that runs out of its band is run again on a full ring.  Forced here with a
+    small budget; with 200 root scores most roots overflow (in the tile phase or in the step kernel) and are retried."""
+    monkeypatch.setenv("WFM_MEM_BUDGET_MB", "96")
+    monkeypatch.setenv("WFM_BAND_ROOT", band_root)
+    monkeypatch.setenv("WFM_DEBUG", "1")
+    monkeypatch.setenv("WFM_OVERLAP", "0")
+    h = capi.Handle(0)
+    try:
+        items = _pairs(31, 40, [9000, 14000], [0.002, 0.01, 0.04])
+        _check_batch(h, oracle, items)
+    finally:
+        h.close()
+    err = capfd.readouterr().err
+    lines = [l for l in err.splitlines() if "narrow rings" in l]
+    assert lines, err[-1500:]
+    jobs, retried = (int(x) for x in __import__("re").search(r"narrow rings: (\d+) jobs, (\d+) ran out", lines[-1]).groups())
+    assert jobs > 0
+    if band_root == "200":
+        assert retried > 0, lines[-1]
+
+
+def test_narrow_rings_can_be_switched_off(oracle, monkeypatch, capfd):
+    monkeypatch.setenv("WFM_MEM_BUDGET_MB", "96")
+    monkeypatch.setenv("WFM_BAND", "0")
+    monkeypatch.setenv("WFM_DEBUG", "1")
+    h = capi.Handle(0)
+    try:
+        _check_batch(h, oracle, _pairs(32, 12, [9000], [0.01]))
+    finally:
+        h.close()
+    assert "narrow rings" not in capfd.readouterr().err
+
+
 def test_repeated_calls_reuse_handle(gpu, oracle):
     items = _pairs(13, 10, [500, 2000], [0.05])
     a = gpu.align(items)

@@ -20,6 +20,7 @@ enum { BT_I1_EXT = 8, BT_I2_EXT = 16, BT_D1_EXT = 32, BT_D2_EXT = 64 };
 
 constexpr int WFM_DEV_UNREACHABLE = -300;
 constexpr int WFM_DEV_OVERFLOW = -2;  // base job exceeded its score budget (smax)
+constexpr int WFM_DEV_BAND = -4;      // bialign job ran out of its diagonal band (BpJob::band)
 
 struct DevPen { int x, o1, e1, o2, e2; };
 
@@ -32,7 +33,10 @@ struct BpJob {
   int32_t koff;                        // column = k + koff (multiple of 4; normally pl + 4)
   int32_t resume_s;                    // -1: start at score 0; >= 0: the forward direction resumes at this score
   int32_t fmax0, rmax0;                // running max antidiagonals at the resume point
-  int32_t pad_;
+  int32_t band;                        // > 0: the ring only holds diagonals |k| <= band + 8 (a job that is expected to end at a low
+                                       // score gets a narrow ring); a direction that would pass score `band` ends the job with
+                                       // WFM_DEV_BAND and the host runs it again on a full ring.  resume_s == -3: the tile phase
+                                       // already ran out of the band
   // resume_sr >= 0: the snapshot is the exact meeting point found by the tile kernels -- forward at resume_s,
   // reverse at resume_sr (= resume_s or resume_s - 1), phase 1 is over; -1: both directions resume at resume_s
   int32_t resume_sr;

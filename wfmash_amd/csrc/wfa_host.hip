@@ -74,6 +74,7 @@ struct Node {
   int32_t score_rem;  // INT_MAX at the root
   int32_t smax;       // base jobs: score budget (0 = derive)
   int32_t endsfree;
+  int32_t noband;     // bialign jobs: 1 = ran out of a narrow ring once, gets the full one now
 };
 
 }  // namespace
@@ -342,6 +343,17 @@ int run_tiled_phase(wfm_handle* h, wfm_seqset* S, const DevPen& dp, int scope, c
     const int chunk = std::max(1, std::min(cfg.chunk, (int)h->tile_ev.size() / 2));
     std::vector<TileJob> got(n);
     while (n_active) {
+      // a job on a narrow ring (BpJob::band) may only start a chunk whose last score still fits; otherwise it leaves
+      // the tile phase here and is run again on a full ring (the host retries it)
+      bool out_of_band = false;
+      for (size_t i = 0; i < n; ++i) {
+        const int band = jobs[(size_t)tiled[i]].band;
+        if (active[i] && band > 0 && tj[i].s0 + chunk * T + 2 > band) {
+          active[i] = 0; tj[i].active = 0; tj[i].mode = 3; out_of_band = true; --n_active;
+        }
+      }
+      if (out_of_band) HIPCHK(h, hipMemcpyAsync(h->tilejobs.p, tj.data(), n * sizeof(TileJob), hipMemcpyHostToDevice, h->stream));
+      if (!n_active) break;
       // as many tiles of `core` diagonals per job and direction as the last block of this chunk can need
       tasks.clear();
       for (size_t i = 0; i < n; ++i) {
@@ -404,6 +416,7 @@ int run_tiled_phase(wfm_handle* h, wfm_seqset* S, const DevPen& dp, int scope, c
     ring2[i] = tj[i].ring_out;
     j.resume_s = tj[i].s0;
     j.resume_sr = -1; j.last_fwd = 0;
+    if (tj[i].mode == 3) { j.resume_s = -3; continue; }  // ran out of its band: wfa_bp_kernel reports WFM_DEV_BAND
     if (tj[i].mode == 2) {  // stopped exactly at the meeting point: the step kernel goes straight to phase 2
       j.resume_s = tj[i].s0 + tj[i].tf;
       j.resume_sr = tj[i].s0 + tj[i].tr;
@@ -466,6 +479,7 @@ int align_resident_impl(wfm_handle* h, const wfm_penalties_t* pen, wfm_seqset* S
   std::vector<int64_t> ring2;
   const TileCfg tcfg = tile_cfg(*pen, scope);
   uint64_t tile_cells_level = 0;
+  uint64_t band_retries = 0, band_jobs = 0;
   std::vector<int32_t> node_of;
   std::vector<BpResult> res;
   uint32_t level = 0;
@@ -473,6 +487,22 @@ int align_resident_impl(wfm_handle* h, const wfm_penalties_t* pen, wfm_seqset* S
     ++level;
     // ---- breakpoint jobs of this level (chunked to the memory budget) ----
     next_bp.clear();
+    // Rings cover every diagonal of a job ((pl + tl) columns of 1280 B, twice for tiled jobs): fine for a batch of
+    // few deep problems, wasteful for thousands of long low-divergence records, whose wavefronts stay within a few
+    // thousand diagonals and which would otherwise be worked off in many small chunks.  When the level does not fit
+    // the budget, jobs get rings for |k| <= band only: a child's total score is known (half of it per direction,
+    // plus the overlap phase), a root gets WFM_BAND_ROOT scores; whoever runs out of its band is run again on a
+    // full ring.  WFM_BAND=0 switches this off.
+    bool use_band = false;
+    {
+      const char* be = getenv("WFM_BAND");
+      const int band_on = be ? atoi(be) : 1;
+      size_t total = 0;
+      for (const Node& nd : bp_nodes) total += (((size_t)nd.pl + nd.tl + 9 + 3) & ~(size_t)3) * 2 * 5 * RING * 2;
+      use_band = band_on && total * 4 > h->mem_budget;
+    }
+    const char* bre = getenv("WFM_BAND_ROOT");
+    const int band_root = bre ? std::max(64, atoi(bre)) : 4096;
     size_t i0 = 0;
     while (i0 < bp_nodes.size()) {
       jobs.clear();
@@ -485,9 +515,21 @@ int align_resident_impl(wfm_handle* h, const wfm_penalties_t* pen, wfm_seqset* S
         const Node& nd = bp_nodes[i];
         const ProbMeta& pm = S->meta[nd.prob];
         size_t width = ((size_t)nd.pl + nd.tl + 9 + 3) & ~(size_t)3;  // columns 4 .. pl+tl+4, 16-byte chunks
-        const int koff = nd.pl + 4;
+        int koff = nd.pl + 4;
         bool tile_it = tcfg.enabled && nd.pl + nd.tl >= tcfg.min_len &&
                              (nd.score_rem == INT_MAX || nd.score_rem >= tcfg.min_score);
+        int band = 0;
+        if (use_band && tile_it && !nd.noband) {
+          // scores one direction is allowed to reach; the ring holds |k| <= band + 8, its left margin stays 4 columns
+          const int64_t dir_scores = nd.score_rem == INT_MAX ? (int64_t)band_root : (int64_t)nd.score_rem / 2 + 64;
+          const int64_t b = dir_scores + (int64_t)tcfg.chunk * tcfg.T + 16;
+          const int64_t shift = ((int64_t)nd.pl - (b + 8)) & ~(int64_t)3;  // columns cut off on the left, whole 16-byte chunks
+          const int64_t right = std::min<int64_t>(nd.tl, b + 8);           // largest diagonal kept
+          if (shift > 0) {
+            const size_t w = ((size_t)((int64_t)nd.pl - shift + right + 9) + 3) & ~(size_t)3;
+            if (w * 2 <= width) { band = (int)b; width = w; koff = (int)(nd.pl + 4 - shift); }
+          }
+        }
         if (tile_it && width * 2 * 5 * RING * 2 * 4 > h->mem_budget) tile_it = false;  // two snapshot rings do not fit: step-by-step kernel
         const size_t need = width * 2 * 5 * RING * (tile_it ? 2 : 1);
         if (!jobs.empty() && (ring_elems + need) * 4 > h->mem_budget) break;
@@ -503,6 +545,8 @@ int align_resident_impl(wfm_handle* h, const wfm_penalties_t* pen, wfm_seqset* S
         j.width = (int32_t)width;
         j.koff = koff;
         j.resume_s = -1; j.resume_sr = -1; j.last_fwd = 0; j.fmax0 = 0; j.rmax0 = 0;
+        j.band = band;
+        band_jobs += band > 0;
         if (tile_it) { tiled.push_back((int)jobs.size()); ring2.push_back((int64_t)(ring_elems + need / 2)); }
         node_of.push_back((int32_t)i);
         ring_elems += need;
@@ -556,10 +600,16 @@ int align_resident_impl(wfm_handle* h, const wfm_penalties_t* pen, wfm_seqset* S
                   (double)c, (double)st1 / jobs.size(), (double)(st - st1) / jobs.size(), t1 / jobs.size() / 1e5, t2 / jobs.size() / 1e5, m1 / 1e5, m2 / 1e5);
         }
         for (size_t q = 0; q < jobs.size(); ++q) {
-          const Node& nd = bp_nodes[(size_t)node_of[q]];
+          const Node nd = bp_nodes[(size_t)node_of[q]];  // a copy: retries are appended to bp_nodes below
           const BpResult& r = res[q];
           prob_cells[nd.prob] += r.cells;
           h->stats.cells_bp += r.cells;
+          if (r.status == WFM_DEV_BAND) {  // ran out of its narrow ring: once more, at the end of this level, on a full one
+            Node again = nd; again.noband = 1;
+            bp_nodes.push_back(again);
+            ++band_retries;
+            continue;
+          }
           if (r.status == 1) {  // end reached at score 0 -> base aligner
             Node b = nd; b.smax = 0; base_nodes.push_back(b);
           } else if (r.status != 0) {
@@ -594,6 +644,7 @@ int align_resident_impl(wfm_handle* h, const wfm_penalties_t* pen, wfm_seqset* S
     }
   }
   h->stats.levels = level;
+  if (getenv("WFM_DEBUG") && band_jobs) fprintf(stderr, "[wfm] narrow rings: %llu jobs, %llu ran out of their band and were run again on full rings\n", (unsigned long long)band_jobs, (unsigned long long)band_retries);
   const auto t_levels = std::chrono::steady_clock::now();
 
   // ---- gather RLE pieces ----
@@ -834,7 +885,16 @@ int wfm_align_resident(wfm_handle_t* h, const wfm_penalties_t* pen, wfm_seqset_t
   // (read-only) sequences and the caller's output buffers.
   static const int want = [] { const char* e = getenv("WFM_STREAMS"); return e ? std::max(1, std::min(8, atoi(e))) : 3; }();  // measured: 2 -> 124, 3 -> 120, 4 -> 160 ms on C3
   // every part needs room for its own arenas: no split below 256 MB per part
-  const size_t parts = std::min<size_t>(std::min<size_t>((size_t)want, n / 4), h->mem_budget_full >> 28);
+  size_t parts = std::min<size_t>(std::min<size_t>((size_t)want, n / 4), h->mem_budget_full >> 28);
+  if (!getenv("WFM_STREAMS") && parts > 2) {
+    // a batch whose full rings would not fit the budget -- thousands of long records, which then run on narrow
+    // rings -- is bound by the host's work between the many small launches: measured best with two parts
+    // (C4-like records, 60 Mbp of queries: 2 -> 2.6 s, 3 -> 3.5 s)
+    size_t ring_bytes = 0;
+    for (size_t i = 0; i < n && ring_bytes <= h->mem_budget_full; ++i)
+      ring_bytes += ((size_t)s->meta[i].plen + (size_t)s->meta[i].tlen + 9) * 2 * 5 * RING * 2 * 4;
+    if (ring_bytes > h->mem_budget_full) parts = 2;
+  }
   if (parts < 2) {
     const int rc = align_resident_impl(h, pen, s, 0, n, out, ops_arena, arena_bytes, 0);
     h->stats.ms_tile_busy = busy_ms(h->tile_iv);

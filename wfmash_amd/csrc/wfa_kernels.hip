@@ -455,6 +455,15 @@ __global__ __launch_bounds__(1024) void wfa_bp_kernel(const uint8_t* __restrict_
   __shared__ int s_bp[8];  // score, score_fwd, score_rev, k_fwd, off_fwd, comp
   __shared__ int s_rmax[2][RING][5];
 
+  if (J.resume_s == -3) {  // the tile phase ran out of the job's band: nothing to do here, the host retries on a full ring
+    if (threadIdx.x == 0) {
+      BpResult r; r.status = WFM_DEV_BAND; r.score = 0; r.score_fwd = 0; r.score_rev = 0; r.k_fwd = 0; r.off_fwd = 0; r.comp = 0; r.steps = 0; r.cells = 0;
+      r.steps_p1 = 0; r.ticks_p1 = 0; r.ticks_p2 = 0; r.pad_ = 0;
+      results[blockIdx.x] = r;
+    }
+    return;
+  }
+  const int band = J.band;
   BpCtx c;
   c.P[0] = seq + J.p_fwd; c.T[0] = seq + J.t_fwd;
   c.P[1] = seq + J.p_rev; c.T[1] = seq + J.t_rev;
@@ -514,6 +523,7 @@ __global__ __launch_bounds__(1024) void wfa_bp_kernel(const uint8_t* __restrict_
   //  computed here in one pass and the checks replayed in the same order)
   for (;;) {
     if (fmax + rmax >= A) break;
+    if (band > 0 && max(sf, sr) + 2 > band) { status = WFM_DEV_BAND; break; }
     buf = (buf + 1) % 3;
     if (tid == 0) { s_mak[(buf + 1) % 3][0] = 0; s_mak[(buf + 1) % 3][1] = 0; }
     // per-component row maxima (phase-2 pruning) ride along: the slots of the rows computed NEXT
@@ -620,6 +630,7 @@ __global__ __launch_bounds__(1024) void wfa_bp_kernel(const uint8_t* __restrict_
         best = s_bp[6];
       }
       // advance the other direction
+      if (band > 0 && max(sf, sr) + 2 > band) { status = WFM_DEV_BAND; break; }
       int mak = 0;
       if (tid < 5) s_rmax[d0 ^ 1][((d0 == 0 ? sr : sf) + 1) & RMASK][tid] = 0;
       __syncthreads();  // the clear must not race with the atomics of faster waves below
@@ -642,6 +653,7 @@ __global__ __launch_bounds__(1024) void wfa_bp_kernel(const uint8_t* __restrict_
     BpResult r;
     r.status = status;
     if (status == 0 && best == INT32_MAX) r.status = WFM_DEV_UNREACHABLE;
+    if (status == WFM_DEV_BAND) r.status = WFM_DEV_BAND;  // a breakpoint found so far may not be the best one
     r.score = best; r.score_fwd = s_bp[1]; r.score_rev = s_bp[2]; r.k_fwd = s_bp[3]; r.off_fwd = s_bp[4]; r.comp = s_bp[5];
     r.steps = sf + sr;
     r.cells = cells;
