@@ -49,6 +49,7 @@ static void usage() {
 int main(int argc, char** argv) {
   wfmh_align_params_t ap;
   wfmh_align_default_params(&ap);
+  ap.threads = 1;  // -t, default 1 as in the reference (parse_args.hpp: thread_count); the C ABI default (0) means all cores
   wfmh_map_params_t mp;
   wfmh_map_default_params(&mp);
   std::string mapping_in, out = "/dev/stdout", target, query;
