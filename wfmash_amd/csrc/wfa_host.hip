@@ -479,7 +479,8 @@ int align_resident_impl(wfm_handle* h, const wfm_penalties_t* pen, wfm_seqset* S
   std::vector<int64_t> ring2;
   const TileCfg tcfg = tile_cfg(*pen, scope);
   uint64_t tile_cells_level = 0;
-  uint64_t band_retries = 0, band_jobs = 0;
+  uint64_t band_retries = 0, band_jobs = 0, roots_banded = 0, roots_out = 0;
+  bool roots_off = false;
   std::vector<int32_t> node_of;
   std::vector<BpResult> res;
   uint32_t level = 0;
@@ -519,7 +520,7 @@ int align_resident_impl(wfm_handle* h, const wfm_penalties_t* pen, wfm_seqset* S
         bool tile_it = tcfg.enabled && nd.pl + nd.tl >= tcfg.min_len &&
                              (nd.score_rem == INT_MAX || nd.score_rem >= tcfg.min_score);
         int band = 0;
-        if (use_band && tile_it && !nd.noband) {
+        if (use_band && tile_it && !nd.noband && !(roots_off && nd.score_rem == INT_MAX)) {
           // scores one direction is allowed to reach; the ring holds |k| <= band + 8, its left margin stays 4 columns
           const int64_t dir_scores = nd.score_rem == INT_MAX ? (int64_t)band_root : (int64_t)nd.score_rem / 2 + 64;
           const int64_t b = dir_scores + (int64_t)tcfg.chunk * tcfg.T + 16;
@@ -604,6 +605,7 @@ int align_resident_impl(wfm_handle* h, const wfm_penalties_t* pen, wfm_seqset* S
           const BpResult& r = res[q];
           prob_cells[nd.prob] += r.cells;
           h->stats.cells_bp += r.cells;
+          if (nd.score_rem == INT_MAX && jobs[q].band > 0) { ++roots_banded; roots_out += r.status == WFM_DEV_BAND; }
           if (r.status == WFM_DEV_BAND) {  // ran out of its narrow ring: once more, at the end of this level, on a full one
             Node again = nd; again.noband = 1;
             bp_nodes.push_back(again);
@@ -630,6 +632,9 @@ int align_resident_impl(wfm_handle* h, const wfm_penalties_t* pen, wfm_seqset* S
           }
         }
       }
+      // a root's band is a guess (its score is not known): when the guess keeps failing -- a batch of divergent
+      // records -- the remaining roots get full rings right away instead of paying for the attempt
+      if (!roots_off && roots_banded >= 16 && roots_out * 4 > roots_banded) roots_off = true;
       i0 = chunk_end;
     }
     bp_nodes.swap(next_bp);
