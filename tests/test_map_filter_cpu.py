@@ -65,6 +65,22 @@ def test_filter_subset_matches_reference_live(fai):
     assert total > 1000
 
 
+def test_filter_input_order_fast_and_general_paths(fai):
+    """The chaining sorts take a shortcut when the mappings arrive the way the GPU stages deliver them (fragment
+    order, per fragment by target position) and fall back to std::sort otherwise: both orders of the same mappings,
+    with the scaffold filter on, against the reference's own code."""
+    if not pyfilter.have_ref():
+        pytest.skip("oracle/_ref/libref_filter.so is built from /root/reference")
+    for seed in (201, 202, 203):
+        m = FC.make_mappings("live", "A#1#c1", seed, {})
+        ordered = np.sort(m, order=["queryStartPos", "refSeqId", "refStartPos"])
+        shuffled = ordered.copy()
+        np.random.default_rng(seed).shuffle(shuffled)
+        P = capi.map_default_params()
+        for arr in (ordered, ordered[::-1].copy(), shuffled):
+            assert capi.host_filter("subset", arr, fai, "A#1#c1", P) == pyfilter.ref_filter("subset", arr, fai, "A#1#c1", P)
+
+
 def test_sequence_id_manager_groups(fai, tmp_path):
     """ids follow the .fai order, groups the sorted names up to the LAST delimiter (sequenceIds.hpp:286-338)."""
     # a mapping onto every target prints its name and length through the id manager

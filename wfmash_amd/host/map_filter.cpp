@@ -291,11 +291,36 @@ std::vector<offset_t> chain_mappings(MappingResultsVector_t& readMappings, int m
 
   std::vector<uint32_t> p(n);
   std::iota(p.begin(), p.end(), 0u);
-  std::sort(p.begin(), p.end(), [&](uint32_t i, uint32_t j) {
-    const MappingResult &a = readMappings[i], &b = readMappings[j];
-    const auto as = a.strand(), bs = b.strand();
-    return std::tie(a.refSeqId, as, a.queryStartPos, a.refStartPos) < std::tie(b.refSeqId, bs, b.queryStartPos, b.refStartPos);
-  });
+  {
+    // the comparator only reads four fields: from a compact key array (16 B per mapping) the index sort touches
+    // a third of the memory; same comparisons, same permutation
+    struct Key { uint32_t ref; int32_t strand; uint32_t q, r; };
+    std::vector<Key> key(n);
+    for (size_t i = 0; i < n; ++i) key[i] = {(uint32_t)readMappings[i].refSeqId, (int32_t)readMappings[i].strand(), (uint32_t)readMappings[i].queryStartPos, (uint32_t)readMappings[i].refStartPos};
+    auto less = [&](uint32_t i, uint32_t j) {
+      const Key &a = key[i], &b = key[j];
+      return std::tie(a.ref, a.strand, a.q, a.r) < std::tie(b.ref, b.strand, b.q, b.r);
+    };
+    // The mappings of one query arrive in fragment order, per fragment by target position: within a (target,
+    // strand) group they are usually in order already.  So: group them stably (a counting pass) and check; when
+    // every key is strictly above its predecessor that IS the sorted order, whatever the sort algorithm.  Any tie
+    // or inversion falls back to std::sort on the original order, whose tie order the reference's output has.
+    bool sorted_fast = false;
+    {
+      std::vector<std::pair<uint64_t, uint32_t>> groups;  // (ref, strand) -> count, in key order
+      std::map<uint64_t, uint32_t> count;
+      for (size_t i = 0; i < n; ++i) ++count[((uint64_t)key[i].ref << 32) | ((uint32_t)key[i].strand ^ 0x80000000u)];
+      std::map<uint64_t, size_t> start;
+      size_t at = 0;
+      for (const auto& kv : count) { start[kv.first] = at; at += kv.second; }
+      std::vector<uint32_t> q(n);
+      for (size_t i = 0; i < n; ++i) q[start[((uint64_t)key[i].ref << 32) | ((uint32_t)key[i].strand ^ 0x80000000u)]++] = (uint32_t)i;
+      sorted_fast = true;
+      for (size_t i = 1; i < n && sorted_fast; ++i) sorted_fast = less(q[i - 1], q[i]);
+      if (sorted_fast) p.swap(q);
+    }
+    if (!sorted_fast) std::sort(p.begin(), p.end(), less);
+  }
   readMappings = permuted(readMappings, p);
   chainOf = permuted(chainOf, p);
 
@@ -329,10 +354,28 @@ std::vector<offset_t> chain_mappings(MappingResultsVector_t& readMappings, int m
   for (size_t i = 0; i < n; ++i) chainOf[i] = (offset_t)sets.find(chainOf[i]);
 
   std::iota(p.begin(), p.end(), 0u);
-  std::sort(p.begin(), p.end(), [&](uint32_t i, uint32_t j) {
-    return std::tie(chainOf[i], readMappings[i].queryStartPos, readMappings[i].refStartPos) <
-           std::tie(chainOf[j], readMappings[j].queryStartPos, readMappings[j].refStartPos);
-  });
+  {
+    struct Key { offset_t chain; uint32_t q, r; };
+    std::vector<Key> key(n);
+    for (size_t i = 0; i < n; ++i) key[i] = {chainOf[i], (uint32_t)readMappings[i].queryStartPos, (uint32_t)readMappings[i].refStartPos};
+    auto less = [&](uint32_t i, uint32_t j) {
+      const Key &a = key[i], &b = key[j];
+      return std::tie(a.chain, a.q, a.r) < std::tie(b.chain, b.q, b.r);
+    };
+    // the same shortcut: chain ids are representatives < n, the members of a chain already stand in (query,
+    // target) order; a stable counting pass by chain id and a strictness check, std::sort otherwise
+    bool sorted_fast = n > 0;
+    for (size_t i = 0; i < n && sorted_fast; ++i) sorted_fast = key[i].chain >= 0 && (size_t)key[i].chain < n;
+    if (sorted_fast) {
+      std::vector<uint32_t> start(n + 1, 0), q(n);
+      for (size_t i = 0; i < n; ++i) ++start[(size_t)key[i].chain + 1];
+      for (size_t c = 0; c < n; ++c) start[c + 1] += start[c];
+      for (size_t i = 0; i < n; ++i) q[start[(size_t)key[i].chain]++] = (uint32_t)i;
+      for (size_t i = 1; i < n && sorted_fast; ++i) sorted_fast = less(q[i - 1], q[i]);
+      if (sorted_fast) p.swap(q);
+    }
+    if (!sorted_fast) std::sort(p.begin(), p.end(), less);
+  }
   readMappings = permuted(readMappings, p);
   chainOf = permuted(chainOf, p);
   return chainOf;
@@ -479,13 +522,42 @@ void MappingFilterUtils::filterByScaffolds(MappingResultsVector_t& readMappings,
     filterByGroup(scaffolds, kept, param.numMappingsForScaffold - 1, false, idManager, sweep);
     scaffolds = std::move(kept);
   }
-  // anchors: the original mappings lying inside a scaffold
+  // anchors: the original mappings lying inside a scaffold.  The reference tests every mapping against every
+  // scaffold (mappingFilter.hpp:955-975) and may list a mapping more than once; only the SET matters (the anchors
+  // feed a nearest-distance query), so scaffolds are ordered by (target, strand, query start) and a mapping is
+  // tested against those that start at or before it and are long enough to still cover it.
   MappingResultsVector_t anchors;
-  for (const auto& chain : scaffolds)
-    for (const auto& orig : originals)
-      if (orig.refSeqId == chain.refSeqId && orig.strand() == chain.strand() && orig.queryStartPos >= chain.queryStartPos &&
-          orig.queryEndPos() <= chain.queryEndPos() && orig.refStartPos >= chain.refStartPos && orig.refEndPos() <= chain.refEndPos())
-        anchors.push_back(orig);
+  {
+    struct Box { uint32_t ref; int strand; int64_t q0, q1, r0, r1; };
+    std::vector<Box> boxes;
+    boxes.reserve(scaffolds.size());
+    for (const auto& c : scaffolds) boxes.push_back({(uint32_t)c.refSeqId, (int)c.strand(), (int64_t)c.queryStartPos, (int64_t)c.queryEndPos(), (int64_t)c.refStartPos, (int64_t)c.refEndPos()});
+    std::sort(boxes.begin(), boxes.end(), [](const Box& a, const Box& b) { return std::tie(a.ref, a.strand, a.q0) < std::tie(b.ref, b.strand, b.q0); });
+    // longest query span per (target, strand) group: a scaffold starting more than that before a mapping cannot contain it
+    std::vector<int64_t> group_span(boxes.size(), 0);
+    for (size_t lo = 0; lo < boxes.size();) {
+      size_t hi = lo;
+      int64_t span = 0;
+      while (hi < boxes.size() && boxes[hi].ref == boxes[lo].ref && boxes[hi].strand == boxes[lo].strand) { span = std::max(span, boxes[hi].q1 - boxes[hi].q0); ++hi; }
+      for (size_t k = lo; k < hi; ++k) group_span[k] = span;
+      lo = hi;
+    }
+    for (const auto& orig : originals) {
+      const uint32_t ref = (uint32_t)orig.refSeqId;
+      const int strand = (int)orig.strand();
+      const int64_t q0 = orig.queryStartPos, q1 = orig.queryEndPos(), r0 = orig.refStartPos, r1 = orig.refEndPos();
+      // last box of the group with box.q0 <= q0, then backwards while the box can still reach q1
+      size_t k = (size_t)(std::upper_bound(boxes.begin(), boxes.end(), std::make_tuple(ref, strand, q0), [](const std::tuple<uint32_t, int, int64_t>& v, const Box& b) {
+                            return v < std::make_tuple(b.ref, b.strand, b.q0); }) - boxes.begin());
+      bool inside = false;
+      while (k-- > 0) {
+        const Box& b = boxes[k];
+        if (b.ref != ref || b.strand != strand || b.q0 + group_span[k] < q1) break;
+        if (b.q1 >= q1 && b.r0 <= r0 && b.r1 >= r1) { inside = true; break; }
+      }
+      if (inside) anchors.push_back(orig);
+    }
+  }
   if (readMappings.empty()) return;
   if (anchors.empty()) { readMappings.clear(); return; }
   const AnchorIndex index(anchors);
