@@ -32,6 +32,23 @@ def test_minhash_sketch_matches_restatement(gpu):
     assert (small == ANI.minhash_sketch(base, 15, 64)).all()
 
 
+def test_minhash_sketch_of_a_long_sequence_selects_before_it_sorts(gpu):
+    """beyond 1 Mbp the sketch comes from the hashes under a threshold (selected, then sorted) instead of a sort of
+    all hashes; the result is the same multiset -- checked against a plain sort of the hash kernel's output, also
+    when a repeat makes the smallest hashes occur many times, and with a sketch so large that the selection falls
+    back to the full sort"""
+    import numpy as np
+    rng = np.random.default_rng(12)
+    seq = bytes(np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, 3_000_000)])
+    rep = seq[:1_500_000] + seq[1000:1400] * 500 + seq[1_500_000:2_500_000]
+    for sq, n in ((seq, 4096), (rep, 4096), (seq, 60000)):
+        h, st = gpu.hash_kmers(sq, 21)
+        assert (st != 0).all()  # k odd, no N: every k-mer is valid
+        want = np.sort(h)[:n]
+        got = gpu.minhash_sketch(sq, k=21, sketch_size=n)
+        assert len(got) == n and (got == want).all()
+
+
 def test_auto_identity_drives_threshold_and_sketch_size(gpu, tmp_path):
     seqs = _pangenome(51)
     fa = str(tmp_path / "pan.fa")

@@ -501,14 +501,47 @@ int64_t wfm_minhash_sketch(wfm_handle_t* h, const char* seq, int64_t len, int k,
     if (c != 'A' && c != 'C' && c != 'G' && c != 'T') { head_ambiguous = true; break; }
   }
   if (head_ambiguous) HIPCHK(h, hipMemsetAsync(d_hash, 0xff, (size_t)std::min<int64_t>(k, nk) * 8, st));
-  size_t tmp = 0;
-  HIPCHK(h, rocprim::radix_sort_keys(nullptr, tmp, d_hash, d_sorted, (size_t)nk, 0, 64, st));
-  char* d_tmp = nullptr;
-  HIPCHK(h, sc.alloc(&d_tmp, tmp));
-  HIPCHK(h, rocprim::radix_sort_keys(d_tmp, tmp, d_hash, d_sorted, (size_t)nk, 0, 64, st));
   const int64_t n = std::min<int64_t>(sketch_size, nk);
-  HIPCHK(h, hipMemcpyAsync(out, d_sorted, (size_t)n * 8, hipMemcpyDeviceToHost, st));
-  HIPCHK(h, hipStreamSynchronize(st));
+  // The sketch is the n smallest hashes (with multiplicity): sorting a chromosome's 2.5e8 hashes for 4096 of them
+  // is most of the ANI estimate's time.  Hashes at most tau are selected first -- tau set so that about 8 n of
+  // them are expected (a canonical hash is the smaller of two uniform values: a fraction t of the range holds
+  // ~2t of the k-mers) -- and only those are sorted; if fewer than n turn up, everything is sorted as before.
+  bool done = false;
+  if (nk > ((int64_t)1 << 20) && n * 64 < nk) {
+    const long double t = 4.0L * (long double)n / (long double)nk;
+    const uint64_t tau = (uint64_t)(t * 18446744073709551616.0L);
+    unsigned long long* d_count = nullptr;
+    HIPCHK(h, sc.alloc(&d_count, sizeof(unsigned long long)));
+    auto below = [tau] __device__(const uint64_t& v) { return v <= tau; };
+    size_t stmp = 0;
+    HIPCHK(h, rocprim::select(nullptr, stmp, d_hash, d_sorted, d_count, (size_t)nk, below, st));
+    char* d_stmp = nullptr;
+    HIPCHK(h, sc.alloc(&d_stmp, stmp));
+    HIPCHK(h, rocprim::select(d_stmp, stmp, d_hash, d_sorted, d_count, (size_t)nk, below, st));
+    unsigned long long m = 0;
+    HIPCHK(h, hipMemcpyAsync(&m, d_count, sizeof(m), hipMemcpyDeviceToHost, st));
+    HIPCHK(h, hipStreamSynchronize(st));
+    if ((int64_t)m >= n) {
+      // d_sorted holds the m selected hashes; sort them back into d_hash (no longer needed)
+      size_t tmp = 0;
+      HIPCHK(h, rocprim::radix_sort_keys(nullptr, tmp, d_sorted, d_hash, (size_t)m, 0, 64, st));
+      char* d_tmp = nullptr;
+      HIPCHK(h, sc.alloc(&d_tmp, tmp));
+      HIPCHK(h, rocprim::radix_sort_keys(d_tmp, tmp, d_sorted, d_hash, (size_t)m, 0, 64, st));
+      HIPCHK(h, hipMemcpyAsync(out, d_hash, (size_t)n * 8, hipMemcpyDeviceToHost, st));
+      HIPCHK(h, hipStreamSynchronize(st));
+      done = true;
+    }
+  }
+  if (!done) {
+    size_t tmp = 0;
+    HIPCHK(h, rocprim::radix_sort_keys(nullptr, tmp, d_hash, d_sorted, (size_t)nk, 0, 64, st));
+    char* d_tmp = nullptr;
+    HIPCHK(h, sc.alloc(&d_tmp, tmp));
+    HIPCHK(h, rocprim::radix_sort_keys(d_tmp, tmp, d_hash, d_sorted, (size_t)nk, 0, 64, st));
+    HIPCHK(h, hipMemcpyAsync(out, d_sorted, (size_t)n * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(h, hipStreamSynchronize(st));
+  }
   int64_t valid = n;
   while (valid > 0 && out[valid - 1] == ~0ull) --valid;  // invalid k-mers sort last
   return valid;
