@@ -16,7 +16,9 @@ N>1: one process per GPU (torch.distributed, backend nccl = RCCL); every rank
 aligns its own shard of mapping records (weak scaling, no data-path
 collective) and the PAF-side payload (run-length CIGARs) is gathered to rank 0
 inside the timed region, as the reference's cluster sharding would
-(scripts/split_approx_mappings_in_chunks.py).
+(scripts/split_approx_mappings_in_chunks.py).  `python bench.py --gpus N` started
+without a torch.distributed environment launches the N ranks itself (it re-executes
+under `python -m torch.distributed.run --nproc-per-node N`, rendezvous on 127.0.0.1).
 """
 import argparse
 import json
@@ -38,7 +40,23 @@ def main():
     ap.add_argument("--pairs", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0, help="pairs in the cpu_baseline sample (0 = auto)")
+    ap.add_argument("--rank-check", action="store_true",
+                    help="launch / join the ranks, print one line per rank and stop (no GPU needed: gloo)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # not under a launcher: start one process per GPU ourselves
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // args.gpus)))
+        raise SystemExit(subprocess.call(cmd, env=env))
 
     import numpy as np
     import torch
@@ -48,16 +66,41 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
+    if args.gpus != world:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.rank_check:
+        if world > 1:
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+            seen = [None] * world
+            dist.all_gather_object(seen, rank)
+            dist.barrier()
+            dist.destroy_process_group()
+        else:
+            seen = [0]
+        print(json.dumps({"rank_check": True, "rank": rank, "n_gpus": world, "ranks_seen": seen}), flush=True)
+        return
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    ndev = torch.cuda.device_count()
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world > ndev and os.environ.get("WFM_BENCH_SHARE_GPU") != "1":
+            raise SystemExit(f"bench.py: --gpus {world} but only {ndev} device(s) visible (WFM_BENCH_SHARE_GPU=1 lets ranks share "
+                             "devices over gloo, for testing the launch path on one GPU)")
+        local_rank = local_rank % ndev
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+        if world > ndev:
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    # collectives run on device tensors over RCCL; the one-GPU launch test (gloo) keeps them on the host
+    comm_dev = dev if (dist is None or dist.get_backend() == "nccl") else torch.device("cpu")
 
     h = capi.Handle(local_rank)
     # this rank's shard of the mapping records (distinct seeds per rank)
@@ -73,7 +116,7 @@ def main():
         from wfmash_amd.dist import gather_bytes
         n_bytes = sum(int(seqset.results[i].ops_len) for i in range(seqset.n))
         payload = seqset.arena[:n_bytes]
-        gather_bytes(torch.from_numpy(payload).to(dev), dist, dst=0)
+        gather_bytes(torch.from_numpy(payload).to(comm_dev), dist, dst=0)
 
     def sync():
         if dist is not None:
@@ -114,7 +157,7 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tt = torch.tensor([dt], dtype=torch.float64, device=comm_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 

@@ -24,6 +24,7 @@
  *     wfm_prefilter_kmers   <- (no counterpart: the device-side thinning of addMinmers' input stream)
  *     wfm_index_build       <- Sketch::build (index stage), winSketch.hpp:266-429
  *     wfm_index_build_sequences <- Sketch::build as a whole, winSketch.hpp:175-457
+ *     wfm_index_replicate   <- (the one Sketch all mapping threads share, computeMap.hpp:431-484: one copy per GPU)
  *     wfm_index_upload / wfm_index_download <- Sketch::readIndex / writeIndex (device side), winSketch.hpp:569-866
  *     wfm_map_l1            <- getSeedIntervalPoints + computeL1CandidateRegions, mappingCore.hpp:82-301
  *     wfm_map_l2            <- computeL2MappedRegions + SlideMapper + doL2Mapping,
@@ -110,6 +111,7 @@ typedef struct {
   uint32_t pad_;
 } wfm_stats_t;
 
+int  wfm_device_count(void);   /* usable HIP devices of this node (0 without a GPU) */
 int  wfm_create(int device, wfm_handle_t** out);
 void wfm_destroy(wfm_handle_t* h);
 const char* wfm_last_error(const wfm_handle_t* h);
@@ -196,6 +198,11 @@ int  wfm_index_info(const wfm_index_t* ix, wfm_index_info_t* out);
  * n_unique+1 offsets into points, the points, and minmerIndex. */
 int  wfm_index_download(wfm_handle_t* h, const wfm_index_t* ix, uint64_t* uhash, int64_t* poff,
                         wfm_interval_point_t* points, wfm_minmer_t* minmers);
+
+/* The index on another GPU of the same node (the index is replicated, read-only, on every device that maps:
+ * computeMap.hpp:431-484 shares one Sketch between all worker threads).  Device-to-device copies of the four
+ * arrays; *out belongs to dst (wfm_index_free(dst, *out)).  src == dst gives a second copy on the same device. */
+int  wfm_index_replicate(wfm_handle_t* src, const wfm_index_t* ix, wfm_handle_t* dst, wfm_index_t** out);
 
 /* The inverse of wfm_index_download: a device index from the structures of an index file (`-I`;
  * Sketch::readIndex, winSketch.hpp:834-866, host/index_file.cpp reads the file).  uhash ascending,

@@ -52,6 +52,14 @@ int wfmh_align_paf(wfm_handle_t* h, const char* target_fasta, const char* query_
                    const char* mapping_paf, const char* out_paf,
                    const wfmh_align_params_t* params, wfmh_align_summary_t* summary);
 
+/* The same over n GPUs of one node (handles[i] from wfm_create(device_i)): batches of mapping records go to whichever
+ * device is free (records are independent, computeAlignments.hpp:398-435; the split the reference's cluster script
+ * makes ahead of time, scripts/split_approx_mappings_in_chunks.py:19-27,47, is made at run time), the output is
+ * written in input order and does not depend on n.  Errors are reported on handles[0]. */
+int wfmh_align_paf_multi(wfm_handle_t* const* handles, int n, const char* target_fasta, const char* query_fasta,
+                         const char* mapping_paf, const char* out_paf,
+                         const wfmh_align_params_t* params, wfmh_align_summary_t* summary);
+
 /* Test hooks: the pure host-side CIGAR functions (erode / merge / swizzle / PAF writer /
  * parseMashmapRow) behind one string interface so the CPU test-suite can check them
  * without a GPU.  fn in {erode, merge, compress, swap_start, swap_end, head_erosion,
@@ -150,6 +158,7 @@ typedef struct {
   float    percentage_identity;  /* the threshold used (estimated when auto_pct_identity) */
   int32_t  sketch_size;          /* the sketch size used */
   double   ms_index, ms_map, ms_filter, ms_total;
+  double   ms_replicate;    /* copying the finished index to the other GPUs (wfmh_map_multi) */
 } wfmh_map_summary_t;
 
 /* The map phase on files: replaces skch::Map's constructor + mapQuery()
@@ -159,6 +168,12 @@ typedef struct {
  * mapping PAF (the -m / -i hand-off file, parse_args.hpp:781-811).  Returns 0 or WFM_E_*. */
 int wfmh_map(wfm_handle_t* h, const char* target_fasta, const char* query_fasta, const char* out_paf,
              const wfmh_map_params_t* params, wfmh_map_summary_t* summary);
+
+/* The same over n GPUs of one node: the index of a target subset is built once (handles[0]) and copied to the other
+ * devices (wfm_index_replicate), batches of whole query sequences go to whichever device is free (one task per query
+ * in the reference, computeMap.hpp:527-688), records are written in query order as with one GPU. */
+int wfmh_map_multi(wfm_handle_t* const* handles, int n, const char* target_fasta, const char* query_fasta, const char* out_paf,
+                   const wfmh_map_params_t* params, wfmh_map_summary_t* summary);
 
 /* Test hook for the host-side post-processing of one query's mappings (CPU tests): runs
  * mappingBoundarySanityCheck + Map::filterSubsetMappings + reportReadMappings

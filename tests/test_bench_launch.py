@@ -1,0 +1,56 @@
+"""bench.py's launch contract: `python bench.py --gpus N` without a torch.distributed environment starts N ranks
+itself (one process per GPU under torch.distributed.run, rendezvous on 127.0.0.1); under the driver's own launcher
+(WORLD_SIZE set) it joins the existing job.  --rank-check stops after the ranks have found each other (gloo, no GPU)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _clean_env():
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    return env
+
+
+def _json_lines(text):
+    out = []
+    for line in text.splitlines():
+        line = line.strip()
+        if line.startswith("{") and line.endswith("}"):
+            out.append(json.loads(line))
+    return out
+
+
+def test_gpus_flag_launches_that_many_ranks():
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--rank-check"], cwd=ROOT, env=_clean_env(), capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [j for j in _json_lines(r.stdout) if j.get("rank_check")]
+    assert sorted(j["rank"] for j in lines) == [0, 1]
+    assert all(j["n_gpus"] == 2 and j["ranks_seen"] == [0, 1] for j in lines)
+
+
+def test_gpus_flag_must_agree_with_the_launcher():
+    env = dict(_clean_env(), WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--rank-check"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)
+
+
+@pytest.mark.gpu
+def test_two_ranks_on_one_gpu_print_one_line_for_the_job():
+    """The N>1 path end to end on the one-GPU box: two ranks share the device (gloo instead of RCCL), each aligns its own
+    shard, the CIGAR payload is gathered to rank 0, rank 0 prints the one JSON line with n_gpus = 2."""
+    env = dict(_clean_env(), WFM_BENCH_SHARE_GPU="1")
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "1", "--warmup", "0", "--pairs", "4", "--no-cpu-baseline"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [j for j in _json_lines(r.stdout) if "metric" in j]
+    assert len(lines) == 1
+    j = lines[0]
+    assert j["n_gpus"] == 2 and j["steps"] == 1 and j["scaling"] == "weak"
+    assert j["value"] > 0 and j["roofline"]["frac"] > 0

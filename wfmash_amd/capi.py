@@ -26,6 +26,7 @@ EXPORTS = [
     "wfm_index_build", "wfm_index_free", "wfm_index_info", "wfm_index_download",
     "wfm_map_l1", "wfm_map_l2", "wfm_map_fragments", "wfm_minhash_sketch", "wfm_add_minmers_multi",
     "wfm_prefilter_kmers", "wfm_index_build_sequences", "wfm_index_upload",
+    "wfm_index_replicate", "wfm_device_count",
 ]
 
 
@@ -538,14 +539,33 @@ class Handle:
 # host-side align driver (include/wfmash_host.h)
 # ---------------------------------------------------------------------------
 HOST_EXPORTS = ["wfmh_align_default_params", "wfmh_align_paf", "wfmh_test_cigar", "wfmh_free", "wfmh_test_winnow",
-                "wfmh_map_default_params", "wfmh_test_filter", "wfmh_map", "wfmh_test_winnow_chunked", "wfmh_test_fasta", "wfmh_test_winnow_thinned", "wfmh_test_sort_records", "wfmh_test_index_file"]
+                "wfmh_map_default_params", "wfmh_test_filter", "wfmh_map", "wfmh_test_winnow_chunked", "wfmh_test_fasta", "wfmh_test_winnow_thinned", "wfmh_test_sort_records", "wfmh_test_index_file",
+                "wfmh_map_multi", "wfmh_align_paf_multi"]
 
 
 class MapSummary(C.Structure):
     _fields_ = [("targets", C.c_uint64), ("queries", C.c_uint64), ("subsets", C.c_uint64), ("target_bp", C.c_uint64),
                 ("query_bp", C.c_uint64), ("index_windows", C.c_uint64), ("fragments", C.c_uint64), ("l2_mappings", C.c_uint64),
                 ("written", C.c_uint64), ("percentage_identity", C.c_float), ("sketch_size", C.c_int32), ("ms_index", C.c_double), ("ms_map", C.c_double), ("ms_filter", C.c_double),
-                ("ms_total", C.c_double)]
+                ("ms_total", C.c_double), ("ms_replicate", C.c_double)]
+
+
+def _handle_array(handles):
+    arr = (C.c_void_p * len(handles))(*[h._p for h in handles])
+    return arr
+
+
+def map_paf_multi(handles, target_fasta: str, out_paf: str, query_fasta: str = None, params=None) -> "MapSummary":
+    """wfmh_map_multi: the map phase over several GPUs of the node (index built once, copied to the others)."""
+    L = load()
+    L.wfmh_map_multi.restype = C.c_int
+    L.wfmh_map_multi.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_char_p, C.c_char_p, C.c_void_p, C.POINTER(MapSummary)]
+    s = MapSummary()
+    rc = L.wfmh_map_multi(_handle_array(handles), len(handles), target_fasta.encode(), query_fasta.encode() if query_fasta else None,
+                          out_paf.encode(), C.byref(params) if params is not None else None, C.byref(s))
+    if rc != 0:
+        raise WfmError(f"wfmh_map_multi failed ({rc}): {handles[0].last_error()}")
+    return s
 
 
 def map_paf(handle, target_fasta: str, out_paf: str, query_fasta: str = None, params=None) -> "MapSummary":
@@ -681,6 +701,24 @@ def align_paf(handle, target_fasta, mapping_paf, out_paf, query_fasta=None, para
                           mapping_paf.encode(), out_paf.encode(), C.byref(prm), C.byref(summ))
     if rc != 0:
         raise WfmError(f"wfmh_align_paf failed ({rc}): {handle.last_error()}")
+    return summ
+
+
+def align_paf_multi(handles, target_fasta, mapping_paf, out_paf, query_fasta=None, params=None):
+    """wfmh_align_paf_multi: the align phase over several GPUs of the node."""
+    L = _host()
+    L.wfmh_align_paf_multi.restype = C.c_int
+    L.wfmh_align_paf_multi.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p,
+                                       C.POINTER(AlignParams), C.POINTER(AlignSummary)]
+    prm = AlignParams()
+    L.wfmh_align_default_params(C.byref(prm))
+    for k, v in (params or {}).items():
+        setattr(prm, k, v)
+    summ = AlignSummary()
+    rc = L.wfmh_align_paf_multi(_handle_array(handles), len(handles), target_fasta.encode(), query_fasta.encode() if query_fasta else None,
+                                mapping_paf.encode(), out_paf.encode(), C.byref(prm), C.byref(summ))
+    if rc != 0:
+        raise WfmError(f"wfmh_align_paf_multi failed ({rc}): {handles[0].last_error()}")
     return summ
 
 

@@ -299,6 +299,44 @@ int wfm_index_upload(wfm_handle_t* h, const uint64_t* uhash, const int64_t* poff
   return WFM_OK;
 }
 
+// The index on another GPU of the node: the four arrays go device to device (xGMI when the devices are peers,
+// through the host otherwise -- hipMemcpyPeer picks the route); the copy belongs to dst.
+int wfm_index_replicate(wfm_handle_t* src, const wfm_index_t* ix, wfm_handle_t* dst, wfm_index_t** out) {
+  if (!src || !ix || !dst || !out) return WFM_E_ARG;
+  *out = nullptr;
+  const int sdev = ix->device, ddev = wfm_device(dst);
+  HIPCHK(dst, hipSetDevice(ddev));
+  if (sdev != ddev) {
+    int can = 0;
+    if (hipDeviceCanAccessPeer(&can, ddev, sdev) == hipSuccess && can) {
+      const hipError_t pe = hipDeviceEnablePeerAccess(sdev, 0);
+      if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
+      else if (pe == hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
+    }
+  }
+  wfm_index* cp = new wfm_index();
+  cp->device = ddev;
+  cp->n_windows = ix->n_windows; cp->n_kept = ix->n_kept; cp->n_unique = ix->n_unique; cp->n_points = ix->n_points;
+  cp->threshold = ix->threshold; cp->filtered = ix->filtered; cp->adjusted = ix->adjusted;
+  const size_t b_uhash = std::max<size_t>((size_t)ix->n_unique, 1) * 8, b_poff = ((size_t)ix->n_unique + 1) * 8,
+               b_points = std::max<size_t>((size_t)ix->n_points, 1) * sizeof(wfm_interval_point_t),
+               b_minmers = std::max<size_t>((size_t)ix->n_kept, 1) * sizeof(wfm_minmer_t);
+  if (hipMalloc((void**)&cp->d_uhash, b_uhash) != hipSuccess || hipMalloc((void**)&cp->d_poff, b_poff) != hipSuccess ||
+      hipMalloc((void**)&cp->d_points, b_points) != hipSuccess || hipMalloc((void**)&cp->d_minmers, b_minmers) != hipSuccess) {
+    wfm_index_free(dst, cp); wfm_set_error(dst, "out of device memory (index copy)"); return WFM_E_NOMEM;
+  }
+  hipStream_t st = wfm_stream(dst);
+  hipError_t e = hipSuccess;
+  if (ix->n_unique) e = hipMemcpyPeerAsync(cp->d_uhash, ddev, ix->d_uhash, sdev, (size_t)ix->n_unique * 8, st);
+  if (e == hipSuccess) e = hipMemcpyPeerAsync(cp->d_poff, ddev, ix->d_poff, sdev, b_poff, st);
+  if (e == hipSuccess && ix->n_points) e = hipMemcpyPeerAsync(cp->d_points, ddev, ix->d_points, sdev, (size_t)ix->n_points * sizeof(wfm_interval_point_t), st);
+  if (e == hipSuccess && ix->n_kept) e = hipMemcpyPeerAsync(cp->d_minmers, ddev, ix->d_minmers, sdev, (size_t)ix->n_kept * sizeof(wfm_minmer_t), st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  if (e != hipSuccess) { wfm_index_free(dst, cp); wfm_set_error(dst, std::string("wfm_index_replicate: ") + hipGetErrorString(e)); return WFM_E_HIP; }
+  *out = cp;
+  return WFM_OK;
+}
+
 void wfm_index_free(wfm_handle_t* h, wfm_index_t* ix) {
   if (!ix) return;
   if (h) (void)hipSetDevice(wfm_device(h));

@@ -741,6 +741,12 @@ int align_resident_impl(wfm_handle* h, const wfm_penalties_t* pen, wfm_seqset* S
 
 extern "C" {
 
+int wfm_device_count(void) {
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess) { (void)hipGetLastError(); return 0; }
+  return ndev < 0 ? 0 : ndev;
+}
+
 int wfm_create(int device, wfm_handle_t** out) {
   if (!out) return WFM_E_ARG;
   *out = nullptr;

@@ -8,6 +8,8 @@
 #include <cstring>
 #include <fstream>
 #include <iostream>
+#include <map>
+#include <mutex>
 #include <sstream>
 #include <stdexcept>
 
@@ -68,7 +70,10 @@ struct Fetched {
 
 }  // namespace
 
-Aligner::Aligner(const Parameters& p, wfm_handle_t* g) : param(p), gpu(g) {
+Aligner::Aligner(const Parameters& p, wfm_handle_t* g) : Aligner(p, std::vector<wfm_handle_t*>{g}) {}
+
+Aligner::Aligner(const Parameters& p, const std::vector<wfm_handle_t*>& g) : param(p), gpus(g) {
+  if (gpus.empty() || std::find(gpus.begin(), gpus.end(), nullptr) != gpus.end()) throw std::runtime_error("[wfmash::align] no GPU handle");
   if (param.refSequences.size() != 1 || param.querySequences.size() != 1)
     throw std::runtime_error("[wfmash::align] exactly one target and one query FASTA are expected");
   ref.reset(new wfmash_host::FastaStore(param.refSequences.front()));
@@ -123,7 +128,9 @@ void Aligner::parseMashmapRow(const std::string& line, MappingBoundaryRow& row, 
   row.mashmap_estimated_identity = mm_id;
 }
 
-std::string Aligner::align_lines(const std::vector<std::string>& lines, Summary& sum) {
+// One batch of mapping rows through the wflign pipeline on one GPU: createSeqRecord + processAlignment
+// (computeAlignments.hpp:582-723) for every row, then the records' output text in row order.
+std::string Aligner::align_batch(wfm_handle_t* gpu_handle, std::vector<std::string>& lines, int threads, Summary& sum) {
   std::string out;
   wflign::wflign_penalties_t pen;
   pen.match = 0;
@@ -137,132 +144,215 @@ std::string Aligner::align_lines(const std::vector<std::string>& lines, Summary&
   pp.min_alignment_length = param.min_alignment_length;
   pp.min_block_identity = param.min_block_identity;
 
-  size_t i = 0;
-  while (i < lines.size()) {
-    // ---- assemble one batch (createSeqRecord + processAlignment front half) ----
-    // rows first (cheap, in order), then the sequence fetches of the whole batch on `threads` threads
-    std::vector<Fetched> rows;
-    uint64_t bases = 0;
-    while (i < lines.size() && rows.size() < param.batch_records && bases < param.batch_bases) {
-      const std::string& line = lines[i++];
-      if (line.empty()) continue;
-      Fetched f;
-      try {
-        parseMashmapRow(line, f.row, param.target_padding, param.query_padding);
-        const int64_t ref_size = ref->seq_len(f.row.refId);
-        if (ref_size < 0) throw std::runtime_error("Reference sequence not found: " + f.row.refId);
-        const int64_t query_size = query->seq_len(f.row.qId);
-        if (query_size < 0) throw std::runtime_error("Query sequence not found: " + f.row.qId);
-        f.ref_total = (uint64_t)ref_size; f.q_total = (uint64_t)query_size;
-        bases += (uint64_t)std::max<int64_t>(0, f.row.rEndPos - f.row.rStartPos) + (uint64_t)std::max<int64_t>(0, f.row.qEndPos - f.row.qStartPos);
-        rows.push_back(std::move(f));
-      } catch (const std::exception& e) {
-        std::cerr << "[wfmash::align] Error processing record: " << e.what() << std::endl;
-        sum.skipped++;
-      }
+  // rows first (cheap, in order), then the sequence fetches of the whole batch on `threads` threads
+  std::vector<Fetched> rows;
+  for (const std::string& line : lines) {
+    if (line.empty()) continue;
+    Fetched f;
+    try {
+      parseMashmapRow(line, f.row, param.target_padding, param.query_padding);
+      const int64_t ref_size = ref->seq_len(f.row.refId);
+      if (ref_size < 0) throw std::runtime_error("Reference sequence not found: " + f.row.refId);
+      const int64_t query_size = query->seq_len(f.row.qId);
+      if (query_size < 0) throw std::runtime_error("Query sequence not found: " + f.row.qId);
+      f.ref_total = (uint64_t)ref_size; f.q_total = (uint64_t)query_size;
+      rows.push_back(std::move(f));
+    } catch (const std::exception& e) {
+      std::cerr << "[wfmash::align] Error processing record: " << e.what() << std::endl;
+      sum.skipped++;
     }
-    std::vector<std::string> fetch_error(rows.size());
-    {
-      std::atomic<size_t> next{0};
-      auto work = [&] {
-        for (size_t k; (k = next.fetch_add(1)) < rows.size();) {
-          Fetched& f = rows[k];
-          try {
-            const int64_t ref_size = (int64_t)f.ref_total;
-            const uint64_t head_pad = (uint64_t)f.row.rStartPos >= param.wflign_max_len_minor ? param.wflign_max_len_minor : (uint64_t)f.row.rStartPos;
-            const uint64_t tail_pad = (uint64_t)(ref_size - f.row.rEndPos) >= param.wflign_max_len_minor ? param.wflign_max_len_minor : (uint64_t)(ref_size - f.row.rEndPos);
-            f.ref = ref->fetch(f.row.refId, f.row.rStartPos - (int64_t)head_pad, f.row.rEndPos + (int64_t)tail_pad - 1);
-            if (f.ref.empty()) throw std::runtime_error("Failed to fetch reference sequence");
-            std::string q = query->fetch(f.row.qId, f.row.qStartPos, f.row.qEndPos - 1);
-            if (q.empty()) throw std::runtime_error("Failed to fetch query sequence");
-            f.ref_start = (uint64_t)f.row.rStartPos - head_pad;
-            upper_valid_dna(f.ref);
-            upper_valid_dna(q);
-            f.qry = f.row.strand == FWD ? std::move(q) : revcomp(q);
-          } catch (const std::exception& e) {
-            fetch_error[k] = e.what();
-            if (fetch_error[k].empty()) fetch_error[k] = "error";
-          }
+  }
+  std::vector<std::string>().swap(lines);
+  std::vector<std::string> fetch_error(rows.size());
+  {
+    std::atomic<size_t> next{0};
+    auto work = [&] {
+      for (size_t k; (k = next.fetch_add(1)) < rows.size();) {
+        Fetched& f = rows[k];
+        try {
+          const int64_t ref_size = (int64_t)f.ref_total;
+          const uint64_t head_pad = (uint64_t)f.row.rStartPos >= param.wflign_max_len_minor ? param.wflign_max_len_minor : (uint64_t)f.row.rStartPos;
+          const uint64_t tail_pad = (uint64_t)(ref_size - f.row.rEndPos) >= param.wflign_max_len_minor ? param.wflign_max_len_minor : (uint64_t)(ref_size - f.row.rEndPos);
+          f.ref = ref->fetch(f.row.refId, f.row.rStartPos - (int64_t)head_pad, f.row.rEndPos + (int64_t)tail_pad - 1);
+          if (f.ref.empty()) throw std::runtime_error("Failed to fetch reference sequence");
+          std::string q = query->fetch(f.row.qId, f.row.qStartPos, f.row.qEndPos - 1);
+          if (q.empty()) throw std::runtime_error("Failed to fetch query sequence");
+          f.ref_start = (uint64_t)f.row.rStartPos - head_pad;
+          upper_valid_dna(f.ref);
+          upper_valid_dna(q);
+          f.qry = f.row.strand == FWD ? std::move(q) : revcomp(q);
+        } catch (const std::exception& e) {
+          fetch_error[k] = e.what();
+          if (fetch_error[k].empty()) fetch_error[k] = "error";
         }
-      };
-      const int nt = (int)std::min<size_t>((size_t)std::max(1, param.threads), rows.size());
-      std::vector<std::thread> pool;
-      for (int t = 1; t < nt; ++t) pool.emplace_back(work);
-      work();
-      for (auto& t : pool) t.join();
-    }
-    std::vector<Fetched> fetched;
-    fetched.reserve(rows.size());
-    for (size_t k = 0; k < rows.size(); ++k) {
-      if (!fetch_error[k].empty()) {
-        std::cerr << "[wfmash::align] Error processing record: " << fetch_error[k] << std::endl;
-        sum.skipped++;
-        continue;
       }
-      fetched.push_back(std::move(rows[k]));
+    };
+    const int nt = (int)std::min<size_t>((size_t)std::max(1, threads), rows.size());
+    std::vector<std::thread> pool;
+    for (int t = 1; t < nt; ++t) pool.emplace_back(work);
+    work();
+    for (auto& t : pool) t.join();
+  }
+  std::vector<Fetched> fetched;
+  fetched.reserve(rows.size());
+  for (size_t k = 0; k < rows.size(); ++k) {
+    if (!fetch_error[k].empty()) {
+      std::cerr << "[wfmash::align] Error processing record: " << fetch_error[k] << std::endl;
+      sum.skipped++;
+      continue;
     }
-    if (fetched.empty()) continue;
-    std::vector<wflign::BiwfaRecord> recs(fetched.size());
-    for (size_t k = 0; k < fetched.size(); ++k) {
-      const Fetched& f = fetched[k];
-      wflign::BiwfaRecord& r = recs[k];
-      r.query_name = f.row.qId;
-      r.query = f.qry.data();
-      r.query_total_length = f.q_total;
-      r.query_offset = (uint64_t)f.row.qStartPos;
-      r.query_length = f.qry.size();
-      r.query_is_rev = f.row.strand != FWD;
-      r.target_name = f.row.refId;
-      const uint64_t skip = (uint64_t)f.row.rStartPos - f.ref_start;
-      r.target = f.ref.data() + skip;
-      r.target_total_length = f.ref_total;
-      r.target_offset = (uint64_t)f.row.rStartPos;
-      r.target_length = (uint64_t)(f.row.rEndPos - f.row.rStartPos);
-      r.target_avail = f.ref.size() - skip;
-      r.mashmap_estimated_identity = f.row.mashmap_estimated_identity;
-      r.chain_id = f.row.chain_id; r.chain_length = f.row.chain_length; r.chain_pos = f.row.chain_pos;
-    }
-    wflign::BiwfaStats st;
-    wflign::OutputFormat fmt;
-    fmt.paf_format_else_sam = !param.sam_format;
-    fmt.no_seq_in_sam = param.no_seq_in_sam;
-    fmt.emit_md_tag = param.emit_md_tag;
-    fmt.threads = param.threads;
-    const int rc = wflign::do_biwfa_alignment_batch(gpu, recs, pen, param.disable_chain_patching, pp, &st, fmt);
-    if (rc < 0) throw std::runtime_error(std::string("[wfmash::align] GPU alignment failed: ") + wfm_last_error(gpu));
-    sum.cells += st.cells; sum.ms_gpu += st.ms_gpu;
-    for (size_t k = 0; k < recs.size(); ++k) {
-      sum.records++;
-      sum.aligned_bp += (uint64_t)(fetched[k].row.qEndPos - fetched[k].row.qStartPos);
-      if (recs[k].paf.empty()) continue;
-      if (param.sam_format) { out += recs[k].paf; sum.written++; continue; }  // no cg:Z: field -> line passes through unchanged
-      // processMappingRecord re-tokenises the writer's line and joins with single tabs (computeAlignments.hpp:484-525)
-      const auto fields = tokenize(recs[k].paf);
-      std::string nl;
-      for (const auto& fld : fields) { if (!nl.empty()) nl += '\t'; nl += fld; }
-      nl += '\n';
-      out += nl;
-      sum.written++;
-    }
+    fetched.push_back(std::move(rows[k]));
+  }
+  if (fetched.empty()) return out;
+  std::vector<wflign::BiwfaRecord> recs(fetched.size());
+  for (size_t k = 0; k < fetched.size(); ++k) {
+    const Fetched& f = fetched[k];
+    wflign::BiwfaRecord& r = recs[k];
+    r.query_name = f.row.qId;
+    r.query = f.qry.data();
+    r.query_total_length = f.q_total;
+    r.query_offset = (uint64_t)f.row.qStartPos;
+    r.query_length = f.qry.size();
+    r.query_is_rev = f.row.strand != FWD;
+    r.target_name = f.row.refId;
+    const uint64_t skip = (uint64_t)f.row.rStartPos - f.ref_start;
+    r.target = f.ref.data() + skip;
+    r.target_total_length = f.ref_total;
+    r.target_offset = (uint64_t)f.row.rStartPos;
+    r.target_length = (uint64_t)(f.row.rEndPos - f.row.rStartPos);
+    r.target_avail = f.ref.size() - skip;
+    r.mashmap_estimated_identity = f.row.mashmap_estimated_identity;
+    r.chain_id = f.row.chain_id; r.chain_length = f.row.chain_length; r.chain_pos = f.row.chain_pos;
+  }
+  wflign::BiwfaStats st;
+  wflign::OutputFormat fmt;
+  fmt.paf_format_else_sam = !param.sam_format;
+  fmt.no_seq_in_sam = param.no_seq_in_sam;
+  fmt.emit_md_tag = param.emit_md_tag;
+  fmt.threads = threads;
+  const int rc = wflign::do_biwfa_alignment_batch(gpu_handle, recs, pen, param.disable_chain_patching, pp, &st, fmt);
+  if (rc < 0) throw std::runtime_error(std::string("[wfmash::align] GPU alignment failed: ") + wfm_last_error(gpu_handle));
+  sum.cells += st.cells; sum.ms_gpu += st.ms_gpu;
+  for (size_t k = 0; k < recs.size(); ++k) {
+    sum.records++;
+    sum.aligned_bp += (uint64_t)(fetched[k].row.qEndPos - fetched[k].row.qStartPos);
+    if (recs[k].paf.empty()) continue;
+    if (param.sam_format) { out += recs[k].paf; sum.written++; continue; }  // no cg:Z: field -> line passes through unchanged
+    // processMappingRecord re-tokenises the writer's line and joins with single tabs (computeAlignments.hpp:484-525)
+    const auto fields = tokenize(recs[k].paf);
+    std::string nl;
+    for (const auto& fld : fields) { if (!nl.empty()) nl += '\t'; nl += fld; }
+    nl += '\n';
+    out += nl;
+    sum.written++;
   }
   return out;
 }
 
+std::string Aligner::align_lines(const std::vector<std::string>& lines, Summary& sum) {
+  std::string out;
+  size_t i = 0;
+  while (i < lines.size()) {
+    std::vector<std::string> batch;
+    uint64_t bases = 0;
+    while (i < lines.size() && batch.size() < param.batch_records && bases < param.batch_bases) {
+      bases += row_bases(lines[i]);
+      batch.push_back(lines[i++]);
+    }
+    out += align_batch(gpus.front(), batch, param.threads, sum);
+  }
+  return out;
+}
+
+// bases a mapping row will align, padding aside (the reader sizes batches by it)
+uint64_t Aligner::row_bases(const std::string& line) {
+  uint64_t v[9] = {0};
+  size_t pos = 0;
+  for (int col = 0; col < 9; ++col) {
+    while (pos < line.size() && std::isspace((unsigned char)line[pos])) ++pos;
+    const size_t st = pos;
+    while (pos < line.size() && !std::isspace((unsigned char)line[pos])) ++pos;
+    if (st == pos) return 0;
+    if (col == 2 || col == 3 || col == 7 || col == 8) v[col] = strtoull(line.c_str() + st, nullptr, 10);
+  }
+  return (v[3] > v[2] ? v[3] - v[2] : 0) + (v[8] > v[7] ? v[8] - v[7] : 0);
+}
+
+// The reference streams records from a reader through a pool of workers to a writer
+// (computeAlignments.hpp:318-455).  Here the reader hands out batches of mapping rows, one worker per GPU
+// takes the next batch whenever its device is free (the greedy least-loaded assignment of
+// scripts/split_approx_mappings_in_chunks.py:19-27,47, taken at run time instead of from predicted weights),
+// and finished batches are written in the order they were read: the output does not depend on the number of
+// GPUs, and host memory holds the batches in flight, not the run.
 Summary Aligner::compute() {
   Summary sum;
   const auto t0 = std::chrono::steady_clock::now();
   std::ifstream in(param.mashmapPafFile);
   if (!in.is_open()) throw std::runtime_error("[wfmash::align] Error! Failed to open input mapping file: " + param.mashmapPafFile);
-  std::vector<std::string> lines;
-  std::string line;
-  while (std::getline(in, line)) if (!line.empty()) lines.push_back(line);
   std::ofstream outstream(param.pafOutputFile);
   if (!outstream.is_open()) throw std::runtime_error("[wfmash::align] Error! Failed to open output file: " + param.pafOutputFile);
   if (param.sam_format) {  // write_sam_header (computeAlignments.hpp:725-736)
     for (int i = 0; i < ref->nseq(); ++i) outstream << "@SQ\tSN:" << ref->name(i) << "\tLN:" << ref->length(i) << "\n";
-    outstream << "@PG\tID:wfmash\tPN:wfmash\tVN:wfmash-hip-r1\tCL:wfmash\n";
+    outstream << "@PG\tID:wfmash\tPN:wfmash\tVN:wfmash-hip-r2\tCL:wfmash\n";
   }
-  outstream << align_lines(lines, sum);
+  const size_t ngpu = gpus.size();
+  // several GPUs: no batch may hold more than an eighth of one GPU's share of the file
+  uint64_t batch_bytes = ~0ull;
+  if (ngpu > 1) {
+    in.seekg(0, std::ios::end);
+    const uint64_t file_bytes = (uint64_t)std::max<std::streamoff>(0, in.tellg());
+    in.seekg(0, std::ios::beg);
+    batch_bytes = std::max<uint64_t>(1, file_bytes / (8 * ngpu));
+  }
+  std::mutex read_mu, write_mu;
+  uint64_t next_seq = 0, next_write = 0;
+  std::map<uint64_t, std::string> pending;
+  std::string first_error;
+  std::atomic<bool> failed{false};
+  auto read_batch = [&](std::vector<std::string>& batch) -> int64_t {  // the batch's number, or -1 at the end
+    std::lock_guard<std::mutex> lk(read_mu);
+    batch.clear();
+    uint64_t bases = 0, bytes = 0;
+    std::string line;
+    while (batch.size() < param.batch_records && bases < param.batch_bases && bytes < batch_bytes && std::getline(in, line)) {
+      if (line.empty()) continue;
+      bases += row_bases(line);
+      bytes += line.size() + 1;
+      batch.push_back(std::move(line));
+    }
+    return batch.empty() ? -1 : (int64_t)next_seq++;
+  };
+  auto write_batch = [&](uint64_t seq, std::string&& text) {
+    std::lock_guard<std::mutex> lk(write_mu);
+    pending.emplace(seq, std::move(text));
+    for (auto it = pending.begin(); it != pending.end() && it->first == next_write; it = pending.erase(it), ++next_write)
+      outstream << it->second;
+    outstream.flush();
+  };
+  std::vector<Summary> part(ngpu);
+  const int threads_each = std::max(1, param.threads / (int)ngpu);
+  auto worker = [&](size_t g) {
+    try {
+      std::vector<std::string> batch;
+      for (int64_t seq; !failed.load() && (seq = read_batch(batch)) >= 0;)
+        write_batch((uint64_t)seq, align_batch(gpus[g], batch, threads_each, part[g]));
+    } catch (const std::exception& e) {
+      std::lock_guard<std::mutex> lk(write_mu);
+      if (first_error.empty()) first_error = e.what();
+      failed.store(true);
+    }
+  };
+  {
+    std::vector<std::thread> pool;
+    for (size_t g = 1; g < ngpu; ++g) pool.emplace_back(worker, g);
+    worker(0);
+    for (auto& t : pool) t.join();
+  }
+  if (failed.load()) throw std::runtime_error(first_error);
+  for (const Summary& p : part) {
+    sum.records += p.records; sum.aligned_bp += p.aligned_bp; sum.written += p.written; sum.skipped += p.skipped;
+    sum.cells += p.cells; sum.ms_gpu = std::max(sum.ms_gpu, p.ms_gpu);
+  }
   outstream.close();
   sum.ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   std::cerr << "[wfmash::align] total aligned records = " << sum.records << ", total aligned bp = " << sum.aligned_bp

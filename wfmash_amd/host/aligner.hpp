@@ -66,16 +66,20 @@ struct Summary {
 class Aligner {
  public:
   Aligner(const Parameters& p, wfm_handle_t* gpu);
+  // one handle per GPU of the node: batches of records go to whichever device is free
+  Aligner(const Parameters& p, const std::vector<wfm_handle_t*>& gpus);
   // throws std::runtime_error on malformed rows (computeAlignments.hpp:199-201,292-297)
   static void parseMashmapRow(const std::string& line, MappingBoundaryRow& row, uint64_t target_padding,
                               uint64_t query_padding = 0);
-  Summary compute();  // reads param.mashmapPafFile, writes param.pafOutputFile
-  // Aligns mapping lines already in memory; returns the PAF text.
+  Summary compute();  // streams param.mashmapPafFile through the GPUs into param.pafOutputFile
+  // Aligns mapping lines already in memory on the first GPU; returns the PAF text.
   std::string align_lines(const std::vector<std::string>& lines, Summary& sum);
 
  private:
+  std::string align_batch(wfm_handle_t* gpu, std::vector<std::string>& lines, int threads, Summary& sum);
+  static uint64_t row_bases(const std::string& line);
   const Parameters& param;
-  wfm_handle_t* gpu;
+  std::vector<wfm_handle_t*> gpus;
   std::unique_ptr<wfmash_host::FastaStore> ref, query_own;
   const wfmash_host::FastaStore* query = nullptr;
 };

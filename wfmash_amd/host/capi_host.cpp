@@ -4,6 +4,7 @@
 #include <iostream>
 #include <string>
 #include <thread>
+#include <vector>
 
 #include "../../include/wfmash_host.h"
 #include "../csrc/wfa_handle.h"
@@ -25,7 +26,14 @@ void wfmh_align_default_params(wfmh_align_params_t* p) {
 
 int wfmh_align_paf(wfm_handle_t* h, const char* target_fasta, const char* query_fasta, const char* mapping_paf,
                    const char* out_paf, const wfmh_align_params_t* params, wfmh_align_summary_t* summary) {
-  if (!h || !target_fasta || !mapping_paf || !out_paf) return WFM_E_ARG;
+  return wfmh_align_paf_multi(&h, 1, target_fasta, query_fasta, mapping_paf, out_paf, params, summary);
+}
+
+int wfmh_align_paf_multi(wfm_handle_t* const* handles, int n, const char* target_fasta, const char* query_fasta, const char* mapping_paf,
+                         const char* out_paf, const wfmh_align_params_t* params, wfmh_align_summary_t* summary) {
+  if (!handles || n < 1 || !target_fasta || !mapping_paf || !out_paf) return WFM_E_ARG;
+  for (int i = 0; i < n; ++i) if (!handles[i]) return WFM_E_ARG;
+  wfm_handle_t* h = handles[0];
   wfmh_align_params_t d;
   wfmh_align_default_params(&d);
   if (params) d = *params;
@@ -49,7 +57,7 @@ int wfmh_align_paf(wfm_handle_t* h, const char* target_fasta, const char* query_
     ap.disable_chain_patching = d.disable_chain_patching != 0;
     ap.sam_format = d.sam_format != 0; ap.emit_md_tag = d.emit_md_tag != 0; ap.no_seq_in_sam = d.no_seq_in_sam != 0;
     ap.threads = d.threads > 0 ? d.threads : (int)std::max(1u, std::thread::hardware_concurrency());
-    align::Aligner aligner(ap, h);
+    align::Aligner aligner(ap, std::vector<wfm_handle_t*>(handles, handles + n));
     const align::Summary s = aligner.compute();
     if (summary) {
       summary->records = s.records; summary->aligned_bp = s.aligned_bp; summary->written = s.written;

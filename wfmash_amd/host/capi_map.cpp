@@ -119,7 +119,14 @@ void wfmh_map_default_params(wfmh_map_params_t* c) {
 
 int wfmh_map(wfm_handle_t* h, const char* target_fasta, const char* query_fasta, const char* out_paf, const wfmh_map_params_t* params,
              wfmh_map_summary_t* summary) {
-  if (!h || !target_fasta || !out_paf) return WFM_E_ARG;
+  return wfmh_map_multi(&h, 1, target_fasta, query_fasta, out_paf, params, summary);
+}
+
+int wfmh_map_multi(wfm_handle_t* const* handles, int n, const char* target_fasta, const char* query_fasta, const char* out_paf,
+                   const wfmh_map_params_t* params, wfmh_map_summary_t* summary) {
+  if (!handles || n < 1 || !target_fasta || !out_paf) return WFM_E_ARG;
+  for (int i = 0; i < n; ++i) if (!handles[i]) return WFM_E_ARG;
+  wfm_handle_t* h = handles[0];
   try {
     wfmh_map_params_t def;
     wfmh_map_default_params(&def);
@@ -135,7 +142,7 @@ int wfmh_map(wfm_handle_t* h, const char* target_fasta, const char* query_fasta,
                                         std::string(1, p.prefix_delim), p.query_list, p.target_list);
       p.percentageIdentity = skch::Stat::estimate_identity_for_groups(p, ids, h);
     }
-    skch::Map mapper(p, h);
+    skch::Map mapper(p, std::vector<wfm_handle_t*>(handles, handles + n));
     skch::MapSummary s;
     const int rc = mapper.mapQuery(&s);
     if (summary) {
@@ -145,6 +152,7 @@ int wfmh_map(wfm_handle_t* h, const char* target_fasta, const char* query_fasta,
       summary->percentage_identity = mapper.parameters().percentageIdentity;
       summary->sketch_size = mapper.parameters().sketchSize;
       summary->ms_index = s.ms_index; summary->ms_map = s.ms_map; summary->ms_filter = s.ms_filter; summary->ms_total = s.ms_total;
+      summary->ms_replicate = s.ms_replicate;
     }
     return rc;
   } catch (const std::exception& e) {

@@ -5,17 +5,23 @@
 //   wfmash-hip -m target.fa [query.fa]         approximate mappings only (parse_args.hpp:77)
 //   wfmash-hip -i map.paf target.fa [query.fa] align the mappings of a previous -m run (:119, :800-804)
 //
-// Differences: output goes to stdout or --out FILE; --device picks the GPU.  Options of the
-// reference that belong to subsystems outside this build (index files -W/-I, external seeds -K,
-// wavefront plots -G/-u, scaffold dump --scaffold-out) are not accepted.
+//   wfmash-hip -W idx target.fa                build the target index, write it and stop (parse_args.hpp:745-751)
+//   wfmash-hip -I idx target.fa [query.fa]     read the index instead of building it (:752-758)
+//
+// Differences: output goes to stdout or --out FILE; --device picks the GPU, --gpus N spreads the
+// queries (map) and the mapping records (align) over N GPUs of the node.  Options of the reference
+// that belong to subsystems outside this build (external seeds -K, wavefront plots -G/-u, scaffold
+// dump --scaffold-out) are not accepted.
 #include <unistd.h>
 
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <limits>
 #include <regex>
 #include <string>
+#include <vector>
 
 #include "../../include/wfmash_host.h"
 
@@ -43,7 +49,7 @@ static void usage() {
           "            -S INT scaffold mass [10k]   -D INT scaffold dist [100k]   -j INT scaffold jump [100k]   -r INT per scaffold [1]\n"
           "            -Y C group delimiter [#]   -X self maps   -L lower triangular   -t INT threads [1]\n"
           "  alignment -g x,o1,e1,o2,e2 [5,8,2,24,1]   -E INT target padding   -U INT query padding   -a SAM   -d MD tag\n"
-          "  other     --out FILE [stdout]   --device INT [0]\n");
+          "  other     --out FILE [stdout]   --device INT [0]   --gpus N|all [1] GPUs of this node, starting at --device\n");
 }
 
 int main(int argc, char** argv) {
@@ -53,8 +59,8 @@ int main(int argc, char** argv) {
   wfmh_map_params_t mp;
   wfmh_map_default_params(&mp);
   std::string mapping_in, out = "/dev/stdout", target, query;
-  bool approx_only = false;
-  int device = 0;
+  bool approx_only = false, target_padding_given = false, query_padding_given = false;
+  int device = 0, gpus = 1;
   for (int i = 1; i < argc; ++i) {
     const std::string a = argv[i];
     auto next = [&](const char* name) -> std::string {
@@ -70,23 +76,45 @@ int main(int argc, char** argv) {
     else if (a == "-i" || a == "--align-paf") mapping_in = next("-i");
     else if (a == "--out") out = next("--out");
     else if (a == "--device") device = atoi(next("--device").c_str());
+    else if (a == "--gpus") { const std::string v = next("--gpus"); gpus = v == "all" ? 0 : atoi(v.c_str()); if (gpus < 0) gpus = 1; }
     else if (a == "-t" || a == "--threads") { mp.threads = atoi(next("-t").c_str()); ap.threads = mp.threads; }
     // ---- mapping (parse_args.hpp:71-115)
     else if (a == "-k" || a == "--kmer-size") mp.kmer_size = atoi(next("-k").c_str());
     else if (a == "-s" || a == "--sketch-size") mp.sketch_size = atoi(next("-s").c_str());
-    else if (a == "-w" || a == "--window-size") mp.window_length = size("-w");
+    else if (a == "-w" || a == "--window-size") {
+      mp.window_length = size("-w");
+      if (mp.window_length <= 0) { fprintf(stderr, "[wfmash] ERROR, skch::parseandSave, window size has to be a float value greater than 0.\n"); return 1; }
+      if (mp.window_length < 100) {  // parse_args.hpp:324-328
+        fprintf(stderr, "[wfmash] ERROR, skch::parseandSave, minimum window size is required to be >= 100 bp.\n");
+        return 1;
+      }
+    }
     else if (a == "-p" || a == "--map-pct-id") {
       const std::string v = next("-p");
       std::smatch m;
-      if (std::regex_match(v, m, std::regex("^ani(\\d+)([+-]\\d+(\\.\\d+)?)?$"))) {  // parse_args.hpp:345-366
+      if (std::regex_match(v, m, std::regex("^ani(\\d+)([+-]\\d+)?$"))) {  // parse_args.hpp:345-366
         mp.auto_pct_identity = 1;
         mp.ani_percentile = atoi(m[1].str().c_str());
+        if (mp.ani_percentile < 1 || mp.ani_percentile > 99) {  // :352-356
+          fprintf(stderr, "[wfmash] ERROR: ANI percentile must be between 1 and 99, got: %d\n", mp.ani_percentile);
+          return 1;
+        }
         mp.ani_adjustment = m[2].matched ? (float)atof(m[2].str().c_str()) : 0.0f;
       } else if (v == "auto") {
         mp.auto_pct_identity = 1; mp.ani_percentile = 25; mp.ani_adjustment = 0.0f;
       } else {
+        char* end = nullptr;
+        const float pct = strtof(v.c_str(), &end);
+        if (end == v.c_str()) {  // std::stof throws (:383-387)
+          fprintf(stderr, "[wfmash] ERROR: Invalid value for -p/--map-pct-id: %s\n", v.c_str());
+          return 1;
+        }
+        if (pct < 50) {  // :377-380
+          fprintf(stderr, "[wfmash] ERROR: minimum nucleotide identity requirement should be >= 50%%.\n");
+          return 1;
+        }
         mp.auto_pct_identity = 0;
-        mp.percentage_identity = (float)(atof(v.c_str()) / 100.0);
+        mp.percentage_identity = pct / 100.0f;
       }
     }
     else if (a == "-n" || a == "--mappings") {
@@ -126,8 +154,8 @@ int main(int argc, char** argv) {
     else if (a == "-X" || a == "--self-maps") mp.skip_self = 0;
     else if (a == "-L" || a == "--lower-triangular") mp.lower_triangular = 1;
     // ---- alignment (parse_args.hpp:119-129)
-    else if (a == "-E" || a == "--target-padding") ap.target_padding = (uint64_t)size("-E");
-    else if (a == "-U" || a == "--query-padding") ap.query_padding = (uint64_t)size("-U");
+    else if (a == "-E" || a == "--target-padding") { ap.target_padding = (uint64_t)size("-E"); target_padding_given = true; }
+    else if (a == "-U" || a == "--query-padding") { ap.query_padding = (uint64_t)size("-U"); query_padding_given = true; }
     else if (a == "-g" || a == "--wfa-params") {
       const std::string v = next("-g");
       if (sscanf(v.c_str(), "%d,%d,%d,%d,%d", &ap.mismatch, &ap.gap_open1, &ap.gap_ext1, &ap.gap_open2, &ap.gap_ext2) != 5) {
@@ -146,9 +174,40 @@ int main(int argc, char** argv) {
   }
   if (target.empty()) { fprintf(stderr, "[wfmash] ERROR: need a target FASTA\n"); usage(); return 1; }
   if (approx_only && !mapping_in.empty()) { fprintf(stderr, "[wfmash] ERROR: -m and -i exclude each other\n"); return 1; }
-  // paddings default to the segment length, capped (parse_args.hpp:566-584)
-  wfm_handle_t* h = nullptr;
-  if (wfm_create(device, &h) != WFM_OK) { fprintf(stderr, "[wfmash] ERROR: no usable MI355X device (there is no CPU fallback)\n"); return 2; }
+  if (!mapping_in.empty() && mp.index_file) { fprintf(stderr, "[wfmash] ERROR: -i (align only) does not read or write an index (-W / -I)\n"); return 1; }
+  if (!approx_only && !(mp.index_file && mp.write_index) && mp.window_length > 10000) {  // parse_args.hpp:330-335
+    fprintf(stderr, "[wfmash] ERROR: window size (-w) must be <= 10kb when running alignment.\n"
+                    "[wfmash] For larger values, use -m/--approx-mapping to generate mappings,\n"
+                    "[wfmash] then align them with: wfmash ... -i mappings.paf\n");
+    return 1;
+  }
+  if ((uint64_t)mp.window_length >= mp.max_mapping_length) {  // parse_args.hpp:485-488
+    fprintf(stderr, "[wfmash] ERROR, skch::parseandSave, window size should not be larger than max mapping length.\n");
+    return 1;
+  }
+  if ((uint64_t)mp.block_length >= mp.max_mapping_length) {  // :489-492
+    fprintf(stderr, "[wfmash] ERROR, skch::parseandSave, block length should not be larger than max mapping length.\n");
+    return 1;
+  }
+  // what the align phase derives from the segment length (parse_args.hpp:590-591, :600-620): the paddings default to
+  // it, capped at 5000, and a mapping may be at most 128 segments long on its shorter axis
+  if (!target_padding_given) ap.target_padding = (uint64_t)std::min<int64_t>(mp.window_length, 5000);
+  if (!query_padding_given) ap.query_padding = (uint64_t)std::min<int64_t>(mp.window_length, 5000);
+  ap.wflign_max_len_minor = (uint64_t)mp.window_length * 128;
+  // one handle per GPU; every phase hands its batches to whichever device is free
+  if (gpus == 0) { gpus = wfm_device_count() - device; if (gpus < 1) gpus = 1; }
+  std::vector<wfm_handle_t*> hs;
+  for (int g = 0; g < gpus; ++g) {
+    wfm_handle_t* hg = nullptr;
+    if (wfm_create(device + g, &hg) != WFM_OK) {
+      fprintf(stderr, "[wfmash] ERROR: no usable MI355X device %d (there is no CPU fallback)\n", device + g);
+      for (wfm_handle_t* o : hs) wfm_destroy(o);
+      return 2;
+    }
+    hs.push_back(hg);
+  }
+  wfm_handle_t* h = hs.front();
+  auto destroy_all = [&] { for (wfm_handle_t* o : hs) wfm_destroy(o); };
   const char* q = query.empty() ? nullptr : query.c_str();
   int rc = WFM_OK;
   std::string mapping = mapping_in;
@@ -158,35 +217,35 @@ int main(int argc, char** argv) {
     else {  // the hand-off file between the phases (temp_file::create, parse_args.hpp:805-808)
       char tmpl[] = "./wfmash-XXXXXX";
       const int fd = mkstemp(tmpl);
-      if (fd < 0) { fprintf(stderr, "[wfmash] ERROR: cannot create a temporary file in the working directory\n"); wfm_destroy(h); return 1; }
+      if (fd < 0) { fprintf(stderr, "[wfmash] ERROR: cannot create a temporary file in the working directory\n"); destroy_all(); return 1; }
       close(fd);
       temp = tmpl;
       mapping = temp;
     }
     wfmh_map_summary_t ms;
-    rc = wfmh_map(h, target.c_str(), q, mapping.c_str(), &mp, &ms);
+    rc = wfmh_map_multi(hs.data(), (int)hs.size(), target.c_str(), q, mapping.c_str(), &mp, &ms);
     if (rc == WFM_OK)
       fprintf(stderr, "[wfmash::map] %llu queries x %llu targets (%llu subsets), identity %.2f%%, sketch %d: %llu fragments, %llu segment mappings, "
-                      "%llu records; index %.0f ms, mapping %.0f ms, filtering %.0f ms, total %.0f ms\n",
+                      "%llu records; index %.0f ms (+ %.0f ms to copy it to the other GPUs), mapping %.0f ms, filtering %.0f ms, total %.0f ms\n",
               (unsigned long long)ms.queries, (unsigned long long)ms.targets, (unsigned long long)ms.subsets, ms.percentage_identity * 100.0,
-              ms.sketch_size, (unsigned long long)ms.fragments, (unsigned long long)ms.l2_mappings, (unsigned long long)ms.written, ms.ms_index,
+              ms.sketch_size, (unsigned long long)ms.fragments, (unsigned long long)ms.l2_mappings, (unsigned long long)ms.written, ms.ms_index, ms.ms_replicate,
               ms.ms_map, ms.ms_filter, ms.ms_total);
     else fprintf(stderr, "[wfmash::map] ERROR: %s\n", wfm_last_error(h));
   }
   if (mp.index_file && mp.write_index) {  // -W: "index construction completed", nothing else runs (computeMap.hpp:405-415)
     if (!temp.empty()) unlink(temp.c_str());
-    wfm_destroy(h);
+    destroy_all();
     return rc == WFM_OK ? 0 : 3;
   }
   if (rc == WFM_OK && !approx_only) {
     wfmh_align_summary_t s;
-    rc = wfmh_align_paf(h, target.c_str(), q, mapping.c_str(), out.c_str(), &ap, &s);
+    rc = wfmh_align_paf_multi(hs.data(), (int)hs.size(), target.c_str(), q, mapping.c_str(), out.c_str(), &ap, &s);
     if (rc == WFM_OK)
       fprintf(stderr, "[wfmash::align] %llu records, %llu aligned bp, %.1f ms GPU kernels, %.1f ms total => %.3g aligned bp/s\n",
               (unsigned long long)s.records, (unsigned long long)s.aligned_bp, s.ms_gpu, s.ms_total, s.aligned_bp / (s.ms_total * 1e-3));
     else fprintf(stderr, "[wfmash::align] ERROR: %s\n", wfm_last_error(h));
   }
   if (!temp.empty()) unlink(temp.c_str());
-  wfm_destroy(h);
+  destroy_all();
   return rc == WFM_OK ? 0 : 3;
 }

@@ -9,6 +9,7 @@
 #include <fstream>
 #include <iostream>
 #include <map>
+#include <mutex>
 #include <sstream>
 #include <stdexcept>
 #include <thread>
@@ -77,7 +78,10 @@ struct DeviceTables {
 
 }  // namespace
 
-Map::Map(const Parameters& p, wfm_handle_t* h) : param_(p), h_(h) {
+Map::Map(const Parameters& p, wfm_handle_t* h) : Map(p, std::vector<wfm_handle_t*>{h}) {}
+
+Map::Map(const Parameters& p, const std::vector<wfm_handle_t*>& hs) : param_(p), h_(hs.empty() ? nullptr : hs.front()), hs_(hs) {
+  if (!h_ || std::find(hs_.begin(), hs_.end(), nullptr) != hs_.end()) throw std::runtime_error("no GPU handle");
   if (param_.querySequences.empty()) param_.querySequences = param_.refSequences;  // all-vs-all
   if (param_.sketchSize <= 0) {
     const double md = 1 - param_.percentageIdentity;
@@ -246,105 +250,177 @@ int Map::mapQuery(MapSummary* summary) {
     }
     sum.ms_index += now_ms() - t0;
 
-    // ---- queries, in batches of whole sequences
-    size_t qi = 0;
-    while (qi < queryNames.size()) {
+    // ---- the other GPUs of the node receive a copy of the finished index (it is read-only from here on,
+    // computeMap.hpp:431-484): built once per node, not once per GPU
+    std::vector<wfm_index_t*> ixs(hs_.size(), nullptr);
+    ixs[0] = ix;
+    if (ix) {
       t0 = now_ms();
-      struct BatchQuery { std::string name; seqno_t id; offset_t len; int64_t base; int64_t first_frag; int nfrag; };
+      for (size_t g = 1; g < hs_.size(); ++g) {
+        const int rc = wfm_index_replicate(h_, ix, hs_[g], &ixs[g]);
+        if (rc != WFM_OK) {
+          wfm_set_error(h_, std::string("index replication failed: ") + wfm_last_error(hs_[g]));
+          for (size_t f = 0; f < hs_.size(); ++f) wfm_index_free(hs_[f], ixs[f]);
+          return rc;
+        }
+      }
+      sum.ms_replicate += now_ms() - t0;
+    }
+    auto free_indexes = [&] { for (size_t g = 0; g < hs_.size(); ++g) if (ixs[g]) wfm_index_free(hs_[g], ixs[g]); };
+
+    // ---- queries, in batches of whole sequences; a GPU takes the next batch when it is free, finished batches
+    // are written in the order they were formed
+    struct BatchQuery { std::string name; seqno_t id; offset_t len; int64_t base; int64_t first_frag; int nfrag; };
+    struct Batch {
       std::vector<BatchQuery> bq;
       std::string buffer;
       std::vector<int64_t> frag_off;
       std::vector<int32_t> frag_seq;
-      while (qi < queryNames.size() && ((int64_t)buffer.size() < kBatchBases || bq.empty())) {
+    };
+    struct QueryOut { MappingResultsVector_t keep; std::string text; };
+    struct BatchOut { std::vector<seqno_t> ids; std::vector<QueryOut> q; };
+    int64_t batch_bases = kBatchBases;
+    if (hs_.size() > 1) batch_bases = std::max<int64_t>(1, std::min<int64_t>(kBatchBases, (int64_t)(sum.query_bp / (2 * hs_.size()))));
+    std::mutex read_mu, write_mu;
+    size_t qi = 0;
+    uint64_t next_seq = 0, next_write = 0;
+    std::map<uint64_t, BatchOut> pending;
+    std::atomic<int> error_rc{WFM_OK};
+    const int threads_each = std::max(1, P.threads / (int)hs_.size());
+    auto read_batch = [&](Batch& b) -> int64_t {
+      std::lock_guard<std::mutex> lk(read_mu);
+      b = Batch();
+      while (qi < queryNames.size() && ((int64_t)b.buffer.size() < batch_bases || b.bq.empty())) {
         const std::string& name = queryNames[qi++];
         const std::string* seq = src.find(P.querySequences, name);
         if (!seq || seq->empty()) continue;  // "not found or empty, skipping" (computeMap.hpp:534-537)
-        BatchQuery q{name, ids.getSequenceId(name), (offset_t)seq->size(), (int64_t)buffer.size(), (int64_t)frag_off.size(), 0};
+        BatchQuery q{name, ids.getSequenceId(name), (offset_t)seq->size(), (int64_t)b.buffer.size(), (int64_t)b.frag_off.size(), 0};
         const int whole = (int)(q.len / w);
-        for (int i = 0; i < whole; ++i) frag_off.push_back(q.base + (int64_t)i * w);
+        for (int i = 0; i < whole; ++i) b.frag_off.push_back(q.base + (int64_t)i * w);
         q.nfrag = whole;
-        if (whole >= 1 && q.len % w != 0) { frag_off.push_back(q.base + q.len - w); q.nfrag++; }  // anchored at the end
-        frag_seq.insert(frag_seq.end(), (size_t)q.nfrag, q.id);
-        buffer += *seq;
-        bq.push_back(std::move(q));
+        if (whole >= 1 && q.len % w != 0) { b.frag_off.push_back(q.base + q.len - w); q.nfrag++; }  // anchored at the end
+        b.frag_seq.insert(b.frag_seq.end(), (size_t)q.nfrag, q.id);
+        b.buffer += *seq;
+        b.bq.push_back(std::move(q));
       }
-      std::vector<wfm_mapping_t> maps;
-      std::vector<int32_t> mfrag;
-      if (ix && !frag_off.empty()) {
-        // a fragment of a pangenome maps about once per target haplotype; a too small buffer costs a
-        // second pass over the batch, so be generous
-        int64_t cap = (int64_t)frag_off.size() * std::min<int64_t>(256, std::max<int64_t>(16, 2 * (int64_t)subset.size())) + (1 << 16);
-        for (;;) {
-          maps.resize((size_t)cap); mfrag.resize((size_t)cap);
-          const int64_t n = wfm_map_fragments(h_, ix, buffer.data(), (int64_t)buffer.size(), frag_off.data(), frag_seq.data(),
-                                              (int64_t)frag_off.size(), &T.prm, maps.data(), mfrag.data(), cap);
-          if (n < 0) { wfm_index_free(h_, ix); return (int)n; }
-          if (n <= cap) { maps.resize((size_t)n); mfrag.resize((size_t)n); break; }
-          cap = n;
-        }
-      }
-      sum.fragments += frag_off.size();
-      sum.l2_mappings += maps.size();
-      sum.ms_map += now_ms() - t0;
-
-      // ---- per query: boundary check, filters, output (processFragment :124-128; query task :634-688)
-      t0 = now_ms();
-      // queries are independent here (the reference runs one Taskflow task per query); results are
-      // written in query order afterwards
-      std::vector<size_t> first_map(bq.size() + 1, maps.size());
-      {
-        size_t m = 0;
-        for (size_t qn = 0; qn < bq.size(); ++qn) {
-          first_map[qn] = m;
-          while (m < maps.size() && mfrag[m] < bq[qn].first_frag + bq[qn].nfrag) ++m;
-        }
-      }
-      struct QueryOut { MappingResultsVector_t keep; std::string text; };
-      std::vector<QueryOut> qout(bq.size());
-      std::atomic<size_t> next{0};
-      auto work = [&]() {
-        for (size_t qn; (qn = next.fetch_add(1)) < bq.size();) {
-          const BatchQuery& q = bq[qn];
-          MappingResultsVector_t results;
-          for (size_t m = first_map[qn]; m < first_map[qn + 1]; ++m) {
-            MappingResult r;
-            std::memcpy(&r, &maps[m], sizeof(r));
-            r.queryStartPos += (uint32_t)((mfrag[m] - q.first_frag) * w);  // fragmentIndex * windowLength, also for the anchored one
-            results.push_back(r);
+      return b.bq.empty() ? -1 : (int64_t)next_seq++;
+    };
+    auto write_batch = [&](uint64_t seq, BatchOut&& bo) {
+      std::lock_guard<std::mutex> lk(write_mu);
+      pending.emplace(seq, std::move(bo));
+      for (auto it = pending.begin(); it != pending.end() && it->first == next_write; it = pending.erase(it), ++next_write) {
+        BatchOut& o = it->second;
+        for (size_t qn = 0; qn < o.q.size(); ++qn) {
+          if (P.filterMode == filter::ONETOONE) {
+            auto& dst = combined[o.ids[qn]];
+            dst.insert(dst.end(), o.q[qn].keep.begin(), o.q[qn].keep.end());
+          } else {
+            out << o.q[qn].text;
+            sum.written += o.q[qn].keep.size();
           }
-          MappingOutput::mappingBoundarySanityCheck(q.len, results, ids);
-          FilteredMappingsResult fr = filterSubsetMappings(results, P, ids, q.len);
-          const bool merged = P.mergeMappings && P.split;
-          MappingResultsVector_t& keep = merged ? fr.mergedMappings : fr.nonMergedMappings;
-          const ChainInfoVector_t& chains = merged ? fr.mergedChainInfo : fr.nonMergedChainInfo;
-          if (P.filterMode != filter::ONETOONE) {
-            std::ostringstream os;
-            MappingOutput::reportReadMappings(keep, chains, q.name, os, ids, P, q.len);
-            qout[qn].text = os.str();
-          }
-          qout[qn].keep = std::move(keep);
-        }
-      };
-      {
-        const int nt = (int)std::min<size_t>((size_t)std::max(1, P.threads), bq.size());
-        std::vector<std::thread> pool;
-        for (int t = 1; t < nt; ++t) pool.emplace_back(work);
-        work();
-        for (auto& t : pool) t.join();
-      }
-      for (size_t qn = 0; qn < bq.size(); ++qn) {
-        if (P.filterMode == filter::ONETOONE) {
-          auto& dst = combined[bq[qn].id];
-          dst.insert(dst.end(), qout[qn].keep.begin(), qout[qn].keep.end());
-        } else {
-          out << qout[qn].text;
-          sum.written += qout[qn].keep.size();
         }
       }
       out.flush();
-      sum.ms_filter += now_ms() - t0;
+    };
+    std::vector<MapSummary> part(hs_.size());
+    auto worker = [&](size_t g) {
+      wfm_handle_t* hg = hs_[g];
+      MapSummary& ps = part[g];
+      Batch b;
+      for (int64_t seq; error_rc.load() == WFM_OK && (seq = read_batch(b)) >= 0;) {
+        double tb = now_ms();
+        std::vector<wfm_mapping_t> maps;
+        std::vector<int32_t> mfrag;
+        if (ixs[g] && !b.frag_off.empty()) {
+          // a fragment of a pangenome maps about once per target haplotype; a too small buffer costs a
+          // second pass over the batch, so be generous
+          int64_t cap = (int64_t)b.frag_off.size() * std::min<int64_t>(256, std::max<int64_t>(16, 2 * (int64_t)subset.size())) + (1 << 16);
+          for (;;) {
+            maps.resize((size_t)cap); mfrag.resize((size_t)cap);
+            const int64_t n = wfm_map_fragments(hg, ixs[g], b.buffer.data(), (int64_t)b.buffer.size(), b.frag_off.data(), b.frag_seq.data(),
+                                                (int64_t)b.frag_off.size(), &T.prm, maps.data(), mfrag.data(), cap);
+            if (n < 0) {
+              if (hg != h_) wfm_set_error(h_, wfm_last_error(hg));
+              error_rc.store((int)n);
+              return;
+            }
+            if (n <= cap) { maps.resize((size_t)n); mfrag.resize((size_t)n); break; }
+            cap = n;
+          }
+        }
+        ps.fragments += b.frag_off.size();
+        ps.l2_mappings += maps.size();
+        ps.ms_map += now_ms() - tb;
+
+        // ---- per query: boundary check, filters, output (processFragment :124-128; query task :634-688)
+        tb = now_ms();
+        // queries are independent here (the reference runs one Taskflow task per query); results are
+        // written in query order afterwards
+        const std::vector<BatchQuery>& bq = b.bq;
+        std::vector<size_t> first_map(bq.size() + 1, maps.size());
+        {
+          size_t m = 0;
+          for (size_t qn = 0; qn < bq.size(); ++qn) {
+            first_map[qn] = m;
+            while (m < maps.size() && mfrag[m] < bq[qn].first_frag + bq[qn].nfrag) ++m;
+          }
+        }
+        BatchOut bo;
+        bo.q.resize(bq.size());
+        for (const auto& q : bq) bo.ids.push_back(q.id);
+        std::vector<QueryOut>& qout = bo.q;
+        std::atomic<size_t> next{0};
+        auto work = [&]() {
+          for (size_t qn; (qn = next.fetch_add(1)) < bq.size();) {
+            const BatchQuery& q = bq[qn];
+            MappingResultsVector_t results;
+            for (size_t m = first_map[qn]; m < first_map[qn + 1]; ++m) {
+              MappingResult r;
+              std::memcpy(&r, &maps[m], sizeof(r));
+              r.queryStartPos += (uint32_t)((mfrag[m] - q.first_frag) * w);  // fragmentIndex * windowLength, also for the anchored one
+              results.push_back(r);
+            }
+            MappingOutput::mappingBoundarySanityCheck(q.len, results, ids);
+            FilteredMappingsResult fr = filterSubsetMappings(results, P, ids, q.len);
+            const bool merged = P.mergeMappings && P.split;
+            MappingResultsVector_t& keep = merged ? fr.mergedMappings : fr.nonMergedMappings;
+            const ChainInfoVector_t& chains = merged ? fr.mergedChainInfo : fr.nonMergedChainInfo;
+            if (P.filterMode != filter::ONETOONE) {
+              std::ostringstream os;
+              MappingOutput::reportReadMappings(keep, chains, q.name, os, ids, P, q.len);
+              qout[qn].text = os.str();
+            }
+            qout[qn].keep = std::move(keep);
+          }
+        };
+        {
+          const int nt = (int)std::min<size_t>((size_t)threads_each, bq.size());
+          std::vector<std::thread> pool;
+          for (int t = 1; t < nt; ++t) pool.emplace_back(work);
+          work();
+          for (auto& t : pool) t.join();
+        }
+        write_batch((uint64_t)seq, std::move(bo));
+        ps.ms_filter += now_ms() - tb;
+      }
+    };
+    {
+      std::vector<std::thread> pool;
+      for (size_t g = 1; g < hs_.size(); ++g) pool.emplace_back(worker, g);
+      worker(0);
+      for (auto& t : pool) t.join();
     }
-    if (ix) wfm_index_free(h_, ix);
+    if (error_rc.load() != WFM_OK) { free_indexes(); return error_rc.load(); }
+    {
+      // the GPUs work side by side: the phase times of a subset are those of its slowest device
+      double mm = 0, mf = 0;
+      for (const MapSummary& ps : part) {
+        sum.fragments += ps.fragments; sum.l2_mappings += ps.l2_mappings;
+        mm = std::max(mm, ps.ms_map); mf = std::max(mf, ps.ms_filter);
+      }
+      sum.ms_map += mm; sum.ms_filter += mf;
+    }
+    free_indexes();
   }
 
   if (P.filterMode == filter::ONETOONE) {

@@ -14,6 +14,7 @@
 #include <cstdint>
 #include <memory>
 #include <string>
+#include <vector>
 
 #include "../../include/wfmash_hip.h"
 #include "map_types.hpp"
@@ -28,13 +29,16 @@ struct MapSummary {
   uint64_t fragments = 0;           // query fragments mapped (summed over subsets)
   uint64_t l2_mappings = 0;         // MappingResults leaving the GPU
   uint64_t written = 0;             // mapping PAF lines written
-  double ms_index = 0, ms_map = 0, ms_filter = 0, ms_total = 0;
+  double ms_index = 0, ms_replicate = 0, ms_map = 0, ms_filter = 0, ms_total = 0;
 };
 
 class Map {
  public:
   // p.sketchSize == 0 derives it from the identity (parse_args.hpp:642-644)
   Map(const Parameters& p, wfm_handle_t* h);
+  // one handle per GPU of the node: the index is built on the first and copied to the others (it is read-only while
+  // mapping, computeMap.hpp:431-484), batches of query sequences go to whichever device is free
+  Map(const Parameters& p, const std::vector<wfm_handle_t*>& hs);
   // maps every query against every target subset and writes param.outFileName; returns 0 or WFM_E_*
   int mapQuery(MapSummary* summary = nullptr);
   const SequenceIdManager& ids() const { return *idManager_; }
@@ -42,7 +46,8 @@ class Map {
 
  private:
   Parameters param_;
-  wfm_handle_t* h_;
+  wfm_handle_t* h_;                // hs_[0]: builds the index, carries the error message
+  std::vector<wfm_handle_t*> hs_;
   std::unique_ptr<SequenceIdManager> idManager_;
   int cached_minimum_hits_ = 0;
 };
