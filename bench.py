@@ -79,7 +79,8 @@ def main():
             dist.destroy_process_group()
         else:
             seen = [0]
-        print(json.dumps({"rank_check": True, "rank": rank, "n_gpus": world, "ranks_seen": seen}), flush=True)
+        sys.stdout.flush()
+        os.write(1, (json.dumps({"rank_check": True, "rank": rank, "n_gpus": world, "ranks_seen": seen}) + "\n").encode())  # one write per line
         return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")

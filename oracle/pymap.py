@@ -37,6 +37,11 @@ def _load(which):
         L.ref_upper_valid.argtypes = [C.c_char_p, C.c_int64]
         L.ref_revcomp.restype = None
         L.ref_revcomp.argtypes = [C.c_char_p, C.c_char_p, C.c_int]
+        if hasattr(L, "ref_group_minhash"):
+            L.ref_group_minhash.restype = C.c_int64
+            L.ref_group_minhash.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int32, C.c_void_p, C.c_int64]
+            L.ref_streaming_minhash.restype = C.c_int64
+            L.ref_streaming_minhash.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int64]
     _libs[which] = L
     return L
 
@@ -73,3 +78,23 @@ def ref_add_minmers(seq: bytes, k: int, w: int, s: int, seq_id: int = 0):
     buf = C.create_string_buffer(seq, len(seq))
     n = L.ref_add_minmers(buf, len(seq), k, w, s, seq_id, out.ctypes.data, cap)
     return out[:n]
+
+
+def ref_group_minhash(seqs, groups, k: int, sketch_size: int, want_group: int):
+    """The reference's GroupedStreamingMinHash over `seqs` (list of bytes), sketch of group `want_group` ascending."""
+    L = _load("ref")
+    n = len(seqs)
+    ptrs = (C.c_char_p * n)(*seqs)
+    lens = np.array([len(x) for x in seqs], dtype=np.int64)
+    grp = np.ascontiguousarray(groups, dtype=np.int32)
+    out = np.zeros(sketch_size, dtype=np.uint64)
+    m = L.ref_group_minhash(ptrs, lens.ctypes.data, grp.ctypes.data, n, k, sketch_size, want_group, out.ctypes.data, sketch_size)
+    return out[:m]
+
+
+def ref_streaming_minhash(values, sketch_size: int):
+    L = _load("ref")
+    v = np.ascontiguousarray(values, dtype=np.uint64)
+    out = np.zeros(sketch_size, dtype=np.uint64)
+    m = L.ref_streaming_minhash(v.ctypes.data, len(v), sketch_size, out.ctypes.data, sketch_size)
+    return out[:m]

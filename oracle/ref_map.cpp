@@ -14,6 +14,11 @@
 
 #include "map/include/base_types.hpp"
 #include "map/include/commonFunc.hpp"
+// streamingMinHash.hpp also compiles unmodified: StreamingMinHash is the sketch Stat::estimate_identity_for_groups
+// keeps per worker and per group (map_stats.hpp:540-660), and GroupedStreamingMinHash::processSequence is the same
+// k-mer loop (ambiguity counter, canonical hash, palindromes dropped) as map_stats.hpp:569-616, which itself cannot be
+// compiled here (GSL, htslib).
+#include "map/include/streamingMinHash.hpp"
 
 extern "C" {
 
@@ -67,6 +72,33 @@ int64_t ref_add_minmers(char* seq, int64_t len, int k, int w, int s, int32_t seq
     ++n;
   }
   return (int64_t)v.size();
+}
+
+// Bottom-`sketch_size` MinHash of a set of sequences pooled by group, by the reference's own classes:
+// GroupedStreamingMinHash::processSequence per sequence (streamingMinHash.hpp:167-241), sketches out in ascending order
+// (StreamingMinHash::getSketch).  groups[i] = group of sequence i; out receives the sketch of `want_group`.
+int64_t ref_group_minhash(const char* const* seqs, const int64_t* lens, const int32_t* groups, int n, int k, int sketch_size,
+                          int32_t want_group, uint64_t* out, int64_t cap) {
+  skch::GroupedStreamingMinHash g((size_t)sketch_size, 0);
+  for (int i = 0; i < n; ++i)
+    if (lens[i] >= k) g.processSequence(seqs[i], lens[i], i, groups[i], k, 4, nullptr);
+  const auto all = g.getAllGroupSketches();
+  const auto it = all.find(want_group);
+  if (it == all.end()) return 0;
+  int64_t m = 0;
+  for (uint64_t h : it->second) { if (m < cap) out[m] = h; ++m; }
+  return m;
+}
+
+// StreamingMinHash alone: add the values in order, return the sketch (keeps duplicates; a value equal to the
+// current maximum does not enter a full sketch)
+int64_t ref_streaming_minhash(const uint64_t* values, int64_t n, int sketch_size, uint64_t* out, int64_t cap) {
+  skch::StreamingMinHash mh((size_t)sketch_size, 0);
+  for (int64_t i = 0; i < n; ++i) mh.add_unsafe(values[i]);
+  const auto v = mh.getSketch();
+  int64_t m = 0;
+  for (uint64_t h : v) { if (m < cap) out[m] = h; ++m; }
+  return m;
 }
 
 }  // extern "C"

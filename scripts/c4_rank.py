@@ -20,47 +20,7 @@ import time
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from wfmash_amd import capi, dist  # noqa: E402
-
-ACGT = np.frombuffer(b"ACGT", dtype=np.uint8)
-COMP = np.zeros(256, dtype=np.uint8)
-COMP[ACGT] = np.frombuffer(b"TGCA", dtype=np.uint8)
-
-
-def haplotype(base: np.ndarray, seed: int) -> np.ndarray:
-    rng = np.random.default_rng(seed)
-    s = base.copy()
-    n = len(s)
-    # SNPs: a different base at 0.1 % of the positions
-    pos = rng.integers(0, n, n // 1000)
-    code = np.searchsorted(ACGT, s[pos])  # ACGT is sorted
-    s[pos] = ACGT[(code + rng.integers(1, 4, len(pos))) % 4]
-    # short indels, 0.01 %: half deletions, half insertions of 1 + Geometric(0.5) bases
-    m = n // 10000
-    pos = np.unique(rng.integers(0, n, m))
-    ln = rng.geometric(0.5, len(pos))
-    is_del = rng.random(len(pos)) < 0.5
-    keep = np.ones(n, dtype=bool)
-    for p, l in zip(pos[is_del], ln[is_del]):
-        keep[p:p + l] = False
-    ins_pos = np.repeat(pos[~is_del], ln[~is_del])
-    ins_val = ACGT[rng.integers(0, 4, len(ins_pos))]
-    # np.insert indexes into the ORIGINAL array; deleted bases are removed afterwards through `keep`
-    keep = np.insert(keep, ins_pos, True)
-    s = np.insert(s, ins_pos, ins_val)[keep]
-    # 20 structural variants
-    for _ in range(20):
-        l = int(rng.integers(10_000, 100_001))
-        p = int(rng.integers(0, len(s) - l))
-        kind = int(rng.integers(0, 3))
-        if kind == 0:
-            s = np.concatenate([s[:p], s[p + l:]])
-        elif kind == 1:
-            s = np.concatenate([s[:p + l], s[p:p + l], s[p + l:]])
-        else:
-            s[p:p + l] = COMP[s[p:p + l]][::-1]
-    return s
-
+from wfmash_amd import capi, dist, synth  # noqa: E402
 
 def main():
     ap = argparse.ArgumentParser()
@@ -76,22 +36,7 @@ def main():
     d = a.keep or tempfile.mkdtemp()
     fa = os.path.join(d, "c4.fa")
     t0 = time.time()
-    L = int(a.mbp * 1e6)
-    base = ACGT[np.random.default_rng(0xC4).integers(0, 4, L, dtype=np.uint8)]
-    names, lengths = [], []
-    with open(fa, "wb") as f, open(fa + ".fai", "w") as fai:
-        for h in range(a.haps):
-            s = haplotype(base, 0xC400 + h)
-            name = f"hap{h + 1}#1#chr1"
-            hdr = f">{name}\n".encode()
-            off = f.tell() + len(hdr)
-            f.write(hdr)
-            s.tofile(f)
-            f.write(b"\n")
-            fai.write(f"{name}\t{len(s)}\t{off}\t{len(s)}\t{len(s) + 1}\n")
-            names.append(name)
-            lengths.append(len(s))
-    del base
+    names, lengths = synth.write_fasta(fa, synth.pangenome(a.haps, int(a.mbp * 1e6)))
     t_gen = time.time() - t0
 
     mine = [names[i] for i in dist.shard_queries(lengths, a.world)[a.rank]]

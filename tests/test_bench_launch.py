@@ -19,10 +19,16 @@ def _clean_env():
 
 def _json_lines(text):
     out = []
+    dec = json.JSONDecoder()
     for line in text.splitlines():
         line = line.strip()
-        if line.startswith("{") and line.endswith("}"):
-            out.append(json.loads(line))
+        while line.startswith("{"):  # two ranks may share a line of the pipe
+            try:
+                obj, end = dec.raw_decode(line)
+            except ValueError:
+                break
+            out.append(obj)
+            line = line[end:].lstrip()
     return out
 
 

@@ -103,3 +103,56 @@ def test_map_sharded_two_ranks_reproduces_single_process_order():
         p.join(timeout=120)
         assert p.exitcode == 0
     assert out == single
+
+
+# ---- the file form: result files gathered in chunks, merged by streaming ----
+
+def _fake_map_file(work):
+    def fn(names):
+        path = os.path.join(work, f"part.{os.getpid()}.paf")
+        with open(path, "w") as f:
+            f.write(_fake_map(names))
+        return path
+    return fn
+
+
+def _file_worker(rank, world, port, work, out_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import wfmash_amd.dist as D
+    D.CHUNK_BYTES = 37  # many chunks per file
+    names = [n for n, _ in _QUERIES]
+    rank_dir = os.path.join(work, f"r{rank}")
+    os.makedirs(rank_dir, exist_ok=True)
+    paths_before = D.gather_files.__defaults__
+    D.map_sharded_files(_fake_map_file(rank_dir), names, [l for _, l in _QUERIES], out_path, rank_dir, dist,
+                        device=None)
+    assert paths_before == D.gather_files.__defaults__
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_map_sharded_files_two_ranks(tmp_path):
+    import wfmash_amd.dist as D
+    names = [n for n, _ in _QUERIES]
+    single = str(tmp_path / "single.paf")
+    D.map_sharded_files(_fake_map_file(str(tmp_path)), names, [l for _, l in _QUERIES], single, str(tmp_path), None)
+    assert open(single).read() == _fake_map(names)
+    # a query's records may come in several pieces (one per target subset): pieces keep their order
+    a, b = tmp_path / "a", tmp_path / "b"
+    a.write_text("q1\tx\nq1\ty\nq2\tz\nq1\tw\n")
+    b.write_text("q3\tu\n")
+    with open(tmp_path / "m", "wb") as f:
+        D.merge_query_block_files([str(a), str(b)], ["q3", "q1", "q2"], f)
+    assert (tmp_path / "m").read_text() == "q3\tu\nq1\tx\nq1\ty\nq1\tw\nq2\tz\n"
+    world, port = 2, _free_port()
+    two = str(tmp_path / "two.paf")
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_file_worker, args=(r, world, port, str(tmp_path), two)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert open(two).read() == open(single).read()

@@ -47,11 +47,15 @@ def _pangenome(seed, L=30000):
 
 
 def _expected(seqs, fa, P, pct, **kw):
-    add = None if pymap.have_ref() else kw.pop("add_minmers")
+    """The expected mapping PAF never comes from the product: minmer intervals from the reference's own addMinmers,
+    post-processing by the reference's own filter code (oracle/_ref).  Without that build the comparison cannot be
+    made and the test says so."""
+    if not (pymap.have_ref() and pyfilter.have_ref()):
+        pytest.skip("oracle/_ref is not built (it is compiled from /root/reference by `make -C oracle ref`): no independent "
+                    "expected output for the map phase in this checkout")
     kw.pop("add_minmers", None)
-    maps, group, S = MP.map_queries(seqs, pct, add_minmers=add, **kw)
-    flt = pyfilter.ref_filter if pyfilter.have_ref() else capi.host_filter
-    return "".join(flt("subset", maps[q], fa, seqs[q][0], P) for q in range(len(seqs))), maps, S
+    maps, group, S = MP.map_queries(seqs, pct, add_minmers=None, **kw)
+    return "".join(pyfilter.ref_filter("subset", maps[q], fa, seqs[q][0], P) for q in range(len(seqs))), maps, S
 
 
 @pytest.mark.parametrize("over", [{}, {"num_mappings_for_segment": 1, "chain_gap": 5000}, {"merge_mappings": 0, "scaffold_gap": 0}],

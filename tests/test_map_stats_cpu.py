@@ -28,3 +28,22 @@ def test_known_values():
 def test_sketch_cutoffs_match_scipy(s, k, ad, ac):
     got = [int(x) for x in capi.host_cigar_fn("sketch_cutoffs", f"{s},{k},{ad},{ac}").split(",")]
     assert got == S.sketch_cutoffs(s, k, ad, ac)
+
+
+def test_threshold_tables_match_the_committed_fixture():
+    """tests/golden/stats_golden.json.gz: the integer tables an independent scipy implementation gives
+    (tests/golden/make_stats_golden.py); the host C++ (own log-gamma distribution functions) must give the same."""
+    import gzip
+    import json
+    import os
+    g = json.load(gzip.open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "stats_golden.json.gz"), "rt"))
+    assert len(g["min_hits"]) > 300
+    for s, k, ident, mh, mhr in g["min_hits"]:
+        assert capi.host_cigar_fn("min_hits", f"{s},{k},{ident},0.95") == f"{mh},{mhr}", (s, k, ident)
+    for c in g["sketch_cutoffs"]:
+        got = [int(x) for x in capi.host_cigar_fn("sketch_cutoffs", f"{c['s']},{c['k']},{c['ani_diff']},{c['ani_diff_conf']}").split(",")]
+        assert got == c["cutoffs"], (c["s"], c["k"])
+    for c in g["l2_tables"]:
+        got = capi.host_cigar_fn("l2_tables", f"{c['s']},{c['k']},{c['identity']},{c['ci']}").split(",")
+        assert [int(x.split(":")[0]) for x in got] == c["keep"], (c["s"], c["identity"])
+        assert [int(x.split(":")[1]) for x in got] == c["ident"], (c["s"], c["identity"])

@@ -92,3 +92,98 @@ def map_sharded(map_fn, query_names, query_lengths, dist=None, device=None):
     if parts is None:
         return None
     return merge_query_blocks([bytes(p.cpu().numpy().tobytes()).decode() for p in parts], query_names)
+
+
+# ---- the same without holding a rank's output in memory: result files, sent in chunks ----
+
+CHUNK_BYTES = 64 << 20
+
+
+def gather_files(path, dist, work_dir, dst=0, device=None, chunk_bytes=CHUNK_BYTES):
+    """Every rank has its records in the file `path`; rank `dst` ends up with one file per rank (its own is `path`
+    itself) and returns their paths in rank order, other ranks return None.  One all_gather of the sizes, then each
+    file travels as point-to-point chunks of at most chunk_bytes (RCCL send/recv over xGMI with device tensors,
+    gloo on the host): memory stays at one chunk per rank whatever the size of the output."""
+    import os
+    world, rank = dist.get_world_size(), dist.get_rank()
+    dev = device if device is not None else torch.device("cpu")
+    size = torch.tensor([os.path.getsize(path)], dtype=torch.int64, device=dev)
+    sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(sizes, size)
+    sizes = [int(x.item()) for x in sizes]
+    if rank == dst:
+        paths = []
+        for r in range(world):
+            if r == dst:
+                paths.append(path)
+                continue
+            dest = os.path.join(work_dir, f"gathered.rank{r}")
+            with open(dest, "wb") as f:
+                left = sizes[r]
+                while left > 0:
+                    n = min(left, chunk_bytes)
+                    buf = torch.empty(n, dtype=torch.uint8, device=dev)
+                    dist.recv(buf, src=r)
+                    f.write(buf.cpu().numpy().tobytes())
+                    left -= n
+            paths.append(dest)
+        return paths
+    with open(path, "rb") as f:
+        left = sizes[rank]
+        while left > 0:
+            n = min(left, chunk_bytes)
+            buf = torch.frombuffer(bytearray(f.read(n)), dtype=torch.uint8).to(dev)
+            dist.send(buf, dst=dst)
+            left -= n
+    return None
+
+
+def merge_query_block_files(paths, query_order, out):
+    """merge_query_blocks on files: one pass over every file notes where the records of each query lie (a rank prints a
+    query's records consecutively, once per target subset), a second pass copies them to `out` (binary file object) in
+    query order, a query's pieces in (rank, position) order.  Only the table of pieces is held in memory."""
+    pieces = {}
+    for fi, p in enumerate(paths):
+        with open(p, "rb") as f:
+            pos = 0
+            cur, start = None, 0
+            for line in f:
+                q = line.split(b"\t", 1)[0]
+                if q != cur:
+                    if cur is not None:
+                        pieces.setdefault(cur, []).append((fi, start, pos - start))
+                    cur, start = q, pos
+                pos += len(line)
+            if cur is not None:
+                pieces.setdefault(cur, []).append((fi, start, pos - start))
+    handles = [open(p, "rb") for p in paths]
+    try:
+        for q in query_order:
+            for fi, off, n in pieces.get(q.encode() if isinstance(q, str) else q, []):
+                handles[fi].seek(off)
+                left = n
+                while left > 0:
+                    b = handles[fi].read(min(left, 16 << 20))
+                    out.write(b)
+                    left -= len(b)
+    finally:
+        for h in handles:
+            h.close()
+
+
+def map_sharded_files(map_fn, query_names, query_lengths, out_path, work_dir, dist=None, device=None):
+    """map_sharded for outputs that should not be held in memory: map_fn(names) -> path of a file with the records of
+    those queries (None when there are none); rank 0 writes out_path in single-GPU record order."""
+    import os
+    world = dist.get_world_size() if dist is not None else 1
+    rank = dist.get_rank() if dist is not None else 0
+    shards = shard_queries(query_lengths, world)
+    mine = [query_names[i] for i in shards[rank]]
+    path = map_fn(mine) if mine else None
+    if path is None:
+        path = os.path.join(work_dir, f"empty.rank{rank}")
+        open(path, "wb").close()
+    paths = [path] if dist is None else gather_files(path, dist, work_dir, dst=0, device=device)
+    if paths is not None:
+        with open(out_path, "wb") as out:
+            merge_query_block_files(paths, query_names, out)

@@ -4,7 +4,22 @@
 // wflign_alignment.cpp:665-678) and forwards every alignment to the C ABI of libwfmash_hip.so.
 // One problem per call: this seam keeps wflign.cpp unchanged; the batch seam
 // (wflign_hip.hpp) is the fast one.
+//
+// The reference's own wflign.cpp / wflign_patch.cpp / wflign_alignment.cpp / wflign_swizzle.cpp compile and link
+// against this header unmodified (oracle/Makefile target `ref`, oracle/ref_wflign.cpp); tests/test_ref_wflign_gpu.py
+// runs their do_biwfa_alignment on the GPU through it.  The members the dormant hierarchical WFlign class uses
+// (wflign.cpp:1097-1168, wflign_patch.cpp:354-362,441-478) are here too: WFAlignerGapAffine, setHeuristicWFmash,
+// setMaxAlignmentSteps, getAlignmentStatus, and the match-callback alignEnd2End, which has no device form and throws.
 #pragma once
+
+// wavefront_align.h status codes as the reference tests them (wflign.cpp:150,1168; wflign_patch.cpp:362,447)
+#ifndef WF_STATUS_ALG_COMPLETED
+#define WF_STATUS_ALG_COMPLETED 0
+#define WF_STATUS_ALG_PARTIAL 1
+#define WF_STATUS_MAX_STEPS_REACHED (-100)
+#define WF_STATUS_OOM (-200)
+#define WF_STATUS_UNATTAINABLE (-300)
+#endif
 
 #include <stdexcept>
 #include <string>
@@ -22,7 +37,14 @@ class WFAligner {
 
   virtual ~WFAligner() = default;
   void setHeuristicNone() {}  // the GPU path is always exact (wflign.cpp:145,289,377)
-  void setMaxAlignmentSteps(int) {}
+  // adaptive band of the dormant WFlambda aligner (wflign.cpp:1106-1110): the exact alignment is a valid answer
+  void setHeuristicWFmash(int /*min_wavefront_length*/, int /*max_distance_threshold*/) {}
+  // an alignment whose score passes `steps` ends with WF_STATUS_MAX_STEPS_REACHED (wflign_patch.cpp:354,441,474)
+  void setMaxAlignmentSteps(int steps) { max_steps_ = steps; }
+  // match-callback form of the dormant hierarchical WFlign (wflign.cpp:1163): the callback is host code per cell
+  int alignEnd2End(int (*)(int, int, void*), void*, int, int) {
+    throw std::logic_error("wfa::WFAligner: the match-callback alignEnd2End (dormant WFlign path) has no device form");
+  }
 
   int alignEnd2End(const char* pattern, int plen, const char* text, int tlen) {
     return run(pattern, plen, text, tlen, mem_ == MemoryUltralow ? WFM_MODE_END2END_BIWFA : WFM_MODE_END2END_UNI, 0, 0, 0, 0);
@@ -60,12 +82,21 @@ class WFAligner {
     res_ = wfm_result_t{};
     const int rc = wfm_align_batch(handle(), &pen_, &pr, 1, &res_, arena_.data(), arena_.size());
     if (rc < 0) res_.status = StatusOOM;
+    else if (res_.status == 0 && max_steps_ >= 0 && res_.score > max_steps_) res_.status = StatusMaxStepsReached;
     return res_.status;  // 0 == WF_STATUS_ALG_COMPLETED (wflign.cpp:150,307,399)
   }
   wfm_penalties_t pen_;
   MemoryModel mem_;
   wfm_result_t res_{};
   std::vector<char> arena_;
+  int max_steps_ = -1;
+};
+
+// gap-affine (one piece) = two identical pieces; only the dormant WFlign class builds it (wflign.cpp:1097-1125)
+class WFAlignerGapAffine : public WFAligner {
+ public:
+  WFAlignerGapAffine(int mismatch, int gapOpening, int gapExtension, AlignmentScope, MemoryModel memoryModel)
+      : WFAligner(mismatch, gapOpening, gapExtension, gapOpening, gapExtension, memoryModel) {}
 };
 
 class WFAlignerGapAffine2Pieces : public WFAligner {

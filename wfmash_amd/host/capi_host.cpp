@@ -118,6 +118,14 @@ char* wfmh_test_cigar(const char* fn, const char* a, const char* b, const char* 
     int sk = 0, k = 0; float ad = 0, ac = 0;
     if (sscanf(sa.c_str(), "%d,%d,%f,%f", &sk, &k, &ad, &ac) == 4)
       for (int v : skch::Stat::sketch_cutoffs(sk, k, ad, ac)) { if (!r.empty()) r += ","; r += std::to_string(v); }
+  } else if (f == "l2_tables") {   // a = "S,k,identity,ci": keep bits and nucIdentity x 1e4 for every (Q.sketchSize, shared)
+    int S = 0, k = 0; float id = 0, ci = 0;
+    if (sscanf(sa.c_str(), "%d,%d,%f,%f", &S, &k, &id, &ci) == 4) {
+      std::vector<uint8_t> keep;
+      std::vector<uint16_t> ident;
+      skch::Stat::l2_identity_tables(S, k, id, true, ci, keep, ident);
+      for (size_t i = 0; i < keep.size(); ++i) { if (i) r += ","; r += std::to_string((int)keep[i]) + ":" + std::to_string((int)ident[i]); }
+    }
   } else if (f == "md") {
     r = wflign::md_string(sa, (int)i0, t.c_str());
   } else if (f == "parse_row") {
