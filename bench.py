@@ -40,6 +40,7 @@ def main():
     ap.add_argument("--pairs", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0, help="pairs in the cpu_baseline sample (0 = auto)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary figures (C5, scaled C4 rank, C2)")
     ap.add_argument("--rank-check", action="store_true",
                     help="launch / join the ranks, print one line per rank and stop (no GPU needed: gloo)")
     args = ap.parse_args()
@@ -129,31 +130,12 @@ def main():
         gather_payload(seqset)
     sync()
     t0 = time.perf_counter()
-    cells_bp = 0
-    cells_tile = 0
-    ms_tile = 0.0
-    ms_tile_busy = 0.0
-    streams = 1
-    tile_launches = 0
-    ms_bp = 0.0
-    ms_base = 0.0
-    cells_total = 0
-    bp_launches = 0
+    acc = _StatAcc()
     for _ in range(args.steps):
         failed = h.align_resident(seqset, collect=False)
         if failed:
             raise SystemExit(f"{failed} alignments failed")
-        st = h.stats()
-        cells_bp += st.cells_bp
-        cells_tile += st.cells_tile
-        ms_tile += st.ms_tile
-        ms_tile_busy += st.ms_tile_busy
-        streams = max(streams, st.streams)
-        tile_launches += st.tile_launches
-        cells_total += st.cells
-        ms_bp += st.ms_breakpoint
-        ms_base += st.ms_base
-        bp_launches += st.bp_launches
+        acc.add(h.stats())
         gather_payload(seqset)
     sync()
     dt = time.perf_counter() - t0
@@ -165,28 +147,18 @@ def main():
     out = None
     if rank == 0:
         value = query_bases * world * args.steps / dt
-        # roofline of the dominant kernel: algorithmic bytes =
-        # 48 B per computed (score,diagonal) cell (7 loads + 5 stores of int32
-        # offsets) + the sequences read once per launch
         seq_bytes = sum(len(p) + len(q) for p, q in mine) * 2  # forward + reversed copies
-        # dominant kernel: the time-tiled phase-1 kernel when it ran (default), else the step kernel
-        if ms_tile > 0.5 * ms_bp:
-            # With the batch split over two streams, launches of the kernel overlap in time: the kernel's bandwidth
-            # is the bytes all its launches handle / the time during which it was running at all (the union of the
-            # launch intervals, HIP events against one time origin), not / the sum of the stretched durations.
-            dom, dom_cells, dom_ms, dom_launches = "wfa_tile_reg_kernel", cells_tile, (ms_tile_busy if streams > 1 else ms_tile), tile_launches
-        else:
-            dom, dom_cells, dom_ms, dom_launches = "wfa_bp_kernel", cells_bp - cells_tile, ms_bp - ms_tile, bp_launches
-        alg_bytes = 48.0 * dom_cells + seq_bytes * args.steps
-        achieved = alg_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-        peak = 8000.0
-        traffic = None  # HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/)
+        # one more, untimed, pass with the parts of the batch one after the other on one stream (WFM_OVERLAP=0): every
+        # launch then has the GPU to itself, which is what rocprofv3's per-launch durations of that mode show
+        excl = _StatAcc()
+        os.environ["WFM_OVERLAP"] = "0"
         try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r1g_traffic.json")))
-            if tj.get("kernel") == dom and args.config == "C3" and args.pairs == 64:
-                traffic = tj["traffic_bytes_per_launch"]
-        except (OSError, ValueError, KeyError):
-            pass
+            for _ in range(2):
+                h.align_resident(seqset, collect=False)
+                excl.add(h.stats())
+        finally:
+            del os.environ["WFM_OVERLAP"]
+        roof = _roofline(acc, excl, seq_bytes, args)
         out = {
             "metric": "aligned bases/sec (whole node) + CIGAR-identical rate vs CPU ref",
             "value": value, "unit": "aligned bases/s", "n_gpus": world, "steps": args.steps,
@@ -198,23 +170,17 @@ def main():
                                    f"{'50' if args.config == 'C3' else '100'}kb segment pairs per GPU, WFA-only "
                                    "(BiWFA gap-affine-2p 5,8,2,24,1; mappings pre-supplied)",
                        "pairs_per_gpu": args.pairs, "parallelism": f"records sharded over {world} GPU(s)"},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": peak,
-                         "unit": "GB/s", "frac": achieved / peak, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": alg_bytes / max(dom_launches, 1),
-                         "cells_per_launch": dom_cells / max(dom_launches, 1),
-                         "avg_launch_ms": (ms_tile if dom == "wfa_tile_reg_kernel" else dom_ms) / max(dom_launches, 1),
-                         "launches": dom_launches,
-                         "streams": streams,
-                         "kernel_busy_ms_per_step": dom_ms / args.steps,
-                         "note": "achieved = 48 B x computed (score,diagonal) cells / time the kernel was running (SURVEY 8d). "
-                                 "The batch runs as up to three parts on as many streams, so launches of this kernel overlap each other: "
-                                 "avg_launch_ms (what rocprofv3 shows per launch) is stretched by the sharing, the running "
-                                 "time is the union of the launch intervals from HIP events; WFM_OVERLAP=0 gives the "
-                                 "exclusive figure (0.93, profiles/r1d_align.md); profiles/r1g_align.md is this configuration. The tiled kernel keeps wavefront history "
-                                 "in registers, so real HBM traffic (traffic, per launch) is far below the algorithmic bytes"},
-            "kernel_ms_per_step": {"wfa_tile_reg_kernel": ms_tile / args.steps, "wfa_bp_kernel": (ms_bp - ms_tile) / args.steps,
-                                   "wfa_base_kernel": ms_base / args.steps},
-            "cells_per_step": cells_total / args.steps,
+            "roofline": roof,
+            # time during which at least one launch of the kernel was running (union of the launch intervals over all
+            # streams, HIP events against one origin), and the sum of the individual launch durations
+            "kernel_busy_ms_per_step": {"wfa_tile_reg_kernel": acc.ms_tile_busy / args.steps, "wfa_bp_kernel": acc.ms_bp_busy / args.steps,
+                                        "wfa_base_kernel": acc.ms_base_busy / args.steps, "any": acc.ms_any_busy / args.steps},
+            "kernel_ms_per_step": {"wfa_tile_reg_kernel": acc.ms_tile / args.steps, "wfa_bp_kernel": (acc.ms_bp - acc.ms_tile) / args.steps,
+                                   "wfa_base_kernel": acc.ms_base / args.steps},
+            "cells_per_step": acc.cells / args.steps,
+            "whole_step": {"algorithmic_GBps": (48.0 * acc.cells_unique + seq_bytes * args.steps) / dt / 1e9,
+                           "frac": (48.0 * acc.cells_unique + seq_bytes * args.steps) / dt / 1e9 / 8000.0,
+                           "note": "48 B x unique cells of all kernels / wall time of the step"},
             "device": h.device_name(),
         }
         # ---- CPU baseline (oracle = "port") on a bounded sample of the same workload ----
@@ -227,6 +193,7 @@ def main():
             t1 = time.perf_counter()
             ops, scores, cst, failed = O.align_batch_biwfa([p for p, _ in sample], [q for _, q in sample], nthreads=threads)
             cdt = time.perf_counter() - t1
+            h.align_resident(seqset, collect=False)
             res = h._collect(seqset)
             ident = sum(1 for i in range(n_s) if res[i].ops == ops[i])
             score_ident = sum(1 for i in range(n_s) if res[i].score == int(scores[i]))
@@ -237,12 +204,185 @@ def main():
                                    "host_cpu": _cpu_model()}
             out["cigar_identical_rate"] = ident / n_s
             out["score_identical_rate"] = score_ident / n_s
+            out["cpu_baseline_map"] = _cpu_baseline_map(h)
+        if not args.no_secondary and world == 1:
+            out["secondary"] = _secondary(h, capi, synth)
         print(json.dumps(out), flush=True)
     seqset.free()
     h.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+class _StatAcc:
+    """wfm_stats_t summed over passes"""
+    FIELDS = ("cells", "cells_bp", "cells_tile", "cells_tile_unique", "ms_tile", "ms_tile_busy", "ms_bp_busy", "ms_base_busy", "ms_any_busy",
+              "tile_launches", "bp_launches", "base_launches", "ms_base")
+
+    def __init__(self):
+        for f in self.FIELDS:
+            setattr(self, f, 0)
+        self.ms_bp = 0.0
+        self.streams = 1
+        self.passes = 0
+
+    def add(self, st):
+        for f in self.FIELDS:
+            setattr(self, f, getattr(self, f) + getattr(st, f))
+        self.ms_bp += st.ms_breakpoint
+        self.streams = max(self.streams, st.streams)
+        self.passes += 1
+
+    @property
+    def cells_unique(self):  # all kernels, the tile kernel's re-run block counted once
+        return self.cells - (self.cells_tile - self.cells_tile_unique)
+
+
+def _roofline(acc, excl, seq_bytes, args):
+    """Dominant kernel = the time-tiled phase-1 kernel (wfa_tile_reg_kernel) when it ran, else the step kernel.
+    achieved = ALGORITHMIC bytes / the kernel's running time: 48 B per (score, diagonal) cell the result needs (7 loads +
+    5 stores of int32 offsets; the block a job runs twice is counted once) + the sequences once per pass."""
+    peak = 8000.0
+    tiled = acc.ms_tile > 0.5 * acc.ms_bp
+    if tiled:
+        dom, cells, cells_all, busy, launches, ms_sum = "wfa_tile_reg_kernel", acc.cells_tile_unique, acc.cells_tile, acc.ms_tile_busy, acc.tile_launches, acc.ms_tile
+        e_cells, e_ms, e_launches = excl.cells_tile_unique, excl.ms_tile, excl.tile_launches
+    else:
+        dom, cells, cells_all, busy, launches, ms_sum = "wfa_bp_kernel", acc.cells_bp - acc.cells_tile, acc.cells_bp - acc.cells_tile, acc.ms_bp_busy, acc.bp_launches, acc.ms_bp - acc.ms_tile
+        e_cells, e_ms, e_launches = excl.cells_bp - excl.cells_tile, excl.ms_bp - excl.ms_tile, excl.bp_launches
+    alg = 48.0 * cells + seq_bytes * acc.passes
+    achieved = alg / (busy * 1e-3) / 1e9 if busy > 0 else 0.0
+    e_alg = 48.0 * e_cells + seq_bytes * excl.passes
+    e_achieved = e_alg / (e_ms * 1e-3) / 1e9 if e_ms > 0 else 0.0
+    traffic = hbm_frac = None  # HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/)
+    src = None
+    for name in ("r2_traffic.json", "r1g_traffic.json"):
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", name)))
+        except (OSError, ValueError):
+            continue
+        if tj.get("kernel") == dom and args.config == "C3" and args.pairs == 64:
+            traffic = tj["traffic_bytes_per_launch"]
+            if tj.get("avg_launch_ms"):
+                hbm_frac = traffic / (tj["avg_launch_ms"] * 1e-3) / 1e9 / peak
+            src = "profiles/" + name
+            break
+    return {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": peak, "unit": "GB/s", "frac": achieved / peak,
+            "traffic": traffic, "hbm_frac": hbm_frac, "traffic_source": src,
+            "frac_exclusive": e_achieved / peak, "achieved_exclusive": e_achieved,
+            "avg_launch_ms_exclusive": e_ms / max(e_launches, 1), "launches_exclusive_per_step": e_launches / max(excl.passes, 1),
+            "algorithmic_bytes_per_launch_exclusive": e_alg / max(e_launches, 1),
+            "algorithmic_bytes_per_launch": alg / max(launches, 1), "cells_per_launch": cells / max(launches, 1),
+            "cells_computed_per_launch": cells_all / max(launches, 1),
+            "avg_launch_ms": ms_sum / max(launches, 1), "launches": launches, "streams": acc.streams,
+            "kernel_busy_ms_per_step": busy / max(acc.passes, 1),
+            "note": "achieved = 48 B x (score,diagonal) cells of the result / time the kernel was running (SURVEY 8d); the block in "
+                    "which a job's wavefronts meet is computed twice (cells_computed_per_launch) and counted once (cells_per_launch). "
+                    "The batch runs as up to three parts on as many streams, so launches of this kernel overlap each other: avg_launch_ms "
+                    "(what rocprofv3 shows per launch in this mode) is stretched by the sharing and the running time is the union of the "
+                    "launch intervals (HIP events of all streams against one origin). frac_exclusive comes from untimed passes with "
+                    "WFM_OVERLAP=0 (one stream, launches one after the other): algorithmic_bytes_per_launch_exclusive / "
+                    "avg_launch_ms_exclusive, the figure a rocprofv3 --kernel-trace of `WFM_OVERLAP=0 python bench.py` reproduces "
+                    "(profiles/). The tiled kernel keeps the wavefront history in registers, so real HBM traffic (traffic, per launch; "
+                    "hbm_frac = traffic / launch duration / 8 TB/s) is far below the algorithmic bytes: the 48 B/cell figure is the "
+                    "contract's yardstick, not this kernel's physical bound, which is the latency of a score step"}
+
+
+def _cpu_baseline_map(h):
+    """Map-phase CPU baseline (SURVEY 8d): the REFERENCE'S OWN CommonFunc::addMinmers (oracle/_ref/libref_map.so, compiled from
+    /root/reference in the build container) on the host cores, one sequence per thread as Sketch::build runs it
+    (winSketch.hpp:175-260), against the product's index build of the same sequences on the GPU."""
+    import threading
+    try:
+        from oracle import pymap
+        if not pymap.have_ref():
+            return {"value": None, "kind": "reference", "note": "oracle/_ref/libref_map.so is not built in this checkout"}
+        import numpy as np
+        from wfmash_amd import synth
+        cores = os.cpu_count() or 1
+        n_seq, L = min(cores, 64), 2_000_000
+        base = synth.random_backbone(0xB45E, L)
+        seqs = [synth.haplotype(base, 0xB45E00 + i, n_sv=2).tobytes() for i in range(n_seq)]
+        k, w, s_sz = 15, 1000, 39
+        t1 = time.perf_counter()
+        ths = [threading.Thread(target=pymap.ref_add_minmers, args=(sq, k, w, s_sz, i)) for i, sq in enumerate(seqs)]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+        cdt = time.perf_counter() - t1
+        t1 = time.perf_counter()
+        h.add_minmers_multi(seqs, k, w, s_sz, threads=cores)
+        gdt = time.perf_counter() - t1
+        bp = sum(len(x) for x in seqs)
+        return {"value": bp / cdt, "unit": "indexed bases/s", "cores": n_seq, "kind": "reference",
+                "sample": f"{n_seq} synthetic haplotypes x {L // 1000000} Mbp, k={k} w={w} s={s_sz}: CommonFunc::addMinmers "
+                          f"(commonFunc.hpp:440-708) one sequence per thread, {cdt:.1f} s",
+                "gpu_value": bp / gdt, "gpu_note": f"wfm_add_minmers_multi of the same sequences (GPU hashing + thinning, host winnowing on {cores} threads), {gdt:.2f} s"}
+    except Exception as e:  # the baseline is a report, never a reason to lose the bench line
+        return {"value": None, "kind": "reference", "note": f"failed: {e}"}
+
+
+def _secondary(h, capi, synth):
+    """Driver-timed figures of the other configs (the bench line's `value` stays C3): C5 align-only, a scaled C4 rank and C2
+    (LPA.subset all-vs-all) end to end through the C ABI."""
+    import tempfile
+    sec = {}
+    try:
+        pairs = synth.pairs("C5", n_pairs=8)
+        ss = h.upload(pairs)
+        h.align_resident(ss, collect=False)
+        acc = _StatAcc()
+        t1 = time.perf_counter()
+        for _ in range(2):
+            failed = h.align_resident(ss, collect=False)
+            acc.add(h.stats())
+        d = (time.perf_counter() - t1) / 2
+        res = h._collect(ss)
+        sec["C5"] = {"workload": "8 synthetic 15%-divergence 100kb pairs, WFA-only", "ms_per_pass": d * 1e3,
+                     "aligned_bp_per_s": sum(len(q) for _, q in pairs) / d, "failed": int(failed), "score_mean": sum(r.score for r in res) / len(res),
+                     "cells_per_pass": acc.cells_unique / 2, "algorithmic_frac_wall": 48.0 * acc.cells_unique / 2 / d / 8e12,
+                     "kernel_busy_ms": {"tile": acc.ms_tile_busy / 2, "bp": acc.ms_bp_busy / 2, "base": acc.ms_base_busy / 2}}
+        ss.free()
+    except Exception as e:
+        sec["C5"] = {"error": str(e)}
+    with tempfile.TemporaryDirectory() as td:
+        try:  # scaled C4 rank: 8 haplotypes x 8 Mbp, one haplotype (1/8 of the queries) against the index of all eight
+            fa = os.path.join(td, "c4.fa")
+            names, lengths = synth.write_fasta(fa, synth.pangenome(8, 8_000_000, n_sv=6))
+            ql = os.path.join(td, "q.txt")
+            open(ql, "w").write(names[0] + "\n")
+            threads = os.cpu_count() or 1
+            m, a = os.path.join(td, "m.paf"), os.path.join(td, "a.paf")
+            t1 = time.perf_counter()
+            ms = capi.map_paf(h, fa, m, params=capi.map_default_params(threads=threads, query_list=ql))
+            t_map = time.perf_counter() - t1
+            t1 = time.perf_counter()
+            al = capi.align_paf(h, fa, m, a, params={"threads": threads})
+            t_al = time.perf_counter() - t1
+            sec["C4_rank_scaled"] = {"workload": "8 synthetic haplotypes x 8 Mbp, -Y '#', defaults (ani50-2): rank 0 of 8 (one haplotype against all)",
+                                     "map_s": t_map, "ms_index": ms.ms_index, "ms_map": ms.ms_map, "ms_filter": ms.ms_filter, "records": int(al.records),
+                                     "align_s": t_al, "aligned_bp": int(al.aligned_bp), "aligned_bp_per_s": al.aligned_bp / t_al,
+                                     "cells": int(al.cells), "ms_gpu": al.ms_gpu, "algorithmic_frac_gpu": 48.0 * al.cells / (al.ms_gpu * 1e-3) / 8e12 if al.ms_gpu else None}
+        except Exception as e:
+            sec["C4_rank_scaled"] = {"error": str(e)}
+        try:  # C2: the reference's LPA test data (a committed fixture), all-vs-all -p 90 -P 50k
+            lpa = os.path.join(ROOT, "tests", "golden", "LPA.subset.fa.gz")
+            threads = os.cpu_count() or 1
+            m, a = os.path.join(td, "lpa.m.paf"), os.path.join(td, "lpa.a.paf")
+            t1 = time.perf_counter()
+            ms = capi.map_paf(h, lpa, m, params=capi.map_default_params(percentage_identity=0.9, auto_pct_identity=0, max_mapping_length=50000, threads=threads))
+            t_map = time.perf_counter() - t1
+            t1 = time.perf_counter()
+            al = capi.align_paf(h, lpa, m, a, params={"threads": threads})
+            t_al = time.perf_counter() - t1
+            sec["C2"] = {"workload": "LPA.subset.fa.gz all-vs-all, -p 90 -P 50k, map + align", "map_s": t_map, "align_s": t_al, "records": int(al.records),
+                         "aligned_bp": int(al.aligned_bp), "aligned_bp_per_s_align": al.aligned_bp / t_al, "aligned_bp_per_s_end_to_end": al.aligned_bp / (t_map + t_al),
+                         "cells": int(al.cells), "ms_gpu": al.ms_gpu}
+        except Exception as e:
+            sec["C2"] = {"error": str(e)}
+    return sec
 
 
 def _cpu_model():

@@ -107,8 +107,13 @@ typedef struct {
   uint32_t tile_launches, tile_tasks;
   double   ms_tile_busy;     /* time during which at least one tile kernel launch was running: equals ms_tile unless
                               * the two halves of a batch ran their tile kernels side by side on two streams */
-  uint32_t streams;          /* 1, or 2 when the batch was split into two concurrently processed halves */
+  uint32_t streams;          /* parts of the batch that ran side by side, each on its own stream */
   uint32_t pad_;
+  uint64_t cells_tile_unique;/* cells_tile without the block a job computes twice: the full block in which its wavefronts
+                              * meet is thrown away and run again up to the meeting point only */
+  double   ms_bp_busy;       /* as ms_tile_busy, for the wfa_bp_kernel launches (ms_breakpoint - ms_tile summed over streams) */
+  double   ms_base_busy;     /* as ms_tile_busy, for the wfa_base_kernel launches */
+  double   ms_any_busy;      /* time during which any of the three kernels was running */
 } wfm_stats_t;
 
 int  wfm_device_count(void);   /* usable HIP devices of this node (0 without a GPU) */

@@ -58,7 +58,9 @@ class Stats(C.Structure):
                 ("cells_bp", C.c_uint64), ("cells_base", C.c_uint64),
                 ("cells_tile", C.c_uint64), ("ms_tile", C.c_double),
                 ("tile_launches", C.c_uint32), ("tile_tasks", C.c_uint32),
-                ("ms_tile_busy", C.c_double), ("streams", C.c_uint32), ("pad_", C.c_uint32)]
+                ("ms_tile_busy", C.c_double), ("streams", C.c_uint32), ("pad_", C.c_uint32),
+                ("cells_tile_unique", C.c_uint64), ("ms_bp_busy", C.c_double), ("ms_base_busy", C.c_double),
+                ("ms_any_busy", C.c_double)]
 
 
 class Minmer(C.Structure):

@@ -96,6 +96,7 @@ struct wfm_handle {
   hipEvent_t ev_base = nullptr;     // time origin of the call (shared by the two halves)
   hipEvent_t call_base = nullptr;   // the origin this call measures against
   std::vector<std::pair<float, float>> tile_iv;  // (start, end) of every tile kernel launch of the call, ms after call_base
+  std::vector<std::pair<float, float>> bp_iv, base_iv;  // the same for the step kernel and the base kernel
   std::string err;
   std::string name;
   size_t mem_budget = 0;       // arena budget in force for the call at hand
@@ -214,6 +215,11 @@ int run_base_jobs(wfm_handle* h, wfm_seqset* S, const wfm_penalties_t& pen, cons
       float ms = 0;
       HIPCHK(h, hipEventElapsedTime(&ms, h->ev2, h->ev3));
       tm.base_ms += ms;
+      if (h->call_base) {
+        float t0 = 0;
+        HIPCHK(h, hipEventElapsedTime(&t0, h->call_base, h->ev2));
+        h->base_iv.emplace_back(t0, t0 + ms);
+      }
       h->stats.base_launches++;
       h->stats.base_jobs += (uint32_t)jobs.size();
       for (size_t q = 0; q < jobs.size(); ++q) {
@@ -410,6 +416,17 @@ int run_tiled_phase(wfm_handle* h, wfm_seqset* S, const DevPen& dp, int scope, c
       }
     }
   }
+  // cells that went into the result: both directions up to where the tile phase leaves the job (the full block in which
+  // the wavefronts met was computed as well, and then again up to the meeting point: tile_cells counts it, this does not)
+  auto upto = [](int64_t pl, int64_t tl, int64_t sc) {  // sum over t = 1..sc of the row width min(tl,t) + min(pl,t) + 1
+    auto f = [](int64_t L, int64_t q) { return q <= L ? q * (q + 1) / 2 : L * (L + 1) / 2 + (q - L) * L; };
+    return (uint64_t)(f(tl, sc) + f(pl, sc) + sc);
+  };
+  for (size_t i = 0; i < n; ++i) {
+    const int sf_end = tj[i].mode == 2 ? tj[i].s0 + tj[i].tf : tj[i].s0, sr_end = tj[i].mode == 2 ? tj[i].s0 + tj[i].tr : tj[i].s0;
+    h->stats.cells_tile_unique += upto(tj[i].pl, tj[i].tl, sf_end) - upto(tj[i].pl, tj[i].tl, s_begin[i]) +
+                                  upto(tj[i].pl, tj[i].tl, sr_end) - upto(tj[i].pl, tj[i].tl, s_begin[i]);
+  }
   for (size_t i = 0; i < n; ++i) {
     BpJob& j = jobs[(size_t)tiled[i]];
     j.ring_off = tj[i].ring_in;
@@ -589,6 +606,11 @@ int align_resident_impl(wfm_handle* h, const wfm_penalties_t* pen, wfm_seqset* S
         float ms = 0;
         HIPCHK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
         tm.bp_ms += ms;
+        if (h->call_base) {
+          float t0 = 0;
+          HIPCHK(h, hipEventElapsedTime(&t0, h->call_base, h->ev0));
+          h->bp_iv.emplace_back(t0, t0 + ms);
+        }
         h->stats.bp_launches++;
         h->stats.bp_jobs += (uint32_t)jobs.size();
 #ifdef WFM_PROFILE_SECTIONS
@@ -868,11 +890,11 @@ int wfm_align_resident(wfm_handle_t* h, const wfm_penalties_t* pen, wfm_seqset_t
                        char* ops_arena, size_t arena_bytes) {
   if (!h || !s || !out || (!ops_arena && arena_bytes)) return WFM_E_ARG;
   const size_t n = s->meta.size();
-  static const bool overlap = !(getenv("WFM_OVERLAP") && atoi(getenv("WFM_OVERLAP")) == 0);
+  const bool overlap = !(getenv("WFM_OVERLAP") && atoi(getenv("WFM_OVERLAP")) == 0);  // read per call: bench.py times both forms
   if (hipSetDevice(h->device) != hipSuccess || hipEventRecord(h->ev_base, h->stream) != hipSuccess ||
       hipEventSynchronize(h->ev_base) != hipSuccess) { h->err = "hipEventRecord failed"; return WFM_E_HIP; }
   h->call_base = h->ev_base;
-  h->tile_iv.clear();
+  h->tile_iv.clear(); h->bp_iv.clear(); h->base_iv.clear();
   auto busy_ms = [](std::vector<std::pair<float, float>> iv) {  // length of the union of the intervals
     std::sort(iv.begin(), iv.end());
     double total = 0, lo = 0, hi = -1;
@@ -884,12 +906,18 @@ int wfm_align_resident(wfm_handle_t* h, const wfm_penalties_t* pen, wfm_seqset_t
     return total;
   };
   h->mem_budget = h->mem_budget_full;
-  if (!overlap || n < 8) {
-    const int rc = align_resident_impl(h, pen, s, 0, n, out, ops_arena, arena_bytes, 0);
+  auto finish_single = [&](int rc) {
     h->stats.ms_tile_busy = busy_ms(h->tile_iv);
+    h->stats.ms_bp_busy = busy_ms(h->bp_iv);
+    h->stats.ms_base_busy = busy_ms(h->base_iv);
+    std::vector<std::pair<float, float>> all = h->tile_iv;
+    all.insert(all.end(), h->bp_iv.begin(), h->bp_iv.end());
+    all.insert(all.end(), h->base_iv.begin(), h->base_iv.end());
+    h->stats.ms_any_busy = busy_ms(all);
     h->stats.streams = 1;
     return rc;
-  }
+  };
+  if (!overlap || n < 8) return finish_single(align_resident_impl(h, pen, s, 0, n, out, ops_arena, arena_bytes, 0));
   // Parts of the batch side by side, each with its own stream and arenas (peer handles on the same device)
   // and its own host thread: while one part sits in the few-workgroup levels of the step kernel or waits for
   // the host, the other parts' tiles fill the machine.  Problems are independent, the parts only share the
@@ -906,12 +934,7 @@ int wfm_align_resident(wfm_handle_t* h, const wfm_penalties_t* pen, wfm_seqset_t
       ring_bytes += ((size_t)s->meta[i].plen + (size_t)s->meta[i].tlen + 9) * 2 * 5 * RING * 2 * 4;
     if (ring_bytes > h->mem_budget_full) parts = 2;
   }
-  if (parts < 2) {
-    const int rc = align_resident_impl(h, pen, s, 0, n, out, ops_arena, arena_bytes, 0);
-    h->stats.ms_tile_busy = busy_ms(h->tile_iv);
-    h->stats.streams = 1;
-    return rc;
-  }
+  if (parts < 2) return finish_single(align_resident_impl(h, pen, s, 0, n, out, ops_arena, arena_bytes, 0));
   while (h->peers.size() + 1 < parts) {
     wfm_handle_t* p = nullptr;
     if (wfm_create(h->device, &p) != WFM_OK) break;
@@ -943,7 +966,7 @@ int wfm_align_resident(wfm_handle_t* h, const wfm_penalties_t* pen, wfm_seqset_t
   for (size_t k = 1; k < np; ++k) {
     wfm_handle* pk = h->peers[k - 1];
     pk->call_base = h->ev_base;
-    pk->tile_iv.clear();
+    pk->tile_iv.clear(); pk->bp_iv.clear(); pk->base_iv.clear();
     th.emplace_back([&, k, pk] { rcs[k] = align_resident_impl(pk, pen, s, cut[k], cut[k + 1], out, ops_arena, arena_bytes, base[k]); });
   }
   rcs[0] = align_resident_impl(h, pen, s, cut[0], cut[1], out, ops_arena, arena_bytes, 0);
@@ -954,17 +977,25 @@ int wfm_align_resident(wfm_handle_t* h, const wfm_penalties_t* pen, wfm_seqset_t
     failed += rcs[k];
   }
   wfm_stats_t& a = h->stats;
-  std::vector<std::pair<float, float>> iv = h->tile_iv;
+  std::vector<std::pair<float, float>> iv = h->tile_iv, ivb = h->bp_iv, ivs = h->base_iv;
   for (size_t k = 1; k < np; ++k) {
     const wfm_stats_t& b = h->peers[k - 1]->stats;
     a.cells += b.cells; a.bytes_algorithmic += b.bytes_algorithmic; a.ms_kernels += b.ms_kernels; a.ms_breakpoint += b.ms_breakpoint;
     a.ms_base += b.ms_base; a.levels = std::max(a.levels, b.levels); a.bp_jobs += b.bp_jobs; a.base_jobs += b.base_jobs;
     a.bp_launches += b.bp_launches; a.base_launches += b.base_launches; a.cells_bp += b.cells_bp; a.cells_base += b.cells_base;
     a.cells_tile += b.cells_tile; a.ms_tile += b.ms_tile; a.tile_launches += b.tile_launches; a.tile_tasks += b.tile_tasks;
+    a.cells_tile_unique += b.cells_tile_unique;
     iv.insert(iv.end(), h->peers[k - 1]->tile_iv.begin(), h->peers[k - 1]->tile_iv.end());
+    ivb.insert(ivb.end(), h->peers[k - 1]->bp_iv.begin(), h->peers[k - 1]->bp_iv.end());
+    ivs.insert(ivs.end(), h->peers[k - 1]->base_iv.begin(), h->peers[k - 1]->base_iv.end());
   }
   a.ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   a.ms_tile_busy = busy_ms(iv);
+  a.ms_bp_busy = busy_ms(ivb);
+  a.ms_base_busy = busy_ms(ivs);
+  iv.insert(iv.end(), ivb.begin(), ivb.end());
+  iv.insert(iv.end(), ivs.begin(), ivs.end());
+  a.ms_any_busy = busy_ms(iv);
   a.streams = (uint32_t)np;
   return failed;
 }

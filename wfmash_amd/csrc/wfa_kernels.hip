@@ -70,6 +70,71 @@ __device__ __forceinline__ int lce_bounded(const uint8_t* P, const uint8_t* T, i
   return min(lce_from(P + v, T + h, 0, maxn), maxn);
 }
 
+// ---- wave-cooperative long extensions (global-memory form; the tile kernel's LDS-window form follows further down) ----
+// A run of matches is usually over within a few bases (a cell off the optimal path) -- or it is hundreds to thousands of
+// bases long (the optimal path of a low-divergence record), and then one lane walks it 32 bases per round while the
+// other 63 lanes of its wave, and behind the step's barrier the whole workgroup, wait.  So a lane only looks at the
+// first 40 bases itself; runs that go on are finished by the whole wave, one pending lane after the other, 64 lanes x
+// 8 bases = 512 bases per round trip.  Every lane of the wave must make the call (pend = false when it has nothing).
+__device__ __forceinline__ int rdlane(int v, int src) { return __builtin_amdgcn_readlane(v, src); }
+
+__device__ __forceinline__ int wave_lce_tail_g(const uint8_t* P, const uint8_t* T, int v, int h, int n, int maxn, bool pend) {
+  unsigned long long todo = __ballot(pend);
+  const int lane = (int)(threadIdx.x & 63u);
+  while (todo) {
+    const int src = __builtin_amdgcn_readfirstlane((int)__builtin_ctzll(todo));
+    todo &= todo - 1;
+    const int v0 = rdlane(v, src), h0 = rdlane(h, src), mx = rdlane(maxn, src);
+    int nn = rdlane(n, src);  // bases known to match so far (uniform)
+    int res;
+    for (;;) {
+      const int off = nn + lane * 8;
+      const bool past = off >= mx;
+      uint64_t x = 0;
+      if (!past) x = load8(P + v0 + off) ^ load8(T + h0 + off);
+      const unsigned long long hit = __ballot(past || x != 0);
+      if (hit) {
+        const int f = __builtin_amdgcn_readfirstlane((int)__builtin_ctzll(hit));
+        const unsigned xlo = (unsigned)rdlane((int)(uint32_t)x, f), xhi = (unsigned)rdlane((int)(uint32_t)(x >> 32), f);
+        const uint64_t xf = ((uint64_t)xhi << 32) | xlo;
+        const int at = nn + f * 8;
+        res = at >= mx ? mx : min(mx, at + (xf ? (int)(__builtin_ctzll(xf) >> 3) : 0));
+        break;
+      }
+      nn += 512;
+    }
+    if (lane == src) n = res;
+  }
+  return n;
+}
+
+// what a lane does on its own: 8 bases (x8 = their xor, already loaded), then one round of 32; more = the run goes on
+__device__ __forceinline__ int lce_head40_g(const uint8_t* P, const uint8_t* T, int v, int h, uint64_t x8, int maxn, bool& more) {
+  more = false;
+  if (x8) return min((int)(__builtin_ctzll(x8) >> 3), maxn);
+  if (maxn <= 8) return maxn;
+  if (maxn < 40) return min(lce_from(P + v, T + h, 8, maxn), maxn);  // the end of the sequences is near
+  const uint8_t* pp = P + (v + 8);
+  const uint8_t* tt = T + (h + 8);
+  const uint64_t x0 = load8(pp) ^ load8(tt), x1 = load8(pp + 8) ^ load8(tt + 8);
+  const uint64_t x2 = load8(pp + 16) ^ load8(tt + 16), x3 = load8(pp + 24) ^ load8(tt + 24);
+  if (x0) return 8 + (int)(__builtin_ctzll(x0) >> 3);
+  if (x1) return 16 + (int)(__builtin_ctzll(x1) >> 3);
+  if (x2) return 24 + (int)(__builtin_ctzll(x2) >> 3);
+  if (x3) return 32 + (int)(__builtin_ctzll(x3) >> 3);
+  more = maxn > 40;
+  return 40;
+}
+
+// extension of one cell per lane from (v, h), at most maxn bases; every lane of the wave calls it (live = false: no cell)
+__device__ __forceinline__ int wave_lce(const uint8_t* P, const uint8_t* T, int v, int h, int maxn, bool live) {
+  bool more = false;
+  int n = 0;
+  if (live && maxn > 0) n = lce_head40_g(P, T, v, h, load8(P + v) ^ load8(T + h), maxn, more);
+  if (__any(more)) n = wave_lce_tail_g(P, T, v, h, n, maxn, more);
+  return n;
+}
+
 struct Src {
   const int32_t* p;  // p[k] addresses diagonal k
   int lo, hi;
@@ -186,68 +251,47 @@ __device__ __forceinline__ v4i ld4(const VSrc& r, int kb) {
 }
 
 // 4 consecutive diagonals k0..k0+3 (one 16-byte column chunk) per thread.
-template <bool MASK, bool TRACK>
-__device__ __forceinline__ void bp_cells4(const BpCtx& c, const uint8_t* P, const uint8_t* T, int k0, int lo, int hi,
-                                          const VSrc& mx, const VSrc& mo1, const VSrc& mo2, const VSrc& i1, const VSrc& d1,
-                                          const VSrc& i2, const VSrc& d2, int32_t* om, int32_t* oi1, int32_t* oi2,
-                                          int32_t* od1, int32_t* od2, int& mak, int* cmax, long long* sec) {
-  SEC_T(t0);
+struct Cells4 {
+  v4i ins1, ins2, del1, del2, m;
+  int ext[4], maxn[4];
+  bool more[4];
+};
+
+// recurrences of 4 consecutive diagonals k0..k0+3 and the first 40 bases of their extensions
+template <bool MASK>
+__device__ __forceinline__ void bp_cells4_compute(const BpCtx& c, const uint8_t* P, const uint8_t* T, int k0, int lo, int hi,
+                                                  const VSrc& mx, const VSrc& mo1, const VSrc& mo2, const VSrc& i1, const VSrc& d1,
+                                                  const VSrc& i2, const VSrc& d2, Cells4& q) {
   const unsigned upl = (unsigned)c.pl, utl = (unsigned)c.tl;
   const v4i a1 = ld4<MASK>(mo1, k0 - 1), b1 = ld4<MASK>(mo1, k0 + 1);
   const v4i a2 = ld4<MASK>(mo2, k0 - 1), b2 = ld4<MASK>(mo2, k0 + 1);
   const v4i vi1 = ld4<MASK>(i1, k0 - 1), vd1 = ld4<MASK>(d1, k0 + 1);
   const v4i vi2 = ld4<MASK>(i2, k0 - 1), vd2 = ld4<MASK>(d2, k0 + 1);
   const v4i vmx = ld4<MASK>(mx, k0);
-  v4i ins1, ins2, del1, del2, m;
   uint64_t x[4];
-  int maxn[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int k = k0 + j;
-    ins1[j] = valid_or_null(max(a1[j], vi1[j]) + 1, k, upl, utl);
-    ins2[j] = valid_or_null(max(a2[j], vi2[j]) + 1, k, upl, utl);
-    del1[j] = valid_or_null(max(b1[j], vd1[j]), k, upl, utl);
-    del2[j] = valid_or_null(max(b2[j], vd2[j]), k, upl, utl);
+    q.ins1[j] = valid_or_null(max(a1[j], vi1[j]) + 1, k, upl, utl);
+    q.ins2[j] = valid_or_null(max(a2[j], vi2[j]) + 1, k, upl, utl);
+    q.del1[j] = valid_or_null(max(b1[j], vd1[j]), k, upl, utl);
+    q.del2[j] = valid_or_null(max(b2[j], vd2[j]), k, upl, utl);
     const int mis = valid_or_null(vmx[j] + 1, k, upl, utl);
-    int mm = max(imax3(ins1[j], ins2[j], mis), max(del1[j], del2[j]));
+    int mm = max(imax3(q.ins1[j], q.ins2[j], mis), max(q.del1[j], q.del2[j]));
     if (k < lo || k > hi) mm = WF_NULL;  // edge chunk: cells outside the row are dead
-    m[j] = mm;
+    q.m[j] = mm;
     // first 8 bases of the extension for all four cells (independent loads)
-    x[j] = 0; maxn[j] = 0;
+    x[j] = 0; q.maxn[j] = 0;
     if (mm >= 0) {
-      maxn[j] = min(c.pl - (mm - k), c.tl - mm);
+      q.maxn[j] = min(c.pl - (mm - k), c.tl - mm);
       x[j] = load8(P + (mm - k)) ^ load8(T + mm);
     }
   }
-  SEC_T(t1);
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    if (m[j] >= 0) {
-      const int k = k0 + j;
-      int n;
-      if (x[j]) n = (int)(__builtin_ctzll(x[j]) >> 3);
-      else n = lce_from(P + (m[j] - k), T + m[j], 8, maxn[j]);
-      m[j] += min(n, maxn[j]);
-      mak = max(mak, 2 * m[j] - k);
-    }
+    q.ext[j] = 0; q.more[j] = false;
+    if (q.m[j] >= 0) q.ext[j] = lce_head40_g(P, T, q.m[j] - (k0 + j), q.m[j], x[j], q.maxn[j], q.more[j]);
   }
-  if (TRACK) {  // per-component row maxima for the phase-2 overlap pruning, while the cells are in registers
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      if (k0 + j >= lo && k0 + j <= hi) {
-        cmax[C_M] = max(cmax[C_M], m[j]); cmax[C_I1] = max(cmax[C_I1], ins1[j]); cmax[C_I2] = max(cmax[C_I2], ins2[j]);
-        cmax[C_D1] = max(cmax[C_D1], del1[j]); cmax[C_D2] = max(cmax[C_D2], del2[j]);
-      }
-    }
-  }
-  SEC_T(t2);
-  *reinterpret_cast<v4i*>(oi1 + k0) = ins1;
-  *reinterpret_cast<v4i*>(oi2 + k0) = ins2;
-  *reinterpret_cast<v4i*>(od1 + k0) = del1;
-  *reinterpret_cast<v4i*>(od2 + k0) = del2;
-  *reinterpret_cast<v4i*>(om + k0) = m;
-  SEC_T(t3);
-  SEC_ADD(0, t0, t1); SEC_ADD(1, t1, t2); SEC_ADD(2, t2, t3);
 }
 
 // Computes + extends row s of direction dir.  Returns #cells of the row (uniform).
@@ -292,13 +336,46 @@ __device__ __forceinline__ int bp_compute_row(const BpCtx& c, int dir, int s, in
   const uint8_t* T = c.T[dir];
   const int koff = c.koff;  // column = k + koff, multiple-of-4 columns are 16-byte aligned
   const int c_lo = (lo + koff) >> 2, c_hi = (hi + koff) >> 2;
-  for (int ch = c_lo + (int)threadIdx.x; ch <= c_hi; ch += (int)blockDim.x) {
+  // the chunk loop is uniform over the workgroup (lanes past the row's end idle through it): the long extensions are
+  // finished by whole waves (wave_lce_tail_g)
+  for (int chb = c_lo; chb <= c_hi; chb += (int)blockDim.x) {
+    const int ch = chb + (int)threadIdx.x;
+    const bool on = ch <= c_hi;
     const int k0 = (ch << 2) - koff;
-    // loads touch k0-1 .. k0+4
-    if (all_live && k0 - 1 >= in_lo && k0 + 4 <= in_hi)
-      bp_cells4<false, TRACK>(c, P, T, k0, lo, hi, mx, mo1, mo2, i1, d1, i2, d2, om, oi1, oi2, od1, od2, mak, cmax, sec);
-    else
-      bp_cells4<true, TRACK>(c, P, T, k0, lo, hi, mx, mo1, mo2, i1, d1, i2, d2, om, oi1, oi2, od1, od2, mak, cmax, sec);
+    Cells4 q;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { q.m[j] = WF_NULL; q.ext[j] = 0; q.maxn[j] = 0; q.more[j] = false; }
+    if (on) {
+      // loads touch k0-1 .. k0+4
+      if (all_live && k0 - 1 >= in_lo && k0 + 4 <= in_hi) bp_cells4_compute<false>(c, P, T, k0, lo, hi, mx, mo1, mo2, i1, d1, i2, d2, q);
+      else bp_cells4_compute<true>(c, P, T, k0, lo, hi, mx, mo1, mo2, i1, d1, i2, d2, q);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (__any(q.more[j])) q.ext[j] = wave_lce_tail_g(P, T, q.m[j] - (k0 + j), q.m[j], q.ext[j], q.maxn[j], q.more[j]);
+    if (on) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (q.m[j] >= 0) {
+          q.m[j] += min(q.ext[j], q.maxn[j]);
+          mak = max(mak, 2 * q.m[j] - (k0 + j));
+        }
+      }
+      if (TRACK) {  // per-component row maxima for the phase-2 overlap pruning, while the cells are in registers
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (k0 + j >= lo && k0 + j <= hi) {
+            cmax[C_M] = max(cmax[C_M], q.m[j]); cmax[C_I1] = max(cmax[C_I1], q.ins1[j]); cmax[C_I2] = max(cmax[C_I2], q.ins2[j]);
+            cmax[C_D1] = max(cmax[C_D1], q.del1[j]); cmax[C_D2] = max(cmax[C_D2], q.del2[j]);
+          }
+        }
+      }
+      *reinterpret_cast<v4i*>(oi1 + k0) = q.ins1;
+      *reinterpret_cast<v4i*>(oi2 + k0) = q.ins2;
+      *reinterpret_cast<v4i*>(od1 + k0) = q.del1;
+      *reinterpret_cast<v4i*>(od2 + k0) = q.del2;
+      *reinterpret_cast<v4i*>(om + k0) = q.m;
+    }
   }
   return hi - lo + 1;
 }
@@ -431,15 +508,19 @@ __device__ __forceinline__ void bp_overlap_scan(const BpCtx& c, int d0, int s0, 
 
 // Row 0 of one direction (wavefront_unialign_init, end2end): the begin component holds
 // offset 0 at k = 0, M is extended.  Returns 1 if the alignment already ends at score 0.
+// Called by one whole wave per direction (the first extension of a sub-problem is often its longest: the wave walks
+// it together); the results are valid in every lane.
 __device__ __forceinline__ int bp_init_row0(const BpCtx& c, int d, int cb, int ce, int& mak) {
   int m0 = WF_NULL;
   mak = 0;
-  for (int cc = 1; cc < 5; ++cc) bp_row(c, d, cc, 0)[0] = (cc == cb) ? 0 : WF_NULL;
+  const bool first = (threadIdx.x & 63u) == 0;
+  if (first) for (int cc = 1; cc < 5; ++cc) bp_row(c, d, cc, 0)[0] = (cc == cb) ? 0 : WF_NULL;
   if (cb == C_M) {
-    m0 = lce_bounded(c.P[d], c.T[d], 0, 0, c.pl, c.tl);
+    m0 = wave_lce(c.P[d], c.T[d], 0, 0, min(c.pl, c.tl), first);
+    m0 = rdlane(m0, 0);
     mak = 2 * m0;
   }
-  bp_row(c, d, C_M, 0)[0] = m0;
+  if (first) bp_row(c, d, C_M, 0)[0] = m0;
   // termination at score 0 (identical sequences): only possible for M/M forms
   return (c.pl == c.tl && ce == C_M && m0 >= c.tl) ? 1 : 0;
 }
@@ -490,12 +571,15 @@ __global__ __launch_bounds__(1024) void wfa_bp_kernel(const uint8_t* __restrict_
       if (sc >= 0) { s_lo[d][sc & RMASK] = max(-J.pl, -sc); s_hi[d][sc & RMASK] = min(J.tl, sc); }
     }
     if (tid == 0) { s_mak[0][0] = J.fmax0; s_mak[0][1] = J.rmax0; s_bp[6] = 0; s_bp[7] = 0; }
-  } else if (tid < 2) {
-    const int d = tid;
+  } else if (tid < 128) {  // wave 0: forward, wave 1: reverse
+    const int d = tid >> 6;
     int mak = 0;
-    s_bp[6 + d] = bp_init_row0(c, d, d == 0 ? J.comp_begin : J.comp_end, d == 0 ? J.comp_end : J.comp_begin, mak);
-    s_lo[d][0] = 0; s_hi[d][0] = 0;
-    s_mak[0][d] = mak;
+    const int ended = bp_init_row0(c, d, d == 0 ? J.comp_begin : J.comp_end, d == 0 ? J.comp_end : J.comp_begin, mak);
+    if ((tid & 63) == 0) {
+      s_bp[6 + d] = ended;
+      s_lo[d][0] = 0; s_hi[d][0] = 0;
+      s_mak[0][d] = mak;
+    }
   }
   __syncthreads();
   int fmax = s_mak[0][0], rmax = s_mak[0][1];
@@ -746,7 +830,9 @@ __global__ __launch_bounds__(256) void wfa_base_kernel(const uint8_t* __restrict
   int lo0, hi0;
   if (J.endsfree) { lo0 = max(-J.pbf, c.kmin); hi0 = min(J.tbf, c.kmax); }
   else { lo0 = 0; hi0 = 0; }
-  for (int k = lo0 + tid; k <= hi0; k += blockDim.x) {
+  for (int kb = lo0; kb <= hi0; kb += blockDim.x) {  // uniform over the workgroup: wave_lce is a wave-wide call
+    const int k = kb + tid;
+    const bool on = k <= hi0;
     int m = WF_NULL;
     int vi1 = WF_NULL, vi2 = WF_NULL, vd1 = WF_NULL, vd2 = WF_NULL;
     if (J.endsfree) m = k > 0 ? k : 0;
@@ -757,9 +843,12 @@ __global__ __launch_bounds__(256) void wfa_base_kernel(const uint8_t* __restrict
       vd1 = J.comp_begin == C_D1 ? 0 : WF_NULL;
       vd2 = J.comp_begin == C_D2 ? 0 : WF_NULL;
     }
+    if (!on) m = WF_NULL;
+    const int ext0 = wave_lce(c.P, c.T, m - k, m, min(c.pl - (m - k), c.tl - m), m >= 0);
+    if (!on) continue;
     c.pre[k] = m; c.bt[k] = 0;
     if (m >= 0) {
-      m += lce_bounded(c.P, c.T, m - k, m, c.pl, c.tl);
+      m += ext0;
       if (J.endsfree) {
         const int h = m, v = m - k;
         if ((h >= c.tl && c.pl - v <= J.pef) || (v >= c.pl && c.tl - h <= J.tef)) atomicMin(&s_endk, k);
@@ -805,7 +894,9 @@ __global__ __launch_bounds__(256) void wfa_base_kernel(const uint8_t* __restrict
       int32_t* od2 = bs_row(c, C_D2, s);
       int32_t* pre = c.pre + (int64_t)s * c.width;
       uint8_t* bt = c.bt + (int64_t)s * c.width;
-      for (int k = lo + tid; k <= hi; k += blockDim.x) {
+      for (int kb = lo; kb <= hi; kb += blockDim.x) {  // uniform over the workgroup (wave_lce below)
+        const int k = kb + tid;
+        const bool on = k <= hi;
         const int m1a = ldk(mo1, k - 1), m1b = ldk(mo1, k + 1);
         const int m2a = ldk(mo2, k - 1), m2b = ldk(mo2, k + 1);
         const int e_i1 = ldk(i1, k - 1), e_i2 = ldk(i2, k - 1);
@@ -827,10 +918,13 @@ __global__ __launch_bounds__(256) void wfa_base_kernel(const uint8_t* __restrict
         if (del1 >= m) { m = del1; src = C_D1; }
         if (del2 >= m) { m = del2; src = C_D2; }
         if (mis >= m)  { m = mis;  src = C_M; }
+        if (!on) m = WF_NULL;
+        const int ext = wave_lce(c.P, c.T, m - k, m, min(c.pl - (m - k), c.tl - m), m >= 0);
+        if (!on) continue;
         pre[k] = m;
         bt[k] = (uint8_t)(bits | src);
         if (m >= 0) {
-          m += lce_bounded(c.P, c.T, m - k, m, c.pl, c.tl);
+          m += ext;
           if (J.endsfree) {
             const int h = m, v = m - k;
             if ((h >= c.tl && c.pl - v <= J.pef) || (v >= c.pl && c.tl - h <= J.tef)) atomicMin(&s_endk, k);
@@ -947,7 +1041,7 @@ __device__ __forceinline__ int rng_hi(int tl, int s) { return min(tl, s); }
 
 __global__ void wfa_tile_init_kernel(const uint8_t* __restrict__ seq, int32_t* __restrict__ ring_arena,
                                      const TileJob* __restrict__ jobs, int32_t* __restrict__ mak0, int njobs) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = blockIdx.x;  // one wave per (job, direction)
   if (i >= njobs * 2) return;
   const TileJob J = jobs[i >> 1];
   const int d = i & 1;
@@ -959,8 +1053,10 @@ __global__ void wfa_tile_init_kernel(const uint8_t* __restrict__ seq, int32_t* _
   c.pl = J.pl; c.tl = J.tl;
   int mak = 0;
   const int end = bp_init_row0(c, d, d == 0 ? J.comp_begin : J.comp_end, d == 0 ? J.comp_end : J.comp_begin, mak);
-  mak0[i * 2 + 0] = mak;
-  mak0[i * 2 + 1] = end;
+  if (threadIdx.x == 0) {
+    mak0[i * 2 + 0] = mak;
+    mak0[i * 2 + 1] = end;
+  }
 }
 
 // LDS rows: M[scope][Wt], I1[e1+1][Wt], D1[e1+1][Wt], I2[e2+1][Wt], D2[e2+1][Wt], mak[T+1]
@@ -1187,6 +1283,86 @@ __device__ __forceinline__ int win_lce(const uint8_t* P, const uint8_t* T, const
   return min(n, maxn);
 }
 
+// ---- wave-cooperative long extensions, reading through the LDS sequence windows (see wave_lce_tail_g) ----
+template <bool USE_WIN>
+__device__ __forceinline__ int wave_lce_tail(const uint8_t* P, const uint8_t* T, const uint32_t* winP, const uint32_t* winT, int v, int h,
+                                             int n, int maxn, bool pend, int wP0, int wT0) {
+  unsigned long long todo = __ballot(pend);
+  const int lane = (int)(threadIdx.x & 63u);
+  while (todo) {
+    const int src = __builtin_amdgcn_readfirstlane((int)__builtin_ctzll(todo));
+    todo &= todo - 1;
+    const int v0 = rdlane(v, src), h0 = rdlane(h, src), mx = rdlane(maxn, src);
+    int nn = rdlane(n, src);  // bases known to match so far (uniform)
+    int res;
+    for (;;) {
+      const int off = nn + lane * 8;
+      const bool past = off >= mx;
+      uint64_t x = 0;
+      if (!past) {
+        if (USE_WIN) x = win_xor8(P, T, winP, winT, v0 + off, h0 + off, wP0, wT0);
+        else x = load8(P + v0 + off) ^ load8(T + h0 + off);
+      }
+      const unsigned long long hit = __ballot(past || x != 0);
+      if (hit) {
+        const int f = __builtin_amdgcn_readfirstlane((int)__builtin_ctzll(hit));
+        const unsigned xlo = (unsigned)rdlane((int)(uint32_t)x, f), xhi = (unsigned)rdlane((int)(uint32_t)(x >> 32), f);
+        const uint64_t xf = ((uint64_t)xhi << 32) | xlo;
+        const int at = nn + f * 8;
+        res = at >= mx ? mx : min(mx, at + (xf ? (int)(__builtin_ctzll(xf) >> 3) : 0));
+        break;
+      }
+      nn += 512;
+    }
+    if (lane == src) n = res;
+  }
+  return n;
+}
+
+// what a lane does on its own: 8 bases (x8 = their xor, already loaded), then one round of 32; more = the run goes on
+template <bool USE_WIN>
+__device__ __forceinline__ int lce_head40(const uint8_t* P, const uint8_t* T, const uint32_t* winP, const uint32_t* winT, int v, int h,
+                                          uint64_t x8, int maxn, int wP0, int wT0, bool& more) {
+  more = false;
+  if (x8) return min((int)(__builtin_ctzll(x8) >> 3), maxn);
+  if (maxn <= 8) return maxn;
+  if (maxn < 40) {  // the end of the sequences is near: 8 bases at a time
+    int n = 8;
+    while (n < maxn) {
+      const uint64_t x = USE_WIN ? win_xor8(P, T, winP, winT, v + n, h + n, wP0, wT0) : (load8(P + v + n) ^ load8(T + h + n));
+      if (x) { n += (int)(__builtin_ctzll(x) >> 3); break; }
+      n += 8;
+    }
+    return min(n, maxn);
+  }
+  uint64_t x0, x1, x2, x3;
+  const unsigned ov = (unsigned)(v + 8 - wP0), oh = (unsigned)(h + 8 - wT0);
+  if (USE_WIN && ov <= (unsigned)(SEQ_WIN - 32) && oh <= (unsigned)(SEQ_WIN - 32)) {
+    const uint32_t* a = winP + (ov >> 2);
+    const uint32_t* b = winT + (oh >> 2);
+    const unsigned sa = (ov & 3u) * 8u, sb = (oh & 3u) * 8u;
+    uint32_t wa[9], wb[9];
+#pragma unroll
+    for (int q = 0; q < 9; ++q) { wa[q] = a[q]; wb[q] = b[q]; }
+    uint32_t d[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) d[q] = __builtin_amdgcn_alignbit(wa[q + 1], wa[q], sa) ^ __builtin_amdgcn_alignbit(wb[q + 1], wb[q], sb);
+    x0 = ((uint64_t)d[1] << 32) | d[0]; x1 = ((uint64_t)d[3] << 32) | d[2];
+    x2 = ((uint64_t)d[5] << 32) | d[4]; x3 = ((uint64_t)d[7] << 32) | d[6];
+  } else {
+    const uint8_t* pp = P + (v + 8);
+    const uint8_t* tt = T + (h + 8);
+    x0 = load8(pp) ^ load8(tt); x1 = load8(pp + 8) ^ load8(tt + 8);
+    x2 = load8(pp + 16) ^ load8(tt + 16); x3 = load8(pp + 24) ^ load8(tt + 24);
+  }
+  if (x0) return 8 + (int)(__builtin_ctzll(x0) >> 3);
+  if (x1) return 16 + (int)(__builtin_ctzll(x1) >> 3);
+  if (x2) return 24 + (int)(__builtin_ctzll(x2) >> 3);
+  if (x3) return 32 + (int)(__builtin_ctzll(x3) >> 3);
+  more = maxn > 40;
+  return 40;
+}
+
 template <int C, int NTMAX, int LX, int LA, int LB, int E1, int E2>
 __global__ __launch_bounds__(NTMAX) void wfa_tile_reg_kernel(const uint8_t* __restrict__ seq, int32_t* __restrict__ ring_arena,
                                                            const TileJob* __restrict__ jobs, const TileTask* __restrict__ tasks,
@@ -1379,15 +1555,23 @@ __global__ __launch_bounds__(NTMAX) void wfa_tile_reg_kernel(const uint8_t* __re
         x[c] = win_xor8(P, Tx, s_winP, s_winT, m - k, m, wP0, wT0);
       }
     }
+    int ext[C];
+    bool more[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      ext[c] = 0; more[c] = false;
+      if (nM[c] >= 0) ext[c] = lce_head40<true>(P, Tx, s_winP, s_winT, nM[c] - (k0 + c), nM[c], x[c], maxn[c], wP0, wT0, more[c]);
+    }
+    // runs longer than 40 bases: the wave finishes them together (uniform control flow: every lane is here)
+#pragma unroll
+    for (int c = 0; c < C; ++c)
+      if (__any(more[c])) ext[c] = wave_lce_tail<true>(P, Tx, s_winP, s_winT, nM[c] - (k0 + c), nM[c], ext[c], maxn[c], more[c], wP0, wT0);
 #pragma unroll
     for (int c = 0; c < C; ++c) {
       const int k = k0 + c;
       int m = nM[c];
       if (m >= 0) {
-        int n;
-        if (x[c]) n = (int)(__builtin_ctzll(x[c]) >> 3);
-        else n = 8 + win_lce(P, Tx, s_winP, s_winT, m - k + 8, m + 8, maxn[c] - 8, wP0, wT0);
-        m += min(n, maxn[c]);
+        m += min(ext[c], maxn[c]);
         nM[c] = m;
         if (k >= tk.core_lo && k <= tk.core_hi && k >= rng_lo(pl, s) && k <= rng_hi(tl, s)) mak = max(mak, 2 * m - k);
       }
@@ -1549,7 +1733,7 @@ void launch_bp(const uint8_t* seq, int32_t* ring, const BpJob* jobs, BpResult* r
   hipLaunchKernelGGL(wfa_bp_kernel, dim3(njobs), dim3(threads), 0, st, seq, ring, jobs, res, pen, scope);
 }
 void launch_tile_init(const uint8_t* seq, int32_t* ring, const TileJob* jobs, int32_t* mak0, int njobs, hipStream_t st) {
-  hipLaunchKernelGGL(wfa_tile_init_kernel, dim3((njobs * 2 + 63) / 64), dim3(64), 0, st, seq, ring, jobs, mak0, njobs);
+  hipLaunchKernelGGL(wfa_tile_init_kernel, dim3(njobs * 2), dim3(64), 0, st, seq, ring, jobs, mak0, njobs);
 }
 void launch_tile(const uint8_t* seq, int32_t* ring, const TileJob* jobs, const TileTask* tasks, int32_t* mak, int ntasks,
                  int threads, int T, int Wt, size_t lds_bytes, DevPen pen, int scope, hipStream_t st) {
