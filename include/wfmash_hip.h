@@ -114,6 +114,8 @@ typedef struct {
   double   ms_bp_busy;       /* as ms_tile_busy, for the wfa_bp_kernel launches (ms_breakpoint - ms_tile summed over streams) */
   double   ms_base_busy;     /* as ms_tile_busy, for the wfa_base_kernel launches */
   double   ms_any_busy;      /* time during which any of the three kernels was running */
+  uint32_t p2_launches, p2_jobs; /* phase 2 from rows computed ahead (tile kernel + wfa_p2_* kernels): launch sets, jobs */
+  uint32_t p2_more, pad2_;   /* of those jobs, the ones wfa_bp_kernel had to finish step by step */
 } wfm_stats_t;
 
 int  wfm_device_count(void);   /* usable HIP devices of this node (0 without a GPU) */

@@ -60,7 +60,8 @@ def run(h, name, pairs, steps):
     ss = h.upload(pairs)
     qb = sum(len(q) for _, q in pairs)
     h.align_resident(ss, collect=False)  # warm-up (arenas)
-    acc = dict(cells=0, ms_k=0.0, ms_tile=0.0, ms_bp=0.0, ms_base=0.0, levels=0, tile_launches=0, bp_launches=0, base_launches=0)
+    acc = dict(cells=0, ms_k=0.0, ms_tile=0.0, ms_bp=0.0, ms_base=0.0, levels=0, tile_launches=0, bp_launches=0, base_launches=0,
+               p2_launches=0, p2_jobs=0, p2_more=0, busy=0.0)
     t0 = time.perf_counter()
     for _ in range(steps):
         failed = h.align_resident(ss, collect=False)
@@ -69,6 +70,7 @@ def run(h, name, pairs, steps):
         acc["cells"] += st.cells; acc["ms_k"] += st.ms_kernels; acc["ms_tile"] += st.ms_tile
         acc["ms_bp"] += st.ms_breakpoint - st.ms_tile; acc["ms_base"] += st.ms_base; acc["levels"] = st.levels
         acc["tile_launches"] += st.tile_launches; acc["bp_launches"] += st.bp_launches; acc["base_launches"] += st.base_launches
+        acc["p2_launches"] += st.p2_launches; acc["p2_jobs"] += st.p2_jobs; acc["p2_more"] += st.p2_more; acc["busy"] += st.ms_any_busy
     dt = (time.perf_counter() - t0) / steps
     res = h._collect(ss)
     scores = np.array([r.score for r in res])
@@ -77,7 +79,9 @@ def run(h, name, pairs, steps):
            "gcells_per_s_wall": round(acc["cells"] / steps / dt / 1e9, 2),
            "alg_frac_of_8TBs_wall": round(48.0 * acc["cells"] / steps / dt / 8e12, 3),
            "kernel_ms": {k[3:]: round(acc[k] / steps, 2) for k in ("ms_tile", "ms_bp", "ms_base")},
-           "launches": {k: acc[k] // steps for k in ("tile_launches", "bp_launches", "base_launches")}, "levels": acc["levels"]}
+           "gpu_busy_ms": round(acc["busy"] / steps, 2), "alg_frac_of_8TBs_busy": round(48.0 * acc["cells"] / max(acc["busy"], 1e-9) / 8e9, 3),
+           "launches": {k: acc[k] // steps for k in ("tile_launches", "bp_launches", "base_launches", "p2_launches", "p2_jobs", "p2_more")},
+           "levels": acc["levels"]}
     ss.free()
     return out
 

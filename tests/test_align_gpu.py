@@ -248,3 +248,25 @@ def test_c5_shape_properties(gpu, oracle):
         assert oracle.ops_score(r.ops) == r.score
     small = synth.pairs("C5", n_pairs=3, length=12000)
     _check_batch(gpu, oracle, small)
+
+
+def test_c5_full_size_pairs_match_the_oracle_fixture(gpu):
+    """BASELINE.json configs[4] at FULL size against the oracle: two 100 kb / 15 % pairs (~10^10 wavefront cells each,
+    scores ~98 k).  The oracle's answer is a committed fixture (tests/golden/c5_golden.json.gz, written by
+    tests/golden/make_c5_golden.py from oracle/wfa2p.c -- minutes of CPU per pair): score, length and every op of the
+    CIGAR must be identical."""
+    import gzip
+    import hashlib
+    import json
+    import os
+    import re
+    g = json.load(gzip.open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "c5_golden.json.gz"), "rt"))
+    pairs = synth.pairs("C5", n_pairs=len(g["pairs"]))
+    res = gpu.align(pairs)
+    for (p, t), r, want in zip(pairs, res, g["pairs"]):
+        assert (len(p), len(t)) == (want["plen"], want["tlen"])
+        assert r.status == 0 and r.score == want["score"] and len(r.ops) == want["n_ops"]
+        assert hashlib.sha256(r.ops).hexdigest() == want["sha256"]
+        rle = "".join(f"{len(m.group(0))}{m.group(0)[0]}" for m in re.finditer(r"M+|X+|I+|D+", r.ops.decode()))
+        assert rle == want["rle"]
+    assert min(w["score"] for w in g["pairs"]) > 90000

@@ -21,6 +21,7 @@ enum { BT_I1_EXT = 8, BT_I2_EXT = 16, BT_D1_EXT = 32, BT_D2_EXT = 64 };
 constexpr int WFM_DEV_UNREACHABLE = -300;
 constexpr int WFM_DEV_OVERFLOW = -2;  // base job exceeded its score budget (smax)
 constexpr int WFM_DEV_BAND = -4;      // bialign job ran out of its diagonal band (BpJob::band)
+constexpr int WFM_DEV_P2_MORE = -5;   // phase 2 did not end within the P2K rows computed ahead: the step kernel takes the job
 
 struct DevPen { int x, o1, e1, o2, e2; };
 
@@ -63,6 +64,33 @@ struct TileJob {
   int32_t mode;                        // 0: full blocks; 1: next block stops exactly at the meeting point; 2: stopped there
   int32_t tf, tr;                      // mode >= 1: steps of the forward / reverse direction inside the block after s0
   int32_t last_fwd;                    // mode >= 1: 1 if the forward check ended phase 1 (reverse is one step behind)
+  int32_t pad_;
+  // mode 4 (phase-2 rows, see P2Job): forward starts at score tf, reverse at tr (s0 is not used), every row goes to the
+  // job's P2 rows instead of an output snapshot
+  int64_t p2_off;
+  int32_t w2, koff2;
+};
+
+// ---- phase 2 (overlap detection) without a step-by-step kernel ----
+// wavefront_bialign_find_breakpoint's second loop alternates "test the newest row of one direction against the last
+// `scope` rows of the other" and "advance the other direction by one row" until no better breakpoint is possible
+// -- about 2 * scope rows past the meeting point.  The rows do not depend on the tests, so they are computed ahead:
+// the tile kernel runs P2K more scores of both directions from the exact snapshot and keeps EVERY row (five components,
+// [dir][comp][P2K][w2]); wfa_p2_overlap_kernel then walks the reference's loop, one workgroup per job, with nothing but
+// the tests left in it (doing all tests of a job side by side was tried: without the best breakpoint so far to prune
+// with, the tests after the first hit cost more than the whole sequential walk).  A job whose loop has not ended after
+// 2 * P2K tests (WFM_DEV_P2_MORE) is finished by wfa_bp_kernel from the same snapshot.
+constexpr int P2K = 48;
+constexpr int P2ROWS = 26 + P2K;   // row maxima per direction: the snapshot's rows sd-25 .. sd, then sd+1 .. sd+P2K
+constexpr int P2TESTS = 2 * P2K;
+constexpr int P2ENT = RING * 5;    // (row of the other direction, component) slots of a test; scope <= RING rows are used
+struct P2Job {
+  int64_t ring_in;                     // the exact snapshot (rows <= sf / sr), int32 element offset of the job's ring
+  int64_t p2_off;                      // int32 element offset of the job's P2 rows
+  int32_t width, koff;                 // ring geometry
+  int32_t w2, koff2;                   // P2 geometry: column = k + koff2
+  int32_t pl, tl;
+  int32_t sf, sr, last_fwd;            // state at the meeting point
   int32_t pad_;
 };
 struct TileTask {
@@ -111,6 +139,12 @@ void launch_tile(const uint8_t* seq, int32_t* ring, const TileJob* jobs, const T
 void launch_tile_advance(TileJob* jobs, int32_t* mak, int njobs, int T, DevPen pen, int exact, hipStream_t st);
 void launch_tile_reg(const uint8_t* seq, int32_t* ring, const TileJob* jobs, const TileTask* tasks, int32_t* mak, int ntasks,
                      int threads, int T, int C, hipStream_t st);
+// phase-2 rows of the jobs in mode 4 (T = P2K scores, two diagonals per thread), their per-row maxima into p2max
+void launch_tile_p2(const uint8_t* seq, int32_t* ring, const TileJob* jobs, const TileTask* tasks, int ntasks, int threads,
+                    int32_t* p2, int32_t* p2max, hipStream_t st);
+void launch_p2_snapmax(const int32_t* ring, const P2Job* jobs, int32_t* p2max, int njobs, hipStream_t st);
+void launch_p2_overlap(const int32_t* ring, const int32_t* p2, const P2Job* jobs, const int32_t* p2max, BpResult* res, int njobs, int threads,
+                       DevPen pen, int scope, hipStream_t st);
 void launch_base(const uint8_t* seq, int32_t* a32, uint8_t* a8, uint32_t* rle, const BaseJob* jobs, BaseResult* res,
                  int njobs, DevPen pen, hipStream_t st);
 void launch_compact(const uint32_t* rle, const int64_t* off, const int64_t* cap, uint32_t* out, unsigned long long* total,

@@ -110,6 +110,8 @@ struct wfm_handle {
   DevBuf<TileJob> tilejobs;
   DevBuf<TileTask> tiletasks;
   DevBuf<int32_t> tilemak;
+  DevBuf<int32_t> p2rows, p2max;  // phase 2 from rows computed ahead (P2Job)
+  DevBuf<P2Job> p2jobs;
   DevBuf<BpResult> bpres;
   DevBuf<BaseJob> bsjobs;
   DevBuf<BaseResult> bsres;
@@ -360,12 +362,29 @@ int run_tiled_phase(wfm_handle* h, wfm_seqset* S, const DevPen& dp, int scope, c
       }
       if (out_of_band) HIPCHK(h, hipMemcpyAsync(h->tilejobs.p, tj.data(), n * sizeof(TileJob), hipMemcpyHostToDevice, h->stream));
       if (!n_active) break;
-      // as many tiles of `core` diagonals per job and direction as the last block of this chunk can need
+      // as many tiles of `core` diagonals per job and direction as the last block of this chunk can need.  While the
+      // widest range of the chunk fits one tile, every job-direction is ONE tile without a halo, and the workgroups
+      // are only as large as that range needs (the first blocks of a level are a few hundred diagonals wide)
       tasks.clear();
+      int threads_c = cfg.threads, core_c = core;
+      if (cfg.reg && cfg.C == 2) {
+        int widest = 0;
+        for (size_t i = 0; i < n; ++i) {
+          if (!active[i]) continue;
+          const int reach = tj[i].s0 + chunk * T;
+          widest = std::max(widest, std::min(tj[i].tl, reach) - std::max(-tj[i].pl, -reach) + 1);
+        }
+        if (widest <= cfg.threads * cfg.C) {
+          threads_c = widest <= 256 ? 128 : (widest <= 512 ? 256 : cfg.threads);
+          threads_c = std::min(threads_c, cfg.threads);
+          core_c = threads_c * cfg.C;
+        }
+      }
       for (size_t i = 0; i < n; ++i) {
         if (!active[i]) continue;
         const int reach = tj[i].s0 + chunk * T;
         const int L = std::max(-tj[i].pl, -reach), R = std::min(tj[i].tl, reach);
+        const int core = core_c;
         const int ntiles = (R - L + core) / core;
         for (int d = 0; d < 2; ++d)
           for (int t = 0; t < ntiles; ++t) tasks.push_back(TileTask{(int32_t)i, d, t, core});  // (tile index, tile width): the kernel places it
@@ -374,7 +393,7 @@ int run_tiled_phase(wfm_handle* h, wfm_seqset* S, const DevPen& dp, int scope, c
       HIPCHK(h, hipMemcpyAsync(h->tiletasks.p, tasks.data(), tasks.size() * sizeof(TileTask), hipMemcpyHostToDevice, h->stream));
       for (int b = 0; b < chunk; ++b) {
         HIPCHK(h, hipEventRecord(h->tile_ev[2 * b], h->stream));
-        if (cfg.reg) launch_tile_reg(S->d_seq, h->ring.p, h->tilejobs.p, h->tiletasks.p, h->tilemak.p, (int)tasks.size(), cfg.threads, T, cfg.C, h->stream);
+        if (cfg.reg) launch_tile_reg(S->d_seq, h->ring.p, h->tilejobs.p, h->tiletasks.p, h->tilemak.p, (int)tasks.size(), threads_c, T, cfg.C, h->stream);
         else launch_tile(S->d_seq, h->ring.p, h->tilejobs.p, h->tiletasks.p, h->tilemak.p, (int)tasks.size(), cfg.threads, T, cfg.Wt, lds, dp, scope, h->stream);
         HIPCHK(h, hipEventRecord(h->tile_ev[2 * b + 1], h->stream));
         launch_tile_advance(h->tilejobs.p, h->tilemak.p, (int)n, T, dp, (cfg.reg && cfg.exact) ? 1 : 0, h->stream);
@@ -442,6 +461,101 @@ int run_tiled_phase(wfm_handle* h, wfm_seqset* S, const DevPen& dp, int scope, c
     j.fmax0 = fmax[i]; j.rmax0 = rmax[i];
   }
   if (getenv("WFM_DEBUG")) fprintf(stderr, "[wfm] level %u: tiled %zu jobs, %u blocks of %d scores (Wt %d), %.3f ms\n", level, n, blocks, T, cfg.Wt, tile_ms);
+  return WFM_OK;
+}
+
+// Phase 2 (overlap detection) of the jobs whose tile phase stopped exactly at the meeting point, without the
+// step-by-step kernel: P2K more rows of both directions by the tile kernel, all rows kept (P2Job in wfa_device.h), then
+// the reference's loop with only the tests left in it (wfa_p2_overlap_kernel).  cand: indices into jobs; res[q] is filled for every
+// candidate, with status WFM_DEV_P2_MORE where the loop had not ended after 2 * P2K tests (wfa_bp_kernel takes those).
+int run_p2_phase(wfm_handle* h, wfm_seqset* S, const DevPen& dp, int scope, const TileCfg& cfg, const std::vector<BpJob>& jobs,
+                 const std::vector<int>& cand, const std::vector<int64_t>& ring_other, std::vector<BpResult>& res, double& ms_out) {
+  if (cand.empty()) return WFM_OK;
+  const int core = cfg.Wt - 2 * P2K;
+  size_t i0 = 0;
+  std::vector<TileJob> tj;
+  std::vector<P2Job> pj;
+  std::vector<TileTask> tasks;
+  std::vector<BpResult> got;
+  // the rows of a chunk of jobs may take a quarter of the budget (the rings hold the rest)
+  const size_t budget = std::max<size_t>(h->mem_budget / 4, (size_t)64 << 20);
+  while (i0 < cand.size()) {
+    tj.clear(); pj.clear(); tasks.clear();
+    size_t elems = 0, i = i0, maxw2 = 0;
+    for (; i < cand.size(); ++i) {
+      const BpJob& j = jobs[(size_t)cand[i]];
+      const int reach = std::max(j.resume_s, j.resume_sr) + P2K;
+      const int L = std::max(-j.pl, -reach), R = std::min(j.tl, reach);
+      const int koff2 = ((-L + 4) + 3) & ~3;                       // column of diagonal 0: a multiple of 4, >= 4 columns of margin
+      const size_t w2 = ((size_t)(R + koff2 + 8) + 3) & ~(size_t)3;
+      const size_t need = w2 * 2 * 5 * P2K;
+      if (!tj.empty() && (elems + need) * 4 > budget) break;
+      maxw2 = std::max(maxw2, w2);
+      TileJob t{};
+      t.p_fwd = j.p_fwd; t.t_fwd = j.t_fwd; t.p_rev = j.p_rev; t.t_rev = j.t_rev;
+      t.ring_in = j.ring_off; t.ring_out = ring_other[i];
+      t.pl = j.pl; t.tl = j.tl; t.comp_begin = j.comp_begin; t.comp_end = j.comp_end;
+      t.width = j.width; t.koff = j.koff; t.s0 = 0; t.active = 1; t.fmax = 0; t.rmax = 0; t.nblocks = 0;
+      t.mode = 4; t.tf = j.resume_s; t.tr = j.resume_sr; t.last_fwd = j.last_fwd; t.pad_ = 0;
+      t.p2_off = (int64_t)elems; t.w2 = (int32_t)w2; t.koff2 = koff2;
+      P2Job q{};
+      q.ring_in = j.ring_off; q.p2_off = (int64_t)elems; q.width = j.width; q.koff = j.koff; q.w2 = (int32_t)w2; q.koff2 = koff2;
+      q.pl = j.pl; q.tl = j.tl; q.sf = j.resume_s; q.sr = j.resume_sr; q.last_fwd = j.last_fwd; q.pad_ = 0;
+      elems += need;
+      tj.push_back(t); pj.push_back(q);
+    }
+    const size_t n = tj.size();
+    // one tile without a halo per job-direction while the widest range of the chunk fits one (see run_tiled_phase)
+    int threads_c = cfg.threads, core_c = core;
+    {
+      int widest = 0;
+      for (const TileJob& t : tj) {
+        const int rd = std::max(t.tf, t.tr) + P2K;
+        widest = std::max(widest, std::min(t.tl, rd) - std::max(-t.pl, -rd) + 1);
+      }
+      if (widest <= cfg.threads * 2) {
+        threads_c = std::min(cfg.threads, widest <= 256 ? 128 : (widest <= 512 ? 256 : cfg.threads));
+        core_c = threads_c * 2;
+      }
+    }
+    for (size_t jn = 0; jn < n; ++jn)
+      for (int d = 0; d < 2; ++d) {
+        const int rd = (d == 0 ? tj[jn].tf : tj[jn].tr) + P2K;
+        const int Ld = std::max(-tj[jn].pl, -rd), Rd = std::min(tj[jn].tl, rd);
+        const int ntiles = (Rd - Ld + core_c) / core_c;
+        for (int t2 = 0; t2 < ntiles; ++t2) tasks.push_back(TileTask{(int32_t)jn, d, t2, core_c});
+      }
+    if (h->p2rows.ensure(elems + 16) || h->p2max.ensure(n * 2 * P2ROWS * 5) ||
+        h->p2jobs.ensure(n) || h->tilejobs.ensure(n) || h->tiletasks.ensure(tasks.size()) || h->bpres.ensure(std::max(n, jobs.size()))) {
+      h->err = "out of device memory (phase-2 rows)"; return WFM_E_NOMEM;
+    }
+    HIPCHK(h, hipMemcpyAsync(h->tilejobs.p, tj.data(), n * sizeof(TileJob), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->p2jobs.p, pj.data(), n * sizeof(P2Job), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->tiletasks.p, tasks.data(), tasks.size() * sizeof(TileTask), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemsetAsync(h->p2max.p, 0, n * 2 * P2ROWS * 5 * sizeof(int32_t), h->stream));
+    HIPCHK(h, hipEventRecord(h->ev0, h->stream));
+    launch_tile_p2(S->d_seq, h->ring.p, h->tilejobs.p, h->tiletasks.p, (int)tasks.size(), threads_c, h->p2rows.p, h->p2max.p, h->stream);
+    launch_p2_snapmax(h->ring.p, h->p2jobs.p, h->p2max.p, (int)n, h->stream);
+    launch_p2_overlap(h->ring.p, h->p2rows.p, h->p2jobs.p, h->p2max.p, h->bpres.p, (int)n, maxw2 <= 4096 ? 256 : (maxw2 <= 32768 ? 512 : 1024), dp,
+                      scope, h->stream);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipEventRecord(h->ev1, h->stream));
+    got.resize(n);
+    HIPCHK(h, hipMemcpyAsync(got.data(), h->bpres.p, n * sizeof(BpResult), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    float ms = 0;
+    HIPCHK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    ms_out += ms;
+    if (h->call_base) {
+      float t0 = 0;
+      HIPCHK(h, hipEventElapsedTime(&t0, h->call_base, h->ev0));
+      h->bp_iv.emplace_back(t0, t0 + ms);
+    }
+    h->stats.p2_launches++;
+    h->stats.p2_jobs += (uint32_t)n;
+    for (size_t q = 0; q < n; ++q) res[(size_t)cand[i0 + q]] = got[q];
+    i0 = i;
+  }
   return WFM_OK;
 }
 
@@ -591,37 +705,59 @@ int align_resident_impl(wfm_handle* h, const wfm_penalties_t* pen, wfm_seqset* S
           for (size_t q = 0; q < tiled.size(); ++q) (void)q;
           tile_cells_level = tcells;
         }
-        // workgroup size: wide wavefronts want all 16 waves of a CU
-        int threads = 1024;
-        if (maxw <= 1024) threads = 256;
-        else if (maxw <= 8192) threads = 512;
-        HIPCHK(h, hipMemcpyAsync(h->bpjobs.p, jobs.data(), jobs.size() * sizeof(BpJob), hipMemcpyHostToDevice, h->stream));
-        HIPCHK(h, hipEventRecord(h->ev0, h->stream));
-        launch_bp(S->d_seq, h->ring.p, h->bpjobs.p, h->bpres.p, (int)jobs.size(), threads, dp, scope, h->stream);
-        HIPCHK(h, hipGetLastError());
-        HIPCHK(h, hipEventRecord(h->ev1, h->stream));
-        res.resize(jobs.size());
-        HIPCHK(h, hipMemcpyAsync(res.data(), h->bpres.p, jobs.size() * sizeof(BpResult), hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(h, hipStreamSynchronize(h->stream));
-        float ms = 0;
-        HIPCHK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
-        tm.bp_ms += ms;
-        if (h->call_base) {
-          float t0 = 0;
-          HIPCHK(h, hipEventElapsedTime(&t0, h->call_base, h->ev0));
-          h->bp_iv.emplace_back(t0, t0 + ms);
+        res.assign(jobs.size(), BpResult{});
+        // ---- phase 2 of the jobs the tile phase left exactly at their meeting point: rows computed ahead + scan + replay
+        std::vector<int> rest;  // jobs for the step kernel: not tiled, not exact, or not finished by the rows computed ahead
+        {
+          static const bool p2_on = !(getenv("WFM_P2") && atoi(getenv("WFM_P2")) == 0);
+          std::vector<int> cand;
+          std::vector<int64_t> other;
+          std::vector<char> is_cand(jobs.size(), 0);
+          if (p2_on && tcfg.reg && tcfg.exact)
+            for (size_t q = 0; q < tiled.size(); ++q) {
+              const BpJob& j = jobs[(size_t)tiled[q]];
+              if (j.resume_s >= 0 && j.resume_sr >= 0) { cand.push_back(tiled[q]); other.push_back(ring2[q]); is_cand[(size_t)tiled[q]] = 1; }
+            }
+          double pms = 0;
+          rc = run_p2_phase(h, S, dp, scope, tcfg, jobs, cand, other, res, pms);
+          if (rc != WFM_OK) return rc;
+          tm.bp_ms += pms;
+          for (size_t q = 0; q < jobs.size(); ++q)
+            if (!is_cand[q] || res[q].status == WFM_DEV_P2_MORE) { rest.push_back((int)q); h->stats.p2_more += is_cand[q]; }
         }
-        h->stats.bp_launches++;
+        if (!rest.empty()) {
+          // workgroup size: wide wavefronts want all 16 waves of a CU
+          int threads = 1024;
+          if (maxw <= 1024) threads = 256;
+          else if (maxw <= 8192) threads = 512;
+          std::vector<BpJob> rj(rest.size());
+          for (size_t q = 0; q < rest.size(); ++q) rj[q] = jobs[(size_t)rest[q]];
+          HIPCHK(h, hipMemcpyAsync(h->bpjobs.p, rj.data(), rj.size() * sizeof(BpJob), hipMemcpyHostToDevice, h->stream));
+          HIPCHK(h, hipEventRecord(h->ev0, h->stream));
+          launch_bp(S->d_seq, h->ring.p, h->bpjobs.p, h->bpres.p, (int)rj.size(), threads, dp, scope, h->stream);
+          HIPCHK(h, hipGetLastError());
+          HIPCHK(h, hipEventRecord(h->ev1, h->stream));
+          std::vector<BpResult> rr(rj.size());
+          HIPCHK(h, hipMemcpyAsync(rr.data(), h->bpres.p, rr.size() * sizeof(BpResult), hipMemcpyDeviceToHost, h->stream));
+          HIPCHK(h, hipStreamSynchronize(h->stream));
+          float ms = 0;
+          HIPCHK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
+          tm.bp_ms += ms;
+          if (h->call_base) {
+            float t0 = 0;
+            HIPCHK(h, hipEventElapsedTime(&t0, h->call_base, h->ev0));
+            h->bp_iv.emplace_back(t0, t0 + ms);
+          }
+          h->stats.bp_launches++;
+          for (size_t q = 0; q < rest.size(); ++q) res[(size_t)rest[q]] = rr[q];
+          if (getenv("WFM_DEBUG")) {
+            uint64_t c = 0; double t1 = 0, t2 = 0; int64_t st1 = 0, st = 0; uint32_t m1 = 0, m2 = 0;
+            for (const BpResult& r : rr) { c += r.cells; t1 += r.ticks_p1; t2 += r.ticks_p2; st1 += r.steps_p1; st += r.steps; m1 = std::max(m1, r.ticks_p1); m2 = std::max(m2, r.ticks_p2); }
+            fprintf(stderr, "[wfm] level %u: %zu bp jobs (step kernel), %d thr, %.3f ms, cells %.3e, avg steps p1 %.0f p2 %.0f, avg ms p1 %.3f p2 %.3f, max ms p1 %.3f p2 %.3f\n", level, rr.size(), threads, ms,
+                    (double)c, (double)st1 / rr.size(), (double)(st - st1) / rr.size(), t1 / rr.size() / 1e5, t2 / rr.size() / 1e5, m1 / 1e5, m2 / 1e5);
+          }
+        }
         h->stats.bp_jobs += (uint32_t)jobs.size();
-#ifdef WFM_PROFILE_SECTIONS
-        { long long sc[8]; wfm::read_sections(sc); fprintf(stderr, "[wfm] sections block0 thread0 (cycles): load+compute %lld, extend %lld, store-issue %lld | rows %lld, reduce %lld, barrier %lld | steps %lld\n", sc[0], sc[1], sc[2], sc[3], sc[4], sc[5], sc[6]); }
-#endif
-        if (getenv("WFM_DEBUG")) {
-          uint64_t c = 0; double t1 = 0, t2 = 0; int64_t st1 = 0, st = 0; uint32_t m1 = 0, m2 = 0;
-          for (const BpResult& r : res) { c += r.cells; t1 += r.ticks_p1; t2 += r.ticks_p2; st1 += r.steps_p1; st += r.steps; m1 = std::max(m1, r.ticks_p1); m2 = std::max(m2, r.ticks_p2); }
-          fprintf(stderr, "[wfm] level %u: %zu bp jobs, %d thr, %.3f ms, cells %.3e, avg steps p1 %.0f p2 %.0f, avg ms p1 %.3f p2 %.3f, max ms p1 %.3f p2 %.3f\n", level, jobs.size(), threads, ms,
-                  (double)c, (double)st1 / jobs.size(), (double)(st - st1) / jobs.size(), t1 / jobs.size() / 1e5, t2 / jobs.size() / 1e5, m1 / 1e5, m2 / 1e5);
-        }
         for (size_t q = 0; q < jobs.size(); ++q) {
           const Node nd = bp_nodes[(size_t)node_of[q]];  // a copy: retries are appended to bp_nodes below
           const BpResult& r = res[q];
@@ -803,6 +939,7 @@ void wfm_destroy(wfm_handle_t* h) {
   (void)hipSetDevice(h->device);
   h->ring.release(); h->base32.release(); h->base8.release(); h->rle.release(); h->rle_out.release();
   h->tilejobs.release(); h->tiletasks.release(); h->tilemak.release();
+  h->p2rows.release(); h->p2max.release(); h->p2jobs.release();
   h->bpjobs.release(); h->bpres.release(); h->bsjobs.release(); h->bsres.release();
   h->i64a.release(); h->i64b.release(); h->i64c.release(); h->i32a.release(); h->total.release();
   if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -983,6 +1120,7 @@ int wfm_align_resident(wfm_handle_t* h, const wfm_penalties_t* pen, wfm_seqset_t
     a.cells += b.cells; a.bytes_algorithmic += b.bytes_algorithmic; a.ms_kernels += b.ms_kernels; a.ms_breakpoint += b.ms_breakpoint;
     a.ms_base += b.ms_base; a.levels = std::max(a.levels, b.levels); a.bp_jobs += b.bp_jobs; a.base_jobs += b.base_jobs;
     a.bp_launches += b.bp_launches; a.base_launches += b.base_launches; a.cells_bp += b.cells_bp; a.cells_base += b.cells_base;
+    a.p2_launches += b.p2_launches; a.p2_jobs += b.p2_jobs; a.p2_more += b.p2_more;
     a.cells_tile += b.cells_tile; a.ms_tile += b.ms_tile; a.tile_launches += b.tile_launches; a.tile_tasks += b.tile_tasks;
     a.cells_tile_unique += b.cells_tile_unique;
     iv.insert(iv.end(), h->peers[k - 1]->tile_iv.begin(), h->peers[k - 1]->tile_iv.end());

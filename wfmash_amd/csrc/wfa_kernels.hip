@@ -1363,10 +1363,13 @@ __device__ __forceinline__ int lce_head40(const uint8_t* P, const uint8_t* T, co
   return 40;
 }
 
-template <int C, int NTMAX, int LX, int LA, int LB, int E1, int E2>
+// P2 = true: the phase-2 form (see P2Job in wfa_device.h) -- the two directions start at their own scores (J.tf / J.tr), T
+// is P2K, every row of the core goes to the job's P2 rows with its per-component maxima, and there is no output snapshot.
+template <int C, int NTMAX, int LX, int LA, int LB, int E1, int E2, bool P2 = false>
 __global__ __launch_bounds__(NTMAX) void wfa_tile_reg_kernel(const uint8_t* __restrict__ seq, int32_t* __restrict__ ring_arena,
                                                            const TileJob* __restrict__ jobs, const TileTask* __restrict__ tasks,
-                                                           int32_t* __restrict__ mak_out, int T) {
+                                                           int32_t* __restrict__ mak_out, int T, int32_t* __restrict__ p2_arena = nullptr,
+                                                           int32_t* __restrict__ p2max = nullptr) {
   constexpr int H = LB + 1;  // rows of M the output snapshot must hold: s_end-LB .. s_end
                              // (the overlap test of the step kernel looks LB rows behind the resume score)
   // The default lags x = 5, o1+e1 = 10, o2+e2 = 25 are all multiples of 5: a step only ever reads M rows of
@@ -1381,28 +1384,31 @@ __global__ __launch_bounds__(NTMAX) void wfa_tile_reg_kernel(const uint8_t* __re
   TileTask tk = tasks[blockIdx.x];
   const TileJob J = jobs[tk.job];
   if (!J.active) return;
+  const int sbase = P2 ? (tk.dir == 0 ? J.tf : J.tr) : J.s0;  // score of the snapshot this direction starts from
+  int halo = T;  // columns computed on either side of the core (the trapezoid loses one per step)
   {  // tasks carry (tile index, tile width): this block's diagonal range [-s1, s1], clipped to the problem, is cut
      // into tiles from its own left end, so every tile but the last is full
-    const int s1 = J.s0 + T;
+    const int s1 = sbase + T;
     const int L = max(-J.pl, -s1), R = min(J.tl, s1);
     const int idx = tk.core_lo, core = tk.core_hi;
     tk.core_lo = L + idx * core;
     tk.core_hi = min(R, tk.core_lo + core - 1);
     if (tk.core_lo > R) return;
+    if (tk.core_lo == L && tk.core_hi == R) halo = 0;  // one tile for the whole range: nothing beside it to take from
   }
   const int dir = tk.dir, tid = threadIdx.x, NT = blockDim.x, lane = tid & 63, wv = tid >> 6, nw = NT >> 6;
   if (tid < 2) s_wlo[tid] = INT32_MAX;
   const uint8_t* P = seq + (dir == 0 ? J.p_fwd : J.p_rev);
   const uint8_t* Tx = seq + (dir == 0 ? J.t_fwd : J.t_rev);
-  const int pl = J.pl, tl = J.tl, s0 = J.s0;
-  const int kA = tk.core_lo - T;
+  const int pl = J.pl, tl = J.tl, s0 = sbase;
+  const int kA = tk.core_lo - halo;
   const int k0 = kA + tid * C;  // first diagonal of this thread
   const int64_t width = J.width;
   const int32_t* rin = ring_arena + J.ring_in + J.koff + (int64_t)dir * 5 * RING * width;
   int32_t* rout = ring_arena + J.ring_out + J.koff + (int64_t)dir * 5 * RING * width;
-  const int kmax = tk.core_hi + T;  // last diagonal of the tile
+  const int kmax = tk.core_hi + halo;  // last diagonal of the tile
   // a job whose meeting point is known runs its last block only up to it (per direction)
-  const int Tn = J.mode == 1 ? (dir == 0 ? J.tf : J.tr) : T;
+  const int Tn = (!P2 && J.mode == 1) ? (dir == 0 ? J.tf : J.tr) : T;
 
   // Mh[c][r][e] = M[sr - 5 e][k0+c], sr = the newest score <= current with (sr - s0) mod 5 == r
   int Mh[C][NCL][DEP];
@@ -1576,8 +1582,30 @@ __global__ __launch_bounds__(NTMAX) void wfa_tile_reg_kernel(const uint8_t* __re
         if (k >= tk.core_lo && k <= tk.core_hi && k >= rng_lo(pl, s) && k <= rng_hi(tl, s)) mak = max(mak, 2 * m - k);
       }
     }
+    if (P2) {
+      // every row of the core is kept: five components into the job's P2 rows, their maxima into p2max
+      int cm[5] = {0, 0, 0, 0, 0};
+      int32_t* prow = p2_arena + J.p2_off + J.koff2 + ((int64_t)(dir * 5) * P2K + (t - 1)) * J.w2;
+      const int64_t cstride = (int64_t)P2K * J.w2;
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        const int k = k0 + c;
+        if (k >= tk.core_lo && k <= tk.core_hi && k >= rng_lo(pl, s) && k <= rng_hi(tl, s)) {
+          prow[C_M * cstride + k] = nM[c]; prow[C_I1 * cstride + k] = nI1[c]; prow[C_I2 * cstride + k] = nI2[c];
+          prow[C_D1 * cstride + k] = nD1[c]; prow[C_D2 * cstride + k] = nD2[c];
+          cm[C_M] = max(cm[C_M], nM[c]); cm[C_I1] = max(cm[C_I1], nI1[c]); cm[C_I2] = max(cm[C_I2], nI2[c]);
+          cm[C_D1] = max(cm[C_D1], nD1[c]); cm[C_D2] = max(cm[C_D2], nD2[c]);
+        }
+      }
+      int32_t* pm = p2max + (((int64_t)tk.job * 2 + dir) * P2ROWS + 25 + t) * 5;
+#pragma unroll
+      for (int cc = 0; cc < 5; ++cc) {
+        const int v = wave_max_dpp63(cm[cc]);
+        if (lane == 63 && v > 0) atomicMax(&pm[cc], v);
+      }
+    }
     // stream the last H rows of I/D of the core to the output snapshot
-    if (t > Tn - H) {
+    if (!P2 && t > Tn - H) {
 #pragma unroll
       for (int c = 0; c < C; ++c) {
         const int k = k0 + c;
@@ -1608,6 +1636,7 @@ __global__ __launch_bounds__(NTMAX) void wfa_tile_reg_kernel(const uint8_t* __re
   // ---- output snapshot: the newest H rows of M for the core ----
   // row s_end - d lives in class (T - d) mod 5 at depth (d - (T - class) mod 5) / 5; T mod 5 is uniform, one
   // compile-time variant per value keeps the history in registers
+  if (P2) return;
   const int s_end = s0 + Tn;
   if (Tn < H) {
     // a short last block: the I/D rows of scores <= s0 that the step kernel still looks at live in the input ring
@@ -1723,6 +1752,205 @@ __global__ __launch_bounds__(64) void wfa_tile_advance_kernel(TileJob* __restric
   jobs[i] = J;
 }
 
+// ---------------------------------------------------------------------------
+// Phase 2 from rows computed ahead (P2Job in wfa_device.h)
+// ---------------------------------------------------------------------------
+// row s of (direction d, component cc), addressable by diagonal: a snapshot row of the ring, or one of the P2 rows
+__device__ __forceinline__ const int32_t* p2_row(const int32_t* ring, const int32_t* p2, const P2Job& J, int d, int cc, int s) {
+  const int sd = d == 0 ? J.sf : J.sr;
+  if (s <= sd) return ring + J.ring_in + J.koff + ((int64_t)((d * 5 + cc) * RING + (s & RMASK))) * J.width;
+  return p2 + J.p2_off + J.koff2 + ((int64_t)((d * 5 + cc) * P2K + (s - sd - 1))) * J.w2;
+}
+__device__ __forceinline__ const int32_t* p2_maxrow(const int32_t* p2max, int job, const P2Job& J, int d, int s) {
+  const int sd = d == 0 ? J.sf : J.sr;
+  return p2max + (((int64_t)job * 2 + d) * P2ROWS + (s - (sd - 25))) * 5;
+}
+// per-component maxima of the snapshot's rows sd-25 .. sd (the rows the P2 tiles compute bring their own)
+__global__ __launch_bounds__(256) void wfa_p2_snapmax_kernel(const int32_t* __restrict__ ring, const P2Job* __restrict__ jobs,
+                                                            int32_t* __restrict__ p2max) {
+  const int job = blockIdx.x / 52, r = blockIdx.x % 52, d = r / 26, back = r % 26;
+  const P2Job J = jobs[job];
+  const int s = (d == 0 ? J.sf : J.sr) - back;
+  __shared__ int s_mx[5];
+  if (threadIdx.x < 5) s_mx[threadIdx.x] = 0;
+  __syncthreads();
+  int mx[5] = {0, 0, 0, 0, 0};
+  if (s >= 0) {
+    const int lo = rng_lo(J.pl, s), hi = rng_hi(J.tl, s);
+    const int32_t* row[5];
+#pragma unroll
+    for (int cc = 0; cc < 5; ++cc) row[cc] = ring + J.ring_in + J.koff + ((int64_t)((d * 5 + cc) * RING + (s & RMASK))) * J.width;
+    const int c_lo = (lo + J.koff) >> 2, c_hi = (hi + J.koff) >> 2;
+    for (int ch = c_lo + (int)threadIdx.x; ch <= c_hi; ch += (int)blockDim.x) {
+      const int k0 = (ch << 2) - J.koff;
+      v4i v[5];
+#pragma unroll
+      for (int cc = 0; cc < 5; ++cc) v[cc] = *reinterpret_cast<const v4i_u*>(row[cc] + k0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (k0 + j >= lo && k0 + j <= hi) {
+#pragma unroll
+          for (int cc = 0; cc < 5; ++cc) mx[cc] = max(mx[cc], v[cc][j]);
+        }
+    }
+  }
+#pragma unroll
+  for (int cc = 0; cc < 5; ++cc) {
+    const int v = wave_max_dpp63(mx[cc]);
+    if ((threadIdx.x & 63) == 63 && v > 0) atomicMax(&s_mx[cc], v);
+  }
+  __syncthreads();
+  if (threadIdx.x < 5) p2max[(((int64_t)job * 2 + d) * P2ROWS + (25 - back)) * 5 + threadIdx.x] = s_mx[threadIdx.x];
+}
+
+// wavefront_bialign_find_breakpoint's second loop over rows that are all there already: one workgroup per job walks the
+// tests in the reference's order -- the data-parallel half of a test (smallest diagonal per (row of the other direction,
+// component) on which the offsets meet, pruned by the best breakpoint so far and by the row maxima) and one lane's replay of
+// the nested conditions, exactly as wfa_bp_kernel does them -- but no row is computed between two tests.
+__global__ __launch_bounds__(1024) void wfa_p2_overlap_kernel(const int32_t* __restrict__ ring, const int32_t* __restrict__ p2,
+                                                             const P2Job* __restrict__ jobs, const int32_t* __restrict__ p2max,
+                                                             BpResult* __restrict__ results, DevPen pen, int scope) {
+  const int job = blockIdx.x, tid = threadIdx.x;
+  const P2Job J = jobs[job];
+  __shared__ int s_mink[P2ENT];
+  __shared__ int s_bp[8];
+  __shared__ int s_rmax[2][P2ROWS][5];
+  for (int i = tid; i < 2 * P2ROWS * 5; i += blockDim.x) ((int*)s_rmax)[i] = p2max[(int64_t)job * 2 * P2ROWS * 5 + i];
+  if (tid < 8) s_bp[tid] = 0;
+  __syncthreads();
+  const int pl = J.pl, tl = J.tl, kinv = tl - pl;
+  const int gopen = max(pen.o1, pen.o2);
+  int sf = J.sf, sr = J.sr, last_fwd = J.last_fwd;
+  int best = INT32_MAX, status = 0;
+  uint64_t cells = 0;
+  for (int u = 0;; ++u) {
+    int d0;  // direction whose newest row is tested, then the OTHER one advances
+    if (last_fwd) {
+      const int min_sr = (sr > scope - 1) ? sr - (scope - 1) : 0;
+      if (sf + min_sr - gopen >= best) break;
+      d0 = 0;
+    } else {
+      const int min_sf = (sf > scope - 1) ? sf - (scope - 1) : 0;
+      if (min_sf + sr - gopen >= best) break;
+      d0 = 1;
+    }
+    if (u >= P2TESTS) { status = WFM_DEV_P2_MORE; break; }
+    const int d1 = d0 ^ 1;
+    const int s0 = d0 == 0 ? sf : sr, s1 = d0 == 0 ? sr : sf;
+    const int sd0 = d0 == 0 ? J.sf : J.sr, sd1 = d1 == 0 ? J.sf : J.sr;
+    const int (*mx0)[5] = &s_rmax[d0][s0 - (sd0 - 25)];
+    // ---- candidate pairs of this test (uniform): bit cc of group i set iff (row s1 - i, component cc) can still give a
+    // better breakpoint and the two rows' maxima can reach tl
+    unsigned long long m0 = 0, m1 = 0, m2 = 0;
+    int klo = INT32_MAX, khi = INT32_MIN;
+    int rm1[5] = {0, 0, 0, 0, 0};
+    for (int i = 0; i < scope; ++i) {
+      const int si = s1 - i;
+      if (si < 0) break;
+      if (s0 + si - pen.o2 >= best) continue;
+      const int (*mx1)[5] = &s_rmax[d1][si - (sd1 - 25)];
+      unsigned bits = 0;
+#pragma unroll
+      for (int cc = 0; cc < 5; ++cc) {
+        if (s0 + si - bp_gap_open(pen, cc) >= best) continue;
+        if ((*mx0)[cc] + (*mx1)[cc] < tl) continue;
+        bits |= 1u << cc;
+        rm1[cc] = max(rm1[cc], (*mx1)[cc]);
+      }
+      if (!bits) continue;
+      klo = min(klo, kinv - rng_hi(tl, si)); khi = max(khi, kinv - rng_lo(pl, si));
+      const int sh = i * 5;
+      if (sh < 60) m0 |= (unsigned long long)bits << sh;
+      else if (sh < 120) m1 |= (unsigned long long)bits << (sh - 60);
+      else m2 |= (unsigned long long)bits << (sh - 120);
+    }
+    if (m0 | m1 | m2) {
+      for (int i = tid; i < P2ENT; i += blockDim.x) s_mink[i] = INT32_MAX;
+      __syncthreads();
+      klo = max(klo, rng_lo(pl, s0)); khi = min(khi, rng_hi(tl, s0));
+      const int32_t* r0[5];
+#pragma unroll
+      for (int cc = 0; cc < 5; ++cc) r0[cc] = p2_row(ring, p2, J, d0, cc, s0);
+      const int ko = s0 <= sd0 ? J.koff : J.koff2;  // both multiples of 4: 16-byte chunks of the tested row
+      const int c_lo = (klo + ko) >> 2, c_hi = (khi + ko) >> 2;
+      for (int ch = c_lo + tid; ch <= c_hi; ch += (int)blockDim.x) {
+        const int kb = (ch << 2) - ko;
+        v4i v[5];
+#pragma unroll
+        for (int cc = 0; cc < 5; ++cc) v[cc] = *reinterpret_cast<const v4i_u*>(r0[cc] + kb);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int k0 = kb + j;
+          if (k0 < klo || k0 > khi) continue;
+          const int k1 = kinv - k0;
+          int o0[5];
+          bool reach = false;  // can this diagonal meet ANY active row of the other direction?  (most cannot)
+#pragma unroll
+          for (int cc = 0; cc < 5; ++cc) {
+            o0[cc] = v[cc][j];
+            reach = reach || (o0[cc] >= 0 && o0[cc] + rm1[cc] >= tl);
+          }
+          if (!reach) continue;
+          for (int i = 0; i < scope; ++i) {
+            const int sh = i * 5;
+            const unsigned bits = (unsigned)((sh < 60 ? m0 >> sh : (sh < 120 ? m1 >> (sh - 60) : m2 >> (sh - 120))) & 31ull);
+            if (!bits) continue;
+            const int si = s1 - i;
+            if (k1 < rng_lo(pl, si) || k1 > rng_hi(tl, si)) continue;
+#pragma unroll
+            for (int cc = 0; cc < 5; ++cc) {
+              if (!(bits & (1u << cc))) continue;
+              if (o0[cc] < 0 || o0[cc] + s_rmax[d1][si - (sd1 - 25)][cc] < tl) continue;
+              const int o1 = p2_row(ring, p2, J, d1, cc, si)[k1];
+              if (o0[cc] + o1 >= tl) atomicMin(&s_mink[i * 5 + cc], k0);
+            }
+          }
+        }
+      }
+      __syncthreads();
+      if (tid == 0) {
+        int b = best;
+        const int order[5] = {C_D2, C_I2, C_D1, C_I1, C_M};
+        for (int i = 0; i < scope; ++i) {
+          const int si = s1 - i;
+          if (si < 0) break;
+          for (int oi = 0; oi < 5; ++oi) {
+            const int cc = order[oi];
+            const int gop = bp_gap_open(pen, cc);
+            // nested `continue`s of wavefront_bialign_overlap: a failed test skips the rest of this i
+            if ((oi == 0 || oi == 2 || oi == 4) && s0 + si - gop >= b) break;
+            const int k0 = s_mink[i * 5 + cc];
+            if (k0 == INT32_MAX) continue;
+            if (s0 + si - gop >= b) continue;
+            const int k1 = kinv - k0;
+            b = s0 + si - gop;
+            s_bp[0] = b;
+            if (d0 == 0) { s_bp[1] = s0; s_bp[2] = si; s_bp[3] = k0; s_bp[4] = p2_row(ring, p2, J, 0, cc, s0)[k0]; }
+            else         { s_bp[1] = si; s_bp[2] = s0; s_bp[3] = k1; s_bp[4] = p2_row(ring, p2, J, 0, cc, si)[k1]; }
+            s_bp[5] = cc;
+          }
+        }
+        s_bp[6] = b;
+      }
+      __syncthreads();
+      best = s_bp[6];
+    }
+    // the other direction advances by one row (computed ahead: only the bookkeeping is left)
+    if (d0 == 0) { ++sr; cells += (uint64_t)(rng_hi(tl, sr) - rng_lo(pl, sr) + 1); last_fwd = 0; }
+    else         { ++sf; cells += (uint64_t)(rng_hi(tl, sf) - rng_lo(pl, sf) + 1); last_fwd = 1; }
+  }
+  if (tid == 0) {
+    BpResult r;
+    r.status = status;
+    r.score = best; r.score_fwd = s_bp[1]; r.score_rev = s_bp[2]; r.k_fwd = s_bp[3]; r.off_fwd = s_bp[4]; r.comp = s_bp[5];
+    r.steps = sf + sr;
+    r.cells = cells;
+    r.steps_p1 = J.sf + J.sr;
+    r.ticks_p1 = 0; r.ticks_p2 = 0; r.pad_ = 0;
+    results[job] = r;
+  }
+}
+
 #ifdef WFM_PROFILE_SECTIONS
 void read_sections(long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sec), sizeof(long long) * 8); }
 #endif
@@ -1752,6 +1980,19 @@ void launch_tile_reg(const uint8_t* seq, int32_t* ring, const TileJob* jobs, con
   const size_t lds = (size_t)(T + 1) * 4;
   if (C == 4) hipLaunchKernelGGL((wfa_tile_reg_kernel<4, 256, 5, 10, 25, 2, 1>), dim3(ntasks), dim3(threads), lds, st, seq, ring, jobs, tasks, mak, T);
   else hipLaunchKernelGGL((wfa_tile_reg_kernel<2, 1024, 5, 10, 25, 2, 1>), dim3(ntasks), dim3(threads), lds, st, seq, ring, jobs, tasks, mak, T);
+}
+void launch_tile_p2(const uint8_t* seq, int32_t* ring, const TileJob* jobs, const TileTask* tasks, int ntasks, int threads,
+                    int32_t* p2, int32_t* p2max, hipStream_t st) {
+  const size_t lds = (size_t)(P2K + 1) * 4;
+  hipLaunchKernelGGL((wfa_tile_reg_kernel<2, 1024, 5, 10, 25, 2, 1, true>), dim3(ntasks), dim3(threads), lds, st, seq, ring, jobs, tasks,
+                     (int32_t*)nullptr, P2K, p2, p2max);
+}
+void launch_p2_snapmax(const int32_t* ring, const P2Job* jobs, int32_t* p2max, int njobs, hipStream_t st) {
+  hipLaunchKernelGGL(wfa_p2_snapmax_kernel, dim3(njobs * 52), dim3(256), 0, st, ring, jobs, p2max);
+}
+void launch_p2_overlap(const int32_t* ring, const int32_t* p2, const P2Job* jobs, const int32_t* p2max, BpResult* res, int njobs, int threads,
+                       DevPen pen, int scope, hipStream_t st) {
+  hipLaunchKernelGGL(wfa_p2_overlap_kernel, dim3(njobs), dim3(threads), 0, st, ring, p2, jobs, p2max, res, pen, scope);
 }
 void launch_base(const uint8_t* seq, int32_t* a32, uint8_t* a8, uint32_t* rle, const BaseJob* jobs, BaseResult* res,
                  int njobs, DevPen pen, hipStream_t st) {
