@@ -41,7 +41,8 @@ typedef struct {
   uint64_t written;      /* PAF lines written */
   uint64_t skipped;      /* invalid rows */
   uint64_t cells;        /* wavefront cells computed on the GPU */
-  double   ms_gpu, ms_total;
+  double   ms_gpu;       /* time during which an align kernel was running (union over the streams; the busiest device of a multi-GPU run) */
+  double   ms_total;
 } wfmh_align_summary_t;
 
 void wfmh_align_default_params(wfmh_align_params_t* p);

@@ -76,7 +76,10 @@ struct TileJob {
 // `scope` rows of the other" and "advance the other direction by one row" until no better breakpoint is possible
 // -- about 2 * scope rows past the meeting point.  The rows do not depend on the tests, so they are computed ahead:
 // the tile kernel runs P2K more scores of both directions from the exact snapshot and keeps EVERY row (five components,
-// [dir][comp][P2K][w2]); wfa_p2_overlap_kernel then walks the reference's loop, one workgroup per job, with nothing but
+// [dir][comp][P2K][w2]); wfa_p2_blockmax_kernel takes the maxima of every row per component and per block of 64
+// diagonals (a pair of rows can only meet where both are far along: the block maxima prune by POSITION, which the row
+// maxima cannot -- a direction that has already crossed most of the text would otherwise let every diagonal of the other
+// through); wfa_p2_overlap_kernel then walks the reference's loop, one workgroup per job, with nothing but
 // the tests left in it (doing all tests of a job side by side was tried: without the best breakpoint so far to prune
 // with, the tests after the first hit cost more than the whole sequential walk).  A job whose loop has not ended after
 // 2 * P2K tests (WFM_DEV_P2_MORE) is finished by wfa_bp_kernel from the same snapshot.
@@ -91,7 +94,8 @@ struct P2Job {
   int32_t w2, koff2;                   // P2 geometry: column = k + koff2
   int32_t pl, tl;
   int32_t sf, sr, last_fwd;            // state at the meeting point
-  int32_t pad_;
+  int32_t nblk;                        // 64-diagonal blocks of a row: block of diagonal k = (k + koff2) >> 6
+  int64_t bm_off;                      // int32 element offset of the job's block maxima [dir][P2ROWS][comp][nblk]
 };
 struct TileTask {
   int32_t job, dir;
@@ -141,10 +145,10 @@ void launch_tile_reg(const uint8_t* seq, int32_t* ring, const TileJob* jobs, con
                      int threads, int T, int C, hipStream_t st);
 // phase-2 rows of the jobs in mode 4 (T = P2K scores, two diagonals per thread), their per-row maxima into p2max
 void launch_tile_p2(const uint8_t* seq, int32_t* ring, const TileJob* jobs, const TileTask* tasks, int ntasks, int threads,
-                    int32_t* p2, int32_t* p2max, hipStream_t st);
-void launch_p2_snapmax(const int32_t* ring, const P2Job* jobs, int32_t* p2max, int njobs, hipStream_t st);
-void launch_p2_overlap(const int32_t* ring, const int32_t* p2, const P2Job* jobs, const int32_t* p2max, BpResult* res, int njobs, int threads,
-                       DevPen pen, int scope, hipStream_t st);
+                    int32_t* p2, hipStream_t st);
+void launch_p2_blockmax(const int32_t* ring, const int32_t* p2, const P2Job* jobs, int32_t* bmax, int32_t* p2max, int njobs, hipStream_t st);
+void launch_p2_overlap(const int32_t* ring, const int32_t* p2, const P2Job* jobs, const int32_t* p2max, const int32_t* bmax, int32_t* pbmax,
+                       BpResult* res, int njobs, int threads, int max_nblk, DevPen pen, int scope, hipStream_t st);
 void launch_base(const uint8_t* seq, int32_t* a32, uint8_t* a8, uint32_t* rle, const BaseJob* jobs, BaseResult* res,
                  int njobs, DevPen pen, hipStream_t st);
 void launch_compact(const uint32_t* rle, const int64_t* off, const int64_t* cap, uint32_t* out, unsigned long long* total,

@@ -24,6 +24,7 @@
 #ifdef WFM_PROFILE_SECTIONS
 namespace wfm { void read_sections(long long* out); }
 #endif
+namespace wfm { void p2_counters(unsigned long long* out); }
 namespace {
 
 using namespace wfm;
@@ -110,7 +111,7 @@ struct wfm_handle {
   DevBuf<TileJob> tilejobs;
   DevBuf<TileTask> tiletasks;
   DevBuf<int32_t> tilemak;
-  DevBuf<int32_t> p2rows, p2max;  // phase 2 from rows computed ahead (P2Job)
+  DevBuf<int32_t> p2rows, p2max, p2bmax, p2pbmax;  // phase 2 from rows computed ahead (P2Job)
   DevBuf<P2Job> p2jobs;
   DevBuf<BpResult> bpres;
   DevBuf<BaseJob> bsjobs;
@@ -481,15 +482,16 @@ int run_p2_phase(wfm_handle* h, wfm_seqset* S, const DevPen& dp, int scope, cons
   const size_t budget = std::max<size_t>(h->mem_budget / 4, (size_t)64 << 20);
   while (i0 < cand.size()) {
     tj.clear(); pj.clear(); tasks.clear();
-    size_t elems = 0, i = i0, maxw2 = 0;
+    size_t elems = 0, i = i0, maxw2 = 0, bm_elems = 0;
     for (; i < cand.size(); ++i) {
       const BpJob& j = jobs[(size_t)cand[i]];
       const int reach = std::max(j.resume_s, j.resume_sr) + P2K;
       const int L = std::max(-j.pl, -reach), R = std::min(j.tl, reach);
       const int koff2 = ((-L + 4) + 3) & ~3;                       // column of diagonal 0: a multiple of 4, >= 4 columns of margin
       const size_t w2 = ((size_t)(R + koff2 + 8) + 3) & ~(size_t)3;
-      const size_t need = w2 * 2 * 5 * P2K;
-      if (!tj.empty() && (elems + need) * 4 > budget) break;
+      const size_t nblk = (w2 >> 6) + 1;
+      const size_t need = w2 * 2 * 5 * P2K, need_bm = nblk * 2 * P2ROWS * 5;
+      if (!tj.empty() && (elems + need + 2 * (bm_elems + need_bm)) * 4 > budget) break;
       maxw2 = std::max(maxw2, w2);
       TileJob t{};
       t.p_fwd = j.p_fwd; t.t_fwd = j.t_fwd; t.p_rev = j.p_rev; t.t_rev = j.t_rev;
@@ -500,7 +502,9 @@ int run_p2_phase(wfm_handle* h, wfm_seqset* S, const DevPen& dp, int scope, cons
       t.p2_off = (int64_t)elems; t.w2 = (int32_t)w2; t.koff2 = koff2;
       P2Job q{};
       q.ring_in = j.ring_off; q.p2_off = (int64_t)elems; q.width = j.width; q.koff = j.koff; q.w2 = (int32_t)w2; q.koff2 = koff2;
-      q.pl = j.pl; q.tl = j.tl; q.sf = j.resume_s; q.sr = j.resume_sr; q.last_fwd = j.last_fwd; q.pad_ = 0;
+      q.pl = j.pl; q.tl = j.tl; q.sf = j.resume_s; q.sr = j.resume_sr; q.last_fwd = j.last_fwd;
+      q.nblk = (int32_t)nblk; q.bm_off = (int64_t)bm_elems;
+      bm_elems += need_bm;
       elems += need;
       tj.push_back(t); pj.push_back(q);
     }
@@ -525,19 +529,18 @@ int run_p2_phase(wfm_handle* h, wfm_seqset* S, const DevPen& dp, int scope, cons
         const int ntiles = (Rd - Ld + core_c) / core_c;
         for (int t2 = 0; t2 < ntiles; ++t2) tasks.push_back(TileTask{(int32_t)jn, d, t2, core_c});
       }
-    if (h->p2rows.ensure(elems + 16) || h->p2max.ensure(n * 2 * P2ROWS * 5) ||
+    if (h->p2rows.ensure(elems + 16) || h->p2max.ensure(n * 2 * P2ROWS * 5) || h->p2bmax.ensure(bm_elems + 16) || h->p2pbmax.ensure(bm_elems + 16) ||
         h->p2jobs.ensure(n) || h->tilejobs.ensure(n) || h->tiletasks.ensure(tasks.size()) || h->bpres.ensure(std::max(n, jobs.size()))) {
       h->err = "out of device memory (phase-2 rows)"; return WFM_E_NOMEM;
     }
     HIPCHK(h, hipMemcpyAsync(h->tilejobs.p, tj.data(), n * sizeof(TileJob), hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemcpyAsync(h->p2jobs.p, pj.data(), n * sizeof(P2Job), hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemcpyAsync(h->tiletasks.p, tasks.data(), tasks.size() * sizeof(TileTask), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipMemsetAsync(h->p2max.p, 0, n * 2 * P2ROWS * 5 * sizeof(int32_t), h->stream));
     HIPCHK(h, hipEventRecord(h->ev0, h->stream));
-    launch_tile_p2(S->d_seq, h->ring.p, h->tilejobs.p, h->tiletasks.p, (int)tasks.size(), threads_c, h->p2rows.p, h->p2max.p, h->stream);
-    launch_p2_snapmax(h->ring.p, h->p2jobs.p, h->p2max.p, (int)n, h->stream);
-    launch_p2_overlap(h->ring.p, h->p2rows.p, h->p2jobs.p, h->p2max.p, h->bpres.p, (int)n, maxw2 <= 4096 ? 256 : (maxw2 <= 32768 ? 512 : 1024), dp,
-                      scope, h->stream);
+    launch_tile_p2(S->d_seq, h->ring.p, h->tilejobs.p, h->tiletasks.p, (int)tasks.size(), threads_c, h->p2rows.p, h->stream);
+    launch_p2_blockmax(h->ring.p, h->p2rows.p, h->p2jobs.p, h->p2bmax.p, h->p2max.p, (int)n, h->stream);
+    launch_p2_overlap(h->ring.p, h->p2rows.p, h->p2jobs.p, h->p2max.p, h->p2bmax.p, h->p2pbmax.p, h->bpres.p, (int)n,
+                      maxw2 <= 4096 ? 256 : (maxw2 <= 32768 ? 512 : 1024), (int)(maxw2 >> 6) + 1, dp, scope, h->stream);
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipEventRecord(h->ev1, h->stream));
     got.resize(n);
@@ -807,6 +810,12 @@ int align_resident_impl(wfm_handle* h, const wfm_penalties_t* pen, wfm_seqset* S
     }
   }
   h->stats.levels = level;
+  if (getenv("WFM_P2_COUNT") && atoi(getenv("WFM_P2_COUNT"))) {
+    unsigned long long c[8];
+    wfm::p2_counters(c);
+    fprintf(stderr, "[wfm] p2 overlap (cumulative): tests %llu, with candidates %llu, blocks looked at %llu, passing %llu, diagonals reaching %llu, o1 loads %llu, hits %llu\n",
+            c[0], c[1], c[2], c[3], c[4], c[5], c[6]);
+  }
   if (getenv("WFM_DEBUG") && band_jobs) fprintf(stderr, "[wfm] narrow rings: %llu jobs, %llu ran out of their band and were run again on full rings\n", (unsigned long long)band_jobs, (unsigned long long)band_retries);
   const auto t_levels = std::chrono::steady_clock::now();
 
@@ -939,7 +948,7 @@ void wfm_destroy(wfm_handle_t* h) {
   (void)hipSetDevice(h->device);
   h->ring.release(); h->base32.release(); h->base8.release(); h->rle.release(); h->rle_out.release();
   h->tilejobs.release(); h->tiletasks.release(); h->tilemak.release();
-  h->p2rows.release(); h->p2max.release(); h->p2jobs.release();
+  h->p2rows.release(); h->p2max.release(); h->p2bmax.release(); h->p2pbmax.release(); h->p2jobs.release();
   h->bpjobs.release(); h->bpres.release(); h->bsjobs.release(); h->bsres.release();
   h->i64a.release(); h->i64b.release(); h->i64c.release(); h->i32a.release(); h->total.release();
   if (h->ev0) (void)hipEventDestroy(h->ev0);

@@ -19,6 +19,7 @@
 // an out-of-bounds I/D offset can only feed out-of-bounds cells.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <cstdlib>
 #include <type_traits>
 
 #include "wfa_device.h"
@@ -1583,8 +1584,7 @@ __global__ __launch_bounds__(NTMAX) void wfa_tile_reg_kernel(const uint8_t* __re
       }
     }
     if (P2) {
-      // every row of the core is kept: five components into the job's P2 rows, their maxima into p2max
-      int cm[5] = {0, 0, 0, 0, 0};
+      // every row of the core is kept: five components into the job's P2 rows
       int32_t* prow = p2_arena + J.p2_off + J.koff2 + ((int64_t)(dir * 5) * P2K + (t - 1)) * J.w2;
       const int64_t cstride = (int64_t)P2K * J.w2;
 #pragma unroll
@@ -1593,15 +1593,7 @@ __global__ __launch_bounds__(NTMAX) void wfa_tile_reg_kernel(const uint8_t* __re
         if (k >= tk.core_lo && k <= tk.core_hi && k >= rng_lo(pl, s) && k <= rng_hi(tl, s)) {
           prow[C_M * cstride + k] = nM[c]; prow[C_I1 * cstride + k] = nI1[c]; prow[C_I2 * cstride + k] = nI2[c];
           prow[C_D1 * cstride + k] = nD1[c]; prow[C_D2 * cstride + k] = nD2[c];
-          cm[C_M] = max(cm[C_M], nM[c]); cm[C_I1] = max(cm[C_I1], nI1[c]); cm[C_I2] = max(cm[C_I2], nI2[c]);
-          cm[C_D1] = max(cm[C_D1], nD1[c]); cm[C_D2] = max(cm[C_D2], nD2[c]);
         }
-      }
-      int32_t* pm = p2max + (((int64_t)tk.job * 2 + dir) * P2ROWS + 25 + t) * 5;
-#pragma unroll
-      for (int cc = 0; cc < 5; ++cc) {
-        const int v = wave_max_dpp63(cm[cc]);
-        if (lane == 63 && v > 0) atomicMax(&pm[cc], v);
       }
     }
     // stream the last H rows of I/D of the core to the output snapshot
@@ -1765,55 +1757,94 @@ __device__ __forceinline__ const int32_t* p2_maxrow(const int32_t* p2max, int jo
   const int sd = d == 0 ? J.sf : J.sr;
   return p2max + (((int64_t)job * 2 + d) * P2ROWS + (s - (sd - 25))) * 5;
 }
-// per-component maxima of the snapshot's rows sd-25 .. sd (the rows the P2 tiles compute bring their own)
-__global__ __launch_bounds__(256) void wfa_p2_snapmax_kernel(const int32_t* __restrict__ ring, const P2Job* __restrict__ jobs,
-                                                            int32_t* __restrict__ p2max) {
-  const int job = blockIdx.x / 52, r = blockIdx.x % 52, d = r / 26, back = r % 26;
+// Maxima of every row of the phase-2 window (the snapshot's rows sd-25 .. sd from the ring, sd+1 .. sd+P2K from the P2 rows):
+// per component over the whole row (p2max) and per block of 64 diagonals (bmax).  One workgroup per (job, direction, row),
+// one wave per block at a time.
+__global__ __launch_bounds__(256) void wfa_p2_blockmax_kernel(const int32_t* __restrict__ ring, const int32_t* __restrict__ p2,
+                                                             const P2Job* __restrict__ jobs, int32_t* __restrict__ bmax,
+                                                             int32_t* __restrict__ p2max) {
+  const int job = blockIdx.x / (2 * P2ROWS), r2 = blockIdx.x % (2 * P2ROWS), d = r2 / P2ROWS, r = r2 % P2ROWS;
   const P2Job J = jobs[job];
-  const int s = (d == 0 ? J.sf : J.sr) - back;
+  const int s = (d == 0 ? J.sf : J.sr) - 25 + r;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
   __shared__ int s_mx[5];
   if (threadIdx.x < 5) s_mx[threadIdx.x] = 0;
   __syncthreads();
+  int32_t* bm = bmax + J.bm_off + ((int64_t)(d * P2ROWS + r) * 5) * J.nblk;
   int mx[5] = {0, 0, 0, 0, 0};
-  if (s >= 0) {
-    const int lo = rng_lo(J.pl, s), hi = rng_hi(J.tl, s);
-    const int32_t* row[5];
+  const int lo = s >= 0 ? rng_lo(J.pl, s) : 1, hi = s >= 0 ? rng_hi(J.tl, s) : 0;
+  const int32_t* row[5];
 #pragma unroll
-    for (int cc = 0; cc < 5; ++cc) row[cc] = ring + J.ring_in + J.koff + ((int64_t)((d * 5 + cc) * RING + (s & RMASK))) * J.width;
-    const int c_lo = (lo + J.koff) >> 2, c_hi = (hi + J.koff) >> 2;
-    for (int ch = c_lo + (int)threadIdx.x; ch <= c_hi; ch += (int)blockDim.x) {
-      const int k0 = (ch << 2) - J.koff;
-      v4i v[5];
+  for (int cc = 0; cc < 5; ++cc) row[cc] = s >= 0 ? p2_row(ring, p2, J, d, cc, s) : nullptr;
+  for (int b = wv; b < J.nblk; b += nw) {
+    const int k = (b << 6) - J.koff2 + lane;
+    int v[5] = {0, 0, 0, 0, 0};
+    if (k >= lo && k <= hi) {
 #pragma unroll
-      for (int cc = 0; cc < 5; ++cc) v[cc] = *reinterpret_cast<const v4i_u*>(row[cc] + k0);
+      for (int cc = 0; cc < 5; ++cc) v[cc] = max(row[cc][k], 0);
+    }
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (k0 + j >= lo && k0 + j <= hi) {
-#pragma unroll
-          for (int cc = 0; cc < 5; ++cc) mx[cc] = max(mx[cc], v[cc][j]);
-        }
+    for (int cc = 0; cc < 5; ++cc) {
+      const int m = wave_max_dpp63(v[cc]);
+      if (lane == 63) { bm[(int64_t)cc * J.nblk + b] = m; mx[cc] = max(mx[cc], m); }
     }
   }
+  if (lane == 63) {
 #pragma unroll
-  for (int cc = 0; cc < 5; ++cc) {
-    const int v = wave_max_dpp63(mx[cc]);
-    if ((threadIdx.x & 63) == 63 && v > 0) atomicMax(&s_mx[cc], v);
+    for (int cc = 0; cc < 5; ++cc) if (mx[cc] > 0) atomicMax(&s_mx[cc], mx[cc]);
   }
   __syncthreads();
-  if (threadIdx.x < 5) p2max[(((int64_t)job * 2 + d) * P2ROWS + (25 - back)) * 5 + threadIdx.x] = s_mx[threadIdx.x];
+  if (threadIdx.x < 5) p2max[(((int64_t)job * 2 + d) * P2ROWS + r) * 5 + threadIdx.x] = s_mx[threadIdx.x];
 }
 
 // wavefront_bialign_find_breakpoint's second loop over rows that are all there already: one workgroup per job walks the
 // tests in the reference's order -- the data-parallel half of a test (smallest diagonal per (row of the other direction,
 // component) on which the offsets meet, pruned by the best breakpoint so far and by the row maxima) and one lane's replay of
 // the nested conditions, exactly as wfa_bp_kernel does them -- but no row is computed between two tests.
+// Running maxima of the block maxima over the rows of a direction: pb[row r] = max over rows 0 .. r.  What a test
+// prunes with (whole blocks of the tested row, then single diagonals) must only be an upper bound of what the rows in its
+// scope hold in a block; the rows before them hold less almost everywhere, so the bound loses little and costs one read.
+__global__ __launch_bounds__(256) void wfa_p2_prefixmax_kernel(const P2Job* __restrict__ jobs, const int32_t* __restrict__ bmax,
+                                                              int32_t* __restrict__ pbmax, int njobs) {
+  const int job = blockIdx.y;
+  const P2Job J = jobs[job];
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;  // (direction, component, block)
+  const int per_dir = 5 * J.nblk;
+  if (e >= 2 * per_dir) return;
+  const int d = e / per_dir, rest = e % per_dir;  // rest = cc * nblk + b
+  const int32_t* src = bmax + J.bm_off + (int64_t)d * P2ROWS * per_dir + rest;
+  int32_t* dst = pbmax + J.bm_off + (int64_t)d * P2ROWS * per_dir + rest;
+  int run = 0;
+  for (int r = 0; r < P2ROWS; ++r) {
+    run = max(run, src[(int64_t)r * per_dir]);
+    dst[(int64_t)r * per_dir] = run;
+  }
+}
+
+__device__ unsigned long long g_p2cnt[8];  // WFM_P2_COUNT diagnostics: tests, tests with candidates, blocks looked at, blocks passing, diagonals reaching, o1 loads, hits
+constexpr int P2LIST = 1024;  // blocks of the tested row that can pass the block-level test before the kernel stops listing them
+
+// One test of the loop for one workgroup.  Every stage is spread over the threads; the stages are separated by barriers:
+//   pairs    which (row i of the other direction, component) pairs can still improve the best breakpoint (score) and can
+//            reach tl at all (row maxima)
+//   blocks   which 64-diagonal blocks of the tested row can meet a mirrored block (block maximum of the row against the
+//            running block maxima of the other direction)
+//   cells    the diagonals of those blocks, each against the pairs whose block maximum lets it: smallest diagonal per pair
+//   pick     the pair the reference's nested loop would end up with: smallest score, first in its order among equals
 __global__ __launch_bounds__(1024) void wfa_p2_overlap_kernel(const int32_t* __restrict__ ring, const int32_t* __restrict__ p2,
                                                              const P2Job* __restrict__ jobs, const int32_t* __restrict__ p2max,
-                                                             BpResult* __restrict__ results, DevPen pen, int scope) {
-  const int job = blockIdx.x, tid = threadIdx.x;
+                                                             const int32_t* __restrict__ bmax, const int32_t* __restrict__ pbmax,
+                                                             BpResult* __restrict__ results, DevPen pen, int scope, int count) {
+  const int job = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, nw = blockDim.x >> 6;
   const P2Job J = jobs[job];
+  const int nblk = J.nblk;
+  const int32_t* bmj = bmax + J.bm_off;
+  const int32_t* pbj = pbmax + J.bm_off;
   __shared__ int s_mink[P2ENT];
+  __shared__ int s_act[P2ENT];
   __shared__ int s_bp[8];
+  __shared__ int s_k[4];      // klo, khi of the candidate rows' mirrored ranges; any; number of listed blocks
+  __shared__ int s_list[P2LIST];
   __shared__ int s_rmax[2][P2ROWS][5];
   for (int i = tid; i < 2 * P2ROWS * 5; i += blockDim.x) ((int*)s_rmax)[i] = p2max[(int64_t)job * 2 * P2ROWS * 5 + i];
   if (tid < 8) s_bp[tid] = 0;
@@ -1838,99 +1869,151 @@ __global__ __launch_bounds__(1024) void wfa_p2_overlap_kernel(const int32_t* __r
     const int d1 = d0 ^ 1;
     const int s0 = d0 == 0 ? sf : sr, s1 = d0 == 0 ? sr : sf;
     const int sd0 = d0 == 0 ? J.sf : J.sr, sd1 = d1 == 0 ? J.sf : J.sr;
-    const int (*mx0)[5] = &s_rmax[d0][s0 - (sd0 - 25)];
-    // ---- candidate pairs of this test (uniform): bit cc of group i set iff (row s1 - i, component cc) can still give a
-    // better breakpoint and the two rows' maxima can reach tl
-    unsigned long long m0 = 0, m1 = 0, m2 = 0;
-    int klo = INT32_MAX, khi = INT32_MIN;
-    int rm1[5] = {0, 0, 0, 0, 0};
-    for (int i = 0; i < scope; ++i) {
-      const int si = s1 - i;
-      if (si < 0) break;
-      if (s0 + si - pen.o2 >= best) continue;
-      const int (*mx1)[5] = &s_rmax[d1][si - (sd1 - 25)];
-      unsigned bits = 0;
-#pragma unroll
-      for (int cc = 0; cc < 5; ++cc) {
-        if (s0 + si - bp_gap_open(pen, cc) >= best) continue;
-        if ((*mx0)[cc] + (*mx1)[cc] < tl) continue;
-        bits |= 1u << cc;
-        rm1[cc] = max(rm1[cc], (*mx1)[cc]);
+    const int r0row = s0 - (sd0 - 25);
+    // ---- pairs
+    if (tid == 0) { s_k[0] = INT32_MAX; s_k[1] = INT32_MIN; s_k[2] = 0; s_k[3] = 0; }
+    for (int i = tid; i < P2ENT; i += blockDim.x) { s_mink[i] = INT32_MAX; s_act[i] = 0; }
+    __syncthreads();
+    if (tid < scope * 5) {
+      const int i = tid / 5, cc = tid % 5, si = s1 - i;
+      if (si >= 0 && s0 + si - pen.o2 < best && s0 + si - bp_gap_open(pen, cc) < best &&
+          s_rmax[d0][r0row][cc] + s_rmax[d1][si - (sd1 - 25)][cc] >= tl) {
+        s_act[tid] = 1;
+        atomicMin(&s_k[0], kinv - rng_hi(tl, si));
+        atomicMax(&s_k[1], kinv - rng_lo(pl, si));
+        s_k[2] = 1;
       }
-      if (!bits) continue;
-      klo = min(klo, kinv - rng_hi(tl, si)); khi = max(khi, kinv - rng_lo(pl, si));
-      const int sh = i * 5;
-      if (sh < 60) m0 |= (unsigned long long)bits << sh;
-      else if (sh < 120) m1 |= (unsigned long long)bits << (sh - 60);
-      else m2 |= (unsigned long long)bits << (sh - 120);
     }
-    if (m0 | m1 | m2) {
-      for (int i = tid; i < P2ENT; i += blockDim.x) s_mink[i] = INT32_MAX;
+    __syncthreads();
+    const int any = s_k[2];
+    if (count && tid == 0) { atomicAdd(&g_p2cnt[0], 1ull); if (any) atomicAdd(&g_p2cnt[1], 1ull); }
+    if (any) {
+      const int klo = max(s_k[0], rng_lo(pl, s0)), khi = min(s_k[1], rng_hi(tl, s0));
+      // what the other direction holds per block up to row s1 (running maxima over its rows)
+      const int32_t* pb1 = pbj + ((int64_t)(d1 * P2ROWS + (s1 - (sd1 - 25))) * 5) * nblk;
+      // ---- blocks of the tested row that can meet a mirrored block
+      const int B_lo = (klo + J.koff2) >> 6, B_hi = (khi + J.koff2) >> 6;
+      const int32_t* bm0 = bmj + ((int64_t)(d0 * P2ROWS + r0row) * 5) * nblk;
+      unsigned c_blk = 0, c_pass = 0, c_reach = 0, c_load = 0, c_hit = 0;
+      for (int b0 = B_lo + tid; b0 <= B_hi; b0 += blockDim.x) {
+        const int kb_lo = max(klo, (b0 << 6) - J.koff2), kb_hi = min(khi, (b0 << 6) - J.koff2 + 63);
+        const int b1a = max(0, (kinv - kb_hi + J.koff2) >> 6), b1b = min(nblk - 1, (kinv - kb_lo + J.koff2) >> 6);
+        bool pass = false;
+#pragma unroll
+        for (int cc = 0; cc < 5; ++cc) {
+          int m1 = 0;
+          for (int b1 = b1a; b1 <= b1b; ++b1) m1 = max(m1, pb1[(int64_t)cc * nblk + b1]);
+          pass = pass || (bm0[(int64_t)cc * nblk + b0] + m1 >= tl);
+        }
+        ++c_blk;
+        if (pass) {
+          ++c_pass;
+          const int pos = atomicAdd(&s_k[3], 1);
+          if (pos < P2LIST) s_list[pos] = b0;
+        }
+      }
       __syncthreads();
-      klo = max(klo, rng_lo(pl, s0)); khi = min(khi, rng_hi(tl, s0));
+      // ---- cells: one wave per listed block, one diagonal per lane
+      const int nl = s_k[3];
+      const bool listed = nl <= P2LIST;  // otherwise (never seen): every block of the range
+      const int ntodo = listed ? nl : B_hi - B_lo + 1;
       const int32_t* r0[5];
 #pragma unroll
       for (int cc = 0; cc < 5; ++cc) r0[cc] = p2_row(ring, p2, J, d0, cc, s0);
-      const int ko = s0 <= sd0 ? J.koff : J.koff2;  // both multiples of 4: 16-byte chunks of the tested row
-      const int c_lo = (klo + ko) >> 2, c_hi = (khi + ko) >> 2;
-      for (int ch = c_lo + tid; ch <= c_hi; ch += (int)blockDim.x) {
-        const int kb = (ch << 2) - ko;
-        v4i v[5];
+      for (int li = wv; li < ntodo; li += nw) {
+        const int b0 = listed ? s_list[li] : B_lo + li;
+        const int k0 = (b0 << 6) - J.koff2 + lane;
+        if (k0 < klo || k0 > khi) continue;
+        const int k1 = kinv - k0;
+        const int b1 = (k1 + J.koff2) >> 6;  // block of the mirrored diagonal
+        int o0[5];
+        bool reach = false;  // can this diagonal meet ANY candidate row THERE?
 #pragma unroll
-        for (int cc = 0; cc < 5; ++cc) v[cc] = *reinterpret_cast<const v4i_u*>(r0[cc] + kb);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int k0 = kb + j;
-          if (k0 < klo || k0 > khi) continue;
-          const int k1 = kinv - k0;
-          int o0[5];
-          bool reach = false;  // can this diagonal meet ANY active row of the other direction?  (most cannot)
-#pragma unroll
-          for (int cc = 0; cc < 5; ++cc) {
-            o0[cc] = v[cc][j];
-            reach = reach || (o0[cc] >= 0 && o0[cc] + rm1[cc] >= tl);
-          }
-          if (!reach) continue;
-          for (int i = 0; i < scope; ++i) {
-            const int sh = i * 5;
-            const unsigned bits = (unsigned)((sh < 60 ? m0 >> sh : (sh < 120 ? m1 >> (sh - 60) : m2 >> (sh - 120))) & 31ull);
-            if (!bits) continue;
-            const int si = s1 - i;
-            if (k1 < rng_lo(pl, si) || k1 > rng_hi(tl, si)) continue;
-#pragma unroll
-            for (int cc = 0; cc < 5; ++cc) {
-              if (!(bits & (1u << cc))) continue;
-              if (o0[cc] < 0 || o0[cc] + s_rmax[d1][si - (sd1 - 25)][cc] < tl) continue;
-              const int o1 = p2_row(ring, p2, J, d1, cc, si)[k1];
-              if (o0[cc] + o1 >= tl) atomicMin(&s_mink[i * 5 + cc], k0);
-            }
-          }
+        for (int cc = 0; cc < 5; ++cc) {
+          o0[cc] = r0[cc][k0];
+          reach = reach || (o0[cc] >= 0 && o0[cc] + pb1[(int64_t)cc * nblk + b1] >= tl);
         }
-      }
-      __syncthreads();
-      if (tid == 0) {
-        int b = best;
-        const int order[5] = {C_D2, C_I2, C_D1, C_I1, C_M};
+        if (!reach) continue;
+        ++c_reach;
         for (int i = 0; i < scope; ++i) {
           const int si = s1 - i;
           if (si < 0) break;
-          for (int oi = 0; oi < 5; ++oi) {
-            const int cc = order[oi];
-            const int gop = bp_gap_open(pen, cc);
-            // nested `continue`s of wavefront_bialign_overlap: a failed test skips the rest of this i
-            if ((oi == 0 || oi == 2 || oi == 4) && s0 + si - gop >= b) break;
-            const int k0 = s_mink[i * 5 + cc];
-            if (k0 == INT32_MAX) continue;
-            if (s0 + si - gop >= b) continue;
-            const int k1 = kinv - k0;
-            b = s0 + si - gop;
-            s_bp[0] = b;
-            if (d0 == 0) { s_bp[1] = s0; s_bp[2] = si; s_bp[3] = k0; s_bp[4] = p2_row(ring, p2, J, 0, cc, s0)[k0]; }
-            else         { s_bp[1] = si; s_bp[2] = s0; s_bp[3] = k1; s_bp[4] = p2_row(ring, p2, J, 0, cc, si)[k1]; }
-            s_bp[5] = cc;
+          if (k1 < rng_lo(pl, si) || k1 > rng_hi(tl, si)) continue;
+#pragma unroll
+          for (int cc = 0; cc < 5; ++cc) {
+            if (!s_act[i * 5 + cc] || o0[cc] < 0) continue;
+            if (o0[cc] + bmj[((int64_t)(d1 * P2ROWS + (si - (sd1 - 25))) * 5 + cc) * nblk + b1] < tl) continue;
+            const int o1 = p2_row(ring, p2, J, d1, cc, si)[k1];
+            ++c_load;
+            if (o0[cc] + o1 >= tl) { atomicMin(&s_mink[i * 5 + cc], k0); ++c_hit; }
           }
         }
-        s_bp[6] = b;
+      }
+      if (count) {
+        atomicAdd(&g_p2cnt[2], (unsigned long long)c_blk); atomicAdd(&g_p2cnt[3], (unsigned long long)c_pass);
+        atomicAdd(&g_p2cnt[4], (unsigned long long)c_reach); atomicAdd(&g_p2cnt[5], (unsigned long long)c_load);
+        atomicAdd(&g_p2cnt[6], (unsigned long long)c_hit);
+      }
+      __syncthreads();
+      // ---- pick.  The reference walks i = 0 .. scope-1 and, inside, D2, I2, D1, I1, M; it takes a hit when its score is
+      // STRICTLY below the best so far (and skips ahead once a gap-open class can no longer beat it): with o2 >= o1 >= 0 the
+      // walk ends on the hit of smallest score, the first in that order among equals -- a minimum over (score, position)
+      if (wv == 0) {
+        long long key = INT64_MAX;
+        if (pen.o2 >= pen.o1) {
+#pragma unroll
+          for (int q = 0; q < 3; ++q) {
+            const int pr = lane + 64 * q;
+            if (pr < scope * 5 && s_mink[pr] != INT32_MAX) {
+              const int i = pr / 5, cc = pr % 5, si = s1 - i;
+              const int sc = s0 + si - bp_gap_open(pen, cc);
+              const int oi = cc == C_D2 ? 0 : (cc == C_I2 ? 1 : (cc == C_D1 ? 2 : (cc == C_I1 ? 3 : 4)));
+              if (sc < best) key = min(key, ((long long)sc << 16) | (long long)(i * 5 + oi));
+            }
+          }
+#pragma unroll
+          for (int dlt = 32; dlt >= 1; dlt >>= 1) {
+            const long long o = __shfl_xor(key, dlt, 64);
+            key = min(key, o);
+          }
+          if (lane == 0) {
+            int b = best;
+            if (key != INT64_MAX) {
+              const int pos = (int)(key & 0xffff), i = pos / 5, oi = pos % 5, si = s1 - i;
+              const int order[5] = {C_D2, C_I2, C_D1, C_I1, C_M};
+              const int cc = order[oi];
+              const int k0 = s_mink[i * 5 + cc], k1 = kinv - k0;
+              b = (int)(key >> 16);
+              s_bp[0] = b;
+              if (d0 == 0) { s_bp[1] = s0; s_bp[2] = si; s_bp[3] = k0; s_bp[4] = p2_row(ring, p2, J, 0, cc, s0)[k0]; }
+              else         { s_bp[1] = si; s_bp[2] = s0; s_bp[3] = k1; s_bp[4] = p2_row(ring, p2, J, 0, cc, si)[k1]; }
+              s_bp[5] = cc;
+            }
+            s_bp[6] = b;
+          }
+        } else if (lane == 0) {  // unusual penalties: the walk itself
+          int b = best;
+          const int order[5] = {C_D2, C_I2, C_D1, C_I1, C_M};
+          for (int i = 0; i < scope; ++i) {
+            const int si = s1 - i;
+            if (si < 0) break;
+            for (int oi = 0; oi < 5; ++oi) {
+              const int cc = order[oi];
+              const int gop = bp_gap_open(pen, cc);
+              if ((oi == 0 || oi == 2 || oi == 4) && s0 + si - gop >= b) break;
+              const int k0 = s_mink[i * 5 + cc];
+              if (k0 == INT32_MAX) continue;
+              if (s0 + si - gop >= b) continue;
+              const int k1 = kinv - k0;
+              b = s0 + si - gop;
+              s_bp[0] = b;
+              if (d0 == 0) { s_bp[1] = s0; s_bp[2] = si; s_bp[3] = k0; s_bp[4] = p2_row(ring, p2, J, 0, cc, s0)[k0]; }
+              else         { s_bp[1] = si; s_bp[2] = s0; s_bp[3] = k1; s_bp[4] = p2_row(ring, p2, J, 0, cc, si)[k1]; }
+              s_bp[5] = cc;
+            }
+          }
+          s_bp[6] = b;
+        }
       }
       __syncthreads();
       best = s_bp[6];
@@ -1982,18 +2065,21 @@ void launch_tile_reg(const uint8_t* seq, int32_t* ring, const TileJob* jobs, con
   else hipLaunchKernelGGL((wfa_tile_reg_kernel<2, 1024, 5, 10, 25, 2, 1>), dim3(ntasks), dim3(threads), lds, st, seq, ring, jobs, tasks, mak, T);
 }
 void launch_tile_p2(const uint8_t* seq, int32_t* ring, const TileJob* jobs, const TileTask* tasks, int ntasks, int threads,
-                    int32_t* p2, int32_t* p2max, hipStream_t st) {
+                    int32_t* p2, hipStream_t st) {
   const size_t lds = (size_t)(P2K + 1) * 4;
   hipLaunchKernelGGL((wfa_tile_reg_kernel<2, 1024, 5, 10, 25, 2, 1, true>), dim3(ntasks), dim3(threads), lds, st, seq, ring, jobs, tasks,
-                     (int32_t*)nullptr, P2K, p2, p2max);
+                     (int32_t*)nullptr, P2K, p2, (int32_t*)nullptr);
 }
-void launch_p2_snapmax(const int32_t* ring, const P2Job* jobs, int32_t* p2max, int njobs, hipStream_t st) {
-  hipLaunchKernelGGL(wfa_p2_snapmax_kernel, dim3(njobs * 52), dim3(256), 0, st, ring, jobs, p2max);
+void launch_p2_blockmax(const int32_t* ring, const int32_t* p2, const P2Job* jobs, int32_t* bmax, int32_t* p2max, int njobs, hipStream_t st) {
+  hipLaunchKernelGGL(wfa_p2_blockmax_kernel, dim3(njobs * 2 * P2ROWS), dim3(256), 0, st, ring, p2, jobs, bmax, p2max);
 }
-void launch_p2_overlap(const int32_t* ring, const int32_t* p2, const P2Job* jobs, const int32_t* p2max, BpResult* res, int njobs, int threads,
-                       DevPen pen, int scope, hipStream_t st) {
-  hipLaunchKernelGGL(wfa_p2_overlap_kernel, dim3(njobs), dim3(threads), 0, st, ring, p2, jobs, p2max, res, pen, scope);
+void launch_p2_overlap(const int32_t* ring, const int32_t* p2, const P2Job* jobs, const int32_t* p2max, const int32_t* bmax, int32_t* pbmax,
+                       BpResult* res, int njobs, int threads, int max_nblk, DevPen pen, int scope, hipStream_t st) {
+  static const int count = getenv("WFM_P2_COUNT") ? atoi(getenv("WFM_P2_COUNT")) : 0;
+  hipLaunchKernelGGL(wfa_p2_prefixmax_kernel, dim3((2 * 5 * max_nblk + 255) / 256, njobs), dim3(256), 0, st, jobs, bmax, pbmax, njobs);
+  hipLaunchKernelGGL(wfa_p2_overlap_kernel, dim3(njobs), dim3(threads), 0, st, ring, p2, jobs, p2max, bmax, pbmax, res, pen, scope, count);
 }
+void p2_counters(unsigned long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_p2cnt), sizeof(unsigned long long) * 8); }
 void launch_base(const uint8_t* seq, int32_t* a32, uint8_t* a8, uint32_t* rle, const BaseJob* jobs, BaseResult* res,
                  int njobs, DevPen pen, hipStream_t st) {
   hipLaunchKernelGGL(wfa_base_kernel, dim3(njobs), dim3(256), 0, st, seq, a32, a8, rle, jobs, res, pen);

@@ -329,13 +329,17 @@ Summary Aligner::compute() {
       outstream << it->second;
     outstream.flush();
   };
-  std::vector<Summary> part(ngpu);
-  const int threads_each = std::max(1, param.threads / (int)ngpu);
-  auto worker = [&](size_t g) {
+  // two batches per GPU in flight when there are host threads for it: the host stages of one (sequence fetches, CIGAR
+  // surgery, PAF text) run while the device works on the other (calls into a handle are serialised, wflign_hip.cpp)
+  const size_t per_gpu = (size_t)param.threads >= 2 * ngpu ? 2 : 1;
+  const size_t nworkers = ngpu * per_gpu;
+  std::vector<Summary> part(nworkers);
+  const int threads_each = std::max(1, param.threads / (int)nworkers);
+  auto worker = [&](size_t wk) {
     try {
       std::vector<std::string> batch;
       for (int64_t seq; !failed.load() && (seq = read_batch(batch)) >= 0;)
-        write_batch((uint64_t)seq, align_batch(gpus[g], batch, threads_each, part[g]));
+        write_batch((uint64_t)seq, align_batch(gpus[wk % ngpu], batch, threads_each, part[wk]));
     } catch (const std::exception& e) {
       std::lock_guard<std::mutex> lk(write_mu);
       if (first_error.empty()) first_error = e.what();
@@ -344,14 +348,19 @@ Summary Aligner::compute() {
   };
   {
     std::vector<std::thread> pool;
-    for (size_t g = 1; g < ngpu; ++g) pool.emplace_back(worker, g);
+    for (size_t wk = 1; wk < nworkers; ++wk) pool.emplace_back(worker, wk);
     worker(0);
     for (auto& t : pool) t.join();
   }
   if (failed.load()) throw std::runtime_error(first_error);
-  for (const Summary& p : part) {
-    sum.records += p.records; sum.aligned_bp += p.aligned_bp; sum.written += p.written; sum.skipped += p.skipped;
-    sum.cells += p.cells; sum.ms_gpu = std::max(sum.ms_gpu, p.ms_gpu);
+  {
+    std::vector<double> gpu_ms(ngpu, 0.0);  // per device: its workers' busy times add up (they take turns on it)
+    for (size_t wk = 0; wk < nworkers; ++wk) {
+      const Summary& p = part[wk];
+      sum.records += p.records; sum.aligned_bp += p.aligned_bp; sum.written += p.written; sum.skipped += p.skipped;
+      sum.cells += p.cells; gpu_ms[wk % ngpu] += p.ms_gpu;
+    }
+    sum.ms_gpu = *std::max_element(gpu_ms.begin(), gpu_ms.end());
   }
   outstream.close();
   sum.ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();

@@ -9,6 +9,9 @@
 #include <cctype>
 #include <cmath>
 #include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
 #include <sstream>
 
 namespace wflign {
@@ -396,6 +399,17 @@ void for_each_record(size_t n, int threads, F&& fn) {
   for (auto& t : pool) t.join();
 }
 
+// A handle runs one batch at a time; several host threads may feed the same GPU (the align driver keeps two batches
+// per device in flight so that the host stages of one overlap the device stages of the other): calls are serialised here.
+std::mutex& handle_lock(wfm_handle_t* h) {
+  static std::mutex reg;
+  static std::map<wfm_handle_t*, std::unique_ptr<std::mutex>> locks;
+  std::lock_guard<std::mutex> lk(reg);
+  auto& m = locks[h];
+  if (!m) m.reset(new std::mutex());
+  return *m;
+}
+
 struct GpuBatch {
   std::vector<wfm_problem_t> probs;
   std::vector<wfm_result_t> res;
@@ -404,10 +418,11 @@ struct GpuBatch {
     res.assign(probs.size(), wfm_result_t{});
     if (probs.empty()) return 0;
     arena.resize(wfm_align_arena_bytes(probs.data(), probs.size()) + 8);
+    std::lock_guard<std::mutex> lk(handle_lock(h));
     const int rc = wfm_align_batch(h, &pen, probs.data(), probs.size(), res.data(), arena.data(), arena.size());
     if (rc >= 0 && st) {
       wfm_stats_t s;
-      if (wfm_get_stats(h, &s) == WFM_OK) { st->cells += s.cells; st->ms_gpu += s.ms_kernels; }
+      if (wfm_get_stats(h, &s) == WFM_OK) { st->cells += s.cells; st->ms_gpu += s.ms_any_busy; }
     }
     return rc;
   }
