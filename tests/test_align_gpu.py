@@ -270,3 +270,21 @@ def test_c5_full_size_pairs_match_the_oracle_fixture(gpu):
         rle = "".join(f"{len(m.group(0))}{m.group(0)[0]}" for m in re.finditer(r"M+|X+|I+|D+", r.ops.decode()))
         assert rle == want["rle"]
     assert min(w["score"] for w in g["pairs"]) > 90000
+
+
+def test_leaf_that_ends_inside_a_long_gap(gpu, oracle):
+    """A record of the 40 Mbp C4 variant (hap7 9257000-9300000 '-' against hap5) that round 1's kernels dropped with status
+    -300: one BiWFA leaf is 5 x 155 bases and must END inside a D2 gap, so its own forward score (208) exceeds both the
+    score its parent credited it with (184: the gap's opening is counted on the other side of the breakpoint) and the
+    unconstrained all-gap bound the retry loop stopped at (205).  The fixture holds the two sequences and the oracle's answer."""
+    import gzip
+    import hashlib
+    import json
+    import os
+    g = json.load(gzip.open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "leaf_in_gap_pair.json.gz"), "rt"))
+    p, t = g["pattern"].encode(), g["text"].encode()
+    r = gpu.align([(p, t)])[0]
+    assert r.status == 0 and r.score == g["score"] == 3044
+    assert len(r.ops) == g["n_ops"] and hashlib.sha256(r.ops).hexdigest() == g["ops_sha"]
+    rc, ops, sc, _ = oracle.align_biwfa(p, t)
+    assert rc == 0 and ops == r.ops

@@ -135,6 +135,9 @@ struct BaseResult {
   uint64_t cells;
 };
 
+// reversed copies of the sequences of a BiWFA problem, made on the device (wfm_upload_sequences)
+struct SeqRev { int64_t p_fwd, p_rev, t_fwd, t_rev; int32_t plen, tlen; };
+void launch_reverse(uint8_t* seq, const SeqRev* jobs, int njobs, int pad, hipStream_t st);
 void launch_bp(const uint8_t* seq, int32_t* ring, const BpJob* jobs, BpResult* res, int njobs, int threads,
                DevPen pen, int scope, hipStream_t st);
 void launch_tile_init(const uint8_t* seq, int32_t* ring, const TileJob* jobs, int32_t* mak0, int njobs, hipStream_t st);

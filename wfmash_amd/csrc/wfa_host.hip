@@ -113,6 +113,9 @@ struct wfm_handle {
   DevBuf<int32_t> tilemak;
   DevBuf<int32_t> p2rows, p2max, p2bmax, p2pbmax;  // phase 2 from rows computed ahead (P2Job)
   DevBuf<P2Job> p2jobs;
+  DevBuf<SeqRev> revjobs;
+  uint8_t* stage = nullptr;  // pinned staging buffer of wfm_upload_sequences (grow-only)
+  size_t stage_cap = 0;
   DevBuf<BpResult> bpres;
   DevBuf<BaseJob> bsjobs;
   DevBuf<BaseResult> bsres;
@@ -232,11 +235,22 @@ int run_base_jobs(wfm_handle* h, wfm_seqset* S, const wfm_penalties_t& pen, cons
         h->stats.cells_base += r.cells;
         if (r.status == WFM_DEV_OVERFLOW) {
           Node again = nd;
-          const int64_t bound = (int64_t)gapcost(pen, nd.pl) + gapcost(pen, nd.tl) + 8;
-          if (nd.smax >= bound) { prob_status[nd.prob] = WFM_ST_UNREACHABLE; continue; }
+          // No alignment costs more than the all-gap one.  A job whose begin or end component is a gap state is held to a
+          // PIECE there (a BiWFA child that ends inside a D2 gap pays o2 + e2 per base for it, however short it is --
+          // its parent counted that gap's opening on the other side of the breakpoint, so the child's own forward score
+          // exceeds the score_rem it was handed): the bound takes the dearer piece for both gaps then.
+          const bool constrained = nd.cb != C_M || nd.ce != C_M;
+          const int64_t bound = constrained
+              ? (int64_t)2 * std::max(pen.o1, pen.o2) + (int64_t)std::max(pen.e1, pen.e2) * ((int64_t)nd.pl + nd.tl) + 8
+              : (int64_t)gapcost(pen, nd.pl) + gapcost(pen, nd.tl) + 8;
+          if (nd.smax >= bound) {
+            if (getenv("WFM_DEBUG")) fprintf(stderr, "[wfm] problem %d: base job pl %d tl %d cb %d ce %d overflowed its score bound %d\n", nd.prob, nd.pl, nd.tl, nd.cb, nd.ce, nd.smax);
+            prob_status[nd.prob] = WFM_ST_UNREACHABLE; continue;
+          }
           again.smax = (int32_t)std::min<int64_t>((int64_t)nd.smax * 2 + 32, bound);
           retry.push_back(again);
         } else if (r.status != 0) {
+          if (getenv("WFM_DEBUG")) fprintf(stderr, "[wfm] problem %d: base job pl %d tl %d status %d\n", nd.prob, nd.pl, nd.tl, r.status);
           prob_status[nd.prob] = WFM_ST_UNREACHABLE;
         }
       }
@@ -776,10 +790,15 @@ int align_resident_impl(wfm_handle* h, const wfm_penalties_t* pen, wfm_seqset* S
           if (r.status == 1) {  // end reached at score 0 -> base aligner
             Node b = nd; b.smax = 0; base_nodes.push_back(b);
           } else if (r.status != 0) {
+            if (getenv("WFM_DEBUG")) fprintf(stderr, "[wfm] problem %d: bialign job pl %d tl %d cb %d ce %d score_rem %d status %d (steps %d)\n", nd.prob, nd.pl, nd.tl, nd.cb, nd.ce, nd.score_rem, r.status, r.steps);
             prob_status[nd.prob] = WFM_ST_UNREACHABLE;
           } else {
             const int bp_h = r.off_fwd, bp_v = r.off_fwd - r.k_fwd;
-            if (bp_h < 0 || bp_v < 0 || bp_h > nd.tl || bp_v > nd.pl) { prob_status[nd.prob] = WFM_ST_UNREACHABLE; continue; }
+            if (bp_h < 0 || bp_v < 0 || bp_h > nd.tl || bp_v > nd.pl) {
+              if (getenv("WFM_DEBUG")) fprintf(stderr, "[wfm] problem %d: bialign job pl %d tl %d: breakpoint (%d, %d) outside, score %d = %d + %d comp %d k %d\n", nd.prob, nd.pl, nd.tl, bp_v, bp_h, r.score, r.score_fwd, r.score_rev, r.comp, r.k_fwd);
+              prob_status[nd.prob] = WFM_ST_UNREACHABLE; continue;
+            }
+            if (getenv("WFM_DEBUG") && atoi(getenv("WFM_DEBUG")) > 1) fprintf(stderr, "[wfm] problem %d level %u: job pl %d tl %d cb %d ce %d rem %d -> bp v %d h %d score %d = %d + %d comp %d\n", nd.prob, level, nd.pl, nd.tl, nd.cb, nd.ce, nd.score_rem, bp_v, bp_h, r.score, r.score_fwd, r.score_rev, r.comp);
             Node a{}, b{};
             a.prob = nd.prob; a.pb = nd.pb; a.pl = bp_v; a.tb = nd.tb; a.tl = bp_h;
             a.cb = nd.cb; a.ce = r.comp; a.score_rem = r.score_fwd;
@@ -787,7 +806,13 @@ int align_resident_impl(wfm_handle* h, const wfm_penalties_t* pen, wfm_seqset* S
             b.cb = r.comp; b.ce = nd.ce; b.score_rem = r.score_rev;
             for (Node* c : {&a, &b}) {
               if (c->pl == 0 || c->tl == 0) { c->smax = 0; base_nodes.push_back(*c); }
-              else if (c->score_rem <= BIALIGN_FALLBACK_MIN_SCORE) { c->smax = std::max(c->score_rem, 0); base_nodes.push_back(*c); }
+              else if (c->score_rem <= BIALIGN_FALLBACK_MIN_SCORE) {
+                // the leaf's own forward score: what the breakpoint credited it with, plus the opening of a gap it has
+                // to end in (counted on the other side of that breakpoint)
+                const int open_end = c->ce == C_M ? 0 : ((c->ce == C_I1 || c->ce == C_D1) ? pen->o1 : pen->o2);
+                c->smax = std::max(c->score_rem, 0) + open_end;
+                base_nodes.push_back(*c);
+              }
               else next_bp.push_back(*c);
             }
           }
@@ -878,6 +903,7 @@ int align_resident_impl(wfm_handle* h, const wfm_penalties_t* pen, wfm_seqset* S
       k = k2;
     }
     if (pc != (uint64_t)S->meta[gi].plen || tc != (uint64_t)S->meta[gi].tlen) {
+      if (getenv("WFM_DEBUG")) fprintf(stderr, "[wfm] problem %zu: CIGAR spans %llu x %llu, sequences %d x %d\n", gi, (unsigned long long)pc, (unsigned long long)tc, S->meta[gi].plen, S->meta[gi].tlen);
       r.status = WFM_ST_UNREACHABLE;  // internal inconsistency: never report a broken CIGAR as ok
       ++failed;
       continue;
@@ -948,6 +974,8 @@ void wfm_destroy(wfm_handle_t* h) {
   (void)hipSetDevice(h->device);
   h->ring.release(); h->base32.release(); h->base8.release(); h->rle.release(); h->rle_out.release();
   h->tilejobs.release(); h->tiletasks.release(); h->tilemak.release();
+  h->revjobs.release();
+  if (h->stage) { (void)hipHostFree(h->stage); h->stage = nullptr; h->stage_cap = 0; }
   h->p2rows.release(); h->p2max.release(); h->p2bmax.release(); h->p2pbmax.release(); h->p2jobs.release();
   h->bpjobs.release(); h->bpres.release(); h->bsjobs.release(); h->bsres.release();
   h->i64a.release(); h->i64b.release(); h->i64c.release(); h->i32a.release(); h->total.release();
@@ -982,7 +1010,7 @@ int wfm_upload_sequences(wfm_handle_t* h, const wfm_problem_t* problems, size_t 
   HIPCHK(h, hipSetDevice(h->device));
   wfm_seqset* S = new wfm_seqset();
   S->meta.resize(n);
-  size_t bytes = SEQ_PAD;
+  size_t bytes = SEQ_PAD, rev_bytes = 0;
   int64_t rle = 0;
   for (size_t i = 0; i < n; ++i) {
     const wfm_problem_t& p = problems[i];
@@ -994,32 +1022,79 @@ int wfm_upload_sequences(wfm_handle_t* h, const wfm_problem_t* problems, size_t 
     m.pbf = std::min(std::max(p.pattern_begin_free, 0), p.plen); m.pef = std::min(std::max(p.pattern_end_free, 0), p.plen);
     m.tbf = std::min(std::max(p.text_begin_free, 0), p.tlen);    m.tef = std::min(std::max(p.text_end_free, 0), p.tlen);
     if (p.mode != WFM_MODE_ENDSFREE) { m.pbf = m.pef = m.tbf = m.tef = 0; }
+    // forward copies first (the only part that crosses PCIe), the reversed copies of the BiWFA problems behind them
     m.p_fwd = (int64_t)bytes; bytes += (size_t)p.plen + SEQ_PAD;
     m.t_fwd = (int64_t)bytes; bytes += (size_t)p.tlen + SEQ_PAD;
     const bool need_rev = (p.mode == WFM_MODE_END2END_BIWFA);
     if (need_rev) {
-      m.p_rev = (int64_t)bytes; bytes += (size_t)p.plen + SEQ_PAD;
-      m.t_rev = (int64_t)bytes; bytes += (size_t)p.tlen + SEQ_PAD;
-    } else { m.p_rev = m.p_fwd; m.t_rev = m.t_fwd; }
+      m.p_rev = (int64_t)rev_bytes; rev_bytes += (size_t)p.plen + SEQ_PAD;   // relative to the end of the forward part for now
+      m.t_rev = (int64_t)rev_bytes; rev_bytes += (size_t)p.tlen + SEQ_PAD;
+    } else { m.p_rev = -1; m.t_rev = -1; }
     m.rle_off = rle; rle += (int64_t)p.plen + p.tlen + 1;
     S->seq_bases += (uint64_t)p.plen + (uint64_t)p.tlen;
   }
   bytes += SEQ_PAD;
-  std::vector<uint8_t> host(bytes, 0);
+  const size_t fwd_bytes = bytes;
   for (size_t i = 0; i < n; ++i) {
-    const wfm_problem_t& p = problems[i];
-    const ProbMeta& m = S->meta[i];
-    if (p.plen) memcpy(host.data() + m.p_fwd, p.pattern, (size_t)p.plen);
-    if (p.tlen) memcpy(host.data() + m.t_fwd, p.text, (size_t)p.tlen);
-    if (p.mode == WFM_MODE_END2END_BIWFA) {
-      for (int q = 0; q < p.plen; ++q) host[(size_t)m.p_rev + q] = (uint8_t)p.pattern[p.plen - 1 - q];
-      for (int q = 0; q < p.tlen; ++q) host[(size_t)m.t_rev + q] = (uint8_t)p.text[p.tlen - 1 - q];
-    }
+    ProbMeta& m = S->meta[i];
+    if (m.p_rev < 0) { m.p_rev = m.p_fwd; m.t_rev = m.t_fwd; }
+    else { m.p_rev += (int64_t)fwd_bytes; m.t_rev += (int64_t)fwd_bytes; }
+  }
+  bytes = fwd_bytes + rev_bytes + SEQ_PAD;
+  // Only the forward sequences (with their zero padding) are written on the host and cross PCIe; the reversed copies
+  // BiWFA's reverse direction reads are made on the device after the upload (half the bytes, no byte-wise host loop).
+  // The forward part is assembled in a pinned staging buffer kept with the handle, by a few threads.
+  if (h->stage_cap < fwd_bytes) {
+    if (h->stage) (void)hipHostFree(h->stage);
+    h->stage = nullptr; h->stage_cap = 0;
+    const size_t want = fwd_bytes + fwd_bytes / 4 + (1 << 20);
+    if (hipHostMalloc((void**)&h->stage, want, hipHostMallocDefault) != hipSuccess) {
+      (void)hipGetLastError();
+      h->stage = nullptr;
+    } else h->stage_cap = want;
+  }
+  std::vector<uint8_t> pageable;
+  uint8_t* host = h->stage;
+  if (!host) { pageable.resize(fwd_bytes); host = pageable.data(); }
+  {
+    const int nt = (int)std::min<size_t>(8, std::max<size_t>(1, n / 64));
+    auto fill = [&](size_t i0, size_t i1) {
+      for (size_t i = i0; i < i1; ++i) {
+        const wfm_problem_t& p = problems[i];
+        const ProbMeta& m = S->meta[i];
+        // sequence, then SEQ_PAD zero bytes (the extension reads up to 40 bytes past a sub-range end)
+        if (p.plen) memcpy(host + m.p_fwd, p.pattern, (size_t)p.plen);
+        memset(host + m.p_fwd + p.plen, 0, SEQ_PAD);
+        if (p.tlen) memcpy(host + m.t_fwd, p.text, (size_t)p.tlen);
+        memset(host + m.t_fwd + p.tlen, 0, SEQ_PAD);
+      }
+    };
+    memset(host, 0, SEQ_PAD);
+    memset(host + fwd_bytes - SEQ_PAD, 0, SEQ_PAD);
+    std::vector<std::thread> th;
+    for (int t = 1; t < nt; ++t) th.emplace_back(fill, n * (size_t)t / nt, n * (size_t)(t + 1) / nt);
+    fill(0, n / (size_t)nt);
+    for (auto& t : th) t.join();
   }
   if (hipMalloc((void**)&S->d_seq, bytes) != hipSuccess) { delete S; h->err = "out of device memory (sequences)"; return WFM_E_NOMEM; }
   S->bytes = bytes;
   S->rle_total = rle;
-  hipError_t e = hipMemcpy(S->d_seq, host.data(), bytes, hipMemcpyHostToDevice);
+  hipError_t e = hipMemcpyAsync(S->d_seq, host, fwd_bytes, hipMemcpyHostToDevice, h->stream);
+  if (e == hipSuccess) e = hipMemsetAsync(S->d_seq + bytes - SEQ_PAD, 0, SEQ_PAD, h->stream);
+  if (e == hipSuccess) {
+    std::vector<SeqRev> rv;
+    rv.reserve(n);
+    for (size_t i = 0; i < n; ++i) {
+      const ProbMeta& m = S->meta[i];
+      if (problems[i].mode == WFM_MODE_END2END_BIWFA) rv.push_back(SeqRev{m.p_fwd, m.p_rev, m.t_fwd, m.t_rev, m.plen, m.tlen});
+    }
+    if (!rv.empty()) {
+      if (h->revjobs.ensure(rv.size())) e = hipErrorOutOfMemory;
+      if (e == hipSuccess) e = hipMemcpyAsync(h->revjobs.p, rv.data(), rv.size() * sizeof(SeqRev), hipMemcpyHostToDevice, h->stream);
+      if (e == hipSuccess) { launch_reverse(S->d_seq, h->revjobs.p, (int)rv.size(), SEQ_PAD, h->stream); e = hipGetLastError(); }
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+  }
   if (e != hipSuccess) { (void)hipFree(S->d_seq); delete S; h->err = hipGetErrorString(e); return WFM_E_HIP; }
   *out = S;
   return WFM_OK;
@@ -1151,10 +1226,17 @@ int wfm_align_batch(wfm_handle_t* h, const wfm_penalties_t* pen, const wfm_probl
                     wfm_result_t* out, char* ops_arena, size_t arena_bytes) {
   if (!h) return WFM_E_ARG;
   wfm_seqset_t* S = nullptr;
+  const auto t0 = std::chrono::steady_clock::now();
   int rc = wfm_upload_sequences(h, problems, n, &S);
   if (rc != WFM_OK) return rc;
+  const auto t1 = std::chrono::steady_clock::now();
   rc = wfm_align_resident(h, pen, S, out, ops_arena, arena_bytes);
+  const auto t2 = std::chrono::steady_clock::now();
   wfm_free_sequences(h, S);
+  if (getenv("WFM_DEBUG"))
+    fprintf(stderr, "[wfm] align_batch: %zu problems, upload %.2f ms, align %.2f ms, free %.2f ms\n", n,
+            std::chrono::duration<double, std::milli>(t1 - t0).count(), std::chrono::duration<double, std::milli>(t2 - t1).count(),
+            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t2).count());
   return rc;
 }
 

@@ -2034,6 +2034,19 @@ __global__ __launch_bounds__(1024) void wfa_p2_overlap_kernel(const int32_t* __r
   }
 }
 
+// reversed copies of pattern and text behind the forward ones, each followed by `pad` zero bytes
+__global__ __launch_bounds__(256) void seq_reverse_kernel(uint8_t* __restrict__ seq, const SeqRev* __restrict__ jobs, int pad) {
+  const SeqRev J = jobs[blockIdx.x >> 1];
+  const bool text = blockIdx.x & 1;
+  const uint8_t* src = seq + (text ? J.t_fwd : J.p_fwd);
+  uint8_t* dst = seq + (text ? J.t_rev : J.p_rev);
+  const int n = text ? J.tlen : J.plen;
+  for (int q = threadIdx.x; q < n + pad; q += blockDim.x) dst[q] = q < n ? src[n - 1 - q] : (uint8_t)0;
+}
+void launch_reverse(uint8_t* seq, const SeqRev* jobs, int njobs, int pad, hipStream_t st) {
+  hipLaunchKernelGGL(seq_reverse_kernel, dim3(njobs * 2), dim3(256), 0, st, seq, jobs, pad);
+}
+
 #ifdef WFM_PROFILE_SECTIONS
 void read_sections(long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sec), sizeof(long long) * 8); }
 #endif

@@ -5,6 +5,8 @@
 #include <atomic>
 #include <cctype>
 #include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <iostream>
@@ -132,6 +134,9 @@ void Aligner::parseMashmapRow(const std::string& line, MappingBoundaryRow& row, 
 // (computeAlignments.hpp:582-723) for every row, then the records' output text in row order.
 std::string Aligner::align_batch(wfm_handle_t* gpu_handle, std::vector<std::string>& lines, int threads, Summary& sum) {
   std::string out;
+  const bool dbg = getenv("WFM_DEBUG") != nullptr;
+  const auto tb0 = std::chrono::steady_clock::now();
+  auto since = [](std::chrono::steady_clock::time_point a) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count(); };
   wflign::wflign_penalties_t pen;
   pen.match = 0;
   pen.mismatch = param.wfa_patching_mismatch_score;
@@ -163,6 +168,8 @@ std::string Aligner::align_batch(wfm_handle_t* gpu_handle, std::vector<std::stri
     }
   }
   std::vector<std::string>().swap(lines);
+  const double ms_parse = since(tb0);
+  const auto tb1 = std::chrono::steady_clock::now();
   std::vector<std::string> fetch_error(rows.size());
   {
     std::atomic<size_t> next{0};
@@ -224,6 +231,8 @@ std::string Aligner::align_batch(wfm_handle_t* gpu_handle, std::vector<std::stri
     r.mashmap_estimated_identity = f.row.mashmap_estimated_identity;
     r.chain_id = f.row.chain_id; r.chain_length = f.row.chain_length; r.chain_pos = f.row.chain_pos;
   }
+  const double ms_fetch = since(tb1);
+  const auto tb2 = std::chrono::steady_clock::now();
   wflign::BiwfaStats st;
   wflign::OutputFormat fmt;
   fmt.paf_format_else_sam = !param.sam_format;
@@ -233,6 +242,8 @@ std::string Aligner::align_batch(wfm_handle_t* gpu_handle, std::vector<std::stri
   const int rc = wflign::do_biwfa_alignment_batch(gpu_handle, recs, pen, param.disable_chain_patching, pp, &st, fmt);
   if (rc < 0) throw std::runtime_error(std::string("[wfmash::align] GPU alignment failed: ") + wfm_last_error(gpu_handle));
   sum.cells += st.cells; sum.ms_gpu += st.ms_gpu;
+  const double ms_biwfa = since(tb2);
+  const auto tb3 = std::chrono::steady_clock::now();
   for (size_t k = 0; k < recs.size(); ++k) {
     sum.records++;
     sum.aligned_bp += (uint64_t)(fetched[k].row.qEndPos - fetched[k].row.qStartPos);
@@ -246,6 +257,9 @@ std::string Aligner::align_batch(wfm_handle_t* gpu_handle, std::vector<std::stri
     out += nl;
     sum.written++;
   }
+  if (dbg)
+    fprintf(stderr, "[wfmash::align] batch of %zu records on %d threads: rows %.1f ms, fetch %.1f ms, wflign %.1f ms (device busy %.1f), text %.1f ms\n",
+            recs.size(), threads, ms_parse, ms_fetch, ms_biwfa, st.ms_gpu, since(tb3));
   return out;
 }
 
@@ -329,17 +343,25 @@ Summary Aligner::compute() {
       outstream << it->second;
     outstream.flush();
   };
-  // two batches per GPU in flight when there are host threads for it: the host stages of one (sequence fetches, CIGAR
-  // surgery, PAF text) run while the device works on the other (calls into a handle are serialised, wflign_hip.cpp)
-  const size_t per_gpu = (size_t)param.threads >= 2 * ngpu ? 2 : 1;
+  // up to three batches per GPU in flight when there are host threads for it: the host stages of a batch (sequence
+  // fetches, CIGAR surgery, PAF text -- about two thirds of its wall time on C4-like records) run while the device works
+  // on another (calls into a handle are serialised, wflign_hip.cpp)
+  const size_t per_gpu = (size_t)param.threads >= 12 * ngpu ? 3 : ((size_t)param.threads >= 2 * ngpu ? 2 : 1);
   const size_t nworkers = ngpu * per_gpu;
   std::vector<Summary> part(nworkers);
   const int threads_each = std::max(1, param.threads / (int)nworkers);
   auto worker = [&](size_t wk) {
     try {
       std::vector<std::string> batch;
-      for (int64_t seq; !failed.load() && (seq = read_batch(batch)) >= 0;)
-        write_batch((uint64_t)seq, align_batch(gpus[wk % ngpu], batch, threads_each, part[wk]));
+      for (int64_t seq; !failed.load() && (seq = read_batch(batch)) >= 0;) {
+        const double at0 = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        std::string text = align_batch(gpus[wk % ngpu], batch, threads_each, part[wk]);
+        const double at1 = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        write_batch((uint64_t)seq, std::move(text));
+        if (getenv("WFM_DEBUG"))
+          fprintf(stderr, "[wfmash::align] worker %zu: batch %lld from +%.0f ms to +%.0f ms, written at +%.0f ms\n", wk, (long long)seq, at0, at1,
+                  std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+      }
     } catch (const std::exception& e) {
       std::lock_guard<std::mutex> lk(write_mu);
       if (first_error.empty()) first_error = e.what();

@@ -146,6 +146,8 @@ bool FastaStore::open_indexed(const std::string& path) {
   fd_ = fd;
   seqs_.resize(names_.size());
   once_.reset(new std::once_flag[names_.size()]);
+  loaded_.reset(new std::atomic<bool>[names_.size()]);
+  for (size_t i = 0; i < names_.size(); ++i) loaded_[i].store(false, std::memory_order_relaxed);
   return true;
 }
 
@@ -275,6 +277,7 @@ const std::string& FastaStore::sequence(int i) const {
       std::string s;
       read_bases(i, 0, lens_[(size_t)i], s);
       seqs_[(size_t)i] = std::move(s);
+      loaded_[(size_t)i].store(true, std::memory_order_release);  // fetch() may look at seqs_[i] from now on
     });
   return seqs_[(size_t)i];
 }
@@ -305,7 +308,9 @@ std::string FastaStore::fetch(const std::string& name, int64_t start, int64_t en
   int64_t end = end_inclusive + 1;
   if (end > lens_[(size_t)i]) end = lens_[(size_t)i];
   if (start >= end) return std::string();
-  if (fd_ < 0 || !seqs_[(size_t)i].empty()) return seqs_[(size_t)i].substr((size_t)start, (size_t)(end - start));
+  // a whole sequence that another thread is loading right now (sequence(i)) is not touched: this fetch reads its range
+  // from the file instead
+  if (fd_ < 0 || loaded_[(size_t)i].load(std::memory_order_acquire)) return seqs_[(size_t)i].substr((size_t)start, (size_t)(end - start));
   std::string out;
   read_bases(i, start, end, out);
   return out;

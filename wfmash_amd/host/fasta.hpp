@@ -15,6 +15,7 @@
 // Both modes return identical bytes; tests/test_fasta_cpu.py holds them against each other.
 #pragma once
 
+#include <atomic>
 #include <cstdint>
 #include <memory>
 #include <mutex>
@@ -68,6 +69,7 @@ class FastaStore {
   std::vector<int64_t> block_coff_, block_uoff_;  // BGZF: start of each block in the file / in the text
   int64_t text_size_ = 0;
   mutable std::unique_ptr<std::once_flag[]> once_;
+  mutable std::unique_ptr<std::atomic<bool>[]> loaded_;  // indexed mode: seqs_[i] holds the whole sequence (set after the load)
 };
 
 }  // namespace wfmash_host
