@@ -25,4 +25,7 @@ if [ $sq = 1 ]; then
 fi
 cd "$root"
 python scripts/prof_summary.py "profiles/$name.md" "$title" "$out/t/t_results.db" "${dbs[@]}" --bench "$out/trace.log" > /dev/null
+mkdir -p "$root/gpurun_out/profiles_out"
+cp "profiles/$name.md" "$root/gpurun_out/profiles_out/"   # profiles/ does not travel back from the GPU box, gpurun_out/ does
+rm -rf "$out"/t "$out"/f "$out"/w "$out"/s                 # the databases stay on the box (tens of MB)
 tail -n +1 "profiles/$name.md" | head -60

@@ -268,7 +268,8 @@ struct TileCfg {
                       // measured neutral on C3: what the step kernel saves, the small tiles cost)
   int chunk = 2;  // tile blocks launched back to back between two looks of the host (WFM_TILE_CHUNK); more only adds idle tiles
   int T = 100, Wt = 1024, threads = 512;  // T: scores per tile block (measured optimum 96-100 on C3: halo 2T of 1024 columns vs per-tile snapshot cost)
-  int min_len = 600, min_score = 64;
+  int min_len = 128, min_score = 64;  // shorter problems go to the step kernel whole (they are base jobs at <= 100 anyway).  600 until round 2: the
+                                      // short, high-score children a 1 kb end gap leaves behind then queued up as one-workgroup step jobs
   bool enabled = true;
   bool reg = false;  // register-resident tile kernel (default penalty lags only)
   int C = 2;
@@ -570,6 +571,12 @@ int run_p2_phase(wfm_handle* h, wfm_seqset* S, const DevPen& dp, int scope, cons
     }
     h->stats.p2_launches++;
     h->stats.p2_jobs += (uint32_t)n;
+    if (getenv("WFM_DEBUG")) {
+      int more = 0;
+      for (const BpResult& r : got) more += r.status == WFM_DEV_P2_MORE;
+      fprintf(stderr, "[wfm] phase 2 from rows computed ahead: %zu jobs, widest %zu columns, %zu tiles of %d threads, %.3f ms, %d left to the step kernel\n",
+              n, maxw2, tasks.size(), threads_c, ms, more);
+    }
     for (size_t q = 0; q < n; ++q) res[(size_t)cand[i0 + q]] = got[q];
     i0 = i;
   }
