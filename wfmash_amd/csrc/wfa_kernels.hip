@@ -1824,13 +1824,19 @@ __global__ __launch_bounds__(256) void wfa_p2_prefixmax_kernel(const P2Job* __re
 __device__ unsigned long long g_p2cnt[8];  // WFM_P2_COUNT diagnostics: tests, tests with candidates, blocks looked at, blocks passing, diagonals reaching, o1 loads, hits
 constexpr int P2LIST = 1024;  // blocks of the tested row that can pass the block-level test before the kernel stops listing them
 
-// One test of the loop for one workgroup.  Every stage is spread over the threads; the stages are separated by barriers:
-//   pairs    which (row i of the other direction, component) pairs can still improve the best breakpoint (score) and can
-//            reach tl at all (row maxima)
-//   blocks   which 64-diagonal blocks of the tested row can meet a mirrored block (block maximum of the row against the
+// The loop for one workgroup, P2G tests per round.  Every stage of a round is spread over the threads; the stages are
+// separated by barriers (each costs a round trip or two to the job's rows in L2, which is what a test's time is made of --
+// hence several tests per round):
+//   pairs    per test: which (row i of the other direction, component) pairs can still improve the best breakpoint (score)
+//            and can reach tl at all (row maxima)
+//   blocks   which 64-diagonal blocks of a tested row can meet a mirrored block (block maximum of the row against the
 //            running block maxima of the other direction)
-//   cells    the diagonals of those blocks, each against the pairs whose block maximum lets it: smallest diagonal per pair
-//   pick     the pair the reference's nested loop would end up with: smallest score, first in its order among equals
+//   cells    the diagonals of those blocks, each against the pairs whose own block maximum lets it: smallest diagonal per pair
+//   pick     test after test in the reference's order: the pair its nested loop would end up with -- smallest score, first in
+//            its order among equals -- and the loop's own end condition
+// The tests of a round see the best breakpoint as it was when the round began: that only lets more pairs through the first
+// three stages than a test on its own would look at; what a test takes is decided in `pick`, with the best of that moment.
+constexpr int P2G = 8;
 __global__ __launch_bounds__(1024) void wfa_p2_overlap_kernel(const int32_t* __restrict__ ring, const int32_t* __restrict__ p2,
                                                              const P2Job* __restrict__ jobs, const int32_t* __restrict__ p2max,
                                                              const int32_t* __restrict__ bmax, const int32_t* __restrict__ pbmax,
@@ -1840,194 +1846,250 @@ __global__ __launch_bounds__(1024) void wfa_p2_overlap_kernel(const int32_t* __r
   const int nblk = J.nblk;
   const int32_t* bmj = bmax + J.bm_off;
   const int32_t* pbj = pbmax + J.bm_off;
-  __shared__ int s_mink[P2ENT];
-  __shared__ int s_act[P2ENT];
+  __shared__ int s_mink[P2G][P2ENT];
+  __shared__ int s_act[P2G][P2ENT];
+  __shared__ int s_k[P2G][4];   // per test: klo, khi of the candidate rows' mirrored ranges; any
+  __shared__ int s_nlist;
+  __shared__ int s_list[P2LIST];  // (test << 24) | block of the tested row
+  __shared__ int s_state[8];    // sf, sr, last_fwd, best, status (0 running, 1 ended, 2 more tests than rows), tests done
   __shared__ int s_bp[8];
-  __shared__ int s_k[4];      // klo, khi of the candidate rows' mirrored ranges; any; number of listed blocks
-  __shared__ int s_list[P2LIST];
+  __shared__ unsigned long long s_cells;
   __shared__ int s_rmax[2][P2ROWS][5];
   for (int i = tid; i < 2 * P2ROWS * 5; i += blockDim.x) ((int*)s_rmax)[i] = p2max[(int64_t)job * 2 * P2ROWS * 5 + i];
   if (tid < 8) s_bp[tid] = 0;
+  if (tid == 0) { s_state[0] = J.sf; s_state[1] = J.sr; s_state[2] = J.last_fwd; s_state[3] = INT32_MAX; s_state[4] = 0; s_state[5] = 0; s_cells = 0; }
   __syncthreads();
   const int pl = J.pl, tl = J.tl, kinv = tl - pl;
   const int gopen = max(pen.o1, pen.o2);
-  int sf = J.sf, sr = J.sr, last_fwd = J.last_fwd;
-  int best = INT32_MAX, status = 0;
-  uint64_t cells = 0;
-  for (int u = 0;; ++u) {
-    int d0;  // direction whose newest row is tested, then the OTHER one advances
-    if (last_fwd) {
-      const int min_sr = (sr > scope - 1) ? sr - (scope - 1) : 0;
-      if (sf + min_sr - gopen >= best) break;
-      d0 = 0;
-    } else {
-      const int min_sf = (sf > scope - 1) ? sf - (scope - 1) : 0;
-      if (min_sf + sr - gopen >= best) break;
-      d0 = 1;
-    }
-    if (u >= P2TESTS) { status = WFM_DEV_P2_MORE; break; }
-    const int d1 = d0 ^ 1;
-    const int s0 = d0 == 0 ? sf : sr, s1 = d0 == 0 ? sr : sf;
-    const int sd0 = d0 == 0 ? J.sf : J.sr, sd1 = d1 == 0 ? J.sf : J.sr;
-    const int r0row = s0 - (sd0 - 25);
+  for (;;) {
+    // ---- state at the start of the round (uniform)
+    const int sf0 = s_state[0], sr0 = s_state[1], lf0 = s_state[2], best = s_state[3], u0 = s_state[5];
+    if (s_state[4] != 0) break;
+    // test g of the round: the direction that stepped last is tested first, then the two alternate
+    auto test_of = [&](int g, int& d0, int& s0, int& s1) {
+      const int first = lf0 ? 0 : 1;
+      const int a = first == 0 ? sf0 : sr0, b = first == 0 ? sr0 : sf0;
+      if ((g & 1) == 0) { d0 = first; s0 = a + g / 2; s1 = b + g / 2; }
+      else { d0 = first ^ 1; s0 = b + (g + 1) / 2; s1 = a + (g - 1) / 2; }
+    };
+    const int ng = min(P2G, P2TESTS - u0);  // tests with rows behind them
     // ---- pairs
-    if (tid == 0) { s_k[0] = INT32_MAX; s_k[1] = INT32_MIN; s_k[2] = 0; s_k[3] = 0; }
-    for (int i = tid; i < P2ENT; i += blockDim.x) { s_mink[i] = INT32_MAX; s_act[i] = 0; }
+    if (tid == 0) s_nlist = 0;
+    for (int i = tid; i < P2G * P2ENT; i += blockDim.x) { ((int*)s_mink)[i] = INT32_MAX; ((int*)s_act)[i] = 0; }
+    if (tid < P2G) { s_k[tid][0] = INT32_MAX; s_k[tid][1] = INT32_MIN; s_k[tid][2] = 0; }
     __syncthreads();
-    if (tid < scope * 5) {
-      const int i = tid / 5, cc = tid % 5, si = s1 - i;
+    for (int e = tid; e < ng * scope * 5; e += blockDim.x) {
+      const int g = e / (scope * 5), pr = e % (scope * 5), i = pr / 5, cc = pr % 5;
+      int d0, s0, s1;
+      test_of(g, d0, s0, s1);
+      const int d1 = d0 ^ 1, sd0 = d0 == 0 ? J.sf : J.sr, sd1 = d1 == 0 ? J.sf : J.sr, si = s1 - i;
       if (si >= 0 && s0 + si - pen.o2 < best && s0 + si - bp_gap_open(pen, cc) < best &&
-          s_rmax[d0][r0row][cc] + s_rmax[d1][si - (sd1 - 25)][cc] >= tl) {
-        s_act[tid] = 1;
-        atomicMin(&s_k[0], kinv - rng_hi(tl, si));
-        atomicMax(&s_k[1], kinv - rng_lo(pl, si));
-        s_k[2] = 1;
+          s_rmax[d0][s0 - (sd0 - 25)][cc] + s_rmax[d1][si - (sd1 - 25)][cc] >= tl) {
+        s_act[g][pr] = 1;
+        atomicMin(&s_k[g][0], kinv - rng_hi(tl, si));
+        atomicMax(&s_k[g][1], kinv - rng_lo(pl, si));
+        s_k[g][2] = 1;
       }
     }
     __syncthreads();
-    const int any = s_k[2];
-    if (count && tid == 0) { atomicAdd(&g_p2cnt[0], 1ull); if (any) atomicAdd(&g_p2cnt[1], 1ull); }
-    if (any) {
-      const int klo = max(s_k[0], rng_lo(pl, s0)), khi = min(s_k[1], rng_hi(tl, s0));
-      // what the other direction holds per block up to row s1 (running maxima over its rows)
-      const int32_t* pb1 = pbj + ((int64_t)(d1 * P2ROWS + (s1 - (sd1 - 25))) * 5) * nblk;
-      // ---- blocks of the tested row that can meet a mirrored block
+    // ---- blocks of the tested rows that can meet a mirrored block
+    unsigned c_blk = 0, c_pass = 0, c_reach = 0, c_load = 0, c_hit = 0;
+    for (int g = 0; g < ng; ++g) {
+      if (!s_k[g][2]) continue;
+      int d0, s0, s1;
+      test_of(g, d0, s0, s1);
+      const int d1 = d0 ^ 1, sd0 = d0 == 0 ? J.sf : J.sr, sd1 = d1 == 0 ? J.sf : J.sr;
+      const int klo = max(s_k[g][0], rng_lo(pl, s0)), khi = min(s_k[g][1], rng_hi(tl, s0));
       const int B_lo = (klo + J.koff2) >> 6, B_hi = (khi + J.koff2) >> 6;
-      const int32_t* bm0 = bmj + ((int64_t)(d0 * P2ROWS + r0row) * 5) * nblk;
-      unsigned c_blk = 0, c_pass = 0, c_reach = 0, c_load = 0, c_hit = 0;
+      const int32_t* bm0 = bmj + ((int64_t)(d0 * P2ROWS + (s0 - (sd0 - 25))) * 5) * nblk;
+      const int32_t* pb1 = pbj + ((int64_t)(d1 * P2ROWS + (s1 - (sd1 - 25))) * 5) * nblk;
       for (int b0 = B_lo + tid; b0 <= B_hi; b0 += blockDim.x) {
         const int kb_lo = max(klo, (b0 << 6) - J.koff2), kb_hi = min(khi, (b0 << 6) - J.koff2 + 63);
-        const int b1a = max(0, (kinv - kb_hi + J.koff2) >> 6), b1b = min(nblk - 1, (kinv - kb_lo + J.koff2) >> 6);
+        const int b1a = max(0, (kinv - kb_hi + J.koff2) >> 6), b1b = min(nblk - 1, (kinv - kb_lo + J.koff2) >> 6);  // b1b <= b1a + 1
+        int v0[5], va[5], vb[5];
+#pragma unroll
+        for (int cc = 0; cc < 5; ++cc) { v0[cc] = bm0[(int64_t)cc * nblk + b0]; va[cc] = pb1[(int64_t)cc * nblk + b1a]; vb[cc] = pb1[(int64_t)cc * nblk + b1b]; }
         bool pass = false;
 #pragma unroll
-        for (int cc = 0; cc < 5; ++cc) {
-          int m1 = 0;
-          for (int b1 = b1a; b1 <= b1b; ++b1) m1 = max(m1, pb1[(int64_t)cc * nblk + b1]);
-          pass = pass || (bm0[(int64_t)cc * nblk + b0] + m1 >= tl);
-        }
+        for (int cc = 0; cc < 5; ++cc) pass = pass || (v0[cc] + max(va[cc], vb[cc]) >= tl);
         ++c_blk;
         if (pass) {
           ++c_pass;
-          const int pos = atomicAdd(&s_k[3], 1);
-          if (pos < P2LIST) s_list[pos] = b0;
+          const int pos = atomicAdd(&s_nlist, 1);
+          if (pos < P2LIST) s_list[pos] = (g << 24) | b0;
         }
       }
-      __syncthreads();
-      // ---- cells: one wave per listed block, one diagonal per lane
-      const int nl = s_k[3];
-      const bool listed = nl <= P2LIST;  // otherwise (never seen): every block of the range
-      const int ntodo = listed ? nl : B_hi - B_lo + 1;
-      const int32_t* r0[5];
-#pragma unroll
-      for (int cc = 0; cc < 5; ++cc) r0[cc] = p2_row(ring, p2, J, d0, cc, s0);
+    }
+    __syncthreads();
+    // ---- cells: one wave per listed block, one diagonal per lane
+    {
+      const int nl = s_nlist;
+      const bool listed = nl <= P2LIST;  // otherwise (never seen): every block of every test of the round
+      int ntodo = nl;
+      int cum[P2G + 1];
+      if (!listed) {
+        cum[0] = 0;
+        for (int g = 0; g < P2G; ++g) {
+          int nbk = 0;
+          if (g < ng && s_k[g][2]) {
+            int d0, s0, s1;
+            test_of(g, d0, s0, s1);
+            const int klo = max(s_k[g][0], rng_lo(pl, s0)), khi = min(s_k[g][1], rng_hi(tl, s0));
+            nbk = max(0, ((khi + J.koff2) >> 6) - ((klo + J.koff2) >> 6) + 1);
+          }
+          cum[g + 1] = cum[g] + nbk;
+        }
+        ntodo = cum[P2G];
+      }
       for (int li = wv; li < ntodo; li += nw) {
-        const int b0 = listed ? s_list[li] : B_lo + li;
+        int g, b0;
+        if (listed) { const int ent = s_list[li]; g = ent >> 24; b0 = ent & 0xffffff; }
+        else {
+          g = 0;
+          while (li >= cum[g + 1]) ++g;
+          int d0, s0, s1;
+          test_of(g, d0, s0, s1);
+          b0 = ((max(s_k[g][0], rng_lo(pl, s0)) + J.koff2) >> 6) + (li - cum[g]);
+        }
+        int d0, s0, s1;
+        test_of(g, d0, s0, s1);
+        const int d1 = d0 ^ 1, sd1 = d1 == 0 ? J.sf : J.sr;
+        const int klo = max(s_k[g][0], rng_lo(pl, s0)), khi = min(s_k[g][1], rng_hi(tl, s0));
         const int k0 = (b0 << 6) - J.koff2 + lane;
         if (k0 < klo || k0 > khi) continue;
         const int k1 = kinv - k0;
         const int b1 = (k1 + J.koff2) >> 6;  // block of the mirrored diagonal
-        int o0[5];
+        const int32_t* pb1 = pbj + ((int64_t)(d1 * P2ROWS + (s1 - (sd1 - 25))) * 5) * nblk;
+        int o0[5], pv[5];
+#pragma unroll
+        for (int cc = 0; cc < 5; ++cc) { o0[cc] = p2_row(ring, p2, J, d0, cc, s0)[k0]; pv[cc] = pb1[(int64_t)cc * nblk + b1]; }
         bool reach = false;  // can this diagonal meet ANY candidate row THERE?
 #pragma unroll
-        for (int cc = 0; cc < 5; ++cc) {
-          o0[cc] = r0[cc][k0];
-          reach = reach || (o0[cc] >= 0 && o0[cc] + pb1[(int64_t)cc * nblk + b1] >= tl);
-        }
+        for (int cc = 0; cc < 5; ++cc) reach = reach || (o0[cc] >= 0 && o0[cc] + pv[cc] >= tl);
         if (!reach) continue;
         ++c_reach;
         for (int i = 0; i < scope; ++i) {
           const int si = s1 - i;
           if (si < 0) break;
           if (k1 < rng_lo(pl, si) || k1 > rng_hi(tl, si)) continue;
+          const int32_t* bmr = bmj + ((int64_t)(d1 * P2ROWS + (si - (sd1 - 25))) * 5) * nblk + b1;
+          int bv[5];
+          bool some = false;
+#pragma unroll
+          for (int cc = 0; cc < 5; ++cc) {  // the five block maxima of the row in flight together
+            const bool on = s_act[g][i * 5 + cc] && o0[cc] >= 0;
+            bv[cc] = on ? bmr[(int64_t)cc * nblk] : INT32_MIN / 2;
+            some = some || on;
+          }
+          if (!some) continue;
 #pragma unroll
           for (int cc = 0; cc < 5; ++cc) {
-            if (!s_act[i * 5 + cc] || o0[cc] < 0) continue;
-            if (o0[cc] + bmj[((int64_t)(d1 * P2ROWS + (si - (sd1 - 25))) * 5 + cc) * nblk + b1] < tl) continue;
+            if (o0[cc] + bv[cc] < tl) continue;
             const int o1 = p2_row(ring, p2, J, d1, cc, si)[k1];
             ++c_load;
-            if (o0[cc] + o1 >= tl) { atomicMin(&s_mink[i * 5 + cc], k0); ++c_hit; }
+            if (o0[cc] + o1 >= tl) { atomicMin(&s_mink[g][i * 5 + cc], k0); ++c_hit; }
           }
         }
       }
-      if (count) {
-        atomicAdd(&g_p2cnt[2], (unsigned long long)c_blk); atomicAdd(&g_p2cnt[3], (unsigned long long)c_pass);
-        atomicAdd(&g_p2cnt[4], (unsigned long long)c_reach); atomicAdd(&g_p2cnt[5], (unsigned long long)c_load);
-        atomicAdd(&g_p2cnt[6], (unsigned long long)c_hit);
-      }
-      __syncthreads();
-      // ---- pick.  The reference walks i = 0 .. scope-1 and, inside, D2, I2, D1, I1, M; it takes a hit when its score is
-      // STRICTLY below the best so far (and skips ahead once a gap-open class can no longer beat it): with o2 >= o1 >= 0 the
-      // walk ends on the hit of smallest score, the first in that order among equals -- a minimum over (score, position)
-      if (wv == 0) {
-        long long key = INT64_MAX;
-        if (pen.o2 >= pen.o1) {
+    }
+    if (count) {
+      atomicAdd(&g_p2cnt[2], (unsigned long long)c_blk); atomicAdd(&g_p2cnt[3], (unsigned long long)c_pass);
+      atomicAdd(&g_p2cnt[4], (unsigned long long)c_reach); atomicAdd(&g_p2cnt[5], (unsigned long long)c_load);
+      atomicAdd(&g_p2cnt[6], (unsigned long long)c_hit);
+    }
+    __syncthreads();
+    // ---- pick, test after test.  The reference walks i = 0 .. scope-1 and, inside, D2, I2, D1, I1, M; it takes a hit when its
+    // score is STRICTLY below the best so far (and skips ahead once a gap-open class can no longer beat it): with o2 >= o1 >= 0
+    // the walk ends on the hit of smallest score, the first in that order among equals -- a minimum over (score, position)
+    if (wv == 0) {
+      int sf = sf0, sr = sr0, last_fwd = lf0, b = best, status = 0, u = u0;
+      unsigned long long cells = 0;
+      for (int g = 0; g < P2G; ++g) {
+        int d0;  // direction whose newest row is tested, then the OTHER one advances
+        if (last_fwd) {
+          const int min_sr = (sr > scope - 1) ? sr - (scope - 1) : 0;
+          if (sf + min_sr - gopen >= b) { status = 1; break; }
+          d0 = 0;
+        } else {
+          const int min_sf = (sf > scope - 1) ? sf - (scope - 1) : 0;
+          if (min_sf + sr - gopen >= b) { status = 1; break; }
+          d0 = 1;
+        }
+        if (u >= P2TESTS) { status = 2; break; }
+        const int s0 = d0 == 0 ? sf : sr, s1 = d0 == 0 ? sr : sf;
+        if (count && lane == 0) { atomicAdd(&g_p2cnt[0], 1ull); if (s_k[g][2]) atomicAdd(&g_p2cnt[1], 1ull); }
+        if (s_k[g][2]) {
+          if (pen.o2 >= pen.o1) {
+            long long key = INT64_MAX;
 #pragma unroll
-          for (int q = 0; q < 3; ++q) {
-            const int pr = lane + 64 * q;
-            if (pr < scope * 5 && s_mink[pr] != INT32_MAX) {
-              const int i = pr / 5, cc = pr % 5, si = s1 - i;
-              const int sc = s0 + si - bp_gap_open(pen, cc);
-              const int oi = cc == C_D2 ? 0 : (cc == C_I2 ? 1 : (cc == C_D1 ? 2 : (cc == C_I1 ? 3 : 4)));
-              if (sc < best) key = min(key, ((long long)sc << 16) | (long long)(i * 5 + oi));
+            for (int q = 0; q < 3; ++q) {
+              const int pr = lane + 64 * q;
+              if (pr < scope * 5 && s_mink[g][pr] != INT32_MAX) {
+                const int i = pr / 5, cc = pr % 5, si = s1 - i;
+                const int sc = s0 + si - bp_gap_open(pen, cc);
+                const int oi = cc == C_D2 ? 0 : (cc == C_I2 ? 1 : (cc == C_D1 ? 2 : (cc == C_I1 ? 3 : 4)));
+                if (sc < b) key = min(key, ((long long)sc << 16) | (long long)(i * 5 + oi));
+              }
             }
-          }
 #pragma unroll
-          for (int dlt = 32; dlt >= 1; dlt >>= 1) {
-            const long long o = __shfl_xor(key, dlt, 64);
-            key = min(key, o);
-          }
-          if (lane == 0) {
-            int b = best;
+            for (int dlt = 32; dlt >= 1; dlt >>= 1) {
+              const long long o = __shfl_xor(key, dlt, 64);
+              key = min(key, o);
+            }
             if (key != INT64_MAX) {
               const int pos = (int)(key & 0xffff), i = pos / 5, oi = pos % 5, si = s1 - i;
-              const int order[5] = {C_D2, C_I2, C_D1, C_I1, C_M};
-              const int cc = order[oi];
-              const int k0 = s_mink[i * 5 + cc], k1 = kinv - k0;
+              const int cc = oi == 0 ? C_D2 : (oi == 1 ? C_I2 : (oi == 2 ? C_D1 : (oi == 3 ? C_I1 : C_M)));
+              const int k0 = s_mink[g][i * 5 + cc], k1 = kinv - k0;
               b = (int)(key >> 16);
-              s_bp[0] = b;
-              if (d0 == 0) { s_bp[1] = s0; s_bp[2] = si; s_bp[3] = k0; s_bp[4] = p2_row(ring, p2, J, 0, cc, s0)[k0]; }
-              else         { s_bp[1] = si; s_bp[2] = s0; s_bp[3] = k1; s_bp[4] = p2_row(ring, p2, J, 0, cc, si)[k1]; }
-              s_bp[5] = cc;
+              if (lane == 0) {
+                s_bp[0] = b;
+                if (d0 == 0) { s_bp[1] = s0; s_bp[2] = si; s_bp[3] = k0; s_bp[4] = p2_row(ring, p2, J, 0, cc, s0)[k0]; }
+                else         { s_bp[1] = si; s_bp[2] = s0; s_bp[3] = k1; s_bp[4] = p2_row(ring, p2, J, 0, cc, si)[k1]; }
+                s_bp[5] = cc;
+              }
             }
-            s_bp[6] = b;
-          }
-        } else if (lane == 0) {  // unusual penalties: the walk itself
-          int b = best;
-          const int order[5] = {C_D2, C_I2, C_D1, C_I1, C_M};
-          for (int i = 0; i < scope; ++i) {
-            const int si = s1 - i;
-            if (si < 0) break;
-            for (int oi = 0; oi < 5; ++oi) {
-              const int cc = order[oi];
-              const int gop = bp_gap_open(pen, cc);
-              if ((oi == 0 || oi == 2 || oi == 4) && s0 + si - gop >= b) break;
-              const int k0 = s_mink[i * 5 + cc];
-              if (k0 == INT32_MAX) continue;
-              if (s0 + si - gop >= b) continue;
-              const int k1 = kinv - k0;
-              b = s0 + si - gop;
-              s_bp[0] = b;
-              if (d0 == 0) { s_bp[1] = s0; s_bp[2] = si; s_bp[3] = k0; s_bp[4] = p2_row(ring, p2, J, 0, cc, s0)[k0]; }
-              else         { s_bp[1] = si; s_bp[2] = s0; s_bp[3] = k1; s_bp[4] = p2_row(ring, p2, J, 0, cc, si)[k1]; }
-              s_bp[5] = cc;
+          } else {  // unusual penalties: the walk itself (every lane runs it; lane 0 records)
+            const int order[5] = {C_D2, C_I2, C_D1, C_I1, C_M};
+            for (int i = 0; i < scope; ++i) {
+              const int si = s1 - i;
+              if (si < 0) break;
+              for (int oi = 0; oi < 5; ++oi) {
+                const int cc = order[oi];
+                const int gop = bp_gap_open(pen, cc);
+                if ((oi == 0 || oi == 2 || oi == 4) && s0 + si - gop >= b) break;
+                const int k0 = s_mink[g][i * 5 + cc];
+                if (k0 == INT32_MAX) continue;
+                if (s0 + si - gop >= b) continue;
+                const int k1 = kinv - k0;
+                b = s0 + si - gop;
+                if (lane == 0) {
+                  s_bp[0] = b;
+                  if (d0 == 0) { s_bp[1] = s0; s_bp[2] = si; s_bp[3] = k0; s_bp[4] = p2_row(ring, p2, J, 0, cc, s0)[k0]; }
+                  else         { s_bp[1] = si; s_bp[2] = s0; s_bp[3] = k1; s_bp[4] = p2_row(ring, p2, J, 0, cc, si)[k1]; }
+                  s_bp[5] = cc;
+                }
+              }
             }
           }
-          s_bp[6] = b;
         }
+        // the other direction advances by one row (computed ahead: only the bookkeeping is left)
+        if (d0 == 0) { ++sr; cells += (unsigned long long)(rng_hi(tl, sr) - rng_lo(pl, sr) + 1); last_fwd = 0; }
+        else         { ++sf; cells += (unsigned long long)(rng_hi(tl, sf) - rng_lo(pl, sf) + 1); last_fwd = 1; }
+        ++u;
       }
-      __syncthreads();
-      best = s_bp[6];
+      if (lane == 0) {
+        s_state[0] = sf; s_state[1] = sr; s_state[2] = last_fwd; s_state[3] = b; s_state[4] = status; s_state[5] = u;
+        s_cells += cells;
+      }
     }
-    // the other direction advances by one row (computed ahead: only the bookkeeping is left)
-    if (d0 == 0) { ++sr; cells += (uint64_t)(rng_hi(tl, sr) - rng_lo(pl, sr) + 1); last_fwd = 0; }
-    else         { ++sf; cells += (uint64_t)(rng_hi(tl, sf) - rng_lo(pl, sf) + 1); last_fwd = 1; }
+    __syncthreads();
   }
   if (tid == 0) {
     BpResult r;
-    r.status = status;
-    r.score = best; r.score_fwd = s_bp[1]; r.score_rev = s_bp[2]; r.k_fwd = s_bp[3]; r.off_fwd = s_bp[4]; r.comp = s_bp[5];
-    r.steps = sf + sr;
-    r.cells = cells;
+    r.status = s_state[4] == 2 ? WFM_DEV_P2_MORE : 0;
+    r.score = s_state[3]; r.score_fwd = s_bp[1]; r.score_rev = s_bp[2]; r.k_fwd = s_bp[3]; r.off_fwd = s_bp[4]; r.comp = s_bp[5];
+    r.steps = s_state[0] + s_state[1];
+    r.cells = s_cells;
     r.steps_p1 = J.sf + J.sr;
     r.ticks_p1 = 0; r.ticks_p2 = 0; r.pad_ = 0;
     results[job] = r;
