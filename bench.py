@@ -184,7 +184,7 @@ def main():
             "device": h.device_name(),
         }
         # ---- CPU baseline (oracle = "port") on a bounded sample of the same workload ----
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # the CPU baseline is timed on rank 0 at N = 1 only
             from oracle import pyoracle as O
             cores = os.cpu_count() or 1
             n_s = args.cpu_sample or min(len(mine), max(8, cores))

@@ -197,3 +197,33 @@ def test_filter_modes_end_to_end(gpu, tmp_path):
     assert {r[2:] for r in o2o} <= {r[2:] for r in base}
     assert lt and all(order[r[0]] > order[r[5]] for r in lt)
     assert {(r[0], r[5]) for r in lt} <= {(r[0], r[5]) for r in none}
+
+
+def test_cli_window_size_drives_the_align_defaults(gpu, tmp_path):
+    """-w other than 1k: the reference derives the paddings (min(w, 5000)) and the length cap of the align phase
+    (128 w) from it (parse_args.hpp:593-620).  wfmash-hip -w 500 must give what the align oracle gives with those values
+    on the CLI's own mappings -- and not what the 1 kb defaults give -- and the checks on -w / -p are the reference's."""
+    import subprocess
+    cli = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "wfmash_amd", "wfmash-hip")
+    seqs = _pangenome(61, L=24000)
+    fa = str(tmp_path / "pan.fa")
+    _write_fasta(fa, seqs)
+    by_name = dict(seqs)
+    m, a = str(tmp_path / "m.paf"), str(tmp_path / "a.paf")
+    subprocess.check_call([cli, "-m", "-w", "500", "-p", "85", "-t", "4", "--out", m, fa], cwd=str(tmp_path))
+    subprocess.check_call([cli, "-w", "500", "-p", "85", "-t", "4", "--out", a, fa], cwd=str(tmp_path))
+    lines = open(m).read().splitlines()
+    got = open(a).read().splitlines()
+    assert len(lines) >= 10
+    want = W.align_mapping_lines(lines, by_name, by_name, target_padding=500, query_padding=500, max_len_minor=64000)
+    assert got == want
+    assert got != W.align_mapping_lines(lines, by_name, by_name)  # the 1 kb defaults align other windows
+    # an explicit -E / -U wins over the derived value
+    e = str(tmp_path / "e.paf")
+    subprocess.check_call([cli, "-w", "500", "-p", "85", "-E", "200", "-U", "0", "-t", "4", "--out", e, fa], cwd=str(tmp_path))
+    assert open(e).read().splitlines() == W.align_mapping_lines(lines, by_name, by_name, target_padding=200, query_padding=0, max_len_minor=64000)
+    for bad in (["-w", "50"], ["-w", "20k"], ["-p", "40"], ["-p", "ani0"], ["-p", "ani120"], ["-i", m, "-W", str(tmp_path / "x.idx")]):
+        r = subprocess.run([cli] + bad + ["--out", str(tmp_path / "bad.paf"), fa], cwd=str(tmp_path), capture_output=True, text=True)
+        assert r.returncode == 1 and "ERROR" in r.stderr, bad
+    ok = subprocess.run([cli, "-m", "-w", "20k", "-P", "50k", "-p", "85", "--out", str(tmp_path / "big.paf"), fa], cwd=str(tmp_path), capture_output=True, text=True)
+    assert ok.returncode == 0, ok.stderr  # large windows are fine for mapping only

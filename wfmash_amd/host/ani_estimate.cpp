@@ -1,6 +1,8 @@
 #include "ani_estimate.hpp"
 
 #include <algorithm>
+#include <atomic>
+#include <thread>
 #include <map>
 #include <memory>
 #include <string>
@@ -30,6 +32,11 @@ void pool(std::vector<hash_t>& group, const std::vector<hash_t>& add) {
 }  // namespace
 
 double estimate_identity_for_groups(const Parameters& params, const SequenceIdManager& idManager, wfm_handle_t* h) {
+  return estimate_identity_for_groups(params, idManager, std::vector<wfm_handle_t*>{h});
+}
+
+double estimate_identity_for_groups(const Parameters& params, const SequenceIdManager& idManager, const std::vector<wfm_handle_t*>& hs) {
+  if (hs.empty()) throw std::runtime_error("no GPU handle");
   struct Role { std::string file; bool is_query = false, is_target = false; };
   std::map<std::string, Role> roles;  // the reference walks a hash map here; the result does not depend on the order
   std::unordered_map<std::string, std::unique_ptr<wfmash_host::FastaStore>> stores;
@@ -58,7 +65,6 @@ double estimate_identity_for_groups(const Parameters& params, const SequenceIdMa
     if (role.is_target) target_groups[g];
   }
   int query_seq_count = 0, target_seq_count = 0;
-  std::vector<hash_t> sketch((size_t)kEstimationSketchSize);
   {  // indexed files: read the sequences side by side instead of one after the other
     std::unordered_map<std::string, std::vector<int>> want;
     for (const auto& [name, role] : roles) {
@@ -67,17 +73,38 @@ double estimate_identity_for_groups(const Parameters& params, const SequenceIdMa
     }
     for (const auto& [file, which] : want) open(file).preload(which, params.threads);
   }
+  // one sketch per sequence: the sequences are spread over the GPUs at hand (a queue, one host thread per device), the
+  // sketches are pooled per group afterwards in the order of the names (the pool of a group does not depend on the order)
+  struct Item { const std::string* name; const Role* role; const std::string* seq; std::vector<hash_t> sketch; };
+  std::vector<Item> items;
   for (const auto& [name, role] : roles) {
     const wfmash_host::FastaStore& fa = open(role.file);
     const int64_t len = fa.seq_len(name);
     if (len <= 0) continue;  // "not found or empty, skipping"
-    const std::string& seq = fa.sequence(fa.find(name));
-    const int64_t n = wfm_minhash_sketch(h, seq.data(), (int64_t)seq.size(), kEstimationK, kEstimationSketchSize, sketch.data());
-    if (n < 0) throw std::runtime_error(std::string("wfm_minhash_sketch failed: ") + wfm_last_error(h));
-    const std::vector<hash_t> s(sketch.begin(), sketch.begin() + n);
-    const int g = idManager.getRefGroup(idManager.getSequenceId(name));
-    if (role.is_query) { pool(query_groups[g], s); ++query_seq_count; }
-    if (role.is_target) { pool(target_groups[g], s); ++target_seq_count; }
+    items.push_back(Item{&name, &role, &fa.sequence(fa.find(name)), {}});
+  }
+  {
+    std::atomic<size_t> next{0};
+    std::vector<std::string> errors(hs.size());
+    auto work = [&](size_t g) {
+      std::vector<hash_t> sketch((size_t)kEstimationSketchSize);
+      for (size_t i; (i = next.fetch_add(1)) < items.size();) {
+        const std::string& seq = *items[i].seq;
+        const int64_t n = wfm_minhash_sketch(hs[g], seq.data(), (int64_t)seq.size(), kEstimationK, kEstimationSketchSize, sketch.data());
+        if (n < 0) { errors[g] = std::string("wfm_minhash_sketch failed: ") + wfm_last_error(hs[g]); return; }
+        items[i].sketch.assign(sketch.begin(), sketch.begin() + n);
+      }
+    };
+    std::vector<std::thread> pool_threads;
+    for (size_t g = 1; g < hs.size(); ++g) pool_threads.emplace_back(work, g);
+    work(0);
+    for (auto& t : pool_threads) t.join();
+    for (const auto& e : errors) if (!e.empty()) throw std::runtime_error(e);
+  }
+  for (const Item& it : items) {
+    const int g = idManager.getRefGroup(idManager.getSequenceId(*it.name));
+    if (it.role->is_query) { pool(query_groups[g], it.sketch); ++query_seq_count; }
+    if (it.role->is_target) { pool(target_groups[g], it.sketch); ++target_seq_count; }
   }
   if (query_seq_count == 0 || target_seq_count == 0) return kFallbackIdentity;
 

@@ -5,6 +5,8 @@
 // and the requested percentile of those, plus the adjustment, becomes the identity threshold.
 #pragma once
 
+#include <vector>
+
 #include "../../include/wfmash_hip.h"
 #include "map_types.hpp"
 #include "sequence_ids.hpp"
@@ -14,6 +16,8 @@ namespace Stat {
 
 // returns the adjusted ANI in [0, 1]; fixed::percentage_identity (0.70) when nothing can be compared
 double estimate_identity_for_groups(const Parameters& params, const SequenceIdManager& idManager, wfm_handle_t* h);
+// the same with the sequences spread over several GPUs of the node (one sketch per sequence, independent of each other)
+double estimate_identity_for_groups(const Parameters& params, const SequenceIdManager& idManager, const std::vector<wfm_handle_t*>& hs);
 
 }  // namespace Stat
 }  // namespace skch

@@ -140,7 +140,7 @@ int wfmh_map_multi(wfm_handle_t* const* handles, int n, const char* target_fasta
       if (!p.target_prefix.empty()) target_prefix_vec.push_back(p.target_prefix);
       const skch::SequenceIdManager ids(p.querySequences, p.refSequences, p.query_prefix, target_prefix_vec,
                                         std::string(1, p.prefix_delim), p.query_list, p.target_list);
-      p.percentageIdentity = skch::Stat::estimate_identity_for_groups(p, ids, h);
+      p.percentageIdentity = skch::Stat::estimate_identity_for_groups(p, ids, std::vector<wfm_handle_t*>(handles, handles + n));
     }
     skch::Map mapper(p, std::vector<wfm_handle_t*>(handles, handles + n));
     skch::MapSummary s;

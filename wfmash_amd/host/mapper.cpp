@@ -256,12 +256,18 @@ int Map::mapQuery(MapSummary* summary) {
     ixs[0] = ix;
     if (ix) {
       t0 = now_ms();
+      // every device pulls its copy at the same time (the source's xGMI links to its peers are separate)
+      std::vector<int> rcs(hs_.size(), WFM_OK);
+      {
+        std::vector<std::thread> pulls;
+        for (size_t g = 1; g < hs_.size(); ++g) pulls.emplace_back([&, g] { rcs[g] = wfm_index_replicate(h_, ix, hs_[g], &ixs[g]); });
+        for (auto& t : pulls) t.join();
+      }
       for (size_t g = 1; g < hs_.size(); ++g) {
-        const int rc = wfm_index_replicate(h_, ix, hs_[g], &ixs[g]);
-        if (rc != WFM_OK) {
+        if (rcs[g] != WFM_OK) {
           wfm_set_error(h_, std::string("index replication failed: ") + wfm_last_error(hs_[g]));
           for (size_t f = 0; f < hs_.size(); ++f) wfm_index_free(hs_[f], ixs[f]);
-          return rc;
+          return rcs[g];
         }
       }
       sum.ms_replicate += now_ms() - t0;
