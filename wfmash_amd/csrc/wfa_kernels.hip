@@ -779,6 +779,7 @@ struct RleWriter {
   int n;
   int cur_op;
   uint32_t cur_len;
+  bool writes = true;  // several lanes may keep the same writer in step; one of them stores
   __device__ void push(int op, int len) {
     if (len <= 0) return;
     if (op == cur_op) { cur_len += (uint32_t)len; return; }
@@ -786,7 +787,7 @@ struct RleWriter {
     cur_op = op; cur_len = (uint32_t)len;
   }
   __device__ void flush() {
-    if (cur_len) { ++n; base[-n] = (cur_len << 2) | (uint32_t)cur_op; }
+    if (cur_len) { ++n; if (writes) base[-n] = (cur_len << 2) | (uint32_t)cur_op; }
     cur_len = 0; cur_op = -1;
   }
 };
@@ -943,11 +944,16 @@ __global__ __launch_bounds__(256) void wfa_base_kernel(const uint8_t* __restrict
     done = J.endsfree ? (s_endk != INT32_MAX) : (s_done != 0);
   }
 
-  // ---- backtrace (wavefront_backtrace_affine), one lane ----
-  if (tid == 0) {
+  // ---- backtrace (wavefront_backtrace_affine): the first wave, every lane with the same state.  Inside a gap the walk
+  // visits one cell per base and each visit is a dependent load of a decision byte; a patch begins with the ~1 kb end gap
+  // of its record, so those walks were most of this kernel's time.  The cells of a gap lie on a known line -- (score - j e,
+  // diagonal +- j) -- so the 64 lanes read the next 64 decision bytes at once and the walk jumps to the first one that
+  // does not say "extension".  Lane 0 writes.
+  if (tid < 64) {
+    const int lane = tid;
     BaseResult r; r.status = status; r.score = s; r.nruns = 0; r.cells = cells;
     if (status == 0) {
-      RleWriter w; w.base = rle + J.rle_end; w.n = 0; w.cur_op = -1; w.cur_len = 0;
+      RleWriter w; w.base = rle + J.rle_end; w.n = 0; w.cur_op = -1; w.cur_len = 0; w.writes = lane == 0;
       int comp = J.endsfree ? C_M : J.comp_end;
       int k = J.endsfree ? s_endk : k_end;
       int off = J.endsfree ? bs_row(c, C_M, s)[k] : c.tl;
@@ -959,17 +965,38 @@ __global__ __launch_bounds__(256) void wfa_base_kernel(const uint8_t* __restrict
       }
       const DevPen& pn = c.pen;
       while (v > 0 && h > 0 && sc > 0) {
-        const unsigned b = c.bt[(int64_t)sc * c.width + k];
-        unsigned src;
-        if (comp == C_M) {
-          const int pre = c.pre[(int64_t)sc * c.width + k];
-          w.push(OP_M, off - pre);
-          off = pre; v = off - k; h = off;
-          if (v <= 0 || h <= 0) break;
-          src = b & 7u;
-        } else {
-          src = (unsigned)comp;
+        if (comp != C_M) {
+          // a run of gap cells: j-th cell of the line, with the loop's own conditions
+          const bool ins = comp == C_I1 || comp == C_I2;
+          const int e = (comp == C_I1 || comp == C_D1) ? pn.e1 : pn.e2, o = (comp == C_I1 || comp == C_D1) ? pn.o1 : pn.o2;
+          const unsigned mask = comp == C_I1 ? BT_I1_EXT : (comp == C_I2 ? BT_I2_EXT : (comp == C_D1 ? BT_D1_EXT : BT_D2_EXT));
+          const int scj = sc - lane * e, kj = ins ? k - lane : k + lane;
+          const bool alive = scj > 0 && (ins ? h - lane > 0 : v - lane > 0);
+          const unsigned bj = alive ? c.bt[(int64_t)scj * c.width + kj] : 0u;
+          const unsigned long long stop = __ballot(!(alive && (bj & mask)));
+          const int j0 = stop ? (int)__builtin_ctzll(stop) : 64;  // cells 0 .. j0-1 continue the gap
+          if (j0 > 0) {
+            w.push(ins ? OP_I : OP_D, j0);
+            sc -= j0 * e;
+            if (ins) { k -= j0; off -= j0; } else k += j0;
+            v = off - k; h = off;
+          }
+          if (j0 < 64) {
+            if (!(v > 0 && h > 0 && sc > 0)) break;   // the walk ends inside the gap
+            // the cell that opened the gap
+            sc -= o + e; comp = C_M;
+            w.push(ins ? OP_I : OP_D, 1);
+            if (ins) { --k; --off; } else ++k;
+            v = off - k; h = off;
+          }
+          continue;
         }
+        const unsigned b = c.bt[(int64_t)sc * c.width + k];
+        const int pre = c.pre[(int64_t)sc * c.width + k];
+        w.push(OP_M, off - pre);
+        off = pre; v = off - k; h = off;
+        if (v <= 0 || h <= 0) break;
+        const unsigned src = b & 7u;
         if (src == C_M) { sc -= pn.x; comp = C_M; w.push(OP_X, 1); --off; }
         else if (src == C_I1) { if (b & BT_I1_EXT) { sc -= pn.e1; comp = C_I1; } else { sc -= pn.o1 + pn.e1; comp = C_M; } w.push(OP_I, 1); --k; --off; }
         else if (src == C_I2) { if (b & BT_I2_EXT) { sc -= pn.e2; comp = C_I2; } else { sc -= pn.o2 + pn.e2; comp = C_M; } w.push(OP_I, 1); --k; --off; }
@@ -983,7 +1010,7 @@ __global__ __launch_bounds__(256) void wfa_base_kernel(const uint8_t* __restrict
       w.flush();
       r.nruns = w.n;
     }
-    results[blockIdx.x] = r;
+    if (lane == 0) results[blockIdx.x] = r;
   }
 }
 
