@@ -148,6 +148,60 @@ def test_thinned_winnowing_equals_single_stream():
     assert total_kept < 0.6 * total, (total_kept, total)
 
 
+def test_device_winnower_model_equals_single_stream():
+    """map_winnow.hip's control flow and capacities, run on the host over plain arrays (the kernel shares the code and
+    swaps in wave-wide primitives): every chunking must give addMinmers' records, or hand the sequence back"""
+    handed = total = 0
+    for name, seq in _thin_cases():
+        for (k, w, s) in ((15, 1000, 39), (15, 500, 16), (19, 256, 5), (15, 1000, 78)):
+            if len(seq) < w:
+                continue
+            h, st = pymap.hash_kmers(capi_norm(seq), k)
+            one = capi.host_winnow(seq, k, w, s, 3, h, st)
+            for c_factor in (3.0, 1.5):
+                for chunk in (0, 4 * w + 17, 9000, 25000):
+                    got, why = capi.host_winnow_model(seq, k, w, s, 3, h, st, c_factor, chunk)
+                    total += 1
+                    if got is None:
+                        handed += 1
+                        assert name == "n_in_first_kmers" and why == 1 << 31, (name, k, w, s, c_factor, chunk, hex(why))
+                        continue
+                    assert len(got) == len(one) and got.tobytes() == one.tobytes(), (name, k, w, s, c_factor, chunk)
+    assert handed * 8 < total, (handed, total)
+
+
+@pytest.mark.skipif(not pymap.have_ref(), reason="reference build (oracle/_ref) only exists in the authoring container")
+def test_device_winnower_model_matches_reference_live():
+    rng = random.Random(12)
+    done = 0
+    for i in range(30):
+        n = rng.choice([4000, 9000, 30000])
+        s = bytearray(synth.random_dna(700 + i, n))
+        for _ in range(rng.randrange(0, 4)):
+            p = rng.randrange(0, n)
+            L = rng.randrange(1, 80)
+            s[p:p + L] = (b"N" * L)[:max(0, min(L, n - p))]
+        if rng.random() < 0.4:
+            unit = bytes(s[:rng.choice([5, 31, 150, 700])])
+            a = rng.randrange(0, n // 2)
+            rep = (unit * (n // len(unit) + 1))[:n // 3]
+            s[a:a + len(rep)] = rep
+            for _ in range(n // 200):
+                s[rng.randrange(0, n)] = rng.choice(b"ACGT")
+        s = bytes(s[:n])
+        k = rng.choice([15, 19])
+        w = rng.choice([256, 1000])
+        sk = rng.choice([5, 23, 39])
+        ref = pymap.ref_add_minmers(s, k, w, sk, 5)
+        h, st = pymap.hash_kmers(capi_norm(s), k)
+        got, why = capi.host_winnow_model(s, k, w, sk, 5, h, st, 3.0, rng.choice([4 * w + 3, 6000]))
+        if got is None:
+            continue
+        done += 1
+        assert _as_list(got) == _as_list(ref), (i, n, k, w, sk)
+    assert done >= 20
+
+
 def test_spread_sort_equals_std_sort_ties_included():
     """records tie under the reference's (wpos, wpos_end) order and std::sort's tie order is part of the output:
     the multi-threaded form must reproduce it exactly"""
@@ -203,7 +257,7 @@ def test_add_minmers_streamed_replay_paths(force):
         "multi = h.add_minmers_multi(seqs, 15, 256, 12, threads=8)\n"
         "assert all(a.tobytes() == b.tobytes() for a, b in zip(multi, single))\n"
         "print('same', sum(len(a) for a in multi))\n")
-    env = dict(os.environ, WFM_WINNOW_CHUNK=str(64 * 256), WFM_WINNOW_FORCE=force, WFM_DEBUG="1")
+    env = dict(os.environ, WFM_WINNOW_CHUNK=str(64 * 256), WFM_WINNOW_FORCE=force, WFM_DEBUG="1", WFM_WINNOW_DEVICE="0")  # the host's chunks
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode == 0 and "same" in r.stdout, r.stderr[-2000:]
     streamed = [l for l in r.stderr.splitlines() if "streamed through the pinned ring" in l]
@@ -225,3 +279,34 @@ def test_prefilter_gpu_matches_host_definition(gpu):
             pos, ph, ps = gpu.prefilter_kmers(seq, k, w, s, c)
             assert pos.tobytes() == kept.tobytes(), (name, k, w, s, c, len(pos), len(kept))
             assert (ph == h[pos]).all() and (ps == st[pos]).all(), (name, k, w, s, c)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dev_chunk", ["1041", "16384"])
+def test_add_minmers_multi_winnows_on_the_device(dev_chunk):
+    """the production path of a thinned stream: one wave per speculative chunk (map_winnow.hip), boundary states compared and
+    interval starts resolved on the device; against one dense host stream per sequence.  The sequences the device may hand
+    back are the ones the test names (an N among the first k-mers that the reference does not notice)."""
+    import subprocess
+    import sys
+    code = (
+        "import sys; sys.path.insert(0, '.'); sys.path.insert(0, 'tests')\n"
+        "from wfmash_amd import capi\n"
+        "from test_minmers import _thin_cases\n"
+        "h = capi.Handle(0)\n"
+        "seqs = [s for _, s in _thin_cases() if len(s) >= 1000]\n"
+        "for (k, w, s) in ((15, 256, 12), (15, 1000, 39), (19, 500, 70)):\n"
+        "    single = [h.add_minmers(sq, k, w, s, i) for i, sq in enumerate(seqs)]\n"
+        "    multi = h.add_minmers_multi(seqs, k, w, s, threads=8)\n"
+        "    bad = [i for i, (a, b) in enumerate(zip(multi, single)) if a.tobytes() != b.tobytes()]\n"
+        "    assert not bad, (k, w, s, bad)\n"
+        "    print('same', k, w, s, sum(len(a) for a in multi))\n")
+    env = dict(os.environ, WFM_WINNOW_CHUNK=str(64 * 1000), WFM_WINNOW_DEV_CHUNK=dev_chunk, WFM_DEBUG="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0 and r.stdout.count("same") == 3, (r.stdout[-1000:], r.stderr[-3000:])
+    lines = [l for l in r.stderr.splitlines() if "winnowing on the device" in l]
+    assert len(lines) == 3, r.stderr[-3000:]
+    for l in lines:
+        nseq = int(l.split("winnowing on the device:")[1].split("sequences")[0])
+        back = int(l.split(";")[1].split("handed back")[0])
+        assert nseq >= 9 and back <= 1, l

@@ -779,6 +779,23 @@ def host_winnow_thinned(seq: bytes, k: int, w: int, s: int, seq_id: int, hashes,
     return out[:n], kept[:nk.value], rep.value
 
 
+def host_winnow_model(seq: bytes, k: int, w: int, s: int, seq_id: int, hashes, strands, c_factor: float = 3.0, chunk_len: int = 0):
+    """The device winnower's control flow and capacities on the host (map_winnow.hip's model) over the thinned stream;
+    returns (minmers or None when the device would hand the sequence back, why-bits)."""
+    L = load()
+    f = L.wfmh_test_winnow_model
+    f.restype = C.c_int64
+    f.argtypes = [C.c_char_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int32, C.c_void_p, C.c_void_p, C.c_double, C.c_int64, C.c_void_p,
+                  C.c_int64, C.POINTER(C.c_uint32)]
+    cap = 4 * len(seq) + 64
+    out = np.zeros(cap, dtype=MINMER_DTYPE)
+    hashes = np.ascontiguousarray(hashes, dtype=np.uint64)
+    strands = np.ascontiguousarray(strands, dtype=np.int8)
+    why = C.c_uint32(0)
+    n = f(seq, len(seq), k, w, s, seq_id, hashes.ctypes.data, strands.ctypes.data, c_factor, chunk_len, out.ctypes.data, cap, C.byref(why))
+    return (None if n < 0 else out[:n]), why.value
+
+
 def host_winnow_chunked(seq: bytes, k: int, w: int, s: int, seq_id: int, hashes, strands, chunk_len: int):
     """The speculative chunked form of the host winnowing (single thread); returns (minmers, replays).
     replays = chunks whose speculation failed and were replayed; -1 = fell back to one stream."""

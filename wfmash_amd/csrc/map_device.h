@@ -119,4 +119,19 @@ int map_sparse_lower_bound(wfm_handle_t* h, const MapSparseSeq* s, const int64_t
 // kept k-mers [c0, c1): uint64 hash[mc] | uint32 pos[mc] | int8 strand[mc], into a ring slot / ordinary memory
 int map_stage_copy_sparse(MapStage* st, int slot, const MapSparseSeq* s, int64_t c0, int64_t c1);
 int map_sparse_fetch_packed(const MapSparseSeq* s, int64_t c0, int64_t c1, char* dst);
+
+// The winnowing of a thinned stream on the device (map_winnow.hip): one wave per speculative chunk.
+struct MapWinnowWork {  // grow-only device buffers, reused from sequence to sequence
+  struct Buf { void* p = nullptr; size_t bytes = 0; };
+  Buf chunks, recs, count, st_begin, st_end, wp_end, flags, off, out, todo;
+};
+void map_winnow_work_free(MapWinnowWork* wk);
+struct MapWinnowInfo { int chunks = 0, bad_chunks = 0, rerun_chunks = 0, resolve_rounds = 0; uint32_t why = 0; int64_t records = 0; };
+// WFM_OK: *d_out (inside wk, valid until the next call) holds *n_out raw records in emission order, interval starts
+// resolved; 1: this sequence is not for the device (info->why), the caller winnows it on the host; < 0: error
+int map_winnow_sparse_device(wfm_handle_t* h, const MapSparseSeq* sp, int64_t len, int k, int w, int s, int32_t seq_id, int64_t chunk_len,
+                             MapWinnowWork* wk, wfm_minmer_t** d_out, int64_t* n_out, MapWinnowInfo* info);
+// the kernel's control flow and capacities on plain host arrays (CPU test-suite); -1 = the device would hand the sequence back
+int64_t map_winnow_model(const uint32_t* pos, const uint64_t* hash, const int8_t* strand, int64_t m, int64_t len, int k, int w, int s, int32_t seq_id,
+                         int64_t chunk_len, std::vector<wfm_minmer_t>* out, uint32_t* why);
 #endif

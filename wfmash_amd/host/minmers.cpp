@@ -557,6 +557,8 @@ struct SeqJob {
   const char* raw = nullptr;             // the caller's sequence, handle and GPU lock: to hash it again if the
   wfm_handle_t* handle = nullptr;        //   dense stream is needed after all (stitch()'s fall-back)
   std::mutex* gpu_mu = nullptr;
+  std::vector<wfm_minmer_t> dev_raw;     // winnowed on the device (map_winnow.hip): raw records in emission order, to be finished
+  bool dev_winnowed = false;
   std::vector<uint32_t> h_pos;           // test hook: the kept k-mers in host memory
   std::vector<uint64_t> h_hash;
   std::vector<int8_t> h_strand;
@@ -642,6 +644,12 @@ struct SeqJob {
     v.sp = packed_sparse(buf.data(), (size_t)(c1 - c0));
     return v;
   }
+  // the closing cut / sort / de-duplication of records the device winnowed
+  void finish_device_records() {
+    std::vector<const std::vector<wfm_minmer_t>*> lists(1, &dev_raw);
+    finish_lists(lists, w, sort_threads, result, ms_parts + 1);
+    std::vector<wfm_minmer_t>().swap(dev_raw);
+  }
   // sequential: check every speculation against the state the previous chunk really reached
   void stitch() {
     // WFM_WINNOW_FORCE (tests): 1 = treat every speculation as failed, 2 = take the one-stream fall-back
@@ -710,6 +718,45 @@ int64_t chunk_length() {
 
 }  // namespace
 
+namespace {
+// the device's selection of k-mers (map_prefilter.hip) restated from its definition: candidates (hash <= tau), fresh
+// candidates, windows with fewer than s of them, and every valid k-mer of such windows
+void thin_on_host(const uint64_t* hash, const int8_t* strand, int64_t n, int64_t W, int s, uint64_t tau, std::vector<uint32_t>& pos,
+                  std::vector<uint64_t>& hs, std::vector<int8_t>& st) {
+  std::vector<std::pair<uint64_t, int64_t>> cand;
+  for (int64_t i = 0; i < n; ++i)
+    if (strand[i] != 0 && hash[i] <= tau) cand.emplace_back(hash[i], i);
+  std::sort(cand.begin(), cand.end());
+  std::vector<uint32_t> F((size_t)n + 1, 0), P((size_t)n + 1, 0);  // prefix sums, shifted by one
+  {
+    std::vector<uint8_t> fresh((size_t)n, 0);
+    for (size_t j = 0; j < cand.size(); ++j)
+      if (j == 0 || cand[j].first != cand[j - 1].first || cand[j].second - cand[j - 1].second >= W) fresh[(size_t)cand[j].second] = 1;
+    for (int64_t i = 0; i < n; ++i) F[(size_t)i + 1] = F[(size_t)i] + fresh[(size_t)i];
+  }
+  for (int64_t a = 0; a < n; ++a) {
+    const uint32_t under = (a + W <= n && F[(size_t)(a + W)] - F[(size_t)a] < (uint32_t)s) ? 1u : 0u;
+    P[(size_t)a + 1] = P[(size_t)a] + under;
+  }
+  for (int64_t i = 0; i < n; ++i) {
+    if (strand[i] == 0) continue;
+    const bool dense = P[(size_t)i + 1] - P[(size_t)std::max<int64_t>(0, i - W + 1)] > 0;  // a window a in (i-W, i] is under the bound
+    if (hash[i] <= tau || dense) { pos.push_back((uint32_t)i); hs.push_back(hash[i]); st.push_back(strand[i]); }
+  }
+}
+// Is there a k-mer among the first k-1 whose N the reference does not notice (Winnower's `extra_`)?  Those are hashed
+// on the host and woven into the stream there; a sequence that has one is not winnowed on the device.
+bool has_unnoticed_n(const char* head, int64_t head_len, int k) {
+  for (int64_t i = 0; i < k - 1 && i + k <= head_len; ++i) {
+    bool late_n = false, any_n = false;
+    for (int64_t b = std::max<int64_t>(i, k - 1); b < i + k; ++b) late_n |= head[b] == 'N';
+    for (int64_t b = i; b < i + k; ++b) any_n |= head[b] == 'N';
+    if (!late_n && any_n) return true;
+  }
+  return false;
+}
+}  // namespace
+
 extern "C" int64_t wfm_add_minmers(wfm_handle_t* h, const char* seq, int64_t len, int k, int w, int s, int32_t seq_id,
                                    wfm_minmer_t* out, int64_t cap) {
   const char* seqs[1] = {seq};
@@ -774,6 +821,19 @@ int64_t add_minmers_core(wfm_handle_t* h, const char* const* seqs, const int64_t
         queue.pop_front();
       }
       SeqJob* J = task.job;
+      if (J->dev_winnowed) {  // winnowed on the device: only the closing sort is left
+        const auto ts = std::chrono::steady_clock::now();
+        J->finish_device_records();
+        J->ms_stitch = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ts).count();
+        J->stitched.store(true, std::memory_order_release);
+        {
+          std::lock_guard<std::mutex> lk(mu);
+          inflight_bases -= J->len;
+          stitched.push_back(J);
+        }
+        cv_room.notify_one();
+        continue;
+      }
       SeqJob::View v;
       v.d = J->whole();
       if (task.slot >= 0) {
@@ -880,6 +940,12 @@ int64_t add_minmers_core(wfm_handle_t* h, const char* const* seqs, const int64_t
   std::mutex gpu_mu;  // the handle's stream and error string: this thread, and a worker that hashes a sequence again
   MapHashWork hash_work;
   MapThinWork thin_work;
+  MapWinnowWork winnow_work;
+  const bool dev_winnow = !(getenv("WFM_WINNOW_DEVICE") && atoi(getenv("WFM_WINNOW_DEVICE")) == 0);
+  const int64_t dev_chunk = getenv("WFM_WINNOW_DEV_CHUNK") ? atoll(getenv("WFM_WINNOW_DEV_CHUNK")) : (int64_t)1 << 14;
+  int64_t dev_seqs = 0, dev_handed_back = 0, dev_chunks = 0;
+  uint32_t dev_why = 0;
+  double ms_winnow = 0;
   std::vector<std::thread> pool;
   for (int t = 0; t < nthreads; ++t) pool.emplace_back(worker);
   std::thread stream_thread;
@@ -932,12 +998,41 @@ int64_t add_minmers_core(wfm_handle_t* h, const char* const* seqs, const int64_t
       J->cidx_warm.assign(r.begin() + (long)nc + 1, r.end());
       map_hashed_free(&J->dev);  // borrowed: just forgets the pointers
       J->on_device = false;
+      // the winnowing itself, one wave per chunk (map_winnow.hip); whatever the device hands back takes the host path below
+      if (dev_winnow && !has_unnoticed_n(J->head.data(), (int64_t)J->head.size(), k)) {
+        const auto tw = std::chrono::steady_clock::now();
+        wfm_minmer_t* d_recs = nullptr;
+        int64_t n_recs = 0;
+        MapWinnowInfo wi;
+        const int wrc = map_winnow_sparse_device(h, &J->sparse, len, k, w, s, J->seq_id, std::max<int64_t>(dev_chunk, 4 * (int64_t)w), &winnow_work, &d_recs, &n_recs, &wi);
+        if (wrc < 0) { rc = wrc; map_sparse_free(&J->sparse); break; }
+        dev_chunks += wi.chunks;
+        if (wrc == WFM_OK) {
+          J->dev_raw.resize((size_t)n_recs);
+          if (n_recs && hipMemcpy(J->dev_raw.data(), d_recs, (size_t)n_recs * sizeof(wfm_minmer_t), hipMemcpyDeviceToHost) != hipSuccess) {
+            wfm_set_error(h, "device-to-host copy of minmer records failed"); rc = WFM_E_HIP; map_sparse_free(&J->sparse); break;
+          }
+          J->dev_winnowed = true;
+          ++dev_seqs;
+        } else {
+          ++dev_handed_back;
+          dev_why |= wi.why;
+        }
+        ms_winnow += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tw).count();
+      }
     }
     gpu.unlock();
     ms_thin += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count();
     SeqJob* Jp = J.get();
     jobs[(size_t)i] = std::move(J);
-    if (streamed) {
+    if (Jp->dev_winnowed) {
+      map_sparse_free(&Jp->sparse);
+      {
+        std::lock_guard<std::mutex> lk(mu);
+        queue.push_back(Task{Jp, 0, -1});
+      }
+      cv_work.notify_one();
+    } else if (streamed) {
       {
         std::lock_guard<std::mutex> lk(mu);
         hashed.push_back(Jp);
@@ -983,6 +1078,10 @@ int64_t add_minmers_core(wfm_handle_t* h, const char* const* seqs, const int64_t
     if (J) { if (J->on_device) { map_hashed_free(&J->dev); J->on_device = false; } map_sparse_free(&J->sparse); }  // after an error
   map_hash_work_free(&hash_work);
   map_thin_work_free(&thin_work);
+  map_winnow_work_free(&winnow_work);
+  if (getenv("WFM_DEBUG") && (dev_seqs || dev_handed_back))
+    fprintf(stderr, "[wfm] winnowing on the device: %lld sequences in %lld chunks of %lld k-mers, %.1f ms; %lld handed back to the host (why 0x%x)\n",
+            (long long)dev_seqs, (long long)dev_chunks, (long long)dev_chunk, ms_winnow, (long long)dev_handed_back, dev_why);
   if (getenv("WFM_DEBUG")) {
     int64_t nchunks = 0, replays = 0;
     double stitch_max = 0;
@@ -1123,28 +1222,7 @@ extern "C" int64_t wfmh_test_winnow_thinned(const char* seq, int64_t len, int k,
   J.strand.reset(new int8_t[(size_t)n]);
   memcpy(J.hash.get(), hash, (size_t)n * 8);
   memcpy(J.strand.get(), strand, (size_t)n);
-  const uint64_t tau = map_prefilter_tau(c_factor, s, W);
-  // candidates sorted by (hash, position) -> fresh flags
-  std::vector<std::pair<uint64_t, int64_t>> cand;
-  for (int64_t i = 0; i < n; ++i)
-    if (strand[i] != 0 && hash[i] <= tau) cand.emplace_back(hash[i], i);
-  std::sort(cand.begin(), cand.end());
-  std::vector<uint32_t> F((size_t)n + 1, 0), P((size_t)n + 1, 0);  // prefix sums, shifted by one
-  {
-    std::vector<uint8_t> fresh((size_t)n, 0);
-    for (size_t j = 0; j < cand.size(); ++j)
-      if (j == 0 || cand[j].first != cand[j - 1].first || cand[j].second - cand[j - 1].second >= W) fresh[(size_t)cand[j].second] = 1;
-    for (int64_t i = 0; i < n; ++i) F[(size_t)i + 1] = F[(size_t)i] + fresh[(size_t)i];
-  }
-  for (int64_t a = 0; a < n; ++a) {
-    const uint32_t under = (a + W <= n && F[(size_t)(a + W)] - F[(size_t)a] < (uint32_t)s) ? 1u : 0u;
-    P[(size_t)a + 1] = P[(size_t)a] + under;
-  }
-  for (int64_t i = 0; i < n; ++i) {
-    if (strand[i] == 0) continue;
-    const bool dense = P[(size_t)i + 1] - P[(size_t)std::max<int64_t>(0, i - W + 1)] > 0;  // a window a in (i-W, i] is under the bound
-    if (hash[i] <= tau || dense) { J.h_pos.push_back((uint32_t)i); J.h_hash.push_back(hash[i]); J.h_strand.push_back(strand[i]); }
-  }
+  thin_on_host(hash, strand, n, W, s, map_prefilter_tau(c_factor, s, W), J.h_pos, J.h_hash, J.h_strand);
   if (n_kept) *n_kept = (int64_t)J.h_pos.size();
   for (size_t i = 0; kept_pos && i < J.h_pos.size() && (int64_t)i < cap_kept; ++i) kept_pos[i] = J.h_pos[i];
   J.thinned = true;
@@ -1179,3 +1257,28 @@ extern "C" void wfmh_test_sort_records(wfm_minmer_t* recs, int64_t n, int thread
   sort_as_std(recs, recs + n, [](const wfm_minmer_t& l, const wfm_minmer_t& r) { return std::tie(l.wpos, l.wpos_end) < std::tie(r.wpos, r.wpos_end); }, threads);
 }
 
+
+// Test hook (CPU test-suite): the device winnower's control flow and capacities run on the host (map_winnow.hip's
+// model) over the thinned stream, chunk after chunk, then the closing cut / sort / de-duplication.  Returns the number
+// of records, or -1 when the device would hand the sequence back to the host (*why: wn::F_* bits; bit 31: an N in the
+// first k-mers that the reference does not notice).
+extern "C" int64_t wfmh_test_winnow_model(const char* seq, int64_t len, int k, int w, int s, int32_t seq_id, const uint64_t* hash,
+                                          const int8_t* strand, double c_factor, int64_t chunk_len, wfm_minmer_t* out, int64_t cap, uint32_t* why) {
+  if (why) *why = 0;
+  if (len < k) return 0;
+  const int64_t n = len - k + 1, W = (int64_t)w - k + 1;
+  std::string norm(seq, (size_t)len);
+  normalise(&norm[0], len);
+  if (has_unnoticed_n(norm.data(), std::min<int64_t>(len, 2 * (int64_t)k), k)) { if (why) *why = 1u << 31; return -1; }
+  std::vector<uint32_t> pos; std::vector<uint64_t> hs; std::vector<int8_t> st;
+  thin_on_host(hash, strand, n, W, s, map_prefilter_tau(c_factor, s, W), pos, hs, st);
+  std::vector<wfm_minmer_t> recs;
+  static const uint32_t none_p = 0; static const uint64_t none_h = 0; static const int8_t none_s = 0;
+  const int64_t got = map_winnow_model(pos.empty() ? &none_p : pos.data(), hs.empty() ? &none_h : hs.data(), st.empty() ? &none_s : st.data(),
+                                       (int64_t)pos.size(), len, k, w, s, seq_id, chunk_len, &recs, why);
+  if (got < 0) return -1;
+  finish_records(recs, w, 1);
+  const int64_t m = (int64_t)recs.size();
+  for (int64_t i = 0; i < m && i < cap; ++i) out[i] = recs[(size_t)i];
+  return m;
+}
