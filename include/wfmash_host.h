@@ -92,6 +92,22 @@ int64_t wfmh_test_winnow_thinned(const char* seq, int64_t len, int k, int w, int
  * threads > 1 the same introsort with its halves on several threads -- same result, ties included */
 void wfmh_test_sort_records(wfm_minmer_t* recs, int64_t n, int threads);
 
+/* The winnowing kernel's control flow and capacities (wfmash_amd/csrc/map_winnow_core.h: one speculative chunk of the
+ * thinned stream per wave, boundary states compared, interval starts resolved) run on the host over plain arrays, then
+ * the closing steps.  Returns the number of records, or -1 when the device would hand the sequence back to the host's
+ * winnower (*why: the wn::F_* bits of map_winnow_core.h; bit 31: an N among the first k-mers the reference does not notice). */
+int64_t wfmh_test_winnow_model(const char* seq, int64_t len, int k, int w, int s, int32_t seq_id, const uint64_t* hash,
+                               const int8_t* strand, double c_factor, int64_t chunk_len, wfm_minmer_t* out, int64_t cap,
+                               uint32_t* why);
+
+/* The arrangement wfm_finish_records computes on the device -- the partitions of std::sort's introsort loop as lists,
+ * swaps and a cut, then a stable sort (wfmash_amd/csrc/map_finish.hip) -- computed on the host, in place; key = (wpos, wpos_end). */
+void wfmh_test_sortlike_model(wfm_minmer_t* recs, int64_t n);
+
+/* The closing steps of addMinmers on raw interval records by the host path (cut, strand signs, std::sort, std::unique):
+ * what wfm_finish_records (wfmash_hip.h) is held against. */
+int64_t wfmh_test_finish_records(const wfm_minmer_t* raw, int64_t n, int w, wfm_minmer_t* out, int64_t cap);
+
 /* ---- map phase (skch::Map, src/map/include/computeMap.hpp) ---- */
 
 /* skch::Parameters as set up by parse_args.hpp; wfmh_map_default_params fills the defaults

@@ -310,3 +310,62 @@ def test_add_minmers_multi_winnows_on_the_device(dev_chunk):
         nseq = int(l.split("winnowing on the device:")[1].split("sequences")[0])
         back = int(l.split(";")[1].split("handed back")[0])
         assert nseq >= 9 and back <= 1, l
+
+
+def _raw_records(rng, n, span, w):
+    """raw interval records as a winnower emits them: nearly ordered by their end, many ties, some empty, some longer than w"""
+    recs = np.zeros(n, dtype=capi.MINMER_DTYPE)
+    end = np.sort(rng.integers(1, span, n))
+    length = rng.integers(0, 3 * w // 2, n)
+    length[rng.random(n) < 0.05] = rng.integers(w, 6 * w, int((rng.random(n) < 0.05).sum()) or 1)[0]
+    recs["wpos_end"] = end + rng.integers(0, 3, n)
+    recs["wpos"] = np.maximum(recs["wpos_end"] - length, 0)
+    recs["hash"] = rng.integers(0, 50 if span < 1000 else 2**62, n, dtype=np.int64).astype(np.uint64)
+    recs["strand"] = rng.integers(-3, 4, n)
+    recs["seqId"] = 7
+    return recs
+
+
+def test_sortlike_model_equals_std_sort():
+    """map_finish.hip's restatement of std::sort -- the partitions of one recursion depth as lists, swaps and a cut,
+    then a stable sort -- leaves every tie where the library leaves it"""
+    rng = np.random.default_rng(11)
+    for n, span in ((17, 5), (300, 40), (5000, 300), (200_000, 3000), (400_000, 5_000_000), (100_000, 3)):
+        recs = np.zeros(n, dtype=capi.MINMER_DTYPE)
+        base = np.sort(rng.integers(0, span, n))
+        recs["wpos"] = np.maximum(base + rng.integers(-3, 4, n), 0)
+        recs["wpos_end"] = recs["wpos"] + rng.integers(1, 4, n)
+        recs["hash"] = rng.integers(0, 2**63, n, dtype=np.int64).astype(np.uint64)
+        assert capi.host_sortlike_model(recs).tobytes() == capi.host_sort_records(recs, 1).tobytes(), (n, span)
+    # a range that spends its depth budget (heap-sorted by the library in both)
+    n = 200_000
+    recs = np.zeros(n, dtype=capi.MINMER_DTYPE)
+    i = np.arange(n)
+    recs["wpos"] = np.where(i % 2 == 1, i, n - i)
+    recs["wpos_end"] = recs["wpos"] + 1
+    recs["hash"] = i.astype(np.uint64)
+    assert capi.host_sortlike_model(recs).tobytes() == capi.host_sort_records(recs, 1).tobytes()
+
+
+@pytest.mark.gpu
+def test_finish_records_on_the_device_equal_the_host(gpu):
+    """cut into pieces of w windows, strand signs, std::sort's order with its ties, de-duplication: the device's
+    data-parallel form (sortlike_level_kernel + a stable radix sort) against the library itself on the host"""
+    rng = np.random.default_rng(23)
+    for n, span, w in ((0, 10, 100), (1, 10, 100), (16, 40, 10), (17, 40, 10), (3000, 200, 16), (250_000, 40_000, 1000), (1_200_000, 30_000_000, 1000),
+                       (300_000, 900, 256)):
+        raw = _raw_records(rng, n, span, w) if n else np.zeros(0, dtype=capi.MINMER_DTYPE)
+        exp = capi.host_finish_records(raw, w)
+        got, levels, heaps = gpu.finish_records(raw, w)
+        assert len(got) == len(exp) and got.tobytes() == exp.tobytes(), (n, span, w, len(got), len(exp), levels, heaps)
+    # the depth budget: ranges go to the library's heapsort
+    n = 300_000
+    raw = np.zeros(n, dtype=capi.MINMER_DTYPE)
+    i = np.arange(n)
+    raw["wpos"] = np.where(i % 2 == 1, i, n - i)
+    raw["wpos_end"] = raw["wpos"] + 1 + (i % 3)
+    raw["hash"] = (i * 2654435761 % 1000).astype(np.uint64)
+    raw["strand"] = 1
+    exp = capi.host_finish_records(raw, 1000)
+    got, levels, heaps = gpu.finish_records(raw, 1000)
+    assert got.tobytes() == exp.tobytes(), (levels, heaps)

@@ -26,7 +26,7 @@ EXPORTS = [
     "wfm_index_build", "wfm_index_free", "wfm_index_info", "wfm_index_download",
     "wfm_map_l1", "wfm_map_l2", "wfm_map_fragments", "wfm_minhash_sketch", "wfm_add_minmers_multi",
     "wfm_prefilter_kmers", "wfm_index_build_sequences", "wfm_index_upload",
-    "wfm_index_replicate", "wfm_device_count",
+    "wfm_index_replicate", "wfm_device_count", "wfm_finish_records",
 ]
 
 
@@ -510,6 +510,24 @@ class Handle:
         offs = np.concatenate([[0], np.cumsum(counts)])
         return [out[offs[i]:offs[i + 1]] for i in range(n)]
 
+    def finish_records(self, raw, w: int):
+        """wfm_finish_records: the closing steps of addMinmers on the device (map_finish.hip) on raw interval records;
+        returns (records, recursion levels, ranges heap-sorted on the host)."""
+        raw = np.ascontiguousarray(raw, dtype=MINMER_DTYPE)
+        f = self._L.wfm_finish_records
+        f.restype = C.c_int64
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int64, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+        cap = 4 * len(raw) + 64
+        lv, hp = C.c_int32(0), C.c_int32(0)
+        while True:
+            out = np.zeros(cap, dtype=MINMER_DTYPE)
+            n = f(self._p, raw.ctypes.data, len(raw), w, out.ctypes.data, cap, C.byref(lv), C.byref(hp))
+            if n < 0:
+                raise WfmError(f"wfm_finish_records failed ({n}): {self.last_error()}")
+            if n <= cap:
+                return out[:n], lv.value, hp.value
+            cap = int(n)
+
     def prefilter_kmers(self, seq: bytes, k: int, w: int, s: int, c_factor: float = 4.0):
         """wfm_prefilter_kmers: the k-mers the host winnowing gets to see; returns (pos, hash, strand)."""
         cap = len(seq) + 1
@@ -543,7 +561,7 @@ class Handle:
 # ---------------------------------------------------------------------------
 HOST_EXPORTS = ["wfmh_align_default_params", "wfmh_align_paf", "wfmh_test_cigar", "wfmh_free", "wfmh_test_winnow",
                 "wfmh_map_default_params", "wfmh_test_filter", "wfmh_map", "wfmh_test_winnow_chunked", "wfmh_test_fasta", "wfmh_test_winnow_thinned", "wfmh_test_sort_records", "wfmh_test_index_file",
-                "wfmh_map_multi", "wfmh_align_paf_multi"]
+                "wfmh_map_multi", "wfmh_align_paf_multi", "wfmh_test_winnow_model", "wfmh_test_sortlike_model", "wfmh_test_finish_records"]
 
 
 class MapSummary(C.Structure):
@@ -794,6 +812,33 @@ def host_winnow_model(seq: bytes, k: int, w: int, s: int, seq_id: int, hashes, s
     why = C.c_uint32(0)
     n = f(seq, len(seq), k, w, s, seq_id, hashes.ctypes.data, strands.ctypes.data, c_factor, chunk_len, out.ctypes.data, cap, C.byref(why))
     return (None if n < 0 else out[:n]), why.value
+
+
+def host_sortlike_model(recs):
+    """map_finish.hip's data-parallel restatement of std::sort's arrangement, run on the host; returns the sorted copy."""
+    L = load()
+    f = L.wfmh_test_sortlike_model
+    f.restype = None
+    f.argtypes = [C.c_void_p, C.c_int64]
+    out = np.ascontiguousarray(recs, dtype=MINMER_DTYPE).copy()
+    f(out.ctypes.data, len(out))
+    return out
+
+
+def host_finish_records(raw, w: int):
+    """cut / strand sign / std::sort / de-duplication of raw interval records on the host (finish_records)."""
+    L = load()
+    f = L.wfmh_test_finish_records
+    f.restype = C.c_int64
+    f.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int64]
+    raw = np.ascontiguousarray(raw, dtype=MINMER_DTYPE)
+    cap = 4 * len(raw) + 64
+    while True:
+        out = np.zeros(cap, dtype=MINMER_DTYPE)
+        n = f(raw.ctypes.data, len(raw), w, out.ctypes.data, cap)
+        if n <= cap:
+            return out[:n]
+        cap = n
 
 
 def host_winnow_chunked(seq: bytes, k: int, w: int, s: int, seq_id: int, hashes, strands, chunk_len: int):

@@ -7,6 +7,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <utility>
 #include <vector>
 
 #include "../../include/wfmash_hip.h"
@@ -131,6 +132,18 @@ struct MapWinnowInfo { int chunks = 0, bad_chunks = 0, rerun_chunks = 0, resolve
 // resolved; 1: this sequence is not for the device (info->why), the caller winnows it on the host; < 0: error
 int map_winnow_sparse_device(wfm_handle_t* h, const MapSparseSeq* sp, int64_t len, int k, int w, int s, int32_t seq_id, int64_t chunk_len,
                              MapWinnowWork* wk, wfm_minmer_t** d_out, int64_t* n_out, MapWinnowInfo* info);
+// The closing steps of addMinmers on the device (map_finish.hip): pieces of at most w windows, strand signs, std::sort's
+// order by (wpos, wpos_end) -- ties as libstdc++'s introsort leaves them -- and de-duplication.
+struct MapFinishWork {  // grow-only device buffers
+  struct Buf { void* p = nullptr; size_t bytes = 0; };
+  Buf ns, np, os, op, R, key, idx, key2, idx2, A, B, seg[4], heap, counts, tmp, out;
+};
+void map_finish_work_free(MapFinishWork* wk);
+struct MapFinishInfo { int64_t laid_out = 0, records = 0; int levels = 0, heap_ranges = 0; };
+int map_finish_records_device(wfm_handle_t* h, const wfm_minmer_t* d_raw, int64_t n_raw, int w, MapFinishWork* wk, wfm_minmer_t** d_out, int64_t* n_out,
+                              MapFinishInfo* info);
+void map_sortlike_model(std::vector<std::pair<uint64_t, uint32_t>>& v);  // the same arrangement computed on the host (CPU test-suite)
+
 // the kernel's control flow and capacities on plain host arrays (CPU test-suite); -1 = the device would hand the sequence back
 int64_t map_winnow_model(const uint32_t* pos, const uint64_t* hash, const int8_t* strand, int64_t m, int64_t len, int k, int w, int s, int32_t seq_id,
                          int64_t chunk_len, std::vector<wfm_minmer_t>* out, uint32_t* why);

@@ -559,6 +559,8 @@ struct SeqJob {
   std::mutex* gpu_mu = nullptr;
   std::vector<wfm_minmer_t> dev_raw;     // winnowed on the device (map_winnow.hip): raw records in emission order, to be finished
   bool dev_winnowed = false;
+  wfm_minmer_t* d_result = nullptr;      // winnowed AND finished on the device (map_finish.hip): the sequence's records, on the device
+  int64_t n_result = 0;
   std::vector<uint32_t> h_pos;           // test hook: the kept k-mers in host memory
   std::vector<uint64_t> h_hash;
   std::vector<int8_t> h_strand;
@@ -775,6 +777,7 @@ namespace {
 struct MinmerSink {
   virtual ~MinmerSink() = default;
   virtual int put(const wfm_minmer_t* recs, int64_t n) = 0;
+  virtual int put_device(const wfm_minmer_t* d_recs, int64_t n) = 0;  // the same, records on the device
 };
 
 int64_t add_minmers_core(wfm_handle_t* h, const char* const* seqs, const int64_t* lens, const int32_t* seq_ids, int64_t nseq,
@@ -930,17 +933,22 @@ int64_t add_minmers_core(wfm_handle_t* h, const char* const* seqs, const int64_t
     for (; next_out < limit; ++next_out) {
       SeqJob* J = jobs[(size_t)next_out].get();
       if (J && !J->stitched.load(std::memory_order_acquire)) break;
-      const int64_t n = J ? (int64_t)J->result.size() : 0;
+      const int64_t n = J ? (J->d_result ? J->n_result : (int64_t)J->result.size()) : 0;
       if (counts) counts[next_out] = n;
-      if (n && sink_rc == WFM_OK) sink_rc = sink.put(J->result.data(), n);
+      if (n && sink_rc == WFM_OK) sink_rc = J->d_result ? sink.put_device(J->d_result, n) : sink.put(J->result.data(), n);
       total += n;
       if (J) J->result.release();
+      if (J && J->d_result) { (void)hipFree(J->d_result); J->d_result = nullptr; }
     }
   };
   std::mutex gpu_mu;  // the handle's stream and error string: this thread, and a worker that hashes a sequence again
   MapHashWork hash_work;
   MapThinWork thin_work;
   MapWinnowWork winnow_work;
+  MapFinishWork finish_work;
+  const bool dev_finish = !(getenv("WFM_FINISH_DEVICE") && atoi(getenv("WFM_FINISH_DEVICE")) == 0);
+  int dev_levels = 0;
+  int64_t dev_heaps = 0;
   const bool dev_winnow = !(getenv("WFM_WINNOW_DEVICE") && atoi(getenv("WFM_WINNOW_DEVICE")) == 0);
   const int64_t dev_chunk = getenv("WFM_WINNOW_DEV_CHUNK") ? atoll(getenv("WFM_WINNOW_DEV_CHUNK")) : (int64_t)1 << 14;
   int64_t dev_seqs = 0, dev_handed_back = 0, dev_chunks = 0;
@@ -1007,7 +1015,28 @@ int64_t add_minmers_core(wfm_handle_t* h, const char* const* seqs, const int64_t
         const int wrc = map_winnow_sparse_device(h, &J->sparse, len, k, w, s, J->seq_id, std::max<int64_t>(dev_chunk, 4 * (int64_t)w), &winnow_work, &d_recs, &n_recs, &wi);
         if (wrc < 0) { rc = wrc; map_sparse_free(&J->sparse); break; }
         dev_chunks += wi.chunks;
-        if (wrc == WFM_OK) {
+        bool finished = false;
+        if (wrc == WFM_OK && dev_finish) {  // the closing cut / sort / de-duplication on the device as well
+          wfm_minmer_t* d_fin = nullptr;
+          int64_t n_fin = 0;
+          MapFinishInfo fi;
+          const int frc = map_finish_records_device(h, d_recs, n_recs, w, &finish_work, &d_fin, &n_fin, &fi);
+          if (frc != WFM_OK) { rc = frc; map_sparse_free(&J->sparse); break; }
+          if (n_fin) {
+            if (hipMalloc((void**)&J->d_result, (size_t)n_fin * sizeof(wfm_minmer_t)) != hipSuccess ||
+                hipMemcpy(J->d_result, d_fin, (size_t)n_fin * sizeof(wfm_minmer_t), hipMemcpyDeviceToDevice) != hipSuccess) {
+              wfm_set_error(h, "out of device memory (minmer records)"); rc = WFM_E_NOMEM; map_sparse_free(&J->sparse); break;
+            }
+          }
+          J->n_result = n_fin;
+          J->dev_winnowed = true;
+          finished = true;
+          ++dev_seqs;
+          dev_levels = std::max(dev_levels, fi.levels);
+          dev_heaps += fi.heap_ranges;
+        }
+        if (finished) {
+        } else if (wrc == WFM_OK) {
           J->dev_raw.resize((size_t)n_recs);
           if (n_recs && hipMemcpy(J->dev_raw.data(), d_recs, (size_t)n_recs * sizeof(wfm_minmer_t), hipMemcpyDeviceToHost) != hipSuccess) {
             wfm_set_error(h, "device-to-host copy of minmer records failed"); rc = WFM_E_HIP; map_sparse_free(&J->sparse); break;
@@ -1025,7 +1054,14 @@ int64_t add_minmers_core(wfm_handle_t* h, const char* const* seqs, const int64_t
     ms_thin += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count();
     SeqJob* Jp = J.get();
     jobs[(size_t)i] = std::move(J);
-    if (Jp->dev_winnowed) {
+    if (Jp->dev_winnowed && (Jp->d_result || Jp->dev_raw.empty())) {  // winnowed and finished on the device: nothing left to do
+      map_sparse_free(&Jp->sparse);
+      Jp->stitched.store(true, std::memory_order_release);
+      {
+        std::lock_guard<std::mutex> lk(mu);
+        inflight_bases -= Jp->len;
+      }
+    } else if (Jp->dev_winnowed) {
       map_sparse_free(&Jp->sparse);
       {
         std::lock_guard<std::mutex> lk(mu);
@@ -1075,13 +1111,15 @@ int64_t add_minmers_core(wfm_handle_t* h, const char* const* seqs, const int64_t
   for (auto& t : pool) t.join();
   release_stitched();
   for (auto& J : jobs)
-    if (J) { if (J->on_device) { map_hashed_free(&J->dev); J->on_device = false; } map_sparse_free(&J->sparse); }  // after an error
+    if (J) { if (J->on_device) { map_hashed_free(&J->dev); J->on_device = false; } map_sparse_free(&J->sparse); if (J->d_result) { (void)hipFree(J->d_result); J->d_result = nullptr; } }  // after an error
   map_hash_work_free(&hash_work);
   map_thin_work_free(&thin_work);
   map_winnow_work_free(&winnow_work);
+  map_finish_work_free(&finish_work);
   if (getenv("WFM_DEBUG") && (dev_seqs || dev_handed_back))
-    fprintf(stderr, "[wfm] winnowing on the device: %lld sequences in %lld chunks of %lld k-mers, %.1f ms; %lld handed back to the host (why 0x%x)\n",
-            (long long)dev_seqs, (long long)dev_chunks, (long long)dev_chunk, ms_winnow, (long long)dev_handed_back, dev_why);
+    fprintf(stderr, "[wfm] winnowing on the device: %lld sequences in %lld chunks of %lld k-mers, %.1f ms (closing sort %s: %d levels at most, %lld ranges heap-sorted); %lld handed back to the host (why 0x%x)\n",
+            (long long)dev_seqs, (long long)dev_chunks, (long long)dev_chunk, ms_winnow, dev_finish ? "on the device" : "on the host", dev_levels, (long long)dev_heaps,
+            (long long)dev_handed_back, dev_why);
   if (getenv("WFM_DEBUG")) {
     int64_t nchunks = 0, replays = 0;
     double stitch_max = 0;
@@ -1113,6 +1151,11 @@ struct HostSink : MinmerSink {
     at += n;
     return WFM_OK;
   }
+  int put_device(const wfm_minmer_t* d_recs, int64_t n) override {
+    if (at < cap && hipMemcpy(out + at, d_recs, (size_t)std::min(n, cap - at) * sizeof(wfm_minmer_t), hipMemcpyDeviceToHost) != hipSuccess) return WFM_E_HIP;
+    at += n;
+    return WFM_OK;
+  }
 };
 
 // records into one growing device array (the index is built from it without a detour through host memory)
@@ -1122,7 +1165,9 @@ struct DeviceSink : MinmerSink {
   int64_t cap = 0, n = 0;
   DeviceSink(wfm_handle_t* hh, int64_t expect) : h(hh), cap(std::max<int64_t>(expect, 4096)) {}
   ~DeviceSink() override { if (d) (void)hipFree(d); }
-  int put(const wfm_minmer_t* recs, int64_t m) override {
+  int put(const wfm_minmer_t* recs, int64_t m) override { return append(recs, m, hipMemcpyHostToDevice); }
+  int put_device(const wfm_minmer_t* d_recs, int64_t m) override { return append(d_recs, m, hipMemcpyDeviceToDevice); }
+  int append(const wfm_minmer_t* recs, int64_t m, hipMemcpyKind kind) {
     if (hipSetDevice(wfm_device(h)) != hipSuccess) return WFM_E_HIP;
     if (!d || n + m > cap) {
       int64_t want = d ? std::max(cap + cap / 2, n + m) : std::max(cap, m);
@@ -1132,7 +1177,7 @@ struct DeviceSink : MinmerSink {
       if (d) (void)hipFree(d);
       d = nd; cap = want;
     }
-    if (hipMemcpy(d + n, recs, (size_t)m * sizeof(wfm_minmer_t), hipMemcpyHostToDevice) != hipSuccess) { wfm_set_error(h, "upload of minmer intervals failed"); return WFM_E_HIP; }
+    if (hipMemcpy(d + n, recs, (size_t)m * sizeof(wfm_minmer_t), kind) != hipSuccess) { wfm_set_error(h, "upload of minmer intervals failed"); return WFM_E_HIP; }
     n += m;
     return WFM_OK;
   }
@@ -1280,5 +1325,15 @@ extern "C" int64_t wfmh_test_winnow_model(const char* seq, int64_t len, int k, i
   finish_records(recs, w, 1);
   const int64_t m = (int64_t)recs.size();
   for (int64_t i = 0; i < m && i < cap; ++i) out[i] = recs[(size_t)i];
+  return m;
+}
+
+// Test hook: the closing steps of a sequence's raw records on the host (cut, strand sign, std::sort, de-duplication), as
+// finish_records runs them; returns the number of records.
+extern "C" int64_t wfmh_test_finish_records(const wfm_minmer_t* raw, int64_t n, int w, wfm_minmer_t* out, int64_t cap) {
+  std::vector<wfm_minmer_t> v(raw, raw + n);
+  finish_records(v, w, 1);
+  const int64_t m = (int64_t)v.size();
+  for (int64_t i = 0; i < m && i < cap; ++i) out[i] = v[(size_t)i];
   return m;
 }
