@@ -136,7 +136,7 @@ int map_winnow_sparse_device(wfm_handle_t* h, const MapSparseSeq* sp, int64_t le
 // order by (wpos, wpos_end) -- ties as libstdc++'s introsort leaves them -- and de-duplication.
 struct MapFinishWork {  // grow-only device buffers
   struct Buf { void* p = nullptr; size_t bytes = 0; };
-  Buf ns, np, os, op, R, key, idx, key2, idx2, A, B, seg[4], heap, counts, tmp, out;
+  Buf ns, np, os, op, R, key, idx, key2, idx2, A, B, seg[4], small_, heap, counts, tiles, tile_cnt, tile0, info, tmp, out;
 };
 void map_finish_work_free(MapFinishWork* wk);
 struct MapFinishInfo { int64_t laid_out = 0, records = 0; int levels = 0, heap_ranges = 0; };

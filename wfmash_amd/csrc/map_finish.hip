@@ -48,18 +48,38 @@ namespace {
   } while (0)
 
 struct Seg { int64_t f, l; int32_t depth, pad_; };
-constexpr int64_t SMALL_SEG = 1024;  // ranges up to this size are partitioned by one wave, larger ones by 16
-constexpr uint32_t NONE = 0xFFFFFFFFu;
+constexpr int64_t SMALL_SEG = 1024;       // ranges up to this size are finished by one wave in LDS, all their depths in one go
+constexpr int64_t HUGE_SEG = 128 * 1024;  // ranges above this size are partitioned by many workgroups (tiles of HUGE_TILE elements)
+constexpr int HUGE_TILE = 8192;
+struct HugeTile { int32_t seg, tile; };
+struct HugeInfo { uint64_t pivot; int32_t nA, nB, T, pad_; int64_t cut; };
 
 __device__ inline void swap_elems(uint64_t* key, uint32_t* idx, int64_t a, int64_t b) {
   const uint64_t k = key[a]; key[a] = key[b]; key[b] = k;
   const uint32_t i = idx[a]; idx[a] = idx[b]; idx[b] = i;
 }
 
+// counts[0]: next level's big ranges, [1]: small ranges (all levels), [2]: ranges for the heapsort, [3]: next level's huge ranges
+__device__ inline void push_child(const Seg& c, Seg* next_huge, Seg* next_big, Seg* small_, int* counts) {
+  const int64_t sz = c.l - c.f;
+  if (sz <= 16) return;
+  if (sz > HUGE_SEG) next_huge[atomicAdd(&counts[3], 1)] = c;
+  else if (sz > SMALL_SEG) next_big[atomicAdd(&counts[0], 1)] = c;
+  else small_[atomicAdd(&counts[1], 1)] = c;
+}
+__device__ inline int64_t median_pick(const uint64_t* key, int64_t f, int64_t l) {  // __move_median_to_first(first, first + 1, mid, last - 1)
+  const int64_t a = f + 1, b = f + (l - f) / 2, c = l - 1;
+  const uint64_t ka = key[a], kb = key[b], kc = key[c];
+  if (ka < kb) { if (kb < kc) return b; if (ka < kc) return c; return a; }
+  if (ka < kc) return a;
+  if (kb < kc) return c;
+  return b;
+}
+
 // One range per workgroup of NW waves: pivot, the lists A and B (positions relative to the array), the swaps, the children.
 template <int NW>
-__global__ void __launch_bounds__(NW * 64) sortlike_level_kernel(const Seg* cur, uint64_t* key, uint32_t* idx, uint32_t* A, uint32_t* B, Seg* next_big, Seg* next_small,
-                                                                  Seg* heap, int* counts) {
+__global__ void __launch_bounds__(NW * 64) sortlike_level_kernel(const Seg* cur, uint64_t* key, uint32_t* idx, uint32_t* A, uint32_t* B, Seg* next_huge, Seg* next_big,
+                                                                  Seg* next_small, Seg* heap, int* counts) {
   const Seg sg = cur[blockIdx.x];
   const int64_t f = sg.f, l = sg.l;
   const int tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -69,15 +89,8 @@ __global__ void __launch_bounds__(NW * 64) sortlike_level_kernel(const Seg* cur,
     if (tid == 0) heap[atomicAdd(&counts[2], 1)] = sg;
     return;
   }
-  if (tid == 0) {  // __move_median_to_first(first, first + 1, mid, last - 1)
-    const int64_t a = f + 1, b = f + (l - f) / 2, c = l - 1;
-    const uint64_t ka = key[a], kb = key[b], kc = key[c];
-    int64_t pick;
-    if (ka < kb) { if (kb < kc) pick = b; else if (ka < kc) pick = c; else pick = a; }
-    else if (ka < kc) pick = a;
-    else if (kb < kc) pick = c;
-    else pick = b;
-    swap_elems(key, idx, f, pick);
+  if (tid == 0) {
+    swap_elems(key, idx, f, median_pick(key, f, l));
     s_p = key[f];
   }
   __syncthreads();
@@ -128,12 +141,183 @@ __global__ void __launch_bounds__(NW * 64) sortlike_level_kernel(const Seg* cur,
   if (tid == 0) {
     const Seg kids[2] = {Seg{f, cut, sg.depth - 1, 0}, Seg{cut, l, sg.depth - 1, 0}};
     for (const Seg& c : kids) {
-      const int64_t sz = c.l - c.f;
-      if (sz <= 16) continue;
-      if (sz > SMALL_SEG) next_big[atomicAdd(&counts[0], 1)] = c;
-      else next_small[atomicAdd(&counts[1], 1)] = c;
+      push_child(c, next_huge, next_big, next_small, counts);
     }
   }
+}
+
+// ---- a range of more than HUGE_SEG elements: the same partition, spread over many workgroups ----
+__global__ void huge_pivot_kernel(const Seg* segs, uint64_t* key, uint32_t* idx, HugeInfo* info, Seg* heap, int* counts) {
+  const Seg sg = segs[blockIdx.x];
+  if (threadIdx.x != 0) return;
+  HugeInfo& I = info[blockIdx.x];
+  I.nA = I.nB = I.T = 0; I.cut = -1;
+  if (sg.depth == 0) { heap[atomicAdd(&counts[2], 1)] = sg; I.cut = -2; return; }  // budget spent: no partition
+  swap_elems(key, idx, sg.f, median_pick(key, sg.f, sg.l));
+  I.pivot = key[sg.f];
+}
+// elements >= pivot and <= pivot per tile
+__global__ void __launch_bounds__(256) huge_count_kernel(const Seg* segs, const HugeTile* tiles, const uint64_t* key, const HugeInfo* info, int2* tile_cnt) {
+  const HugeTile t = tiles[blockIdx.x];
+  const HugeInfo I = info[t.seg];
+  if (I.cut == -2) return;
+  const Seg sg = segs[t.seg];
+  const int64_t lo = sg.f + 1 + (int64_t)t.tile * HUGE_TILE, hi = lo + HUGE_TILE < sg.l ? lo + HUGE_TILE : sg.l;
+  int cge = 0, cle = 0;
+  for (int64_t i = lo + threadIdx.x; i < hi; i += 256) { const uint64_t k = key[i]; cge += k >= I.pivot; cle += k <= I.pivot; }
+  __shared__ int s_a[4], s_b[4];
+  for (int o = 32; o; o >>= 1) { cge += __shfl_xor(cge, o, 64); cle += __shfl_xor(cle, o, 64); }
+  if ((threadIdx.x & 63) == 0) { s_a[threadIdx.x >> 6] = cge; s_b[threadIdx.x >> 6] = cle; }
+  __syncthreads();
+  if (threadIdx.x == 0) tile_cnt[blockIdx.x] = make_int2(s_a[0] + s_a[1] + s_a[2] + s_a[3], s_b[0] + s_b[1] + s_b[2] + s_b[3]);
+}
+// per range: its tiles' counts -> offsets (in place), totals
+__global__ void __launch_bounds__(256) huge_offsets_kernel(const int* seg_tile0, int2* tile_cnt, HugeInfo* info) {
+  const int s = blockIdx.x;
+  if (info[s].cut == -2) return;
+  const int t0 = seg_tile0[s], t1 = seg_tile0[s + 1];
+  __shared__ int s_a[256], s_b[256];
+  int ra = 0, rb = 0;  // running totals of the tiles before this round
+  for (int base = t0; base < t1; base += 256) {
+    const int t = base + (int)threadIdx.x;
+    const int2 c = t < t1 ? tile_cnt[t] : make_int2(0, 0);
+    s_a[threadIdx.x] = c.x; s_b[threadIdx.x] = c.y;
+    __syncthreads();
+    int pa = 0, pb = 0, ta = 0, tb = 0;
+    for (int q = 0; q < 256; ++q) { if (q < (int)threadIdx.x) { pa += s_a[q]; pb += s_b[q]; } ta += s_a[q]; tb += s_b[q]; }
+    if (t < t1) tile_cnt[t] = make_int2(ra + pa, rb + pb);
+    ra += ta; rb += tb;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { info[s].nA = ra; info[s].nB = rb; }
+}
+// the lists
+__global__ void __launch_bounds__(256) huge_lists_kernel(const Seg* segs, const HugeTile* tiles, const uint64_t* key, const HugeInfo* info, const int2* tile_off, uint32_t* A,
+                                                         uint32_t* B) {
+  const HugeTile t = tiles[blockIdx.x];
+  const HugeInfo I = info[t.seg];
+  if (I.cut == -2) return;
+  const Seg sg = segs[t.seg];
+  const int64_t lo0 = sg.f + 1;
+  const int64_t lo = lo0 + (int64_t)t.tile * HUGE_TILE, hi = lo + HUGE_TILE < sg.l ? lo + HUGE_TILE : sg.l;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  __shared__ int s_a[4], s_b[4];
+  int oge = tile_off[blockIdx.x].x, ole = tile_off[blockIdx.x].y;
+  for (int64_t base = lo; base < hi; base += 256) {
+    const int64_t i = base + threadIdx.x;
+    const bool in = i < hi;
+    const uint64_t k = in ? key[i] : 0ull;
+    const bool ge = in && k >= I.pivot, le = in && k <= I.pivot;
+    const unsigned long long mg = __ballot(ge), ml = __ballot(le), below = (1ull << lane) - 1ull;
+    if (lane == 0) { s_a[wv] = __popcll(mg); s_b[wv] = __popcll(ml); }
+    __syncthreads();
+    int wa = 0, wb = 0, ta = 0, tb = 0;
+    for (int q = 0; q < 4; ++q) { if (q < wv) { wa += s_a[q]; wb += s_b[q]; } ta += s_a[q]; tb += s_b[q]; }
+    if (ge) A[lo0 + oge + wa + __popcll(mg & below)] = (uint32_t)(i - lo0);
+    if (le) B[lo0 + (I.nB - 1 - (ole + wb + __popcll(ml & below)))] = (uint32_t)(i - lo0);
+    oge += ta; ole += tb;
+    __syncthreads();
+  }
+}
+// T and the cut (A[t] < B[t] holds for t < T and for no later t: a bisection), the children
+__global__ void huge_cut_kernel(const Seg* segs, HugeInfo* info, const uint32_t* A, const uint32_t* B, Seg* next_huge, Seg* next_big, Seg* small_, int* counts) {
+  const int s = blockIdx.x;
+  if (threadIdx.x != 0 || info[s].cut == -2) return;
+  const Seg sg = segs[s];
+  HugeInfo& I = info[s];
+  const int64_t lo = sg.f + 1;
+  int a = 0, b = I.nA < I.nB ? I.nA : I.nB;  // T in [a, b]
+  while (a < b) { const int m = a + (b - a) / 2; if (A[lo + m] < B[lo + m]) a = m + 1; else b = m; }
+  const int T = a;
+  const int64_t ca = T < I.nA ? lo + (int64_t)A[lo + T] : INT64_MAX, cb = T > 0 ? lo + (int64_t)B[lo + T - 1] : INT64_MAX;
+  I.T = T; I.cut = ca < cb ? ca : cb;
+  push_child(Seg{sg.f, I.cut, sg.depth - 1, 0}, next_huge, next_big, small_, counts);
+  push_child(Seg{I.cut, sg.l, sg.depth - 1, 0}, next_huge, next_big, small_, counts);
+}
+__global__ void __launch_bounds__(256) huge_swap_kernel(const Seg* segs, const HugeTile* tiles, const HugeInfo* info, const uint32_t* A, const uint32_t* B, uint64_t* key,
+                                                        uint32_t* idx) {
+  const HugeTile t = tiles[blockIdx.x];
+  const HugeInfo I = info[t.seg];
+  if (I.cut == -2) return;
+  const int64_t lo = segs[t.seg].f + 1;
+  const int64_t t0 = (int64_t)t.tile * HUGE_TILE, t1 = t0 + HUGE_TILE < I.T ? t0 + HUGE_TILE : I.T;
+  for (int64_t q = t0 + threadIdx.x; q < t1; q += 256) swap_elems(key, idx, lo + (int64_t)A[lo + q], lo + (int64_t)B[lo + q]);
+}
+
+// ---- a range of at most SMALL_SEG elements: one wave, everything in LDS, all depths ----
+__global__ void __launch_bounds__(64) sortlike_small_kernel(const Seg* segs, uint64_t* key, uint32_t* idx, Seg* heap, int* counts) {
+  const Seg sg = segs[blockIdx.x];
+  const int m = (int)(sg.l - sg.f), lane = (int)threadIdx.x;
+  __shared__ uint64_t k[SMALL_SEG];
+  __shared__ uint32_t ix[SMALL_SEG];
+  __shared__ uint16_t A[SMALL_SEG], B[SMALL_SEG];
+  __shared__ int st_f[64], st_l[64], st_d[64];
+  for (int i = lane; i < m; i += 64) { k[i] = key[sg.f + i]; ix[i] = idx[sg.f + i]; }
+  __syncthreads();
+  int sp = 1;
+  if (lane == 0) { st_f[0] = 0; st_l[0] = m; st_d[0] = sg.depth; }
+  __syncthreads();
+  while (sp > 0) {
+    --sp;
+    int f = st_f[sp], l = st_l[sp], d = st_d[sp];
+    __syncthreads();
+    while (l - f > 16) {
+      if (d == 0) {  // budget spent: the library's heapsort on the host
+        if (lane == 0) heap[atomicAdd(&counts[2], 1)] = Seg{sg.f + f, sg.f + l, 0, 0};
+        break;
+      }
+      --d;
+      if (lane == 0) {
+        const int a = f + 1, b = f + (l - f) / 2, c = l - 1;
+        const uint64_t ka = k[a], kb = k[b], kc = k[c];
+        int pick;
+        if (ka < kb) { if (kb < kc) pick = b; else if (ka < kc) pick = c; else pick = a; }
+        else if (ka < kc) pick = a;
+        else if (kb < kc) pick = c;
+        else pick = b;
+        const uint64_t tk = k[f]; k[f] = k[pick]; k[pick] = tk;
+        const uint32_t ti = ix[f]; ix[f] = ix[pick]; ix[pick] = ti;
+      }
+      __syncthreads();
+      const uint64_t p = k[f];
+      const int lo = f + 1;
+      int nA = 0, nB = 0;
+      for (int base = lo; base < l; base += 64) {
+        const int i = base + lane;
+        const bool in = i < l;
+        const uint64_t kk = in ? k[i] : 0ull;
+        const bool ge = in && kk >= p, le = in && kk <= p;
+        const unsigned long long mg = __ballot(ge), ml = __ballot(le), below = (1ull << lane) - 1ull;
+        if (ge) A[nA + __popcll(mg & below)] = (uint16_t)i;
+        if (le) B[nB + __popcll(ml & below)] = (uint16_t)i;  // ascending here: B[t] of the text is B[nB - 1 - t]
+        nA += __popcll(mg); nB += __popcll(ml);
+      }
+      __syncthreads();
+      const int nmin = nA < nB ? nA : nB;
+      int T = 0;
+      for (int base = 0; base < nmin; base += 64) {
+        const int t = base + lane;
+        const unsigned long long mk = __ballot(t < nmin && A[t] < B[nB - 1 - t]);
+        T += __popcll(mk);
+        if (mk != ~0ull) break;  // the condition holds for a prefix only
+      }
+      const int ca = T < nA ? (int)A[T] : INT32_MAX, cb = T > 0 ? (int)B[nB - T] : INT32_MAX;
+      const int cut = ca < cb ? ca : cb;
+      for (int t = lane; t < T; t += 64) {
+        const int i = A[t], j = B[nB - 1 - t];
+        const uint64_t tk = k[i]; k[i] = k[j]; k[j] = tk;
+        const uint32_t ti = ix[i]; ix[i] = ix[j]; ix[j] = ti;
+      }
+      __syncthreads();
+      if (l - cut > 16) {
+        if (lane == 0) { st_f[sp] = cut; st_l[sp] = l; st_d[sp] = d; }
+        ++sp;
+      }
+      l = cut;
+      __syncthreads();
+    }
+  }
+  for (int i = lane; i < m; i += 64) { key[sg.f + i] = k[i]; idx[sg.f + i] = ix[i]; }
 }
 
 // ---- cut / layout / de-duplication ----
@@ -219,9 +403,12 @@ int sortlike_loop_device(wfm_handle_t* h, MapFinishWork* wk, uint64_t* key, uint
   if (levels_out) *levels_out = 0;
   if (heaps_out) *heaps_out = 0;
   if (n <= 16) return WFM_OK;
-  const size_t seg_cap = (size_t)n / 16 + 4;
-  if (grow(wk->A, (size_t)n * 4) || grow(wk->B, (size_t)n * 4) || grow(wk->seg[0], seg_cap * sizeof(Seg)) || grow(wk->seg[1], seg_cap * sizeof(Seg)) ||
-      grow(wk->seg[2], seg_cap * sizeof(Seg)) || grow(wk->seg[3], seg_cap * sizeof(Seg)) || grow(wk->heap, seg_cap * sizeof(Seg)) || grow(wk->counts, 64)) {
+  const size_t cap_small = (size_t)n / 16 + 4, cap_big = (size_t)n / (size_t)SMALL_SEG + 4, cap_huge = (size_t)n / (size_t)HUGE_SEG + 4;
+  const size_t cap_tiles = (size_t)n / HUGE_TILE + cap_huge + 4;
+  if (grow(wk->A, (size_t)n * 4) || grow(wk->B, (size_t)n * 4) || grow(wk->seg[0], cap_big * sizeof(Seg)) || grow(wk->seg[1], cap_big * sizeof(Seg)) ||
+      grow(wk->seg[2], cap_huge * sizeof(Seg)) || grow(wk->seg[3], cap_huge * sizeof(Seg)) || grow(wk->small_, cap_small * sizeof(Seg)) ||
+      grow(wk->heap, cap_small * sizeof(Seg)) || grow(wk->counts, 64) || grow(wk->tiles, cap_tiles * sizeof(HugeTile)) || grow(wk->tile_cnt, cap_tiles * sizeof(int2)) ||
+      grow(wk->tile0, (cap_huge + 1) * sizeof(int)) || grow(wk->info, cap_huge * sizeof(HugeInfo))) {
     wfm_set_error(h, "out of device memory (closing sort)");
     return WFM_E_NOMEM;
   }
@@ -229,30 +416,68 @@ int sortlike_loop_device(wfm_handle_t* h, MapFinishWork* wk, uint64_t* key, uint
   while (((int64_t)1 << (lg + 1)) <= n) ++lg;
   const Seg root{0, n, 2 * lg, 0};
   Seg* big[2] = {(Seg*)wk->seg[0].p, (Seg*)wk->seg[1].p};
-  Seg* small_[2] = {(Seg*)wk->seg[2].p, (Seg*)wk->seg[3].p};
+  Seg* huge[2] = {(Seg*)wk->seg[2].p, (Seg*)wk->seg[3].p};
+  Seg* small_ = (Seg*)wk->small_.p;
+  Seg* heap = (Seg*)wk->heap.p;
+  uint32_t *A = (uint32_t*)wk->A.p, *B = (uint32_t*)wk->B.p;
   int* d_counts = (int*)wk->counts.p;
-  int nbig = 0, nsmall = 0, nheap_total = 0;
-  if (n > SMALL_SEG) { HIPCHK(h, hipMemcpyAsync(big[0], &root, sizeof(Seg), hipMemcpyHostToDevice, st)); nbig = 1; }
-  else { HIPCHK(h, hipMemcpyAsync(small_[0], &root, sizeof(Seg), hipMemcpyHostToDevice, st)); nsmall = 1; }
+  int nbig = 0, nhuge = 0, nsmall = 0, nheap_total = 0;
   HIPCHK(h, hipMemsetAsync(d_counts, 0, 16, st));
+  if (n > HUGE_SEG) { HIPCHK(h, hipMemcpyAsync(huge[0], &root, sizeof(Seg), hipMemcpyHostToDevice, st)); nhuge = 1; }
+  else if (n > SMALL_SEG) { HIPCHK(h, hipMemcpyAsync(big[0], &root, sizeof(Seg), hipMemcpyHostToDevice, st)); nbig = 1; }
+  else { HIPCHK(h, hipMemcpyAsync(small_, &root, sizeof(Seg), hipMemcpyHostToDevice, st)); nsmall = 1; const int one = 1; HIPCHK(h, hipMemcpyAsync(d_counts + 1, &one, 4, hipMemcpyHostToDevice, st)); }
   int cur = 0, levels = 0;
-  while (nbig || nsmall) {
-    // counts[0], counts[1]: the next level's lists; counts[2]: ranges for the heapsort (kept across levels)
-    HIPCHK(h, hipMemsetAsync(d_counts, 0, 8, st));
+  std::vector<Seg> hsegs;
+  std::vector<HugeTile> tiles;
+  std::vector<int> tile0;
+  while (nbig || nhuge) {
+    // counts[0] / [3]: the next level's big / huge ranges; [1] small ranges and [2] ranges for the heapsort keep counting
+    HIPCHK(h, hipMemsetAsync(d_counts, 0, 4, st));
+    HIPCHK(h, hipMemsetAsync(d_counts + 3, 0, 4, st));
+    if (nhuge) {
+      hsegs.resize((size_t)nhuge);
+      HIPCHK(h, hipMemcpyAsync(hsegs.data(), huge[cur], (size_t)nhuge * sizeof(Seg), hipMemcpyDeviceToHost, st));
+      HIPCHK(h, hipStreamSynchronize(st));
+      tiles.clear(); tile0.assign(1, 0);
+      for (int q = 0; q < nhuge; ++q) {
+        const int64_t m = hsegs[(size_t)q].l - hsegs[(size_t)q].f - 1;
+        const int nt = (int)((m + HUGE_TILE - 1) / HUGE_TILE);
+        for (int t = 0; t < nt; ++t) tiles.push_back(HugeTile{q, t});
+        tile0.push_back((int)tiles.size());
+      }
+      if (tiles.size() > cap_tiles) { wfm_set_error(h, "closing sort: tile list overflow"); return WFM_E_HIP; }
+      HugeTile* d_tiles = (HugeTile*)wk->tiles.p;
+      int2* d_tc = (int2*)wk->tile_cnt.p;
+      int* d_t0 = (int*)wk->tile0.p;
+      HugeInfo* d_info = (HugeInfo*)wk->info.p;
+      HIPCHK(h, hipMemcpyAsync(d_tiles, tiles.data(), tiles.size() * sizeof(HugeTile), hipMemcpyHostToDevice, st));
+      HIPCHK(h, hipMemcpyAsync(d_t0, tile0.data(), tile0.size() * sizeof(int), hipMemcpyHostToDevice, st));
+      const unsigned nt = (unsigned)tiles.size();
+      hipLaunchKernelGGL(huge_pivot_kernel, dim3((unsigned)nhuge), dim3(64), 0, st, huge[cur], key, idx, d_info, heap, d_counts);
+      hipLaunchKernelGGL(huge_count_kernel, dim3(nt), dim3(256), 0, st, huge[cur], d_tiles, key, d_info, d_tc);
+      hipLaunchKernelGGL(huge_offsets_kernel, dim3((unsigned)nhuge), dim3(256), 0, st, d_t0, d_tc, d_info);
+      hipLaunchKernelGGL(huge_lists_kernel, dim3(nt), dim3(256), 0, st, huge[cur], d_tiles, key, d_info, d_tc, A, B);
+      hipLaunchKernelGGL(huge_cut_kernel, dim3((unsigned)nhuge), dim3(64), 0, st, huge[cur], d_info, A, B, huge[cur ^ 1], big[cur ^ 1], small_, d_counts);
+      hipLaunchKernelGGL(huge_swap_kernel, dim3(nt), dim3(256), 0, st, huge[cur], d_tiles, d_info, A, B, key, idx);
+    }
     if (nbig)
-      hipLaunchKernelGGL(sortlike_level_kernel<16>, dim3((unsigned)nbig), dim3(1024), 0, st, big[cur], key, idx, (uint32_t*)wk->A.p, (uint32_t*)wk->B.p, big[cur ^ 1],
-                         small_[cur ^ 1], (Seg*)wk->heap.p, d_counts);
-    if (nsmall)
-      hipLaunchKernelGGL(sortlike_level_kernel<1>, dim3((unsigned)nsmall), dim3(64), 0, st, small_[cur], key, idx, (uint32_t*)wk->A.p, (uint32_t*)wk->B.p, big[cur ^ 1],
-                         small_[cur ^ 1], (Seg*)wk->heap.p, d_counts);
+      hipLaunchKernelGGL(sortlike_level_kernel<16>, dim3((unsigned)nbig), dim3(1024), 0, st, big[cur], key, idx, A, B, huge[cur ^ 1], big[cur ^ 1], small_, heap, d_counts);
     HIPCHK(h, hipGetLastError());
     int c[4] = {0, 0, 0, 0};
-    HIPCHK(h, hipMemcpyAsync(c, d_counts, 12, hipMemcpyDeviceToHost, st));
+    HIPCHK(h, hipMemcpyAsync(c, d_counts, 16, hipMemcpyDeviceToHost, st));
     HIPCHK(h, hipStreamSynchronize(st));
-    nbig = c[0]; nsmall = c[1]; nheap_total = c[2];
+    nbig = c[0]; nsmall = c[1]; nheap_total = c[2]; nhuge = c[3];
     cur ^= 1;
     ++levels;
     if (levels > 4 * lg + 8) { wfm_set_error(h, "closing sort: the recursion does not end"); return WFM_E_HIP; }
+  }
+  if (nsmall) {
+    hipLaunchKernelGGL(sortlike_small_kernel, dim3((unsigned)nsmall), dim3(64), 0, st, small_, key, idx, heap, d_counts);
+    HIPCHK(h, hipGetLastError());
+    int c[4] = {0, 0, 0, 0};
+    HIPCHK(h, hipMemcpyAsync(c, d_counts, 16, hipMemcpyDeviceToHost, st));
+    HIPCHK(h, hipStreamSynchronize(st));
+    nheap_total = c[2];
   }
   if (nheap_total) {  // ranges that spent their depth budget: __partial_sort(first, last, last) = make_heap + sort_heap
     std::vector<Seg> hs((size_t)nheap_total);
@@ -284,7 +509,7 @@ int sortlike_loop_device(wfm_handle_t* h, MapFinishWork* wk, uint64_t* key, uint
 void map_finish_work_free(MapFinishWork* wk) {
   if (!wk) return;
   for (MapFinishWork::Buf* b : {&wk->ns, &wk->np, &wk->os, &wk->op, &wk->R, &wk->key, &wk->idx, &wk->key2, &wk->idx2, &wk->A, &wk->B, &wk->seg[0], &wk->seg[1], &wk->seg[2],
-                                &wk->seg[3], &wk->heap, &wk->counts, &wk->tmp, &wk->out}) {
+                                &wk->seg[3], &wk->small_, &wk->heap, &wk->counts, &wk->tiles, &wk->tile_cnt, &wk->tile0, &wk->info, &wk->tmp, &wk->out}) {
     if (b->p) (void)hipFree(b->p);
     b->p = nullptr; b->bytes = 0;
   }
