@@ -95,7 +95,9 @@ void wfmh_test_sort_records(wfm_minmer_t* recs, int64_t n, int threads);
 /* The winnowing kernel's control flow and capacities (wfmash_amd/csrc/map_winnow_core.h: one speculative chunk of the
  * thinned stream per wave, boundary states compared, interval starts resolved) run on the host over plain arrays, then
  * the closing steps.  Returns the number of records, or -1 when the device would hand the sequence back to the host's
- * winnower (*why: the wn::F_* bits of map_winnow_core.h; bit 31: an N among the first k-mers the reference does not notice). */
+ * winnower (*why: the wn::F_* bits of map_winnow_core.h; bit 31: an N among the first k-mers the reference does not notice).
+ * chunk_len < 0: chunks of -chunk_len k-mers, and every second speculation counts as failed (the replay from the
+ * predecessor's state). */
 int64_t wfmh_test_winnow_model(const char* seq, int64_t len, int k, int w, int s, int32_t seq_id, const uint64_t* hash,
                                const int8_t* strand, double c_factor, int64_t chunk_len, wfm_minmer_t* out, int64_t cap,
                                uint32_t* why);

@@ -46,7 +46,7 @@ def main():
     if pmcs:
         L.append("\n## PMC passes (separate runs, sums over all dispatches of the kernel)\n\n| kernel | counter | sum | dispatches |\n|---|---|---|---|\n")
         for db in pmcs:
-            for r in q(db, "select kernel_name, counter_name, sum(value), count(*) from counters_collection where kernel_name like '%wfm::%' group by kernel_name, counter_name order by 1, 2"):
+            for r in q(db, "select kernel_name, counter_name, sum(value), count(*) from counters_collection where kernel_name not like '%rocprim%' and kernel_name not like '__amd%' group by kernel_name, counter_name order by 1, 2"):
                 name = short(r[0])
                 L.append("| %s | %s | %.6g | %d |\n" % (name, r[1], r[2], r[3]))
                 if r[1] == "FETCH_SIZE":

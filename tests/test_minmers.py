@@ -159,7 +159,7 @@ def test_device_winnower_model_equals_single_stream():
             h, st = pymap.hash_kmers(capi_norm(seq), k)
             one = capi.host_winnow(seq, k, w, s, 3, h, st)
             for c_factor in (3.0, 1.5):
-                for chunk in (0, 4 * w + 17, 9000, 25000):
+                for chunk in (0, 4 * w + 17, 9000, 25000, -(4 * w + 17), -7000):  # negative: with replays forced
                     got, why = capi.host_winnow_model(seq, k, w, s, 3, h, st, c_factor, chunk)
                     total += 1
                     if got is None:
@@ -282,8 +282,8 @@ def test_prefilter_gpu_matches_host_definition(gpu):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("dev_chunk", ["1041", "16384"])
-def test_add_minmers_multi_winnows_on_the_device(dev_chunk):
+@pytest.mark.parametrize("dev_chunk,force", [("1041", "0"), ("16384", "0"), ("2100", "1")])
+def test_add_minmers_multi_winnows_on_the_device(dev_chunk, force):
     """the production path of a thinned stream: one wave per speculative chunk (map_winnow.hip), boundary states compared and
     interval starts resolved on the device; against one dense host stream per sequence.  The sequences the device may hand
     back are the ones the test names (an N among the first k-mers that the reference does not notice)."""
@@ -301,7 +301,7 @@ def test_add_minmers_multi_winnows_on_the_device(dev_chunk):
         "    bad = [i for i, (a, b) in enumerate(zip(multi, single)) if a.tobytes() != b.tobytes()]\n"
         "    assert not bad, (k, w, s, bad)\n"
         "    print('same', k, w, s, sum(len(a) for a in multi))\n")
-    env = dict(os.environ, WFM_WINNOW_CHUNK=str(64 * 1000), WFM_WINNOW_DEV_CHUNK=dev_chunk, WFM_DEBUG="1")
+    env = dict(os.environ, WFM_WINNOW_CHUNK=str(64 * 1000), WFM_WINNOW_DEV_CHUNK=dev_chunk, WFM_DEBUG="1", WFM_WINNOW_FORCE=force)  # force 1: replays
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode == 0 and r.stdout.count("same") == 3, (r.stdout[-1000:], r.stderr[-3000:])
     lines = [l for l in r.stderr.splitlines() if "winnowing on the device" in l]
@@ -310,6 +310,8 @@ def test_add_minmers_multi_winnows_on_the_device(dev_chunk):
         nseq = int(l.split("winnowing on the device:")[1].split("sequences")[0])
         back = int(l.split(";")[1].split("handed back")[0])
         assert nseq >= 9 and back <= 1, l
+        if force == "1":
+            assert int(l.split(" chunks replayed")[0].split()[-1]) > 10, l
 
 
 def _raw_records(rng, n, span, w):

@@ -127,7 +127,7 @@ struct MapWinnowWork {  // grow-only device buffers, reused from sequence to seq
   Buf chunks, recs, count, st_begin, st_end, wp_end, flags, off, out, todo;
 };
 void map_winnow_work_free(MapWinnowWork* wk);
-struct MapWinnowInfo { int chunks = 0, bad_chunks = 0, rerun_chunks = 0, resolve_rounds = 0; uint32_t why = 0; int64_t records = 0; };
+struct MapWinnowInfo { int chunks = 0, bad_chunks = 0, rerun_chunks = 0, replays = 0, resolve_rounds = 0; uint32_t why = 0; int64_t records = 0; };
 // WFM_OK: *d_out (inside wk, valid until the next call) holds *n_out raw records in emission order, interval starts
 // resolved; 1: this sequence is not for the device (info->why), the caller winnows it on the host; < 0: error
 int map_winnow_sparse_device(wfm_handle_t* h, const MapSparseSeq* sp, int64_t len, int k, int w, int s, int32_t seq_id, int64_t chunk_len,
@@ -146,5 +146,5 @@ void map_sortlike_model(std::vector<std::pair<uint64_t, uint32_t>>& v);  // the 
 
 // the kernel's control flow and capacities on plain host arrays (CPU test-suite); -1 = the device would hand the sequence back
 int64_t map_winnow_model(const uint32_t* pos, const uint64_t* hash, const int8_t* strand, int64_t m, int64_t len, int k, int w, int s, int32_t seq_id,
-                         int64_t chunk_len, std::vector<wfm_minmer_t>* out, uint32_t* why);
+                         int64_t chunk_len, std::vector<wfm_minmer_t>* out, uint32_t* why, int force_replay = 0, int* replays_out = nullptr);
 #endif

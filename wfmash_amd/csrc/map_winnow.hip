@@ -5,7 +5,7 @@
 // the sketch (sorted, <= s hashes with their open interval, strand tally and occurrence list), the pool (window k-mers
 // outside the sketch) and the list nodes live in the wave's LDS; searching the sketch, the pool's minimum and the
 // shifts of an insertion are done by the 64 lanes side by side, the control flow (map_winnow_core.h) is the reference's
-// and uniform across the wave.  The stream is read through two 64-entry windows in LDS (coalesced refills).
+// and uniform across the wave.  The stream is read through two 64-entry windows in registers (coalesced refills).
 // After the chunks: the live state every chunk started from is compared with the one its predecessor reached
 // (winnow_check_kernel), intervals that were open across a boundary get their true start (winnow_resolve_*), and the
 // records are gathered in emission order.  Whatever does not fit the device's fixed capacities, and every failed
@@ -51,9 +51,11 @@ struct DevOps {
   SkA* ska; SkB* skb;
   uint64_t* pl_h; uint32_t* pl_r;
   uint32_t* nd_r; uint16_t* nd_n;
-  uint64_t* ch_h[2]; uint32_t* ch_p[2]; int32_t* ch_s[2];
+  // per lane: the two stream windows
+  uint32_t cw_lo[2], cw_hi[2], cw_p[2]; int cw_s[2];
   // uniform
   int n, S, P, N;
+  uint64_t skmax;  // hash of the sketch's last entry (n > 0)
   int ph, pe;  // the pool's entries: [ph, pe), ascending (hash, index); dead ones (k-mer left the window) in between
   uint32_t free_head;
   int64_t ch_base[2];
@@ -65,25 +67,28 @@ struct DevOps {
   __device__ void flag(uint32_t f) { flags |= f; }
   __device__ void put(uint32_t* p, int i, uint32_t v) { if (lane == 0) p[i] = v; }
 
-  // ---- the stream, through two 64-entry windows (0: the oldest k-mer of the window, 1: the next to arrive) ----
+  // ---- the stream, through two 64-entry windows held in registers, one entry per lane (0: around the oldest k-mer of the
+  //      window, 1: around the next to arrive); an entry is read with v_readlane, a window is refilled by coalesced loads ----
   __device__ void load_block(int which, uint32_t i) {
     const int64_t base = (int64_t)(i & ~63u);
-    __syncthreads();
     const int64_t j = base + lane;
-    if (j < prm->m) { ch_h[which][lane] = prm->hash[j]; ch_p[which][lane] = prm->pos[j]; ch_s[which][lane] = prm->strand[j]; }
+    uint64_t hh = 0; uint32_t pp = 0; int ss = 0;
+    if (j < prm->m) { hh = prm->hash[j]; pp = prm->pos[j]; ss = prm->strand[j]; }
+    cw_lo[which] = (uint32_t)hh; cw_hi[which] = (uint32_t)(hh >> 32); cw_p[which] = pp; cw_s[which] = ss;
     ch_base[which] = base;
-    __syncthreads();
   }
   __device__ void need(int which, uint32_t i) { if ((int64_t)(i & ~63u) != ch_base[which]) load_block(which, i); }
-  __device__ uint64_t fr_hash(uint32_t i) { need(0, i); return ch_h[0][i & 63]; }
-  __device__ uint32_t fr_pos(uint32_t i) { need(0, i); return ch_p[0][i & 63]; }
-  __device__ int fr_strand(uint32_t i) { need(0, i); return ch_s[0][i & 63]; }
-  __device__ uint64_t ar_hash(uint32_t i) { need(1, i); return ch_h[1][i & 63]; }
-  __device__ uint32_t ar_pos(uint32_t i) { need(1, i); return ch_p[1][i & 63]; }
-  __device__ int ar_strand(uint32_t i) { need(1, i); return ch_s[1][i & 63]; }
+  __device__ static int sl(uint32_t i) { return __builtin_amdgcn_readfirstlane((int)(i & 63u)); }
+  __device__ uint64_t fr_hash(uint32_t i) { need(0, i); const int l = sl(i); return (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)cw_lo[0], l) | ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)cw_hi[0], l) << 32); }
+  __device__ uint32_t fr_pos(uint32_t i) { need(0, i); return (uint32_t)__builtin_amdgcn_readlane((int)cw_p[0], sl(i)); }
+  __device__ int fr_strand(uint32_t i) { need(0, i); return __builtin_amdgcn_readlane(cw_s[0], sl(i)); }
+  __device__ uint64_t ar_hash(uint32_t i) { need(1, i); const int l = sl(i); return (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)cw_lo[1], l) | ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)cw_hi[1], l) << 32); }
+  __device__ uint32_t ar_pos(uint32_t i) { need(1, i); return (uint32_t)__builtin_amdgcn_readlane((int)cw_p[1], sl(i)); }
+  __device__ int ar_strand(uint32_t i) { need(1, i); return __builtin_amdgcn_readlane(cw_s[1], sl(i)); }
 
   // ---- sketch: entries 0 .. n-1, ascending hashes ----
   __device__ int sk_n() const { return n; }
+  __device__ uint64_t sk_max() const { return skmax; }
   __device__ uint64_t sk_hash(int r) const { return ska[r].h; }
   __device__ uint32_t sk_wpos(int r) const { return ska[r].wpos; }
   __device__ int sk_tally(int r) const { return (int)(int16_t)(ska[r].tc & 0xFFFFu); }
@@ -125,6 +130,7 @@ struct DevOps {
     if (lane == 0) { ska[p] = SkA{h, wpos, 0u}; skb[p] = SkB{0u, NIL16 | (NIL16 << 16)}; }
     ++n;
     __syncthreads();
+    if (p == n - 1) skmax = h;
     return p;
   }
   __device__ void sk_erase(int r) {
@@ -150,6 +156,7 @@ struct DevOps {
       __syncthreads();
     }
     --n;
+    if (r == n && n > 0) skmax = ska[n - 1].h;
   }
 
   // ---- occurrence lists: the first occurrence sits in the sketch entry, further ones in list nodes ----
@@ -237,10 +244,18 @@ struct DevOps {
       below += __popcll(__ballot(lt));
     }
     const int p = ph + below;
-    if (below == 0 && ph > 0) {  // in front of everything: the slot before the first entry is free
-      __syncthreads();
+    if (ph > 0 && below <= pe - p) {  // the front part is the shorter one: it moves down by one (the slot before it is free)
+      for (int lo = ph; lo < p; lo += 64) {
+        const int j = lo + lane;
+        const bool v = j < p;
+        uint64_t a = 0; uint32_t b = 0;
+        if (v) { a = pl_h[j]; b = pl_r[j]; }
+        __syncthreads();
+        if (v) { pl_h[j - 1] = a; pl_r[j - 1] = b; }
+        __syncthreads();
+      }
       --ph;
-      if (lane == 0) { pl_h[ph] = h; pl_r[ph] = ref; }
+      if (lane == 0) { pl_h[p - 1] = h; pl_r[p - 1] = ref; }
       __syncthreads();
       return;
     }
@@ -293,10 +308,10 @@ struct DevOps {
 };
 
 __host__ __device__ inline size_t winnow_lds_bytes(int S, int P, int N) {
-  return (size_t)S * 16 + (size_t)S * 8 + (size_t)P * 8 + (size_t)P * 4 + (size_t)N * 4 + (size_t)N * 2 + 2 * 64 * 16 + 64;
+  return (size_t)S * 16 + (size_t)S * 8 + (size_t)P * 8 + (size_t)P * 4 + (size_t)N * 4 + (size_t)N * 2 + 64;
 }
 
-__global__ void __launch_bounds__(64) winnow_chunks_kernel(Params prm, const Chunk* chunks, const int* todo, int S, int P, int N, Rec* recs, uint32_t* rec_count,
+__global__ void __launch_bounds__(64) winnow_chunks_kernel(Params prm, const Chunk* chunks, const int* todo, int replay, int S, int P, int N, Rec* recs, uint32_t* rec_count,
                                                            uint32_t* st_begin, uint32_t* st_end, uint32_t* wp_end, uint32_t* flags) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int cj = todo ? todo[blockIdx.x] : (int)blockIdx.x;
@@ -306,14 +321,8 @@ __global__ void __launch_bounds__(64) winnow_chunks_kernel(Params prm, const Chu
   o.ska = (SkA*)p; p += (size_t)S * 16;
   o.skb = (SkB*)p; p += (size_t)S * 8;
   o.pl_h = (uint64_t*)p; p += (size_t)P * 8;
-  o.ch_h[0] = (uint64_t*)p; p += 64 * 8;
-  o.ch_h[1] = (uint64_t*)p; p += 64 * 8;
   o.pl_r = (uint32_t*)p; p += (size_t)P * 4;
   o.nd_r = (uint32_t*)p; p += (size_t)N * 4;
-  o.ch_p[0] = (uint32_t*)p; p += 64 * 4;
-  o.ch_p[1] = (uint32_t*)p; p += 64 * 4;
-  o.ch_s[0] = (int32_t*)p; p += 64 * 4;
-  o.ch_s[1] = (int32_t*)p; p += 64 * 4;
   o.nd_n = (uint16_t*)p; p += (size_t)N * 2;
   o.n = 0; o.ph = 0; o.pe = 0; o.S = S; o.P = P; o.N = N;
   o.lane = (int)threadIdx.x;
@@ -326,27 +335,29 @@ __global__ void __launch_bounds__(64) winnow_chunks_kernel(Params prm, const Chu
   __syncthreads();
   wn::Stream<DevOps> S_(o, prm, (uint32_t)ch.c0);
   const size_t cap = (size_t)prm.state_words;
-  S_.run(ch, st_begin + (size_t)cj * cap, nullptr, st_end + (size_t)cj * cap, wp_end + (size_t)cj * prm.s, prm.state_words);
+  if (replay) S_.run_replay(ch, st_end + (size_t)(cj - 1) * cap, wp_end + (size_t)(cj - 1) * prm.s, st_begin + (size_t)cj * cap, st_end + (size_t)cj * cap,
+                            wp_end + (size_t)cj * prm.s, prm.state_words);
+  else S_.run(ch, st_begin + (size_t)cj * cap, nullptr, st_end + (size_t)cj * cap, wp_end + (size_t)cj * prm.s, prm.state_words);
   if (o.lane == 0) {
     rec_count[cj] = o.nrec < o.rec_cap ? o.nrec : o.rec_cap;
     flags[cj] = o.flags;
   }
 }
 
-// does chunk j start from the state chunk j-1 reached?
-__global__ void winnow_check_kernel(const uint32_t* st_begin, const uint32_t* st_end, int cap, int nchunks, uint32_t* flags) {
-  const int j = blockIdx.x + 1;
-  if (j >= nchunks) return;
+// does chunk j start from the state chunk j-1 reached?  (which: the boundaries to look at, or all of them)
+__global__ void winnow_check_kernel(const uint32_t* st_begin, const uint32_t* st_end, int cap, int nchunks, const int* which, uint32_t* flags) {
+  const int j = which ? which[blockIdx.x] : (int)blockIdx.x + 1;
+  if (j < 1 || j >= nchunks) return;
   const uint32_t* a = st_begin + (size_t)j * cap;
   const uint32_t* b = st_end + (size_t)(j - 1) * cap;
   __shared__ int bad;
   if (threadIdx.x == 0) bad = 0;
   __syncthreads();
   const uint32_t na = a[0], nb = b[0];
-  if (na != nb || na > (uint32_t)cap) { if (threadIdx.x == 0) bad = 1; }
+  if (na != nb || na > (uint32_t)cap || na < 4) { if (threadIdx.x == 0) bad = 1; }
   else for (uint32_t i = threadIdx.x; i < na; i += blockDim.x) if (a[i] != b[i]) bad = 1;
   __syncthreads();
-  if (threadIdx.x == 0 && bad) atomicOr(&flags[j], (uint32_t)wn::F_MISMATCH);
+  if (threadIdx.x == 0) flags[j] = (flags[j] & ~(uint32_t)wn::F_MISMATCH) | (bad ? (uint32_t)wn::F_MISMATCH : 0u);
 }
 
 // sketch hashes of a snapshot: entry r starts after the entries before it (3 words + their occurrences)
@@ -435,6 +446,7 @@ struct HostOps {
   uint32_t ar_pos(uint32_t i) const { return prm->pos[i]; }
   int ar_strand(uint32_t i) const { return prm->strand[i]; }
   int sk_n() const { return (int)sk.size(); }
+  uint64_t sk_max() const { return sk.back().h; }
   uint64_t sk_hash(int r) const { return sk[(size_t)r].h; }
   uint32_t sk_wpos(int r) const { return sk[(size_t)r].wpos; }
   int sk_tally(int r) const { return sk[(size_t)r].tally; }
@@ -540,7 +552,7 @@ Caps caps_for(int k, int w, int s, bool small) {
 // The model: the chunks one after the other on the host, with the kernel's control flow and capacities.  Returns the
 // number of raw records (emission order, unknown starts resolved), or -1 when the device would hand the sequence back.
 int64_t map_winnow_model(const uint32_t* pos, const uint64_t* hash, const int8_t* strand, int64_t m, int64_t len, int k, int w, int s, int32_t seq_id,
-                         int64_t chunk_len, std::vector<wfm_minmer_t>* out, uint32_t* why) {
+                         int64_t chunk_len, std::vector<wfm_minmer_t>* out, uint32_t* why, int force_replay, int* replays_out) {
   Params prm{};
   prm.k = k; prm.w = w; prm.s = s; prm.nk = len - k + 1; prm.m = m; prm.hash = hash; prm.pos = pos; prm.strand = strand;
   const Caps cp = caps_for(k, w, s, false);
@@ -551,11 +563,14 @@ int64_t map_winnow_model(const uint32_t* pos, const uint64_t* hash, const int8_t
   std::vector<std::vector<uint32_t>> st_begin(nc, std::vector<uint32_t>((size_t)cp.state_words, 0)), st_end(nc, std::vector<uint32_t>((size_t)cp.state_words, 0));
   std::vector<std::vector<uint32_t>> wp_end(nc, std::vector<uint32_t>((size_t)s, UNK)), wp_dummy(1, std::vector<uint32_t>((size_t)s, UNK));
   uint32_t flags = 0;
+  std::vector<Chunk> chunks(nc);
   for (size_t j = 0; j < nc; ++j) {
-    Chunk ch{};
+    Chunk& ch = chunks[j];
+    ch = Chunk{};
     ch.from = bounds[j]; ch.to = bounds[j + 1];
     ch.warm_from = j > 0 ? std::max<int64_t>(0, bounds[j] - 2 * (int64_t)w) : 0;
     ch.c0 = std::lower_bound(pos, pos + m, ch.warm_from, [](uint32_t p, int64_t x) { return (int64_t)p < x; }) - pos;
+    ch.c1 = std::lower_bound(pos, pos + m, ch.from, [](uint32_t p, int64_t x) { return (int64_t)p < x; }) - pos;
     ch.first = j == 0; ch.last = j + 1 == nc;
     HostOps o;
     o.prm = &prm; o.out = &recs[j]; o.chunk_id = (uint32_t)j; o.pool_cap = cp.P; o.occ_cap = cp.N;
@@ -563,10 +578,22 @@ int64_t map_winnow_model(const uint32_t* pos, const uint64_t* hash, const int8_t
     S.run(ch, st_begin[j].data(), wp_dummy[0].data(), st_end[j].data(), wp_end[j].data(), cp.state_words);
     flags |= o.flags;
   }
+  // failed speculations (force_replay: every second one counts as failed): the chunk once more, from its predecessor's state
+  int replays = 0;
   for (size_t j = 1; j < nc; ++j) {
     const uint32_t na = st_begin[j][0];
-    if (na != st_end[j - 1][0] || memcmp(st_begin[j].data(), st_end[j - 1].data(), (size_t)na * 4) != 0) flags |= wn::F_MISMATCH;
+    const bool differs = na != st_end[j - 1][0] || memcmp(st_begin[j].data(), st_end[j - 1].data(), (size_t)na * 4) != 0;
+    if (!differs && !(force_replay && (j & 1))) continue;
+    ++replays;
+    recs[j].clear();
+    std::fill(wp_end[j].begin(), wp_end[j].end(), UNK);
+    HostOps o;
+    o.prm = &prm; o.out = &recs[j]; o.chunk_id = (uint32_t)j; o.pool_cap = cp.P; o.occ_cap = cp.N;
+    wn::Stream<HostOps> S(o, prm, (uint32_t)chunks[j].c0);
+    S.run_replay(chunks[j], st_end[j - 1].data(), wp_end[j - 1].data(), st_begin[j].data(), st_end[j].data(), wp_end[j].data(), cp.state_words);
+    flags |= o.flags;
   }
+  if (replays_out) *replays_out = replays;
   if (!flags) {
     for (size_t j = 1; j + 1 < nc; ++j) {  // in order: the predecessor's starts are final
       const int n = (int)st_end[j][2];
@@ -646,8 +673,10 @@ int map_winnow_sparse_device(wfm_handle_t* h, const MapSparseSeq* sp, int64_t le
     Chunk& ch = chunks[(size_t)c];
     ch.from = bounds[(size_t)c]; ch.to = bounds[(size_t)c + 1]; ch.warm_from = q[(size_t)nc + 1 + c];
     ch.c0 = r[(size_t)nc + 1 + c];
+    ch.c1 = r[(size_t)c];
     const int64_t kept = r[(size_t)c + 1] - r[(size_t)c];
-    ch.rec_cap = (int32_t)std::min<int64_t>(2 * kept + s + 64, INT32_MAX);
+    // an iteration emits at most three records (leave, arrive, the swap), a kept k-mer has two iterations; the flush adds s
+    ch.rec_cap = (int32_t)std::min<int64_t>(6 * kept + s + 64, INT32_MAX);
     ch.rec_off = rec_total;
     rec_total += ch.rec_cap;
     ch.first = c == 0; ch.last = c + 1 == nc; ch.pad_ = 0;
@@ -676,7 +705,7 @@ int map_winnow_sparse_device(wfm_handle_t* h, const MapSparseSeq* sp, int64_t le
   // the first words of the snapshots: a chunk that does not write one (first / last) must not compare equal by accident
   HIPCHK(h, hipMemsetAsync(d_stb, 0, (size_t)nc * cap * 4, st));
   HIPCHK(h, hipMemsetAsync(d_ste, 0, (size_t)nc * cap * 4, st));
-  hipLaunchKernelGGL(winnow_chunks_kernel, dim3((unsigned)nc), dim3(64), lds_small, st, prm, d_chunks, (const int*)nullptr, cs.S, cs.P, cs.N, d_recs, d_count, d_stb,
+  hipLaunchKernelGGL(winnow_chunks_kernel, dim3((unsigned)nc), dim3(64), lds_small, st, prm, d_chunks, (const int*)nullptr, 0, cs.S, cs.P, cs.N, d_recs, d_count, d_stb,
                      d_ste, d_wpe, d_flags);
   HIPCHK(h, hipGetLastError());
   std::vector<uint32_t> flags((size_t)nc), count((size_t)nc);
@@ -690,13 +719,43 @@ int map_winnow_sparse_device(wfm_handle_t* h, const MapSparseSeq* sp, int64_t le
     if (!todo.empty() && lds <= 64 * 1024) {
       if (grow(wk->todo, todo.size() * sizeof(int))) { wfm_set_error(h, "out of device memory (winnowing)"); return WFM_E_NOMEM; }
       HIPCHK(h, hipMemcpyAsync(wk->todo.p, todo.data(), todo.size() * sizeof(int), hipMemcpyHostToDevice, st));
-      hipLaunchKernelGGL(winnow_chunks_kernel, dim3((unsigned)todo.size()), dim3(64), lds, st, prm, d_chunks, (const int*)wk->todo.p, cp.S, cp.P, cp.N, d_recs, d_count,
+      hipLaunchKernelGGL(winnow_chunks_kernel, dim3((unsigned)todo.size()), dim3(64), lds, st, prm, d_chunks, (const int*)wk->todo.p, 0, cp.S, cp.P, cp.N, d_recs, d_count,
                          d_stb, d_ste, d_wpe, d_flags);
       HIPCHK(h, hipGetLastError());
     }
   }
   if (nc > 1) {
-    hipLaunchKernelGGL(winnow_check_kernel, dim3((unsigned)(nc - 1)), dim3(64), 0, st, d_stb, d_ste, (int)cap, nc, d_flags);
+    hipLaunchKernelGGL(winnow_check_kernel, dim3((unsigned)(nc - 1)), dim3(64), 0, st, d_stb, d_ste, (int)cap, nc, (const int*)nullptr, d_flags);
+    HIPCHK(h, hipMemcpyAsync(flags.data(), d_flags, (size_t)nc * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(h, hipStreamSynchronize(st));
+    // WFM_WINNOW_FORCE=1 (tests): every second speculation counts as failed
+    static const int force = [] { const char* e = getenv("WFM_WINNOW_FORCE"); return e ? atoi(e) : 0; }();
+    if (force == 1) {
+      for (int c = 1; c < nc; c += 2) flags[(size_t)c] |= wn::F_MISMATCH;
+      HIPCHK(h, hipMemcpyAsync(d_flags, flags.data(), (size_t)nc * 4, hipMemcpyHostToDevice, st));
+    }
+    // Failed speculations: the chunk runs again from the state its predecessor really reached (full capacities), then the
+    // next boundary is looked at again.  Chunks whose predecessor is itself waiting for its replay wait for the next round.
+    std::vector<int> todo, next;
+    for (int round = 0; lds <= 64 * 1024; ++round) {
+      todo.clear(); next.clear();
+      for (int c = 1; c < nc; ++c)
+        if ((flags[(size_t)c] & wn::F_MISMATCH) && !(flags[(size_t)c - 1] & wn::F_MISMATCH)) { todo.push_back(c); if (c + 1 < nc) next.push_back(c + 1); }
+      if (todo.empty()) break;
+      if (round > 2 * nc + 8) { inf.why |= wn::F_MISMATCH; break; }
+      inf.replays += (int)todo.size();
+      if (grow(wk->todo, (todo.size() + next.size() + 1) * sizeof(int))) { wfm_set_error(h, "out of device memory (winnowing)"); return WFM_E_NOMEM; }
+      int* d_todo = (int*)wk->todo.p;
+      HIPCHK(h, hipMemcpyAsync(d_todo, todo.data(), todo.size() * sizeof(int), hipMemcpyHostToDevice, st));
+      if (!next.empty()) HIPCHK(h, hipMemcpyAsync(d_todo + todo.size(), next.data(), next.size() * sizeof(int), hipMemcpyHostToDevice, st));
+      hipLaunchKernelGGL(winnow_chunks_kernel, dim3((unsigned)todo.size()), dim3(64), lds, st, prm, d_chunks, (const int*)d_todo, 1, cp.S, cp.P, cp.N, d_recs, d_count, d_stb,
+                         d_ste, d_wpe, d_flags);
+      if (!next.empty())
+        hipLaunchKernelGGL(winnow_check_kernel, dim3((unsigned)next.size()), dim3(64), 0, st, d_stb, d_ste, (int)cap, nc, (const int*)(d_todo + todo.size()), d_flags);
+      HIPCHK(h, hipGetLastError());
+      HIPCHK(h, hipMemcpyAsync(flags.data(), d_flags, (size_t)nc * 4, hipMemcpyDeviceToHost, st));
+      HIPCHK(h, hipStreamSynchronize(st));
+    }
     for (int it = 0; it < 64 && nc > 2; ++it) {
       HIPCHK(h, hipMemsetAsync(d_pending, 0, 4, st));
       hipLaunchKernelGGL(winnow_resolve_states_kernel, dim3((unsigned)(nc - 1)), dim3(64), 0, st, d_ste, d_wpe, (int)cap, s, nc, d_pending, d_flags);

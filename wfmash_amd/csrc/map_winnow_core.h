@@ -42,6 +42,7 @@ struct Params {
 struct Chunk {
   int64_t warm_from, from, to;  // k-mer starts: warm-up [warm_from, from), the chunk's own [from, to)
   int64_t c0;                   // first kept k-mer with pos >= warm_from
+  int64_t c1;                   // first kept k-mer with pos >= from
   int64_t rec_off;              // where the chunk's records go
   int32_t rec_cap, first, last, pad_;
 };
@@ -72,7 +73,7 @@ struct Stream {
     const uint64_t lh = o.fr_hash(a_lo);
     const int ls = o.fr_strand(a_lo);
     const int n = o.sk_n();
-    const int r = (n > 0 && lh <= o.sk_hash(n - 1)) ? o.sk_find(lh) : -1;
+    const int r = (n > 0 && lh <= o.sk_max()) ? o.sk_find(lh) : -1;
     if (r >= 0) {
       if (o.sk_cnt(r) == 1) {
         emit(lh, o.sk_wpos(r), win, o.sk_tally(r));
@@ -97,7 +98,7 @@ struct Stream {
     const int st = o.ar_strand(c);
     const uint32_t ref = c | (st < 0 ? SBIT : 0u);
     const int n = o.sk_n();
-    const int r = (n > 0 && h <= o.sk_hash(n - 1)) ? o.sk_find(h) : -1;
+    const int r = (n > 0 && h <= o.sk_max()) ? o.sk_find(h) : -1;
     if (r >= 0) {
       o.occ_push(r, ref);
       const int t = o.sk_tally(r);
@@ -108,7 +109,7 @@ struct Stream {
       o.sk_set_tally(r, (int)(int16_t)(t + st));
     } else {
       o.pool_push(h, ref, a_lo);
-      if (n < s || h < o.sk_hash(n - 1)) dirty = true;
+      if (n < s || h < o.sk_max()) dirty = true;
     }
     ++c;
   }
@@ -126,7 +127,7 @@ struct Stream {
     uint64_t mh = 0;
     bool have = o.pool_min(a_lo, &mh);
     const int n = o.sk_n();
-    if (n > 0 && have && n == s && mh < o.sk_hash(n - 1)) {
+    if (n > 0 && have && n == s && mh < o.sk_max()) {
       const int r = n - 1;
       const uint64_t out_h = o.sk_hash(r);
       emit(out_h, o.sk_wpos(r), win, o.sk_tally(r));
@@ -212,6 +213,41 @@ struct Stream {
     }
     if (full) o.flag(F_STATE_FULL);
     o.put(st, 0, (uint32_t)at); o.put(st, 1, a_lo); o.put(st, 2, (uint32_t)n); o.put(st, 3, (uint32_t)np);
+  }
+
+  // take over the state another chunk reached (its snapshot and interval starts): sketch entries in ascending order, their
+  // occurrences, the pool
+  __host__ __device__ void load(const uint32_t* st, const uint32_t* wpos) {
+    a_lo = st[1];
+    const int n = (int)st[2], np = (int)st[3];
+    int at = 4;
+    for (int r = 0; r < n; ++r) {
+      const uint64_t h = (uint64_t)st[at] | ((uint64_t)st[at + 1] << 32);
+      const uint32_t tc = st[at + 2];
+      const int cnt = (int)(tc >> 16);
+      const int rr = o.sk_insert(h, wpos[r]);
+      for (int q = 0; q < cnt; ++q) o.occ_push(rr, st[at + 3 + q]);
+      o.sk_set_tally(rr, (int)(int16_t)(tc & 0xFFFFu));
+      at += 3 + cnt;
+    }
+    for (int q = 0; q < np; ++q) {
+      const uint64_t h = (uint64_t)st[at] | ((uint64_t)st[at + 1] << 32);
+      o.pool_push(h, st[at + 2], a_lo);
+      at += 3;
+    }
+  }
+
+  // the replay after a failed speculation: the chunk once more, from the state its predecessor really reached.  The state
+  // it starts from is also what it is compared with from now on (st_begin).
+  __host__ __device__ void run_replay(const Chunk& ch, const uint32_t* prev_end, const uint32_t* prev_wpos, uint32_t* st_begin, uint32_t* st_end,
+                                      uint32_t* wpos_end, int cap) {
+    load(prev_end, prev_wpos);
+    c = (uint32_t)ch.c1;
+    const int nw = (int)prev_end[0];
+    for (int i = 0; i < nw; ++i) o.put(st_begin, i, prev_end[i]);
+    advance(ch.from, ch.to);
+    if (ch.last) flush_end();
+    else snapshot(st_end, wpos_end, cap);
   }
 
   // one chunk: warm-up from an empty state two windows before it, then the chunk itself

@@ -950,8 +950,8 @@ int64_t add_minmers_core(wfm_handle_t* h, const char* const* seqs, const int64_t
   int dev_levels = 0;
   int64_t dev_heaps = 0;
   const bool dev_winnow = !(getenv("WFM_WINNOW_DEVICE") && atoi(getenv("WFM_WINNOW_DEVICE")) == 0);
-  const int64_t dev_chunk = getenv("WFM_WINNOW_DEV_CHUNK") ? atoll(getenv("WFM_WINNOW_DEV_CHUNK")) : (int64_t)1 << 14;
-  int64_t dev_seqs = 0, dev_handed_back = 0, dev_chunks = 0;
+  const int64_t dev_chunk = getenv("WFM_WINNOW_DEV_CHUNK") ? atoll(getenv("WFM_WINNOW_DEV_CHUNK")) : 0;  // 0: by sequence length
+  int64_t dev_seqs = 0, dev_handed_back = 0, dev_chunks = 0, dev_replays = 0;
   uint32_t dev_why = 0;
   double ms_winnow = 0;
   std::vector<std::thread> pool;
@@ -1012,9 +1012,14 @@ int64_t add_minmers_core(wfm_handle_t* h, const char* const* seqs, const int64_t
         wfm_minmer_t* d_recs = nullptr;
         int64_t n_recs = 0;
         MapWinnowInfo wi;
-        const int wrc = map_winnow_sparse_device(h, &J->sparse, len, k, w, s, J->seq_id, std::max<int64_t>(dev_chunk, 4 * (int64_t)w), &winnow_work, &d_recs, &n_recs, &wi);
+        // chunk length: one wave per chunk, and about as many chunks as the device keeps resident at once (a chunk's two
+        // windows of warm-up are its overhead: no chunk under four windows)
+        const int64_t auto_chunk = std::min<int64_t>((J->nk + 6143) / 6144, (int64_t)1 << 16);
+        const int wrc = map_winnow_sparse_device(h, &J->sparse, len, k, w, s, J->seq_id, std::max<int64_t>(dev_chunk > 0 ? dev_chunk : auto_chunk, 4 * (int64_t)w),
+                                                 &winnow_work, &d_recs, &n_recs, &wi);
         if (wrc < 0) { rc = wrc; map_sparse_free(&J->sparse); break; }
         dev_chunks += wi.chunks;
+        dev_replays += wi.replays;
         bool finished = false;
         if (wrc == WFM_OK && dev_finish) {  // the closing cut / sort / de-duplication on the device as well
           wfm_minmer_t* d_fin = nullptr;
@@ -1117,8 +1122,8 @@ int64_t add_minmers_core(wfm_handle_t* h, const char* const* seqs, const int64_t
   map_winnow_work_free(&winnow_work);
   map_finish_work_free(&finish_work);
   if (getenv("WFM_DEBUG") && (dev_seqs || dev_handed_back))
-    fprintf(stderr, "[wfm] winnowing on the device: %lld sequences in %lld chunks of %lld k-mers, %.1f ms (closing sort %s: %d levels at most, %lld ranges heap-sorted); %lld handed back to the host (why 0x%x)\n",
-            (long long)dev_seqs, (long long)dev_chunks, (long long)dev_chunk, ms_winnow, dev_finish ? "on the device" : "on the host", dev_levels, (long long)dev_heaps,
+    fprintf(stderr, "[wfm] winnowing on the device: %lld sequences in %lld chunks (WFM_WINNOW_DEV_CHUNK %lld), %lld chunks replayed after a failed speculation, %.1f ms (closing sort %s: %d levels at most, %lld ranges heap-sorted); %lld handed back to the host (why 0x%x)\n",
+            (long long)dev_seqs, (long long)dev_chunks, (long long)dev_chunk, (long long)dev_replays, ms_winnow, dev_finish ? "on the device" : "on the host", dev_levels, (long long)dev_heaps,
             (long long)dev_handed_back, dev_why);
   if (getenv("WFM_DEBUG")) {
     int64_t nchunks = 0, replays = 0;
@@ -1309,6 +1314,9 @@ extern "C" void wfmh_test_sort_records(wfm_minmer_t* recs, int64_t n, int thread
 // first k-mers that the reference does not notice).
 extern "C" int64_t wfmh_test_winnow_model(const char* seq, int64_t len, int k, int w, int s, int32_t seq_id, const uint64_t* hash,
                                           const int8_t* strand, double c_factor, int64_t chunk_len, wfm_minmer_t* out, int64_t cap, uint32_t* why) {
+  // chunk_len < 0: chunks of -chunk_len k-mers, and every second speculation counts as failed (the replay path)
+  const int force_replay = chunk_len < 0;
+  if (chunk_len < 0) chunk_len = -chunk_len;
   if (why) *why = 0;
   if (len < k) return 0;
   const int64_t n = len - k + 1, W = (int64_t)w - k + 1;
@@ -1320,7 +1328,7 @@ extern "C" int64_t wfmh_test_winnow_model(const char* seq, int64_t len, int k, i
   std::vector<wfm_minmer_t> recs;
   static const uint32_t none_p = 0; static const uint64_t none_h = 0; static const int8_t none_s = 0;
   const int64_t got = map_winnow_model(pos.empty() ? &none_p : pos.data(), hs.empty() ? &none_h : hs.data(), st.empty() ? &none_s : st.data(),
-                                       (int64_t)pos.size(), len, k, w, s, seq_id, chunk_len, &recs, why);
+                                       (int64_t)pos.size(), len, k, w, s, seq_id, chunk_len, &recs, why, force_replay, nullptr);
   if (got < 0) return -1;
   finish_records(recs, w, 1);
   const int64_t m = (int64_t)recs.size();
