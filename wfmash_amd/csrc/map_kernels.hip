@@ -128,16 +128,79 @@ __global__ void kmer_hash_kernel(const uint8_t* __restrict__ seq /*normalised, p
   }
 }
 
+// The same for 9 <= K <= 16, the k-mer in two words and nothing byte by byte: the reverse complement is the
+// complement of every byte -- A <-> T differ in bits 0, 2, 4, C <-> G in bit 2, and bit 1 tells the two pairs apart --
+// followed by a reversal of the 16 bytes and a shift; an N is a zero byte of word ^ 'NNNNNNNN'.
+template <int K>
+__global__ void __launch_bounds__(256) kmer_hash_2w_kernel(const uint8_t* __restrict__ seq /*normalised, padded*/, int64_t nk, uint64_t* __restrict__ hash,
+                                                           int8_t* __restrict__ strand) {
+  static_assert(K >= 9 && K <= 16, "two words");
+  constexpr uint64_t hi_mask = K == 16 ? ~0ull : ((~0ull) >> (64 - 8 * (K - 8)));
+  constexpr uint64_t ones = 0x0101010101010101ULL;
+  constexpr int sh = 8 * (16 - K);
+  const uint64_t c1 = 0x87c37b91114253d5ULL, c2 = 0x4cf5ad432745937fULL;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nk; i += (int64_t)gridDim.x * blockDim.x) {
+    const uint64_t f0 = ld8(seq + i), f1 = ld8(seq + i + 8) & hi_mask;
+    const uint64_t n0 = f0 ^ (ones * 'N'), n1 = f1 ^ (ones * 'N');
+    const bool has_n = (((n0 - ones) & ~n0) | ((n1 - ones) & ~n1)) & (ones * 0x80);
+    uint64_t h = ~0ull;
+    int8_t st = 0;
+    if (!has_n) {
+      // complement, reverse the 16 bytes, drop the 16 - K bytes that were past the k-mer
+      const uint64_t m0 = (~f0 >> 1) & ones, m1 = (~f1 >> 1) & ones;
+      const uint64_t q0 = f0 ^ (ones * 4) ^ (m0 * 0x11), q1 = f1 ^ (ones * 4) ^ (m1 * 0x11);
+      const uint64_t b0 = __builtin_bswap64(q1), b1 = __builtin_bswap64(q0);  // reversed: low word, high word
+      const uint64_t r0 = sh == 0 ? b0 : ((b0 >> sh) | (b1 << ((64 - sh) & 63))), r1 = sh == 0 ? b1 : (b1 >> sh);
+      uint64_t hv[2];
+#pragma unroll
+      for (int d = 0; d < 2; ++d) {
+        uint64_t k1 = d == 0 ? f0 : r0, k2 = d == 0 ? f1 : r1;
+        uint64_t h1 = 42u, h2 = 42u;
+        if (K == 16) {
+          k1 *= c1; k1 = rotl64(k1, 31); k1 *= c2; h1 ^= k1;
+          h1 = rotl64(h1, 27); h1 += h2; h1 = h1 * 5 + 0x52dce729;
+          k2 *= c2; k2 = rotl64(k2, 33); k2 *= c1; h2 ^= k2;
+          h2 = rotl64(h2, 31); h2 += h1; h2 = h2 * 5 + 0x38495ab5;
+        } else {
+          k2 *= c2; k2 = rotl64(k2, 33); k2 *= c1; h2 ^= k2;
+          k1 *= c1; k1 = rotl64(k1, 31); k1 *= c2; h1 ^= k1;
+        }
+        h1 ^= (uint64_t)K; h2 ^= (uint64_t)K;
+        h1 += h2; h2 += h1;
+        h1 = fmix64(h1); h2 = fmix64(h2);
+        hv[d] = h1 + h2;
+      }
+      if (hv[0] != hv[1]) { h = hv[0] < hv[1] ? hv[0] : hv[1]; st = hv[0] < hv[1] ? 1 : -1; }
+    }
+    hash[i] = h;
+    strand[i] = st;
+  }
+}
+
+// canonical hash + strand of every k-mer start of a normalised, padded sequence
+static void launch_kmer_hash(const uint8_t* d_norm, int64_t nk, int k, uint64_t* d_hash, int8_t* d_strand, hipStream_t st) {
+  const int blocks = (int)std::min<int64_t>((nk + 255) / 256, 256 * 8);
+  switch (k) {
+#define WFM_K2W(K) case K: hipLaunchKernelGGL(kmer_hash_2w_kernel<K>, dim3(blocks), dim3(256), 0, st, d_norm, nk, d_hash, d_strand); break;
+    WFM_K2W(9) WFM_K2W(10) WFM_K2W(11) WFM_K2W(12) WFM_K2W(13) WFM_K2W(14) WFM_K2W(15) WFM_K2W(16)
+#undef WFM_K2W
+    default: hipLaunchKernelGGL(kmer_hash_kernel, dim3(blocks), dim3(256), 0, st, d_norm, nk, k, d_hash, d_strand);
+  }
+}
+
 // One workgroup per fragment.  LDS: key[npow2] (u64) + pv[npow2] (u32: pos<<1 | isRev).
 __global__ __launch_bounds__(256) void sketch_fragments_kernel(const uint8_t* __restrict__ seq, const int64_t* __restrict__ frag_off,
                                                                const int32_t* __restrict__ frag_len, int k, int s, int32_t seq_id,
-                                                               int npow2, wfm_minmer_t* __restrict__ out, int32_t* __restrict__ out_count) {
+                                                               int npow2, wfm_minmer_t* __restrict__ out, int32_t* __restrict__ out_count,
+                                                               uint64_t* gkey, uint32_t* gpv) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  uint64_t* key = reinterpret_cast<uint64_t*>(smem);
-  uint32_t* pv = reinterpret_cast<uint32_t*>(smem + (size_t)npow2 * 8);
-  int* ssum = reinterpret_cast<int*>(smem + (size_t)npow2 * 12);          // [s] strand sums
-  int* sbase = ssum + s;                                                  // [4] wave scan totals + running base
   const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  // the (hash, position) pairs of the fragment: in LDS, or -- fragments of more k-mers than LDS holds (windows above 8 k) --
+  // in a slice of global memory; the sort and the selection below are the same either way
+  uint64_t* key = gkey ? gkey + (size_t)f * npow2 : reinterpret_cast<uint64_t*>(smem);
+  uint32_t* pv = gpv ? gpv + (size_t)f * npow2 : reinterpret_cast<uint32_t*>(smem + (size_t)npow2 * 8);
+  int* ssum = reinterpret_cast<int*>(smem + (gkey ? 0 : (size_t)npow2 * 12));  // [s] strand sums
+  int* sbase = ssum + s;                                                       // [4] wave scan totals + running base
   const uint8_t* p = seq + frag_off[f];
   const int len = frag_len[f];
   const int nk = len - k + 1;
@@ -255,8 +318,10 @@ int map_sketch_device(wfm_handle_t* h, MapScratch& ms, const char* seq, int64_t 
   }
   int npow2 = 512;
   while (npow2 < maxk) npow2 <<= 1;
-  const size_t lds = (size_t)npow2 * 12 + (size_t)s * 4 + 64;
-  if (lds > 160 * 1024) { wfm_set_error(h, "fragment too long for the LDS sort (max 8192 k-mers)"); return WFM_E_UNSUPPORTED; }
+  size_t lds = (size_t)npow2 * 12 + (size_t)s * 4 + 64;
+  const bool in_global = lds > 160 * 1024;  // more than 8192 k-mers per fragment: the pairs go to global memory
+  if (in_global) lds = (size_t)s * 4 + 64;
+  if (in_global && n * (size_t)npow2 * 12 > ((size_t)16 << 30)) { wfm_set_error(h, "fragments too long for this many at once"); return WFM_E_UNSUPPORTED; }
   HIPCHK(h, hipSetDevice(wfm_device(h)));
   Scoped sc;  // the raw / normalised sequence copies are only needed until the sketch kernel has run
   uint8_t* d_norm = nullptr;
@@ -274,7 +339,12 @@ int map_sketch_device(wfm_handle_t* h, MapScratch& ms, const char* seq, int64_t 
   if (lds > 64 * 1024) {
     HIPCHK(h, hipFuncSetAttribute((const void*)sketch_fragments_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   }
-  hipLaunchKernelGGL(sketch_fragments_kernel, dim3((unsigned)n), dim3(256), lds, st, d_norm, d_off, d_len, k, s, seq_id, npow2, d_out, d_cnt);
+  uint64_t* d_gkey = nullptr; uint32_t* d_gpv = nullptr;
+  if (in_global) {
+    HIPCHK(h, sc.alloc(&d_gkey, n * (size_t)npow2 * 8));
+    HIPCHK(h, sc.alloc(&d_gpv, n * (size_t)npow2 * 4));
+  }
+  hipLaunchKernelGGL(sketch_fragments_kernel, dim3((unsigned)n), dim3(256), lds, st, d_norm, d_off, d_len, k, s, seq_id, npow2, d_out, d_cnt, d_gkey, d_gpv);
   HIPCHK(h, hipGetLastError());
   HIPCHK(h, hipStreamSynchronize(st));  // d_norm / d_off / d_len are released on return
   *d_out_p = d_out; *d_cnt_p = d_cnt;
@@ -304,8 +374,7 @@ int map_hash_sequence_device(wfm_handle_t* h, const char* seq, int64_t len, int 
   if ((e = hipMemcpyAsync(d_raw, seq, (size_t)len, hipMemcpyHostToDevice, st)) != hipSuccess) return fail(e, "hipMemcpyAsync");
   const int64_t nthreads = (len + 15) / 16;
   hipLaunchKernelGGL(normalize_kernel, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, st, d_raw, out->d_norm, len);
-  const int blocks = (int)std::min<int64_t>((out->nk + 255) / 256, 256 * 8);
-  hipLaunchKernelGGL(kmer_hash_kernel, dim3(blocks), dim3(256), 0, st, out->d_norm, out->nk, k, out->d_hash, out->d_strand);
+  launch_kmer_hash(out->d_norm, out->nk, k, out->d_hash, out->d_strand, st);
   if ((e = hipGetLastError()) != hipSuccess) return fail(e, "kernel launch");
   if ((e = hipStreamSynchronize(st)) != hipSuccess) return fail(e, "hipStreamSynchronize");
   (void)hipFree(d_raw);
@@ -346,8 +415,7 @@ int map_hash_sequence_into(wfm_handle_t* h, MapHashWork* wk, const char* seq, in
   HIPCHK(h, hipMemcpyAsync(wk->d_raw, seq, (size_t)len, hipMemcpyHostToDevice, st));
   const int64_t nthreads = (len + 15) / 16;
   hipLaunchKernelGGL(normalize_kernel, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, st, wk->d_raw, wk->d_norm, len);
-  const int blocks = (int)std::min<int64_t>((out->nk + 255) / 256, 256 * 8);
-  hipLaunchKernelGGL(kmer_hash_kernel, dim3(blocks), dim3(256), 0, st, wk->d_norm, out->nk, k, wk->d_hash, wk->d_strand);
+  launch_kmer_hash(wk->d_norm, out->nk, k, wk->d_hash, wk->d_strand, st);
   HIPCHK(h, hipGetLastError());
   HIPCHK(h, hipStreamSynchronize(st));
   out->d_norm = wk->d_norm; out->d_hash = wk->d_hash; out->d_strand = wk->d_strand;
@@ -455,8 +523,7 @@ int wfm_hash_kmers_norm(wfm_handle_t* h, const char* seq, int64_t len, int k, ui
   HIPCHK(h, sc.alloc(&d_hash, (size_t)nk * 8));
   HIPCHK(h, sc.alloc(&d_st, (size_t)nk));
   hipStream_t st = wfm_stream(h);
-  const int blocks = (int)std::min<int64_t>((nk + 255) / 256, 256 * 8);
-  hipLaunchKernelGGL(kmer_hash_kernel, dim3(blocks), dim3(256), 0, st, d_norm, nk, k, d_hash, d_st);
+  launch_kmer_hash(d_norm, nk, k, d_hash, d_st, st);
   HIPCHK(h, hipGetLastError());
   HIPCHK(h, hipMemcpyAsync(hash, d_hash, (size_t)nk * 8, hipMemcpyDeviceToHost, st));
   HIPCHK(h, hipMemcpyAsync(strand, d_st, (size_t)nk, hipMemcpyDeviceToHost, st));
@@ -491,8 +558,7 @@ int64_t wfm_minhash_sketch(wfm_handle_t* h, const char* seq, int64_t len, int k,
   HIPCHK(h, sc.alloc(&d_sorted, (size_t)nk * 8));
   HIPCHK(h, sc.alloc(&d_st, (size_t)nk));
   hipStream_t st = wfm_stream(h);
-  const int blocks = (int)std::min<int64_t>((nk + 255) / 256, 256 * 8);
-  hipLaunchKernelGGL(kmer_hash_kernel, dim3(blocks), dim3(256), 0, st, d_norm, nk, k, d_hash, d_st);
+  launch_kmer_hash(d_norm, nk, k, d_hash, d_st, st);
   HIPCHK(h, hipGetLastError());
   bool head_ambiguous = false;
   for (int j = 0; j < k && j < len; ++j) {

@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -64,12 +65,12 @@ struct DevOps {
   Rec* recs;
   uint32_t nrec, rec_cap, chunk_id, flags;
 
-  __device__ void flag(uint32_t f) { flags |= f; }
-  __device__ void put(uint32_t* p, int i, uint32_t v) { if (lane == 0) p[i] = v; }
+  __device__ __forceinline__ void flag(uint32_t f) { flags |= f; }
+  __device__ __forceinline__ void put(uint32_t* p, int i, uint32_t v) { if (lane == 0) p[i] = v; }
 
   // ---- the stream, through two 64-entry windows held in registers, one entry per lane (0: around the oldest k-mer of the
   //      window, 1: around the next to arrive); an entry is read with v_readlane, a window is refilled by coalesced loads ----
-  __device__ void load_block(int which, uint32_t i) {
+  __device__ __forceinline__ void load_block(int which, uint32_t i) {
     const int64_t base = (int64_t)(i & ~63u);
     const int64_t j = base + lane;
     uint64_t hh = 0; uint32_t pp = 0; int ss = 0;
@@ -77,31 +78,31 @@ struct DevOps {
     cw_lo[which] = (uint32_t)hh; cw_hi[which] = (uint32_t)(hh >> 32); cw_p[which] = pp; cw_s[which] = ss;
     ch_base[which] = base;
   }
-  __device__ void need(int which, uint32_t i) { if ((int64_t)(i & ~63u) != ch_base[which]) load_block(which, i); }
-  __device__ static int sl(uint32_t i) { return __builtin_amdgcn_readfirstlane((int)(i & 63u)); }
-  __device__ uint64_t fr_hash(uint32_t i) { need(0, i); const int l = sl(i); return (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)cw_lo[0], l) | ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)cw_hi[0], l) << 32); }
-  __device__ uint32_t fr_pos(uint32_t i) { need(0, i); return (uint32_t)__builtin_amdgcn_readlane((int)cw_p[0], sl(i)); }
-  __device__ int fr_strand(uint32_t i) { need(0, i); return __builtin_amdgcn_readlane(cw_s[0], sl(i)); }
-  __device__ uint64_t ar_hash(uint32_t i) { need(1, i); const int l = sl(i); return (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)cw_lo[1], l) | ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)cw_hi[1], l) << 32); }
-  __device__ uint32_t ar_pos(uint32_t i) { need(1, i); return (uint32_t)__builtin_amdgcn_readlane((int)cw_p[1], sl(i)); }
-  __device__ int ar_strand(uint32_t i) { need(1, i); return __builtin_amdgcn_readlane(cw_s[1], sl(i)); }
+  __device__ __forceinline__ void need(int which, uint32_t i) { if ((int64_t)(i & ~63u) != ch_base[which]) load_block(which, i); }
+  __device__ __forceinline__ static int sl(uint32_t i) { return __builtin_amdgcn_readfirstlane((int)(i & 63u)); }
+  __device__ __forceinline__ uint64_t fr_hash(uint32_t i) { need(0, i); const int l = sl(i); return (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)cw_lo[0], l) | ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)cw_hi[0], l) << 32); }
+  __device__ __forceinline__ uint32_t fr_pos(uint32_t i) { need(0, i); return (uint32_t)__builtin_amdgcn_readlane((int)cw_p[0], sl(i)); }
+  __device__ __forceinline__ int fr_strand(uint32_t i) { need(0, i); return __builtin_amdgcn_readlane(cw_s[0], sl(i)); }
+  __device__ __forceinline__ uint64_t ar_hash(uint32_t i) { need(1, i); const int l = sl(i); return (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)cw_lo[1], l) | ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)cw_hi[1], l) << 32); }
+  __device__ __forceinline__ uint32_t ar_pos(uint32_t i) { need(1, i); return (uint32_t)__builtin_amdgcn_readlane((int)cw_p[1], sl(i)); }
+  __device__ __forceinline__ int ar_strand(uint32_t i) { need(1, i); return __builtin_amdgcn_readlane(cw_s[1], sl(i)); }
 
   // ---- sketch: entries 0 .. n-1, ascending hashes ----
-  __device__ int sk_n() const { return n; }
-  __device__ uint64_t sk_max() const { return skmax; }
-  __device__ uint64_t sk_hash(int r) const { return ska[r].h; }
-  __device__ uint32_t sk_wpos(int r) const { return ska[r].wpos; }
-  __device__ int sk_tally(int r) const { return (int)(int16_t)(ska[r].tc & 0xFFFFu); }
-  __device__ int sk_cnt(int r) const { return (int)(ska[r].tc >> 16); }
-  __device__ void sk_set_wpos(int r, uint32_t v) { if (lane == 0) ska[r].wpos = v; __syncthreads(); }
-  __device__ void sk_set_tally(int r, int v) {
+  __device__ __forceinline__ int sk_n() const { return n; }
+  __device__ __forceinline__ uint64_t sk_max() const { return skmax; }
+  __device__ __forceinline__ uint64_t sk_hash(int r) const { return ska[r].h; }
+  __device__ __forceinline__ uint32_t sk_wpos(int r) const { return ska[r].wpos; }
+  __device__ __forceinline__ int sk_tally(int r) const { return (int)(int16_t)(ska[r].tc & 0xFFFFu); }
+  __device__ __forceinline__ int sk_cnt(int r) const { return (int)(ska[r].tc >> 16); }
+  __device__ __forceinline__ void sk_set_wpos(int r, uint32_t v) { if (lane == 0) ska[r].wpos = v; __syncthreads(); }
+  __device__ __forceinline__ void sk_set_tally(int r, int v) {
     const uint32_t tc = ska[r].tc;
     __syncthreads();
     if (lane == 0) ska[r].tc = (tc & 0xFFFF0000u) | ((uint32_t)v & 0xFFFFu);
     __syncthreads();
   }
-  __device__ void sk_all_unknown() { for (int j = lane; j < n; j += 64) ska[j].wpos = UNK; __syncthreads(); }
-  __device__ int sk_find(uint64_t h) const {
+  __device__ __forceinline__ void sk_all_unknown() { for (int j = lane; j < n; j += 64) ska[j].wpos = UNK; __syncthreads(); }
+  __device__ __forceinline__ int sk_find(uint64_t h) const {
     for (int base = 0; base < n; base += 64) {
       const int j = base + lane;
       const bool hit = j < n && ska[j].h == h;
@@ -110,7 +111,7 @@ struct DevOps {
     }
     return -1;
   }
-  __device__ int sk_insert(uint64_t h, uint32_t wpos) {
+  __device__ __forceinline__ int sk_insert(uint64_t h, uint32_t wpos) {
     int p = 0;
     for (int base = 0; base < n; base += 64) {
       const int j = base + lane;
@@ -133,7 +134,7 @@ struct DevOps {
     if (p == n - 1) skmax = h;
     return p;
   }
-  __device__ void sk_erase(int r) {
+  __device__ __forceinline__ void sk_erase(int r) {
     // nodes of a list that is still there go back to the free list
     if ((ska[r].tc >> 16) > 1) {
       uint32_t node = skb[r].ht & 0xFFFFu;
@@ -160,7 +161,7 @@ struct DevOps {
   }
 
   // ---- occurrence lists: the first occurrence sits in the sketch entry, further ones in list nodes ----
-  __device__ void occ_push(int r, uint32_t ref) {
+  __device__ __forceinline__ void occ_push(int r, uint32_t ref) {
     const uint32_t tc = ska[r].tc, cnt = tc >> 16;
     if (cnt == 0) {
       __syncthreads();
@@ -180,7 +181,7 @@ struct DevOps {
     }
     __syncthreads();
   }
-  __device__ uint32_t occ_pop(int r) {
+  __device__ __forceinline__ uint32_t occ_pop(int r) {
     const uint32_t tc = ska[r].tc, cnt = tc >> 16;
     const SkB b = skb[r];
     uint32_t node = NIL16, nref = 0, nnext = NIL16;
@@ -197,7 +198,7 @@ struct DevOps {
     __syncthreads();
     return b.first;
   }
-  __device__ void occ_copy(int r, uint32_t* st, int at) {
+  __device__ __forceinline__ void occ_copy(int r, uint32_t* st, int at) {
     const uint32_t cnt = ska[r].tc >> 16;
     if (cnt == 0) return;
     put(st, at, skb[r].first);
@@ -207,7 +208,7 @@ struct DevOps {
 
   // ---- pool ----
   // first live entry at or after position q (-1: none)
-  __device__ int pool_scan(int q, uint32_t a_lo) const {
+  __device__ __forceinline__ int pool_scan(int q, uint32_t a_lo) const {
     for (int base = q; base < pe; base += 64) {
       const int j = base + lane;
       const unsigned long long b = __ballot(j < pe && wn::ref_idx(pl_r[j]) >= a_lo);
@@ -215,7 +216,7 @@ struct DevOps {
     }
     return -1;
   }
-  __device__ void pool_compact(uint32_t a_lo) {  // the live entries move to the front, order kept
+  __device__ __forceinline__ void pool_compact(uint32_t a_lo) {  // the live entries move to the front, order kept
     int out = 0;
     for (int base = ph; base < pe; base += 64) {
       const int j = base + lane;
@@ -232,7 +233,7 @@ struct DevOps {
     }
     ph = 0; pe = out;
   }
-  __device__ void pool_push(uint64_t h, uint32_t ref, uint32_t a_lo) {
+  __device__ __forceinline__ void pool_push(uint64_t h, uint32_t ref, uint32_t a_lo) {
     if (pe >= P) pool_compact(a_lo);
     if (pe >= P) { flag(wn::F_POOL_FULL); return; }
     const uint32_t idx = wn::ref_idx(ref);
@@ -274,7 +275,7 @@ struct DevOps {
     __syncthreads();
   }
   // the smallest hash among the live entries; the dead ones in front of it are dropped
-  __device__ bool pool_min(uint32_t a_lo, uint64_t* mh) {
+  __device__ __forceinline__ bool pool_min(uint32_t a_lo, uint64_t* mh) {
     const int q = pool_scan(ph, a_lo);
     if (q < 0) { ph = 0; pe = 0; return false; }
     ph = q;
@@ -283,7 +284,7 @@ struct DevOps {
     return true;
   }
   // takes out the live entry of hash h with the smallest index: it is the first live one, or there is none
-  __device__ bool pool_pop_hash(uint64_t h, uint32_t a_lo, uint32_t* ref) {
+  __device__ __forceinline__ bool pool_pop_hash(uint64_t h, uint32_t a_lo, uint32_t* ref) {
     const int q = pool_scan(ph, a_lo);
     if (q < 0) { ph = 0; pe = 0; return false; }
     ph = q;
@@ -292,12 +293,12 @@ struct DevOps {
     ph = q + 1;
     return true;
   }
-  __device__ int pool_first(uint32_t a_lo) const { return pool_scan(ph, a_lo); }
-  __device__ int pool_next(int q, uint32_t a_lo) const { return pool_scan(q + 1, a_lo); }
-  __device__ uint64_t pool_hash(int q) const { return pl_h[q]; }
-  __device__ uint32_t pool_ref(int q) const { return pl_r[q]; }
+  __device__ __forceinline__ int pool_first(uint32_t a_lo) const { return pool_scan(ph, a_lo); }
+  __device__ __forceinline__ int pool_next(int q, uint32_t a_lo) const { return pool_scan(q + 1, a_lo); }
+  __device__ __forceinline__ uint64_t pool_hash(int q) const { return pl_h[q]; }
+  __device__ __forceinline__ uint32_t pool_ref(int q) const { return pl_r[q]; }
 
-  __device__ void emit(uint64_t h, uint32_t wpos, uint32_t wend, int tally) {
+  __device__ __forceinline__ void emit(uint64_t h, uint32_t wpos, uint32_t wend, int tally) {
     if (nrec < rec_cap) {
       if (lane == 0) { Rec r; r.hash = h; r.wpos = wpos; r.wend = wend; r.tally = tally; r.chunk = chunk_id; recs[nrec] = r; }
     } else {
@@ -311,7 +312,8 @@ __host__ __device__ inline size_t winnow_lds_bytes(int S, int P, int N) {
   return (size_t)S * 16 + (size_t)S * 8 + (size_t)P * 8 + (size_t)P * 4 + (size_t)N * 4 + (size_t)N * 2 + 64;
 }
 
-__global__ void __launch_bounds__(64) winnow_chunks_kernel(Params prm, const Chunk* chunks, const int* todo, int replay, int S, int P, int N, Rec* recs, uint32_t* rec_count,
+template <bool REPLAY>
+__global__ void __launch_bounds__(64) winnow_chunks_kernel(Params prm, const Chunk* chunks, const int* todo, int S, int P, int N, Rec* recs, uint32_t* rec_count,
                                                            uint32_t* st_begin, uint32_t* st_end, uint32_t* wp_end, uint32_t* flags) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int cj = todo ? todo[blockIdx.x] : (int)blockIdx.x;
@@ -335,7 +337,7 @@ __global__ void __launch_bounds__(64) winnow_chunks_kernel(Params prm, const Chu
   __syncthreads();
   wn::Stream<DevOps> S_(o, prm, (uint32_t)ch.c0);
   const size_t cap = (size_t)prm.state_words;
-  if (replay) S_.run_replay(ch, st_end + (size_t)(cj - 1) * cap, wp_end + (size_t)(cj - 1) * prm.s, st_begin + (size_t)cj * cap, st_end + (size_t)cj * cap,
+  if (REPLAY) S_.run_replay(ch, st_end + (size_t)(cj - 1) * cap, wp_end + (size_t)(cj - 1) * prm.s, st_begin + (size_t)cj * cap, st_end + (size_t)cj * cap,
                             wp_end + (size_t)cj * prm.s, prm.state_words);
   else S_.run(ch, st_begin + (size_t)cj * cap, nullptr, st_end + (size_t)cj * cap, wp_end + (size_t)cj * prm.s, prm.state_words);
   if (o.lane == 0) {
@@ -659,6 +661,10 @@ int map_winnow_sparse_device(wfm_handle_t* h, const MapSparseSeq* sp, int64_t le
   if (lds_small > 64 * 1024 || sp->m >= ((int64_t)1 << 31) || nk >= ((int64_t)1 << 32) - 1 || s < 1) { inf.why = wn::F_STATE_FULL; if (info) *info = inf; return 1; }
   HIPCHK(h, hipSetDevice(sp->device));
   hipStream_t st = wfm_stream(h);
+  static const bool dbg = getenv("WFM_DEBUG") && atoi(getenv("WFM_DEBUG")) > 1;
+  auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double t0 = now();
+  double t_alloc = 0, t_main = 0, t_check = 0, t_resolve = 0;
   const std::vector<int64_t> bounds = plan_bounds(nk, chunk_len);
   const int nc = (int)bounds.size() - 1;
   // kept k-mers before every boundary and warm-up start
@@ -688,6 +694,7 @@ int map_winnow_sparse_device(wfm_handle_t* h, const MapSparseSeq* sp, int64_t le
     wfm_set_error(h, "out of device memory (winnowing)");
     return WFM_E_NOMEM;
   }
+  t_alloc = now();
   Params prm{};
   prm.k = k; prm.w = w; prm.s = s; prm.nk = nk; prm.m = sp->m; prm.hash = sp->d_hash; prm.pos = sp->d_pos; prm.strand = sp->d_strand;
   prm.pool_cap = cp.P; prm.occ_cap = cp.N; prm.state_words = cp.state_words;
@@ -705,7 +712,7 @@ int map_winnow_sparse_device(wfm_handle_t* h, const MapSparseSeq* sp, int64_t le
   // the first words of the snapshots: a chunk that does not write one (first / last) must not compare equal by accident
   HIPCHK(h, hipMemsetAsync(d_stb, 0, (size_t)nc * cap * 4, st));
   HIPCHK(h, hipMemsetAsync(d_ste, 0, (size_t)nc * cap * 4, st));
-  hipLaunchKernelGGL(winnow_chunks_kernel, dim3((unsigned)nc), dim3(64), lds_small, st, prm, d_chunks, (const int*)nullptr, 0, cs.S, cs.P, cs.N, d_recs, d_count, d_stb,
+  hipLaunchKernelGGL(winnow_chunks_kernel<false>, dim3((unsigned)nc), dim3(64), lds_small, st, prm, d_chunks, (const int*)nullptr, cs.S, cs.P, cs.N, d_recs, d_count, d_stb,
                      d_ste, d_wpe, d_flags);
   HIPCHK(h, hipGetLastError());
   std::vector<uint32_t> flags((size_t)nc), count((size_t)nc);
@@ -719,11 +726,13 @@ int map_winnow_sparse_device(wfm_handle_t* h, const MapSparseSeq* sp, int64_t le
     if (!todo.empty() && lds <= 64 * 1024) {
       if (grow(wk->todo, todo.size() * sizeof(int))) { wfm_set_error(h, "out of device memory (winnowing)"); return WFM_E_NOMEM; }
       HIPCHK(h, hipMemcpyAsync(wk->todo.p, todo.data(), todo.size() * sizeof(int), hipMemcpyHostToDevice, st));
-      hipLaunchKernelGGL(winnow_chunks_kernel, dim3((unsigned)todo.size()), dim3(64), lds, st, prm, d_chunks, (const int*)wk->todo.p, 0, cp.S, cp.P, cp.N, d_recs, d_count,
+      hipLaunchKernelGGL(winnow_chunks_kernel<false>, dim3((unsigned)todo.size()), dim3(64), lds, st, prm, d_chunks, (const int*)wk->todo.p, cp.S, cp.P, cp.N, d_recs, d_count,
                          d_stb, d_ste, d_wpe, d_flags);
       HIPCHK(h, hipGetLastError());
     }
   }
+  if (dbg) { (void)hipStreamSynchronize(st); }
+  t_main = now();
   if (nc > 1) {
     hipLaunchKernelGGL(winnow_check_kernel, dim3((unsigned)(nc - 1)), dim3(64), 0, st, d_stb, d_ste, (int)cap, nc, (const int*)nullptr, d_flags);
     HIPCHK(h, hipMemcpyAsync(flags.data(), d_flags, (size_t)nc * 4, hipMemcpyDeviceToHost, st));
@@ -748,7 +757,7 @@ int map_winnow_sparse_device(wfm_handle_t* h, const MapSparseSeq* sp, int64_t le
       int* d_todo = (int*)wk->todo.p;
       HIPCHK(h, hipMemcpyAsync(d_todo, todo.data(), todo.size() * sizeof(int), hipMemcpyHostToDevice, st));
       if (!next.empty()) HIPCHK(h, hipMemcpyAsync(d_todo + todo.size(), next.data(), next.size() * sizeof(int), hipMemcpyHostToDevice, st));
-      hipLaunchKernelGGL(winnow_chunks_kernel, dim3((unsigned)todo.size()), dim3(64), lds, st, prm, d_chunks, (const int*)d_todo, 1, cp.S, cp.P, cp.N, d_recs, d_count, d_stb,
+      hipLaunchKernelGGL(winnow_chunks_kernel<true>, dim3((unsigned)todo.size()), dim3(64), lds, st, prm, d_chunks, (const int*)d_todo, cp.S, cp.P, cp.N, d_recs, d_count, d_stb,
                          d_ste, d_wpe, d_flags);
       if (!next.empty())
         hipLaunchKernelGGL(winnow_check_kernel, dim3((unsigned)next.size()), dim3(64), 0, st, d_stb, d_ste, (int)cap, nc, (const int*)(d_todo + todo.size()), d_flags);
@@ -756,6 +765,7 @@ int map_winnow_sparse_device(wfm_handle_t* h, const MapSparseSeq* sp, int64_t le
       HIPCHK(h, hipMemcpyAsync(flags.data(), d_flags, (size_t)nc * 4, hipMemcpyDeviceToHost, st));
       HIPCHK(h, hipStreamSynchronize(st));
     }
+    t_check = now();
     for (int it = 0; it < 64 && nc > 2; ++it) {
       HIPCHK(h, hipMemsetAsync(d_pending, 0, 4, st));
       hipLaunchKernelGGL(winnow_resolve_states_kernel, dim3((unsigned)(nc - 1)), dim3(64), 0, st, d_ste, d_wpe, (int)cap, s, nc, d_pending, d_flags);
@@ -771,6 +781,7 @@ int map_winnow_sparse_device(wfm_handle_t* h, const MapSparseSeq* sp, int64_t le
   HIPCHK(h, hipMemcpyAsync(flags.data(), d_flags, (size_t)nc * 4, hipMemcpyDeviceToHost, st));
   HIPCHK(h, hipMemcpyAsync(count.data(), d_count, (size_t)nc * 4, hipMemcpyDeviceToHost, st));
   HIPCHK(h, hipStreamSynchronize(st));
+  t_resolve = now();
   uint32_t why = 0;
   for (int c = 0; c < nc; ++c) { why |= flags[(size_t)c]; inf.bad_chunks += flags[(size_t)c] != 0; }
   inf.chunks = nc; inf.why = why;
@@ -783,6 +794,9 @@ int map_winnow_sparse_device(wfm_handle_t* h, const MapSparseSeq* sp, int64_t le
   hipLaunchKernelGGL(winnow_gather_kernel, dim3((unsigned)nc), dim3(256), 0, st, d_recs, d_chunks, d_count, (const int64_t*)wk->off.p, seq_id, (wfm_minmer_t*)wk->out.p);
   HIPCHK(h, hipGetLastError());
   HIPCHK(h, hipStreamSynchronize(st));
+  if (dbg)
+    fprintf(stderr, "[wfm] winnow: %d chunks, lower bounds + buffers %.2f ms, chunks kernel (+ reruns of %d) %.2f, check + %d replays %.2f, resolve %.2f, gather %.2f ms\n", nc,
+            t_alloc - t0, inf.rerun_chunks, t_main - t_alloc, inf.replays, t_check - t_main, t_resolve - t_check, now() - t_resolve);
   *d_out = (wfm_minmer_t*)wk->out.p;
   *n_out = total;
   inf.records = total;

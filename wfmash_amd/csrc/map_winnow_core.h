@@ -62,12 +62,12 @@ struct Stream {
 
   __host__ __device__ Stream(Ops& ops, const Params& p, uint32_t c0) : o(ops), k(p.k), w(p.w), s(p.s), nk(p.nk), m(p.m), a_lo(c0), c(c0), emit_on(true), dirty(true) {}
 
-  __host__ __device__ void emit(uint64_t h, uint32_t wpos, int64_t wend, int tally) {
+  __host__ __device__ __forceinline__ void emit(uint64_t h, uint32_t wpos, int64_t wend, int tally) {
     if (emit_on) o.emit(h, wpos, (uint32_t)wend, tally);
   }
 
   // ---- the k-mer that fell out of the window (Winnower::leave) ----
-  __host__ __device__ void leave(int64_t win) {
+  __host__ __device__ __forceinline__ void leave(int64_t win) {
     if (a_lo >= c) return;
     if ((int64_t)o.fr_pos(a_lo) >= win) return;
     const uint64_t lh = o.fr_hash(a_lo);
@@ -93,7 +93,7 @@ struct Stream {
   }
 
   // ---- a kept k-mer enters the window (Winnower::arrive) ----
-  __host__ __device__ void arrive(int64_t win) {
+  __host__ __device__ __forceinline__ void arrive(int64_t win) {
     const uint64_t h = o.ar_hash(c);
     const int st = o.ar_strand(c);
     const uint32_t ref = c | (st < 0 ? SBIT : 0u);
@@ -115,7 +115,7 @@ struct Stream {
   }
 
   // does the k-mer behind `ref` start after `win`?  (in the window, and not the one that leaves next if that one starts AT win)
-  __host__ __device__ bool starts_after(uint32_t ref, int64_t win) {
+  __host__ __device__ __forceinline__ bool starts_after(uint32_t ref, int64_t win) {
     const uint32_t i = ref_idx(ref);
     if (i < a_lo) return false;
     if (i == a_lo && (int64_t)o.fr_pos(a_lo) == win) return false;
@@ -123,7 +123,7 @@ struct Stream {
   }
 
   // ---- keep the sketch at the s smallest hashes of the window (Winnower::maintain) ----
-  __host__ __device__ void maintain(int64_t win) {
+  __host__ __device__ __forceinline__ void maintain(int64_t win) {
     uint64_t mh = 0;
     bool have = o.pool_min(a_lo, &mh);
     const int n = o.sk_n();
@@ -155,7 +155,7 @@ struct Stream {
 
   // the stream for k-mer starts [from, to) (Winnower::advance_sparse): only the iterations in which a kept k-mer arrives
   // or leaves, and the one that completes the first window, do anything
-  __host__ __device__ void advance(int64_t from, int64_t to) {
+  __host__ __device__ __forceinline__ void advance(int64_t from, int64_t to) {
     const int64_t W = (int64_t)w - k + 1, first_full = (int64_t)w - k;
     const int64_t never = INT64_MAX;
     int64_t i = from;
@@ -178,7 +178,7 @@ struct Stream {
   }
 
   // remaining open intervals close at len - k + 1 (commonFunc.hpp:647-658)
-  __host__ __device__ void flush_end() {
+  __host__ __device__ __forceinline__ void flush_end() {
     const int n = o.sk_n();
     for (int r = 0; r < n && r < s; ++r) emit(o.sk_hash(r), o.sk_wpos(r), nk, o.sk_tally(r));
   }
@@ -188,7 +188,7 @@ struct Stream {
   //   per sketch entry (ascending hashes): hash lo, hash hi, tally (16 bits) | occurrences << 16, the occurrences' references
   //   per pool entry (ascending (hash, index)): hash lo, hash hi, reference
   // The starts of the open intervals are not part of it; they go to wpos[0 .. s).
-  __host__ __device__ void snapshot(uint32_t* st, uint32_t* wpos, int cap) {
+  __host__ __device__ __forceinline__ void snapshot(uint32_t* st, uint32_t* wpos, int cap) {
     int at = 4;
     const int n = o.sk_n();
     bool full = false;
@@ -217,7 +217,7 @@ struct Stream {
 
   // take over the state another chunk reached (its snapshot and interval starts): sketch entries in ascending order, their
   // occurrences, the pool
-  __host__ __device__ void load(const uint32_t* st, const uint32_t* wpos) {
+  __host__ __device__ __forceinline__ void load(const uint32_t* st, const uint32_t* wpos) {
     a_lo = st[1];
     const int n = (int)st[2], np = (int)st[3];
     int at = 4;
@@ -239,7 +239,7 @@ struct Stream {
 
   // the replay after a failed speculation: the chunk once more, from the state its predecessor really reached.  The state
   // it starts from is also what it is compared with from now on (st_begin).
-  __host__ __device__ void run_replay(const Chunk& ch, const uint32_t* prev_end, const uint32_t* prev_wpos, uint32_t* st_begin, uint32_t* st_end,
+  __host__ __device__ __forceinline__ void run_replay(const Chunk& ch, const uint32_t* prev_end, const uint32_t* prev_wpos, uint32_t* st_begin, uint32_t* st_end,
                                       uint32_t* wpos_end, int cap) {
     load(prev_end, prev_wpos);
     c = (uint32_t)ch.c1;
@@ -251,7 +251,7 @@ struct Stream {
   }
 
   // one chunk: warm-up from an empty state two windows before it, then the chunk itself
-  __host__ __device__ void run(const Chunk& ch, uint32_t* st_begin, uint32_t* wpos_begin, uint32_t* st_end, uint32_t* wpos_end, int cap) {
+  __host__ __device__ __forceinline__ void run(const Chunk& ch, uint32_t* st_begin, uint32_t* wpos_begin, uint32_t* st_end, uint32_t* wpos_end, int cap) {
     if (!ch.first) {
       emit_on = false;
       advance(ch.warm_from, ch.from);
