@@ -116,7 +116,7 @@ void map_thin_work_free(MapThinWork* wk);
 int map_prefilter_device(wfm_handle_t* h, const MapHashedSeq* q, int64_t W, int s, uint64_t tau, MapSparseSeq* out, MapThinWork* wk = nullptr);
 void map_sparse_free(MapSparseSeq* s);
 // out[i] = number of kept k-mers with position < query[i] (host arrays)
-int map_sparse_lower_bound(wfm_handle_t* h, const MapSparseSeq* s, const int64_t* query, int nq, int64_t* out);
+int map_sparse_lower_bound(wfm_handle_t* h, const MapSparseSeq* s, const int64_t* query, int nq, int64_t* out, hipStream_t stream = nullptr);
 // kept k-mers [c0, c1): uint64 hash[mc] | uint32 pos[mc] | int8 strand[mc], into a ring slot / ordinary memory
 int map_stage_copy_sparse(MapStage* st, int slot, const MapSparseSeq* s, int64_t c0, int64_t c1);
 int map_sparse_fetch_packed(const MapSparseSeq* s, int64_t c0, int64_t c1, char* dst);
@@ -131,7 +131,7 @@ struct MapWinnowInfo { int chunks = 0, bad_chunks = 0, rerun_chunks = 0, replays
 // WFM_OK: *d_out (inside wk, valid until the next call) holds *n_out raw records in emission order, interval starts
 // resolved; 1: this sequence is not for the device (info->why), the caller winnows it on the host; < 0: error
 int map_winnow_sparse_device(wfm_handle_t* h, const MapSparseSeq* sp, int64_t len, int k, int w, int s, int32_t seq_id, int64_t chunk_len,
-                             MapWinnowWork* wk, wfm_minmer_t** d_out, int64_t* n_out, MapWinnowInfo* info);
+                             MapWinnowWork* wk, wfm_minmer_t** d_out, int64_t* n_out, MapWinnowInfo* info, hipStream_t stream = nullptr);
 // The closing steps of addMinmers on the device (map_finish.hip): pieces of at most w windows, strand signs, std::sort's
 // order by (wpos, wpos_end) -- ties as libstdc++'s introsort leaves them -- and de-duplication.
 struct MapFinishWork {  // grow-only device buffers
@@ -141,7 +141,7 @@ struct MapFinishWork {  // grow-only device buffers
 void map_finish_work_free(MapFinishWork* wk);
 struct MapFinishInfo { int64_t laid_out = 0, records = 0; int levels = 0, heap_ranges = 0; };
 int map_finish_records_device(wfm_handle_t* h, const wfm_minmer_t* d_raw, int64_t n_raw, int w, MapFinishWork* wk, wfm_minmer_t** d_out, int64_t* n_out,
-                              MapFinishInfo* info);
+                              MapFinishInfo* info, hipStream_t stream = nullptr);
 void map_sortlike_model(std::vector<std::pair<uint64_t, uint32_t>>& v);  // the same arrangement computed on the host (CPU test-suite)
 
 // the kernel's control flow and capacities on plain host arrays (CPU test-suite); -1 = the device would hand the sequence back

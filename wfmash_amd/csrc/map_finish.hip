@@ -481,22 +481,25 @@ int sortlike_loop_device(wfm_handle_t* h, MapFinishWork* wk, uint64_t* key, uint
   }
   if (nheap_total) {  // ranges that spent their depth budget: __partial_sort(first, last, last) = make_heap + sort_heap
     std::vector<Seg> hs((size_t)nheap_total);
-    HIPCHK(h, hipMemcpy(hs.data(), wk->heap.p, (size_t)nheap_total * sizeof(Seg), hipMemcpyDeviceToHost));
+    HIPCHK(h, hipMemcpyAsync(hs.data(), wk->heap.p, (size_t)nheap_total * sizeof(Seg), hipMemcpyDeviceToHost, st));
+    HIPCHK(h, hipStreamSynchronize(st));
     std::vector<std::pair<uint64_t, uint32_t>> v;
     std::vector<uint64_t> hk;
     std::vector<uint32_t> hi;
     for (const Seg& s : hs) {
       const size_t m = (size_t)(s.l - s.f);
       hk.resize(m); hi.resize(m); v.resize(m);
-      HIPCHK(h, hipMemcpy(hk.data(), key + s.f, m * 8, hipMemcpyDeviceToHost));
-      HIPCHK(h, hipMemcpy(hi.data(), idx + s.f, m * 4, hipMemcpyDeviceToHost));
+      HIPCHK(h, hipMemcpyAsync(hk.data(), key + s.f, m * 8, hipMemcpyDeviceToHost, st));
+      HIPCHK(h, hipMemcpyAsync(hi.data(), idx + s.f, m * 4, hipMemcpyDeviceToHost, st));
+      HIPCHK(h, hipStreamSynchronize(st));
       for (size_t i = 0; i < m; ++i) v[i] = {hk[i], hi[i]};
       auto lessk = [](const std::pair<uint64_t, uint32_t>& a, const std::pair<uint64_t, uint32_t>& b) { return a.first < b.first; };
       std::make_heap(v.begin(), v.end(), lessk);
       std::sort_heap(v.begin(), v.end(), lessk);
       for (size_t i = 0; i < m; ++i) { hk[i] = v[i].first; hi[i] = v[i].second; }
-      HIPCHK(h, hipMemcpy(key + s.f, hk.data(), m * 8, hipMemcpyHostToDevice));
-      HIPCHK(h, hipMemcpy(idx + s.f, hi.data(), m * 4, hipMemcpyHostToDevice));
+      HIPCHK(h, hipMemcpyAsync(key + s.f, hk.data(), m * 8, hipMemcpyHostToDevice, st));
+      HIPCHK(h, hipMemcpyAsync(idx + s.f, hi.data(), m * 4, hipMemcpyHostToDevice, st));
+      HIPCHK(h, hipStreamSynchronize(st));
     }
   }
   if (levels_out) *levels_out = levels;
@@ -518,13 +521,13 @@ void map_finish_work_free(MapFinishWork* wk) {
 // Raw records of one sequence (emission order, on the device) -> addMinmers' records: *d_out (inside wk, valid until the next
 // call) holds *n_out of them.
 int map_finish_records_device(wfm_handle_t* h, const wfm_minmer_t* d_raw, int64_t n_raw, int w, MapFinishWork* wk, wfm_minmer_t** d_out, int64_t* n_out,
-                              MapFinishInfo* info) {
+                              MapFinishInfo* info, hipStream_t stream) {
   if (!h || !wk || !d_out || !n_out || (n_raw && !d_raw)) return WFM_E_ARG;
   *d_out = nullptr; *n_out = 0;
   MapFinishInfo inf{};
   if (n_raw == 0) { if (info) *info = inf; return WFM_OK; }
   if (n_raw >= ((int64_t)1 << 31)) { wfm_set_error(h, "too many records for the closing sort"); return WFM_E_UNSUPPORTED; }
-  hipStream_t st = wfm_stream(h);
+  hipStream_t st = stream ? stream : wfm_stream(h);
   const size_t nr = (size_t)n_raw;
   if (grow(wk->ns, nr * 4 + 4) || grow(wk->np, nr * 4 + 4) || grow(wk->os, nr * 4 + 4) || grow(wk->op, nr * 4 + 4)) { wfm_set_error(h, "out of device memory (closing sort)"); return WFM_E_NOMEM; }
   const unsigned gb = (unsigned)((nr + 255) / 256);

@@ -207,11 +207,11 @@ int map_prefilter_device(wfm_handle_t* h, const MapHashedSeq* q, int64_t W, int 
   return WFM_OK;
 }
 
-int map_sparse_lower_bound(wfm_handle_t* h, const MapSparseSeq* s, const int64_t* query, int nq, int64_t* out) {
+int map_sparse_lower_bound(wfm_handle_t* h, const MapSparseSeq* s, const int64_t* query, int nq, int64_t* out, hipStream_t stream) {
   if (nq <= 0) return WFM_OK;
   if (s->m == 0) { for (int i = 0; i < nq; ++i) out[i] = 0; return WFM_OK; }
   HIPCHK(h, hipSetDevice(s->device));
-  hipStream_t st = wfm_stream(h);
+  hipStream_t st = stream ? stream : wfm_stream(h);
   MapScratch sc;
   int64_t *d_q = nullptr, *d_o = nullptr;
   HIPCHK(h, sc.alloc(&d_q, (size_t)nq));

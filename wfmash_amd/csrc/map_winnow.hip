@@ -651,7 +651,7 @@ int grow(MapWinnowWork::Buf& b, size_t bytes) {
 // (commonFunc.hpp:660-706).  1: not for the device (capacities, a failed speculation, ...): the caller winnows the
 // sequence on the host; *why says which.
 int map_winnow_sparse_device(wfm_handle_t* h, const MapSparseSeq* sp, int64_t len, int k, int w, int s, int32_t seq_id, int64_t chunk_len,
-                             MapWinnowWork* wk, wfm_minmer_t** d_out, int64_t* n_out, MapWinnowInfo* info) {
+                             MapWinnowWork* wk, wfm_minmer_t** d_out, int64_t* n_out, MapWinnowInfo* info, hipStream_t stream) {
   if (!h || !sp || !wk || !d_out || !n_out) return WFM_E_ARG;
   *d_out = nullptr; *n_out = 0;
   MapWinnowInfo inf{};
@@ -660,7 +660,7 @@ int map_winnow_sparse_device(wfm_handle_t* h, const MapSparseSeq* sp, int64_t le
   const int64_t nk = len - k + 1;
   if (lds_small > 64 * 1024 || sp->m >= ((int64_t)1 << 31) || nk >= ((int64_t)1 << 32) - 1 || s < 1) { inf.why = wn::F_STATE_FULL; if (info) *info = inf; return 1; }
   HIPCHK(h, hipSetDevice(sp->device));
-  hipStream_t st = wfm_stream(h);
+  hipStream_t st = stream ? stream : wfm_stream(h);
   static const bool dbg = getenv("WFM_DEBUG") && atoi(getenv("WFM_DEBUG")) > 1;
   auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   const double t0 = now();
@@ -671,7 +671,7 @@ int map_winnow_sparse_device(wfm_handle_t* h, const MapSparseSeq* sp, int64_t le
   std::vector<int64_t> q((size_t)2 * nc + 1), r((size_t)2 * nc + 1);
   for (int c = 0; c <= nc; ++c) q[(size_t)c] = bounds[(size_t)c];
   for (int c = 0; c < nc; ++c) q[(size_t)nc + 1 + c] = c > 0 ? std::max<int64_t>(0, bounds[(size_t)c] - 2 * (int64_t)w) : 0;
-  int rc = map_sparse_lower_bound(h, sp, q.data(), (int)q.size(), r.data());
+  int rc = map_sparse_lower_bound(h, sp, q.data(), (int)q.size(), r.data(), st);
   if (rc != WFM_OK) return rc;
   std::vector<Chunk> chunks((size_t)nc);
   int64_t rec_total = 0;

@@ -382,18 +382,22 @@ int run_tiled_phase(wfm_handle* h, wfm_seqset* S, const DevPen& dp, int scope, c
       // widest range of the chunk fits one tile, every job-direction is ONE tile without a halo, and the workgroups
       // are only as large as that range needs (the first blocks of a level are a few hundred diagonals wide)
       tasks.clear();
-      int threads_c = cfg.threads, core_c = core;
+      int core_c = core;
+      std::vector<int> threads_b((size_t)chunk, cfg.threads);  // workgroup size of every block of the chunk
       if (cfg.reg && cfg.C == 2) {
-        int widest = 0;
+        std::vector<int> wb((size_t)chunk, 0);  // widest range per block
         for (size_t i = 0; i < n; ++i) {
           if (!active[i]) continue;
-          const int reach = tj[i].s0 + chunk * T;
-          widest = std::max(widest, std::min(tj[i].tl, reach) - std::max(-tj[i].pl, -reach) + 1);
+          for (int b = 0; b < chunk; ++b) {
+            const int reach = tj[i].s0 + (b + 1) * T;
+            wb[(size_t)b] = std::max(wb[(size_t)b], std::min(tj[i].tl, reach) - std::max(-tj[i].pl, -reach) + 1);
+          }
         }
-        if (widest <= cfg.threads * cfg.C) {
-          threads_c = widest <= 256 ? 128 : (widest <= 512 ? 256 : cfg.threads);
-          threads_c = std::min(threads_c, cfg.threads);
-          core_c = threads_c * cfg.C;
+        if (wb[(size_t)chunk - 1] <= cfg.threads * cfg.C) {
+          // one tile per job-direction: whole waves, as many as the block's own widest range needs (two diagonals per lane)
+          for (int b = 0; b < chunk; ++b)
+            threads_b[(size_t)b] = std::min(cfg.threads, std::max(64, ((wb[(size_t)b] + cfg.C - 1) / cfg.C + 63) / 64 * 64));
+          core_c = threads_b[(size_t)chunk - 1] * cfg.C;
         }
       }
       for (size_t i = 0; i < n; ++i) {
@@ -409,7 +413,7 @@ int run_tiled_phase(wfm_handle* h, wfm_seqset* S, const DevPen& dp, int scope, c
       HIPCHK(h, hipMemcpyAsync(h->tiletasks.p, tasks.data(), tasks.size() * sizeof(TileTask), hipMemcpyHostToDevice, h->stream));
       for (int b = 0; b < chunk; ++b) {
         HIPCHK(h, hipEventRecord(h->tile_ev[2 * b], h->stream));
-        if (cfg.reg) launch_tile_reg(S->d_seq, h->ring.p, h->tilejobs.p, h->tiletasks.p, h->tilemak.p, (int)tasks.size(), threads_c, T, cfg.C, h->stream);
+        if (cfg.reg) launch_tile_reg(S->d_seq, h->ring.p, h->tilejobs.p, h->tiletasks.p, h->tilemak.p, (int)tasks.size(), threads_b[(size_t)b], T, cfg.C, h->stream);
         else launch_tile(S->d_seq, h->ring.p, h->tilejobs.p, h->tiletasks.p, h->tilemak.p, (int)tasks.size(), cfg.threads, T, cfg.Wt, lds, dp, scope, h->stream);
         HIPCHK(h, hipEventRecord(h->tile_ev[2 * b + 1], h->stream));
         launch_tile_advance(h->tilejobs.p, h->tilemak.p, (int)n, T, dp, (cfg.reg && cfg.exact) ? 1 : 0, h->stream);
@@ -533,7 +537,7 @@ int run_p2_phase(wfm_handle* h, wfm_seqset* S, const DevPen& dp, int scope, cons
         widest = std::max(widest, std::min(t.tl, rd) - std::max(-t.pl, -rd) + 1);
       }
       if (widest <= cfg.threads * 2) {
-        threads_c = std::min(cfg.threads, widest <= 256 ? 128 : (widest <= 512 ? 256 : cfg.threads));
+        threads_c = std::min(cfg.threads, std::max(64, ((widest + 1) / 2 + 63) / 64 * 64));
         core_c = threads_c * 2;
       }
     }

@@ -559,6 +559,7 @@ struct SeqJob {
   std::mutex* gpu_mu = nullptr;
   std::vector<wfm_minmer_t> dev_raw;     // winnowed on the device (map_winnow.hip): raw records in emission order, to be finished
   bool dev_winnowed = false;
+  bool for_device = false;               // thinned, and nothing that keeps it from the device winnower
   wfm_minmer_t* d_result = nullptr;      // winnowed AND finished on the device (map_finish.hip): the sequence's records, on the device
   int64_t n_result = 0;
   std::vector<uint32_t> h_pos;           // test hook: the kept k-mers in host memory
@@ -944,6 +945,7 @@ int64_t add_minmers_core(wfm_handle_t* h, const char* const* seqs, const int64_t
   std::mutex gpu_mu;  // the handle's stream and error string: this thread, and a worker that hashes a sequence again
   MapHashWork hash_work;
   MapThinWork thin_work;
+
   MapWinnowWork winnow_work;
   MapFinishWork finish_work;
   const bool dev_finish = !(getenv("WFM_FINISH_DEVICE") && atoi(getenv("WFM_FINISH_DEVICE")) == 0);
@@ -954,8 +956,106 @@ int64_t add_minmers_core(wfm_handle_t* h, const char* const* seqs, const int64_t
   int64_t dev_seqs = 0, dev_handed_back = 0, dev_chunks = 0, dev_replays = 0;
   uint32_t dev_why = 0;
   double ms_winnow = 0;
+  // Winnowing and the closing sort of thinned sequences on the device (map_winnow.hip, map_finish.hip), on a stream and a
+  // thread of their own: the calling thread is hashing and thinning the next sequence meanwhile.  A sequence the device
+  // hands back joins the host path (the streamer's list).
+  std::deque<SeqJob*> dev_queue;
+  std::condition_variable cv_dev;
+  bool dev_done = false;
+  auto seq_finished = [&](SeqJob* J) {
+    J->stitched.store(true, std::memory_order_release);
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      inflight_bases -= J->len;
+    }
+    cv_room.notify_one();
+  };
+  auto device_thread = [&]() {
+    (void)hipSetDevice(wfm_device(h));
+    hipStream_t st2 = nullptr;
+    if (hipStreamCreateWithFlags(&st2, hipStreamNonBlocking) != hipSuccess) st2 = nullptr;
+    for (;;) {
+      SeqJob* J;
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        cv_dev.wait(lk, [&] { return dev_done || !dev_queue.empty(); });
+        if (dev_queue.empty()) break;
+        J = dev_queue.front();
+        dev_queue.pop_front();
+      }
+      const auto tw = std::chrono::steady_clock::now();
+      wfm_minmer_t* d_recs = nullptr;
+      int64_t n_recs = 0;
+      MapWinnowInfo wi;
+      // chunk length: one wave per chunk, and about as many chunks as the device keeps resident at once (a chunk's two
+      // windows of warm-up are its overhead: no chunk under four windows)
+      const int64_t auto_chunk = std::min<int64_t>((J->nk + 6143) / 6144, (int64_t)1 << 16);
+      int wrc = st2 ? map_winnow_sparse_device(h, &J->sparse, J->len, k, w, s, J->seq_id, std::max<int64_t>(dev_chunk > 0 ? dev_chunk : auto_chunk, 4 * (int64_t)w),
+                                               &winnow_work, &d_recs, &n_recs, &wi, st2)
+                    : WFM_E_HIP;
+      dev_chunks += wi.chunks;
+      dev_replays += wi.replays;
+      if (wrc == WFM_OK && dev_finish) {  // the closing cut / sort / de-duplication on the device as well
+        wfm_minmer_t* d_fin = nullptr;
+        int64_t n_fin = 0;
+        MapFinishInfo fi;
+        wrc = map_finish_records_device(h, d_recs, n_recs, w, &finish_work, &d_fin, &n_fin, &fi, st2);
+        if (wrc == WFM_OK && n_fin) {
+          if (hipMalloc((void**)&J->d_result, (size_t)n_fin * sizeof(wfm_minmer_t)) != hipSuccess ||
+              hipMemcpyAsync(J->d_result, d_fin, (size_t)n_fin * sizeof(wfm_minmer_t), hipMemcpyDeviceToDevice, st2) != hipSuccess ||
+              hipStreamSynchronize(st2) != hipSuccess) {
+            wfm_set_error(h, "out of device memory (minmer records)");
+            wrc = WFM_E_NOMEM;
+          }
+        }
+        if (wrc == WFM_OK) {
+          J->n_result = n_fin;
+          J->dev_winnowed = true;
+          ++dev_seqs;
+          dev_levels = std::max(dev_levels, fi.levels);
+          dev_heaps += fi.heap_ranges;
+        }
+      } else if (wrc == WFM_OK) {  // WFM_FINISH_DEVICE=0: the closing sort by a host worker
+        J->dev_raw.resize((size_t)n_recs);
+        if (n_recs && (hipMemcpyAsync(J->dev_raw.data(), d_recs, (size_t)n_recs * sizeof(wfm_minmer_t), hipMemcpyDeviceToHost, st2) != hipSuccess ||
+                       hipStreamSynchronize(st2) != hipSuccess)) {
+          wfm_set_error(h, "device-to-host copy of minmer records failed");
+          wrc = WFM_E_HIP;
+        } else {
+          J->dev_winnowed = true;
+          ++dev_seqs;
+        }
+      }
+      ms_winnow += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tw).count();
+      if (wrc < 0) {  // an error: the sequence ends here with no records, the call fails
+        async_rc.store(wrc);
+        map_sparse_free(&J->sparse);
+        seq_finished(J);
+      } else if (wrc == 1) {  // not for the device after all: the host's chunks
+        ++dev_handed_back;
+        dev_why |= wi.why;
+        {
+          std::lock_guard<std::mutex> lk(mu);
+          hashed.push_back(J);
+        }
+        cv_hashed.notify_one();
+      } else if (J->d_result || J->dev_raw.empty()) {  // winnowed and finished: nothing left to do
+        map_sparse_free(&J->sparse);
+        seq_finished(J);
+      } else {
+        map_sparse_free(&J->sparse);
+        {
+          std::lock_guard<std::mutex> lk(mu);
+          queue.push_back(Task{J, 0, -1});
+        }
+        cv_work.notify_one();
+      }
+    }
+    if (st2) (void)hipStreamDestroy(st2);
+  };
   std::vector<std::thread> pool;
   for (int t = 0; t < nthreads; ++t) pool.emplace_back(worker);
+  std::thread dev_thread(device_thread);
   std::thread stream_thread;
   if (streamed) stream_thread = std::thread(streamer);
   int rc = WFM_OK;
@@ -1006,73 +1106,20 @@ int64_t add_minmers_core(wfm_handle_t* h, const char* const* seqs, const int64_t
       J->cidx_warm.assign(r.begin() + (long)nc + 1, r.end());
       map_hashed_free(&J->dev);  // borrowed: just forgets the pointers
       J->on_device = false;
-      // the winnowing itself, one wave per chunk (map_winnow.hip); whatever the device hands back takes the host path below
-      if (dev_winnow && !has_unnoticed_n(J->head.data(), (int64_t)J->head.size(), k)) {
-        const auto tw = std::chrono::steady_clock::now();
-        wfm_minmer_t* d_recs = nullptr;
-        int64_t n_recs = 0;
-        MapWinnowInfo wi;
-        // chunk length: one wave per chunk, and about as many chunks as the device keeps resident at once (a chunk's two
-        // windows of warm-up are its overhead: no chunk under four windows)
-        const int64_t auto_chunk = std::min<int64_t>((J->nk + 6143) / 6144, (int64_t)1 << 16);
-        const int wrc = map_winnow_sparse_device(h, &J->sparse, len, k, w, s, J->seq_id, std::max<int64_t>(dev_chunk > 0 ? dev_chunk : auto_chunk, 4 * (int64_t)w),
-                                                 &winnow_work, &d_recs, &n_recs, &wi);
-        if (wrc < 0) { rc = wrc; map_sparse_free(&J->sparse); break; }
-        dev_chunks += wi.chunks;
-        dev_replays += wi.replays;
-        bool finished = false;
-        if (wrc == WFM_OK && dev_finish) {  // the closing cut / sort / de-duplication on the device as well
-          wfm_minmer_t* d_fin = nullptr;
-          int64_t n_fin = 0;
-          MapFinishInfo fi;
-          const int frc = map_finish_records_device(h, d_recs, n_recs, w, &finish_work, &d_fin, &n_fin, &fi);
-          if (frc != WFM_OK) { rc = frc; map_sparse_free(&J->sparse); break; }
-          if (n_fin) {
-            if (hipMalloc((void**)&J->d_result, (size_t)n_fin * sizeof(wfm_minmer_t)) != hipSuccess ||
-                hipMemcpy(J->d_result, d_fin, (size_t)n_fin * sizeof(wfm_minmer_t), hipMemcpyDeviceToDevice) != hipSuccess) {
-              wfm_set_error(h, "out of device memory (minmer records)"); rc = WFM_E_NOMEM; map_sparse_free(&J->sparse); break;
-            }
-          }
-          J->n_result = n_fin;
-          J->dev_winnowed = true;
-          finished = true;
-          ++dev_seqs;
-          dev_levels = std::max(dev_levels, fi.levels);
-          dev_heaps += fi.heap_ranges;
-        }
-        if (finished) {
-        } else if (wrc == WFM_OK) {
-          J->dev_raw.resize((size_t)n_recs);
-          if (n_recs && hipMemcpy(J->dev_raw.data(), d_recs, (size_t)n_recs * sizeof(wfm_minmer_t), hipMemcpyDeviceToHost) != hipSuccess) {
-            wfm_set_error(h, "device-to-host copy of minmer records failed"); rc = WFM_E_HIP; map_sparse_free(&J->sparse); break;
-          }
-          J->dev_winnowed = true;
-          ++dev_seqs;
-        } else {
-          ++dev_handed_back;
-          dev_why |= wi.why;
-        }
-        ms_winnow += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tw).count();
-      }
+      // the winnowing itself goes to the device (map_winnow.hip, its own thread and stream below) unless the sequence starts
+      // with a k-mer whose N the reference does not notice
+      J->for_device = dev_winnow && !has_unnoticed_n(J->head.data(), (int64_t)J->head.size(), k);
     }
     gpu.unlock();
     ms_thin += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count();
     SeqJob* Jp = J.get();
     jobs[(size_t)i] = std::move(J);
-    if (Jp->dev_winnowed && (Jp->d_result || Jp->dev_raw.empty())) {  // winnowed and finished on the device: nothing left to do
-      map_sparse_free(&Jp->sparse);
-      Jp->stitched.store(true, std::memory_order_release);
+    if (Jp->for_device) {
       {
         std::lock_guard<std::mutex> lk(mu);
-        inflight_bases -= Jp->len;
+        dev_queue.push_back(Jp);
       }
-    } else if (Jp->dev_winnowed) {
-      map_sparse_free(&Jp->sparse);
-      {
-        std::lock_guard<std::mutex> lk(mu);
-        queue.push_back(Task{Jp, 0, -1});
-      }
-      cv_work.notify_one();
+      cv_dev.notify_one();
     } else if (streamed) {
       {
         std::lock_guard<std::mutex> lk(mu);
@@ -1094,6 +1141,12 @@ int64_t add_minmers_core(wfm_handle_t* h, const char* const* seqs, const int64_t
       cv_work.notify_one();
     }
   }
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    dev_done = true;
+  }
+  cv_dev.notify_all();
+  dev_thread.join();  // before the streamer is told that nothing more will come: the device may still hand sequences back
   {
     std::lock_guard<std::mutex> lk(mu);
     hashed_done = true;
