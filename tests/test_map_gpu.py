@@ -31,7 +31,8 @@ def _noisy(seed, n):
 
 def test_hash_kmers_matches_oracle(gpu):
     for seed, n, k in [(1, 15, 15), (2, 16, 15), (3, 1000, 15), (4, 5000, 21), (5, 70000, 15), (6, 333, 11), (7, 2000, 31), (8, 900, 16), (9, 100, 32),
-                       (10, 3000, 9), (11, 3000, 10), (12, 3000, 12), (13, 3000, 13), (14, 3000, 14), (15, 3000, 8), (16, 40000, 16)]:  # 9..16: the two-word kernel
+                       (10, 3000, 9), (11, 3000, 10), (12, 3000, 12), (13, 3000, 13), (14, 3000, 14), (15, 3000, 8), (16, 40000, 16),
+                       (17, 3000, 17), (18, 3000, 19), (19, 30000, 21), (20, 3000, 23), (21, 3000, 24), (22, 3000, 25)]:  # 9..24: the word-wise kernel
         s = _noisy(seed, n)
         h, st = gpu.hash_kmers(s, k)
         eh, est = pymap.hash_kmers(s, k)

@@ -128,41 +128,57 @@ __global__ void kmer_hash_kernel(const uint8_t* __restrict__ seq /*normalised, p
   }
 }
 
-// The same for 9 <= K <= 16, the k-mer in two words and nothing byte by byte: the reverse complement is the
+// The same for 9 <= K <= 24, the k-mer in two or three words and nothing byte by byte: the reverse complement is the
 // complement of every byte -- A <-> T differ in bits 0, 2, 4, C <-> G in bit 2, and bit 1 tells the two pairs apart --
-// followed by a reversal of the 16 bytes and a shift; an N is a zero byte of word ^ 'NNNNNNNN'.
+// followed by a reversal of the bytes and a shift; an N is a zero byte of word ^ 'NNNNNNNN'.
 template <int K>
 __global__ void __launch_bounds__(256) kmer_hash_2w_kernel(const uint8_t* __restrict__ seq /*normalised, padded*/, int64_t nk, uint64_t* __restrict__ hash,
                                                            int8_t* __restrict__ strand) {
-  static_assert(K >= 9 && K <= 16, "two words");
-  constexpr uint64_t hi_mask = K == 16 ? ~0ull : ((~0ull) >> (64 - 8 * (K - 8)));
+  static_assert(K >= 9 && K <= 24, "two or three words");
+  constexpr int NWD = (K + 7) / 8;                       // words that hold the k-mer
+  constexpr int LASTB = K - 8 * (NWD - 1);               // bytes of the last one
+  constexpr uint64_t last_mask = LASTB == 8 ? ~0ull : ((~0ull) >> (64 - 8 * LASTB));
   constexpr uint64_t ones = 0x0101010101010101ULL;
-  constexpr int sh = 8 * (16 - K);
+  constexpr int sh = 8 * (8 * NWD - K);                  // bits the reversed words are shifted down by
   const uint64_t c1 = 0x87c37b91114253d5ULL, c2 = 0x4cf5ad432745937fULL;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nk; i += (int64_t)gridDim.x * blockDim.x) {
-    const uint64_t f0 = ld8(seq + i), f1 = ld8(seq + i + 8) & hi_mask;
-    const uint64_t n0 = f0 ^ (ones * 'N'), n1 = f1 ^ (ones * 'N');
-    const bool has_n = (((n0 - ones) & ~n0) | ((n1 - ones) & ~n1)) & (ones * 0x80);
+    uint64_t f[3] = {0, 0, 0};
+    uint64_t nbits = 0;
+#pragma unroll
+    for (int q = 0; q < NWD; ++q) {
+      f[q] = ld8(seq + i + 8 * q);
+      if (q == NWD - 1) f[q] &= last_mask;
+      const uint64_t x = f[q] ^ (ones * 'N');
+      nbits |= (x - ones) & ~x;
+    }
     uint64_t h = ~0ull;
     int8_t st = 0;
-    if (!has_n) {
-      // complement, reverse the 16 bytes, drop the 16 - K bytes that were past the k-mer
-      const uint64_t m0 = (~f0 >> 1) & ones, m1 = (~f1 >> 1) & ones;
-      const uint64_t q0 = f0 ^ (ones * 4) ^ (m0 * 0x11), q1 = f1 ^ (ones * 4) ^ (m1 * 0x11);
-      const uint64_t b0 = __builtin_bswap64(q1), b1 = __builtin_bswap64(q0);  // reversed: low word, high word
-      const uint64_t r0 = sh == 0 ? b0 : ((b0 >> sh) | (b1 << ((64 - sh) & 63))), r1 = sh == 0 ? b1 : (b1 >> sh);
+    if (!(nbits & (ones * 0x80))) {
+      // complement, reverse the bytes, drop the bytes that were past the k-mer
+      uint64_t b[3] = {0, 0, 0}, r[3] = {0, 0, 0};
+#pragma unroll
+      for (int q = 0; q < NWD; ++q) {
+        const uint64_t m = (~f[q] >> 1) & ones;
+        b[NWD - 1 - q] = __builtin_bswap64(f[q] ^ (ones * 4) ^ (m * 0x11));
+      }
+#pragma unroll
+      for (int q = 0; q < NWD; ++q) r[q] = sh == 0 ? b[q] : ((b[q] >> sh) | (q + 1 < NWD ? b[q + 1] << ((64 - sh) & 63) : 0ull));
       uint64_t hv[2];
 #pragma unroll
       for (int d = 0; d < 2; ++d) {
-        uint64_t k1 = d == 0 ? f0 : r0, k2 = d == 0 ? f1 : r1;
+        const uint64_t* w = d == 0 ? f : r;
         uint64_t h1 = 42u, h2 = 42u;
-        if (K == 16) {
+        if (K >= 16) {  // one whole block
+          uint64_t k1 = w[0], k2 = w[1];
           k1 *= c1; k1 = rotl64(k1, 31); k1 *= c2; h1 ^= k1;
           h1 = rotl64(h1, 27); h1 += h2; h1 = h1 * 5 + 0x52dce729;
           k2 *= c2; k2 = rotl64(k2, 33); k2 *= c1; h2 ^= k2;
           h2 = rotl64(h2, 31); h2 += h1; h2 = h2 * 5 + 0x38495ab5;
-        } else {
-          k2 *= c2; k2 = rotl64(k2, 33); k2 *= c1; h2 ^= k2;
+        }
+        constexpr int tail = K & 15;
+        if (tail) {
+          uint64_t k1 = K >= 16 ? w[2] : w[0], k2 = K >= 16 ? 0ull : w[1];
+          if (tail > 8) { k2 *= c2; k2 = rotl64(k2, 33); k2 *= c1; h2 ^= k2; }
           k1 *= c1; k1 = rotl64(k1, 31); k1 *= c2; h1 ^= k1;
         }
         h1 ^= (uint64_t)K; h2 ^= (uint64_t)K;
@@ -183,6 +199,7 @@ static void launch_kmer_hash(const uint8_t* d_norm, int64_t nk, int k, uint64_t*
   switch (k) {
 #define WFM_K2W(K) case K: hipLaunchKernelGGL(kmer_hash_2w_kernel<K>, dim3(blocks), dim3(256), 0, st, d_norm, nk, d_hash, d_strand); break;
     WFM_K2W(9) WFM_K2W(10) WFM_K2W(11) WFM_K2W(12) WFM_K2W(13) WFM_K2W(14) WFM_K2W(15) WFM_K2W(16)
+    WFM_K2W(17) WFM_K2W(18) WFM_K2W(19) WFM_K2W(20) WFM_K2W(21) WFM_K2W(22) WFM_K2W(23) WFM_K2W(24)
 #undef WFM_K2W
     default: hipLaunchKernelGGL(kmer_hash_kernel, dim3(blocks), dim3(256), 0, st, d_norm, nk, k, d_hash, d_strand);
   }

@@ -395,8 +395,12 @@ int run_tiled_phase(wfm_handle* h, wfm_seqset* S, const DevPen& dp, int scope, c
         }
         if (wb[(size_t)chunk - 1] <= cfg.threads * cfg.C) {
           // one tile per job-direction: whole waves, as many as the block's own widest range needs (two diagonals per lane)
-          for (int b = 0; b < chunk; ++b)
-            threads_b[(size_t)b] = std::min(cfg.threads, std::max(64, ((wb[(size_t)b] + cfg.C - 1) / cfg.C + 63) / 64 * 64));
+          static const bool fine = !(getenv("WFM_TILE_FINE") && atoi(getenv("WFM_TILE_FINE")) == 0);
+          for (int b = 0; b < chunk; ++b) {
+            const int wdt = fine ? wb[(size_t)b] : wb[(size_t)chunk - 1];
+            threads_b[(size_t)b] = fine ? std::min(cfg.threads, std::max(64, ((wdt + cfg.C - 1) / cfg.C + 63) / 64 * 64))
+                                        : std::min(cfg.threads, wdt <= 256 ? 128 : (wdt <= 512 ? 256 : cfg.threads));
+          }
           core_c = threads_b[(size_t)chunk - 1] * cfg.C;
         }
       }
@@ -558,8 +562,9 @@ int run_p2_phase(wfm_handle* h, wfm_seqset* S, const DevPen& dp, int scope, cons
     HIPCHK(h, hipEventRecord(h->ev0, h->stream));
     launch_tile_p2(S->d_seq, h->ring.p, h->tilejobs.p, h->tiletasks.p, (int)tasks.size(), threads_c, h->p2rows.p, h->stream);
     launch_p2_blockmax(h->ring.p, h->p2rows.p, h->p2jobs.p, h->p2bmax.p, h->p2max.p, (int)n, h->stream);
+    static const int p2_threads = getenv("WFM_P2_THREADS") ? atoi(getenv("WFM_P2_THREADS")) : 0;
     launch_p2_overlap(h->ring.p, h->p2rows.p, h->p2jobs.p, h->p2max.p, h->p2bmax.p, h->p2pbmax.p, h->bpres.p, (int)n,
-                      maxw2 <= 4096 ? 256 : (maxw2 <= 32768 ? 512 : 1024), (int)(maxw2 >> 6) + 1, dp, scope, h->stream);
+                      p2_threads > 0 ? p2_threads : (maxw2 <= 4096 ? 256 : (maxw2 <= 32768 ? 512 : 1024)), (int)(maxw2 >> 6) + 1, dp, scope, h->stream);
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipEventRecord(h->ev1, h->stream));
     got.resize(n);
