@@ -81,6 +81,12 @@ typedef struct {
   int32_t mode;                           /* WFM_MODE_*                      */
   int32_t pattern_begin_free, pattern_end_free;   /* ENDSFREE only */
   int32_t text_begin_free, text_end_free;
+  int32_t score_hint;                     /* END2END_BIWFA only; 0 = none.  A guess of an upper bound of the alignment's
+                                           * score (e.g. the cost of the end gaps the caller's padding implies plus a
+                                           * divergence allowance).  The wavefronts are then only computed where an
+                                           * alignment of at most that score can pass; a guess that turns out too small
+                                           * costs a second run without it, never a different result. */
+  int32_t pad_;
 } wfm_problem_t;
 
 typedef struct {

@@ -288,3 +288,41 @@ def test_leaf_that_ends_inside_a_long_gap(gpu, oracle):
     assert len(r.ops) == g["n_ops"] and hashlib.sha256(r.ops).hexdigest() == g["ops_sha"]
     rc, ops, sc, _ = oracle.align_biwfa(p, t)
     assert rc == 0 and ops == r.ops
+
+
+def _padded_records(seed, n, qlen, pad, rate):
+    """records as the align driver hands them over: a query against its target window, the window padded on both sides
+    (pattern = target, text = query: wflign.cpp:136-148)"""
+    rng = random.Random(seed)
+    out = []
+    for i in range(n):
+        tgt = synth.random_dna(seed * 100 + i, qlen + rng.randrange(0, 2 * pad + 1))
+        a = rng.randrange(0, len(tgt) - qlen + 1)
+        q = synth.mutate(tgt[a:a + qlen], rate, seed * 57 + i)
+        if rng.random() < 0.1:  # a structural difference in the middle: the score leaves every sensible guess behind
+            cut = rng.randrange(200, 900)
+            q = q[:qlen // 2] + q[qlen // 2 + cut:]
+        out.append((tgt, q))
+    return out
+
+
+def test_score_hints_cut_the_wavefronts_not_the_result(gpu, oracle):
+    """wfm_problem_t::score_hint: an upper bound of the score lets the kernels skip every diagonal from which the end is
+    out of reach (children of a BiWFA split always carry their exact bound).  A generous hint, a tight one, one that is
+    too small (the record runs again without it) and none at all must give the oracle's CIGAR -- and fewer cells."""
+    items = _padded_records(3, 48, 6000, 400, 0.004) + _padded_records(4, 16, 12000, 1000, 0.02)
+    exp = [oracle.align_biwfa(p, t) for p, t in items]
+    assert all(e[0] == 0 for e in exp)
+    E = capi.WFM_MODE_END2END_BIWFA
+    plain = gpu.align([(p, t, E, 0, 0, 0, 0, 0) for p, t in items])
+    cells = {}
+    for name, hint in (("generous", lambda sc: 2 * sc + 500), ("tight", lambda sc: sc + 60), ("exact", lambda sc: sc), ("small", lambda sc: max(1, sc // 2)),
+                       ("tiny", lambda sc: 1)):
+        res = gpu.align([(p, t, E, 0, 0, 0, 0, hint(e[2])) for (p, t), e in zip(items, exp)])
+        bad = [i for i, (r, e) in enumerate(zip(res, exp)) if r.status != 0 or r.score != e[2] or r.ops != e[1]]
+        assert not bad, (name, bad[:5])
+        cells[name] = sum(r.cells for r in res)
+    assert all(r.status == 0 and r.ops == e[1] for r, e in zip(plain, exp))
+    c0 = sum(r.cells for r in plain)
+    assert cells["exact"] <= cells["tight"] < 0.95 * c0 and cells["generous"] <= c0, (cells, c0)
+    assert cells["small"] >= c0  # every record ran again without its hint

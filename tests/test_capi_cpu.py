@@ -43,7 +43,7 @@ def test_struct_sizes_match_header():
     assert C.sizeof(capi.Penalties) == 20
     assert C.sizeof(capi.Result) == 32
     assert C.sizeof(capi.Minmer) == 32  # skch::MinmerInfo, base_types.hpp:28-35
-    assert C.sizeof(capi.Problem) == 48
+    assert C.sizeof(capi.Problem) == 56
 
 
 def test_product_never_imports_oracle():

@@ -40,7 +40,8 @@ class Problem(C.Structure):
                 ("text", C.c_char_p), ("tlen", C.c_int32),
                 ("mode", C.c_int32),
                 ("pattern_begin_free", C.c_int32), ("pattern_end_free", C.c_int32),
-                ("text_begin_free", C.c_int32), ("text_end_free", C.c_int32)]
+                ("text_begin_free", C.c_int32), ("text_end_free", C.c_int32),
+                ("score_hint", C.c_int32), ("pad_", C.c_int32)]
 
 
 class Result(C.Structure):
@@ -164,7 +165,7 @@ class AlignResult:
 
 
 def _make_problems(items):
-    """items: iterable of (pattern, text) or (pattern, text, mode, pbf, pef, tbf, tef)."""
+    """items: iterable of (pattern, text) or (pattern, text, mode, pbf, pef, tbf, tef[, score_hint])."""
     items = list(items)
     arr = (Problem * max(len(items), 1))()
     keep = []
@@ -178,6 +179,8 @@ def _make_problems(items):
             if len(it) > 3:
                 (arr[i].pattern_begin_free, arr[i].pattern_end_free,
                  arr[i].text_begin_free, arr[i].text_end_free) = it[3:7]
+                if len(it) > 7:
+                    arr[i].score_hint = it[7]
         else:
             arr[i].mode = WFM_MODE_END2END_BIWFA
     return arr, keep, len(items)

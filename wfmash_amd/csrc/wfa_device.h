@@ -21,6 +21,7 @@ enum { BT_I1_EXT = 8, BT_I2_EXT = 16, BT_D1_EXT = 32, BT_D2_EXT = 64 };
 constexpr int WFM_DEV_UNREACHABLE = -300;
 constexpr int WFM_DEV_OVERFLOW = -2;  // base job exceeded its score budget (smax)
 constexpr int WFM_DEV_BAND = -4;      // bialign job ran out of its diagonal band (BpJob::band)
+constexpr int SUB_NONE = 1 << 29;     // "no upper bound of the score is known" (BpJob::sub, TileJob::sub, P2Job::sub)
 constexpr int WFM_DEV_P2_MORE = -5;   // phase 2 did not end within the P2K rows computed ahead: the step kernel takes the job
 
 struct DevPen { int x, o1, e1, o2, e2; };
@@ -42,6 +43,8 @@ struct BpJob {
   // reverse at resume_sr (= resume_s or resume_s - 1), phase 1 is over; -1: both directions resume at resume_s
   int32_t resume_sr;
   int32_t last_fwd;                    // with resume_sr >= 0: 1 if the forward step was the last one taken
+  int32_t sub;                         // upper bound of the job's score (SUB_NONE: none): rows only hold |k - (tl - pl)| <= sub - s
+  int32_t pad_;
 };
 
 // ---- time-tiled phase 1 (wfa_tile_kernel) ----
@@ -69,6 +72,8 @@ struct TileJob {
   // job's P2 rows instead of an output snapshot
   int64_t p2_off;
   int32_t w2, koff2;
+  int32_t sub;                         // as BpJob::sub
+  int32_t pad2_;
 };
 
 // ---- phase 2 (overlap detection) without a step-by-step kernel ----
@@ -94,6 +99,7 @@ struct P2Job {
   int32_t w2, koff2;                   // P2 geometry: column = k + koff2
   int32_t pl, tl;
   int32_t sf, sr, last_fwd;            // state at the meeting point
+  int32_t sub, pad_;                   // as BpJob::sub
   int32_t nblk;                        // 64-diagonal blocks of a row: block of diagonal k = (k + koff2) >> 6
   int64_t bm_off;                      // int32 element offset of the job's block maxima [dir][P2ROWS][comp][nblk]
 };

@@ -65,6 +65,7 @@ struct ProbMeta {
   int64_t p_fwd, t_fwd, p_rev, t_rev;  // offsets into device sequence buffer
   int32_t plen, tlen;
   int32_t mode, pbf, pef, tbf, tef;
+  int32_t hint;     // the caller's guess of an upper bound of the score (0: none)
   int64_t rle_off;  // start of this problem's RLE slot range
 };
 
@@ -76,6 +77,8 @@ struct Node {
   int32_t smax;       // base jobs: score budget (0 = derive)
   int32_t endsfree;
   int32_t noband;     // bialign jobs: 1 = ran out of a narrow ring once, gets the full one now
+  int32_t sub;        // bialign jobs: upper bound of the score (SUB_NONE: none); the wavefronts are cut to what can stay under it
+  int32_t hinted;     // the bound is the caller's guess (a root): the job is run again without it if the guess was too small
 };
 
 }  // namespace
@@ -131,6 +134,15 @@ namespace {
 inline int gapcost(const wfm_penalties_t& p, int L) {
   if (L <= 0) return 0;
   return std::min(p.o1 + p.e1 * L, p.o2 + p.e2 * L);
+}
+
+// Row ranges with a bound of the score (wfa_kernels.hip: Rng): the kernels' arithmetic, for tile counts and cell counts
+inline int h_rng_lo(int pl, int tl, int sub, int s) { return std::max(std::max(-pl, -s), (tl - pl) - sub + s); }
+inline int h_rng_hi(int pl, int tl, int sub, int s) { return std::min(std::min(tl, s), (tl - pl) + sub - s); }
+inline int64_t h_row_cells(int pl, int tl, int sub, int s) { return std::max(0, h_rng_hi(pl, tl, sub, s) - h_rng_lo(pl, tl, sub, s) + 1); }
+inline void h_rng_block(int pl, int tl, int sub, int s_from, int s_to, int* L, int* R) {
+  *L = std::max(std::max(-pl, -s_to), (tl - pl) - sub + s_from);
+  *R = std::min(std::min(tl, s_to), (tl - pl) + sub - s_from);
 }
 
 int validate_pen(const wfm_penalties_t* pen, int* scope) {
@@ -324,6 +336,7 @@ int run_tiled_phase(wfm_handle* h, wfm_seqset* S, const DevPen& dp, int scope, c
     t.ring_in = j.ring_off; t.ring_out = ring2[i];
     t.pl = j.pl; t.tl = j.tl; t.comp_begin = j.comp_begin; t.comp_end = j.comp_end;
     t.width = j.width; t.koff = j.koff; t.s0 = 0; t.active = 1; t.fmax = 0; t.rmax = 0; t.nblocks = 0; t.mode = 0; t.tf = 0; t.tr = 0; t.last_fwd = 0; t.pad_ = 0;
+    t.p2_off = 0; t.w2 = 0; t.koff2 = 0; t.sub = j.sub; t.pad2_ = 0;
   }
   if (h->tilejobs.ensure(n) || h->tilemak.ensure(n * 2 * (size_t)std::max(T, 2))) { h->err = "out of device memory (tiles)"; return WFM_E_NOMEM; }
   size_t n_active = 0;
@@ -375,6 +388,15 @@ int run_tiled_phase(wfm_handle* h, wfm_seqset* S, const DevPen& dp, int scope, c
         if (active[i] && band > 0 && tj[i].s0 + chunk * T + 2 > band) {
           active[i] = 0; tj[i].active = 0; tj[i].mode = 3; out_of_band = true; --n_active;
         }
+        // a job whose score bound is a guess: the two directions meet near half the score, so one that is still going
+        // well past half the bound has a score above it -- it leaves here as well and is run again without the bound
+        if (active[i] && tj[i].sub != SUB_NONE) {
+          int L, R;
+          h_rng_block(tj[i].pl, tj[i].tl, tj[i].sub, tj[i].s0, tj[i].s0 + T, &L, &R);
+          if (2 * tj[i].s0 > tj[i].sub + 128 || R < L) {  // (or nothing is left within the bound)
+            active[i] = 0; tj[i].active = 0; tj[i].mode = 3; out_of_band = true; --n_active;
+          }
+        }
       }
       if (out_of_band) HIPCHK(h, hipMemcpyAsync(h->tilejobs.p, tj.data(), n * sizeof(TileJob), hipMemcpyHostToDevice, h->stream));
       if (!n_active) break;
@@ -388,9 +410,14 @@ int run_tiled_phase(wfm_handle* h, wfm_seqset* S, const DevPen& dp, int scope, c
         std::vector<int> wb((size_t)chunk, 0);  // widest range per block
         for (size_t i = 0; i < n; ++i) {
           if (!active[i]) continue;
+          // a job may run the same block twice (the block in which its wavefronts met, up to the meeting point), and with a
+          // score bound the ranges shrink again towards the end: block b of the chunk needs the widest range up to b
+          int wmax = 0;
           for (int b = 0; b < chunk; ++b) {
-            const int reach = tj[i].s0 + (b + 1) * T;
-            wb[(size_t)b] = std::max(wb[(size_t)b], std::min(tj[i].tl, reach) - std::max(-tj[i].pl, -reach) + 1);
+            int L, R;
+            h_rng_block(tj[i].pl, tj[i].tl, tj[i].sub, tj[i].s0 + b * T, tj[i].s0 + (b + 1) * T, &L, &R);
+            wmax = std::max(wmax, R - L + 1);
+            wb[(size_t)b] = std::max(wb[(size_t)b], wmax);
           }
         }
         if (wb[(size_t)chunk - 1] <= cfg.threads * cfg.C) {
@@ -406,13 +433,17 @@ int run_tiled_phase(wfm_handle* h, wfm_seqset* S, const DevPen& dp, int scope, c
       }
       for (size_t i = 0; i < n; ++i) {
         if (!active[i]) continue;
-        const int reach = tj[i].s0 + chunk * T;
-        const int L = std::max(-tj[i].pl, -reach), R = std::min(tj[i].tl, reach);
         const int core = core_c;
-        const int ntiles = (R - L + core) / core;
+        int ntiles = 0;  // of the widest block of the chunk
+        for (int b = 0; b < chunk; ++b) {
+          int L, R;
+          h_rng_block(tj[i].pl, tj[i].tl, tj[i].sub, tj[i].s0 + b * T, tj[i].s0 + (b + 1) * T, &L, &R);
+          if (R >= L) ntiles = std::max(ntiles, (R - L + core) / core);
+        }
         for (int d = 0; d < 2; ++d)
           for (int t = 0; t < ntiles; ++t) tasks.push_back(TileTask{(int32_t)i, d, t, core});  // (tile index, tile width): the kernel places it
       }
+      if (tasks.empty()) { h->err = "tile phase: active jobs without a tile"; return WFM_E_HIP; }
       if (h->tiletasks.ensure(tasks.size())) { h->err = "out of device memory (tile tasks)"; return WFM_E_NOMEM; }
       HIPCHK(h, hipMemcpyAsync(h->tiletasks.p, tasks.data(), tasks.size() * sizeof(TileTask), hipMemcpyHostToDevice, h->stream));
       for (int b = 0; b < chunk; ++b) {
@@ -448,7 +479,7 @@ int run_tiled_phase(wfm_handle* h, wfm_seqset* S, const DevPen& dp, int scope, c
             const int steps = last_exact ? (d == 0 ? got[i].tf : got[i].tr) : T;
             for (int t = 1; t <= steps; ++t) {
               const int sc = base + t;
-              tile_cells += (uint64_t)(std::min(tj[i].tl, sc) - std::max(-tj[i].pl, -sc) + 1);
+              tile_cells += (uint64_t)h_row_cells(tj[i].pl, tj[i].tl, tj[i].sub, sc);
             }
           }
         }
@@ -461,14 +492,12 @@ int run_tiled_phase(wfm_handle* h, wfm_seqset* S, const DevPen& dp, int scope, c
   }
   // cells that went into the result: both directions up to where the tile phase leaves the job (the full block in which
   // the wavefronts met was computed as well, and then again up to the meeting point: tile_cells counts it, this does not)
-  auto upto = [](int64_t pl, int64_t tl, int64_t sc) {  // sum over t = 1..sc of the row width min(tl,t) + min(pl,t) + 1
-    auto f = [](int64_t L, int64_t q) { return q <= L ? q * (q + 1) / 2 : L * (L + 1) / 2 + (q - L) * L; };
-    return (uint64_t)(f(tl, sc) + f(pl, sc) + sc);
-  };
   for (size_t i = 0; i < n; ++i) {
     const int sf_end = tj[i].mode == 2 ? tj[i].s0 + tj[i].tf : tj[i].s0, sr_end = tj[i].mode == 2 ? tj[i].s0 + tj[i].tr : tj[i].s0;
-    h->stats.cells_tile_unique += upto(tj[i].pl, tj[i].tl, sf_end) - upto(tj[i].pl, tj[i].tl, s_begin[i]) +
-                                  upto(tj[i].pl, tj[i].tl, sr_end) - upto(tj[i].pl, tj[i].tl, s_begin[i]);
+    uint64_t u = 0;
+    for (int sc = s_begin[i] + 1; sc <= std::max(sf_end, sr_end); ++sc)
+      u += (uint64_t)h_row_cells(tj[i].pl, tj[i].tl, tj[i].sub, sc) * (uint64_t)((sc <= sf_end) + (sc <= sr_end));
+    h->stats.cells_tile_unique += u;
   }
   for (size_t i = 0; i < n; ++i) {
     BpJob& j = jobs[(size_t)tiled[i]];
@@ -509,7 +538,9 @@ int run_p2_phase(wfm_handle* h, wfm_seqset* S, const DevPen& dp, int scope, cons
     for (; i < cand.size(); ++i) {
       const BpJob& j = jobs[(size_t)cand[i]];
       const int reach = std::max(j.resume_s, j.resume_sr) + P2K;
-      const int L = std::max(-j.pl, -reach), R = std::min(j.tl, reach);
+      int L, R;  // every diagonal a row of the window can hold: the snapshot's rows (26 back) and the rows computed ahead
+      h_rng_block(j.pl, j.tl, j.sub, std::max(0, std::min(j.resume_s, j.resume_sr) - 27), reach, &L, &R);
+      if (R < L) { L = 0; R = 0; }
       const int koff2 = ((-L + 4) + 3) & ~3;                       // column of diagonal 0: a multiple of 4, >= 4 columns of margin
       const size_t w2 = ((size_t)(R + koff2 + 8) + 3) & ~(size_t)3;
       const size_t nblk = (w2 >> 6) + 1;
@@ -522,10 +553,10 @@ int run_p2_phase(wfm_handle* h, wfm_seqset* S, const DevPen& dp, int scope, cons
       t.pl = j.pl; t.tl = j.tl; t.comp_begin = j.comp_begin; t.comp_end = j.comp_end;
       t.width = j.width; t.koff = j.koff; t.s0 = 0; t.active = 1; t.fmax = 0; t.rmax = 0; t.nblocks = 0;
       t.mode = 4; t.tf = j.resume_s; t.tr = j.resume_sr; t.last_fwd = j.last_fwd; t.pad_ = 0;
-      t.p2_off = (int64_t)elems; t.w2 = (int32_t)w2; t.koff2 = koff2;
+      t.p2_off = (int64_t)elems; t.w2 = (int32_t)w2; t.koff2 = koff2; t.sub = j.sub;
       P2Job q{};
       q.ring_in = j.ring_off; q.p2_off = (int64_t)elems; q.width = j.width; q.koff = j.koff; q.w2 = (int32_t)w2; q.koff2 = koff2;
-      q.pl = j.pl; q.tl = j.tl; q.sf = j.resume_s; q.sr = j.resume_sr; q.last_fwd = j.last_fwd;
+      q.pl = j.pl; q.tl = j.tl; q.sf = j.resume_s; q.sr = j.resume_sr; q.last_fwd = j.last_fwd; q.sub = j.sub;
       q.nblk = (int32_t)nblk; q.bm_off = (int64_t)bm_elems;
       bm_elems += need_bm;
       elems += need;
@@ -536,10 +567,12 @@ int run_p2_phase(wfm_handle* h, wfm_seqset* S, const DevPen& dp, int scope, cons
     int threads_c = cfg.threads, core_c = core;
     {
       int widest = 0;
-      for (const TileJob& t : tj) {
-        const int rd = std::max(t.tf, t.tr) + P2K;
-        widest = std::max(widest, std::min(t.tl, rd) - std::max(-t.pl, -rd) + 1);
-      }
+      for (const TileJob& t : tj)
+        for (int d = 0; d < 2; ++d) {
+          int L, R;
+          h_rng_block(t.pl, t.tl, t.sub, d == 0 ? t.tf : t.tr, (d == 0 ? t.tf : t.tr) + P2K, &L, &R);
+          widest = std::max(widest, R - L + 1);
+        }
       if (widest <= cfg.threads * 2) {
         threads_c = std::min(cfg.threads, std::max(64, ((widest + 1) / 2 + 63) / 64 * 64));
         core_c = threads_c * 2;
@@ -547,9 +580,9 @@ int run_p2_phase(wfm_handle* h, wfm_seqset* S, const DevPen& dp, int scope, cons
     }
     for (size_t jn = 0; jn < n; ++jn)
       for (int d = 0; d < 2; ++d) {
-        const int rd = (d == 0 ? tj[jn].tf : tj[jn].tr) + P2K;
-        const int Ld = std::max(-tj[jn].pl, -rd), Rd = std::min(tj[jn].tl, rd);
-        const int ntiles = (Rd - Ld + core_c) / core_c;
+        int Ld, Rd;
+        h_rng_block(tj[jn].pl, tj[jn].tl, tj[jn].sub, d == 0 ? tj[jn].tf : tj[jn].tr, (d == 0 ? tj[jn].tf : tj[jn].tr) + P2K, &Ld, &Rd);
+        const int ntiles = Rd >= Ld ? (Rd - Ld + core_c) / core_c : 0;
         for (int t2 = 0; t2 < ntiles; ++t2) tasks.push_back(TileTask{(int32_t)jn, d, t2, core_c});
       }
     if (h->p2rows.ensure(elems + 16) || h->p2max.ensure(n * 2 * P2ROWS * 5) || h->p2bmax.ensure(bm_elems + 16) || h->p2pbmax.ensure(bm_elems + 16) ||
@@ -621,6 +654,9 @@ int align_resident_impl(wfm_handle* h, const wfm_penalties_t* pen, wfm_seqset* S
     Node nd{};
     nd.prob = (int32_t)i; nd.pb = 0; nd.pl = pm.plen; nd.tb = 0; nd.tl = pm.tlen;
     nd.cb = C_M; nd.ce = C_M; nd.score_rem = INT_MAX; nd.endsfree = 0;
+    nd.sub = SUB_NONE; nd.hinted = 0;
+    static const bool use_hints = !(getenv("WFM_SCORE_HINT") && atoi(getenv("WFM_SCORE_HINT")) == 0);
+    if (use_hints && pm.hint > 0 && pm.mode == WFM_MODE_END2END_BIWFA) { nd.sub = pm.hint; nd.hinted = 1; }
     const int64_t bound = (int64_t)gapcost(*pen, pm.plen) + gapcost(*pen, pm.tlen) + 8;
     if (pm.mode == WFM_MODE_ENDSFREE) {
       nd.endsfree = 1;
@@ -643,7 +679,7 @@ int align_resident_impl(wfm_handle* h, const wfm_penalties_t* pen, wfm_seqset* S
   std::vector<int64_t> ring2;
   const TileCfg tcfg = tile_cfg(*pen, scope);
   uint64_t tile_cells_level = 0;
-  uint64_t band_retries = 0, band_jobs = 0, roots_banded = 0, roots_out = 0;
+  uint64_t band_retries = 0, band_jobs = 0, roots_banded = 0, roots_out = 0, hint_retries = 0, hinted_roots = 0;
   bool roots_off = false;
   std::vector<int32_t> node_of;
   std::vector<BpResult> res;
@@ -711,6 +747,7 @@ int align_resident_impl(wfm_handle* h, const wfm_penalties_t* pen, wfm_seqset* S
         j.koff = koff;
         j.resume_s = -1; j.resume_sr = -1; j.last_fwd = 0; j.fmax0 = 0; j.rmax0 = 0;
         j.band = band;
+        j.sub = nd.sub; j.pad_ = 0;
         band_jobs += band > 0;
         if (tile_it) { tiled.push_back((int)jobs.size()); ring2.push_back((int64_t)(ring_elems + need / 2)); }
         node_of.push_back((int32_t)i);
@@ -797,10 +834,13 @@ int align_resident_impl(wfm_handle* h, const wfm_penalties_t* pen, wfm_seqset* S
           prob_cells[nd.prob] += r.cells;
           h->stats.cells_bp += r.cells;
           if (nd.score_rem == INT_MAX && jobs[q].band > 0) { ++roots_banded; roots_out += r.status == WFM_DEV_BAND; }
-          if (r.status == WFM_DEV_BAND) {  // ran out of its narrow ring: once more, at the end of this level, on a full one
-            Node again = nd; again.noband = 1;
+          if (r.status == WFM_DEV_BAND || (nd.hinted && (r.status < 0 || (r.status == 0 && r.score > nd.sub)))) {
+            // ran out of its narrow ring, or past the caller's guess of its score: once more, at the end of this level, on
+            // a full ring and without the guess
+            Node again = nd; again.noband = 1; again.sub = SUB_NONE; again.hinted = 0;
             bp_nodes.push_back(again);
             ++band_retries;
+            hint_retries += nd.hinted;
             continue;
           }
           if (r.status == 1) {  // end reached at score 0 -> base aligner
@@ -817,6 +857,13 @@ int align_resident_impl(wfm_handle* h, const wfm_penalties_t* pen, wfm_seqset* S
             if (getenv("WFM_DEBUG") && atoi(getenv("WFM_DEBUG")) > 1) fprintf(stderr, "[wfm] problem %d level %u: job pl %d tl %d cb %d ce %d rem %d -> bp v %d h %d score %d = %d + %d comp %d\n", nd.prob, level, nd.pl, nd.tl, nd.cb, nd.ce, nd.score_rem, bp_v, bp_h, r.score, r.score_fwd, r.score_rev, r.comp);
             Node a{}, b{};
             a.prob = nd.prob; a.pb = nd.pb; a.pl = bp_v; a.tb = nd.tb; a.tl = bp_h;
+            // what a child can cost: the score its parent found for it, plus the opening of a gap it begins or ends in
+            // (counted on the other side of the breakpoint)
+            static const int slack_env = getenv("WFM_SUB_SLACK") ? atoi(getenv("WFM_SUB_SLACK")) : -1;  // tests: < 0 default, >= 2^28 none
+            const int slack = slack_env >= 0 ? slack_env : 2 * std::max(pen->o1, pen->o2) + 8;
+            a.sub = (int)std::min<int64_t>((int64_t)r.score_fwd + slack, SUB_NONE);
+            b.sub = (int)std::min<int64_t>((int64_t)r.score_rev + slack, SUB_NONE);
+            a.hinted = 0; b.hinted = 0;
             a.cb = nd.cb; a.ce = r.comp; a.score_rem = r.score_fwd;
             b.prob = nd.prob; b.pb = nd.pb + bp_v; b.pl = nd.pl - bp_v; b.tb = nd.tb + bp_h; b.tl = nd.tl - bp_h;
             b.cb = r.comp; b.ce = nd.ce; b.score_rem = r.score_rev;
@@ -857,6 +904,8 @@ int align_resident_impl(wfm_handle* h, const wfm_penalties_t* pen, wfm_seqset* S
     fprintf(stderr, "[wfm] p2 overlap (cumulative): tests %llu, with candidates %llu, blocks looked at %llu, passing %llu, diagonals reaching %llu, o1 loads %llu, hits %llu\n",
             c[0], c[1], c[2], c[3], c[4], c[5], c[6]);
   }
+  if (getenv("WFM_DEBUG") && hint_retries) fprintf(stderr, "[wfm] score hints: %llu roots ran past their hint and were run again without it\n", (unsigned long long)hint_retries);
+  (void)hinted_roots;
   if (getenv("WFM_DEBUG") && band_jobs) fprintf(stderr, "[wfm] narrow rings: %llu jobs, %llu ran out of their band and were run again on full rings\n", (unsigned long long)band_jobs, (unsigned long long)band_retries);
   const auto t_levels = std::chrono::steady_clock::now();
 
@@ -1035,6 +1084,7 @@ int wfm_upload_sequences(wfm_handle_t* h, const wfm_problem_t* problems, size_t 
     }
     ProbMeta& m = S->meta[i];
     m.plen = p.plen; m.tlen = p.tlen; m.mode = p.mode;
+    m.hint = (p.mode == WFM_MODE_END2END_BIWFA && p.score_hint > 0) ? p.score_hint : 0;
     m.pbf = std::min(std::max(p.pattern_begin_free, 0), p.plen); m.pef = std::min(std::max(p.pattern_end_free, 0), p.plen);
     m.tbf = std::min(std::max(p.text_begin_free, 0), p.tlen);    m.tef = std::min(std::max(p.text_end_free, 0), p.tlen);
     if (p.mode != WFM_MODE_ENDSFREE) { m.pbf = m.pef = m.tbf = m.tef = 0; }

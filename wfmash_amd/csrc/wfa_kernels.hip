@@ -195,12 +195,33 @@ __device__ __forceinline__ int imax3(int a, int b, int c) { return max(a, max(b,
 // ---------------------------------------------------------------------------
 // BiWFA breakpoint kernel
 // ---------------------------------------------------------------------------
+// Row ranges in closed form.  Score s reaches the diagonals [-s, s] (every change of diagonal costs at least e2 = 1), clipped to
+// the problem -- and, when an upper bound `sub` of the problem's score is known (a BiWFA child is handed its score by its
+// parent; a root may come with a hint), only the diagonals from which the end diagonal kinv = tl - pl is still within
+// reach: |k - kinv| <= sub - s.  A cell outside cannot lie on an alignment of score <= sub, and no cell inside depends on one
+// outside (a predecessor is one diagonal away at most and at least e2 cheaper), so the cells inside keep their exact
+// values and every breakpoint of score <= sub is found where the reference finds it: the phase-1 trigger (the running
+// maxima of the antidiagonals) can only fire LATER without the cells outside, never after a pair of cells of a real
+// overlap exists, and phase 2 tests the rows that triggered.  For a record with 1 kb end gaps this removes half the cells.
+struct Rng { int pl, tl, kb_lo, kb_hi; };  // kb_lo = kinv - sub, kb_hi = kinv + sub
+__device__ __forceinline__ Rng make_rng(int pl, int tl, int sub) { Rng r; r.pl = pl; r.tl = tl; r.kb_lo = (tl - pl) - sub; r.kb_hi = (tl - pl) + sub; return r; }
+__device__ __forceinline__ int rng_lo(const Rng& r, int s) { return max(max(-r.pl, -s), r.kb_lo + s); }
+__device__ __forceinline__ int rng_hi(const Rng& r, int s) { return min(min(r.tl, s), r.kb_hi - s); }
+// The diagonals a tile pass over the scores (s_from, s_to] has to hold: every bound at its loosest score of the block -- and
+// the score bound at s_from itself, one diagonal beyond the first new row's edge: that row's edge cell takes a gap from the
+// diagonal next to it, which is inside the (wider) older rows.
+__device__ __forceinline__ void rng_block(const Rng& r, int s_from, int s_to, int& L, int& R) {
+  L = max(max(-r.pl, -s_to), r.kb_lo + s_from);
+  R = min(min(r.tl, s_to), r.kb_hi - s_from);
+}
+
 struct BpCtx {
   const uint8_t* P[2];
   const uint8_t* T[2];
   int32_t* ring;  // job ring base, already offset so that [row*width + k] works with +pl+1 applied
   int64_t width;
   int pl, tl, koff;
+  int kb_lo, kb_hi;  // (tl - pl) -+ the job's score bound
   DevPen pen;
 };
 
@@ -320,8 +341,8 @@ __device__ __forceinline__ int bp_compute_row(const BpCtx& c, int dir, int s, in
   ROW_RANGE(mx, 0, 0) ROW_RANGE(mo1, -1, 1) ROW_RANGE(mo2, -1, 1) ROW_RANGE(i1, -1, 1) ROW_RANGE(i2, -1, 1)
 #undef ROW_RANGE
   if (d1.span == 0u && d1.lo == INT32_MIN / 2) all_live = false;
-  lo = max(lo, -c.pl);
-  hi = min(hi, c.tl);
+  lo = max(max(lo, -c.pl), c.kb_lo + s);  // and only what can still reach the end diagonal within the score bound (see Rng)
+  hi = min(min(hi, c.tl), c.kb_hi - s);
   const bool valid = (lo <= hi);
   if (threadIdx.x == 0) {
     s_lo[dir][s & RMASK] = valid ? lo : 1;
@@ -553,6 +574,7 @@ __global__ __launch_bounds__(1024) void wfa_bp_kernel(const uint8_t* __restrict_
   c.koff = J.koff;  // columns start at 4: chunk 0 is never touched, so k0-1 loads stay inside the row
   c.ring = ring_arena + J.ring_off + c.koff;
   c.pl = J.pl; c.tl = J.tl;
+  c.kb_lo = (J.tl - J.pl) - J.sub; c.kb_hi = (J.tl - J.pl) + J.sub;
   c.pen = pen;
   const int tid = threadIdx.x;
   const int A = J.pl + J.tl - 1;  // max_antidiagonal
@@ -569,7 +591,7 @@ __global__ __launch_bounds__(1024) void wfa_bp_kernel(const uint8_t* __restrict_
   if (J.resume_s >= 0) {
     if (tid < 2 * RING) {
       const int d = tid / RING, sc = (d == 0 ? rs_f : rs_r) - (tid % RING);
-      if (sc >= 0) { s_lo[d][sc & RMASK] = max(-J.pl, -sc); s_hi[d][sc & RMASK] = min(J.tl, sc); }
+      if (sc >= 0) { const Rng RG = make_rng(J.pl, J.tl, J.sub); s_lo[d][sc & RMASK] = rng_lo(RG, sc); s_hi[d][sc & RMASK] = rng_hi(RG, sc); }
     }
     if (tid == 0) { s_mak[0][0] = J.fmax0; s_mak[0][1] = J.rmax0; s_bp[6] = 0; s_bp[7] = 0; }
   } else if (tid < 128) {  // wave 0: forward, wave 1: reverse
@@ -649,7 +671,12 @@ __global__ __launch_bounds__(1024) void wfa_bp_kernel(const uint8_t* __restrict_
   }
 
   // ---- phase 2: overlap detection (wavefront_bialign_find_breakpoint, 2nd loop) ----
-  int best = INT32_MAX;
+  // With a bound of the job's score the loop starts as if a breakpoint of score bound + 1 were in hand: pairs that cannot do
+  // better are never looked at, and the loop ends where none can follow.  The bound of a child is exact, so its breakpoint
+  // is below it; a root whose guess was too small ends here without one and is run again (WFM_DEV_BAND).
+  const int best0 = J.sub < SUB_NONE ? J.sub + 1 : INT32_MAX;
+  int best = best0;
+  if (tid == 0) s_bp[7] = 0;  // a real breakpoint has been taken
   const long long t_mid = wall_clock64();
 #ifdef WFM_PROFILE_SECTIONS
   if (tid == 0 && blockIdx.x == 0) { for (int q = 0; q < 6; ++q) g_sec[q] = sec[q]; g_sec[6] = sf + sr; }
@@ -707,6 +734,7 @@ __global__ __launch_bounds__(1024) void wfa_bp_kernel(const uint8_t* __restrict_
               if (d0 == 0) { s_bp[1] = s0; s_bp[2] = si; s_bp[3] = k0; s_bp[4] = o0; }
               else         { s_bp[1] = si; s_bp[2] = s0; s_bp[3] = k1; s_bp[4] = o1; }
               s_bp[5] = cc;
+              s_bp[7] = 1;
             }
           }
           s_bp[6] = b;
@@ -734,10 +762,12 @@ __global__ __launch_bounds__(1024) void wfa_bp_kernel(const uint8_t* __restrict_
       if (d0 == 1 && (int64_t)sf + sr > max_steps && best == INT32_MAX) { status = WFM_DEV_UNREACHABLE; break; }
     }
   }
+  __syncthreads();
   if (tid == 0) {
     BpResult r;
     r.status = status;
     if (status == 0 && best == INT32_MAX) r.status = WFM_DEV_UNREACHABLE;
+    if (status == 0 && best0 != INT32_MAX && !s_bp[7]) r.status = WFM_DEV_BAND;  // nothing within the bound
     if (status == WFM_DEV_BAND) r.status = WFM_DEV_BAND;  // a breakpoint found so far may not be the best one
     r.score = best; r.score_fwd = s_bp[1]; r.score_rev = s_bp[2]; r.k_fwd = s_bp[3]; r.off_fwd = s_bp[4]; r.comp = s_bp[5];
     r.steps = sf + sr;
@@ -1064,8 +1094,7 @@ __global__ __launch_bounds__(256) void rle_compact_kernel(const uint32_t* __rest
 // ---------------------------------------------------------------------------
 // unconditional LDS read, range applied by select (every local column k-1..k+1 is inside the tile row)
 __device__ __forceinline__ int sel_rng(int v, int k, int lo, int hi) { return (k >= lo && k <= hi) ? v : WF_NULL; }
-__device__ __forceinline__ int rng_lo(int pl, int s) { return max(-pl, -s); }
-__device__ __forceinline__ int rng_hi(int tl, int s) { return min(tl, s); }
+
 
 __global__ void wfa_tile_init_kernel(const uint8_t* __restrict__ seq, int32_t* __restrict__ ring_arena,
                                      const TileJob* __restrict__ jobs, int32_t* __restrict__ mak0, int njobs) {
@@ -1079,6 +1108,7 @@ __global__ void wfa_tile_init_kernel(const uint8_t* __restrict__ seq, int32_t* _
   c.width = J.width; c.koff = J.koff;
   c.ring = ring_arena + J.ring_in + c.koff;
   c.pl = J.pl; c.tl = J.tl;
+  c.kb_lo = -SUB_NONE; c.kb_hi = SUB_NONE;  // rows 0: a handful of cells
   int mak = 0;
   const int end = bp_init_row0(c, d, d == 0 ? J.comp_begin : J.comp_end, d == 0 ? J.comp_end : J.comp_begin, mak);
   if (threadIdx.x == 0) {
@@ -1095,10 +1125,12 @@ __global__ __launch_bounds__(1024) void wfa_tile_kernel(const uint8_t* __restric
   TileTask tk = tasks[blockIdx.x];
   const TileJob J = jobs[tk.job];
   if (!J.active) return;
+  const Rng RG = make_rng(J.pl, J.tl, J.sub);
   {  // tasks carry (tile index, tile width): this block's diagonal range [-s1, s1], clipped to the problem, is cut
      // into tiles from its own left end, so every tile but the last is full
     const int s1 = J.s0 + T;
-    const int L = max(-J.pl, -s1), R = min(J.tl, s1);
+    int L, R;
+    rng_block(RG, J.s0, s1, L, R);
     const int idx = tk.core_lo, core = tk.core_hi;
     tk.core_lo = L + idx * core;
     tk.core_hi = min(R, tk.core_lo + core - 1);
@@ -1131,7 +1163,7 @@ __global__ __launch_bounds__(1024) void wfa_tile_kernel(const uint8_t* __restric
     else if ((r -= pen.e1) < pen.e1) { comp = C_D1; sc = s0 - r; slot = ((sc % n1) + n1) % n1; dst = sD1; }
     else if ((r -= pen.e1) < pen.e2) { comp = C_I2; sc = s0 - r; slot = ((sc % n2) + n2) % n2; dst = sI2; }
     else { r -= pen.e2; comp = C_D2; sc = s0 - r; slot = ((sc % n2) + n2) % n2; dst = sD2; }
-    const int lo = sc >= 0 ? rng_lo(pl, sc) : 1, hi = sc >= 0 ? rng_hi(tl, sc) : 0;
+    const int lo = sc >= 0 ? rng_lo(RG, sc) : 1, hi = sc >= 0 ? rng_hi(RG, sc) : 0;
     const int32_t* src = rin + ((int64_t)(comp * RING + (sc & RMASK))) * width;
     for (int j = tid; j < Wt; j += NT) {
       const int k = kA + j;
@@ -1155,11 +1187,11 @@ __global__ __launch_bounds__(1024) void wfa_tile_kernel(const uint8_t* __restric
     cur2 = cur2 + 1 == n2 ? 0 : cur2 + 1;
     const int sx = s - pen.x, so1 = s - pen.o1 - pen.e1, so2 = s - pen.o2 - pen.e2, se1 = s - pen.e1, se2 = s - pen.e2;
     // closed-form ranges of the source rows (dead rows: lo > hi)
-    const int lx = sx >= 0 ? rng_lo(pl, sx) : 1, hx = sx >= 0 ? rng_hi(tl, sx) : 0;
-    const int l1 = so1 >= 0 ? rng_lo(pl, so1) : 1, h1 = so1 >= 0 ? rng_hi(tl, so1) : 0;
-    const int l2 = so2 >= 0 ? rng_lo(pl, so2) : 1, h2 = so2 >= 0 ? rng_hi(tl, so2) : 0;
-    const int le1 = se1 >= 0 ? rng_lo(pl, se1) : 1, he1 = se1 >= 0 ? rng_hi(tl, se1) : 0;
-    const int le2 = se2 >= 0 ? rng_lo(pl, se2) : 1, he2 = se2 >= 0 ? rng_hi(tl, se2) : 0;
+    const int lx = sx >= 0 ? rng_lo(RG, sx) : 1, hx = sx >= 0 ? rng_hi(RG, sx) : 0;
+    const int l1 = so1 >= 0 ? rng_lo(RG, so1) : 1, h1 = so1 >= 0 ? rng_hi(RG, so1) : 0;
+    const int l2 = so2 >= 0 ? rng_lo(RG, so2) : 1, h2 = so2 >= 0 ? rng_hi(RG, so2) : 0;
+    const int le1 = se1 >= 0 ? rng_lo(RG, se1) : 1, he1 = se1 >= 0 ? rng_hi(RG, se1) : 0;
+    const int le2 = se2 >= 0 ? rng_lo(RG, se2) : 1, he2 = se2 >= 0 ? rng_hi(RG, se2) : 0;
     // ring slots: (s - d) mod n == cur - d (+ n if negative), all look-backs d < n
     int qx = curM - pen.x; if (qx < 0) qx += scope;
     int q1 = curM - pen.o1 - pen.e1; if (q1 < 0) q1 += scope;
@@ -1178,7 +1210,7 @@ __global__ __launch_bounds__(1024) void wfa_tile_kernel(const uint8_t* __restric
     int* oD1 = sD1 + cur1 * Wt - kA;
     int* oI2 = sI2 + cur2 * Wt - kA;
     int* oD2 = sD2 + cur2 * Wt - kA;
-    const int klo = max(kA + t, rng_lo(pl, s)), khi = min(tk.core_hi + T - t, rng_hi(tl, s));
+    const int klo = max(kA + t, rng_lo(RG, s)), khi = min(tk.core_hi + T - t, rng_hi(RG, s));
     const bool stream = (t > T - scope);  // the last `scope` rows of I/D go to the output snapshot
     int32_t* gI1 = rout + ((int64_t)(C_I1 * RING + (s & RMASK))) * width;
     int32_t* gI2 = rout + ((int64_t)(C_I2 * RING + (s & RMASK))) * width;
@@ -1235,7 +1267,7 @@ __global__ __launch_bounds__(1024) void wfa_tile_kernel(const uint8_t* __restric
     const int r = idx / ncore;
     const int k = tk.core_lo + (idx - r * ncore);
     const int sc = s0 + T - r;
-    if (sc < 0 || k < rng_lo(pl, sc) || k > rng_hi(tl, sc)) continue;
+    if (sc < 0 || k < rng_lo(RG, sc) || k > rng_hi(RG, sc)) continue;
     rout[((int64_t)(C_M * RING + (sc & RMASK))) * width + k] = sM[(sc % scope) * Wt + (k - kA)];
   }
   int32_t* mk = mak_out + ((int64_t)tk.job * 2 + dir) * T;
@@ -1413,11 +1445,13 @@ __global__ __launch_bounds__(NTMAX) void wfa_tile_reg_kernel(const uint8_t* __re
   const TileJob J = jobs[tk.job];
   if (!J.active) return;
   const int sbase = P2 ? (tk.dir == 0 ? J.tf : J.tr) : J.s0;  // score of the snapshot this direction starts from
+  const Rng RG = make_rng(J.pl, J.tl, J.sub);
   int halo = T;  // columns computed on either side of the core (the trapezoid loses one per step)
   {  // tasks carry (tile index, tile width): this block's diagonal range [-s1, s1], clipped to the problem, is cut
      // into tiles from its own left end, so every tile but the last is full
     const int s1 = sbase + T;
-    const int L = max(-J.pl, -s1), R = min(J.tl, s1);
+    int L, R;
+    rng_block(RG, sbase, s1, L, R);
     const int idx = tk.core_lo, core = tk.core_hi;
     tk.core_lo = L + idx * core;
     tk.core_hi = min(R, tk.core_lo + core - 1);
@@ -1453,18 +1487,18 @@ __global__ __launch_bounds__(NTMAX) void wfa_tile_reg_kernel(const uint8_t* __re
 #pragma unroll
     for (int d = 0; d < H; ++d) {
       const int sc = s0 - d;
-      const int v = (kin && sc >= 0 && k >= rng_lo(pl, sc) && k <= rng_hi(tl, sc)) ? rin[((int64_t)(C_M * RING + (sc & RMASK))) * width + k] : WF_NULL;
+      const int v = (kin && sc >= 0 && k >= rng_lo(RG, sc) && k <= rng_hi(RG, sc)) ? rin[((int64_t)(C_M * RING + (sc & RMASK))) * width + k] : WF_NULL;
       Mh[c][(NCL - d % NCL) % NCL][d / NCL] = v;  // row s0-d: class (-d mod 5), the (d/5)-th newest of its class
     }
 #pragma unroll
     for (int d = 0; d < E1; ++d) {
       const int sc = s0 - d;
-      const bool ok = kin && sc >= 0 && k >= rng_lo(pl, sc) && k <= rng_hi(tl, sc);
+      const bool ok = kin && sc >= 0 && k >= rng_lo(RG, sc) && k <= rng_hi(RG, sc);
       I1h[c][d] = ok ? rin[((int64_t)(C_I1 * RING + (sc & RMASK))) * width + k] : WF_NULL;
       D1h[c][d] = ok ? rin[((int64_t)(C_D1 * RING + (sc & RMASK))) * width + k] : WF_NULL;
     }
     {
-      const bool ok = kin && s0 >= 0 && k >= rng_lo(pl, s0) && k <= rng_hi(tl, s0);
+      const bool ok = kin && s0 >= 0 && k >= rng_lo(RG, s0) && k <= rng_hi(RG, s0);
       I2h[c] = ok ? rin[((int64_t)(C_I2 * RING + (s0 & RMASK))) * width + k] : WF_NULL;
       D2h[c] = ok ? rin[((int64_t)(C_D2 * RING + (s0 & RMASK))) * width + k] : WF_NULL;
     }
@@ -1540,9 +1574,11 @@ __global__ __launch_bounds__(NTMAX) void wfa_tile_reg_kernel(const uint8_t* __re
     // The closed-form source ranges are nested, the oldest row (s - LB) is the narrowest:
     // a thread whose neighbourhood k0-1 .. k0+C lies inside it needs no range select at all.
     const int sb = s - LB;
-    const bool interior = sb >= 0 && (k0 - 1 >= rng_lo(pl, sb)) && (k0 + C <= rng_hi(tl, sb));
+    // (the triangle's bound is tightest at the oldest row, the score bound's at the newest: s - E2)
+    const bool interior = sb >= 0 && (k0 - 1 >= max(rng_lo(RG, sb), rng_lo(RG, s - E2))) && (k0 + C <= min(rng_hi(RG, sb), rng_hi(RG, s - E2)));
     int nM[C], nI1[C], nI2[C], nD1[C], nD2[C];
     int mak = 0;
+    const int cut_lo = RG.kb_lo + s, cut_hi = RG.kb_hi - s;
 #pragma unroll
     for (int c = 0; c < C; ++c) {
       const int k = k0 + c;
@@ -1553,11 +1589,11 @@ __global__ __launch_bounds__(NTMAX) void wfa_tile_reg_kernel(const uint8_t* __re
       int mx = Mh[c][cl][0];
       if (!interior) {
         const int sx = s - LX, sa = s - LA, se1 = s - E1, se2 = s - E2;
-        const int lx = sx >= 0 ? rng_lo(pl, sx) : 1, hx = sx >= 0 ? rng_hi(tl, sx) : 0;
-        const int la = sa >= 0 ? rng_lo(pl, sa) : 1, ha = sa >= 0 ? rng_hi(tl, sa) : 0;
-        const int lb = sb >= 0 ? rng_lo(pl, sb) : 1, hb = sb >= 0 ? rng_hi(tl, sb) : 0;
-        const int le1 = se1 >= 0 ? rng_lo(pl, se1) : 1, he1 = se1 >= 0 ? rng_hi(tl, se1) : 0;
-        const int le2 = se2 >= 0 ? rng_lo(pl, se2) : 1, he2 = se2 >= 0 ? rng_hi(tl, se2) : 0;
+        const int lx = sx >= 0 ? rng_lo(RG, sx) : 1, hx = sx >= 0 ? rng_hi(RG, sx) : 0;
+        const int la = sa >= 0 ? rng_lo(RG, sa) : 1, ha = sa >= 0 ? rng_hi(RG, sa) : 0;
+        const int lb = sb >= 0 ? rng_lo(RG, sb) : 1, hb = sb >= 0 ? rng_hi(RG, sb) : 0;
+        const int le1 = se1 >= 0 ? rng_lo(RG, se1) : 1, he1 = se1 >= 0 ? rng_hi(RG, se1) : 0;
+        const int le2 = se2 >= 0 ? rng_lo(RG, se2) : 1, he2 = se2 >= 0 ? rng_hi(RG, se2) : 0;
         a10 = sel_rng(a10, k - 1, la, ha); i1 = sel_rng(i1, k - 1, le1, he1);
         a25 = sel_rng(a25, k - 1, lb, hb); i2 = sel_rng(i2, k - 1, le2, he2);
         b10 = sel_rng(b10, k + 1, la, ha); d1 = sel_rng(d1, k + 1, le1, he1);
@@ -1574,8 +1610,9 @@ __global__ __launch_bounds__(NTMAX) void wfa_tile_reg_kernel(const uint8_t* __re
       mis = (unsigned)mis <= hm ? mis : WF_NULL;
       nI1[c] = ins1; nI2[c] = ins2; nD1[c] = del1; nD2[c] = del2;
       int m = max(imax3(ins1, ins2, mis), max(del1, del2));
-      // columns outside [-pl, tl] hold no cell at all (hmaxu = 0 would let offset 0 through)
-      nM[c] = colok[c] ? m : WF_NULL;
+      // columns outside [-pl, tl] hold no cell at all (hmaxu = 0 would let offset 0 through), nor do columns the score
+      // bound has cut off (their values would never be read; their extensions would be done for nothing)
+      nM[c] = (colok[c] && k >= cut_lo && k <= cut_hi) ? m : WF_NULL;
     }
     // extension: first 8 bases of all C cells in flight together
     uint64_t x[C];
@@ -1607,7 +1644,7 @@ __global__ __launch_bounds__(NTMAX) void wfa_tile_reg_kernel(const uint8_t* __re
       if (m >= 0) {
         m += min(ext[c], maxn[c]);
         nM[c] = m;
-        if (k >= tk.core_lo && k <= tk.core_hi && k >= rng_lo(pl, s) && k <= rng_hi(tl, s)) mak = max(mak, 2 * m - k);
+        if (k >= tk.core_lo && k <= tk.core_hi && k >= rng_lo(RG, s) && k <= rng_hi(RG, s)) mak = max(mak, 2 * m - k);
       }
     }
     if (P2) {
@@ -1617,7 +1654,7 @@ __global__ __launch_bounds__(NTMAX) void wfa_tile_reg_kernel(const uint8_t* __re
 #pragma unroll
       for (int c = 0; c < C; ++c) {
         const int k = k0 + c;
-        if (k >= tk.core_lo && k <= tk.core_hi && k >= rng_lo(pl, s) && k <= rng_hi(tl, s)) {
+        if (k >= tk.core_lo && k <= tk.core_hi && k >= rng_lo(RG, s) && k <= rng_hi(RG, s)) {
           prow[C_M * cstride + k] = nM[c]; prow[C_I1 * cstride + k] = nI1[c]; prow[C_I2 * cstride + k] = nI2[c];
           prow[C_D1 * cstride + k] = nD1[c]; prow[C_D2 * cstride + k] = nD2[c];
         }
@@ -1628,7 +1665,7 @@ __global__ __launch_bounds__(NTMAX) void wfa_tile_reg_kernel(const uint8_t* __re
 #pragma unroll
       for (int c = 0; c < C; ++c) {
         const int k = k0 + c;
-        if (k >= tk.core_lo && k <= tk.core_hi && k >= rng_lo(pl, s) && k <= rng_hi(tl, s)) {
+        if (k >= tk.core_lo && k <= tk.core_hi && k >= rng_lo(RG, s) && k <= rng_hi(RG, s)) {
           const int64_t ro = ((int64_t)(s & RMASK)) * width + k;
           rout[(int64_t)C_I1 * RING * width + ro] = nI1[c];
           rout[(int64_t)C_I2 * RING * width + ro] = nI2[c];
@@ -1665,7 +1702,7 @@ __global__ __launch_bounds__(NTMAX) void wfa_tile_reg_kernel(const uint8_t* __re
       if (k < tk.core_lo || k > tk.core_hi) continue;
       for (int d = Tn; d < H; ++d) {
         const int sc = s_end - d;
-        if (sc < 0 || k < rng_lo(pl, sc) || k > rng_hi(tl, sc)) continue;
+        if (sc < 0 || k < rng_lo(RG, sc) || k > rng_hi(RG, sc)) continue;
         const int64_t ro = ((int64_t)(sc & RMASK)) * width + k;
         rout[(int64_t)C_I1 * RING * width + ro] = rin[(int64_t)C_I1 * RING * width + ro];
         rout[(int64_t)C_I2 * RING * width + ro] = rin[(int64_t)C_I2 * RING * width + ro];
@@ -1686,7 +1723,7 @@ __global__ __launch_bounds__(NTMAX) void wfa_tile_reg_kernel(const uint8_t* __re
         const int back = ((tr - r) % NCL + NCL) % NCL;     // s_end - (newest score of class r)
         const int e = (d - back) / NCL;
         const int sc = s_end - d;
-        if (sc >= 0 && k >= rng_lo(pl, sc) && k <= rng_hi(tl, sc)) rout[((int64_t)(C_M * RING + (sc & RMASK))) * width + k] = Mh[c][r][e];
+        if (sc >= 0 && k >= rng_lo(RG, sc) && k <= rng_hi(RG, sc)) rout[((int64_t)(C_M * RING + (sc & RMASK))) * width + k] = Mh[c][r][e];
       }
     }
   };
@@ -1793,13 +1830,14 @@ __global__ __launch_bounds__(256) void wfa_p2_blockmax_kernel(const int32_t* __r
   const int job = blockIdx.x / (2 * P2ROWS), r2 = blockIdx.x % (2 * P2ROWS), d = r2 / P2ROWS, r = r2 % P2ROWS;
   const P2Job J = jobs[job];
   const int s = (d == 0 ? J.sf : J.sr) - 25 + r;
+  const Rng RG = make_rng(J.pl, J.tl, J.sub);
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
   __shared__ int s_mx[5];
   if (threadIdx.x < 5) s_mx[threadIdx.x] = 0;
   __syncthreads();
   int32_t* bm = bmax + J.bm_off + ((int64_t)(d * P2ROWS + r) * 5) * J.nblk;
   int mx[5] = {0, 0, 0, 0, 0};
-  const int lo = s >= 0 ? rng_lo(J.pl, s) : 1, hi = s >= 0 ? rng_hi(J.tl, s) : 0;
+  const int lo = s >= 0 ? rng_lo(RG, s) : 1, hi = s >= 0 ? rng_hi(RG, s) : 0;
   const int32_t* row[5];
 #pragma unroll
   for (int cc = 0; cc < 5; ++cc) row[cc] = s >= 0 ? p2_row(ring, p2, J, d, cc, s) : nullptr;
@@ -1884,9 +1922,11 @@ __global__ __launch_bounds__(1024) void wfa_p2_overlap_kernel(const int32_t* __r
   __shared__ int s_rmax[2][P2ROWS][5];
   for (int i = tid; i < 2 * P2ROWS * 5; i += blockDim.x) ((int*)s_rmax)[i] = p2max[(int64_t)job * 2 * P2ROWS * 5 + i];
   if (tid < 8) s_bp[tid] = 0;
-  if (tid == 0) { s_state[0] = J.sf; s_state[1] = J.sr; s_state[2] = J.last_fwd; s_state[3] = INT32_MAX; s_state[4] = 0; s_state[5] = 0; s_cells = 0; }
+  // (with a bound of the job's score the walk starts as if a breakpoint of score bound + 1 were in hand: see wfa_bp_kernel)
+  if (tid == 0) { s_state[0] = J.sf; s_state[1] = J.sr; s_state[2] = J.last_fwd; s_state[3] = J.sub < SUB_NONE ? J.sub + 1 : INT32_MAX; s_state[4] = 0; s_state[5] = 0; s_cells = 0; }
   __syncthreads();
   const int pl = J.pl, tl = J.tl, kinv = tl - pl;
+  const Rng RG = make_rng(pl, tl, J.sub);
   const int gopen = max(pen.o1, pen.o2);
   for (;;) {
     // ---- state at the start of the round (uniform)
@@ -1913,8 +1953,8 @@ __global__ __launch_bounds__(1024) void wfa_p2_overlap_kernel(const int32_t* __r
       if (si >= 0 && s0 + si - pen.o2 < best && s0 + si - bp_gap_open(pen, cc) < best &&
           s_rmax[d0][s0 - (sd0 - 25)][cc] + s_rmax[d1][si - (sd1 - 25)][cc] >= tl) {
         s_act[g][pr] = 1;
-        atomicMin(&s_k[g][0], kinv - rng_hi(tl, si));
-        atomicMax(&s_k[g][1], kinv - rng_lo(pl, si));
+        atomicMin(&s_k[g][0], kinv - rng_hi(RG, si));
+        atomicMax(&s_k[g][1], kinv - rng_lo(RG, si));
         s_k[g][2] = 1;
       }
     }
@@ -1926,7 +1966,7 @@ __global__ __launch_bounds__(1024) void wfa_p2_overlap_kernel(const int32_t* __r
       int d0, s0, s1;
       test_of(g, d0, s0, s1);
       const int d1 = d0 ^ 1, sd0 = d0 == 0 ? J.sf : J.sr, sd1 = d1 == 0 ? J.sf : J.sr;
-      const int klo = max(s_k[g][0], rng_lo(pl, s0)), khi = min(s_k[g][1], rng_hi(tl, s0));
+      const int klo = max(s_k[g][0], rng_lo(RG, s0)), khi = min(s_k[g][1], rng_hi(RG, s0));
       const int B_lo = (klo + J.koff2) >> 6, B_hi = (khi + J.koff2) >> 6;
       const int32_t* bm0 = bmj + ((int64_t)(d0 * P2ROWS + (s0 - (sd0 - 25))) * 5) * nblk;
       const int32_t* pb1 = pbj + ((int64_t)(d1 * P2ROWS + (s1 - (sd1 - 25))) * 5) * nblk;
@@ -1961,7 +2001,7 @@ __global__ __launch_bounds__(1024) void wfa_p2_overlap_kernel(const int32_t* __r
           if (g < ng && s_k[g][2]) {
             int d0, s0, s1;
             test_of(g, d0, s0, s1);
-            const int klo = max(s_k[g][0], rng_lo(pl, s0)), khi = min(s_k[g][1], rng_hi(tl, s0));
+            const int klo = max(s_k[g][0], rng_lo(RG, s0)), khi = min(s_k[g][1], rng_hi(RG, s0));
             nbk = max(0, ((khi + J.koff2) >> 6) - ((klo + J.koff2) >> 6) + 1);
           }
           cum[g + 1] = cum[g] + nbk;
@@ -1976,12 +2016,12 @@ __global__ __launch_bounds__(1024) void wfa_p2_overlap_kernel(const int32_t* __r
           while (li >= cum[g + 1]) ++g;
           int d0, s0, s1;
           test_of(g, d0, s0, s1);
-          b0 = ((max(s_k[g][0], rng_lo(pl, s0)) + J.koff2) >> 6) + (li - cum[g]);
+          b0 = ((max(s_k[g][0], rng_lo(RG, s0)) + J.koff2) >> 6) + (li - cum[g]);
         }
         int d0, s0, s1;
         test_of(g, d0, s0, s1);
         const int d1 = d0 ^ 1, sd1 = d1 == 0 ? J.sf : J.sr;
-        const int klo = max(s_k[g][0], rng_lo(pl, s0)), khi = min(s_k[g][1], rng_hi(tl, s0));
+        const int klo = max(s_k[g][0], rng_lo(RG, s0)), khi = min(s_k[g][1], rng_hi(RG, s0));
         const int k0 = (b0 << 6) - J.koff2 + lane;
         if (k0 < klo || k0 > khi) continue;
         const int k1 = kinv - k0;
@@ -1998,7 +2038,7 @@ __global__ __launch_bounds__(1024) void wfa_p2_overlap_kernel(const int32_t* __r
         for (int i = 0; i < scope; ++i) {
           const int si = s1 - i;
           if (si < 0) break;
-          if (k1 < rng_lo(pl, si) || k1 > rng_hi(tl, si)) continue;
+          if (k1 < rng_lo(RG, si) || k1 > rng_hi(RG, si)) continue;
           const int32_t* bmr = bmj + ((int64_t)(d1 * P2ROWS + (si - (sd1 - 25))) * 5) * nblk + b1;
           int bv[5];
           bool some = false;
@@ -2072,7 +2112,7 @@ __global__ __launch_bounds__(1024) void wfa_p2_overlap_kernel(const int32_t* __r
                 s_bp[0] = b;
                 if (d0 == 0) { s_bp[1] = s0; s_bp[2] = si; s_bp[3] = k0; s_bp[4] = p2_row(ring, p2, J, 0, cc, s0)[k0]; }
                 else         { s_bp[1] = si; s_bp[2] = s0; s_bp[3] = k1; s_bp[4] = p2_row(ring, p2, J, 0, cc, si)[k1]; }
-                s_bp[5] = cc;
+                s_bp[5] = cc; s_bp[7] = 1;
               }
             }
           } else {  // unusual penalties: the walk itself (every lane runs it; lane 0 records)
@@ -2093,15 +2133,15 @@ __global__ __launch_bounds__(1024) void wfa_p2_overlap_kernel(const int32_t* __r
                   s_bp[0] = b;
                   if (d0 == 0) { s_bp[1] = s0; s_bp[2] = si; s_bp[3] = k0; s_bp[4] = p2_row(ring, p2, J, 0, cc, s0)[k0]; }
                   else         { s_bp[1] = si; s_bp[2] = s0; s_bp[3] = k1; s_bp[4] = p2_row(ring, p2, J, 0, cc, si)[k1]; }
-                  s_bp[5] = cc;
+                  s_bp[5] = cc; s_bp[7] = 1;
                 }
               }
             }
           }
         }
         // the other direction advances by one row (computed ahead: only the bookkeeping is left)
-        if (d0 == 0) { ++sr; cells += (unsigned long long)(rng_hi(tl, sr) - rng_lo(pl, sr) + 1); last_fwd = 0; }
-        else         { ++sf; cells += (unsigned long long)(rng_hi(tl, sf) - rng_lo(pl, sf) + 1); last_fwd = 1; }
+        if (d0 == 0) { ++sr; cells += (unsigned long long)(rng_hi(RG, sr) - rng_lo(RG, sr) + 1); last_fwd = 0; }
+        else         { ++sf; cells += (unsigned long long)(rng_hi(RG, sf) - rng_lo(RG, sf) + 1); last_fwd = 1; }
         ++u;
       }
       if (lane == 0) {
@@ -2114,6 +2154,7 @@ __global__ __launch_bounds__(1024) void wfa_p2_overlap_kernel(const int32_t* __r
   if (tid == 0) {
     BpResult r;
     r.status = s_state[4] == 2 ? WFM_DEV_P2_MORE : 0;
+    if (r.status == 0 && !s_bp[7]) r.status = J.sub < SUB_NONE ? WFM_DEV_BAND : WFM_DEV_UNREACHABLE;  // the walk ended without a breakpoint
     r.score = s_state[3]; r.score_fwd = s_bp[1]; r.score_rev = s_bp[2]; r.k_fwd = s_bp[3]; r.off_fwd = s_bp[4]; r.comp = s_bp[5];
     r.steps = s_state[0] + s_state[1];
     r.cells = s_cells;

@@ -449,6 +449,18 @@ int do_biwfa_alignment_batch(wfm_handle_t* h, std::vector<BiwfaRecord>& recs, co
     p.pattern = r.target; p.plen = (int32_t)r.target_length;
     p.text = r.query; p.tlen = (int32_t)r.query_length;
     p.mode = WFM_MODE_END2END_BIWFA;
+    {
+      // A guess of an upper bound of the score, for the device to cut its wavefronts with (wfm_problem_t::score_hint): the
+      // target window is the mapped range plus padding, so the alignment opens with and ends in a gap -- two gap openings
+      // and the length difference -- and in between it pays for the divergence mashmap estimated, at 6 per differing base
+      // (a mismatch costs 5), with 0.1 % and 200 on top.  Too small a guess only costs that record a second run.
+      double id = r.mashmap_estimated_identity > 1.0f ? r.mashmap_estimated_identity / 100.0 : r.mashmap_estimated_identity;
+      id = std::min(1.0, std::max(0.5, id));
+      const double len = (double)std::min(r.target_length, r.query_length);
+      const double dl = std::fabs((double)r.target_length - (double)r.query_length);
+      const double hint = 2.0 * penalties.gap_opening2 + penalties.gap_extension2 * dl + (1.0 - id + 0.001) * len * 6.0 + 200.0;
+      p.score_hint = hint < 1e9 ? (int32_t)hint : 0;
+    }
     g.probs.push_back(p);
   }
   int rc = g.run(h, pen, stats);
