@@ -838,7 +838,9 @@ int align_resident_impl(wfm_handle* h, const wfm_penalties_t* pen, wfm_seqset* S
             // ran out of its narrow ring, or past the caller's guess of its score: once more, at the end of this level, on
             // a full ring and without the guess
             Node again = nd; again.noband = 1; again.sub = SUB_NONE; again.hinted = 0;
-            bp_nodes.push_back(again);
+            // (a root that ran past its guess joins the next level's jobs instead of holding this level up on its own:
+            // nodes are independent, only the gather at the end waits for all of them)
+            if (nd.hinted) next_bp.push_back(again); else bp_nodes.push_back(again);
             ++band_retries;
             hint_retries += nd.hinted;
             continue;
