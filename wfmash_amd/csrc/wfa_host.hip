@@ -14,6 +14,7 @@
 #include <climits>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -1319,7 +1320,11 @@ int wfm_get_stats(const wfm_handle_t* h, wfm_stats_t* out) {
 #include "wfa_handle.h"
 hipStream_t wfm_stream(wfm_handle_t* h) { return h->stream; }
 int wfm_device(const wfm_handle_t* h) { return h->device; }
-void wfm_set_error(wfm_handle_t* h, const std::string& msg) { h->err = msg; }
+void wfm_set_error(wfm_handle_t* h, const std::string& msg) {
+  static std::mutex mu;  // several host threads may work on one handle (the device winnower next to the hashing thread)
+  std::lock_guard<std::mutex> lk(mu);
+  h->err = msg;
+}
 void* wfm_attachment(wfm_handle_t* h) { return h->attachment; }
 void wfm_set_attachment(wfm_handle_t* h, void* p, void (*destroy)(void*)) {
   if (h->attachment && h->attachment_free && h->attachment != p) h->attachment_free(h->attachment);
