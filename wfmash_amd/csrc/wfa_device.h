@@ -151,10 +151,10 @@ void launch_tile(const uint8_t* seq, int32_t* ring, const TileJob* jobs, const T
                  int threads, int T, int Wt, size_t lds_bytes, DevPen pen, int scope, hipStream_t st);
 void launch_tile_advance(TileJob* jobs, int32_t* mak, int njobs, int T, DevPen pen, int exact, hipStream_t st);
 void launch_tile_reg(const uint8_t* seq, int32_t* ring, const TileJob* jobs, const TileTask* tasks, int32_t* mak, int ntasks,
-                     int threads, int T, int C, hipStream_t st);
+                     int threads, int T, int C, bool cut, hipStream_t st);  // cut: some job of the launch carries a score bound
 // phase-2 rows of the jobs in mode 4 (T = P2K scores, two diagonals per thread), their per-row maxima into p2max
 void launch_tile_p2(const uint8_t* seq, int32_t* ring, const TileJob* jobs, const TileTask* tasks, int ntasks, int threads,
-                    int32_t* p2, hipStream_t st);
+                    int32_t* p2, bool cut, hipStream_t st);
 void launch_p2_blockmax(const int32_t* ring, const int32_t* p2, const P2Job* jobs, int32_t* bmax, int32_t* p2max, int njobs, hipStream_t st);
 void launch_p2_overlap(const int32_t* ring, const int32_t* p2, const P2Job* jobs, const int32_t* p2max, const int32_t* bmax, int32_t* pbmax,
                        BpResult* res, int njobs, int threads, int max_nblk, DevPen pen, int scope, hipStream_t st);

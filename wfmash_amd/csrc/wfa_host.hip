@@ -339,6 +339,8 @@ int run_tiled_phase(wfm_handle* h, wfm_seqset* S, const DevPen& dp, int scope, c
     t.width = j.width; t.koff = j.koff; t.s0 = 0; t.active = 1; t.fmax = 0; t.rmax = 0; t.nblocks = 0; t.mode = 0; t.tf = 0; t.tr = 0; t.last_fwd = 0; t.pad_ = 0;
     t.p2_off = 0; t.w2 = 0; t.koff2 = 0; t.sub = j.sub; t.pad2_ = 0;
   }
+  bool any_cut = false;  // the kernel form with the score bounds' bookkeeping is only launched when a job carries one
+  for (size_t i = 0; i < n; ++i) any_cut |= tj[i].sub != SUB_NONE;
   if (h->tilejobs.ensure(n) || h->tilemak.ensure(n * 2 * (size_t)std::max(T, 2))) { h->err = "out of device memory (tiles)"; return WFM_E_NOMEM; }
   size_t n_active = 0;
   std::vector<int> s_begin(n, 0);  // score the jobs start this pass at
@@ -449,7 +451,7 @@ int run_tiled_phase(wfm_handle* h, wfm_seqset* S, const DevPen& dp, int scope, c
       HIPCHK(h, hipMemcpyAsync(h->tiletasks.p, tasks.data(), tasks.size() * sizeof(TileTask), hipMemcpyHostToDevice, h->stream));
       for (int b = 0; b < chunk; ++b) {
         HIPCHK(h, hipEventRecord(h->tile_ev[2 * b], h->stream));
-        if (cfg.reg) launch_tile_reg(S->d_seq, h->ring.p, h->tilejobs.p, h->tiletasks.p, h->tilemak.p, (int)tasks.size(), threads_b[(size_t)b], T, cfg.C, h->stream);
+        if (cfg.reg) launch_tile_reg(S->d_seq, h->ring.p, h->tilejobs.p, h->tiletasks.p, h->tilemak.p, (int)tasks.size(), threads_b[(size_t)b], T, cfg.C, any_cut, h->stream);
         else launch_tile(S->d_seq, h->ring.p, h->tilejobs.p, h->tiletasks.p, h->tilemak.p, (int)tasks.size(), cfg.threads, T, cfg.Wt, lds, dp, scope, h->stream);
         HIPCHK(h, hipEventRecord(h->tile_ev[2 * b + 1], h->stream));
         launch_tile_advance(h->tilejobs.p, h->tilemak.p, (int)n, T, dp, (cfg.reg && cfg.exact) ? 1 : 0, h->stream);
@@ -594,7 +596,9 @@ int run_p2_phase(wfm_handle* h, wfm_seqset* S, const DevPen& dp, int scope, cons
     HIPCHK(h, hipMemcpyAsync(h->p2jobs.p, pj.data(), n * sizeof(P2Job), hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemcpyAsync(h->tiletasks.p, tasks.data(), tasks.size() * sizeof(TileTask), hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipEventRecord(h->ev0, h->stream));
-    launch_tile_p2(S->d_seq, h->ring.p, h->tilejobs.p, h->tiletasks.p, (int)tasks.size(), threads_c, h->p2rows.p, h->stream);
+    bool any_cut = false;
+    for (const TileJob& t : tj) any_cut |= t.sub != SUB_NONE;
+    launch_tile_p2(S->d_seq, h->ring.p, h->tilejobs.p, h->tiletasks.p, (int)tasks.size(), threads_c, h->p2rows.p, any_cut, h->stream);
     launch_p2_blockmax(h->ring.p, h->p2rows.p, h->p2jobs.p, h->p2bmax.p, h->p2max.p, (int)n, h->stream);
     static const int p2_threads = getenv("WFM_P2_THREADS") ? atoi(getenv("WFM_P2_THREADS")) : 0;
     launch_p2_overlap(h->ring.p, h->p2rows.p, h->p2jobs.p, h->p2max.p, h->p2bmax.p, h->p2pbmax.p, h->bpres.p, (int)n,
@@ -748,7 +752,11 @@ int align_resident_impl(wfm_handle* h, const wfm_penalties_t* pen, wfm_seqset* S
         j.koff = koff;
         j.resume_s = -1; j.resume_sr = -1; j.last_fwd = 0; j.fmax0 = 0; j.rmax0 = 0;
         j.band = band;
-        j.sub = nd.sub; j.pad_ = 0;
+        // a bound only earns its keep when the end diagonal is far from the start diagonal relative to the score (padded
+        // records and their children): for a balanced problem it starts to bind where the wavefronts meet, and costs the
+        // tile kernel its bookkeeping all the way there
+        j.sub = (nd.sub != SUB_NONE && (int64_t)std::abs(nd.tl - nd.pl) * 8 >= (int64_t)nd.sub) ? nd.sub : SUB_NONE;
+        j.pad_ = 0;
         band_jobs += band > 0;
         if (tile_it) { tiled.push_back((int)jobs.size()); ring2.push_back((int64_t)(ring_elems + need / 2)); }
         node_of.push_back((int32_t)i);
@@ -835,15 +843,16 @@ int align_resident_impl(wfm_handle* h, const wfm_penalties_t* pen, wfm_seqset* S
           prob_cells[nd.prob] += r.cells;
           h->stats.cells_bp += r.cells;
           if (nd.score_rem == INT_MAX && jobs[q].band > 0) { ++roots_banded; roots_out += r.status == WFM_DEV_BAND; }
-          if (r.status == WFM_DEV_BAND || (nd.hinted && (r.status < 0 || (r.status == 0 && r.score > nd.sub)))) {
+          const bool guessed = nd.hinted && jobs[q].sub != SUB_NONE;  // the job really ran under the caller's guess
+          if (r.status == WFM_DEV_BAND || (guessed && (r.status < 0 || (r.status == 0 && r.score > nd.sub)))) {
             // ran out of its narrow ring, or past the caller's guess of its score: once more, at the end of this level, on
             // a full ring and without the guess
             Node again = nd; again.noband = 1; again.sub = SUB_NONE; again.hinted = 0;
             // (a root that ran past its guess joins the next level's jobs instead of holding this level up on its own:
             // nodes are independent, only the gather at the end waits for all of them)
-            if (nd.hinted) next_bp.push_back(again); else bp_nodes.push_back(again);
+            if (guessed) next_bp.push_back(again); else bp_nodes.push_back(again);
             ++band_retries;
-            hint_retries += nd.hinted;
+            hint_retries += guessed;
             continue;
           }
           if (r.status == 1) {  // end reached at score 0 -> base aligner

@@ -1425,7 +1425,7 @@ __device__ __forceinline__ int lce_head40(const uint8_t* P, const uint8_t* T, co
 
 // P2 = true: the phase-2 form (see P2Job in wfa_device.h) -- the two directions start at their own scores (J.tf / J.tr), T
 // is P2K, every row of the core goes to the job's P2 rows with its per-component maxima, and there is no output snapshot.
-template <int C, int NTMAX, int LX, int LA, int LB, int E1, int E2, bool P2 = false>
+template <int C, int NTMAX, int LX, int LA, int LB, int E1, int E2, bool P2 = false, bool CUT = true>
 __global__ __launch_bounds__(NTMAX) void wfa_tile_reg_kernel(const uint8_t* __restrict__ seq, int32_t* __restrict__ ring_arena,
                                                            const TileJob* __restrict__ jobs, const TileTask* __restrict__ tasks,
                                                            int32_t* __restrict__ mak_out, int T, int32_t* __restrict__ p2_arena = nullptr,
@@ -1445,13 +1445,18 @@ __global__ __launch_bounds__(NTMAX) void wfa_tile_reg_kernel(const uint8_t* __re
   const TileJob J = jobs[tk.job];
   if (!J.active) return;
   const int sbase = P2 ? (tk.dir == 0 ? J.tf : J.tr) : J.s0;  // score of the snapshot this direction starts from
-  const Rng RG = make_rng(J.pl, J.tl, J.sub);
+  // CUT = false: no job of the launch carries a score bound that can bind (the host checks): the ranges are the triangle's,
+  // and the step loop is spared the bound's bookkeeping (7 % of its instructions on C3)
+  const Rng RG = make_rng(J.pl, J.tl, CUT ? J.sub : SUB_NONE);
+  auto rlo = [&](int sc) { return CUT ? rng_lo(RG, sc) : max(-RG.pl, -sc); };
+  auto rhi = [&](int sc) { return CUT ? rng_hi(RG, sc) : min(RG.tl, sc); };
   int halo = T;  // columns computed on either side of the core (the trapezoid loses one per step)
   {  // tasks carry (tile index, tile width): this block's diagonal range [-s1, s1], clipped to the problem, is cut
      // into tiles from its own left end, so every tile but the last is full
     const int s1 = sbase + T;
     int L, R;
-    rng_block(RG, sbase, s1, L, R);
+    if (CUT) rng_block(RG, sbase, s1, L, R);
+    else { L = max(-J.pl, -s1); R = min(J.tl, s1); }
     const int idx = tk.core_lo, core = tk.core_hi;
     tk.core_lo = L + idx * core;
     tk.core_hi = min(R, tk.core_lo + core - 1);
@@ -1487,18 +1492,18 @@ __global__ __launch_bounds__(NTMAX) void wfa_tile_reg_kernel(const uint8_t* __re
 #pragma unroll
     for (int d = 0; d < H; ++d) {
       const int sc = s0 - d;
-      const int v = (kin && sc >= 0 && k >= rng_lo(RG, sc) && k <= rng_hi(RG, sc)) ? rin[((int64_t)(C_M * RING + (sc & RMASK))) * width + k] : WF_NULL;
+      const int v = (kin && sc >= 0 && k >= rlo(sc) && k <= rhi(sc)) ? rin[((int64_t)(C_M * RING + (sc & RMASK))) * width + k] : WF_NULL;
       Mh[c][(NCL - d % NCL) % NCL][d / NCL] = v;  // row s0-d: class (-d mod 5), the (d/5)-th newest of its class
     }
 #pragma unroll
     for (int d = 0; d < E1; ++d) {
       const int sc = s0 - d;
-      const bool ok = kin && sc >= 0 && k >= rng_lo(RG, sc) && k <= rng_hi(RG, sc);
+      const bool ok = kin && sc >= 0 && k >= rlo(sc) && k <= rhi(sc);
       I1h[c][d] = ok ? rin[((int64_t)(C_I1 * RING + (sc & RMASK))) * width + k] : WF_NULL;
       D1h[c][d] = ok ? rin[((int64_t)(C_D1 * RING + (sc & RMASK))) * width + k] : WF_NULL;
     }
     {
-      const bool ok = kin && s0 >= 0 && k >= rng_lo(RG, s0) && k <= rng_hi(RG, s0);
+      const bool ok = kin && s0 >= 0 && k >= rlo(s0) && k <= rhi(s0);
       I2h[c] = ok ? rin[((int64_t)(C_I2 * RING + (s0 & RMASK))) * width + k] : WF_NULL;
       D2h[c] = ok ? rin[((int64_t)(C_D2 * RING + (s0 & RMASK))) * width + k] : WF_NULL;
     }
@@ -1575,7 +1580,8 @@ __global__ __launch_bounds__(NTMAX) void wfa_tile_reg_kernel(const uint8_t* __re
     // a thread whose neighbourhood k0-1 .. k0+C lies inside it needs no range select at all.
     const int sb = s - LB;
     // (the triangle's bound is tightest at the oldest row, the score bound's at the newest: s - E2)
-    const bool interior = sb >= 0 && (k0 - 1 >= max(rng_lo(RG, sb), rng_lo(RG, s - E2))) && (k0 + C <= min(rng_hi(RG, sb), rng_hi(RG, s - E2)));
+    const bool interior = CUT ? (sb >= 0 && (k0 - 1 >= max(rlo(sb), rlo(s - E2))) && (k0 + C <= min(rhi(sb), rhi(s - E2))))
+                              : (sb >= 0 && (k0 - 1 >= rlo(sb)) && (k0 + C <= rhi(sb)));
     int nM[C], nI1[C], nI2[C], nD1[C], nD2[C];
     int mak = 0;
     const int cut_lo = RG.kb_lo + s, cut_hi = RG.kb_hi - s;
@@ -1589,11 +1595,11 @@ __global__ __launch_bounds__(NTMAX) void wfa_tile_reg_kernel(const uint8_t* __re
       int mx = Mh[c][cl][0];
       if (!interior) {
         const int sx = s - LX, sa = s - LA, se1 = s - E1, se2 = s - E2;
-        const int lx = sx >= 0 ? rng_lo(RG, sx) : 1, hx = sx >= 0 ? rng_hi(RG, sx) : 0;
-        const int la = sa >= 0 ? rng_lo(RG, sa) : 1, ha = sa >= 0 ? rng_hi(RG, sa) : 0;
-        const int lb = sb >= 0 ? rng_lo(RG, sb) : 1, hb = sb >= 0 ? rng_hi(RG, sb) : 0;
-        const int le1 = se1 >= 0 ? rng_lo(RG, se1) : 1, he1 = se1 >= 0 ? rng_hi(RG, se1) : 0;
-        const int le2 = se2 >= 0 ? rng_lo(RG, se2) : 1, he2 = se2 >= 0 ? rng_hi(RG, se2) : 0;
+        const int lx = sx >= 0 ? rlo(sx) : 1, hx = sx >= 0 ? rhi(sx) : 0;
+        const int la = sa >= 0 ? rlo(sa) : 1, ha = sa >= 0 ? rhi(sa) : 0;
+        const int lb = sb >= 0 ? rlo(sb) : 1, hb = sb >= 0 ? rhi(sb) : 0;
+        const int le1 = se1 >= 0 ? rlo(se1) : 1, he1 = se1 >= 0 ? rhi(se1) : 0;
+        const int le2 = se2 >= 0 ? rlo(se2) : 1, he2 = se2 >= 0 ? rhi(se2) : 0;
         a10 = sel_rng(a10, k - 1, la, ha); i1 = sel_rng(i1, k - 1, le1, he1);
         a25 = sel_rng(a25, k - 1, lb, hb); i2 = sel_rng(i2, k - 1, le2, he2);
         b10 = sel_rng(b10, k + 1, la, ha); d1 = sel_rng(d1, k + 1, le1, he1);
@@ -1612,7 +1618,7 @@ __global__ __launch_bounds__(NTMAX) void wfa_tile_reg_kernel(const uint8_t* __re
       int m = max(imax3(ins1, ins2, mis), max(del1, del2));
       // columns outside [-pl, tl] hold no cell at all (hmaxu = 0 would let offset 0 through), nor do columns the score
       // bound has cut off (their values would never be read; their extensions would be done for nothing)
-      nM[c] = (colok[c] && k >= cut_lo && k <= cut_hi) ? m : WF_NULL;
+      nM[c] = (colok[c] && (!CUT || (k >= cut_lo && k <= cut_hi))) ? m : WF_NULL;
     }
     // extension: first 8 bases of all C cells in flight together
     uint64_t x[C];
@@ -1644,7 +1650,7 @@ __global__ __launch_bounds__(NTMAX) void wfa_tile_reg_kernel(const uint8_t* __re
       if (m >= 0) {
         m += min(ext[c], maxn[c]);
         nM[c] = m;
-        if (k >= tk.core_lo && k <= tk.core_hi && k >= rng_lo(RG, s) && k <= rng_hi(RG, s)) mak = max(mak, 2 * m - k);
+        if (k >= tk.core_lo && k <= tk.core_hi && k >= rlo(s) && k <= rhi(s)) mak = max(mak, 2 * m - k);
       }
     }
     if (P2) {
@@ -1654,7 +1660,7 @@ __global__ __launch_bounds__(NTMAX) void wfa_tile_reg_kernel(const uint8_t* __re
 #pragma unroll
       for (int c = 0; c < C; ++c) {
         const int k = k0 + c;
-        if (k >= tk.core_lo && k <= tk.core_hi && k >= rng_lo(RG, s) && k <= rng_hi(RG, s)) {
+        if (k >= tk.core_lo && k <= tk.core_hi && k >= rlo(s) && k <= rhi(s)) {
           prow[C_M * cstride + k] = nM[c]; prow[C_I1 * cstride + k] = nI1[c]; prow[C_I2 * cstride + k] = nI2[c];
           prow[C_D1 * cstride + k] = nD1[c]; prow[C_D2 * cstride + k] = nD2[c];
         }
@@ -1665,7 +1671,7 @@ __global__ __launch_bounds__(NTMAX) void wfa_tile_reg_kernel(const uint8_t* __re
 #pragma unroll
       for (int c = 0; c < C; ++c) {
         const int k = k0 + c;
-        if (k >= tk.core_lo && k <= tk.core_hi && k >= rng_lo(RG, s) && k <= rng_hi(RG, s)) {
+        if (k >= tk.core_lo && k <= tk.core_hi && k >= rlo(s) && k <= rhi(s)) {
           const int64_t ro = ((int64_t)(s & RMASK)) * width + k;
           rout[(int64_t)C_I1 * RING * width + ro] = nI1[c];
           rout[(int64_t)C_I2 * RING * width + ro] = nI2[c];
@@ -1702,7 +1708,7 @@ __global__ __launch_bounds__(NTMAX) void wfa_tile_reg_kernel(const uint8_t* __re
       if (k < tk.core_lo || k > tk.core_hi) continue;
       for (int d = Tn; d < H; ++d) {
         const int sc = s_end - d;
-        if (sc < 0 || k < rng_lo(RG, sc) || k > rng_hi(RG, sc)) continue;
+        if (sc < 0 || k < rlo(sc) || k > rhi(sc)) continue;
         const int64_t ro = ((int64_t)(sc & RMASK)) * width + k;
         rout[(int64_t)C_I1 * RING * width + ro] = rin[(int64_t)C_I1 * RING * width + ro];
         rout[(int64_t)C_I2 * RING * width + ro] = rin[(int64_t)C_I2 * RING * width + ro];
@@ -1723,7 +1729,7 @@ __global__ __launch_bounds__(NTMAX) void wfa_tile_reg_kernel(const uint8_t* __re
         const int back = ((tr - r) % NCL + NCL) % NCL;     // s_end - (newest score of class r)
         const int e = (d - back) / NCL;
         const int sc = s_end - d;
-        if (sc >= 0 && k >= rng_lo(RG, sc) && k <= rng_hi(RG, sc)) rout[((int64_t)(C_M * RING + (sc & RMASK))) * width + k] = Mh[c][r][e];
+        if (sc >= 0 && k >= rlo(sc) && k <= rhi(sc)) rout[((int64_t)(C_M * RING + (sc & RMASK))) * width + k] = Mh[c][r][e];
       }
     }
   };
@@ -2202,16 +2208,19 @@ void launch_tile_advance(TileJob* jobs, int32_t* mak, int njobs, int T, DevPen p
   hipLaunchKernelGGL(wfa_tile_advance_kernel, dim3(njobs), dim3(64), 0, st, jobs, mak, njobs, T, pen, exact);
 }
 void launch_tile_reg(const uint8_t* seq, int32_t* ring, const TileJob* jobs, const TileTask* tasks, int32_t* mak, int ntasks,
-                     int threads, int T, int C, hipStream_t st) {
+                     int threads, int T, int C, bool cut, hipStream_t st) {
   const size_t lds = (size_t)(T + 1) * 4;
   if (C == 4) hipLaunchKernelGGL((wfa_tile_reg_kernel<4, 256, 5, 10, 25, 2, 1>), dim3(ntasks), dim3(threads), lds, st, seq, ring, jobs, tasks, mak, T);
-  else hipLaunchKernelGGL((wfa_tile_reg_kernel<2, 1024, 5, 10, 25, 2, 1>), dim3(ntasks), dim3(threads), lds, st, seq, ring, jobs, tasks, mak, T);
+  else if (cut) hipLaunchKernelGGL((wfa_tile_reg_kernel<2, 1024, 5, 10, 25, 2, 1, false, true>), dim3(ntasks), dim3(threads), lds, st, seq, ring, jobs, tasks, mak, T);
+  else hipLaunchKernelGGL((wfa_tile_reg_kernel<2, 1024, 5, 10, 25, 2, 1, false, false>), dim3(ntasks), dim3(threads), lds, st, seq, ring, jobs, tasks, mak, T);
 }
 void launch_tile_p2(const uint8_t* seq, int32_t* ring, const TileJob* jobs, const TileTask* tasks, int ntasks, int threads,
-                    int32_t* p2, hipStream_t st) {
+                    int32_t* p2, bool cut, hipStream_t st) {
   const size_t lds = (size_t)(P2K + 1) * 4;
-  hipLaunchKernelGGL((wfa_tile_reg_kernel<2, 1024, 5, 10, 25, 2, 1, true>), dim3(ntasks), dim3(threads), lds, st, seq, ring, jobs, tasks,
-                     (int32_t*)nullptr, P2K, p2, (int32_t*)nullptr);
+  if (cut) hipLaunchKernelGGL((wfa_tile_reg_kernel<2, 1024, 5, 10, 25, 2, 1, true, true>), dim3(ntasks), dim3(threads), lds, st, seq, ring, jobs, tasks,
+                              (int32_t*)nullptr, P2K, p2, (int32_t*)nullptr);
+  else hipLaunchKernelGGL((wfa_tile_reg_kernel<2, 1024, 5, 10, 25, 2, 1, true, false>), dim3(ntasks), dim3(threads), lds, st, seq, ring, jobs, tasks,
+                          (int32_t*)nullptr, P2K, p2, (int32_t*)nullptr);
 }
 void launch_p2_blockmax(const int32_t* ring, const int32_t* p2, const P2Job* jobs, int32_t* bmax, int32_t* p2max, int njobs, hipStream_t st) {
   hipLaunchKernelGGL(wfa_p2_blockmax_kernel, dim3(njobs * 2 * P2ROWS), dim3(256), 0, st, ring, p2, jobs, bmax, p2max);
