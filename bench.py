@@ -319,7 +319,7 @@ def _cpu_baseline_map(h):
         return {"value": bp / cdt, "unit": "indexed bases/s", "cores": n_seq, "kind": "reference",
                 "sample": f"{n_seq} synthetic haplotypes x {L // 1000000} Mbp, k={k} w={w} s={s_sz}: CommonFunc::addMinmers "
                           f"(commonFunc.hpp:440-708) one sequence per thread, {cdt:.1f} s",
-                "gpu_value": bp / gdt, "gpu_note": f"wfm_add_minmers_multi of the same sequences (hashing, thinning, winnowing and the closing sort on the device; {cores} host threads for what it hands back), {gdt:.2f} s"}
+                "gpu_value": bp / gdt, "gpu_note": f"wfm_add_minmers_multi of the same sequences (hashing and thinning on the device; sequences of 2 Mbp are winnowed by {cores} host threads side by side, from 4 Mbp on by the device), {gdt:.2f} s"}
     except Exception as e:  # the baseline is a report, never a reason to lose the bench line
         return {"value": None, "kind": "reference", "note": f"failed: {e}"}
 

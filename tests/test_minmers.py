@@ -301,7 +301,8 @@ def test_add_minmers_multi_winnows_on_the_device(dev_chunk, force):
         "    bad = [i for i, (a, b) in enumerate(zip(multi, single)) if a.tobytes() != b.tobytes()]\n"
         "    assert not bad, (k, w, s, bad)\n"
         "    print('same', k, w, s, sum(len(a) for a in multi))\n")
-    env = dict(os.environ, WFM_WINNOW_CHUNK=str(64 * 1000), WFM_WINNOW_DEV_CHUNK=dev_chunk, WFM_DEBUG="1", WFM_WINNOW_FORCE=force)  # force 1: replays
+    env = dict(os.environ, WFM_WINNOW_CHUNK=str(64 * 1000), WFM_WINNOW_DEV_CHUNK=dev_chunk, WFM_DEBUG="1", WFM_WINNOW_FORCE=force,  # force 1: replays
+               WFM_WINNOW_DEV_MIN="0")  # (sequences this short go to the host's workers by default)
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode == 0 and r.stdout.count("same") == 3, (r.stdout[-1000:], r.stderr[-3000:])
     lines = [l for l in r.stderr.splitlines() if "winnowing on the device" in l]

@@ -952,6 +952,7 @@ int64_t add_minmers_core(wfm_handle_t* h, const char* const* seqs, const int64_t
   int dev_levels = 0;
   int64_t dev_heaps = 0;
   const bool dev_winnow = !(getenv("WFM_WINNOW_DEVICE") && atoi(getenv("WFM_WINNOW_DEVICE")) == 0);
+  const int64_t dev_min = getenv("WFM_WINNOW_DEV_MIN") ? atoll(getenv("WFM_WINNOW_DEV_MIN")) : (int64_t)1 << 22;
   const int64_t dev_chunk = getenv("WFM_WINNOW_DEV_CHUNK") ? atoll(getenv("WFM_WINNOW_DEV_CHUNK")) : 0;  // 0: by sequence length
   int64_t dev_seqs = 0, dev_handed_back = 0, dev_chunks = 0, dev_replays = 0;
   uint32_t dev_why = 0;
@@ -1108,7 +1109,9 @@ int64_t add_minmers_core(wfm_handle_t* h, const char* const* seqs, const int64_t
       J->on_device = false;
       // the winnowing itself goes to the device (map_winnow.hip, its own thread and stream below) unless the sequence starts
       // with a k-mer whose N the reference does not notice
-      J->for_device = dev_winnow && !has_unnoticed_n(J->head.data(), (int64_t)J->head.size(), k);
+      // -- or is short: the device path costs a few milliseconds per sequence in launches and round trips whatever its
+      // length, the host's workers take short sequences side by side (WFM_WINNOW_DEV_MIN: k-mers from which on the device is used)
+      J->for_device = dev_winnow && J->nk >= dev_min && !has_unnoticed_n(J->head.data(), (int64_t)J->head.size(), k);
     }
     gpu.unlock();
     ms_thin += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count();
