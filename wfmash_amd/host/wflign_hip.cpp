@@ -458,7 +458,10 @@ int do_biwfa_alignment_batch(wfm_handle_t* h, std::vector<BiwfaRecord>& recs, co
       id = std::min(1.0, std::max(0.5, id));
       const double len = (double)std::min(r.target_length, r.query_length);
       const double dl = std::fabs((double)r.target_length - (double)r.query_length);
-      const double hint = 2.0 * penalties.gap_opening2 + penalties.gap_extension2 * dl + (1.0 - id + 0.001) * len * 6.0 + 200.0;
+      static const double per_base = getenv("WFM_HINT_PER_BASE") ? atof(getenv("WFM_HINT_PER_BASE")) : 6.0;
+      static const double id_slack = getenv("WFM_HINT_ID_SLACK") ? atof(getenv("WFM_HINT_ID_SLACK")) : 0.001;
+      static const double konst = getenv("WFM_HINT_CONST") ? atof(getenv("WFM_HINT_CONST")) : 200.0;
+      const double hint = 2.0 * penalties.gap_opening2 + penalties.gap_extension2 * dl + (1.0 - id + id_slack) * len * per_base + konst;
       p.score_hint = hint < 1e9 ? (int32_t)hint : 0;
     }
     g.probs.push_back(p);
