@@ -112,6 +112,13 @@ struct MapThinWork {
   int device = 0;
 };
 void map_thin_work_free(MapThinWork* wk);
+// Device blocks that come and go once per sequence (the kept k-mers, a sequence's records) are taken from and returned to
+// a small pool: hipMalloc / hipFree wait for the whole device, and with the winnowing on a thread and stream of its own
+// every such call would make the two threads wait for each other's kernels.  map_dev_pool_trim frees what is pooled
+// (add_minmers_core calls it before it returns: the memory belongs to whoever runs next).
+void* map_dev_pool_get(int device, size_t bytes);
+void map_dev_pool_put(int device, void* p);
+void map_dev_pool_trim();
 // W = k-mers per window (w - k + 1), s = sketch size, tau = hash threshold
 int map_prefilter_device(wfm_handle_t* h, const MapHashedSeq* q, int64_t W, int s, uint64_t tau, MapSparseSeq* out, MapThinWork* wk = nullptr);
 void map_sparse_free(MapSparseSeq* s);

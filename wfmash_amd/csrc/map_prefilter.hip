@@ -22,6 +22,7 @@
 #include <stdint.h>
 
 #include <cstring>  // rocprim's texture iterator calls host memset
+#include <mutex>
 #include <string>
 
 #include <rocprim/rocprim.hpp>
@@ -135,11 +136,60 @@ void map_thin_work_free(MapThinWork* wk) {
   }
 }
 
+namespace {
+struct DevPool {
+  struct Blk { void* p; size_t bytes; int device; bool busy; };
+  std::mutex mu;
+  std::vector<Blk> blks;
+};
+DevPool& dev_pool() { static DevPool p; return p; }
+}  // namespace
+
+void* map_dev_pool_get(int device, size_t bytes) {
+  if (bytes == 0) bytes = 16;
+  DevPool& P = dev_pool();
+  {
+    std::lock_guard<std::mutex> lk(P.mu);
+    DevPool::Blk* best = nullptr;
+    for (auto& b : P.blks)  // the smallest free block that is large enough, and not more than four times too large
+      if (!b.busy && b.device == device && b.bytes >= bytes && b.bytes <= 4 * bytes + 65536 && (!best || b.bytes < best->bytes)) best = &b;
+    if (best) { best->busy = true; return best->p; }
+  }
+  if (hipSetDevice(device) != hipSuccess) return nullptr;
+  void* p = nullptr;
+  const size_t want = bytes + bytes / 8 + 256;
+  if (hipMalloc(&p, want) != hipSuccess) return nullptr;
+  std::lock_guard<std::mutex> lk(P.mu);
+  P.blks.push_back(DevPool::Blk{p, want, device, true});
+  return p;
+}
+void map_dev_pool_put(int device, void* p) {
+  if (!p) return;
+  DevPool& P = dev_pool();
+  {
+    std::lock_guard<std::mutex> lk(P.mu);
+    for (auto& b : P.blks)
+      if (b.p == p) { b.busy = false; return; }
+  }
+  (void)hipSetDevice(device);
+  (void)hipFree(p);  // not one of the pool's
+}
+void map_dev_pool_trim() {
+  DevPool& P = dev_pool();
+  std::lock_guard<std::mutex> lk(P.mu);
+  size_t o = 0;
+  for (size_t i = 0; i < P.blks.size(); ++i) {
+    if (P.blks[i].busy) { P.blks[o++] = P.blks[i]; continue; }
+    (void)hipSetDevice(P.blks[i].device);
+    (void)hipFree(P.blks[i].p);
+  }
+  P.blks.resize(o);
+}
+
 void map_sparse_free(MapSparseSeq* s) {
-  (void)hipSetDevice(s->device);
-  if (s->d_pos) (void)hipFree(s->d_pos);
-  if (s->d_hash) (void)hipFree(s->d_hash);
-  if (s->d_strand) (void)hipFree(s->d_strand);
+  map_dev_pool_put(s->device, s->d_pos);
+  map_dev_pool_put(s->device, s->d_hash);
+  map_dev_pool_put(s->device, s->d_strand);
   s->d_pos = nullptr; s->d_hash = nullptr; s->d_strand = nullptr; s->m = 0;
 }
 
@@ -196,10 +246,10 @@ int map_prefilter_device(wfm_handle_t* h, const MapHashedSeq* q, int64_t W, int 
   HIPCHK(h, hipStreamSynchronize(st));
   out->m = m32;
   if (out->m > 0) {
-    hipError_t e = hipMalloc((void**)&out->d_pos, (size_t)out->m * 4);
-    if (e == hipSuccess) e = hipMalloc((void**)&out->d_hash, (size_t)out->m * 8);
-    if (e == hipSuccess) e = hipMalloc((void**)&out->d_strand, (size_t)out->m);
-    if (e != hipSuccess) { map_sparse_free(out); wfm_set_error(h, std::string("hipMalloc: ") + hipGetErrorString(e)); return e == hipErrorOutOfMemory ? WFM_E_NOMEM : WFM_E_HIP; }
+    out->d_pos = (uint32_t*)map_dev_pool_get(out->device, (size_t)out->m * 4);
+    out->d_hash = (uint64_t*)map_dev_pool_get(out->device, (size_t)out->m * 8);
+    out->d_strand = (int8_t*)map_dev_pool_get(out->device, (size_t)out->m);
+    if (!out->d_pos || !out->d_hash || !out->d_strand) { map_sparse_free(out); wfm_set_error(h, "out of device memory (kept k-mers)"); return WFM_E_NOMEM; }
     hipLaunchKernelGGL(pf_emit_kernel, grid_for(n), dim3(256), 0, st, q->d_hash, q->d_strand, A, B, out->d_pos, out->d_hash, out->d_strand, n);
   }
   HIPCHK(h, hipGetLastError());
@@ -212,10 +262,12 @@ int map_sparse_lower_bound(wfm_handle_t* h, const MapSparseSeq* s, const int64_t
   if (s->m == 0) { for (int i = 0; i < nq; ++i) out[i] = 0; return WFM_OK; }
   HIPCHK(h, hipSetDevice(s->device));
   hipStream_t st = stream ? stream : wfm_stream(h);
-  MapScratch sc;
-  int64_t *d_q = nullptr, *d_o = nullptr;
-  HIPCHK(h, sc.alloc(&d_q, (size_t)nq));
-  HIPCHK(h, sc.alloc(&d_o, (size_t)nq));
+  struct Pooled {
+    int device; void* p;
+    ~Pooled() { map_dev_pool_put(device, p); }
+  } blk{s->device, map_dev_pool_get(s->device, (size_t)nq * 16)};
+  if (!blk.p) { wfm_set_error(h, "out of device memory (lower bounds)"); return WFM_E_NOMEM; }
+  int64_t *d_q = (int64_t*)blk.p, *d_o = d_q + nq;
   HIPCHK(h, hipMemcpyAsync(d_q, query, (size_t)nq * 8, hipMemcpyHostToDevice, st));
   hipLaunchKernelGGL(pf_lower_bound_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, s->d_pos, s->m, d_q, nq, d_o);
   HIPCHK(h, hipMemcpyAsync(out, d_o, (size_t)nq * 8, hipMemcpyDeviceToHost, st));

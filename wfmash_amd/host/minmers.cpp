@@ -939,7 +939,7 @@ int64_t add_minmers_core(wfm_handle_t* h, const char* const* seqs, const int64_t
       if (n && sink_rc == WFM_OK) sink_rc = J->d_result ? sink.put_device(J->d_result, n) : sink.put(J->result.data(), n);
       total += n;
       if (J) J->result.release();
-      if (J && J->d_result) { (void)hipFree(J->d_result); J->d_result = nullptr; }
+      if (J && J->d_result) { map_dev_pool_put(wfm_device(h), J->d_result); J->d_result = nullptr; }
     }
   };
   std::mutex gpu_mu;  // the handle's stream and error string: this thread, and a worker that hashes a sequence again
@@ -1002,8 +1002,8 @@ int64_t add_minmers_core(wfm_handle_t* h, const char* const* seqs, const int64_t
         MapFinishInfo fi;
         wrc = map_finish_records_device(h, d_recs, n_recs, w, &finish_work, &d_fin, &n_fin, &fi, st2);
         if (wrc == WFM_OK && n_fin) {
-          if (hipMalloc((void**)&J->d_result, (size_t)n_fin * sizeof(wfm_minmer_t)) != hipSuccess ||
-              hipMemcpyAsync(J->d_result, d_fin, (size_t)n_fin * sizeof(wfm_minmer_t), hipMemcpyDeviceToDevice, st2) != hipSuccess ||
+          J->d_result = (wfm_minmer_t*)map_dev_pool_get(wfm_device(h), (size_t)n_fin * sizeof(wfm_minmer_t));
+          if (!J->d_result || hipMemcpyAsync(J->d_result, d_fin, (size_t)n_fin * sizeof(wfm_minmer_t), hipMemcpyDeviceToDevice, st2) != hipSuccess ||
               hipStreamSynchronize(st2) != hipSuccess) {
             wfm_set_error(h, "out of device memory (minmer records)");
             wrc = WFM_E_NOMEM;
@@ -1172,11 +1172,12 @@ int64_t add_minmers_core(wfm_handle_t* h, const char* const* seqs, const int64_t
   for (auto& t : pool) t.join();
   release_stitched();
   for (auto& J : jobs)
-    if (J) { if (J->on_device) { map_hashed_free(&J->dev); J->on_device = false; } map_sparse_free(&J->sparse); if (J->d_result) { (void)hipFree(J->d_result); J->d_result = nullptr; } }  // after an error
+    if (J) { if (J->on_device) { map_hashed_free(&J->dev); J->on_device = false; } map_sparse_free(&J->sparse); if (J->d_result) { map_dev_pool_put(wfm_device(h), J->d_result); J->d_result = nullptr; } }  // after an error
   map_hash_work_free(&hash_work);
   map_thin_work_free(&thin_work);
   map_winnow_work_free(&winnow_work);
   map_finish_work_free(&finish_work);
+  map_dev_pool_trim();
   if (getenv("WFM_DEBUG") && (dev_seqs || dev_handed_back))
     fprintf(stderr, "[wfm] winnowing on the device: %lld sequences in %lld chunks (WFM_WINNOW_DEV_CHUNK %lld), %lld chunks replayed after a failed speculation, %.1f ms (closing sort %s: %d levels at most, %lld ranges heap-sorted); %lld handed back to the host (why 0x%x)\n",
             (long long)dev_seqs, (long long)dev_chunks, (long long)dev_chunk, (long long)dev_replays, ms_winnow, dev_finish ? "on the device" : "on the host", dev_levels, (long long)dev_heaps,
@@ -1197,8 +1198,9 @@ int64_t add_minmers_core(wfm_handle_t* h, const char* const* seqs, const int64_t
             std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_fed).count(), stitch_max);
   }
   if (rc == WFM_OK && async_rc.load() != WFM_OK) { rc = async_rc.load(); wfm_set_error(h, "device-to-host streaming of k-mer hashes failed"); }
-  if (rc != WFM_OK) return rc;
+  if (rc != WFM_OK) { map_dev_pool_trim(); return rc; }
   flush_ready(nseq);
+  map_dev_pool_trim();  // the records of the last sequences have left their blocks by now
   if (sink_rc != WFM_OK) return sink_rc;
   return total;
 }
