@@ -16,11 +16,13 @@
 //   so the lists of the ORIGINAL arrangement stay valid.  With T = the number of such t, the swaps are the pairs
 //   (A[t], B[t]), t < T, and the returned cut is min(A[T], B[T-1]) (a missing entry counts as infinity): the left
 //   pointer's next stop is the next original element >= pivot or, if it comes first, the one swapped into B[T-1].
-// * Ranges are independent, so all ranges of one recursion depth are partitioned by one launch, one workgroup each
-//   (sortlike_level_kernel); children of more than 16 elements go to the next launch.  A range that spends its depth
-//   budget (2 floor(log2 n) levels; not seen outside adversarial inputs) is heap-sorted by the library itself on the host.
-// scripts/ has no part in this; the CPU suite holds a host restatement of these steps (map_sortlike_model) against
-// std::sort, the GPU suite holds the kernels against it.
+// * Ranges are independent, so all ranges of one recursion depth are partitioned side by side: ranges above 128 k elements by
+//   many workgroups each (huge_* kernels: counts per tile, offsets, lists, cut, swaps), ranges up to 128 k by one workgroup
+//   each (sortlike_level_kernel), and a range of at most 1 k elements by one wave that keeps it in LDS through all its
+//   remaining depths (sortlike_small_kernel).  A range that spends its depth budget (2 floor(log2 n) levels; not seen
+//   outside adversarial inputs) is heap-sorted by the library itself on the host.
+// The CPU suite holds a host restatement of these steps (map_sortlike_model) against std::sort, the GPU suite holds the
+// kernels against the host's finish_records (tests/test_minmers.py).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
