@@ -15,6 +15,8 @@ from tests import filter_cases as FC
 from wfmash_amd import capi
 
 GOLDEN = json.loads(gzip.open(os.path.join(os.path.dirname(__file__), "golden", "filter_golden.json.gz")).read())
+# sha256 of the reference's output (oracle/_ref/libref_filter.so) for the input test_large_query_passes_split_over_threads builds
+LARGE_QUERY_SHA = "3a5eafce1f19cea2bb326cd397e8a21c82290f8f13d15b322e36b55f70426a4c"
 
 
 @pytest.fixture(scope="module")
@@ -90,3 +92,47 @@ def test_sequence_id_manager_groups(fai, tmp_path):
     assert [(l.split("\t")[5], int(l.split("\t")[6])) for l in out] == FC.NAMES
     with pytest.raises(capi.WfmError):
         capi.host_filter("subset", m, fai, "absent_sequence_name", P)
+
+
+def test_large_query_passes_split_over_threads(tmp_path, monkeypatch):
+    """a chromosome-sized query: the chaining passes are split over host threads above 128 k mappings (the batch has no other
+    query to give the cores to); whatever the split, the output is the single-threaded one -- and the reference's, when its
+    code is here"""
+    import hashlib
+    fa = str(tmp_path / "pan.fa")
+    open(fa, "w").close()
+    names = [f"hap{i}#1#chr1" for i in range(1, 9)]
+    with open(fa + ".fai", "w") as f:
+        for n in names:
+            f.write(f"{n}\t70000000\t0\t60\t61\n")
+    rng = np.random.default_rng(1)
+    nf = 60000
+    recs = []
+    for t in range(1, 8):
+        keep = rng.random(nf) < 0.995
+        q = np.arange(nf, dtype=np.int64)[keep] * 1000
+        m = np.zeros(int(keep.sum()), dtype=FC.MAPPING_DTYPE)
+        m["refSeqId"] = t
+        m["refStartPos"] = np.maximum(q + rng.integers(-40, 41, len(q)) + t * 137, 0)
+        m["queryStartPos"] = q
+        m["blockLength"] = 1000
+        m["n_merged"] = 1
+        m["conservedSketches"] = rng.integers(15, 24, len(q))
+        m["nucIdentity"] = rng.integers(9970, 10000, len(q))
+        m["kmerComplexity"] = 100
+        if t == 3:  # an inverted stretch: both strands of one target
+            m["flags"][20000:26000] = 1
+        recs.append(m)
+    allm = np.concatenate(recs)
+    allm = allm[np.lexsort((allm["refSeqId"], allm["queryStartPos"]))]  # the order the GPU stages deliver: per fragment, by target
+    assert len(allm) > (1 << 17)
+    P = capi.map_default_params()
+    out = {}
+    for threads in ("1", "3", "8"):
+        monkeypatch.setenv("WFM_FILTER_THREADS", threads)
+        out[threads] = capi.host_filter("subset", allm, fa, names[0], P)
+    assert out["1"] == out["3"] == out["8"] and out["1"].count("\n") > 5000
+    if pyfilter.have_ref():
+        assert out["8"] == pyfilter.ref_filter("subset", allm, fa, names[0], P)
+    else:
+        assert hashlib.sha256(out["8"].encode()).hexdigest() == LARGE_QUERY_SHA

@@ -171,6 +171,7 @@ char* wfmh_test_filter(const char* stage, const wfm_mapping_t* maps, int64_t n, 
     const skch::SequenceIdManager ids({std::string(fasta)}, {std::string(fasta)}, {}, {std::string()}, delim);
     skch::MappingResultsVector_t v((size_t)n);
     if (n) std::memcpy(v.data(), maps, (size_t)n * sizeof(wfm_mapping_t));
+    skch::set_filter_threads(getenv("WFM_FILTER_THREADS") ? atoi(getenv("WFM_FILTER_THREADS")) : 1);  // tests: the split passes
     const skch::seqno_t qid = ids.getSequenceId(query_name);
     const skch::offset_t qlen = ids.getSequenceLength(qid);
     std::ostringstream os;

@@ -1,6 +1,9 @@
 #include "map_filter.hpp"
 
 #include <algorithm>
+#include <chrono>
+#include <thread>
+#include <atomic>
 #include <cmath>
 #include <limits>
 #include <map>
@@ -273,17 +276,45 @@ class ChainSets {
   std::vector<uint64_t> rank_;
 };
 
+// Host threads this thread may use inside one call (set_filter_threads): a batch with one chromosome-sized query has
+// nothing else to give its cores to.  The passes below are split into ranges; what they compute does not depend on it.
+thread_local int tl_filter_threads = 1;
+
+template <class F>
+void par_ranges(size_t n, F fn) {  // fn(lo, hi) over a partition of [0, n)
+  const size_t T = n >= ((size_t)1 << 17) ? (size_t)std::min<int>(tl_filter_threads, 32) : 1;
+  if (T <= 1) { fn((size_t)0, n); return; }
+  std::vector<std::thread> pool;
+  for (size_t t = 1; t < T; ++t) pool.emplace_back(fn, n * t / T, n * (t + 1) / T);
+  fn((size_t)0, n / T);
+  for (auto& th : pool) th.join();
+}
+
 template <typename T>
 std::vector<T> permuted(const std::vector<T>& in, const std::vector<uint32_t>& p) {
   std::vector<T> out(in.size());
-  for (size_t i = 0; i < p.size(); ++i) out[i] = in[p[i]];
+  par_ranges(p.size(), [&](size_t lo, size_t hi) { for (size_t i = lo; i < hi; ++i) out[i] = in[p[i]]; });
   return out;
+}
+
+// is less(q[i-1], q[i]) true for every i?
+template <class Less>
+bool strictly_ascending(const std::vector<uint32_t>& q, Less less) {
+  std::atomic<bool> ok{true};
+  par_ranges(q.size(), [&](size_t lo, size_t hi) {
+    for (size_t i = std::max<size_t>(lo, 1); i < hi && ok.load(std::memory_order_relaxed); ++i)
+      if (!less(q[i - 1], q[i])) ok.store(false, std::memory_order_relaxed);
+  });
+  return ok.load();
 }
 
 // Steps 1-4 of mergeMappingsInRange[WithChains] (mappingFilter.hpp:402-498, :593-675): sorts
 // readMappings into chains and returns each mapping's chain representative.
 std::vector<offset_t> chain_mappings(MappingResultsVector_t& readMappings, int max_dist, const Parameters& param) {
   const size_t n = readMappings.size();
+  static const bool tdbg = getenv("WFM_FILTER_TIMES") != nullptr;
+  auto tnow = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  double tt[8] = {0}; int ti = 0; tt[ti++] = tnow();
   std::vector<offset_t> chainOf(n);
   std::iota(chainOf.begin(), chainOf.end(), (offset_t)0);
   std::vector<double> linkScore(n, std::numeric_limits<double>::max());
@@ -296,7 +327,9 @@ std::vector<offset_t> chain_mappings(MappingResultsVector_t& readMappings, int m
     // a third of the memory; same comparisons, same permutation
     struct Key { uint32_t ref; int32_t strand; uint32_t q, r; };
     std::vector<Key> key(n);
-    for (size_t i = 0; i < n; ++i) key[i] = {(uint32_t)readMappings[i].refSeqId, (int32_t)readMappings[i].strand(), (uint32_t)readMappings[i].queryStartPos, (uint32_t)readMappings[i].refStartPos};
+    par_ranges(n, [&](size_t lo, size_t hi) {
+      for (size_t i = lo; i < hi; ++i) key[i] = {(uint32_t)readMappings[i].refSeqId, (int32_t)readMappings[i].strand(), (uint32_t)readMappings[i].queryStartPos, (uint32_t)readMappings[i].refStartPos};
+    });
     auto less = [&](uint32_t i, uint32_t j) {
       const Key &a = key[i], &b = key[j];
       return std::tie(a.ref, a.strand, a.q, a.r) < std::tie(b.ref, b.strand, b.q, b.r);
@@ -307,57 +340,92 @@ std::vector<offset_t> chain_mappings(MappingResultsVector_t& readMappings, int m
     // or inversion falls back to std::sort on the original order, whose tie order the reference's output has.
     bool sorted_fast = false;
     {
-      std::vector<std::pair<uint64_t, uint32_t>> groups;  // (ref, strand) -> count, in key order
-      std::map<uint64_t, uint32_t> count;
-      for (size_t i = 0; i < n; ++i) ++count[((uint64_t)key[i].ref << 32) | ((uint32_t)key[i].strand ^ 0x80000000u)];
-      std::map<uint64_t, size_t> start;
-      size_t at = 0;
-      for (const auto& kv : count) { start[kv.first] = at; at += kv.second; }
+      // groups in key order: (ref, strand) with strand -1 before +1; a flat table when the ids are small and the strands
+      // are the two the mapper knows, an ordered map otherwise
       std::vector<uint32_t> q(n);
-      for (size_t i = 0; i < n; ++i) q[start[((uint64_t)key[i].ref << 32) | ((uint32_t)key[i].strand ^ 0x80000000u)]++] = (uint32_t)i;
-      sorted_fast = true;
-      for (size_t i = 1; i < n && sorted_fast; ++i) sorted_fast = less(q[i - 1], q[i]);
+      uint32_t max_ref = 0;
+      bool two_strands = true;
+      for (size_t i = 0; i < n; ++i) { max_ref = std::max(max_ref, key[i].ref); two_strands &= key[i].strand == 1 || key[i].strand == -1; }
+      if (two_strands && (uint64_t)max_ref * 2 + 2 <= ((uint64_t)1 << 22)) {
+        std::vector<size_t> start((size_t)max_ref * 2 + 3, 0);
+        auto slot = [](const Key& k) { return (size_t)k.ref * 2 + (k.strand > 0 ? 1 : 0); };
+        for (size_t i = 0; i < n; ++i) ++start[slot(key[i]) + 1];
+        for (size_t g = 1; g < start.size(); ++g) start[g] += start[g - 1];
+        for (size_t i = 0; i < n; ++i) q[start[slot(key[i])]++] = (uint32_t)i;
+      } else {
+        std::map<uint64_t, uint32_t> count;
+        for (size_t i = 0; i < n; ++i) ++count[((uint64_t)key[i].ref << 32) | ((uint32_t)key[i].strand ^ 0x80000000u)];
+        std::map<uint64_t, size_t> start;
+        size_t at = 0;
+        for (const auto& kv : count) { start[kv.first] = at; at += kv.second; }
+        for (size_t i = 0; i < n; ++i) q[start[((uint64_t)key[i].ref << 32) | ((uint32_t)key[i].strand ^ 0x80000000u)]++] = (uint32_t)i;
+      }
+      sorted_fast = strictly_ascending(q, less);
       if (sorted_fast) p.swap(q);
     }
     if (!sorted_fast) std::sort(p.begin(), p.end(), less);
   }
+  tt[ti++] = tnow();
   readMappings = permuted(readMappings, p);
   chainOf = permuted(chainOf, p);
+  tt[ti++] = tnow();
 
-  ChainSets sets(n);
+  // Within one (target, strand) run every mapping links to its closest admissible successor.  The runs do not see each
+  // other, so they are worked through side by side; the unions are replayed afterwards in the reference's order (a
+  // mapping's link is final before the loop reaches it: only its predecessors set it), because the representative a
+  // chain ends up with -- a sort key of the output -- depends on that order.
+  std::vector<std::pair<size_t, size_t>> runs;
   for (size_t lo = 0; lo < n;) {
     size_t hi = lo + 1;
     while (hi < n && readMappings[hi].refSeqId == readMappings[lo].refSeqId && readMappings[hi].strand() == readMappings[lo].strand()) ++hi;
-    // within one (target, strand) run every mapping links to its closest admissible successor
-    for (size_t i = lo; i < hi; ++i) {
-      if (linkScore[i] != std::numeric_limits<double>::max()) sets.unite(chainOf[i], linkFrom[i]);
-      double best = std::numeric_limits<double>::max();
-      size_t best_j = hi;
-      const MappingResult& a = readMappings[i];
-      for (size_t j = i + 1; j < hi; ++j) {
-        const MappingResult& b = readMappings[j];
-        if (b.queryStartPos > a.queryEndPos() + max_dist) break;
-        int64_t q_dist = b.queryStartPos - a.queryEndPos();
-        if (q_dist < 0) q_dist = 0;
-        const int64_t r_dist = (a.strand() == strnd::FWD) ? (b.refStartPos - a.refEndPos()) : (a.refStartPos - b.refEndPos());
-        if (q_dist <= max_dist && r_dist >= -param.windowLength / 5 && r_dist <= max_dist) {
-          const double d2 = (double)q_dist * q_dist + (double)r_dist * r_dist;
-          if (d2 < best && d2 < linkScore[j]) { best = d2; best_j = j; }
-        }
-      }
-      if (best_j != hi) { linkScore[best_j] = best; linkFrom[best_j] = chainOf[i]; }
-    }
+    runs.emplace_back(lo, hi);
     lo = hi;
   }
-  for (size_t i = 0; i < n; ++i)
-    if (linkScore[i] != std::numeric_limits<double>::max()) sets.unite(chainOf[i], linkFrom[i]);
+  {
+    std::atomic<size_t> next{0};
+    auto work = [&]() {
+      for (size_t rn; (rn = next.fetch_add(1)) < runs.size();) {
+        const size_t lo = runs[rn].first, hi = runs[rn].second;
+        for (size_t i = lo; i < hi; ++i) {
+          double best = std::numeric_limits<double>::max();
+          size_t best_j = hi;
+          const MappingResult& a = readMappings[i];
+          for (size_t j = i + 1; j < hi; ++j) {
+            const MappingResult& b = readMappings[j];
+            if (b.queryStartPos > a.queryEndPos() + max_dist) break;
+            int64_t q_dist = b.queryStartPos - a.queryEndPos();
+            if (q_dist < 0) q_dist = 0;
+            const int64_t r_dist = (a.strand() == strnd::FWD) ? (b.refStartPos - a.refEndPos()) : (a.refStartPos - b.refEndPos());
+            if (q_dist <= max_dist && r_dist >= -param.windowLength / 5 && r_dist <= max_dist) {
+              const double d2 = (double)q_dist * q_dist + (double)r_dist * r_dist;
+              if (d2 < best && d2 < linkScore[j]) { best = d2; best_j = j; }
+            }
+          }
+          if (best_j != hi) { linkScore[best_j] = best; linkFrom[best_j] = chainOf[i]; }
+        }
+      }
+    };
+    const size_t T = n >= ((size_t)1 << 17) ? std::min<size_t>((size_t)tl_filter_threads, runs.size()) : 1;
+    std::vector<std::thread> pool;
+    for (size_t t = 1; t < T; ++t) pool.emplace_back(work);
+    work();
+    for (auto& th : pool) th.join();
+  }
+  tt[ti++] = tnow();
+  ChainSets sets(n);
+  for (int pass = 0; pass < 2; ++pass)  // the loop's own unions, then the closing pass over everything (a repeat: no change)
+    for (size_t i = 0; i < n; ++i)
+      if (linkScore[i] != std::numeric_limits<double>::max()) sets.unite(chainOf[i], linkFrom[i]);
   for (size_t i = 0; i < n; ++i) chainOf[i] = (offset_t)sets.find(chainOf[i]);
+  tt[ti++] = tnow();
 
   std::iota(p.begin(), p.end(), 0u);
   {
     struct Key { offset_t chain; uint32_t q, r; };
     std::vector<Key> key(n);
-    for (size_t i = 0; i < n; ++i) key[i] = {chainOf[i], (uint32_t)readMappings[i].queryStartPos, (uint32_t)readMappings[i].refStartPos};
+    par_ranges(n, [&](size_t lo, size_t hi) {
+      for (size_t i = lo; i < hi; ++i) key[i] = {chainOf[i], (uint32_t)readMappings[i].queryStartPos, (uint32_t)readMappings[i].refStartPos};
+    });
     auto less = [&](uint32_t i, uint32_t j) {
       const Key &a = key[i], &b = key[j];
       return std::tie(a.chain, a.q, a.r) < std::tie(b.chain, b.q, b.r);
@@ -371,13 +439,18 @@ std::vector<offset_t> chain_mappings(MappingResultsVector_t& readMappings, int m
       for (size_t i = 0; i < n; ++i) ++start[(size_t)key[i].chain + 1];
       for (size_t c = 0; c < n; ++c) start[c + 1] += start[c];
       for (size_t i = 0; i < n; ++i) q[start[(size_t)key[i].chain]++] = (uint32_t)i;
-      for (size_t i = 1; i < n && sorted_fast; ++i) sorted_fast = less(q[i - 1], q[i]);
+      sorted_fast = strictly_ascending(q, less);
       if (sorted_fast) p.swap(q);
     }
     if (!sorted_fast) std::sort(p.begin(), p.end(), less);
   }
+  tt[ti++] = tnow();
   readMappings = permuted(readMappings, p);
   chainOf = permuted(chainOf, p);
+  tt[ti++] = tnow();
+  if (tdbg && n >= 100000)
+    fprintf(stderr, "[filter] chain_mappings n=%zu, %d threads: order %.1f, permute %.1f, links %.1f, unions %.1f, order %.1f, permute %.1f ms\n", n, tl_filter_threads,
+            tt[1] - tt[0], tt[2] - tt[1], tt[3] - tt[2], tt[4] - tt[3], tt[5] - tt[4], tt[6] - tt[5]);
   return chainOf;
 }
 
@@ -571,6 +644,8 @@ void MappingFilterUtils::filterByScaffolds(MappingResultsVector_t& readMappings,
 // ---------------------------------------------------------------------------------------------
 // Map::filterSubsetMappings (computeMap.hpp:1076-1165)
 // ---------------------------------------------------------------------------------------------
+void set_filter_threads(int threads) { tl_filter_threads = std::max(1, threads); }
+
 FilteredMappingsResult filterSubsetMappings(MappingResultsVector_t& mappings, const Parameters& param, const SequenceIdManager& idManager,
                                             offset_t queryLen) {
   FilteredMappingsResult result;

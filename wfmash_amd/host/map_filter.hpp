@@ -47,6 +47,9 @@ struct FilteredMappingsResult {
   MappingResultsVector_t nonMergedMappings, mergedMappings;
   ChainInfoVector_t nonMergedChainInfo, mergedChainInfo;
 };
+// host threads the CALLING thread may use inside filterSubsetMappings (default 1): a batch with a single long query
+void set_filter_threads(int threads);
+
 // Map::filterSubsetMappings: everything between a query's raw L2 mappings and what is printed
 FilteredMappingsResult filterSubsetMappings(MappingResultsVector_t& mappings, const Parameters& param, const SequenceIdManager& idManager,
                                             offset_t queryLen);

@@ -376,7 +376,9 @@ int Map::mapQuery(MapSummary* summary) {
         for (const auto& q : bq) bo.ids.push_back(q.id);
         std::vector<QueryOut>& qout = bo.q;
         std::atomic<size_t> next{0};
+        const int nt_filter = (int)std::min<size_t>((size_t)threads_each, bq.size());
         auto work = [&]() {
+          set_filter_threads(std::max(1, threads_each / std::max(1, nt_filter)));  // few queries: each may use the idle threads
           for (size_t qn; (qn = next.fetch_add(1)) < bq.size();) {
             const BatchQuery& q = bq[qn];
             MappingResultsVector_t results;
