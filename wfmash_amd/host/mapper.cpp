@@ -382,6 +382,7 @@ int Map::mapQuery(MapSummary* summary) {
           for (size_t qn; (qn = next.fetch_add(1)) < bq.size();) {
             const BatchQuery& q = bq[qn];
             MappingResultsVector_t results;
+            results.reserve(first_map[qn + 1] - first_map[qn]);
             for (size_t m = first_map[qn]; m < first_map[qn + 1]; ++m) {
               MappingResult r;
               std::memcpy(&r, &maps[m], sizeof(r));

@@ -42,6 +42,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <deque>
+#include <functional>
 #include <limits>
 #include <map>
 #include <memory>
@@ -781,8 +782,11 @@ struct MinmerSink {
   virtual int put_device(const wfm_minmer_t* d_recs, int64_t n) = 0;  // the same, records on the device
 };
 
+// later: (optional) receives the release of the device work buffers and of the block pool instead of it being done before
+// the return -- the caller that goes on to allocate gigabytes (the index) runs it afterwards: memory the driver has just
+// been handed back is scrubbed in the background, and an allocation that follows on its heels waits for that
 int64_t add_minmers_core(wfm_handle_t* h, const char* const* seqs, const int64_t* lens, const int32_t* seq_ids, int64_t nseq,
-                         int k, int w, int s, int threads, MinmerSink& sink, int64_t* counts) {
+                         int k, int w, int s, int threads, MinmerSink& sink, int64_t* counts, std::function<void()>* later = nullptr) {
   if (!h || nseq < 0 || (nseq && (!seqs || !lens || !seq_ids))) return WFM_E_ARG;
   if (k < 1 || k > 32 || w < k || s < 1) { wfm_set_error(h, "need 1 <= k <= 32, w >= k, s >= 1"); return WFM_E_UNSUPPORTED; }
   const int nthreads = std::max(1, threads);
@@ -1173,11 +1177,13 @@ int64_t add_minmers_core(wfm_handle_t* h, const char* const* seqs, const int64_t
   release_stitched();
   for (auto& J : jobs)
     if (J) { if (J->on_device) { map_hashed_free(&J->dev); J->on_device = false; } map_sparse_free(&J->sparse); if (J->d_result) { map_dev_pool_put(wfm_device(h), J->d_result); J->d_result = nullptr; } }  // after an error
-  map_hash_work_free(&hash_work);
-  map_thin_work_free(&thin_work);
-  map_winnow_work_free(&winnow_work);
-  map_finish_work_free(&finish_work);
-  map_dev_pool_trim();
+  auto release_work = [hash_work, thin_work, winnow_work, finish_work]() mutable {
+    map_hash_work_free(&hash_work);
+    map_thin_work_free(&thin_work);
+    map_winnow_work_free(&winnow_work);
+    map_finish_work_free(&finish_work);
+    map_dev_pool_trim();
+  };
   if (getenv("WFM_DEBUG") && (dev_seqs || dev_handed_back))
     fprintf(stderr, "[wfm] winnowing on the device: %lld sequences in %lld chunks (WFM_WINNOW_DEV_CHUNK %lld), %lld chunks replayed after a failed speculation, %.1f ms (closing sort %s: %d levels at most, %lld ranges heap-sorted); %lld handed back to the host (why 0x%x)\n",
             (long long)dev_seqs, (long long)dev_chunks, (long long)dev_chunk, (long long)dev_replays, ms_winnow, dev_finish ? "on the device" : "on the host", dev_levels, (long long)dev_heaps,
@@ -1198,9 +1204,9 @@ int64_t add_minmers_core(wfm_handle_t* h, const char* const* seqs, const int64_t
             std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_fed).count(), stitch_max);
   }
   if (rc == WFM_OK && async_rc.load() != WFM_OK) { rc = async_rc.load(); wfm_set_error(h, "device-to-host streaming of k-mer hashes failed"); }
-  if (rc != WFM_OK) { map_dev_pool_trim(); return rc; }
-  flush_ready(nseq);
-  map_dev_pool_trim();  // the records of the last sequences have left their blocks by now
+  if (rc != WFM_OK) { release_work(); return rc; }
+  flush_ready(nseq);  // (the records of the last sequences leave their pooled blocks here)
+  if (later) *later = release_work; else release_work();
   if (sink_rc != WFM_OK) return sink_rc;
   return total;
 }
@@ -1263,11 +1269,13 @@ extern "C" int wfm_index_build_sequences(wfm_handle_t* h, const char* const* seq
   int64_t bases = 0;
   for (int64_t i = 0; i < nseq && lens; ++i) bases += std::max<int64_t>(0, lens[i]);
   DeviceSink sink(h, bases / std::max(1, w) * (int64_t)s * 5 / 2 + 4096);  // about 2 s / w intervals per base
-  const int64_t n = add_minmers_core(h, seqs, lens, seq_ids, nseq, k, w, s, threads, sink, nullptr);
-  if (n < 0) return (int)n;
-  if (n_windows) *n_windows = n;
-  if (n == 0) return WFM_OK;  // no index: *out stays NULL
-  return map_index_build_device(h, sink.d, n, max_kmer_freq, out);
+  std::function<void()> release;
+  const int64_t n = add_minmers_core(h, seqs, lens, seq_ids, nseq, k, w, s, threads, sink, nullptr, &release);
+  int rc = n < 0 ? (int)n : WFM_OK;
+  if (n_windows && n >= 0) *n_windows = n;
+  if (n > 0) rc = map_index_build_device(h, sink.d, n, max_kmer_freq, out);  // n == 0: no index, *out stays NULL
+  if (release) release();
+  return rc;
 }
 
 // Test hook (CPU test-suite): the host winnowing stage on caller-supplied k-mer hashes.
