@@ -372,3 +372,55 @@ def test_finish_records_on_the_device_equal_the_host(gpu):
     exp = capi.host_finish_records(raw, 1000)
     got, levels, heaps = gpu.finish_records(raw, 1000)
     assert got.tobytes() == exp.tobytes(), (levels, heaps)
+
+
+def test_sortlike_model_on_arbitrary_keys():
+    """property: for ANY multiset of keys in ANY order the restated partition steps leave what std::sort leaves (the
+    derivation in map_finish.hip -- lists A / B, T, the cut -- does not lean on the shape of winnowing records)"""
+    from hypothesis import given, settings, strategies as st
+
+    @settings(max_examples=150, deadline=None)
+    @given(st.lists(st.tuples(st.integers(0, 40), st.integers(0, 3)), min_size=0, max_size=1500), st.integers(0, 2))
+    def check(pairs, shape):
+        n = len(pairs)
+        recs = np.zeros(n, dtype=capi.MINMER_DTYPE)
+        if n:
+            a = np.array(pairs, dtype=np.int64)
+            if shape == 1:
+                a = a[np.lexsort((a[:, 1], a[:, 0]))]      # already sorted
+            elif shape == 2:
+                a = a[np.lexsort((a[:, 1], a[:, 0]))][::-1]  # descending
+            recs["wpos"] = a[:, 0]
+            recs["wpos_end"] = a[:, 0] + a[:, 1]
+        recs["hash"] = np.arange(n, dtype=np.uint64)  # tells tied records apart
+        assert capi.host_sortlike_model(recs).tobytes() == capi.host_sort_records(recs, 1).tobytes()
+
+    check()
+
+
+def test_device_winnower_model_on_arbitrary_sequences():
+    """property: the kernel's control flow (host model) over ANY chunking of short, repeat- and N-rich sequences gives the
+    one-stream records, or hands the sequence back for the one reason it may (an unnoticed N among the first k-mers)"""
+    from hypothesis import given, settings, strategies as st
+
+    unit = st.text(alphabet="ACGT", min_size=1, max_size=12)
+
+    @settings(max_examples=60, deadline=None)
+    @given(st.lists(st.one_of(st.text(alphabet="ACGT", min_size=20, max_size=400), st.tuples(unit, st.integers(2, 60)).map(lambda t: t[0] * t[1]),
+                              st.integers(1, 30).map(lambda n: "N" * n)), min_size=3, max_size=25),
+           st.sampled_from([(15, 64, 5), (11, 40, 3), (15, 128, 12)]), st.integers(1, 6), st.booleans())
+    def check(parts, kws, chunk_windows, force):
+        k, w, s = kws
+        seq = "".join(parts).encode()
+        if len(seq) < w + k:
+            return
+        h, st_ = pymap.hash_kmers(capi_norm(seq), k)
+        one = capi.host_winnow(seq, k, w, s, 3, h, st_)
+        chunk = chunk_windows * w + 7
+        got, why = capi.host_winnow_model(seq, k, w, s, 3, h, st_, 1.5, -chunk if force else chunk)
+        if got is None:
+            assert why == 1 << 31, hex(why)
+            return
+        assert got.tobytes() == one.tobytes()
+
+    check()
