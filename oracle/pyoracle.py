@@ -62,6 +62,8 @@ def lib():
         L.wfo_align_end2end_comp.argtypes = [cp, ci, cp, ci, PP, ci, ci, C.c_char_p, pi, pi, SP]
         L.wfo_find_breakpoint.restype = ci
         L.wfo_find_breakpoint.argtypes = [cp, ci, cp, ci, PP, ci, ci, C.POINTER(Breakpoint), SP]
+        L.wfo_find_breakpoint_bounded.restype = ci
+        L.wfo_find_breakpoint_bounded.argtypes = [cp, ci, cp, ci, PP, ci, ci, ci, C.POINTER(Breakpoint), SP]
         L.wfo_ops_score.restype = C.c_int64
         L.wfo_ops_score.argtypes = [cp, ci, PP]
         L.wfo_ops_check.restype = ci
@@ -122,6 +124,15 @@ def find_breakpoint(pattern: bytes, text: bytes, comp_begin=0, comp_end=0, pen=N
     bp, st = Breakpoint(), Stats()
     rc = lib().wfo_find_breakpoint(pattern, len(pattern), text, len(text), C.byref(p), comp_begin, comp_end,
                                    C.byref(bp), C.byref(st))
+    return rc, bp, st
+
+
+def find_breakpoint_bounded(pattern: bytes, text: bytes, sub: int, comp_begin=0, comp_end=0, pen=None):
+    """the product's form of the breakpoint search under a bound of the score (rows cut to what can stay under it)"""
+    p = _pen(pen)
+    bp, st = Breakpoint(), Stats()
+    rc = lib().wfo_find_breakpoint_bounded(pattern, len(pattern), text, len(text), C.byref(p), comp_begin, comp_end, sub,
+                                           C.byref(bp), C.byref(st))
     return rc, bp, st
 
 

@@ -69,6 +69,7 @@ typedef struct {
   int32_t* nullrow_mem;
   int32_t* nullrow;       /* valid for -plen-4 .. tlen+4 */
   wfo_stats_t* st;
+  int bounded, sub;       /* wfo_find_breakpoint_bounded: rows only hold |k - (tlen - plen)| <= sub - s */
 } al_t;
 
 /* ------------------------------------------------------------------ */
@@ -226,6 +227,14 @@ static int compute_step(al_t* a, int s) {
   if (i2e)  { lo = MINI(lo, i2e->lo + 1);  hi = MAXI(hi, i2e->hi + 1); }
   if (d1e)  { lo = MINI(lo, d1e->lo - 1);  hi = MAXI(hi, d1e->hi - 1); }
   if (d2e)  { lo = MINI(lo, d2e->lo - 1);  hi = MAXI(hi, d2e->hi - 1); }
+  if (a->bounded) {
+    /* The product's score bound (wfmash_amd/csrc/wfa_kernels.hip, struct Rng): a cell from which the end diagonal is out of
+     * reach within the bound is not computed.  Not part of the reference's algorithm: this branch exists so that the claim
+     * "the bound does not change the breakpoint" can be checked on the CPU (tests/test_oracle_wfa.py). */
+    const int kinv = a->tlen - a->plen;
+    lo = MAXI(lo, kinv - (a->sub - s));
+    hi = MINI(hi, kinv + (a->sub - s));
+  }
   if (lo > hi) { /* cannot happen with a non-null input, keep defensive */
     for (int c = 0; c < 5; ++c) set_wf(a, c, s, NULL);
     return ST_OK;
@@ -580,8 +589,17 @@ static void overlap(const al_t* a0, const al_t* a1, int s0, int s1, int fwd0, wf
 }
 
 /* wavefront_bialign_find_breakpoint */
+static int find_breakpoint_sub(const char* p, int plen, const char* t, int tlen, const wfo_penalties_t* pen,
+                               int comp_begin, int comp_end, wfo_breakpoint_t* bp, wfo_stats_t* st, int bounded, int sub);
 static int find_breakpoint(const char* p, int plen, const char* t, int tlen, const wfo_penalties_t* pen,
                            int comp_begin, int comp_end, wfo_breakpoint_t* bp, wfo_stats_t* st) {
+  return find_breakpoint_sub(p, plen, t, tlen, pen, comp_begin, comp_end, bp, st, 0, 0);
+}
+/* bounded != 0: the product's form of the search under an upper bound `sub` of the score -- rows cut as above, and the
+ * second loop starts as if a breakpoint of score sub + 1 were in hand.  Returns ST_OK with bp->score <= sub, or
+ * ST_UNREACHABLE when nothing lies within the bound. */
+static int find_breakpoint_sub(const char* p, int plen, const char* t, int tlen, const wfo_penalties_t* pen,
+                               int comp_begin, int comp_end, wfo_breakpoint_t* bp, wfo_stats_t* st, int bounded, int sub) {
   al_t f, r;
   int rc = al_init(&f, p, plen, t, tlen, pen, 1, 0, st);
   if (rc != ST_OK) { al_free(&f); return rc; }
@@ -589,12 +607,14 @@ static int find_breakpoint(const char* p, int plen, const char* t, int tlen, con
   if (rc != ST_OK) { al_free(&f); al_free(&r); return rc; }
   f.comp_begin = comp_begin; f.comp_end = comp_end;
   r.comp_begin = comp_end;   r.comp_end = comp_begin;
+  f.bounded = r.bounded = bounded; f.sub = r.sub = sub;
   rc = init_wavefronts(&f); if (rc == ST_OK) rc = init_wavefronts(&r);
   if (rc != ST_OK) { al_free(&f); al_free(&r); return rc; }
   const int max_antidiag = plen + tlen - 1;
   const int64_t max_steps = (int64_t)(pen->o2 + pen->o1) * 4 + (int64_t)(plen + tlen + 2) * MAXI(pen->x, MAXI(pen->e1, pen->e2)) * 2 + 256;
   int sf = 0, sr = 0, fmax = 0, rmax = 0, mak = 0, fin;
-  bp->score = INT_MAX;
+  bp->score = bounded ? sub + 1 : INT_MAX;
+  bp->component = -1;
   fin = extend_step(&f, sf, &fmax, 1);
   if (fin == 1) { al_free(&f); al_free(&r); return ST_END_REACHED; }
   fin = extend_step(&r, sr, &rmax, 1);
@@ -615,6 +635,7 @@ static int find_breakpoint(const char* p, int plen, const char* t, int tlen, con
     if (rmax < mak) rmax = mak;
     last_fwd = 0;
     if ((int64_t)sf + sr > max_steps) { rc = ST_UNREACHABLE; goto done; }
+    if (bounded && 2 * sf > sub + 128) { rc = ST_UNREACHABLE; goto done; }  /* the product gives up here too */
   }
   {
     const int scope = f.scope;
@@ -638,6 +659,7 @@ static int find_breakpoint(const char* p, int plen, const char* t, int tlen, con
       last_fwd = 1;
     }
   }
+  if (bounded && bp->component < 0) rc = ST_UNREACHABLE;  /* the loop ended on the stand-in, no breakpoint was taken */
 done:
   al_free(&f); al_free(&r);
   return rc;
@@ -702,6 +724,12 @@ int wfo_find_breakpoint(const char* pattern, int plen, const char* text, int tle
                         const wfo_penalties_t* pen, int comp_begin, int comp_end,
                         wfo_breakpoint_t* bp, wfo_stats_t* stats) {
   return find_breakpoint(pattern, plen, text, tlen, pen, comp_begin, comp_end, bp, stats);
+}
+
+int wfo_find_breakpoint_bounded(const char* pattern, int plen, const char* text, int tlen,
+                                const wfo_penalties_t* pen, int comp_begin, int comp_end, int sub,
+                                wfo_breakpoint_t* bp, wfo_stats_t* stats) {
+  return find_breakpoint_sub(pattern, plen, text, tlen, pen, comp_begin, comp_end, bp, stats, 1, sub);
 }
 
 int wfo_align_end2end_biwfa(const char* pattern, int plen, const char* text, int tlen,

@@ -102,6 +102,13 @@ typedef struct {
 int wfo_find_breakpoint(const char* pattern, int plen, const char* text, int tlen,
                         const wfo_penalties_t* pen, int comp_begin, int comp_end,
                         wfo_breakpoint_t* bp, wfo_stats_t* stats);
+/* The same search under an upper bound `sub` of the score, as the PRODUCT runs it (not the reference): rows only hold the
+ * diagonals from which the end diagonal is within reach, |k - (tlen - plen)| <= sub - s, and the overlap loop starts as
+ * if a breakpoint of score sub + 1 were in hand.  The claim under test: for sub >= the unbounded breakpoint's score the
+ * result is the unbounded one, field for field; below it nothing is found (a negative status). */
+int wfo_find_breakpoint_bounded(const char* pattern, int plen, const char* text, int tlen,
+                                const wfo_penalties_t* pen, int comp_begin, int comp_end, int sub,
+                                wfo_breakpoint_t* bp, wfo_stats_t* stats);
 
 /* Score implied by an op string under the reference's cost model
  * (wflign_alignment.cpp:680-722: a gap run of length L costs

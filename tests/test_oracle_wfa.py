@@ -144,3 +144,50 @@ def test_legacy_reads_fixture_is_plausible(oracle):
         assert rc == 0 and sc <= oracle.ops_score(bytes(fixed))
         n += 1
     assert n >= 1
+
+
+def test_a_score_bound_does_not_change_the_breakpoint(oracle):
+    """The product cuts its wavefronts to the diagonals from which the end is within reach of a score bound (children of a
+    BiWFA split: the score their parent found + two gap openings; roots: the caller's guess) and starts the overlap loop
+    as if a breakpoint just above the bound were in hand.  The claim -- same breakpoint, field for field, whenever the
+    bound holds; nothing found when it does not -- is checked here on the CPU restatement of the reference's loop, with
+    the cut and the stand-in added to it (oracle/wfa2p.c: wfo_find_breakpoint_bounded), over padded records, structural
+    differences, and begin / end components as the recursion produces them."""
+    rng = random.Random(77)
+    fields = ("score", "score_forward", "score_reverse", "k_forward", "k_reverse", "offset_forward", "offset_reverse", "component")
+    checked = failed_as_expected = fewer_cells = 0
+    for i in range(260):
+        L = rng.choice([300, 900, 2500])
+        core = synth.random_dna(9000 + i, L)
+        q = synth.mutate(core, rng.choice([0.002, 0.02, 0.08]), 31 * i + 1)
+        shape = i % 4
+        if shape == 0:      # a query against its padded window: two end gaps
+            tgt = synth.random_dna(50000 + i, rng.randrange(20, 400)) + core + synth.random_dna(60000 + i, rng.randrange(20, 400))
+        elif shape == 1:    # one-sided padding
+            tgt = core + synth.random_dna(60000 + i, rng.randrange(50, 600))
+        elif shape == 2:    # a structural difference in the middle
+            cut = rng.randrange(50, 300)
+            tgt, q = core, q[:len(q) // 2] + q[len(q) // 2 + cut:]
+        else:               # balanced
+            tgt = core
+        constrained = i % 3 == 0
+        cb, ce = (rng.randrange(0, 5), rng.randrange(0, 5)) if constrained else (0, 0)
+        rc0, bp0, st0 = oracle.find_breakpoint(tgt, q, cb, ce)
+        if rc0 != 0:
+            continue
+        S = bp0.score
+        slack = 2 * 24 + 8 if constrained else 0  # a child that begins or ends inside a gap: see wfa_host.hip (children's bounds)
+        for sub in (S + slack, S + slack + 1, S + slack + 9, S + 300, 3 * S + 1000):
+            rc, bp, st = oracle.find_breakpoint_bounded(tgt, q, sub, cb, ce)
+            assert rc == 0, (i, shape, cb, ce, S, sub, rc)
+            assert all(getattr(bp, f) == getattr(bp0, f) for f in fields), (i, shape, cb, ce, S, sub)
+            assert st.cells <= st0.cells
+            fewer_cells += st.cells < st0.cells
+            checked += 1
+        for sub in (S - 1, S // 2):
+            if sub < 1:
+                continue
+            rc, bp, st = oracle.find_breakpoint_bounded(tgt, q, sub, cb, ce)
+            assert rc != 0, (i, shape, cb, ce, S, sub, bp.score)
+            failed_as_expected += 1
+    assert checked > 700 and failed_as_expected > 250 and fewer_cells > 200, (checked, failed_as_expected, fewer_cells)
