@@ -48,7 +48,7 @@ def fragments(seq_len, w):
 
 
 def map_queries(seqs, pct_identity, k=15, w=1000, s=None, minimum_hits=3, max_kmer_freq=0.0002, add_minmers=None,
-                skip_self=True, skip_prefix=True, lower_triangular=False, kc_threshold=0.0):
+                skip_self=True, skip_prefix=True, lower_triangular=False, kc_threshold=0.0, queries=None):
     """seqs: list of (name, bytes) in file order (all-vs-all).  Returns {query index: MAPPING_DTYPE array} of raw L2
     mappings (after processFragment's query offset, before the boundary check), and the group table."""
     names = [n for n, _ in seqs]
@@ -72,6 +72,8 @@ def map_queries(seqs, pct_identity, k=15, w=1000, s=None, minimum_hits=3, max_km
               cutoff_j=[0.0] + [L2.cutoff_j(q, k) for q in range(1, S + 1)], skip_prefix=skip_prefix)
     out = {}
     for qid, (_, sq) in enumerate(seqs):
+        if queries is not None and qid not in queries:  # (a C4-sized test maps one query haplotype against the whole index)
+            continue
         rows = []
         for fi, off in enumerate(fragments(len(sq), w)):
             sk = pymap.sketch_sequence(sq[off:off + w], k, S)

@@ -71,12 +71,13 @@ def sketch_sequence(seq: bytes, k: int, s: int, seq_id: int = 0, which="oracle")
     return out[:n]
 
 
-def ref_add_minmers(seq: bytes, k: int, w: int, s: int, seq_id: int = 0):
+def ref_add_minmers(seq: bytes, k: int, w: int, s: int, seq_id: int = 0, cap=None):
     L = _load("ref")
-    cap = 4 * len(seq) + 64
+    cap = int(cap) if cap else 4 * len(seq) + 64
     out = np.zeros(cap, dtype=MINMER)
     buf = C.create_string_buffer(seq, len(seq))
     n = L.ref_add_minmers(buf, len(seq), k, w, s, seq_id, out.ctypes.data, cap)
+    assert n <= cap, (n, cap)
     return out[:n]
 
 

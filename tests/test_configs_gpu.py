@@ -173,3 +173,57 @@ def test_c4_shape_sharded_runs_give_the_single_gpu_bytes(gpu, tmp_path):
     assert r.returncode == 0, r.stderr[-3000:]
     assert '"index_once_per_node": true' in r.stderr
     assert open(out).read() == text
+
+
+def test_c4_shape_against_the_oracles(gpu, tmp_path):
+    """C4 at a size where the production switches are the ones under test: 8 haplotypes `hapN#1#chr1` of 5.2 Mbp (above
+    WFM_WINNOW_DEV_MIN: hashing, thinning, winnowing and the closing sort run on the device), defaults (-Y '#', ani50-2),
+    `wfmash-hip -m` then the align phase.  Held against the oracles, not against the product:
+      * identity threshold = the ANI oracle's estimate;
+      * mapping PAF of one query haplotype byte-identical to the reference's own addMinmers (oracle/_ref/libref_map.so) ->
+        index / L1 / L2 stage oracles -> the reference's own filter + output code (oracle/_ref/libref_filter.so);
+      * aligned PAF of a sample of 240 mapping records (all query haplotypes) byte-identical to oracle/wflign_host.py over
+        oracle/wfa2p.c; the sample's records appear unchanged in the run over the whole mapping file."""
+    if not (pymap.have_ref() and pyfilter.have_ref()):
+        pytest.skip("oracle/_ref is not built (compiled from /root/reference by `make -C oracle ref`)")
+    recs = [(n, s.tobytes()) for n, s in synth.pangenome(8, 5_200_000, n_sv=4, sv_min=5_000, sv_max=50_000)]
+    fa = str(tmp_path / "c4.fa")
+    names, lengths = synth.write_fasta(fa, recs)
+    assert names == [f"hap{i}#1#chr1" for i in range(1, 9)] and min(lengths) > 5_000_000
+    seqs = dict(recs)
+    m = str(tmp_path / "m.paf")
+    env = {k: v for k, v in os.environ.items() if not k.startswith("WFM_")}
+    env["WFM_DEBUG"] = "1"
+    r = subprocess.run([CLI, "-m", "-t", "16", "--out", m, fa], cwd=str(tmp_path), env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    dev = [l for l in r.stderr.splitlines() if "winnowing on the device" in l]
+    assert dev and int(dev[-1].split("winnowing on the device:")[1].split("sequences")[0]) == 8 and "closing sort on the device" in dev[-1], r.stderr[-3000:]
+    got = open(m).read()
+    # -- map: one query haplotype against the index of all eight
+    q = 2
+    groups = MP.ref_groups(names)
+    pct = np.float32(ANI.estimate_identity([s for _, s in recs], groups, 50, -2.0))
+    S = MP.sketch_size(pct, 1000, 15)
+    maps, _, _ = MP.map_queries(recs, pct, queries={q})
+    Pexp = capi.map_default_params(percentage_identity=float(pct), auto_pct_identity=0, sketch_size=S)
+    exp = pyfilter.ref_filter("subset", maps[q], fa, names[q], Pexp)
+    mine = "".join(l + "\n" for l in got.splitlines() if l.split("\t", 1)[0] == names[q])
+    assert len(maps[q]) > 30_000 and len(exp.splitlines()) >= 7 * 90
+    assert mine == exp
+    # -- align: a sample over all queries against the align oracle
+    lines = got.splitlines()
+    assert len(lines) >= 8 * 7 * 90
+    sample = lines[::max(1, len(lines) // 240)][:240]
+    ms, as_, a = str(tmp_path / "ms.paf"), str(tmp_path / "as.paf"), str(tmp_path / "a.paf")
+    open(ms, "w").write("".join(l + "\n" for l in sample))
+    capi.align_paf(gpu, fa, ms, as_, params={"threads": 16})
+    got_s = [l.rstrip("\n") for l in open(as_)]
+    want = W.align_mapping_lines(sample, seqs, seqs)
+    assert len(want) >= 230 and got_s == want
+    summ = capi.align_paf(gpu, fa, m, a, params={"threads": 16})
+    full = [l.rstrip("\n") for l in open(a)]
+    assert summ.written == len(full) >= len(lines) - 8
+    assert set(got_s) <= set(full)
+    it = iter(full)
+    assert all(any(x == y for y in it) for x in got_s)  # ... and in the same order
+    _check_records("".join(l + "\n" for l in full[::7]), seqs, 600)

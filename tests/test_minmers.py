@@ -285,18 +285,22 @@ def test_prefilter_gpu_matches_host_definition(gpu):
 @pytest.mark.parametrize("dev_chunk,force", [("1041", "0"), ("16384", "0"), ("2100", "1")])
 def test_add_minmers_multi_winnows_on_the_device(dev_chunk, force):
     """the production path of a thinned stream: one wave per speculative chunk (map_winnow.hip), boundary states compared and
-    interval starts resolved on the device; against one dense host stream per sequence.  The sequences the device may hand
-    back are the ones the test names (an N among the first k-mers that the reference does not notice)."""
+    interval starts resolved on the device, closing sort on the device; against the REFERENCE'S OWN addMinmers
+    (commonFunc.hpp:440-708, compiled in place: oracle/_ref/libref_map.so), one call per sequence.  The sequences the
+    device may hand back are the ones the test names (an N among the first k-mers that the reference does not notice)."""
     import subprocess
     import sys
     code = (
         "import sys; sys.path.insert(0, '.'); sys.path.insert(0, 'tests')\n"
         "from wfmash_amd import capi\n"
+        "from oracle import pymap\n"
         "from test_minmers import _thin_cases\n"
         "h = capi.Handle(0)\n"
         "seqs = [s for _, s in _thin_cases() if len(s) >= 1000]\n"
         "for (k, w, s) in ((15, 256, 12), (15, 1000, 39), (19, 500, 70)):\n"
-        "    single = [h.add_minmers(sq, k, w, s, i) for i, sq in enumerate(seqs)]\n"
+        "    # the oracle: the reference's own addMinmers (commonFunc.hpp:440-708, oracle/_ref/libref_map.so)\n"
+        "    assert pymap.have_ref(), 'oracle/_ref/libref_map.so did not travel'\n"
+        "    single = [pymap.ref_add_minmers(sq, k, w, s, i) for i, sq in enumerate(seqs)]\n"
         "    multi = h.add_minmers_multi(seqs, k, w, s, threads=8)\n"
         "    bad = [i for i, (a, b) in enumerate(zip(multi, single)) if a.tobytes() != b.tobytes()]\n"
         "    assert not bad, (k, w, s, bad)\n"
@@ -313,6 +317,47 @@ def test_add_minmers_multi_winnows_on_the_device(dev_chunk, force):
         assert nseq >= 9 and back <= 1, l
         if force == "1":
             assert int(l.split(" chunks replayed")[0].split()[-1]) > 10, l
+
+
+@pytest.mark.gpu
+def test_production_switch_device_winnower_against_the_reference():
+    """m3 at DEFAULT thresholds (no WFM_WINNOW_* override): a 5.5 Mbp sequence is above WFM_WINNOW_DEV_MIN, so hashing,
+    thinning, one wave per speculative chunk and the closing std::sort order all run on the device; a 0.6 Mbp sequence in
+    the same call goes wherever the production switch sends it.  Held against the REFERENCE'S OWN addMinmers
+    (commonFunc.hpp:440-708, oracle/_ref/libref_map.so), record for record, order included.  The long sequence carries
+    what shapes the reference's quirks: N runs, lower case, a microsatellite, a long-period tandem repeat."""
+    import subprocess
+    import sys
+    code = (
+        "import sys; sys.path.insert(0, '.')\n"
+        "import numpy as np\n"
+        "from wfmash_amd import capi, synth\n"
+        "from oracle import pymap\n"
+        "assert pymap.have_ref(), 'oracle/_ref/libref_map.so did not travel'\n"
+        "b = bytearray(synth.random_dna(0x3a3, 5_500_000))\n"
+        "b[1_000_000:1_020_000] = b'N' * 20_000\n"
+        "b[2_000_000:2_030_000] = (bytes(b[100:107]) * 5000)[:30_000]\n"
+        "b[3_000_000:3_048_000] = bytes(b[5000:6200]) * 40\n"
+        "b[4_000_000:4_100_000] = bytes(b[4_000_000:4_100_000]).lower()\n"
+        "b[4_500_000:4_500_001] = b'n'\n"
+        "seqs = [bytes(b), synth.random_dna(0x3a4, 600_000)]\n"
+        "h = capi.Handle(0)\n"
+        "for (k, w, s) in ((15, 1000, 39), (15, 1000, 78)):\n"
+        "    multi = h.add_minmers_multi(seqs, k, w, s, threads=8, cap=2_000_000)\n"
+        "    for i, sq in enumerate(seqs):\n"
+        "        ref = pymap.ref_add_minmers(sq, k, w, s, i, cap=2_000_000)\n"
+        "        assert len(multi[i]) == len(ref) and multi[i].tobytes() == ref.tobytes(), (k, w, s, i, len(multi[i]), len(ref))\n"
+        "    print('same', k, w, s, [len(a) for a in multi])\n")
+    env = {k: v for k, v in os.environ.items() if not k.startswith("WFM_WINNOW") and k not in ("WFM_FINISH_DEVICE", "WFM_PREFILTER")}
+    env["WFM_DEBUG"] = "1"
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0 and r.stdout.count("same") == 2, (r.stdout[-1000:], r.stderr[-3000:])
+    lines = [l for l in r.stderr.splitlines() if "winnowing on the device" in l]
+    assert len(lines) == 2, r.stderr[-3000:]
+    for l in lines:
+        nseq = int(l.split("winnowing on the device:")[1].split("sequences")[0])
+        back = int(l.split(";")[1].split("handed back")[0])
+        assert nseq >= 1 and back == 0 and "closing sort on the device" in l, l
 
 
 def _raw_records(rng, n, span, w):

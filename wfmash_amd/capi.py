@@ -492,7 +492,7 @@ class Handle:
                 return out[:n], frag[:n]
             cap = int(n)
 
-    def add_minmers_multi(self, seqs, k: int, w: int, s: int, seq_ids=None, threads: int = 1):
+    def add_minmers_multi(self, seqs, k: int, w: int, s: int, seq_ids=None, threads: int = 1, cap=None):
         """wfm_add_minmers_multi: minmer intervals of several sequences (GPU hashing, threaded host winnowing);
         returns one array per sequence."""
         n = len(seqs)
@@ -500,7 +500,7 @@ class Handle:
         bufs = [np.frombuffer(x, dtype=np.uint8) for x in seqs]
         ptrs = (C.c_void_p * n)(*[b.ctypes.data for b in bufs])
         lens = np.array([len(x) for x in seqs], dtype=np.int64)
-        cap = 4 * int(lens.sum()) + 64
+        cap = int(cap) if cap else 4 * int(lens.sum()) + 64
         out = np.zeros(cap, dtype=MINMER_DTYPE)
         counts = np.zeros(n, dtype=np.int64)
         f = self._L.wfm_add_minmers_multi

@@ -2197,11 +2197,9 @@ void launch_tile_init(const uint8_t* seq, int32_t* ring, const TileJob* jobs, in
 }
 void launch_tile(const uint8_t* seq, int32_t* ring, const TileJob* jobs, const TileTask* tasks, int32_t* mak, int ntasks,
                  int threads, int T, int Wt, size_t lds_bytes, DevPen pen, int scope, hipStream_t st) {
-  static size_t configured = 0;
-  if (lds_bytes > configured) {
-    (void)hipFuncSetAttribute((const void*)wfa_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    configured = lds_bytes;
-  }
+  // the attribute is per device and several devices / host threads share the process: set it on every launch of this
+  // (non-default, WFM_TILE_REG=0) form rather than cache it
+  (void)hipFuncSetAttribute((const void*)wfa_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
   hipLaunchKernelGGL(wfa_tile_kernel, dim3(ntasks), dim3(threads), lds_bytes, st, seq, ring, jobs, tasks, mak, T, Wt, pen, scope);
 }
 void launch_tile_advance(TileJob* jobs, int32_t* mak, int njobs, int T, DevPen pen, int exact, hipStream_t st) {

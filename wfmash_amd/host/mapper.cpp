@@ -329,7 +329,15 @@ int Map::mapQuery(MapSummary* summary) {
       out.flush();
     };
     std::vector<MapSummary> part(hs_.size());
-    auto worker = [&](size_t g) {
+    // an exception on a worker thread (FASTA I/O, bad_alloc, a filter throw) must come back as a WFM_E_* code like
+    // everything else: the first message is kept, every thread is joined (Aligner::compute does the same)
+    std::mutex err_mu;
+    auto fail = [&](int rc, const std::string& what) {
+      std::lock_guard<std::mutex> lk(err_mu);
+      int expected = WFM_OK;
+      if (error_rc.compare_exchange_strong(expected, rc)) wfm_set_error(h_, what);
+    };
+    auto worker_body = [&](size_t g) {
       wfm_handle_t* hg = hs_[g];
       MapSummary& ps = part[g];
       Batch b;
@@ -346,8 +354,7 @@ int Map::mapQuery(MapSummary* summary) {
             const int64_t n = wfm_map_fragments(hg, ixs[g], b.buffer.data(), (int64_t)b.buffer.size(), b.frag_off.data(), b.frag_seq.data(),
                                                 (int64_t)b.frag_off.size(), &T.prm, maps.data(), mfrag.data(), cap);
             if (n < 0) {
-              if (hg != h_) wfm_set_error(h_, wfm_last_error(hg));
-              error_rc.store((int)n);
+              fail((int)n, wfm_last_error(hg));
               return;
             }
             if (n <= cap) { maps.resize((size_t)n); mfrag.resize((size_t)n); break; }
@@ -378,8 +385,9 @@ int Map::mapQuery(MapSummary* summary) {
         std::atomic<size_t> next{0};
         const int nt_filter = (int)std::min<size_t>((size_t)threads_each, bq.size());
         auto work = [&]() {
+         try {
           set_filter_threads(std::max(1, threads_each / std::max(1, nt_filter)));  // few queries: each may use the idle threads
-          for (size_t qn; (qn = next.fetch_add(1)) < bq.size();) {
+          for (size_t qn; error_rc.load() == WFM_OK && (qn = next.fetch_add(1)) < bq.size();) {
             const BatchQuery& q = bq[qn];
             MappingResultsVector_t results;
             results.reserve(first_map[qn + 1] - first_map[qn]);
@@ -401,6 +409,11 @@ int Map::mapQuery(MapSummary* summary) {
             }
             qout[qn].keep = std::move(keep);
           }
+         } catch (const std::bad_alloc&) {
+          fail(WFM_E_NOMEM, "out of host memory while post-processing mappings");
+         } catch (const std::exception& e) {
+          fail(WFM_E_ARG, std::string("post-processing failed: ") + e.what());
+         }
         };
         {
           const int nt = (int)std::min<size_t>((size_t)threads_each, bq.size());
@@ -409,13 +422,29 @@ int Map::mapQuery(MapSummary* summary) {
           work();
           for (auto& t : pool) t.join();
         }
+        if (error_rc.load() != WFM_OK) return;
         write_batch((uint64_t)seq, std::move(bo));
         ps.ms_filter += now_ms() - tb;
       }
     };
+    auto worker = [&](size_t g) {
+      try {
+        worker_body(g);
+      } catch (const std::bad_alloc&) {
+        fail(WFM_E_NOMEM, "out of host memory in the map driver");
+      } catch (const std::exception& e) {
+        fail(WFM_E_ARG, std::string("map driver: ") + e.what());
+      } catch (...) {
+        fail(WFM_E_ARG, "map driver: unknown exception");
+      }
+    };
     {
       std::vector<std::thread> pool;
-      for (size_t g = 1; g < hs_.size(); ++g) pool.emplace_back(worker, g);
+      try {
+        for (size_t g = 1; g < hs_.size(); ++g) pool.emplace_back(worker, g);
+      } catch (const std::exception& e) {
+        fail(WFM_E_NOMEM, std::string("map driver: could not start a device thread: ") + e.what());
+      }
       worker(0);
       for (auto& t : pool) t.join();
     }

@@ -814,6 +814,7 @@ int64_t add_minmers_core(wfm_handle_t* h, const char* const* seqs, const int64_t
   std::condition_variable cv_work, cv_room, cv_slot, cv_hashed;
   bool done = false, hashed_done = false;
   std::atomic<int> async_rc{WFM_OK};
+  std::atomic<bool> async_msg_set{false};  // the failing path left its own text in the handle: do not overwrite it
   int64_t inflight_bases = 0;
   const int64_t max_inflight = 1ll << 31;  // ~2 Gbp hashed but not yet winnowed: 10 B/base on the device
 
@@ -943,7 +944,13 @@ int64_t add_minmers_core(wfm_handle_t* h, const char* const* seqs, const int64_t
       if (n && sink_rc == WFM_OK) sink_rc = J->d_result ? sink.put_device(J->d_result, n) : sink.put(J->result.data(), n);
       total += n;
       if (J) J->result.release();
-      if (J && J->d_result) { map_dev_pool_put(wfm_device(h), J->d_result); J->d_result = nullptr; }
+      if (J && J->d_result) {
+        // the sink's device-to-device copy runs on the null stream and need not be over when the call returns; the
+        // device thread's stream does not wait for the null stream, so the block must not go back to the pool before it is
+        if (hipStreamSynchronize(nullptr) != hipSuccess && sink_rc == WFM_OK) sink_rc = WFM_E_HIP;
+        map_dev_pool_put(wfm_device(h), J->d_result);
+        J->d_result = nullptr;
+      }
     }
   };
   std::mutex gpu_mu;  // the handle's stream and error string: this thread, and a worker that hashes a sequence again
@@ -995,9 +1002,10 @@ int64_t add_minmers_core(wfm_handle_t* h, const char* const* seqs, const int64_t
       // chunk length: one wave per chunk, and about as many chunks as the device keeps resident at once (a chunk's two
       // windows of warm-up are its overhead: no chunk under four windows)
       const int64_t auto_chunk = std::min<int64_t>((J->nk + 6143) / 6144, (int64_t)1 << 16);
+      // (no stream of its own: the sequence goes to the host's winnower like any other the device hands back)
       int wrc = st2 ? map_winnow_sparse_device(h, &J->sparse, J->len, k, w, s, J->seq_id, std::max<int64_t>(dev_chunk > 0 ? dev_chunk : auto_chunk, 4 * (int64_t)w),
                                                &winnow_work, &d_recs, &n_recs, &wi, st2)
-                    : WFM_E_HIP;
+                    : 1;
       dev_chunks += wi.chunks;
       dev_replays += wi.replays;
       if (wrc == WFM_OK && dev_finish) {  // the closing cut / sort / de-duplication on the device as well
@@ -1032,7 +1040,8 @@ int64_t add_minmers_core(wfm_handle_t* h, const char* const* seqs, const int64_t
         }
       }
       ms_winnow += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tw).count();
-      if (wrc < 0) {  // an error: the sequence ends here with no records, the call fails
+      if (wrc < 0) {  // an error: the sequence ends here with no records, the call fails (the failing path has set the message)
+        async_msg_set.store(true);
         async_rc.store(wrc);
         map_sparse_free(&J->sparse);
         seq_finished(J);
@@ -1203,7 +1212,10 @@ int64_t add_minmers_core(wfm_handle_t* h, const char* const* seqs, const int64_t
             std::chrono::duration<double, std::milli>(t_fed - t_start).count(), ms_hash, ms_thin,
             std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_fed).count(), stitch_max);
   }
-  if (rc == WFM_OK && async_rc.load() != WFM_OK) { rc = async_rc.load(); wfm_set_error(h, "device-to-host streaming of k-mer hashes failed"); }
+  if (rc == WFM_OK && async_rc.load() != WFM_OK) {
+    rc = async_rc.load();
+    if (!async_msg_set.load()) wfm_set_error(h, "device-to-host streaming of k-mer hashes failed");
+  }
   if (rc != WFM_OK) { release_work(); return rc; }
   flush_ready(nseq);  // (the records of the last sequences leave their pooled blocks here)
   if (later) *later = release_work; else release_work();
