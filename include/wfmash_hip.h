@@ -65,6 +65,8 @@ extern "C" {
 #define WFM_ST_UNREACHABLE (-300)
 #define WFM_ST_OOM         (-200)
 
+#define WFMASH_HIP_VERSION "wfmash-hip-0.3"   /* SAM @PG VN:, `wfmash-hip --version` */
+
 typedef struct wfm_handle wfm_handle_t;
 
 /* wflign_penalties_t (wflign_alignment.hpp:21) minus match (always 0) */
@@ -92,7 +94,7 @@ typedef struct {
 typedef struct {
   int32_t  status;     /* WFM_ST_*                                             */
   int32_t  score;      /* gap-affine-2p penalty of the returned alignment      */
-  uint64_t ops_off;    /* offset of this problem's op string in ops_arena      */
+  uint64_t ops_off;    /* offset of this problem's op string in ops_arena (wfm_align_batch_rle: index of its first run) */
   uint32_t ops_len;    /* number of ops over {M,X,I,D}; I = text-only, D = pattern-only */
   uint32_t n_runs;     /* number of run-length encoded CIGAR runs             */
   uint64_t cells;      /* (score,diagonal) cells computed on the device        */
@@ -143,6 +145,21 @@ int  wfm_align_batch(wfm_handle_t* h, const wfm_penalties_t* pen,
                      const wfm_problem_t* problems, size_t n,
                      wfm_result_t* out, char* ops_arena, size_t arena_bytes);
 
+/* The same with run-length output, the form the align driver consumes: the reference's own pipeline compresses the op
+ * string at once (compress_cigar, wflign.cpp:183-208) and works on runs from there on (erosion scan, merge, swizzle and
+ * write_alignment_paf: wflign.cpp:174-231,241-454), so nothing on that path needs one byte per base; wfm_align_batch's
+ * expanded form stays for getAlignment(char**, int*) (wflign_alignment.cpp:671-677).
+ * *runs receives a buffer of 32-bit runs owned by the caller (release with wfm_free_runs), run = (length << 2) | op
+ * with op 0 = M, 1 = X, 2 = I (text only), 3 = D (pattern only); adjacent runs of one problem never share an op.
+ * out[i].ops_off = index of problem i's first run in *runs, out[i].n_runs their number, out[i].ops_len the number of
+ * ops they spell.  Returns as wfm_align_batch. */
+#define WFM_RUN_LEN(r) ((uint32_t)(r) >> 2)
+#define WFM_RUN_OP(r)  ((uint32_t)(r) & 3u)
+int  wfm_align_batch_rle(wfm_handle_t* h, const wfm_penalties_t* pen,
+                         const wfm_problem_t* problems, size_t n,
+                         wfm_result_t* out, uint32_t** runs, size_t* n_runs_total);
+void wfm_free_runs(uint32_t* runs);
+
 /* Same, but sequences are already resident in device memory (the timed region
  * of bench.py starts here): d_seqs is a device pointer, offsets index into it.
  * Sequences must be laid out by wfm_upload_sequences. */
@@ -151,6 +168,8 @@ int  wfm_upload_sequences(wfm_handle_t* h, const wfm_problem_t* problems, size_t
 void wfm_free_sequences(wfm_handle_t* h, wfm_seqset_t* s);
 int  wfm_align_resident(wfm_handle_t* h, const wfm_penalties_t* pen, wfm_seqset_t* s,
                         wfm_result_t* out, char* ops_arena, size_t arena_bytes);
+int  wfm_align_resident_rle(wfm_handle_t* h, const wfm_penalties_t* pen, wfm_seqset_t* s,
+                            wfm_result_t* out, uint32_t** runs, size_t* n_runs_total);
 
 int  wfm_get_stats(const wfm_handle_t* h, wfm_stats_t* out);
 
@@ -227,16 +246,20 @@ int  wfm_index_upload(wfm_handle_t* h, const uint64_t* uhash, const int64_t* pof
                       wfm_index_t** out);
 
 /* addMinmers (commonFunc.hpp:440-708): winnowed minmer intervals [wpos, wpos_end) of one target
- * sequence, sorted by (wpos, wpos_end), spans chunked to <= w.  K-mer hashing runs on the GPU,
- * the sequential window bookkeeping on the calling host thread (one sequence per thread is the
- * reference's parallelism, winSketch.hpp:200-239).  Returns the number of intervals (which may
- * exceed cap; only cap are written) or a negative WFM_E_* code. */
+ * sequence, sorted by (wpos, wpos_end), spans chunked to <= w.  This single-sequence form hashes on
+ * the GPU and winnows on the calling host thread (the threads == 1 path; it is what the tests use
+ * as the one-stream form).  The production path is wfm_add_minmers_multi / wfm_index_build_sequences:
+ * hashing, thinning, winnowing (one wave per speculative chunk) and the closing sort all on the device.
+ * Returns the number of intervals (which may exceed cap; only cap are written) or a negative WFM_E_* code. */
 int64_t wfm_add_minmers(wfm_handle_t* h, const char* seq, int64_t len, int k, int w, int s, int32_t seq_id,
                         wfm_minmer_t* out, int64_t cap);
 
-/* wfm_add_minmers for nseq sequences: the GPU hashes one sequence after the other while `threads`
- * host workers winnow the ones already hashed (one sequence per worker = the reference's
- * ThreadPool, winSketch.hpp:200-239).  out receives the intervals of all sequences concatenated
+/* wfm_add_minmers for nseq sequences (the reference: one sequence per ThreadPool worker,
+ * winSketch.hpp:200-239).  With threads > 1 every stage runs on the device: hashing, thinning of the
+ * k-mer stream, winnowing (map_winnow.hip: one wave per speculative chunk, chunks of many sequences in
+ * one launch) and the closing std::sort order (map_finish.hip); a sequence the device hands back (an N
+ * among its first k-mers that the reference does not notice, a refill anomaly) is winnowed by the
+ * `threads` host workers.  out receives the intervals of all sequences concatenated
  * in input order, counts[i] (optional) the number of sequence i.  Returns the total (may exceed
  * cap; only cap are written) or a WFM_E_* code. */
 int64_t wfm_add_minmers_multi(wfm_handle_t* h, const char* const* seqs, const int64_t* lens, const int32_t* seq_ids,

@@ -326,3 +326,37 @@ def test_score_hints_cut_the_wavefronts_not_the_result(gpu, oracle):
     c0 = sum(r.cells for r in plain)
     assert cells["exact"] <= cells["tight"] < 0.95 * c0 and cells["generous"] <= c0, (cells, c0)
     assert cells["small"] >= c0  # every record ran again without its hint
+
+
+def _expand(runs):
+    return b"".join(op * n for n, op in runs)
+
+
+def test_run_length_output_spells_the_oracles_ops(gpu, oracle):
+    """wfm_align_batch_rle (the form the align driver consumes): per problem the runs spell the oracle's op string, no two
+    neighbours share an op, ops_len / n_runs / score agree with the expanded form; mixed batch (BiWFA over three parts of
+    the batch, ends-free patches, empty sequences), so the parts' run buffers are stitched into one."""
+    rng = random.Random(77)
+    items = _pairs(7, 120, [0, 3, 99, 130, 777, 2500, 6000], [0.0, 0.01, 0.05, 0.2])
+    for i in range(30):
+        p = synth.random_dna(9100 + i, rng.choice([60, 400, 1500]))
+        t = synth.mutate(p, rng.choice([0.0, 0.05, 0.3]), 9200 + i) or b"A"
+        if i % 2:
+            items.append((p, t, capi.WFM_MODE_ENDSFREE, len(p), 0, len(t), 0))
+        else:
+            items.append((p, t, capi.WFM_MODE_ENDSFREE, 0, len(p), 0, len(t)))
+    rng.shuffle(items)
+    rle = gpu.align_rle(items)
+    full = gpu.align(items)
+    for it, (r, ops_len), f in zip(items, rle, full):
+        p, t = it[0], it[1]
+        if len(it) > 2:
+            rc, ops, sc, _ = oracle.align_endsfree(p, it[3], it[4], t, it[5], it[6])
+        else:
+            rc, ops, sc, _ = oracle.align_biwfa(p, t)
+        assert rc == 0 and r.status == 0 and f.status == 0
+        assert _expand(r.ops) == ops == f.ops
+        assert all(a[1] != b[1] for a, b in zip(r.ops, r.ops[1:])) and all(n > 0 for n, _ in r.ops)
+        assert ops_len == len(ops) and r.n_runs == len(r.ops) == f.n_runs and r.score == f.score
+        if len(it) == 2:
+            assert r.score == sc

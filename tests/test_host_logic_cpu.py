@@ -151,3 +151,68 @@ def test_md_string_matches_oracle_and_known_answers():
         tlen = sum(n for n, o in W.parse(c) if o in "=XD")
         tgt = bytes(rng.choice(b"ACGT") for _ in range(tlen + 4))
         assert capi.host_cigar_fn("md", c, target=tgt, i0=0) == W.md_string(c, 0, tgt)
+
+
+# ---- the batch pipeline's forms on runs (wflign_hip.cpp: *_ops) against the text forms and the oracle ----
+
+def test_run_forms_equal_the_text_forms_random():
+    rng = random.Random(29)
+    for _ in range(600):
+        c = _rand_cigar(rng, rng.randrange(1, 11))
+        for head in (True, False):
+            assert capi.host_cigar_fn("erode_ops", c, i0=3, i1=int(head)) == W.erode_short_matches_in_cigar(c, 3, head)
+        c2 = _rand_cigar(rng, rng.randrange(0, 5))
+        assert capi.host_cigar_fn("merge_ops", c, c2) == W.merge_adjacent_ops(c, c2)
+        q, t, p = W.head_erosion(c)
+        assert capi.host_cigar_fn("head_erosion_ops", c) == f"{q},{t},{p}"
+
+
+def test_runs_to_cigar():
+    # run = (length << 2) | op, op 0 M (written '='), 1 X, 2 I, 3 D (include/wfmash_hip.h)
+    runs = [(100 << 2) | 0, (1 << 2) | 1, (7 << 2) | 2, (3 << 2) | 3, (12 << 2) | 0]
+    assert capi.host_cigar_fn("runs", ",".join(map(str, runs))) == "100=1X7I3D12="
+    assert capi.host_cigar_fn("runs", "") == ""
+
+
+def test_swizzle_run_forms_match_oracle():
+    rng = random.Random(31)
+    hit = 0
+    for it in range(800):
+        unit = bytes(rng.choice(b"ACGT") for _ in range(rng.choice([1, 2, 3])))
+        n, d = rng.randrange(1, 12), rng.randrange(1, 8)
+        rest = bytes(rng.choice(b"ACGT") for _ in range(40))
+        query = (unit * 30)[:n] + rest
+        target = (unit * 30)[:n + d] + rest if rng.random() < 0.7 else bytes(rng.choice(b"ACGT") for _ in range(n + d)) + rest
+        # (a following '=' run makes the swapped CIGAR merge: n= dD 40= -> dD (n+40)=)
+        c = rng.choice([f"{n}={d}D40=", f"{n}={d}D20=1X19=", f"{n}={d}D3I40=", f"{n}={d}D"])
+        a = capi.host_cigar_fn("swap_start_ops", c, query=query, target=target + b"ACGTACGT")
+        assert a == W.try_swap_start_pattern(c, query, target + b"ACGTACGT"), (c, query, target)
+        hit += a != c
+        query2 = rest + (unit * 30)[:n]
+        target2 = rest + (unit * 30)[:n + d] if rng.random() < 0.8 else rest + bytes(rng.choice(b"ACGT") for _ in range(n + d))
+        c2 = rng.choice([f"40={d}D{n}=", f"20=1X19={d}D{n}=", f"2D38={d}D{n}=", f"{d}D{n}="])
+        q2 = query2 if not c2.startswith("2D") else query2[2:]
+        b = capi.host_cigar_fn("swap_end_ops", c2, query=q2, target=target2 + b"TTTT")
+        assert b == W.try_swap_end_pattern(c2, q2, target2 + b"TTTT"), (c2, q2, target2)
+        hit += b != c2
+    assert hit > 80
+
+
+def test_paf_writer_run_form_matches_oracle():
+    """write_alignment_paf_ops emits the record as the align driver finally writes it: the reference writer's fields
+    re-joined with single tabs (computeAlignments.hpp:484-525) and a newline"""
+    rng = random.Random(37)
+    for _ in range(400):
+        c = _rand_cigar(rng, rng.randrange(1, 12), maxlen=3000 if rng.random() < 0.2 else 40)
+        ops = W.parse(c)
+        qlen = sum(n for n, o in ops if o in "=XI")
+        tlen = sum(n for n, o in ops if o in "=XD")
+        qoff, toff = rng.randrange(0, 5_000_000_000), rng.randrange(0, 5000)
+        rev = rng.random() < 0.5
+        mm = rng.choice([0.95, 0.8731, 1.0, 0.7, 0.999999, 0.123456789])
+        cid, clen, cpos = rng.choice([(-1, 1, 1), (3, 4, 2), (7, 1, 1), (12345, 0, 1)])
+        meta = f"q#1|{qoff + qlen + 77}|{qoff}|{qlen}|{int(rev)}|t#2|{toff + tlen + 99}|{toff}|{mm}|{cid}|{clen}|{cpos}"
+        got = capi.host_cigar_fn("paf_ops", c, meta)
+        exp = W.write_alignment_paf(c, "q#1", qoff + qlen + 77, qoff, qlen, rev, "t#2", toff + tlen + 99, toff, mm, cid, clen, cpos)
+        assert got == ("\t".join(exp.split()) + "\n" if exp else ""), (c, meta)
+        assert got == ("\t".join(capi.host_cigar_fn("paf", c, meta).split()) + "\n" if exp else "")

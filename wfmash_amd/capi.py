@@ -27,6 +27,7 @@ EXPORTS = [
     "wfm_map_l1", "wfm_map_l2", "wfm_map_fragments", "wfm_minhash_sketch", "wfm_add_minmers_multi",
     "wfm_prefilter_kmers", "wfm_index_build_sequences", "wfm_index_upload",
     "wfm_index_replicate", "wfm_device_count", "wfm_finish_records",
+    "wfm_align_batch_rle", "wfm_align_resident_rle", "wfm_free_runs",
 ]
 
 
@@ -317,6 +318,37 @@ class Handle:
             r = res[i]
             ops = arena[r.ops_off:r.ops_off + r.ops_len].tobytes() if r.status == 0 else None
             out.append(AlignResult(r.status, r.score, ops, r.n_runs, r.cells))
+        return out
+
+    def align_rle(self, items, pen=None):
+        """wfm_align_batch_rle: the same problems, run-length output.  AlignResult.ops is the list of (length, op) runs
+        with op in b'MXID' (adjacent runs never share an op), .n_runs their number; `ops_len` travels as an extra
+        attribute on the tuple: returns [(AlignResult, ops_len)]."""
+        probs, keep, n = _make_problems(items)
+        pn = Penalties(*(pen or DEFAULT_PEN))
+        res = (Result * max(n, 1))()
+        runs = C.POINTER(C.c_uint32)()
+        total = C.c_size_t(0)
+        f = self._L.wfm_align_batch_rle
+        f.restype = C.c_int
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(C.POINTER(C.c_uint32)), C.POINTER(C.c_size_t)]
+        self._L.wfm_free_runs.restype = None
+        self._L.wfm_free_runs.argtypes = [C.POINTER(C.c_uint32)]
+        rc = f(self._p, C.byref(pn), probs, n, res, C.byref(runs), C.byref(total))
+        if rc < 0:
+            raise WfmError(f"wfm_align_batch_rle failed ({rc}): {self.last_error()}")
+        try:
+            arr = np.ctypeslib.as_array(runs, shape=(total.value,)).copy() if total.value else np.zeros(0, dtype=np.uint32)
+        finally:
+            self._L.wfm_free_runs(runs)
+        out = []
+        for i in range(n):
+            r = res[i]
+            ops = None
+            if r.status == 0:
+                mine = arr[r.ops_off:r.ops_off + r.n_runs]
+                ops = [(int(x) >> 2, b"MXID"[int(x) & 3:(int(x) & 3) + 1]) for x in mine]
+            out.append((AlignResult(r.status, r.score, ops, r.n_runs, r.cells), int(r.ops_len)))
         return out
 
     # ---- map path ----

@@ -681,8 +681,12 @@ int map_winnow_sparse_device(wfm_handle_t* h, const MapSparseSeq* sp, int64_t le
     ch.c0 = r[(size_t)nc + 1 + c];
     ch.c1 = r[(size_t)c];
     const int64_t kept = r[(size_t)c + 1] - r[(size_t)c];
-    // an iteration emits at most three records (leave, arrive, the swap), a kept k-mer has two iterations; the flush adds s
-    ch.rec_cap = (int32_t)std::min<int64_t>(6 * kept + s + 64, INT32_MAX);
+    // an iteration emits at most three records (leave, arrive, the swap).  The chunk's iterations are the arrivals of its
+    // own kept k-mers and the departures of those and of the ones that were in the window when it began -- kept k-mers
+    // of the two windows before it at most (a chunk inside a run of N has none of its own and still closes the
+    // intervals of everything that leaves); the flush adds s
+    const int64_t before = r[(size_t)c] - r[(size_t)nc + 1 + c];
+    ch.rec_cap = (int32_t)std::min<int64_t>(3 * (2 * kept + before) + s + 64, INT32_MAX);
     ch.rec_off = rec_total;
     rec_total += ch.rec_cap;
     ch.first = c == 0; ch.last = c + 1 == nc; ch.pad_ = 0;

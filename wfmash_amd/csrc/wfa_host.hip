@@ -631,8 +631,10 @@ int run_p2_phase(wfm_handle* h, wfm_seqset* S, const DevPen& dp, int scope, cons
 }
 
 // Aligns problems [first, last) of S; their op strings go to ops_arena from byte arena_base on.
+// runs_out != nullptr: run-length output (wfm_align_batch_rle) -- the part's merged runs are appended to *runs_out and
+// ops_off counts from the part's first run (the caller shifts the parts into one buffer); ops_arena is not touched
 int align_resident_impl(wfm_handle* h, const wfm_penalties_t* pen, wfm_seqset* S, size_t first, size_t last, wfm_result_t* out,
-                        char* ops_arena, size_t arena_bytes, size_t arena_base) {
+                        char* ops_arena, size_t arena_bytes, size_t arena_base, std::vector<uint32_t>* runs_out = nullptr) {
   int scope = 0;
   int rc = validate_pen(pen, &scope);
   if (rc != WFM_OK) { h->err = "unsupported penalties"; return rc; }
@@ -944,7 +946,8 @@ int align_resident_impl(wfm_handle* h, const wfm_penalties_t* pen, wfm_seqset* S
 
   // ---- expand to op strings ----
   static const char opc[4] = {'M', 'X', 'I', 'D'};
-  size_t arena_pos = arena_base;
+  size_t arena_pos = runs_out ? runs_out->size() : arena_base;
+  if (runs_out) runs_out->reserve(runs_out->size() + (size_t)total);
   int failed = 0;
   uint64_t cells_total = 0;
   for (size_t i = 0; i < n; ++i) {
@@ -967,9 +970,14 @@ int align_resident_impl(wfm_handle* h, const wfm_penalties_t* pen, wfm_seqset* S
       uint64_t len = e[k] >> 2;
       int k2 = k + 1;
       while (k2 < cnt && (int)(e[k2] & 3u) == op) { len += e[k2] >> 2; ++k2; }
-      if (pos + len > arena_bytes) { h->err = "ops arena too small"; return WFM_E_ARENA; }
-      memset(ops_arena + pos, opc[op], (size_t)len);
-      pos += (size_t)len;
+      if (runs_out) {
+        if (len >= (1u << 30)) { h->err = "run too long"; return WFM_E_ARG; }
+        runs_out->push_back((uint32_t)(len << 2) | (uint32_t)op);
+      } else {
+        if (pos + len > arena_bytes) { h->err = "ops arena too small"; return WFM_E_ARENA; }
+        memset(ops_arena + pos, opc[op], (size_t)len);
+        pos += (size_t)len;
+      }
       ++nruns;
       if (op == OP_X) { score += (int64_t)len * pen->x; pc += len; tc += len; }
       else if (op == OP_M) { pc += len; tc += len; }
@@ -983,9 +991,18 @@ int align_resident_impl(wfm_handle* h, const wfm_penalties_t* pen, wfm_seqset* S
       if (getenv("WFM_DEBUG")) fprintf(stderr, "[wfm] problem %zu: CIGAR spans %llu x %llu, sequences %d x %d\n", gi, (unsigned long long)pc, (unsigned long long)tc, S->meta[gi].plen, S->meta[gi].tlen);
       r.status = WFM_ST_UNREACHABLE;  // internal inconsistency: never report a broken CIGAR as ok
       ++failed;
+      if (runs_out) runs_out->resize(arena_pos);
       continue;
     }
-    r.ops_len = (uint32_t)(pos - arena_pos);
+    if (runs_out) {
+      // ops spelled: every M / X op advances both sequences, I the text, D the pattern
+      uint64_t both = 0;
+      for (size_t q = arena_pos; q < runs_out->size(); ++q) if (((*runs_out)[q] & 3u) <= (uint32_t)OP_X) both += (*runs_out)[q] >> 2;
+      r.ops_len = (uint32_t)(pc + tc - both);
+      pos = runs_out->size();
+    } else {
+      r.ops_len = (uint32_t)(pos - arena_pos);
+    }
     r.n_runs = nruns;
     r.score = (int32_t)score;
     arena_pos = pos;
@@ -1036,7 +1053,11 @@ int wfm_create(int device, wfm_handle_t** out) {
   (void)hipEventCreate(&h->ev_base);
   size_t fr = 0, tot = 0;
   if (hipMemGetInfo(&fr, &tot) != hipSuccess) { fr = (size_t)16 << 30; }
-  h->mem_budget = (size_t)((double)fr * 0.40);
+  // 40 % of the free HBM, but no more than 32 GB: on this driver a first hipMalloc beyond a few tens of GB costs 35-40 ms
+  // per GB (64 GB: 2.5-4.4 s, 110 GB: 3.9 s, 16 GB: 0.3 ms -- scripts/malloc_cost.hip, profiles/r3_cold_start.md), which a
+  // one-shot run pays in full: LPA all-vs-all (C2) aligned in 3.3 s cold and 0.33 s warm with rings sized for 115 GB.  A
+  // level that needs more is worked off in chunks and on narrow rings
+  h->mem_budget = std::min<size_t>((size_t)((double)fr * 0.40), (size_t)32 << 30);
   const char* env = getenv("WFM_MEM_BUDGET_MB");
   if (env) h->mem_budget = (size_t)atoll(env) << 20;
   h->mem_budget_full = h->mem_budget;
@@ -1185,10 +1206,32 @@ void wfm_free_sequences(wfm_handle_t* h, wfm_seqset_t* s) {
   delete s;
 }
 
-int wfm_align_resident(wfm_handle_t* h, const wfm_penalties_t* pen, wfm_seqset_t* s, wfm_result_t* out,
-                       char* ops_arena, size_t arena_bytes) {
-  if (!h || !s || !out || (!ops_arena && arena_bytes)) return WFM_E_ARG;
+namespace {
+// both output forms: ops_arena (one byte per op) or, with runs != nullptr, one malloc'd buffer of merged runs
+int align_resident_any(wfm_handle_t* h, const wfm_penalties_t* pen, wfm_seqset_t* s, wfm_result_t* out,
+                       char* ops_arena, size_t arena_bytes, uint32_t** runs, size_t* n_runs_total) {
+  if (!h || !s || !out || (!runs && !ops_arena && arena_bytes)) return WFM_E_ARG;
+  if (runs) *runs = nullptr;
+  if (n_runs_total) *n_runs_total = 0;
   const size_t n = s->meta.size();
+  std::vector<std::vector<uint32_t>> part_runs(1);
+  // the parts' runs side by side in one buffer; ops_off of part k's problems shifted by what lies before it
+  auto hand_over_runs = [&](const std::vector<size_t>& cut) -> int {
+    if (!runs) return WFM_OK;
+    size_t total = 0;
+    for (const auto& v : part_runs) total += v.size();
+    uint32_t* buf = (uint32_t*)malloc((total + 1) * sizeof(uint32_t));
+    if (!buf) { h->err = "out of host memory (CIGAR runs)"; return WFM_E_NOMEM; }
+    size_t at = 0;
+    for (size_t k = 0; k < part_runs.size(); ++k) {
+      if (!part_runs[k].empty()) memcpy(buf + at, part_runs[k].data(), part_runs[k].size() * sizeof(uint32_t));
+      if (at) for (size_t i = cut[k]; i < cut[k + 1]; ++i) out[i].ops_off += at;
+      at += part_runs[k].size();
+    }
+    *runs = buf;
+    if (n_runs_total) *n_runs_total = total;
+    return WFM_OK;
+  };
   const bool overlap = !(getenv("WFM_OVERLAP") && atoi(getenv("WFM_OVERLAP")) == 0);  // read per call: bench.py times both forms
   if (hipSetDevice(h->device) != hipSuccess || hipEventRecord(h->ev_base, h->stream) != hipSuccess ||
       hipEventSynchronize(h->ev_base) != hipSuccess) { h->err = "hipEventRecord failed"; return WFM_E_HIP; }
@@ -1216,7 +1259,13 @@ int wfm_align_resident(wfm_handle_t* h, const wfm_penalties_t* pen, wfm_seqset_t
     h->stats.streams = 1;
     return rc;
   };
-  if (!overlap || n < 8) return finish_single(align_resident_impl(h, pen, s, 0, n, out, ops_arena, arena_bytes, 0));
+  auto run_single = [&]() {
+    const int rc = finish_single(align_resident_impl(h, pen, s, 0, n, out, ops_arena, arena_bytes, 0, runs ? &part_runs[0] : nullptr));
+    if (rc < 0) return rc;
+    const int hrc = hand_over_runs(std::vector<size_t>{0, n});
+    return hrc != WFM_OK ? hrc : rc;
+  };
+  if (!overlap || n < 8) return run_single();
   // Parts of the batch side by side, each with its own stream and arenas (peer handles on the same device)
   // and its own host thread: while one part sits in the few-workgroup levels of the step kernel or waits for
   // the host, the other parts' tiles fill the machine.  Problems are independent, the parts only share the
@@ -1233,7 +1282,7 @@ int wfm_align_resident(wfm_handle_t* h, const wfm_penalties_t* pen, wfm_seqset_t
       ring_bytes += ((size_t)s->meta[i].plen + (size_t)s->meta[i].tlen + 9) * 2 * 5 * RING * 2 * 4;
     if (ring_bytes > h->mem_budget_full) parts = 2;
   }
-  if (parts < 2) return finish_single(align_resident_impl(h, pen, s, 0, n, out, ops_arena, arena_bytes, 0));
+  if (parts < 2) return run_single();
   while (h->peers.size() + 1 < parts) {
     wfm_handle_t* p = nullptr;
     if (wfm_create(h->device, &p) != WFM_OK) break;
@@ -1262,18 +1311,23 @@ int wfm_align_resident(wfm_handle_t* h, const wfm_penalties_t* pen, wfm_seqset_t
   const auto t0 = std::chrono::steady_clock::now();
   std::vector<int> rcs(np, 0);
   std::vector<std::thread> th;
+  part_runs.resize(np);
   for (size_t k = 1; k < np; ++k) {
     wfm_handle* pk = h->peers[k - 1];
     pk->call_base = h->ev_base;
     pk->tile_iv.clear(); pk->bp_iv.clear(); pk->base_iv.clear();
-    th.emplace_back([&, k, pk] { rcs[k] = align_resident_impl(pk, pen, s, cut[k], cut[k + 1], out, ops_arena, arena_bytes, base[k]); });
+    th.emplace_back([&, k, pk] { rcs[k] = align_resident_impl(pk, pen, s, cut[k], cut[k + 1], out, ops_arena, arena_bytes, base[k], runs ? &part_runs[k] : nullptr); });
   }
-  rcs[0] = align_resident_impl(h, pen, s, cut[0], cut[1], out, ops_arena, arena_bytes, 0);
+  rcs[0] = align_resident_impl(h, pen, s, cut[0], cut[1], out, ops_arena, arena_bytes, 0, runs ? &part_runs[0] : nullptr);
   for (auto& t : th) t.join();
   int failed = 0;
   for (size_t k = 0; k < np; ++k) {
     if (rcs[k] < 0) { if (k) h->err = h->peers[k - 1]->err; return rcs[k]; }
     failed += rcs[k];
+  }
+  {
+    const int hrc = hand_over_runs(cut);
+    if (hrc != WFM_OK) return hrc;
   }
   wfm_stats_t& a = h->stats;
   std::vector<std::pair<float, float>> iv = h->tile_iv, ivb = h->bp_iv, ivs = h->base_iv;
@@ -1300,15 +1354,46 @@ int wfm_align_resident(wfm_handle_t* h, const wfm_penalties_t* pen, wfm_seqset_t
   return failed;
 }
 
+int align_batch_any(wfm_handle_t* h, const wfm_penalties_t* pen, const wfm_problem_t* problems, size_t n,
+                    wfm_result_t* out, char* ops_arena, size_t arena_bytes, uint32_t** runs, size_t* n_runs_total);
+}  // namespace
+
+int wfm_align_resident(wfm_handle_t* h, const wfm_penalties_t* pen, wfm_seqset_t* s, wfm_result_t* out,
+                       char* ops_arena, size_t arena_bytes) {
+  return align_resident_any(h, pen, s, out, ops_arena, arena_bytes, nullptr, nullptr);
+}
+
+int wfm_align_resident_rle(wfm_handle_t* h, const wfm_penalties_t* pen, wfm_seqset_t* s, wfm_result_t* out,
+                           uint32_t** runs, size_t* n_runs_total) {
+  if (!runs) return WFM_E_ARG;
+  return align_resident_any(h, pen, s, out, nullptr, 0, runs, n_runs_total);
+}
+
 int wfm_align_batch(wfm_handle_t* h, const wfm_penalties_t* pen, const wfm_problem_t* problems, size_t n,
                     wfm_result_t* out, char* ops_arena, size_t arena_bytes) {
+  return align_batch_any(h, pen, problems, n, out, ops_arena, arena_bytes, nullptr, nullptr);
+}
+
+int wfm_align_batch_rle(wfm_handle_t* h, const wfm_penalties_t* pen, const wfm_problem_t* problems, size_t n,
+                        wfm_result_t* out, uint32_t** runs, size_t* n_runs_total) {
+  if (!runs) return WFM_E_ARG;
+  return align_batch_any(h, pen, problems, n, out, nullptr, 0, runs, n_runs_total);
+}
+
+void wfm_free_runs(uint32_t* runs) { free(runs); }
+
+namespace {
+int align_batch_any(wfm_handle_t* h, const wfm_penalties_t* pen, const wfm_problem_t* problems, size_t n,
+                    wfm_result_t* out, char* ops_arena, size_t arena_bytes, uint32_t** runs, size_t* n_runs_total) {
   if (!h) return WFM_E_ARG;
+  if (runs) *runs = nullptr;
+  if (n_runs_total) *n_runs_total = 0;
   wfm_seqset_t* S = nullptr;
   const auto t0 = std::chrono::steady_clock::now();
   int rc = wfm_upload_sequences(h, problems, n, &S);
   if (rc != WFM_OK) return rc;
   const auto t1 = std::chrono::steady_clock::now();
-  rc = wfm_align_resident(h, pen, S, out, ops_arena, arena_bytes);
+  rc = align_resident_any(h, pen, S, out, ops_arena, arena_bytes, runs, n_runs_total);
   const auto t2 = std::chrono::steady_clock::now();
   wfm_free_sequences(h, S);
   if (getenv("WFM_DEBUG"))
@@ -1317,6 +1402,7 @@ int wfm_align_batch(wfm_handle_t* h, const wfm_penalties_t* pen, const wfm_probl
             std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t2).count());
   return rc;
 }
+}  // namespace
 
 int wfm_get_stats(const wfm_handle_t* h, wfm_stats_t* out) {
   if (!h || !out) return WFM_E_ARG;

@@ -240,7 +240,7 @@ std::string Aligner::align_batch(wfm_handle_t* gpu_handle, std::vector<std::stri
   fmt.emit_md_tag = param.emit_md_tag;
   fmt.threads = threads;
   const int rc = wflign::do_biwfa_alignment_batch(gpu_handle, recs, pen, param.disable_chain_patching, pp, &st, fmt);
-  if (rc < 0) throw std::runtime_error(std::string("[wfmash::align] GPU alignment failed: ") + wfm_last_error(gpu_handle));
+  if (rc < 0) throw std::runtime_error(std::string("[wfmash::align] GPU alignment failed: ") + st.error);
   sum.cells += st.cells; sum.ms_gpu += st.ms_gpu;
   const double ms_biwfa = since(tb2);
   const auto tb3 = std::chrono::steady_clock::now();
@@ -248,13 +248,9 @@ std::string Aligner::align_batch(wfm_handle_t* gpu_handle, std::vector<std::stri
     sum.records++;
     sum.aligned_bp += (uint64_t)(fetched[k].row.qEndPos - fetched[k].row.qStartPos);
     if (recs[k].paf.empty()) continue;
-    if (param.sam_format) { out += recs[k].paf; sum.written++; continue; }  // no cg:Z: field -> line passes through unchanged
-    // processMappingRecord re-tokenises the writer's line and joins with single tabs (computeAlignments.hpp:484-525)
-    const auto fields = tokenize(recs[k].paf);
-    std::string nl;
-    for (const auto& fld : fields) { if (!nl.empty()) nl += '\t'; nl += fld; }
-    nl += '\n';
-    out += nl;
+    // PAF: the record is already in the form processMappingRecord gives it (fields re-joined with single tabs,
+    // computeAlignments.hpp:484-525); SAM: no cg:Z: field -> the writer's line passes through unchanged
+    out += recs[k].paf;
     sum.written++;
   }
   if (dbg)
@@ -307,16 +303,19 @@ Summary Aligner::compute() {
   if (!outstream.is_open()) throw std::runtime_error("[wfmash::align] Error! Failed to open output file: " + param.pafOutputFile);
   if (param.sam_format) {  // write_sam_header (computeAlignments.hpp:725-736)
     for (int i = 0; i < ref->nseq(); ++i) outstream << "@SQ\tSN:" << ref->name(i) << "\tLN:" << ref->length(i) << "\n";
-    outstream << "@PG\tID:wfmash\tPN:wfmash\tVN:wfmash-hip-r2\tCL:wfmash\n";
+    outstream << "@PG\tID:wfmash\tPN:wfmash\tVN:" WFMASH_HIP_VERSION "\tCL:wfmash\n";
   }
   const size_t ngpu = gpus.size();
-  // several GPUs: no batch may hold more than an eighth of one GPU's share of the file
+  // several GPUs: no batch may hold more than an eighth of one GPU's share of the file.  One GPU: a file that would fit
+  // one or two batches is still cut into WFM_ALIGN_MIN_BATCHES, so that the host stages of one part (fetches, patches,
+  // records) run while the device works on another
   uint64_t batch_bytes = ~0ull;
-  if (ngpu > 1) {
+  static const uint64_t min_batches = getenv("WFM_ALIGN_MIN_BATCHES") ? (uint64_t)std::max(1, atoi(getenv("WFM_ALIGN_MIN_BATCHES"))) : 1;
+  if (ngpu > 1 || min_batches > 1) {
     in.seekg(0, std::ios::end);
     const uint64_t file_bytes = (uint64_t)std::max<std::streamoff>(0, in.tellg());
     in.seekg(0, std::ios::beg);
-    batch_bytes = std::max<uint64_t>(1, file_bytes / (8 * ngpu));
+    batch_bytes = std::max<uint64_t>(1, file_bytes / (ngpu > 1 ? 8 * ngpu : min_batches) + 1);
   }
   std::mutex read_mu, write_mu;
   uint64_t next_seq = 0, next_write = 0;

@@ -92,6 +92,49 @@ char* wfmh_test_cigar(const char* fn, const char* a, const char* b, const char* 
   else if (f == "compress") r = wflign::compress_ops(sa.data(), sa.size());
   else if (f == "swap_start") r = wflign::try_swap_start_pattern(sa, q, t, 0, 0);
   else if (f == "swap_end") r = wflign::try_swap_end_pattern(sa, q, t, 0, 0);
+  // ---- the batch pipeline's forms on runs (count, op): held against the text forms above by the CPU suite ----
+  else if (f == "erode_ops") {
+    wflign::CigarOps o = wflign::parse_cigar(sa);
+    wflign::erode_short_matches_ops(o, (int)i0, i1 != 0);
+    r = wflign::cigar_to_string(o);
+  } else if (f == "merge_ops") {
+    wflign::CigarOps o = wflign::parse_cigar(sa);
+    const wflign::CigarOps o2 = wflign::parse_cigar(sb);
+    wflign::append_merged(o, o2, 0, o2.size());
+    r = wflign::cigar_to_string(o);
+  } else if (f == "swap_start_ops") {
+    wflign::CigarOps o = wflign::parse_cigar(sa);
+    wflign::try_swap_start_ops(o, q.data(), (int64_t)q.size(), t.data(), (int64_t)t.size());
+    r = wflign::cigar_to_string(o);
+  } else if (f == "swap_end_ops") {
+    wflign::CigarOps o = wflign::parse_cigar(sa);
+    wflign::try_swap_end_ops(o, q.data(), (int64_t)q.size(), t.data(), (int64_t)t.size());
+    r = wflign::cigar_to_string(o);
+  } else if (f == "head_erosion_ops") {  // third value: the text position behind the eroded runs, for comparison
+    const wflign::CigarOps o = wflign::parse_cigar(sa);
+    const wflign::Erosion e = wflign::scan_head_erosion_ops(o);
+    const size_t pos = wflign::cigar_to_string(wflign::CigarOps(o.begin(), o.begin() + (long)e.erode_end_pos)).size();
+    r = std::to_string(e.query_eroded) + "," + std::to_string(e.target_eroded) + "," + std::to_string(pos);
+  } else if (f == "runs") {  // a = runs as decimal numbers separated by commas -> CIGAR text
+    std::vector<uint32_t> runs;
+    std::stringstream ss(sa);
+    std::string item;
+    while (std::getline(ss, item, ',')) if (!item.empty()) runs.push_back((uint32_t)std::stoul(item));
+    wflign::CigarOps o;
+    wflign::ops_from_runs(runs.data(), runs.size(), o);
+    r = wflign::cigar_to_string(o);
+  } else if (f == "paf_ops") {
+    std::vector<std::string> p;
+    std::stringstream ss(sb);
+    std::string item;
+    while (std::getline(ss, item, '|')) p.push_back(item);
+    if (p.size() == 12) {
+      wflign::PafParams pp;
+      wflign::write_alignment_paf_ops(r, wflign::parse_cigar(sa), p[0], std::stoull(p[1]), std::stoull(p[2]), std::stoull(p[3]), p[4] == "1", p[5],
+                                      std::stoull(p[6]), std::stoull(p[7]), pp, std::stof(p[8]), std::stoi(p[9]), std::stoi(p[10]),
+                                      std::stoi(p[11]));
+    }
+  }
   else if (f == "head_erosion") {
     const wflign::Erosion e = wflign::scan_head_erosion(sa);
     r = std::to_string(e.query_eroded) + "," + std::to_string(e.target_eroded) + "," + std::to_string(e.erode_end_pos);

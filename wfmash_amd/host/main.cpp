@@ -169,6 +169,7 @@ int main(int argc, char** argv) {
     else if (a == "-a" || a == "--sam") ap.sam_format = 1;
     else if (a == "-d" || a == "--md-tag") ap.emit_md_tag = 1;
     else if (a == "-h" || a == "--help") { usage(); return 0; }
+    else if (a == "-v" || a == "--version") { std::printf("%s\n", WFMASH_HIP_VERSION); return 0; }
     else if (a[0] != '-') { if (target.empty()) target = a; else query = a; }
     else { fprintf(stderr, "[wfmash] unknown option %s\n", a.c_str()); usage(); return 1; }
   }

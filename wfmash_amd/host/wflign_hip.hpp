@@ -6,10 +6,11 @@
 // aligns one mapping record per Taskflow task; here every stage of
 // do_biwfa_alignment runs over a whole batch so each stage is one
 // wfm_align_batch call on the GPU:
-//   stage 1  main BiWFA alignment                      (wflign.cpp:136-165)
-//   stage 2  head erosion scan + ends-free head patch  (wflign.cpp:241-320)
-//   stage 3  tail erosion scan + ends-free tail patch  (wflign.cpp:323-418)
-//   stage 4  swizzle + PAF record                      (wflign.cpp:423-454)
+//   stage 1    main BiWFA alignment                        (wflign.cpp:136-165)
+//   stage 2+3  erosion scans + ends-free head and tail patches, one call for both
+//                                                          (wflign.cpp:241-320, 323-418)
+//   stage 4    swizzle + PAF record                         (wflign.cpp:423-454)
+// and CIGARs are runs (count, op) from the device to the record's text: nothing is expanded to one byte per base.
 #pragma once
 
 #include <cstdint>
@@ -51,6 +52,14 @@ struct Erosion {
 Erosion scan_head_erosion(const std::string& main_cigar);                       // wflign.cpp:241-276
 Erosion scan_tail_erosion(const CigarOps& ops);                                 // wflign.cpp:331-364
 
+// ---- the same on runs (the batch pipeline's form; "position in the text" = index of the run) ----
+void ops_from_runs(const uint32_t* runs, size_t n, CigarOps& out);            // wfm_align_batch_rle runs -> (count, op), M as '='
+bool erode_short_matches_ops(CigarOps& ops, int max_match_length, bool is_head_cigar);
+void append_merged(CigarOps& dst, const CigarOps& src, size_t from, size_t to);
+Erosion scan_head_erosion_ops(const CigarOps& ops);                           // erode_end_pos = runs eroded
+bool try_swap_start_ops(CigarOps& ops, const char* q, int64_t qn, const char* t, int64_t tn);
+bool try_swap_end_ops(CigarOps& ops, const char* q, int64_t qn, const char* t, int64_t tn);
+
 // ---- swizzle (wflign_swizzle.cpp:217-299) ----
 std::string try_swap_start_pattern(const std::string& cigar, const std::string& query_seq,
                                    const std::string& target_seq, int64_t query_start, int64_t target_start);
@@ -71,6 +80,13 @@ bool write_alignment_paf(std::string& out, const std::string& cigar_str, const s
                          const std::string& target_name, uint64_t target_total_length, uint64_t target_offset,
                          const PafParams& pp, float mashmap_estimated_identity, int32_t chain_id, int32_t chain_length,
                          int32_t chain_pos);
+
+// The same from runs, in the form the align driver writes in the end: fields joined by single tabs, closing newline
+// (processMappingRecord re-tokenises the writer's text, computeAlignments.hpp:484-525).
+bool write_alignment_paf_ops(std::string& out, const CigarOps& ops, const std::string& query_name, uint64_t query_total_length,
+                             uint64_t query_offset, uint64_t query_length, bool query_is_rev, const std::string& target_name,
+                             uint64_t target_total_length, uint64_t target_offset, const PafParams& pp,
+                             float mashmap_estimated_identity, int32_t chain_id, int32_t chain_length, int32_t chain_pos);
 
 // SAM record (wflign_patch.cpp:2480-2609) incl. the MD:Z tag (write_tag_and_md_string :2397-2478).
 // `query` / `target` are the strand-adjusted query window and the target window (target offset 0).
@@ -96,14 +112,15 @@ struct BiwfaRecord {
   // outputs
   bool ok = false;
   int32_t score = -1;
-  std::string cigar;                 // final CIGAR (after patching + swizzle)
-  std::string paf;                   // PAF line (or SAM line incl. newline) as the reference's writer emits it ("" if filtered)
+  CigarOps ops;                      // final CIGAR as runs (after patching + swizzle)
+  std::string paf;                   // the record's line incl. newline, as the align driver writes it ("" if filtered)
 };
 
 struct BiwfaStats {
   uint64_t cells = 0;
   double ms_gpu = 0;
   uint64_t main_failed = 0, head_patches = 0, tail_patches = 0;
+  std::string error;                 // the device call's message when do_biwfa_alignment_batch returns < 0
 };
 
 struct OutputFormat {
