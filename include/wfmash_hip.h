@@ -160,6 +160,14 @@ int  wfm_align_batch_rle(wfm_handle_t* h, const wfm_penalties_t* pen,
                          wfm_result_t* out, uint32_t** runs, size_t* n_runs_total);
 void wfm_free_runs(uint32_t* runs);
 
+/* Upper bounds of the END2END scores of n problems without aligning them: the cost of one valid global alignment per
+ * problem, found by a greedy walk on the device (one wave per problem: extend along the diagonal, at a difference try a
+ * substitution and the indels up to 31 bases side by side; wfmash_amd/csrc/wfa_kernels.hip, wfa_bound_kernel).  out[i] >= the
+ * optimal gap-affine-2p score of problem i, or -1 where the walk gave up (divergent sequences, structural differences,
+ * sequences under 256 bases).  wfm_align_batch runs this itself for its long BiWFA problems and cuts their wavefronts to
+ * what an alignment of at most that score can touch; the entry point exists for callers that want the bound and for tests. */
+int  wfm_score_bounds(wfm_handle_t* h, const wfm_penalties_t* pen, const wfm_problem_t* problems, size_t n, int32_t* out);
+
 /* Same, but sequences are already resident in device memory (the timed region
  * of bench.py starts here): d_seqs is a device pointer, offsets index into it.
  * Sequences must be laid out by wfm_upload_sequences. */
@@ -172,6 +180,10 @@ int  wfm_align_resident_rle(wfm_handle_t* h, const wfm_penalties_t* pen, wfm_seq
                             wfm_result_t* out, uint32_t** runs, size_t* n_runs_total);
 
 int  wfm_get_stats(const wfm_handle_t* h, wfm_stats_t* out);
+/* The intervals during which a kernel of the handle's last align call was running, merged, as (start, end) pairs in ms on a
+ * clock all handles of one device share: a caller that keeps several calls in flight on handles of their own (the align
+ * driver does) merges them to get the time the device was really busy.  Returns their number (may exceed cap). */
+size_t wfm_get_busy_intervals(const wfm_handle_t* h, double* start_end_ms, size_t cap);
 
 /* ---- map path (see header comment for the reference functions) ---- */
 

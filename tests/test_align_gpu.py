@@ -360,3 +360,51 @@ def test_run_length_output_spells_the_oracles_ops(gpu, oracle):
         assert ops_len == len(ops) and r.n_runs == len(r.ops) == f.n_runs and r.score == f.score
         if len(it) == 2:
             assert r.score == sc
+
+
+def _padded_record(seed, L, snp, indel, pad_t, pad_q=0, sv=0):
+    """a mapping record as the align driver hands it over: query against its padded target window"""
+    import numpy as np
+    base = synth.random_backbone(seed, L + 2 * pad_t + 64)
+    hap = synth.haplotype(base, seed + 1, snp=snp, indel=indel, n_sv=sv, sv_min=300, sv_max=900)
+    t = base.tobytes()
+    q = hap.tobytes()[pad_t - pad_q:pad_t - pad_q + L]
+    return t[:L + 2 * pad_t], q
+
+
+def test_score_bounds_are_upper_bounds_and_tight_on_padded_records(gpu, oracle):
+    """wfm_score_bounds: never below the optimal score (oracle: the O(nm)-checked WFA score), -1 allowed; on low-divergence
+    padded records -- what a pangenome batch is made of -- within a few per cent of it; divergent pairs give -1 or a bound."""
+    items, kinds = [], []
+    for i in range(24):
+        t, q = _padded_record(500 + i, 6000 + 400 * i, 1e-3 * (1 + i % 4), 1e-4 * (1 + i % 3), pad_t=[1000, 300, 1000, 0][i % 4] if i % 4 != 3 else 64,
+                              pad_q=[0, 0, 200, 0][i % 4])
+        items.append((t, q)); kinds.append("padded")
+    for i in range(6):  # the query runs ahead instead (an insertion opens the alignment)
+        t, q = _padded_record(700 + i, 5000, 1e-3, 1e-4, pad_t=800)
+        items.append((q, t)); kinds.append("swapped")
+    for i in range(6):
+        p = synth.random_dna(900 + i, 4000)
+        items.append((p, synth.mutate(p, [0.02, 0.05, 0.15][i % 3], 950 + i))); kinds.append("divergent")
+    for i in range(4):
+        t, q = _padded_record(800 + i, 9000, 1e-3, 1e-4, pad_t=500, sv=2)
+        items.append((t, q)); kinds.append("sv")
+    items.append((synth.random_dna(1, 100), synth.random_dna(2, 120))); kinds.append("short")
+    ub = gpu.score_bounds(items)
+    tight = 0
+    for (p, t), u, kind in zip(items, ub, kinds):
+        rc, ops, sc, _ = oracle.align_biwfa(p, t)
+        assert rc == 0
+        assert u == -1 or u >= sc, (kind, len(p), len(t), int(u), sc)
+        if kind in ("padded", "swapped"):
+            assert u != -1, (kind, len(p), len(t))
+            assert u <= sc + max(40, sc // 20), (kind, int(u), sc)
+            tight += u <= sc + 10
+        if kind == "short":
+            assert u == -1
+    assert tight >= 20
+    # and the alignments themselves do not change (the bound only cuts cells no alignment of that score can touch)
+    res = gpu.align(items)
+    for (p, t), r in zip(items, res):
+        rc, ops, sc, _ = oracle.align_biwfa(p, t)
+        assert r.status == 0 and r.ops == ops and r.score == sc

@@ -27,7 +27,7 @@ EXPORTS = [
     "wfm_map_l1", "wfm_map_l2", "wfm_map_fragments", "wfm_minhash_sketch", "wfm_add_minmers_multi",
     "wfm_prefilter_kmers", "wfm_index_build_sequences", "wfm_index_upload",
     "wfm_index_replicate", "wfm_device_count", "wfm_finish_records",
-    "wfm_align_batch_rle", "wfm_align_resident_rle", "wfm_free_runs",
+    "wfm_align_batch_rle", "wfm_align_resident_rle", "wfm_free_runs", "wfm_score_bounds", "wfm_get_busy_intervals",
 ]
 
 
@@ -319,6 +319,19 @@ class Handle:
             ops = arena[r.ops_off:r.ops_off + r.ops_len].tobytes() if r.status == 0 else None
             out.append(AlignResult(r.status, r.score, ops, r.n_runs, r.cells))
         return out
+
+    def score_bounds(self, items, pen=None):
+        """wfm_score_bounds: per (pattern, text) an upper bound of the end-to-end score, or -1."""
+        probs, keep, n = _make_problems(items)
+        pn = Penalties(*(pen or DEFAULT_PEN))
+        out = np.zeros(max(n, 1), dtype=np.int32)
+        f = self._L.wfm_score_bounds
+        f.restype = C.c_int
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        rc = f(self._p, C.byref(pn), probs, n, out.ctypes.data)
+        if rc < 0:
+            raise WfmError(f"wfm_score_bounds failed ({rc}): {self.last_error()}")
+        return out[:n]
 
     def align_rle(self, items, pen=None):
         """wfm_align_batch_rle: the same problems, run-length output.  AlignResult.ops is the list of (length, op) runs

@@ -141,6 +141,10 @@ struct BaseResult {
   uint64_t cells;
 };
 
+// ---- an upper bound of a root's score before its wavefronts are computed (wfa_bound_kernel) ----
+struct BoundJob { int64_t p_off, t_off; int32_t pl, tl; };
+void launch_bound(const uint8_t* seq, const BoundJob* jobs, int32_t* out, int njobs, DevPen pen, hipStream_t st);
+
 // reversed copies of the sequences of a BiWFA problem, made on the device (wfm_upload_sequences)
 struct SeqRev { int64_t p_fwd, p_rev, t_fwd, t_rev; int32_t plen, tlen; };
 void launch_reverse(uint8_t* seq, const SeqRev* jobs, int njobs, int pad, hipStream_t st);
@@ -159,7 +163,7 @@ void launch_p2_blockmax(const int32_t* ring, const int32_t* p2, const P2Job* job
 void launch_p2_overlap(const int32_t* ring, const int32_t* p2, const P2Job* jobs, const int32_t* p2max, const int32_t* bmax, int32_t* pbmax,
                        BpResult* res, int njobs, int threads, int max_nblk, DevPen pen, int scope, hipStream_t st);
 void launch_base(const uint8_t* seq, int32_t* a32, uint8_t* a8, uint32_t* rle, const BaseJob* jobs, BaseResult* res,
-                 int njobs, DevPen pen, hipStream_t st);
+                 int njobs, DevPen pen, bool wide, hipStream_t st);  // wide: 1024 threads per job instead of 256
 void launch_compact(const uint32_t* rle, const int64_t* off, const int64_t* cap, uint32_t* out, unsigned long long* total,
                     int64_t* out_start, int32_t* out_count, int nprob, hipStream_t st);
 

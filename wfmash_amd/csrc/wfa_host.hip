@@ -14,6 +14,7 @@
 #include <climits>
 #include <cstdio>
 #include <cstring>
+#include <atomic>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -92,8 +93,25 @@ struct wfm_seqset {
   uint64_t seq_bases = 0;
 };
 
+namespace {
+// one time origin per device for the whole process: the busy intervals of calls on different handles of a device (the align
+// driver keeps several batches in flight, each on a handle of its own) are reported against it and can be merged
+std::mutex g_base_mu;
+hipEvent_t g_dev_base[64] = {};
+hipEvent_t device_base_event(int device) {
+  std::lock_guard<std::mutex> lk(g_base_mu);
+  if (device < 0 || device >= 64) return nullptr;
+  if (!g_dev_base[device]) {
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) == hipSuccess && hipEventRecord(e, nullptr) == hipSuccess && hipEventSynchronize(e) == hipSuccess) g_dev_base[device] = e;
+  }
+  return g_dev_base[device];
+}
+}  // namespace
+
 struct wfm_handle {
   int device = 0;
+  std::vector<std::pair<double, double>> busy_abs;  // merged intervals during which a kernel of the last align call ran, ms after the device's origin
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
   std::vector<hipEvent_t> tile_ev;  // start/stop pairs for the tile blocks of one chunk
@@ -118,6 +136,8 @@ struct wfm_handle {
   DevBuf<int32_t> p2rows, p2max, p2bmax, p2pbmax;  // phase 2 from rows computed ahead (P2Job)
   DevBuf<P2Job> p2jobs;
   DevBuf<SeqRev> revjobs;
+  DevBuf<BoundJob> bndjobs;   // roots whose score is bounded from above before their wavefronts run (wfa_bound_kernel)
+  DevBuf<int32_t> bndres;
   uint8_t* stage = nullptr;  // pinned staging buffer of wfm_upload_sequences (grow-only)
   size_t stage_cap = 0;
   DevBuf<BpResult> bpres;
@@ -141,9 +161,49 @@ inline int gapcost(const wfm_penalties_t& p, int L) {
 inline int h_rng_lo(int pl, int tl, int sub, int s) { return std::max(std::max(-pl, -s), (tl - pl) - sub + s); }
 inline int h_rng_hi(int pl, int tl, int sub, int s) { return std::min(std::min(tl, s), (tl - pl) + sub - s); }
 inline int64_t h_row_cells(int pl, int tl, int sub, int s) { return std::max(0, h_rng_hi(pl, tl, sub, s) - h_rng_lo(pl, tl, sub, s) + 1); }
+// sum of h_row_cells over the scores a .. b: the row's edges are piecewise linear in the score (each a min / max of three
+// lines), so between two consecutive kinks the count is an arithmetic series
+inline int64_t h_cells_sum(int pl, int tl, int sub, int a, int b) {
+  if (b < a) return 0;
+  const int64_t kinv = (int64_t)tl - pl, khi = kinv + sub, klo = kinv - sub;
+  // scores at which two of the lines of an edge cross (the kink lies between the floor and the next integer)
+  int64_t cand[16];
+  int nc = 0;
+  auto add = [&](int64_t x) { for (int64_t y : {x, x + 1}) if (y > a && y <= b) cand[nc++] = y; };
+  add(tl); add(khi / 2 - (khi < 0 && (khi & 1) ? 1 : 0)); add(khi - tl);     // hi: s vs tl, s vs khi - s, tl vs khi - s
+  add(pl); add((-klo) / 2 - (-klo < 0 && ((-klo) & 1) ? 1 : 0)); add(-klo - pl);  // lo: -s vs -pl, -s vs klo + s, -pl vs klo + s
+  std::sort(cand, cand + nc);
+  int64_t total = 0;
+  int64_t u = a;
+  auto cells = [&](int64_t s) { return (int64_t)h_rng_hi(pl, tl, sub, (int)s) - h_rng_lo(pl, tl, sub, (int)s) + 1; };
+  auto seg = [&](int64_t x, int64_t y) {  // linear on [x, y]
+    if (y < x) return;
+    const int64_t cx = cells(x), cy = cells(y);
+    if (cx <= 0 && cy <= 0) return;
+    if (cx > 0 && cy > 0) { total += (cx + cy) * (y - x + 1) / 2; return; }
+    if (y == x) { total += std::max<int64_t>(cx, 0); return; }
+    // one end at or below zero: the slope is (cy - cx) / (y - x), an integer (each edge moves by whole diagonals per score)
+    const int64_t slope = (cy - cx) / (y - x);
+    if (cx > 0) {  // falls: positive up to x + (cx - 1) / -slope
+      const int64_t last = x + (cx - 1) / (-slope);
+      total += (cx + cells(last)) * (last - x + 1) / 2;
+    } else {       // rises: positive from y - (cy - 1) / slope
+      const int64_t first = y - (cy - 1) / slope;
+      total += (cells(first) + cy) * (y - first + 1) / 2;
+    }
+  };
+  for (int q = 0; q < nc; ++q) {
+    if (cand[q] <= u) continue;
+    seg(u, cand[q] - 1);
+    u = cand[q];
+  }
+  seg(u, b);
+  return total;
+}
+// (the kernels' rng_block: the score bound as it stood RNG_BACK = 25 scores before the block, see wfa_kernels.hip)
 inline void h_rng_block(int pl, int tl, int sub, int s_from, int s_to, int* L, int* R) {
-  *L = std::max(std::max(-pl, -s_to), (tl - pl) - sub + s_from);
-  *R = std::min(std::min(tl, s_to), (tl - pl) + sub - s_from);
+  *L = std::max(std::max(-pl, -s_to), (tl - pl) - sub + s_from - 25);
+  *R = std::min(std::min(tl, s_to), (tl - pl) + sub - s_from + 25);
 }
 
 int validate_pen(const wfm_penalties_t* pen, int* scope) {
@@ -159,12 +219,23 @@ struct LevelTimer {
   double bp_ms = 0, base_ms = 0, tile_ms = 0;
 };
 
-// Runs all base jobs of `nodes` (chunked to the memory budget); appends
-// overflowed nodes (with a doubled budget) to `retry`.
-int run_base_jobs(wfm_handle* h, wfm_seqset* S, const wfm_penalties_t& pen, const std::vector<Node>& nodes,
+// widest row a base job can reach (0 for the trivial all-gap jobs)
+inline int64_t base_row_width(const Node& nd, const ProbMeta& pm) {
+  if (nd.tl == 0 || nd.pl == 0) return 0;
+  const int64_t kmin = nd.endsfree ? std::max<int64_t>(-nd.pl, -(int64_t)pm.pbf - nd.smax) : std::max<int64_t>(-nd.pl, -nd.smax);
+  const int64_t kmax = nd.endsfree ? std::min<int64_t>(nd.tl, (int64_t)pm.tbf + nd.smax) : std::min<int64_t>(nd.tl, nd.smax);
+  return kmax - kmin + 1;
+}
+
+// Runs all base jobs of `nodes` (chunked to the memory budget, wide jobs apart from narrow ones); appends
+// overflowed nodes (with a larger budget) to `retry`.
+int run_base_jobs(wfm_handle* h, wfm_seqset* S, const wfm_penalties_t& pen, std::vector<Node>& nodes,
                   std::vector<Node>& retry, std::vector<int32_t>& prob_status, std::vector<uint64_t>& prob_cells,
                   LevelTimer& tm) {
   if (nodes.empty()) return WFM_OK;
+  std::stable_sort(nodes.begin(), nodes.end(), [&](const Node& a, const Node& b) {
+    return (base_row_width(a, S->meta[a.prob]) > 2048) < (base_row_width(b, S->meta[b.prob]) > 2048);
+  });
   const DevPen dp{pen.x, pen.o1, pen.e1, pen.o2, pen.e2};
   size_t i0 = 0;
   std::vector<BaseJob> jobs;
@@ -173,9 +244,15 @@ int run_base_jobs(wfm_handle* h, wfm_seqset* S, const wfm_penalties_t& pen, cons
     jobs.clear();
     size_t n32 = 0, n8 = 0;
     size_t i = i0;
+    bool chunk_wide = false;
     for (; i < nodes.size(); ++i) {
       const Node& nd = nodes[i];
       const ProbMeta& pm = S->meta[nd.prob];
+      {  // a chunk holds jobs of one kind: rows beyond 2 k diagonals get 1024 threads
+        const bool wide = base_row_width(nd, pm) > 2048;
+        if (jobs.empty()) chunk_wide = wide;
+        else if (wide != chunk_wide) break;
+      }
       BaseJob j{};
       j.p_off = pm.p_fwd + nd.pb;
       j.t_off = pm.t_fwd + nd.tb;
@@ -225,7 +302,8 @@ int run_base_jobs(wfm_handle* h, wfm_seqset* S, const wfm_penalties_t& pen, cons
       }
       HIPCHK(h, hipMemcpyAsync(h->bsjobs.p, jobs.data(), jobs.size() * sizeof(BaseJob), hipMemcpyHostToDevice, h->stream));
       HIPCHK(h, hipEventRecord(h->ev2, h->stream));
-      launch_base(S->d_seq, h->base32.p, h->base8.p, h->rle.p, h->bsjobs.p, h->bsres.p, (int)jobs.size(), dp, h->stream);
+      // (jobs arrive sorted: the wide ones -- long patches, retries with a larger budget -- in chunks of their own)
+      launch_base(S->d_seq, h->base32.p, h->base8.p, h->rle.p, h->bsjobs.p, h->bsres.p, (int)jobs.size(), dp, chunk_wide, h->stream);
       HIPCHK(h, hipGetLastError());
       HIPCHK(h, hipEventRecord(h->ev3, h->stream));
       res.resize(jobs.size());
@@ -241,6 +319,12 @@ int run_base_jobs(wfm_handle* h, wfm_seqset* S, const wfm_penalties_t& pen, cons
       }
       h->stats.base_launches++;
       h->stats.base_jobs += (uint32_t)jobs.size();
+      if (getenv("WFM_DEBUG") && atoi(getenv("WFM_DEBUG")) > 1) {
+        int64_t wsum = 0, wmax = 0, smx = 0; int over = 0, ef = 0;
+        for (size_t q = 0; q < jobs.size(); ++q) { wsum += jobs[q].width; wmax = std::max<int64_t>(wmax, jobs[q].width); smx = std::max<int64_t>(smx, jobs[q].smax); over += res[q].status == WFM_DEV_OVERFLOW; ef += jobs[q].endsfree; }
+        fprintf(stderr, "[wfm] base launch: %zu jobs (%d ends-free), %d threads, rows %lld wide on average (max %lld), score budget up to %lld, %.3f ms, %d overflowed\n", jobs.size(), ef,
+                chunk_wide ? 1024 : 256, (long long)(wsum / (int64_t)jobs.size()), (long long)wmax, (long long)smx, ms, over);
+      }
       for (size_t q = 0; q < jobs.size(); ++q) {
         const Node& nd = nodes[(size_t)jobs[q].pad_];
         const BaseResult& r = res[q];
@@ -260,7 +344,7 @@ int run_base_jobs(wfm_handle* h, wfm_seqset* S, const wfm_penalties_t& pen, cons
             if (getenv("WFM_DEBUG")) fprintf(stderr, "[wfm] problem %d: base job pl %d tl %d cb %d ce %d overflowed its score bound %d\n", nd.prob, nd.pl, nd.tl, nd.cb, nd.ce, nd.smax);
             prob_status[nd.prob] = WFM_ST_UNREACHABLE; continue;
           }
-          again.smax = (int32_t)std::min<int64_t>((int64_t)nd.smax * 2 + 32, bound);
+          again.smax = (int32_t)std::min<int64_t>((int64_t)nd.smax * 4 + 32, bound);  // (x 2 until round 3: every retry is a launch that a few jobs hold up)
           retry.push_back(again);
         } else if (r.status != 0) {
           if (getenv("WFM_DEBUG")) fprintf(stderr, "[wfm] problem %d: base job pl %d tl %d status %d\n", nd.prob, nd.pl, nd.tl, r.status);
@@ -336,7 +420,8 @@ int run_tiled_phase(wfm_handle* h, wfm_seqset* S, const DevPen& dp, int scope, c
     t.p_fwd = j.p_fwd; t.t_fwd = j.t_fwd; t.p_rev = j.p_rev; t.t_rev = j.t_rev;
     t.ring_in = j.ring_off; t.ring_out = ring2[i];
     t.pl = j.pl; t.tl = j.tl; t.comp_begin = j.comp_begin; t.comp_end = j.comp_end;
-    t.width = j.width; t.koff = j.koff; t.s0 = 0; t.active = 1; t.fmax = 0; t.rmax = 0; t.nblocks = 0; t.mode = 0; t.tf = 0; t.tr = 0; t.last_fwd = 0; t.pad_ = 0;
+    static const int no_wave_skip = (getenv("WFM_WAVE_SKIP") && atoi(getenv("WFM_WAVE_SKIP")) == 0) ? 1 : 0;
+    t.width = j.width; t.koff = j.koff; t.s0 = 0; t.active = 1; t.fmax = 0; t.rmax = 0; t.nblocks = 0; t.mode = 0; t.tf = 0; t.tr = 0; t.last_fwd = 0; t.pad_ = no_wave_skip;
     t.p2_off = 0; t.w2 = 0; t.koff2 = 0; t.sub = j.sub; t.pad2_ = 0;
   }
   bool any_cut = false;  // the kernel form with the score bounds' bookkeeping is only launched when a job carries one
@@ -382,7 +467,11 @@ int run_tiled_phase(wfm_handle* h, wfm_seqset* S, const DevPen& dp, int scope, c
     HIPCHK(h, hipMemsetAsync(h->tilemak.p, 0, n * 2 * (size_t)T * sizeof(int32_t), h->stream));
     const int chunk = std::max(1, std::min(cfg.chunk, (int)h->tile_ev.size() / 2));
     std::vector<TileJob> got(n);
+    auto clk = [] { return std::chrono::steady_clock::now(); };
+    auto msd = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    double ms_prep = 0, ms_launch = 0, ms_wait = 0, ms_post = 0;
     while (n_active) {
+      const auto tq0 = clk();
       // a job on a narrow ring (BpJob::band) may only start a chunk whose last score still fits; otherwise it leaves
       // the tile phase here and is run again on a full ring (the host retries it)
       bool out_of_band = false;
@@ -449,6 +538,7 @@ int run_tiled_phase(wfm_handle* h, wfm_seqset* S, const DevPen& dp, int scope, c
       if (tasks.empty()) { h->err = "tile phase: active jobs without a tile"; return WFM_E_HIP; }
       if (h->tiletasks.ensure(tasks.size())) { h->err = "out of device memory (tile tasks)"; return WFM_E_NOMEM; }
       HIPCHK(h, hipMemcpyAsync(h->tiletasks.p, tasks.data(), tasks.size() * sizeof(TileTask), hipMemcpyHostToDevice, h->stream));
+      const auto tq1 = clk();
       for (int b = 0; b < chunk; ++b) {
         HIPCHK(h, hipEventRecord(h->tile_ev[2 * b], h->stream));
         if (cfg.reg) launch_tile_reg(S->d_seq, h->ring.p, h->tilejobs.p, h->tiletasks.p, h->tilemak.p, (int)tasks.size(), threads_b[(size_t)b], T, cfg.C, any_cut, h->stream);
@@ -458,7 +548,9 @@ int run_tiled_phase(wfm_handle* h, wfm_seqset* S, const DevPen& dp, int scope, c
       }
       HIPCHK(h, hipGetLastError());
       HIPCHK(h, hipMemcpyAsync(got.data(), h->tilejobs.p, n * sizeof(TileJob), hipMemcpyDeviceToHost, h->stream));
+      const auto tq2 = clk();
       HIPCHK(h, hipStreamSynchronize(h->stream));
+      const auto tq3 = clk();
       for (int b = 0; b < chunk; ++b) {
         float ms = 0;
         HIPCHK(h, hipEventElapsedTime(&ms, h->tile_ev[2 * b], h->tile_ev[2 * b + 1]));
@@ -480,10 +572,7 @@ int run_tiled_phase(wfm_handle* h, wfm_seqset* S, const DevPen& dp, int scope, c
           const int base = s_begin[i] + (last_exact ? bl - 1 : bl) * T;          // it re-ran the block before it
           for (int d = 0; d < 2; ++d) {
             const int steps = last_exact ? (d == 0 ? got[i].tf : got[i].tr) : T;
-            for (int t = 1; t <= steps; ++t) {
-              const int sc = base + t;
-              tile_cells += (uint64_t)h_row_cells(tj[i].pl, tj[i].tl, tj[i].sub, sc);
-            }
+            tile_cells += (uint64_t)h_cells_sum(tj[i].pl, tj[i].tl, tj[i].sub, base + 1, base + steps);
           }
         }
         tj[i] = got[i];
@@ -491,16 +580,17 @@ int run_tiled_phase(wfm_handle* h, wfm_seqset* S, const DevPen& dp, int scope, c
         fmax[i] = got[i].fmax; rmax[i] = got[i].rmax;
         n_active += active[i];
       }
+      ms_prep += msd(tq0, tq1); ms_launch += msd(tq1, tq2); ms_wait += msd(tq2, tq3); ms_post += msd(tq3, clk());
     }
+    if (getenv("WFM_DEBUG") && atoi(getenv("WFM_DEBUG")) > 1)
+      fprintf(stderr, "[wfm] level %u tile phase, host side: task lists %.2f ms, launches %.2f ms, waiting for the device %.2f ms, bookkeeping %.2f ms\n", level, ms_prep, ms_launch, ms_wait, ms_post);
   }
   // cells that went into the result: both directions up to where the tile phase leaves the job (the full block in which
   // the wavefronts met was computed as well, and then again up to the meeting point: tile_cells counts it, this does not)
   for (size_t i = 0; i < n; ++i) {
     const int sf_end = tj[i].mode == 2 ? tj[i].s0 + tj[i].tf : tj[i].s0, sr_end = tj[i].mode == 2 ? tj[i].s0 + tj[i].tr : tj[i].s0;
-    uint64_t u = 0;
-    for (int sc = s_begin[i] + 1; sc <= std::max(sf_end, sr_end); ++sc)
-      u += (uint64_t)h_row_cells(tj[i].pl, tj[i].tl, tj[i].sub, sc) * (uint64_t)((sc <= sf_end) + (sc <= sr_end));
-    h->stats.cells_tile_unique += u;
+    h->stats.cells_tile_unique += (uint64_t)h_cells_sum(tj[i].pl, tj[i].tl, tj[i].sub, s_begin[i] + 1, sf_end) +
+                                  (uint64_t)h_cells_sum(tj[i].pl, tj[i].tl, tj[i].sub, s_begin[i] + 1, sr_end);
   }
   for (size_t i = 0; i < n; ++i) {
     BpJob& j = jobs[(size_t)tiled[i]];
@@ -555,7 +645,8 @@ int run_p2_phase(wfm_handle* h, wfm_seqset* S, const DevPen& dp, int scope, cons
       t.ring_in = j.ring_off; t.ring_out = ring_other[i];
       t.pl = j.pl; t.tl = j.tl; t.comp_begin = j.comp_begin; t.comp_end = j.comp_end;
       t.width = j.width; t.koff = j.koff; t.s0 = 0; t.active = 1; t.fmax = 0; t.rmax = 0; t.nblocks = 0;
-      t.mode = 4; t.tf = j.resume_s; t.tr = j.resume_sr; t.last_fwd = j.last_fwd; t.pad_ = 0;
+      static const int no_wave_skip = (getenv("WFM_WAVE_SKIP") && atoi(getenv("WFM_WAVE_SKIP")) == 0) ? 1 : 0;
+      t.mode = 4; t.tf = j.resume_s; t.tr = j.resume_sr; t.last_fwd = j.last_fwd; t.pad_ = no_wave_skip;
       t.p2_off = (int64_t)elems; t.w2 = (int32_t)w2; t.koff2 = koff2; t.sub = j.sub;
       P2Job q{};
       q.ring_in = j.ring_off; q.p2_off = (int64_t)elems; q.width = j.width; q.koff = j.koff; q.w2 = (int32_t)w2; q.koff2 = koff2;
@@ -602,7 +693,7 @@ int run_p2_phase(wfm_handle* h, wfm_seqset* S, const DevPen& dp, int scope, cons
     launch_p2_blockmax(h->ring.p, h->p2rows.p, h->p2jobs.p, h->p2bmax.p, h->p2max.p, (int)n, h->stream);
     static const int p2_threads = getenv("WFM_P2_THREADS") ? atoi(getenv("WFM_P2_THREADS")) : 0;
     launch_p2_overlap(h->ring.p, h->p2rows.p, h->p2jobs.p, h->p2max.p, h->p2bmax.p, h->p2pbmax.p, h->bpres.p, (int)n,
-                      p2_threads > 0 ? p2_threads : (maxw2 <= 4096 ? 256 : (maxw2 <= 32768 ? 512 : 1024)), (int)(maxw2 >> 6) + 1, dp, scope, h->stream);
+                      p2_threads > 0 ? p2_threads : 1024, (int)(maxw2 >> 6) + 1, dp, scope, h->stream);  // 16 waves over the 5 x P2G (test, component) scans of a round and their rows
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipEventRecord(h->ev1, h->stream));
     got.resize(n);
@@ -616,13 +707,27 @@ int run_p2_phase(wfm_handle* h, wfm_seqset* S, const DevPen& dp, int scope, cons
       HIPCHK(h, hipEventElapsedTime(&t0, h->call_base, h->ev0));
       h->bp_iv.emplace_back(t0, t0 + ms);
     }
+    if (const char* de = getenv("WFM_P2_DUMP")) {  // diagnosis: the row maxima of one job of the chunk
+      const size_t q = std::min<size_t>((size_t)atoi(de), n - 1);
+      std::vector<int32_t> rm((size_t)2 * P2ROWS * 5);
+      HIPCHK(h, hipMemcpy(rm.data(), h->p2max.p + q * 2 * P2ROWS * 5, rm.size() * 4, hipMemcpyDeviceToHost));
+      const P2Job& pjq = pj[q];
+      fprintf(stderr, "[wfm] p2 dump job %zu: pl %d tl %d sf %d sr %d last_fwd %d sub %d w2 %d nblk %d -> status %d score %d (fwd %d rev %d comp %d k %d) rounds %d\n", q, pjq.pl, pjq.tl, pjq.sf,
+              pjq.sr, pjq.last_fwd, pjq.sub, pjq.w2, pjq.nblk, got[q].status, got[q].score, got[q].score_fwd, got[q].score_rev, got[q].comp, got[q].k_fwd, got[q].pad_);
+      for (int d = 0; d < 2; ++d)
+        for (int r = 0; r < P2ROWS; r += 3) {
+          const int32_t* m = rm.data() + ((size_t)d * P2ROWS + r) * 5;
+          fprintf(stderr, "[wfm]   dir %d row %d (s = %d): max M %d I1 %d I2 %d D1 %d D2 %d\n", d, r, (d == 0 ? pjq.sf : pjq.sr) - 25 + r, m[0], m[1], m[2], m[3], m[4]);
+        }
+    }
     h->stats.p2_launches++;
     h->stats.p2_jobs += (uint32_t)n;
     if (getenv("WFM_DEBUG")) {
       int more = 0;
-      for (const BpResult& r : got) more += r.status == WFM_DEV_P2_MORE;
-      fprintf(stderr, "[wfm] phase 2 from rows computed ahead: %zu jobs, widest %zu columns, %zu tiles of %d threads, %.3f ms, %d left to the step kernel\n",
-              n, maxw2, tasks.size(), threads_c, ms, more);
+      double tk = 0, tc = 0, rd = 0; uint32_t tkmax = 0; int rdmax = 0;
+      for (const BpResult& r : got) { more += r.status == WFM_DEV_P2_MORE; tk += r.ticks_p2; tc += r.ticks_p1; rd += r.pad_; tkmax = std::max(tkmax, r.ticks_p2); rdmax = std::max(rdmax, r.pad_); }
+      fprintf(stderr, "[wfm] phase 2 from rows computed ahead: %zu jobs, widest %zu columns, %zu tiles of %d threads, %.3f ms, %d left to the step kernel; walk per job: %.1f rounds (max %d), %.0f us (max %.0f), of which cells stage %.0f us\n",
+              n, maxw2, tasks.size(), threads_c, ms, more, rd / n, rdmax, tk / n / 100.0, tkmax / 100.0, tc / n / 100.0);
     }
     for (size_t q = 0; q < n; ++q) res[(size_t)cand[i0 + q]] = got[q];
     i0 = i;
@@ -679,6 +784,50 @@ int align_resident_impl(wfm_handle* h, const wfm_penalties_t* pen, wfm_seqset* S
     }
   }
 
+  // ---- an upper bound of every long root's score, from one greedy walk per root (wfa_bound_kernel): rigorous, so the root's
+  // wavefronts are cut to what an alignment of at most that score can touch -- usually a fifth of what the caller's guess
+  // leaves.  The guess stays where the walk gives up (divergent records, structural differences).
+  uint64_t bounded_roots = 0, bound_gain = 0;
+  double bound_ms = 0;
+  {
+    static const bool use_bound = !(getenv("WFM_BOUND") && atoi(getenv("WFM_BOUND")) == 0) && !(getenv("WFM_SCORE_HINT") && atoi(getenv("WFM_SCORE_HINT")) == 0);
+    std::vector<BoundJob> bj;
+    std::vector<size_t> owner;
+    if (use_bound)
+      for (size_t q = 0; q < bp_nodes.size(); ++q) {
+        const Node& nd = bp_nodes[q];
+        const ProbMeta& pm = S->meta[nd.prob];
+        // only where a bound can bind: the end diagonal far from the start diagonal (see BpJob::sub below)
+        if (pm.mode != WFM_MODE_END2END_BIWFA || std::min(nd.pl, nd.tl) < 1024 || std::abs(nd.tl - nd.pl) < 64) continue;
+        bj.push_back(BoundJob{pm.p_fwd, pm.t_fwd, nd.pl, nd.tl});
+        owner.push_back(q);
+      }
+    if (!bj.empty()) {
+      const auto tb0 = std::chrono::steady_clock::now();
+      if (h->bndjobs.ensure(bj.size()) || h->bndres.ensure(bj.size())) { h->err = "out of device memory (score bounds)"; return WFM_E_NOMEM; }
+      HIPCHK(h, hipMemcpyAsync(h->bndjobs.p, bj.data(), bj.size() * sizeof(BoundJob), hipMemcpyHostToDevice, h->stream));
+      launch_bound(S->d_seq, h->bndjobs.p, h->bndres.p, (int)bj.size(), dp, h->stream);
+      HIPCHK(h, hipGetLastError());
+      std::vector<int32_t> ub(bj.size());
+      HIPCHK(h, hipMemcpyAsync(ub.data(), h->bndres.p, bj.size() * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+      HIPCHK(h, hipStreamSynchronize(h->stream));
+      for (size_t q = 0; q < bj.size(); ++q) {
+        if (ub[q] < 0) continue;
+        Node& nd = bp_nodes[owner[q]];
+        if (nd.sub == SUB_NONE || ub[q] < nd.sub) {
+          if (nd.sub != SUB_NONE) bound_gain += (uint64_t)(nd.sub - ub[q]);
+          nd.sub = ub[q];
+          nd.hinted = 1;  // (cannot fail; the retry of a root that runs past its bound stays as the safety net it is)
+          ++bounded_roots;
+        }
+      }
+      bound_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tb0).count();
+      if (getenv("WFM_DEBUG"))
+        fprintf(stderr, "[wfm] score bounds: %zu roots walked in %.2f ms, %llu bounded (on average %.0f below the caller's guess)\n", bj.size(), bound_ms,
+                (unsigned long long)bounded_roots, bounded_roots ? (double)bound_gain / (double)bounded_roots : 0.0);
+    }
+  }
+
   LevelTimer tm;
   double wall_tile = 0, wall_base = 0;
   std::vector<BpJob> jobs;
@@ -707,7 +856,9 @@ int align_resident_impl(wfm_handle* h, const wfm_penalties_t* pen, wfm_seqset* S
       const int band_on = be ? atoi(be) : 1;
       size_t total = 0;
       for (const Node& nd : bp_nodes) total += (((size_t)nd.pl + nd.tl + 9 + 3) & ~(size_t)3) * 2 * 5 * RING * 2;
-      use_band = band_on && total * 4 > h->mem_budget;
+      // (narrow rings whenever full ones would take more than 2 GB, not only when they would not fit: every fresh GB of a
+      // first hipMalloc costs ~30 ms on this driver, scripts/malloc_cost2.hip, and a one-shot run pays it)
+      use_band = band_on && total * 4 > std::min<size_t>(h->mem_budget, (size_t)2 << 30);
     }
     const char* bre = getenv("WFM_BAND_ROOT");
     const int band_root = bre ? std::max(64, atoi(bre)) : 4096;
@@ -729,7 +880,9 @@ int align_resident_impl(wfm_handle* h, const wfm_penalties_t* pen, wfm_seqset* S
         int band = 0;
         if (use_band && tile_it && !nd.noband && !(roots_off && nd.score_rem == INT_MAX)) {
           // scores one direction is allowed to reach; the ring holds |k| <= band + 8, its left margin stays 4 columns
-          const int64_t dir_scores = nd.score_rem == INT_MAX ? (int64_t)band_root : (int64_t)nd.score_rem / 2 + 64;
+          // (a root under a bound of its score leaves the tile phase once a direction passes (bound + 128) / 2)
+          int64_t dir_scores = nd.score_rem == INT_MAX ? (int64_t)band_root : (int64_t)nd.score_rem / 2 + 64;
+          if (nd.score_rem == INT_MAX && nd.sub != SUB_NONE) dir_scores = std::min<int64_t>(dir_scores, ((int64_t)nd.sub + 128) / 2 + 64);
           const int64_t b = dir_scores + (int64_t)tcfg.chunk * tcfg.T + 16;
           const int64_t shift = ((int64_t)nd.pl - (b + 8)) & ~(int64_t)3;  // columns cut off on the left, whole 16-byte chunks
           const int64_t right = std::min<int64_t>(nd.tl, b + 8);           // largest diagonal kept
@@ -865,7 +1018,21 @@ int align_resident_impl(wfm_handle* h, const wfm_penalties_t* pen, wfm_seqset* S
           } else {
             const int bp_h = r.off_fwd, bp_v = r.off_fwd - r.k_fwd;
             if (bp_h < 0 || bp_v < 0 || bp_h > nd.tl || bp_v > nd.pl) {
-              if (getenv("WFM_DEBUG")) fprintf(stderr, "[wfm] problem %d: bialign job pl %d tl %d: breakpoint (%d, %d) outside, score %d = %d + %d comp %d k %d\n", nd.prob, nd.pl, nd.tl, bp_v, bp_h, r.score, r.score_fwd, r.score_rev, r.comp, r.k_fwd);
+              if (getenv("WFM_DEBUG")) fprintf(stderr, "[wfm] problem %d: bialign job pl %d tl %d (at %d, %d of the problem; level %u, begin / end components %d %d, bound %d%s): breakpoint (%d, %d) outside, score %d = %d + %d comp %d k %d\n", nd.prob, nd.pl, nd.tl, nd.pb, nd.tb, level, nd.cb, nd.ce, jobs[q].sub, nd.hinted ? " guessed" : "", bp_v, bp_h, r.score, r.score_fwd, r.score_rev, r.comp, r.k_fwd);
+              if (const char* dd = getenv("WFM_DUMP_FAIL")) {  // diagnosis: the whole problem's sequences, for a replay
+                const ProbMeta& pm = S->meta[nd.prob];
+                std::vector<char> pb((size_t)pm.plen), tb((size_t)pm.tlen);
+                (void)hipMemcpy(pb.data(), S->d_seq + pm.p_fwd, pb.size(), hipMemcpyDeviceToHost);
+                (void)hipMemcpy(tb.data(), S->d_seq + pm.t_fwd, tb.size(), hipMemcpyDeviceToHost);
+                static std::atomic<int> nfail{0};
+                const std::string fn = std::string(dd) + "/fail_" + std::to_string(nfail.fetch_add(1)) + ".txt";
+                if (FILE* f = fopen(fn.c_str(), "w")) {
+                  fprintf(f, "%d %d %d\n", pm.plen, pm.tlen, pm.hint);
+                  fwrite(pb.data(), 1, pb.size(), f); fputc('\n', f);
+                  fwrite(tb.data(), 1, tb.size(), f); fputc('\n', f);
+                  fclose(f);
+                }
+              }
               prob_status[nd.prob] = WFM_ST_UNREACHABLE; continue;
             }
             if (getenv("WFM_DEBUG") && atoi(getenv("WFM_DEBUG")) > 1) fprintf(stderr, "[wfm] problem %d level %u: job pl %d tl %d cb %d ce %d rem %d -> bp v %d h %d score %d = %d + %d comp %d\n", nd.prob, level, nd.pl, nd.tl, nd.cb, nd.ce, nd.score_rem, bp_v, bp_h, r.score, r.score_fwd, r.score_rev, r.comp);
@@ -915,7 +1082,7 @@ int align_resident_impl(wfm_handle* h, const wfm_penalties_t* pen, wfm_seqset* S
   if (getenv("WFM_P2_COUNT") && atoi(getenv("WFM_P2_COUNT"))) {
     unsigned long long c[8];
     wfm::p2_counters(c);
-    fprintf(stderr, "[wfm] p2 overlap (cumulative): tests %llu, with candidates %llu, blocks looked at %llu, passing %llu, diagonals reaching %llu, o1 loads %llu, hits %llu\n",
+    fprintf(stderr, "[wfm] p2 overlap (cumulative): tests %llu, with candidates %llu, pairs listed %llu, blocks tested cell by cell %llu, pairs that met %llu; most pairs in a round %llu, most blocks one wave tested in a round %llu\n",
             c[0], c[1], c[2], c[3], c[4], c[5], c[6]);
   }
   if (getenv("WFM_DEBUG") && hint_retries) fprintf(stderr, "[wfm] score hints: %llu roots ran past their hint and were run again without it\n", (unsigned long long)hint_retries);
@@ -1072,7 +1239,7 @@ void wfm_destroy(wfm_handle_t* h) {
   (void)hipSetDevice(h->device);
   h->ring.release(); h->base32.release(); h->base8.release(); h->rle.release(); h->rle_out.release();
   h->tilejobs.release(); h->tiletasks.release(); h->tilemak.release();
-  h->revjobs.release();
+  h->revjobs.release(); h->bndjobs.release(); h->bndres.release();
   if (h->stage) { (void)hipHostFree(h->stage); h->stage = nullptr; h->stage_cap = 0; }
   h->p2rows.release(); h->p2max.release(); h->p2bmax.release(); h->p2pbmax.release(); h->p2jobs.release();
   h->bpjobs.release(); h->bpres.release(); h->bsjobs.release(); h->bsres.release();
@@ -1248,6 +1415,19 @@ int align_resident_any(wfm_handle_t* h, const wfm_penalties_t* pen, wfm_seqset_t
     return total;
   };
   h->mem_budget = h->mem_budget_full;
+  auto keep_abs = [&](std::vector<std::pair<float, float>> iv) {  // the union as intervals on the device's own clock
+    h->busy_abs.clear();
+    hipEvent_t db = device_base_event(h->device);
+    float off = 0;
+    if (!db || hipEventElapsedTime(&off, db, h->ev_base) != hipSuccess) return;
+    std::sort(iv.begin(), iv.end());
+    double lo = 0, hi = -1;
+    for (const auto& x : iv) {
+      if (x.first > hi) { if (hi > lo) h->busy_abs.emplace_back(off + lo, off + hi); lo = x.first; hi = x.second; }
+      else hi = std::max<double>(hi, x.second);
+    }
+    if (hi > lo) h->busy_abs.emplace_back(off + lo, off + hi);
+  };
   auto finish_single = [&](int rc) {
     h->stats.ms_tile_busy = busy_ms(h->tile_iv);
     h->stats.ms_bp_busy = busy_ms(h->bp_iv);
@@ -1256,6 +1436,7 @@ int align_resident_any(wfm_handle_t* h, const wfm_penalties_t* pen, wfm_seqset_t
     all.insert(all.end(), h->bp_iv.begin(), h->bp_iv.end());
     all.insert(all.end(), h->base_iv.begin(), h->base_iv.end());
     h->stats.ms_any_busy = busy_ms(all);
+    keep_abs(all);
     h->stats.streams = 1;
     return rc;
   };
@@ -1273,6 +1454,9 @@ int align_resident_any(wfm_handle_t* h, const wfm_penalties_t* pen, wfm_seqset_t
   static const int want = [] { const char* e = getenv("WFM_STREAMS"); return e ? std::max(1, std::min(8, atoi(e))) : 3; }();  // measured: 2 -> 124, 3 -> 120, 4 -> 160 ms on C3
   // every part needs room for its own arenas: no split below 256 MB per part
   size_t parts = std::min<size_t>(std::min<size_t>((size_t)want, n / 4), h->mem_budget_full >> 28);
+  // A batch of hundreds of problems fills the device on its own -- its levels are thousands of workgroups wide -- and the
+  // align driver keeps further batches in flight on handles of their own: such a batch runs as one part
+  if (!getenv("WFM_STREAMS") && n >= 512) parts = 1;
   if (!getenv("WFM_STREAMS") && parts > 2) {
     // a batch whose full rings would not fit the budget -- thousands of long records, which then run on narrow
     // rings -- is bound by the host's work between the many small launches: measured best with two parts
@@ -1350,6 +1534,7 @@ int align_resident_any(wfm_handle_t* h, const wfm_penalties_t* pen, wfm_seqset_t
   iv.insert(iv.end(), ivb.begin(), ivb.end());
   iv.insert(iv.end(), ivs.begin(), ivs.end());
   a.ms_any_busy = busy_ms(iv);
+  keep_abs(iv);
   a.streams = (uint32_t)np;
   return failed;
 }
@@ -1382,6 +1567,28 @@ int wfm_align_batch_rle(wfm_handle_t* h, const wfm_penalties_t* pen, const wfm_p
 
 void wfm_free_runs(uint32_t* runs) { free(runs); }
 
+int wfm_score_bounds(wfm_handle_t* h, const wfm_penalties_t* pen, const wfm_problem_t* problems, size_t n, int32_t* out) {
+  if (!h || !pen || !out || (n && !problems)) return WFM_E_ARG;
+  if (n == 0) return WFM_OK;
+  wfm_seqset_t* S = nullptr;
+  int rc = wfm_upload_sequences(h, problems, n, &S);
+  if (rc != WFM_OK) return rc;
+  std::vector<BoundJob> bj(n);
+  for (size_t i = 0; i < n; ++i) bj[i] = BoundJob{S->meta[i].p_fwd, S->meta[i].t_fwd, S->meta[i].plen, S->meta[i].tlen};
+  auto run = [&]() -> int {
+    if (h->bndjobs.ensure(n) || h->bndres.ensure(n)) { h->err = "out of device memory (score bounds)"; return WFM_E_NOMEM; }
+    HIPCHK(h, hipMemcpyAsync(h->bndjobs.p, bj.data(), n * sizeof(BoundJob), hipMemcpyHostToDevice, h->stream));
+    launch_bound(S->d_seq, h->bndjobs.p, h->bndres.p, (int)n, DevPen{pen->x, pen->o1, pen->e1, pen->o2, pen->e2}, h->stream);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipMemcpyAsync(out, h->bndres.p, n * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return WFM_OK;
+  };
+  rc = run();
+  wfm_free_sequences(h, S);
+  return rc;
+}
+
 namespace {
 int align_batch_any(wfm_handle_t* h, const wfm_penalties_t* pen, const wfm_problem_t* problems, size_t n,
                     wfm_result_t* out, char* ops_arena, size_t arena_bytes, uint32_t** runs, size_t* n_runs_total) {
@@ -1403,6 +1610,13 @@ int align_batch_any(wfm_handle_t* h, const wfm_penalties_t* pen, const wfm_probl
   return rc;
 }
 }  // namespace
+
+size_t wfm_get_busy_intervals(const wfm_handle_t* h, double* start_end_ms, size_t cap) {
+  if (!h) return 0;
+  const size_t n = h->busy_abs.size();
+  for (size_t i = 0; i < n && i < cap && start_end_ms; ++i) { start_end_ms[2 * i] = h->busy_abs[i].first; start_end_ms[2 * i + 1] = h->busy_abs[i].second; }
+  return n;
+}
 
 int wfm_get_stats(const wfm_handle_t* h, wfm_stats_t* out) {
   if (!h || !out) return WFM_E_ARG;

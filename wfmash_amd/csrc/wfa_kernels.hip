@@ -208,11 +208,18 @@ __device__ __forceinline__ Rng make_rng(int pl, int tl, int sub) { Rng r; r.pl =
 __device__ __forceinline__ int rng_lo(const Rng& r, int s) { return max(max(-r.pl, -s), r.kb_lo + s); }
 __device__ __forceinline__ int rng_hi(const Rng& r, int s) { return min(min(r.tl, s), r.kb_hi - s); }
 // The diagonals a tile pass over the scores (s_from, s_to] has to hold: every bound at its loosest score of the block -- and
-// the score bound at s_from itself, one diagonal beyond the first new row's edge: that row's edge cell takes a gap from the
-// diagonal next to it, which is inside the (wider) older rows.
+// the score bound as it stood 25 scores BEFORE the block: the edge a score bound sets moves inwards, so the rows the block
+// starts from are wider than its own, and the snapshot it leaves behind must hold every row of the last 26 scores whole --
+// a short last block (one that stops at the meeting point after a few steps) hands rows older than its own first row to
+// phase 2, which reads each row over its full range.  (Until round 3 the bound was taken at s_from: the cells of the older
+// rows beyond it never reached the output ring, and phase 2 read whatever the ring held there.  With the slack the bounds
+// used to carry -- 56 for a child, 200 for a caller's guess -- those cells could not complete an overlap within the bound
+// and stale values of the same job never made one up; an exact bound on a small batch, where rings are reused across
+// jobs, did: a false breakpoint one point under the optimum.)
+constexpr int RNG_BACK = 25;
 __device__ __forceinline__ void rng_block(const Rng& r, int s_from, int s_to, int& L, int& R) {
-  L = max(max(-r.pl, -s_to), r.kb_lo + s_from);
-  R = min(min(r.tl, s_to), r.kb_hi - s_from);
+  L = max(max(-r.pl, -s_to), r.kb_lo + s_from - RNG_BACK);
+  R = min(min(r.tl, s_to), r.kb_hi - s_from + RNG_BACK);
 }
 
 struct BpCtx {
@@ -822,7 +829,12 @@ struct RleWriter {
   }
 };
 
-__global__ __launch_bounds__(256) void wfa_base_kernel(const uint8_t* __restrict__ seq, int32_t* __restrict__ arena32,
+// NT: threads of a workgroup.  256 for leaves and ordinary patches (rows of a few hundred to 1.3 k diagonals); 1024 for the
+// jobs with wide rows -- a patch eroded to its 4096-base limit starts 8 k diagonals wide, and the ones that overflow
+// their first score budget are exactly those: at 256 threads a step walked its row in 30 rounds of dependent loads and a
+// handful of such jobs ran 5 - 10 ms behind everybody else's 0.3.
+template <int NT>
+__global__ __launch_bounds__(NT) void wfa_base_kernel(const uint8_t* __restrict__ seq, int32_t* __restrict__ arena32,
                                                        uint8_t* __restrict__ arena8, uint32_t* __restrict__ rle,
                                                        const BaseJob* __restrict__ jobs, BaseResult* __restrict__ results,
                                                        DevPen pen) {
@@ -1558,6 +1570,18 @@ __global__ __launch_bounds__(NTMAX) void wfa_tile_reg_kernel(const uint8_t* __re
     const int cl = jj % NCL;  // residue class of this step's score: compile time after unrolling
     const int s = s0 + t;
     const int par = t & 1;
+    // A wave none of whose diagonals (nor the one next to them) lies in a row this step can read or write has nothing to do
+    // but keep the step's barrier: its history is all NULL before its first cell comes into range (ranges only grow at the
+    // triangle's edges), and at an edge that a score bound moves inwards it goes on for LB more steps, until no row a
+    // neighbour may still read holds one of its diagonals.  What its mailbox slots hold in the meantime is masked by the
+    // readers' range selects.  (The workgroup is as wide as the widest job-direction of the launch: most of the waves of a
+    // narrow job -- a child under its exact bound, a root under its walked bound -- are such waves.)
+    {
+      const int lo_all = (CUT ? max(max(-pl, -s), RG.kb_lo + s - LB) : max(-pl, -s)) - 1;
+      const int hi_all = (CUT ? min(min(tl, s), RG.kb_hi - s + LB) : min(tl, s)) + 1;
+      const int kw_lo = kA + wv * 64 * C;
+      if (!J.pad_ && (kw_lo + 64 * C - 1 < lo_all || kw_lo > hi_all)) { __syncthreads(); continue; }  // (TileJob::pad_ != 0: WFM_WAVE_SKIP=0, for A/B runs)
+    }
     // rows this step reads from its class: [0] = s-5, [1] = s-10, [4] = s-25
     // publish the wave-edge history values needed by the neighbouring waves in this step
     if (lane == 63) { int* e = s_edge[par][wv][0]; e[0] = Mh[C - 1][cl][1]; e[1] = Mh[C - 1][cl][4]; e[2] = I1h[C - 1][E1 - 1]; e[3] = I2h[C - 1]; }
@@ -1892,21 +1916,20 @@ __global__ __launch_bounds__(256) void wfa_p2_prefixmax_kernel(const P2Job* __re
   }
 }
 
-__device__ unsigned long long g_p2cnt[8];  // WFM_P2_COUNT diagnostics: tests, tests with candidates, blocks looked at, blocks passing, diagonals reaching, o1 loads, hits
-constexpr int P2LIST = 1024;  // blocks of the tested row that can pass the block-level test before the kernel stops listing them
+__device__ unsigned long long g_p2cnt[8];  // WFM_P2_COUNT diagnostics: tests, tests with candidates, pairs listed, blocks tested cell by cell, pairs that met, most pairs in a round, most blocks one wave tested in a round
 
 // The loop for one workgroup, P2G tests per round.  Every stage of a round is spread over the threads; the stages are
 // separated by barriers (each costs a round trip or two to the job's rows in L2, which is what a test's time is made of --
 // hence several tests per round):
 //   pairs    per test: which (row i of the other direction, component) pairs can still improve the best breakpoint (score)
-//            and can reach tl at all (row maxima)
-//   blocks   which 64-diagonal blocks of a tested row can meet a mirrored block (block maximum of the row against the
-//            running block maxima of the other direction)
-//   cells    the diagonals of those blocks, each against the pairs whose own block maximum lets it: smallest diagonal per pair
+//            and can reach tl at all (row maxima); they are listed
+//   scan     one wave per (test, component) and all its rows: the 64-diagonal blocks of the tested row in ascending order, each
+//            against the block maxima of every row (one row per lane), then the cells of the rows that pass (four rows
+//            in flight), every pair up to the first diagonal on which its offsets meet
 //   pick     test after test in the reference's order: the pair its nested loop would end up with -- smallest score, first in
 //            its order among equals -- and the loop's own end condition
 // The tests of a round see the best breakpoint as it was when the round began: that only lets more pairs through the first
-// three stages than a test on its own would look at; what a test takes is decided in `pick`, with the best of that moment.
+// two stages than a test on its own would look at; what a test takes is decided in `pick`, with the best of that moment.
 constexpr int P2G = 8;
 __global__ __launch_bounds__(1024) void wfa_p2_overlap_kernel(const int32_t* __restrict__ ring, const int32_t* __restrict__ p2,
                                                              const P2Job* __restrict__ jobs, const int32_t* __restrict__ p2max,
@@ -1916,12 +1939,10 @@ __global__ __launch_bounds__(1024) void wfa_p2_overlap_kernel(const int32_t* __r
   const P2Job J = jobs[job];
   const int nblk = J.nblk;
   const int32_t* bmj = bmax + J.bm_off;
-  const int32_t* pbj = pbmax + J.bm_off;
+  (void)pbmax;
   __shared__ int s_mink[P2G][P2ENT];
-  __shared__ int s_act[P2G][P2ENT];
-  __shared__ int s_k[P2G][4];   // per test: klo, khi of the candidate rows' mirrored ranges; any
-  __shared__ int s_nlist;
-  __shared__ int s_list[P2LIST];  // (test << 24) | block of the tested row
+  __shared__ int s_k[P2G][4];   // per test: [2] = some pair can still matter
+  __shared__ unsigned s_pmask[P2G][5];  // per (test, component): the rows of the other direction (bit i = row s1 - i) that can still matter
   __shared__ int s_state[8];    // sf, sr, last_fwd, best, status (0 running, 1 ended, 2 more tests than rows), tests done
   __shared__ int s_bp[8];
   __shared__ unsigned long long s_cells;
@@ -1934,7 +1955,11 @@ __global__ __launch_bounds__(1024) void wfa_p2_overlap_kernel(const int32_t* __r
   const int pl = J.pl, tl = J.tl, kinv = tl - pl;
   const Rng RG = make_rng(pl, tl, J.sub);
   const int gopen = max(pen.o1, pen.o2);
+  const long long t_begin = wall_clock64();
+  long long t_cells = 0;
+  int rounds = 0;
   for (;;) {
+    ++rounds;
     // ---- state at the start of the round (uniform)
     const int sf0 = s_state[0], sr0 = s_state[1], lf0 = s_state[2], best = s_state[3], u0 = s_state[5];
     if (s_state[4] != 0) break;
@@ -1946,10 +1971,11 @@ __global__ __launch_bounds__(1024) void wfa_p2_overlap_kernel(const int32_t* __r
       else { d0 = first ^ 1; s0 = b + (g + 1) / 2; s1 = a + (g - 1) / 2; }
     };
     const int ng = min(P2G, P2TESTS - u0);  // tests with rows behind them
-    // ---- pairs
-    if (tid == 0) s_nlist = 0;
-    for (int i = tid; i < P2G * P2ENT; i += blockDim.x) { ((int*)s_mink)[i] = INT32_MAX; ((int*)s_act)[i] = 0; }
-    if (tid < P2G) { s_k[tid][0] = INT32_MAX; s_k[tid][1] = INT32_MIN; s_k[tid][2] = 0; }
+    // ---- pairs: the (test, row of the other direction, component) triples that can still matter: per (test, component)
+    // a mask over the rows
+    for (int i = tid; i < P2G * P2ENT; i += blockDim.x) ((int*)s_mink)[i] = INT32_MAX;
+    if (tid < P2G * 5) ((unsigned*)s_pmask)[tid] = 0u;
+    if (tid < P2G) s_k[tid][2] = 0;
     __syncthreads();
     for (int e = tid; e < ng * scope * 5; e += blockDim.x) {
       const int g = e / (scope * 5), pr = e % (scope * 5), i = pr / 5, cc = pr % 5;
@@ -1958,119 +1984,105 @@ __global__ __launch_bounds__(1024) void wfa_p2_overlap_kernel(const int32_t* __r
       const int d1 = d0 ^ 1, sd0 = d0 == 0 ? J.sf : J.sr, sd1 = d1 == 0 ? J.sf : J.sr, si = s1 - i;
       if (si >= 0 && s0 + si - pen.o2 < best && s0 + si - bp_gap_open(pen, cc) < best &&
           s_rmax[d0][s0 - (sd0 - 25)][cc] + s_rmax[d1][si - (sd1 - 25)][cc] >= tl) {
-        s_act[g][pr] = 1;
-        atomicMin(&s_k[g][0], kinv - rng_hi(RG, si));
-        atomicMax(&s_k[g][1], kinv - rng_lo(RG, si));
+        atomicOr(&s_pmask[g][cc], 1u << i);
         s_k[g][2] = 1;
       }
     }
     __syncthreads();
-    // ---- blocks of the tested rows that can meet a mirrored block
-    unsigned c_blk = 0, c_pass = 0, c_reach = 0, c_load = 0, c_hit = 0;
-    for (int g = 0; g < ng; ++g) {
-      if (!s_k[g][2]) continue;
-      int d0, s0, s1;
-      test_of(g, d0, s0, s1);
-      const int d1 = d0 ^ 1, sd0 = d0 == 0 ? J.sf : J.sr, sd1 = d1 == 0 ? J.sf : J.sr;
-      const int klo = max(s_k[g][0], rng_lo(RG, s0)), khi = min(s_k[g][1], rng_hi(RG, s0));
-      const int B_lo = (klo + J.koff2) >> 6, B_hi = (khi + J.koff2) >> 6;
-      const int32_t* bm0 = bmj + ((int64_t)(d0 * P2ROWS + (s0 - (sd0 - 25))) * 5) * nblk;
-      const int32_t* pb1 = pbj + ((int64_t)(d1 * P2ROWS + (s1 - (sd1 - 25))) * 5) * nblk;
-      for (int b0 = B_lo + tid; b0 <= B_hi; b0 += blockDim.x) {
-        const int kb_lo = max(klo, (b0 << 6) - J.koff2), kb_hi = min(khi, (b0 << 6) - J.koff2 + 63);
-        const int b1a = max(0, (kinv - kb_hi + J.koff2) >> 6), b1b = min(nblk - 1, (kinv - kb_lo + J.koff2) >> 6);  // b1b <= b1a + 1
-        int v0[5], va[5], vb[5];
-#pragma unroll
-        for (int cc = 0; cc < 5; ++cc) { v0[cc] = bm0[(int64_t)cc * nblk + b0]; va[cc] = pb1[(int64_t)cc * nblk + b1a]; vb[cc] = pb1[(int64_t)cc * nblk + b1b]; }
-        bool pass = false;
-#pragma unroll
-        for (int cc = 0; cc < 5; ++cc) pass = pass || (v0[cc] + max(va[cc], vb[cc]) >= tl);
-        ++c_blk;
-        if (pass) {
-          ++c_pass;
-          const int pos = atomicAdd(&s_nlist, 1);
-          if (pos < P2LIST) s_list[pos] = (g << 24) | b0;
-        }
-      }
-    }
-    __syncthreads();
-    // ---- cells: one wave per listed block, one diagonal per lane
+    const long long t_c0 = wall_clock64();
+    // ---- scan: one wave per (test, component) with the rows of the other direction that can still matter, ALL of them at
+    // once.  The 64-diagonal blocks of the tested row go by in ascending order (the reference's loop only ever takes the
+    // smallest diagonal on which a pair of rows meets): a block that holds a value large enough for some row is looked at
+    // -- first its maximum against the block maxima of every row, one row per lane, then, for the rows that pass, cell
+    // by cell, one diagonal per lane, four rows in flight.  A pair leaves the mask with its first hit.
+    // (Pair by pair this was the walk's whole cost: a direction that has reached the end of the text holds the value tl in
+    // every row, so no maximum prunes anything, and each of up to 26 x 5 pairs per test paid its own two or three dependent
+    // round trips to find that the rows do not share a diagonal yet; the walk of one job took 1 - 10 ms and its launch with it.)
     {
-      const int nl = s_nlist;
-      const bool listed = nl <= P2LIST;  // otherwise (never seen): every block of every test of the round
-      int ntodo = nl;
-      int cum[P2G + 1];
-      if (!listed) {
-        cum[0] = 0;
-        for (int g = 0; g < P2G; ++g) {
-          int nbk = 0;
-          if (g < ng && s_k[g][2]) {
-            int d0, s0, s1;
-            test_of(g, d0, s0, s1);
-            const int klo = max(s_k[g][0], rng_lo(RG, s0)), khi = min(s_k[g][1], rng_hi(RG, s0));
-            nbk = max(0, ((khi + J.koff2) >> 6) - ((klo + J.koff2) >> 6) + 1);
-          }
-          cum[g + 1] = cum[g] + nbk;
-        }
-        ntodo = cum[P2G];
-      }
-      for (int li = wv; li < ntodo; li += nw) {
-        int g, b0;
-        if (listed) { const int ent = s_list[li]; g = ent >> 24; b0 = ent & 0xffffff; }
-        else {
-          g = 0;
-          while (li >= cum[g + 1]) ++g;
-          int d0, s0, s1;
-          test_of(g, d0, s0, s1);
-          b0 = ((max(s_k[g][0], rng_lo(RG, s0)) + J.koff2) >> 6) + (li - cum[g]);
-        }
+      unsigned c_rounds = 0, c_hits = 0;
+      for (int it = wv; it < ng * 5; it += nw) {
+        const int g = it / 5, cc = it % 5;
+        unsigned todo = s_pmask[g][cc];
+        if (!todo) continue;
         int d0, s0, s1;
         test_of(g, d0, s0, s1);
-        const int d1 = d0 ^ 1, sd1 = d1 == 0 ? J.sf : J.sr;
-        const int klo = max(s_k[g][0], rng_lo(RG, s0)), khi = min(s_k[g][1], rng_hi(RG, s0));
-        const int k0 = (b0 << 6) - J.koff2 + lane;
-        if (k0 < klo || k0 > khi) continue;
-        const int k1 = kinv - k0;
-        const int b1 = (k1 + J.koff2) >> 6;  // block of the mirrored diagonal
-        const int32_t* pb1 = pbj + ((int64_t)(d1 * P2ROWS + (s1 - (sd1 - 25))) * 5) * nblk;
-        int o0[5], pv[5];
+        const int d1 = d0 ^ 1, sd0 = d0 == 0 ? J.sf : J.sr, sd1 = d1 == 0 ? J.sf : J.sr;
+        // the diagonals of the tested row that some row of the mask mirrors
+        int ka = INT32_MAX, kb = INT32_MIN;
+        for (unsigned q = todo; q; q &= q - 1) {
+          const int si = s1 - (int)__builtin_ctz(q);
+          ka = min(ka, kinv - rng_hi(RG, si)); kb = max(kb, kinv - rng_lo(RG, si));
+        }
+        ka = max(ka, rng_lo(RG, s0)); kb = min(kb, rng_hi(RG, s0));
+        if (ka > kb) continue;
+        const int32_t* R0 = p2_row(ring, p2, J, d0, cc, s0);
+        const int32_t* bm0 = bmj + ((int64_t)(d0 * P2ROWS + (s0 - (sd0 - 25))) * 5 + cc) * nblk;
+        int M1 = 0;  // the largest value any of the rows holds anywhere
+        for (unsigned q = todo; q; q &= q - 1) M1 = max(M1, s_rmax[d1][s1 - (int)__builtin_ctz(q) - (sd1 - 25)][cc]);
+        const int B_lo = (ka + J.koff2) >> 6, B_hi = (kb + J.koff2) >> 6;
+        for (int bb = B_lo; bb <= B_hi && todo; bb += 64) {
+          const int bl = bb + lane;
+          const int bv = bl <= B_hi ? bm0[bl] : 0;
+          unsigned long long m = __ballot(bl <= B_hi && bv + M1 >= tl);
+          while (m && todo) {
+            const int f = (int)__builtin_ctzll(m);
+            m &= m - 1;
+            const int b = bb + f, v0 = rdlane(bv, f);
+            const int kb_lo = max(ka, (b << 6) - J.koff2), kb_hi = min(kb, (b << 6) - J.koff2 + 63);
+            // rows whose mirrored block(s) can meet this one: one row per lane
+            bool pass = false;
+            if (lane < scope && ((todo >> lane) & 1u)) {
+              const int si = s1 - lane;
+              const int32_t* bm1 = bmj + ((int64_t)(d1 * P2ROWS + (si - (sd1 - 25))) * 5 + cc) * nblk;
+              // the part of this block the row mirrors, and the row's one or two blocks that hold it
+              const int q_lo = max(kb_lo, kinv - rng_hi(RG, si)), q_hi = min(kb_hi, kinv - rng_lo(RG, si));
+              if (q_lo <= q_hi) {
+                const int b1a = (kinv - q_hi + J.koff2) >> 6, b1b = (kinv - q_lo + J.koff2) >> 6;  // b1a <= b1b <= b1a + 1, inside the row
+                pass = v0 + max(bm1[b1a], bm1[b1b]) >= tl;
+              }
+            }
+            unsigned rows = (unsigned)__ballot(pass);
+            if (!rows) continue;
+            // the cells: one diagonal per lane against up to four rows at a time
+            const int k0 = (b << 6) - J.koff2 + lane, k1 = kinv - k0;
+            const int o0 = (k0 >= kb_lo && k0 <= kb_hi) ? R0[k0] : WF_NULL;
+            while (rows) {
+              int ri[4], o1[4];
 #pragma unroll
-        for (int cc = 0; cc < 5; ++cc) { o0[cc] = p2_row(ring, p2, J, d0, cc, s0)[k0]; pv[cc] = pb1[(int64_t)cc * nblk + b1]; }
-        bool reach = false;  // can this diagonal meet ANY candidate row THERE?
+              for (int j = 0; j < 4; ++j) {
+                ri[j] = rows ? (int)__builtin_ctz(rows) : -1;
+                if (rows) rows &= rows - 1;
+              }
 #pragma unroll
-        for (int cc = 0; cc < 5; ++cc) reach = reach || (o0[cc] >= 0 && o0[cc] + pv[cc] >= tl);
-        if (!reach) continue;
-        ++c_reach;
-        for (int i = 0; i < scope; ++i) {
-          const int si = s1 - i;
-          if (si < 0) break;
-          if (k1 < rng_lo(RG, si) || k1 > rng_hi(RG, si)) continue;
-          const int32_t* bmr = bmj + ((int64_t)(d1 * P2ROWS + (si - (sd1 - 25))) * 5) * nblk + b1;
-          int bv[5];
-          bool some = false;
+              for (int j = 0; j < 4; ++j) {
+                o1[j] = WF_NULL;
+                if (ri[j] >= 0) {
+                  const int si = s1 - ri[j];
+                  if (k1 >= rng_lo(RG, si) && k1 <= rng_hi(RG, si)) o1[j] = p2_row(ring, p2, J, d1, cc, si)[k1];
+                }
+              }
+              ++c_rounds;
 #pragma unroll
-          for (int cc = 0; cc < 5; ++cc) {  // the five block maxima of the row in flight together
-            const bool on = s_act[g][i * 5 + cc] && o0[cc] >= 0;
-            bv[cc] = on ? bmr[(int64_t)cc * nblk] : INT32_MIN / 2;
-            some = some || on;
-          }
-          if (!some) continue;
-#pragma unroll
-          for (int cc = 0; cc < 5; ++cc) {
-            if (o0[cc] + bv[cc] < tl) continue;
-            const int o1 = p2_row(ring, p2, J, d1, cc, si)[k1];
-            ++c_load;
-            if (o0[cc] + o1 >= tl) { atomicMin(&s_mink[g][i * 5 + cc], k0); ++c_hit; }
+              for (int j = 0; j < 4; ++j) {
+                if (ri[j] < 0) continue;
+                const unsigned long long hh = __ballot(o0 + o1[j] >= tl);  // (a NULL offset is -2^30: the sum stays far below)
+                if (hh) {
+                  if (lane == 0) s_mink[g][ri[j] * 5 + cc] = (b << 6) - J.koff2 + (int)__builtin_ctzll(hh);
+                  todo &= ~(1u << ri[j]);
+                  ++c_hits;
+                }
+              }
+            }
           }
         }
       }
-    }
-    if (count) {
-      atomicAdd(&g_p2cnt[2], (unsigned long long)c_blk); atomicAdd(&g_p2cnt[3], (unsigned long long)c_pass);
-      atomicAdd(&g_p2cnt[4], (unsigned long long)c_reach); atomicAdd(&g_p2cnt[5], (unsigned long long)c_load);
-      atomicAdd(&g_p2cnt[6], (unsigned long long)c_hit);
+      if (count == 1 && lane == 0) {  // WFM_P2_COUNT: rounds of cell tests (up to four rows each), pairs that met
+        atomicAdd(&g_p2cnt[3], (unsigned long long)c_rounds); atomicAdd(&g_p2cnt[4], (unsigned long long)c_hits);
+        atomicMax(&g_p2cnt[6], (unsigned long long)c_rounds);
+      }
     }
     __syncthreads();
+    t_cells += wall_clock64() - t_c0;
     // ---- pick, test after test.  The reference walks i = 0 .. scope-1 and, inside, D2, I2, D1, I1, M; it takes a hit when its
     // score is STRICTLY below the best so far (and skips ahead once a gap-open class can no longer beat it): with o2 >= o1 >= 0
     // the walk ends on the hit of smallest score, the first in that order among equals -- a minimum over (score, position)
@@ -2165,9 +2177,110 @@ __global__ __launch_bounds__(1024) void wfa_p2_overlap_kernel(const int32_t* __r
     r.steps = s_state[0] + s_state[1];
     r.cells = s_cells;
     r.steps_p1 = J.sf + J.sr;
-    r.ticks_p1 = 0; r.ticks_p2 = 0; r.pad_ = 0;
+    r.ticks_p1 = (uint32_t)t_cells; r.ticks_p2 = (uint32_t)(wall_clock64() - t_begin); r.pad_ = rounds;  // diagnostics (WFM_DEBUG)
     results[job] = r;
   }
+}
+
+// ---------------------------------------------------------------------------
+// An upper bound of a root's score: the cost of ONE valid global alignment, found greedily
+// ---------------------------------------------------------------------------
+// The tile kernels only compute the cells from which the end diagonal is still within reach of a known upper bound `sub` of
+// the score (Rng).  A BiWFA child is handed its score by its parent; a root only had the caller's guess, which has to allow
+// for what the caller cannot know (the divergence estimate of a sketch, +- 0.1 % of 50 kb = 300 points) -- and every point
+// of slack is a diagonal on either side of every row: the roots of a pangenome batch ran 1150 diagonals wide where their
+// children run 260.  Any alignment's cost is an upper bound of the optimal score, and for the records this matters for (long,
+// a few differences per kilobase, offset by their padding) a good one is found by walking: one wave per root extends along
+// the diagonal it is on, 512 bases per round trip, and at a difference lets its lanes try the edits side by side -- lane 0 a
+// substitution, lanes 1..31 a deletion of that many bases, lanes 32..62 an insertion -- and takes the cheapest edit after which
+// 16 bases match (or a sequence ends).  The first diagonal is searched the same way over shifts up to 4096 (the padding of the
+// target window).  Where no edit qualifies a few times in a row, or edits come thicker than one per 64 bases, the walk gives up
+// (-1): the job keeps the caller's guess.  The bound is rigorous whatever the walk chooses -- it is charged at least the
+// gap-affine cost of the ops it spells -- so a root that runs under it cannot fail; the host keeps the retry all the same.
+__global__ __launch_bounds__(64) void wfa_bound_kernel(const uint8_t* __restrict__ seq, const BoundJob* __restrict__ jobs,
+                                                       int32_t* __restrict__ out, DevPen pen, int njobs) {
+  const int i = blockIdx.x, lane = (int)threadIdx.x;
+  if (i >= njobs) return;
+  const BoundJob J = jobs[i];
+  const uint8_t* P = seq + J.p_off;
+  const uint8_t* T = seq + J.t_off;
+  const int pl = J.pl, tl = J.tl;
+  auto gap = [&](int L) -> long long { return L <= 0 ? 0ll : min((long long)pen.o1 + (long long)L * pen.e1, (long long)pen.o2 + (long long)L * pen.e2); };
+  auto give_up = [&]() { if (lane == 0) out[i] = -1; };
+  if (min(pl, tl) < 256) { give_up(); return; }
+  constexpr int PROBE = 24, RUN = 16, LOOK = 32;
+  int v = 0, h = 0;
+  long long score = 0;
+  // ---- the first diagonal: the smallest shift (D: the pattern runs ahead, I: the text) under which PROBE bases agree
+  {
+    bool found = false;
+    const int amax = min(4096, max(pl, tl) - 128);
+    for (int q0 = 0; q0 <= 96 && !found; q0 += 48) {
+      for (int base = 0; base < amax && !found; base += 32) {
+        const bool del = lane < 32;
+        const int sh = base + (lane & 31);
+        bool ok = false;
+        if (del) {
+          if (sh + q0 + PROBE <= pl && q0 + PROBE <= tl)
+            ok = load8(P + sh + q0) == load8(T + q0) && load8(P + sh + q0 + 8) == load8(T + q0 + 8) && load8(P + sh + q0 + 16) == load8(T + q0 + 16);
+        } else if (sh > 0) {
+          if (q0 + PROBE <= pl && sh + q0 + PROBE <= tl)
+            ok = load8(P + q0) == load8(T + sh + q0) && load8(P + q0 + 8) == load8(T + sh + q0 + 8) && load8(P + q0 + 16) == load8(T + sh + q0 + 16);
+        }
+        const unsigned long long hit = __ballot(ok);
+        if (hit) {
+          const unsigned hd = (unsigned)(hit & 0xffffffffull), hi = (unsigned)(hit >> 32);
+          const int a = hd ? base + (int)__builtin_ctz(hd) : INT32_MAX, b = hi ? base + (int)__builtin_ctz(hi) : INT32_MAX;
+          if (a <= b) { v = a; score += gap(a); } else { h = b; score += gap(b); }
+          found = true;
+        }
+      }
+    }
+    if (!found) { give_up(); return; }
+  }
+  const int max_events = 64 + (pl + tl) / 64;
+  int events = 0, forced = 0;
+  for (;;) {
+    const int maxn = min(pl - v, tl - h);
+    int n = wave_lce_tail_g(P, T, v, h, 0, maxn, lane == 0 && maxn > 0);
+    n = rdlane(n, 0);
+    v += n; h += n;
+    if (v >= pl || h >= tl) break;
+    if (++events > max_events) { give_up(); return; }
+    // the edits side by side
+    int dv = 0, dh = 0;
+    long long cost = 0;
+    bool cand = true;
+    if (lane == 0) { dv = 1; dh = 1; cost = pen.x; }
+    else if (lane < 32) { dv = lane; cost = gap(lane); }
+    else if (lane < 63) { dh = lane - 31; cost = gap(lane - 31); }
+    else cand = false;
+    const int v2 = v + dv, h2 = h + dh;
+    cand = cand && v2 <= pl && h2 <= tl;
+    int m = 0, mx = 0;
+    if (cand) {
+      mx = min(min(pl - v2, tl - h2), LOOK);
+      m = min(lce_from(P + v2, T + h2, 0, mx), mx);
+    }
+    const bool pass = cand && (m >= RUN || m == min(pl - v2, tl - h2));
+    long long key = pass ? ((cost << 8) | (long long)lane) : INT64_MAX;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) key = min(key, __shfl_xor(key, d, 64));
+    if (key != INT64_MAX) {
+      const int w = (int)(key & 0xff);
+      score += key >> 8;
+      v += rdlane(dv, w); h += rdlane(dh, w);
+      forced = 0;
+    } else {
+      if (++forced > 6) { give_up(); return; }
+      score += pen.x; ++v; ++h;  // a substitution whatever follows: the next difference is looked at on its own
+    }
+  }
+  score += gap(pl - v) + gap(tl - h);
+  if (lane == 0) out[i] = score < (long long)(SUB_NONE - 1) ? (int32_t)score : -1;
+}
+void launch_bound(const uint8_t* seq, const BoundJob* jobs, int32_t* out, int njobs, DevPen pen, hipStream_t st) {
+  hipLaunchKernelGGL(wfa_bound_kernel, dim3(njobs), dim3(64), 0, st, seq, jobs, out, pen, njobs);
 }
 
 // reversed copies of pattern and text behind the forward ones, each followed by `pad` zero bytes
@@ -2226,13 +2339,14 @@ void launch_p2_blockmax(const int32_t* ring, const int32_t* p2, const P2Job* job
 void launch_p2_overlap(const int32_t* ring, const int32_t* p2, const P2Job* jobs, const int32_t* p2max, const int32_t* bmax, int32_t* pbmax,
                        BpResult* res, int njobs, int threads, int max_nblk, DevPen pen, int scope, hipStream_t st) {
   static const int count = getenv("WFM_P2_COUNT") ? atoi(getenv("WFM_P2_COUNT")) : 0;
-  hipLaunchKernelGGL(wfa_p2_prefixmax_kernel, dim3((2 * 5 * max_nblk + 255) / 256, njobs), dim3(256), 0, st, jobs, bmax, pbmax, njobs);
+  (void)max_nblk;  // (the walk prunes with each row's own block maxima; the running maxima over the rows are not needed any more)
   hipLaunchKernelGGL(wfa_p2_overlap_kernel, dim3(njobs), dim3(threads), 0, st, ring, p2, jobs, p2max, bmax, pbmax, res, pen, scope, count);
 }
 void p2_counters(unsigned long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_p2cnt), sizeof(unsigned long long) * 8); }
 void launch_base(const uint8_t* seq, int32_t* a32, uint8_t* a8, uint32_t* rle, const BaseJob* jobs, BaseResult* res,
-                 int njobs, DevPen pen, hipStream_t st) {
-  hipLaunchKernelGGL(wfa_base_kernel, dim3(njobs), dim3(256), 0, st, seq, a32, a8, rle, jobs, res, pen);
+                 int njobs, DevPen pen, bool wide, hipStream_t st) {
+  if (wide) hipLaunchKernelGGL(wfa_base_kernel<1024>, dim3(njobs), dim3(1024), 0, st, seq, a32, a8, rle, jobs, res, pen);
+  else hipLaunchKernelGGL(wfa_base_kernel<256>, dim3(njobs), dim3(256), 0, st, seq, a32, a8, rle, jobs, res, pen);
 }
 void launch_compact(const uint32_t* rle, const int64_t* off, const int64_t* cap, uint32_t* out, unsigned long long* total,
                     int64_t* out_start, int32_t* out_count, int nprob, hipStream_t st) {

@@ -1,4 +1,5 @@
 #include "aligner.hpp"
+#include "../csrc/wfa_handle.h"
 
 #include <algorithm>
 #include <thread>
@@ -242,6 +243,7 @@ std::string Aligner::align_batch(wfm_handle_t* gpu_handle, std::vector<std::stri
   const int rc = wflign::do_biwfa_alignment_batch(gpu_handle, recs, pen, param.disable_chain_patching, pp, &st, fmt);
   if (rc < 0) throw std::runtime_error(std::string("[wfmash::align] GPU alignment failed: ") + st.error);
   sum.cells += st.cells; sum.ms_gpu += st.ms_gpu;
+  sum.busy.insert(sum.busy.end(), st.busy.begin(), st.busy.end());
   const double ms_biwfa = since(tb2);
   const auto tb3 = std::chrono::steady_clock::now();
   for (size_t k = 0; k < recs.size(); ++k) {
@@ -349,12 +351,22 @@ Summary Aligner::compute() {
   const size_t nworkers = ngpu * per_gpu;
   std::vector<Summary> part(nworkers);
   const int threads_each = std::max(1, param.threads / (int)nworkers);
+  // Every worker beyond the first of a device works on a handle of its own (own stream, own arenas): its batch's device
+  // calls then really run beside the other workers' -- the few-workgroup tails of one batch (the patches that overflow
+  // their score budget, the last leaves) under the wide levels of another -- instead of taking turns on one handle.
+  std::vector<wfm_handle_t*> own(nworkers, nullptr), use(nworkers, nullptr);
+  static const bool own_handles = !(getenv("WFM_ALIGN_OWN_HANDLES") && atoi(getenv("WFM_ALIGN_OWN_HANDLES")) == 0);
+  for (size_t wk = 0; wk < nworkers; ++wk) {
+    use[wk] = gpus[wk % ngpu];
+    if (wk >= ngpu && own_handles && wfm_create(wfm_device(gpus[wk % ngpu]), &own[wk]) == WFM_OK) use[wk] = own[wk];
+  }
+  struct OwnGuard { std::vector<wfm_handle_t*>& v; ~OwnGuard() { for (wfm_handle_t* x : v) if (x) wfm_destroy(x); } } own_guard{own};
   auto worker = [&](size_t wk) {
     try {
       std::vector<std::string> batch;
       for (int64_t seq; !failed.load() && (seq = read_batch(batch)) >= 0;) {
         const double at0 = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-        std::string text = align_batch(gpus[wk % ngpu], batch, threads_each, part[wk]);
+        std::string text = align_batch(use[wk], batch, threads_each, part[wk]);
         const double at1 = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         write_batch((uint64_t)seq, std::move(text));
         if (getenv("WFM_DEBUG"))
@@ -375,13 +387,24 @@ Summary Aligner::compute() {
   }
   if (failed.load()) throw std::runtime_error(first_error);
   {
-    std::vector<double> gpu_ms(ngpu, 0.0);  // per device: its workers' busy times add up (they take turns on it)
+    // per device: the time during which a kernel of any of its workers' calls was running (their calls overlap)
+    std::vector<std::vector<std::pair<double, double>>> iv(ngpu);
     for (size_t wk = 0; wk < nworkers; ++wk) {
       const Summary& p = part[wk];
       sum.records += p.records; sum.aligned_bp += p.aligned_bp; sum.written += p.written; sum.skipped += p.skipped;
-      sum.cells += p.cells; gpu_ms[wk % ngpu] += p.ms_gpu;
+      sum.cells += p.cells;
+      iv[wk % ngpu].insert(iv[wk % ngpu].end(), p.busy.begin(), p.busy.end());
     }
-    sum.ms_gpu = *std::max_element(gpu_ms.begin(), gpu_ms.end());
+    for (auto& v : iv) {
+      std::sort(v.begin(), v.end());
+      double total = 0, lo = 0, hi = -1;
+      for (const auto& x : v) {
+        if (x.first > hi) { if (hi > lo) total += hi - lo; lo = x.first; hi = x.second; }
+        else hi = std::max(hi, x.second);
+      }
+      if (hi > lo) total += hi - lo;
+      sum.ms_gpu = std::max(sum.ms_gpu, total);
+    }
   }
   outstream.close();
   sum.ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();

@@ -61,6 +61,7 @@ struct Summary {
   uint64_t skipped = 0;            // invalid mapping rows
   uint64_t cells = 0;
   double ms_gpu = 0, ms_total = 0;
+  std::vector<std::pair<double, double>> busy;  // a worker's device-busy intervals (merged per device at the end of compute())
 };
 
 class Aligner {

@@ -631,6 +631,12 @@ struct GpuBatch {
     if (rc >= 0 && st) {
       wfm_stats_t s;
       if (wfm_get_stats(h, &s) == WFM_OK) { st->cells += s.cells; st->ms_gpu += s.ms_any_busy; }
+      const size_t ni = wfm_get_busy_intervals(h, nullptr, 0);
+      if (ni) {
+        std::vector<double> iv(2 * ni);
+        wfm_get_busy_intervals(h, iv.data(), ni);
+        for (size_t q = 0; q < ni; ++q) st->busy.emplace_back(iv[2 * q], iv[2 * q + 1]);
+      }
     }
     return rc;
   }

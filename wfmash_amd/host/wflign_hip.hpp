@@ -121,6 +121,7 @@ struct BiwfaStats {
   double ms_gpu = 0;
   uint64_t main_failed = 0, head_patches = 0, tail_patches = 0;
   std::string error;                 // the device call's message when do_biwfa_alignment_batch returns < 0
+  std::vector<std::pair<double, double>> busy;  // when kernels of this batch's device calls ran (ms on the device's clock, wfm_get_busy_intervals)
 };
 
 struct OutputFormat {
