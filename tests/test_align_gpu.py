@@ -408,3 +408,30 @@ def test_score_bounds_are_upper_bounds_and_tight_on_padded_records(gpu, oracle):
     for (p, t), r in zip(items, res):
         rc, ops, sc, _ = oracle.align_biwfa(p, t)
         assert r.status == 0 and r.ops == ops and r.score == sc
+
+
+def test_exact_bounds_on_small_batches_with_reused_rings(oracle):
+    """Round-3 regression.  Three padded records whose greedy bound IS their optimal score (end gaps and perfect matches),
+    aligned in small batches on a handle whose rings other jobs have just used: under an exact bound a short last tile block
+    handed phase 2 rows older than its own first row, and the cells of those rows beyond the block's columns had never reached
+    the output ring -- phase 2 read what the previous tenant had left there and took a false breakpoint one point under the
+    optimum (the record was then dropped).  Fixture: tests/golden/exact_bound_pairs.json.gz (make_exact_bound_pairs.py)."""
+    import gzip
+    import json
+    import os
+    fix = json.load(gzip.open(os.path.join(os.path.dirname(__file__), "golden", "exact_bound_pairs.json.gz"), "rt"))
+    assert len(fix) >= 3
+    h = capi.Handle(0)
+    try:
+        dirty = [(synth.random_dna(4000 + i, 9000), synth.mutate(synth.random_dna(4000 + i, 9000), 0.03, 4100 + i)) for i in range(40)]
+        pairs = [(e["pattern"].encode(), e["text"].encode()) for e in fix]
+        ub = h.score_bounds(pairs)
+        assert [int(u) for u in ub] == [e["score"] for e in fix]  # the bound is exact on these
+        for rep in range(4):
+            h.align(dirty)  # large offsets all over the rings
+            res = h.align(pairs * 20)
+            for j, r in enumerate(res):
+                e = fix[j % len(fix)]
+                assert r.status == 0 and r.score == e["score"] and r.ops == e["ops"].encode(), (rep, j)
+    finally:
+        h.close()

@@ -53,11 +53,15 @@ struct DevBuf {
     if (p) (void)hipFree(p);
     p = nullptr; cap = 0;
     size_t want = n + n / 8 + 64;
+    const auto t0 = std::chrono::steady_clock::now();
     if (hipMalloc((void**)&p, want * sizeof(T)) != hipSuccess) {
       if (hipMalloc((void**)&p, n * sizeof(T)) != hipSuccess) { p = nullptr; return -1; }
       want = n;
     }
     cap = want;
+    if (want * sizeof(T) >= ((size_t)256 << 20) && getenv("WFM_DEBUG"))
+      fprintf(stderr, "[wfm] hipMalloc of %.2f GB took %.1f ms\n", (double)(want * sizeof(T)) / 1073741824.0,
+              std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
     return 0;
   }
   void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
@@ -420,8 +424,7 @@ int run_tiled_phase(wfm_handle* h, wfm_seqset* S, const DevPen& dp, int scope, c
     t.p_fwd = j.p_fwd; t.t_fwd = j.t_fwd; t.p_rev = j.p_rev; t.t_rev = j.t_rev;
     t.ring_in = j.ring_off; t.ring_out = ring2[i];
     t.pl = j.pl; t.tl = j.tl; t.comp_begin = j.comp_begin; t.comp_end = j.comp_end;
-    static const int no_wave_skip = (getenv("WFM_WAVE_SKIP") && atoi(getenv("WFM_WAVE_SKIP")) == 0) ? 1 : 0;
-    t.width = j.width; t.koff = j.koff; t.s0 = 0; t.active = 1; t.fmax = 0; t.rmax = 0; t.nblocks = 0; t.mode = 0; t.tf = 0; t.tr = 0; t.last_fwd = 0; t.pad_ = no_wave_skip;
+    t.width = j.width; t.koff = j.koff; t.s0 = 0; t.active = 1; t.fmax = 0; t.rmax = 0; t.nblocks = 0; t.mode = 0; t.tf = 0; t.tr = 0; t.last_fwd = 0; t.pad_ = 0;
     t.p2_off = 0; t.w2 = 0; t.koff2 = 0; t.sub = j.sub; t.pad2_ = 0;
   }
   bool any_cut = false;  // the kernel form with the score bounds' bookkeeping is only launched when a job carries one
@@ -645,8 +648,7 @@ int run_p2_phase(wfm_handle* h, wfm_seqset* S, const DevPen& dp, int scope, cons
       t.ring_in = j.ring_off; t.ring_out = ring_other[i];
       t.pl = j.pl; t.tl = j.tl; t.comp_begin = j.comp_begin; t.comp_end = j.comp_end;
       t.width = j.width; t.koff = j.koff; t.s0 = 0; t.active = 1; t.fmax = 0; t.rmax = 0; t.nblocks = 0;
-      static const int no_wave_skip = (getenv("WFM_WAVE_SKIP") && atoi(getenv("WFM_WAVE_SKIP")) == 0) ? 1 : 0;
-      t.mode = 4; t.tf = j.resume_s; t.tr = j.resume_sr; t.last_fwd = j.last_fwd; t.pad_ = no_wave_skip;
+      t.mode = 4; t.tf = j.resume_s; t.tr = j.resume_sr; t.last_fwd = j.last_fwd; t.pad_ = 0;
       t.p2_off = (int64_t)elems; t.w2 = (int32_t)w2; t.koff2 = koff2; t.sub = j.sub;
       P2Job q{};
       q.ring_in = j.ring_off; q.p2_off = (int64_t)elems; q.width = j.width; q.koff = j.koff; q.w2 = (int32_t)w2; q.koff2 = koff2;
@@ -850,7 +852,7 @@ int align_resident_impl(wfm_handle* h, const wfm_penalties_t* pen, wfm_seqset* S
     // the budget, jobs get rings for |k| <= band only: a child's total score is known (half of it per direction,
     // plus the overlap phase), a root gets WFM_BAND_ROOT scores; whoever runs out of its band is run again on a
     // full ring.  WFM_BAND=0 switches this off.
-    bool use_band = false;
+    bool use_band = false, over_budget = false;
     {
       const char* be = getenv("WFM_BAND");
       const int band_on = be ? atoi(be) : 1;
@@ -859,6 +861,7 @@ int align_resident_impl(wfm_handle* h, const wfm_penalties_t* pen, wfm_seqset* S
       // (narrow rings whenever full ones would take more than 2 GB, not only when they would not fit: every fresh GB of a
       // first hipMalloc costs ~30 ms on this driver, scripts/malloc_cost2.hip, and a one-shot run pays it)
       use_band = band_on && total * 4 > std::min<size_t>(h->mem_budget, (size_t)2 << 30);
+      over_budget = total * 4 > h->mem_budget;
     }
     const char* bre = getenv("WFM_BAND_ROOT");
     const int band_root = bre ? std::max(64, atoi(bre)) : 4096;
@@ -878,7 +881,10 @@ int align_resident_impl(wfm_handle* h, const wfm_penalties_t* pen, wfm_seqset* S
         bool tile_it = tcfg.enabled && nd.pl + nd.tl >= tcfg.min_len &&
                              (nd.score_rem == INT_MAX || nd.score_rem >= tcfg.min_score);
         int band = 0;
-        if (use_band && tile_it && !nd.noband && !(roots_off && nd.score_rem == INT_MAX)) {
+        // (a root without a bound gets a guessed band only when the level would not fit otherwise: below the budget the
+        // guess has nothing to win and a deep record -- 5 % divergence: 6 k scores per direction -- everything to lose)
+        const bool known = nd.score_rem != INT_MAX || nd.sub != SUB_NONE;
+        if (use_band && (known || over_budget) && tile_it && !nd.noband && !(roots_off && nd.score_rem == INT_MAX)) {
           // scores one direction is allowed to reach; the ring holds |k| <= band + 8, its left margin stays 4 columns
           // (a root under a bound of its score leaves the tile phase once a direction passes (bound + 128) / 2)
           int64_t dir_scores = nd.score_rem == INT_MAX ? (int64_t)band_root : (int64_t)nd.score_rem / 2 + 64;
@@ -893,7 +899,9 @@ int align_resident_impl(wfm_handle* h, const wfm_penalties_t* pen, wfm_seqset* S
         }
         if (tile_it && width * 2 * 5 * RING * 2 * 4 > h->mem_budget) tile_it = false;  // two snapshot rings do not fit: step-by-step kernel
         const size_t need = width * 2 * 5 * RING * (tile_it ? 2 : 1);
-        if (!jobs.empty() && (ring_elems + need) * 4 > h->mem_budget) break;
+        // (a chunk of a level stops at 8 GB of rings even when the budget allows more: thousands of jobs fill the device
+        // long before that, and every GB of a first allocation may cost 30 ms)
+        if (!jobs.empty() && (ring_elems + need) * 4 > std::min<size_t>(h->mem_budget, (size_t)8 << 30)) break;
         if (need * 4 > h->mem_budget) { prob_status[nd.prob] = WFM_ST_OOM; continue; }
         BpJob j{};
         j.p_fwd = pm.p_fwd + nd.pb;
@@ -1419,7 +1427,12 @@ int align_resident_any(wfm_handle_t* h, const wfm_penalties_t* pen, wfm_seqset_t
     h->busy_abs.clear();
     hipEvent_t db = device_base_event(h->device);
     float off = 0;
-    if (!db || hipEventElapsedTime(&off, db, h->ev_base) != hipSuccess) return;
+    const hipError_t ee = db ? hipEventElapsedTime(&off, db, h->ev_base) : hipErrorInvalidValue;
+    if (ee != hipSuccess) {
+      (void)hipGetLastError();
+      if (getenv("WFM_DEBUG")) fprintf(stderr, "[wfm] busy intervals: no common clock (%s)\n", hipGetErrorString(ee));
+      return;
+    }
     std::sort(iv.begin(), iv.end());
     double lo = 0, hi = -1;
     for (const auto& x : iv) {

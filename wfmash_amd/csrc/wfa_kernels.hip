@@ -1570,18 +1570,10 @@ __global__ __launch_bounds__(NTMAX) void wfa_tile_reg_kernel(const uint8_t* __re
     const int cl = jj % NCL;  // residue class of this step's score: compile time after unrolling
     const int s = s0 + t;
     const int par = t & 1;
-    // A wave none of whose diagonals (nor the one next to them) lies in a row this step can read or write has nothing to do
-    // but keep the step's barrier: its history is all NULL before its first cell comes into range (ranges only grow at the
-    // triangle's edges), and at an edge that a score bound moves inwards it goes on for LB more steps, until no row a
-    // neighbour may still read holds one of its diagonals.  What its mailbox slots hold in the meantime is masked by the
-    // readers' range selects.  (The workgroup is as wide as the widest job-direction of the launch: most of the waves of a
-    // narrow job -- a child under its exact bound, a root under its walked bound -- are such waves.)
-    {
-      const int lo_all = (CUT ? max(max(-pl, -s), RG.kb_lo + s - LB) : max(-pl, -s)) - 1;
-      const int hi_all = (CUT ? min(min(tl, s), RG.kb_hi - s + LB) : min(tl, s)) + 1;
-      const int kw_lo = kA + wv * 64 * C;
-      if (!J.pad_ && (kw_lo + 64 * C - 1 < lo_all || kw_lo > hi_all)) { __syncthreads(); continue; }  // (TileJob::pad_ != 0: WFM_WAVE_SKIP=0, for A/B runs)
-    }
+    // (Tried in round 3 and taken out again: letting a wave whose diagonals lie outside every row of the step skip to the
+    // step's barrier.  On pangenome batches 40 % of the waves are such waves, and skipping them changed nothing -- the step's
+    // time is the chain of its busiest wave, the idle ones cost issue slots nobody was waiting for -- while the test itself
+    // made the step 10 % slower on C3.)
     // rows this step reads from its class: [0] = s-5, [1] = s-10, [4] = s-25
     // publish the wave-edge history values needed by the neighbouring waves in this step
     if (lane == 63) { int* e = s_edge[par][wv][0]; e[0] = Mh[C - 1][cl][1]; e[1] = Mh[C - 1][cl][4]; e[2] = I1h[C - 1][E1 - 1]; e[3] = I2h[C - 1]; }

@@ -354,17 +354,44 @@ Summary Aligner::compute() {
   // Every worker beyond the first of a device works on a handle of its own (own stream, own arenas): its batch's device
   // calls then really run beside the other workers' -- the few-workgroup tails of one batch (the patches that overflow
   // their score budget, the last leaves) under the wide levels of another -- instead of taking turns on one handle.
-  std::vector<wfm_handle_t*> own(nworkers, nullptr), use(nworkers, nullptr);
+  // The extra handles stay with the process (two per device at most) and serve the next run as well: their arenas are
+  // what a first use pays for, and a handle given back to the driver costs the next hipMalloc its scrubbing.
+  std::vector<wfm_handle_t*> use(nworkers, nullptr);
+  std::vector<std::pair<int, int>> borrowed;  // (device, slot) taken from the pool
   static const bool own_handles = !(getenv("WFM_ALIGN_OWN_HANDLES") && atoi(getenv("WFM_ALIGN_OWN_HANDLES")) == 0);
+  struct Pool {
+    std::mutex mu;
+    std::map<int, std::vector<std::pair<wfm_handle_t*, bool>>> by_device;  // handle, in use
+  };
+  static Pool pool;
   for (size_t wk = 0; wk < nworkers; ++wk) {
     use[wk] = gpus[wk % ngpu];
-    if (wk >= ngpu && own_handles && wfm_create(wfm_device(gpus[wk % ngpu]), &own[wk]) == WFM_OK) use[wk] = own[wk];
+    if (wk < ngpu || !own_handles) continue;
+    const int dev = wfm_device(gpus[wk % ngpu]);
+    std::lock_guard<std::mutex> lk(pool.mu);
+    auto& v = pool.by_device[dev];
+    int slot = -1;
+    for (size_t q = 0; q < v.size(); ++q) if (!v[q].second) { slot = (int)q; break; }
+    if (slot < 0 && v.size() < 2) {
+      wfm_handle_t* nh = nullptr;
+      if (wfm_create(dev, &nh) == WFM_OK) { v.emplace_back(nh, false); slot = (int)v.size() - 1; }
+    }
+    if (slot >= 0) { v[(size_t)slot].second = true; use[wk] = v[(size_t)slot].first; borrowed.emplace_back(dev, slot); }
   }
-  struct OwnGuard { std::vector<wfm_handle_t*>& v; ~OwnGuard() { for (wfm_handle_t* x : v) if (x) wfm_destroy(x); } } own_guard{own};
+  struct Return {
+    Pool& p; std::vector<std::pair<int, int>>& b;
+    ~Return() { std::lock_guard<std::mutex> lk(p.mu); for (auto& x : b) p.by_device[x.first][(size_t)x.second].second = false; }
+  } give_back{pool, borrowed};
+  // (the first batch of a device goes to its first worker, the one on the caller's handle: a file of one batch then runs
+  // on arenas that are most likely there already)
+  std::vector<std::atomic<int>> first_taken(ngpu);
+  for (auto& a : first_taken) a.store(0);
   auto worker = [&](size_t wk) {
     try {
       std::vector<std::string> batch;
+      if (wk >= ngpu) while (!first_taken[wk % ngpu].load() && !failed.load()) std::this_thread::yield();
       for (int64_t seq; !failed.load() && (seq = read_batch(batch)) >= 0;) {
+        first_taken[wk % ngpu].store(1);
         const double at0 = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         std::string text = align_batch(use[wk], batch, threads_each, part[wk]);
         const double at1 = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -378,6 +405,7 @@ Summary Aligner::compute() {
       if (first_error.empty()) first_error = e.what();
       failed.store(true);
     }
+    first_taken[wk % ngpu].store(1);  // (nothing left for this device's first worker either: the others must not wait)
   };
   {
     std::vector<std::thread> pool;
@@ -405,6 +433,8 @@ Summary Aligner::compute() {
       if (hi > lo) total += hi - lo;
       sum.ms_gpu = std::max(sum.ms_gpu, total);
     }
+    // (a worker's own calls follow one another: the sum of their busy times is a lower bound of its device's)
+    for (size_t wk = 0; wk < nworkers; ++wk) sum.ms_gpu = std::max(sum.ms_gpu, part[wk].ms_gpu);
   }
   outstream.close();
   sum.ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();

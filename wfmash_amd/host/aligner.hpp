@@ -40,9 +40,12 @@ struct Parameters {
   bool disable_chain_patching = false;
   uint64_t target_padding = 1000;         // min(w, 5000), parse_args.hpp:608
   uint64_t query_padding = 1000;          // parse_args.hpp:620
-  // batching (not in the reference): records per GPU batch are bounded by bases
-  uint64_t batch_bases = 256ull << 20;
-  size_t batch_records = 4096;
+  // batching (not in the reference): a batch is bounded by bases and by records.  1536 records of 50 kb fill the device
+  // level by level (3 k workgroups per launch) and leave a mid-sized mapping file -- one rank's share of a pangenome,
+  // 6 k records -- in enough batches for the workers' host stages to overlap the device (measured: 2 batches of 2.9 k
+  // records 0.63 s, 6 batches 0.51 s; a 1.2 k-record file is best left whole)
+  uint64_t batch_bases = 160ull << 20;
+  size_t batch_records = 1536;
 };
 
 // MappingBoundaryRow (align_types.hpp:17)
