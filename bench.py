@@ -257,7 +257,7 @@ def _roofline(acc, excl, seq_bytes, args):
     e_achieved = e_alg / (e_ms * 1e-3) / 1e9 if e_ms > 0 else 0.0
     traffic = hbm_frac = None  # HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/)
     src = None
-    for name in ("r2_traffic.json", "r1g_traffic.json"):
+    for name in ("r3_traffic.json", "r2_traffic.json", "r1g_traffic.json"):
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", name)))
         except (OSError, ValueError):
@@ -268,7 +268,20 @@ def _roofline(acc, excl, seq_bytes, args):
                 hbm_frac = traffic / (tj["avg_launch_ms"] * 1e-3) / 1e9 / peak
             src = "profiles/" + name
             break
-    return {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": peak, "unit": "GB/s", "frac": achieved / peak,
+    issue = None  # issue-side figures of the same kernel from the committed SQ passes (profiles/): the 48 B/cell yardstick is
+    for name in ("r3_sq.json", "r2_sq.json"):  # saturated (C5 passes 1.0), what the kernel is really short of is issue slots and latency
+        try:
+            issue = json.load(open(os.path.join(ROOT, "profiles", name)))
+            issue["source"] = "profiles/" + name
+            break
+        except (OSError, ValueError):
+            continue
+    return {"bound": "hbm", "kernel": dom,
+            # the figure rocprofv3 reproduces: launches one after the other on one stream (untimed passes with WFM_OVERLAP=0)
+            "achieved": e_achieved, "peak": peak, "unit": "GB/s", "frac": e_achieved / peak,
+            # the timed region itself: up to three parts of the batch on as many streams, the kernel's running time = the union of its launch intervals
+            "achieved_overlapped": achieved, "frac_overlapped": achieved / peak,
+            "valu_frac": issue.get("valu_frac") if issue else None, "wait_frac": issue.get("wait_frac") if issue else None, "issue_source": issue.get("source") if issue else None,
             "traffic": traffic, "hbm_frac": hbm_frac, "traffic_source": src,
             "frac_exclusive": e_achieved / peak, "achieved_exclusive": e_achieved,
             "avg_launch_ms_exclusive": e_ms / max(e_launches, 1), "launches_exclusive_per_step": e_launches / max(excl.passes, 1),
@@ -277,7 +290,10 @@ def _roofline(acc, excl, seq_bytes, args):
             "cells_computed_per_launch": cells_all / max(launches, 1),
             "avg_launch_ms": ms_sum / max(launches, 1), "launches": launches, "streams": acc.streams,
             "kernel_busy_ms_per_step": busy / max(acc.passes, 1),
-            "note": "achieved = 48 B x (score,diagonal) cells of the result / time the kernel was running (SURVEY 8d); the block in "
+            "note": "frac = the exclusive figure (what a rocprofv3 --kernel-trace of `WFM_OVERLAP=0 python bench.py` reproduces: profiles/); "
+                    "frac_overlapped = the timed region's own figure. valu_frac = SQ_INSTS_VALU x 4 cycles / (SIMDs x kernel time), "
+                    "wait_frac = SQ_WAIT_ANY / SQ_WAVE_CYCLES, from the committed SQ passes. "
+                    "achieved = 48 B x (score,diagonal) cells of the result / time the kernel was running (SURVEY 8d); the block in "
                     "which a job's wavefronts meet is computed twice (cells_computed_per_launch) and counted once (cells_per_launch). "
                     "The batch runs as up to three parts on as many streams, so launches of this kernel overlap each other: avg_launch_ms "
                     "(what rocprofv3 shows per launch in this mode) is stretched by the sharing and the running time is the union of the "
@@ -324,11 +340,67 @@ def _cpu_baseline_map(h):
         return {"value": None, "kind": "reference", "note": f"failed: {e}"}
 
 
+def _align_fields(al, t_al):
+    """what a wfmh_align_paf run says about itself: throughput, device share, host stages (summed over the batches)"""
+    return {"align_s": t_al, "records": int(al.records), "aligned_bp": int(al.aligned_bp), "aligned_bp_per_s": al.aligned_bp / t_al,
+            "cells": int(al.cells), "ms_gpu": al.ms_gpu, "gpu_share_of_align": al.ms_gpu * 1e-3 / t_al,
+            "algorithmic_frac_gpu": 48.0 * al.cells / (al.ms_gpu * 1e-3) / 8e12 if al.ms_gpu else None,
+            "batches": int(al.batches), "host_ms_summed_over_batches": {"rows": al.ms_rows, "fetch": al.ms_fetch, "wflign_incl_device_calls": al.ms_wflign, "text": al.ms_text}}
+
+
+def _sampled_cigar_identity(fa_seqs, map_lines, aln_path, n_sample, **oracle_kw):
+    """CIGAR-identical rate of a sample of a run's records against the align oracle (oracle/wflign_host.py over oracle/wfa2p.c):
+    every k-th mapping line is aligned by the oracle; its record must be, byte for byte, a line of the run's output."""
+    from oracle import wflign_host as W
+    step = max(1, len(map_lines) // n_sample)
+    sample = map_lines[::step][:n_sample]
+    from concurrent.futures import ThreadPoolExecutor
+    nt = max(1, min(len(sample), (os.cpu_count() or 1), 32))  # (the oracle is C behind ctypes: the calls run side by side)
+    with ThreadPoolExecutor(nt) as ex:
+        parts = list(ex.map(lambda i: W.align_mapping_lines(sample[i::nt], fa_seqs, fa_seqs, **oracle_kw), range(nt)))
+    want = [w for p in parts for w in p]
+    got = set(l.rstrip("\n") for l in open(aln_path))
+    same = sum(1 for w in want if w in got)
+    return {"sampled_records": len(sample), "oracle_records": len(want), "identical": same, "cigar_identical_rate": same / max(1, len(want))}
+
+
+def _mapping_identity(h, capi, synth, td):
+    """mapping-coordinate identity (PAF columns 1-9 + ch:Z:) of the map path on a small pangenome against the
+    stage oracles + the reference's own filter code; None where oracle/_ref did not travel"""
+    from oracle import map_ani as ANI
+    from oracle import map_pipeline as MP
+    from oracle import pyfilter, pymap
+    import numpy as np
+    if not (pymap.have_ref() and pyfilter.have_ref()):
+        return {"mapping_identical_rate": None, "note": "oracle/_ref is not built in this checkout"}
+    recs = [(n, s.tobytes()) for n, s in synth.pangenome(8, 600_000, n_sv=2, sv_min=3_000, sv_max=20_000)]
+    fa = os.path.join(td, "mi.fa")
+    names, _ = synth.write_fasta(fa, recs)
+    m = os.path.join(td, "mi.paf")
+    capi.map_paf(h, fa, m, params=capi.map_default_params(threads=os.cpu_count() or 1))
+    got = [l for l in open(m).read().splitlines()]
+    q = 3
+    pct = np.float32(ANI.estimate_identity([s for _, s in recs], MP.ref_groups(names), 50, -2.0))
+    S = MP.sketch_size(pct, 1000, 15)
+    maps, _, _ = MP.map_queries(recs, pct, queries={q})
+    exp = pyfilter.ref_filter("subset", maps[q], fa, names[q], capi.map_default_params(percentage_identity=float(pct), auto_pct_identity=0, sketch_size=S)).splitlines()
+
+    def key(l):
+        f = l.split("\t")
+        return tuple(f[:9]) + tuple(x for x in f[12:] if x.startswith("ch:Z:"))
+    mine = [key(l) for l in got if l.split("\t", 1)[0] == names[q]]
+    want = [key(l) for l in exp]
+    same = len(set(mine) & set(want))
+    return {"mapping_identical_rate": same / max(1, len(want)), "records_oracle": len(want), "records_gpu": len(mine), "byte_identical": [l for l in got if l.split("\t", 1)[0] == names[q]] == exp,
+            "workload": "8 synthetic haplotypes x 0.6 Mbp, defaults: one query haplotype against the stage oracles + the reference's filter code"}
+
+
 def _secondary(h, capi, synth):
-    """Driver-timed figures of the other configs (the bench line's `value` stays C3): C5 align-only, a scaled C4 rank and C2
-    (LPA.subset all-vs-all) end to end through the C ABI."""
+    """Driver-timed figures of the other configs (the bench line's `value` stays C3): C5 align-only, C4 ranks at two sizes
+    and C2 (LPA.subset all-vs-all) end to end through the C ABI, each with a parity check against the oracles."""
     import tempfile
     sec = {}
+    threads = os.cpu_count() or 1
     try:
         pairs = synth.pairs("C5", n_pairs=8)
         ss = h.upload(pairs)
@@ -348,28 +420,33 @@ def _secondary(h, capi, synth):
     except Exception as e:
         sec["C5"] = {"error": str(e)}
     with tempfile.TemporaryDirectory() as td:
-        try:  # scaled C4 rank: 8 haplotypes x 8 Mbp, one haplotype (1/8 of the queries) against the index of all eight
-            fa = os.path.join(td, "c4.fa")
-            names, lengths = synth.write_fasta(fa, synth.pangenome(8, 8_000_000, n_sv=6))
-            ql = os.path.join(td, "q.txt")
-            open(ql, "w").write(names[0] + "\n")
-            threads = os.cpu_count() or 1
-            m, a = os.path.join(td, "m.paf"), os.path.join(td, "a.paf")
-            t1 = time.perf_counter()
-            ms = capi.map_paf(h, fa, m, params=capi.map_default_params(threads=threads, query_list=ql))
-            t_map = time.perf_counter() - t1
-            t1 = time.perf_counter()
-            al = capi.align_paf(h, fa, m, a, params={"threads": threads})
-            t_al = time.perf_counter() - t1
-            sec["C4_rank_scaled"] = {"workload": "8 synthetic haplotypes x 8 Mbp, -Y '#', defaults (ani50-2): rank 0 of 8 (one haplotype against all)",
-                                     "map_s": t_map, "ms_index": ms.ms_index, "ms_map": ms.ms_map, "ms_filter": ms.ms_filter, "records": int(al.records),
-                                     "align_s": t_al, "aligned_bp": int(al.aligned_bp), "aligned_bp_per_s": al.aligned_bp / t_al,
-                                     "cells": int(al.cells), "ms_gpu": al.ms_gpu, "algorithmic_frac_gpu": 48.0 * al.cells / (al.ms_gpu * 1e-3) / 8e12 if al.ms_gpu else None}
-        except Exception as e:
-            sec["C4_rank_scaled"] = {"error": str(e)}
+        for tag, mbp, n_cig in (("C4_rank_scaled", 8, 48), ("C4_rank_40mbp", 40, 64)):
+            try:  # one rank of C4: 8 haplotypes, one of them (1/8 of the queries) against the index of all eight
+                fa = os.path.join(td, f"c4_{mbp}.fa")
+                recs = [(n, s) for n, s in synth.pangenome(8, mbp * 1_000_000, n_sv=6 if mbp == 8 else 20)]
+                names, lengths = synth.write_fasta(fa, recs)
+                ql = os.path.join(td, "q.txt")
+                open(ql, "w").write(names[0] + "\n")
+                m, a = os.path.join(td, "m.paf"), os.path.join(td, "a.paf")
+                t1 = time.perf_counter()
+                ms = capi.map_paf(h, fa, m, params=capi.map_default_params(threads=threads, query_list=ql))
+                t_map = time.perf_counter() - t1
+                t1 = time.perf_counter()
+                al = capi.align_paf(h, fa, m, a, params={"threads": threads})
+                t_al = time.perf_counter() - t1
+                leg = {"workload": f"8 synthetic haplotypes x {mbp} Mbp, -Y '#', defaults (ani50-2): rank 0 of 8 (one haplotype against all)",
+                       "map_s": t_map, "ms_index": ms.ms_index, "ms_map": ms.ms_map, "ms_filter": ms.ms_filter, "mapping_records": int(ms.written)}
+                leg.update(_align_fields(al, t_al))
+                leg["aligned_bp_per_s_map_and_align"] = al.aligned_bp / (t_map + t_al)
+                seqs = {n: s.tobytes() for n, s in recs}
+                leg["parity"] = _sampled_cigar_identity(seqs, open(m).read().splitlines(), a, n_cig)
+                sec[tag] = leg
+                del recs, seqs
+            except Exception as e:
+                sec[tag] = {"error": str(e)}
         try:  # C2: the reference's LPA test data (a committed fixture), all-vs-all -p 90 -P 50k
+            import gzip
             lpa = os.path.join(ROOT, "tests", "golden", "LPA.subset.fa.gz")
-            threads = os.cpu_count() or 1
             m, a = os.path.join(td, "lpa.m.paf"), os.path.join(td, "lpa.a.paf")
             t1 = time.perf_counter()
             ms = capi.map_paf(h, lpa, m, params=capi.map_default_params(percentage_identity=0.9, auto_pct_identity=0, max_mapping_length=50000, threads=threads))
@@ -377,11 +454,26 @@ def _secondary(h, capi, synth):
             t1 = time.perf_counter()
             al = capi.align_paf(h, lpa, m, a, params={"threads": threads})
             t_al = time.perf_counter() - t1
-            sec["C2"] = {"workload": "LPA.subset.fa.gz all-vs-all, -p 90 -P 50k, map + align", "map_s": t_map, "align_s": t_al, "records": int(al.records),
-                         "aligned_bp": int(al.aligned_bp), "aligned_bp_per_s_align": al.aligned_bp / t_al, "aligned_bp_per_s_end_to_end": al.aligned_bp / (t_map + t_al),
-                         "cells": int(al.cells), "ms_gpu": al.ms_gpu}
+            leg = {"workload": "LPA.subset.fa.gz all-vs-all, -p 90 -P 50k, map + align", "map_s": t_map, "mapping_records": int(ms.written)}
+            leg.update(_align_fields(al, t_al))
+            leg["aligned_bp_per_s_align"] = al.aligned_bp / t_al
+            leg["aligned_bp_per_s_end_to_end"] = al.aligned_bp / (t_map + t_al)
+            seqs, name = {}, None
+            for line in gzip.open(lpa, "rt"):
+                if line.startswith(">"):
+                    name = line[1:].split()[0]
+                    seqs[name] = []
+                else:
+                    seqs[name].append(line.strip())
+            seqs = {k: "".join(v).encode() for k, v in seqs.items()}
+            leg["parity"] = _sampled_cigar_identity(seqs, open(m).read().splitlines(), a, 16)
+            sec["C2"] = leg
         except Exception as e:
             sec["C2"] = {"error": str(e)}
+        try:
+            sec["map_parity"] = _mapping_identity(h, capi, synth, td)
+        except Exception as e:
+            sec["map_parity"] = {"error": str(e)}
     return sec
 
 

@@ -41,8 +41,15 @@ typedef struct {
   uint64_t written;      /* PAF lines written */
   uint64_t skipped;      /* invalid rows */
   uint64_t cells;        /* wavefront cells computed on the GPU */
-  double   ms_gpu;       /* time during which an align kernel was running (union over the streams; the busiest device of a multi-GPU run) */
+  double   ms_gpu;       /* time during which an align kernel was running (union over the streams and over the handles the
+                            driver's workers use; the busiest device of a multi-GPU run) */
   double   ms_total;
+  /* host stages, summed over the batches (batches of different workers overlap: the sums may exceed ms_total) */
+  double   ms_rows;      /* parsing the mapping rows */
+  double   ms_fetch;     /* fetching, normalising and strand-adjusting the sequence windows */
+  double   ms_wflign;    /* the wflign pipeline of a batch: device calls (upload, alignment, patches) and the work on runs between them */
+  double   ms_text;      /* collecting the records' text */
+  uint64_t batches;
 } wfmh_align_summary_t;
 
 void wfmh_align_default_params(wfmh_align_params_t* p);

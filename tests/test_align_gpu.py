@@ -96,7 +96,28 @@ def test_custom_penalties(gpu, oracle):
 
 def test_unsupported_penalties_fail_loudly(gpu):
     with pytest.raises(capi.WfmError):
-        gpu.align([(b"ACGT" * 50, b"ACGA" * 50)], pen=(5, 8, 2, 60, 1))  # scope 62 > 32-row ring
+        gpu.align([(b"ACGT" * 50, b"ACGA" * 50)], pen=(5, 8, 2, 200, 1))  # scope 202 > the 128-row rings
+    with pytest.raises(capi.WfmError):
+        gpu.align([(b"ACGT" * 50, b"ACGA" * 50)], pen=(0, 8, 2, 24, 1))   # mismatch 0: no wavefront order
+
+
+def test_penalties_beyond_the_default_scope(gpu, oracle):
+    """Any -g the reference accepts (parse_args.hpp:272-288) up to o2 + e2 = 125: scopes above 32 run on 128-row rings
+    (step kernel, LDS tiles where they fit, base kernel).  Against the oracle, which is generic in its penalties."""
+    items = _pairs(15, 36, [60, 150, 700, 2600], [0.03, 0.12])
+    rng = random.Random(8)
+    for i in range(10):  # long gaps: the second piece is what a large o2 prices
+        a = synth.random_dna(8000 + i, rng.choice([300, 1500]))
+        b = synth.random_dna(8100 + i, rng.choice([200, 900]))
+        items.append((a + b, b) if i % 2 else (b, a + b))
+    for pen in ((5, 8, 2, 60, 1), (6, 10, 3, 124, 1), (9, 40, 2, 100, 1), (33, 20, 2, 24, 1)):
+        _check_batch(gpu, oracle, items, pen=pen)
+    # and through the ends-free form (patches)
+    p = synth.random_dna(8300, 900)
+    t = synth.random_dna(8301, 40) + synth.mutate(p, 0.1, 8302)
+    r = gpu.align([(p, t, capi.WFM_MODE_ENDSFREE, len(p), 0, len(t), 0)], pen=(5, 8, 2, 60, 1))[0]
+    rc, ops, sc, _ = oracle.align_endsfree(p, len(p), 0, t, len(t), 0, pen=(5, 8, 2, 60, 1))
+    assert rc == 0 and r.status == 0 and r.ops == ops
 
 
 def test_endsfree_patches_match_oracle(gpu, oracle):

@@ -8,8 +8,9 @@
 namespace wfm {
 
 constexpr int WF_NULL = -(1 << 30);
-constexpr int RING = 32;  // rows kept per component; must be >= score scope
-constexpr int RMASK = RING - 1;
+constexpr int RING = 32;  // rows kept per component; must be >= score scope.  The default penalties (scope 26) and everything
+constexpr int RMASK = RING - 1;  // built for them (register tiles, phase 2 from rows computed ahead) use this depth
+constexpr int RING_BIG = 128;  // the depth for other penalties whose scope passes 32 (o2 + e2 up to 125): step kernel + base kernel only
 
 // wavefront components (same numbering as oracle/wfa2p.h)
 enum { C_M = 0, C_I1 = 1, C_I2 = 2, C_D1 = 3, C_D2 = 4 };
@@ -149,10 +150,10 @@ void launch_bound(const uint8_t* seq, const BoundJob* jobs, int32_t* out, int nj
 struct SeqRev { int64_t p_fwd, p_rev, t_fwd, t_rev; int32_t plen, tlen; };
 void launch_reverse(uint8_t* seq, const SeqRev* jobs, int njobs, int pad, hipStream_t st);
 void launch_bp(const uint8_t* seq, int32_t* ring, const BpJob* jobs, BpResult* res, int njobs, int threads,
-               DevPen pen, int scope, hipStream_t st);
-void launch_tile_init(const uint8_t* seq, int32_t* ring, const TileJob* jobs, int32_t* mak0, int njobs, hipStream_t st);
+               DevPen pen, int scope, int ring_rows, hipStream_t st);
+void launch_tile_init(const uint8_t* seq, int32_t* ring, const TileJob* jobs, int32_t* mak0, int njobs, int ring_rows, hipStream_t st);
 void launch_tile(const uint8_t* seq, int32_t* ring, const TileJob* jobs, const TileTask* tasks, int32_t* mak, int ntasks,
-                 int threads, int T, int Wt, size_t lds_bytes, DevPen pen, int scope, hipStream_t st);
+                 int threads, int T, int Wt, size_t lds_bytes, DevPen pen, int scope, int ring_rows, hipStream_t st);
 void launch_tile_advance(TileJob* jobs, int32_t* mak, int njobs, int T, DevPen pen, int exact, hipStream_t st);
 void launch_tile_reg(const uint8_t* seq, int32_t* ring, const TileJob* jobs, const TileTask* tasks, int32_t* mak, int ntasks,
                      int threads, int T, int C, bool cut, hipStream_t st);  // cut: some job of the launch carries a score bound
@@ -163,7 +164,7 @@ void launch_p2_blockmax(const int32_t* ring, const int32_t* p2, const P2Job* job
 void launch_p2_overlap(const int32_t* ring, const int32_t* p2, const P2Job* jobs, const int32_t* p2max, const int32_t* bmax, int32_t* pbmax,
                        BpResult* res, int njobs, int threads, int max_nblk, DevPen pen, int scope, hipStream_t st);
 void launch_base(const uint8_t* seq, int32_t* a32, uint8_t* a8, uint32_t* rle, const BaseJob* jobs, BaseResult* res,
-                 int njobs, DevPen pen, bool wide, hipStream_t st);  // wide: 1024 threads per job instead of 256
+                 int njobs, DevPen pen, bool wide, int ring_rows, hipStream_t st);  // wide: 1024 threads per job instead of 256
 void launch_compact(const uint32_t* rle, const int64_t* off, const int64_t* cap, uint32_t* out, unsigned long long* total,
                     int64_t* out_start, int32_t* out_count, int nprob, hipStream_t st);
 

@@ -214,10 +214,15 @@ int validate_pen(const wfm_penalties_t* pen, int* scope) {
   if (!pen) return WFM_E_ARG;
   if (pen->x <= 0 || pen->e1 <= 0 || pen->e2 <= 0 || pen->o1 < 0 || pen->o2 < 0) return WFM_E_UNSUPPORTED;
   const int sc = std::max(pen->x, std::max(pen->o1 + pen->e1, pen->o2 + pen->e2)) + 1;
-  if (sc > RING) return WFM_E_UNSUPPORTED;
+  // (two rows of a ring are always in the making: the step kernel clears the row-maximum slot of row s + 2 while rows back to
+  // s - scope + 1 are still read, so a ring of R rows serves scopes up to R - 2)
+  if (sc > RING_BIG - 2) return WFM_E_UNSUPPORTED;  // o2 + e2 (or o1 + e1, or x) beyond 125: deeper rings than the kernels are built with
   *scope = sc;
   return WFM_OK;
 }
+
+// rows of a wavefront ring for penalties of this scope: 32 (the default penalties: scope 26) or 128
+inline int ring_rows_for(int scope) { return scope <= RING - 2 ? RING : RING_BIG; }
 
 struct LevelTimer {
   double bp_ms = 0, base_ms = 0, tile_ms = 0;
@@ -237,6 +242,7 @@ int run_base_jobs(wfm_handle* h, wfm_seqset* S, const wfm_penalties_t& pen, std:
                   std::vector<Node>& retry, std::vector<int32_t>& prob_status, std::vector<uint64_t>& prob_cells,
                   LevelTimer& tm) {
   if (nodes.empty()) return WFM_OK;
+  const int RR = ring_rows_for(std::max(pen.x, std::max(pen.o1 + pen.e1, pen.o2 + pen.e2)) + 1);
   std::stable_sort(nodes.begin(), nodes.end(), [&](const Node& a, const Node& b) {
     return (base_row_width(a, S->meta[a.prob]) > 2048) < (base_row_width(b, S->meta[b.prob]) > 2048);
   });
@@ -285,7 +291,7 @@ int run_base_jobs(wfm_handle* h, wfm_seqset* S, const wfm_penalties_t& pen, std:
       j.kmin = kmin;
       j.width = kmax - kmin + 1;
       const size_t rows = (size_t)nd.smax + 1;
-      const size_t need32 = rows * (size_t)j.width + (size_t)5 * RING * (size_t)j.width;
+      const size_t need32 = rows * (size_t)j.width + (size_t)5 * RR * (size_t)j.width;
       const size_t need8 = rows * (size_t)j.width;
       if (!jobs.empty() && (n32 + need32) * 4 + (n8 + need8) > h->mem_budget) break;
       if (need32 * 4 + need8 > h->mem_budget) {  // a single job beyond the budget
@@ -307,7 +313,7 @@ int run_base_jobs(wfm_handle* h, wfm_seqset* S, const wfm_penalties_t& pen, std:
       HIPCHK(h, hipMemcpyAsync(h->bsjobs.p, jobs.data(), jobs.size() * sizeof(BaseJob), hipMemcpyHostToDevice, h->stream));
       HIPCHK(h, hipEventRecord(h->ev2, h->stream));
       // (jobs arrive sorted: the wide ones -- long patches, retries with a larger budget -- in chunks of their own)
-      launch_base(S->d_seq, h->base32.p, h->base8.p, h->rle.p, h->bsjobs.p, h->bsres.p, (int)jobs.size(), dp, chunk_wide, h->stream);
+      launch_base(S->d_seq, h->base32.p, h->base8.p, h->rle.p, h->bsjobs.p, h->bsres.p, (int)jobs.size(), dp, chunk_wide, RR, h->stream);
       HIPCHK(h, hipGetLastError());
       HIPCHK(h, hipEventRecord(h->ev3, h->stream));
       res.resize(jobs.size());
@@ -386,8 +392,9 @@ TileCfg tile_cfg(const wfm_penalties_t& pen, int scope) {
   if (const char* e = getenv("WFM_TILE_THREADS")) c.threads = atoi(e);
   if (const char* e = getenv("WFM_TILE_MIN_LEN")) c.min_len = atoi(e);
   if (const char* e = getenv("WFM_TILE_MIN_SCORE")) c.min_score = atoi(e);
-  c.T = std::max(c.T, RING);  // the output snapshot needs `scope` rows of the block itself
-  if (c.T_refine > 0) c.T_refine = std::max(c.T_refine, RING);
+  const int RR = ring_rows_for(scope);
+  c.T = std::max(c.T, RR);  // the output snapshot needs `scope` rows of the block itself
+  if (c.T_refine > 0) c.T_refine = std::max(c.T_refine, RR);
   const bool dflt = pen.x == 5 && pen.o1 + pen.e1 == 10 && pen.o2 + pen.e2 == 25 && pen.e1 == 2 && pen.e2 == 1;
   c.reg = dflt && !(getenv("WFM_TILE_REG") && atoi(getenv("WFM_TILE_REG")) == 0);
   if (c.reg) {
@@ -400,7 +407,7 @@ TileCfg tile_cfg(const wfm_penalties_t& pen, int scope) {
   }
   const size_t rows = (size_t)scope + 2 * (pen.e1 + 1) + 2 * (pen.e2 + 1);
   while ((rows * c.Wt + c.T + 1) * 4 > 160 * 1024 && c.Wt > 4 * c.T) c.Wt -= 64;
-  if (c.Wt < 4 * c.T) c.enabled = false;
+  if (c.Wt < 4 * c.T || (rows * c.Wt + c.T + 1) * 4 > 160 * 1024) c.enabled = false;  // (a scope beyond ~60 rows: the step kernel does it all)
   return c;
 }
 
@@ -434,7 +441,7 @@ int run_tiled_phase(wfm_handle* h, wfm_seqset* S, const DevPen& dp, int scope, c
   std::vector<int> s_begin(n, 0);  // score the jobs start this pass at
   if (!refine) {
     HIPCHK(h, hipMemcpyAsync(h->tilejobs.p, tj.data(), n * sizeof(TileJob), hipMemcpyHostToDevice, h->stream));
-    launch_tile_init(S->d_seq, h->ring.p, h->tilejobs.p, h->tilemak.p, (int)n, h->stream);
+    launch_tile_init(S->d_seq, h->ring.p, h->tilejobs.p, h->tilemak.p, (int)n, ring_rows_for(scope), h->stream);
     HIPCHK(h, hipGetLastError());
     std::vector<int32_t> mak(n * 4);
     HIPCHK(h, hipMemcpyAsync(mak.data(), h->tilemak.p, n * 4 * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
@@ -545,7 +552,7 @@ int run_tiled_phase(wfm_handle* h, wfm_seqset* S, const DevPen& dp, int scope, c
       for (int b = 0; b < chunk; ++b) {
         HIPCHK(h, hipEventRecord(h->tile_ev[2 * b], h->stream));
         if (cfg.reg) launch_tile_reg(S->d_seq, h->ring.p, h->tilejobs.p, h->tiletasks.p, h->tilemak.p, (int)tasks.size(), threads_b[(size_t)b], T, cfg.C, any_cut, h->stream);
-        else launch_tile(S->d_seq, h->ring.p, h->tilejobs.p, h->tiletasks.p, h->tilemak.p, (int)tasks.size(), cfg.threads, T, cfg.Wt, lds, dp, scope, h->stream);
+        else launch_tile(S->d_seq, h->ring.p, h->tilejobs.p, h->tiletasks.p, h->tilemak.p, (int)tasks.size(), cfg.threads, T, cfg.Wt, lds, dp, scope, ring_rows_for(scope), h->stream);
         HIPCHK(h, hipEventRecord(h->tile_ev[2 * b + 1], h->stream));
         launch_tile_advance(h->tilejobs.p, h->tilemak.p, (int)n, T, dp, (cfg.reg && cfg.exact) ? 1 : 0, h->stream);
       }
@@ -836,6 +843,7 @@ int align_resident_impl(wfm_handle* h, const wfm_penalties_t* pen, wfm_seqset* S
   std::vector<int> tiled;
   std::vector<int64_t> ring2;
   const TileCfg tcfg = tile_cfg(*pen, scope);
+  const int RR = ring_rows_for(scope);  // rows of every ring of this call
   uint64_t tile_cells_level = 0;
   uint64_t band_retries = 0, band_jobs = 0, roots_banded = 0, roots_out = 0, hint_retries = 0, hinted_roots = 0;
   bool roots_off = false;
@@ -857,7 +865,7 @@ int align_resident_impl(wfm_handle* h, const wfm_penalties_t* pen, wfm_seqset* S
       const char* be = getenv("WFM_BAND");
       const int band_on = be ? atoi(be) : 1;
       size_t total = 0;
-      for (const Node& nd : bp_nodes) total += (((size_t)nd.pl + nd.tl + 9 + 3) & ~(size_t)3) * 2 * 5 * RING * 2;
+      for (const Node& nd : bp_nodes) total += (((size_t)nd.pl + nd.tl + 9 + 3) & ~(size_t)3) * 2 * 5 * RR * 2;
       // (narrow rings whenever full ones would take more than 2 GB, not only when they would not fit: every fresh GB of a
       // first hipMalloc costs ~30 ms on this driver, scripts/malloc_cost2.hip, and a one-shot run pays it)
       use_band = band_on && total * 4 > std::min<size_t>(h->mem_budget, (size_t)2 << 30);
@@ -897,8 +905,8 @@ int align_resident_impl(wfm_handle* h, const wfm_penalties_t* pen, wfm_seqset* S
             if (w * 2 <= width) { band = (int)b; width = w; koff = (int)(nd.pl + 4 - shift); }
           }
         }
-        if (tile_it && width * 2 * 5 * RING * 2 * 4 > h->mem_budget) tile_it = false;  // two snapshot rings do not fit: step-by-step kernel
-        const size_t need = width * 2 * 5 * RING * (tile_it ? 2 : 1);
+        if (tile_it && width * 2 * 5 * RR * 2 * 4 > h->mem_budget) tile_it = false;  // two snapshot rings do not fit: step-by-step kernel
+        const size_t need = width * 2 * 5 * RR * (tile_it ? 2 : 1);
         // (a chunk of a level stops at 8 GB of rings even when the budget allows more: thousands of jobs fill the device
         // long before that, and every GB of a first allocation may cost 30 ms)
         if (!jobs.empty() && (ring_elems + need) * 4 > std::min<size_t>(h->mem_budget, (size_t)8 << 30)) break;
@@ -976,7 +984,7 @@ int align_resident_impl(wfm_handle* h, const wfm_penalties_t* pen, wfm_seqset* S
           for (size_t q = 0; q < rest.size(); ++q) rj[q] = jobs[(size_t)rest[q]];
           HIPCHK(h, hipMemcpyAsync(h->bpjobs.p, rj.data(), rj.size() * sizeof(BpJob), hipMemcpyHostToDevice, h->stream));
           HIPCHK(h, hipEventRecord(h->ev0, h->stream));
-          launch_bp(S->d_seq, h->ring.p, h->bpjobs.p, h->bpres.p, (int)rj.size(), threads, dp, scope, h->stream);
+          launch_bp(S->d_seq, h->ring.p, h->bpjobs.p, h->bpres.p, (int)rj.size(), threads, dp, scope, RR, h->stream);
           HIPCHK(h, hipGetLastError());
           HIPCHK(h, hipEventRecord(h->ev1, h->stream));
           std::vector<BpResult> rr(rj.size());

@@ -255,9 +255,11 @@ std::string Aligner::align_batch(wfm_handle_t* gpu_handle, std::vector<std::stri
     out += recs[k].paf;
     sum.written++;
   }
+  const double ms_text = since(tb3);
+  sum.ms_rows += ms_parse; sum.ms_fetch += ms_fetch; sum.ms_wflign += ms_biwfa; sum.ms_text += ms_text; sum.batches++;
   if (dbg)
     fprintf(stderr, "[wfmash::align] batch of %zu records on %d threads: rows %.1f ms, fetch %.1f ms, wflign %.1f ms (device busy %.1f), text %.1f ms\n",
-            recs.size(), threads, ms_parse, ms_fetch, ms_biwfa, st.ms_gpu, since(tb3));
+            recs.size(), threads, ms_parse, ms_fetch, ms_biwfa, st.ms_gpu, ms_text);
   return out;
 }
 
@@ -421,6 +423,7 @@ Summary Aligner::compute() {
       const Summary& p = part[wk];
       sum.records += p.records; sum.aligned_bp += p.aligned_bp; sum.written += p.written; sum.skipped += p.skipped;
       sum.cells += p.cells;
+      sum.ms_rows += p.ms_rows; sum.ms_fetch += p.ms_fetch; sum.ms_wflign += p.ms_wflign; sum.ms_text += p.ms_text; sum.batches += p.batches;
       iv[wk % ngpu].insert(iv[wk % ngpu].end(), p.busy.begin(), p.busy.end());
     }
     for (auto& v : iv) {

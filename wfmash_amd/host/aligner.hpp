@@ -64,6 +64,8 @@ struct Summary {
   uint64_t skipped = 0;            // invalid mapping rows
   uint64_t cells = 0;
   double ms_gpu = 0, ms_total = 0;
+  double ms_rows = 0, ms_fetch = 0, ms_wflign = 0, ms_text = 0;  // host stages, summed over the batches
+  uint64_t batches = 0;
   std::vector<std::pair<double, double>> busy;  // a worker's device-busy intervals (merged per device at the end of compute())
 };
 

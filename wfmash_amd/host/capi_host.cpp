@@ -62,6 +62,8 @@ int wfmh_align_paf_multi(wfm_handle_t* const* handles, int n, const char* target
     if (summary) {
       summary->records = s.records; summary->aligned_bp = s.aligned_bp; summary->written = s.written;
       summary->skipped = s.skipped; summary->cells = s.cells; summary->ms_gpu = s.ms_gpu; summary->ms_total = s.ms_total;
+      summary->ms_rows = s.ms_rows; summary->ms_fetch = s.ms_fetch; summary->ms_wflign = s.ms_wflign; summary->ms_text = s.ms_text;
+      summary->batches = s.batches;
     }
     return WFM_OK;
   } catch (const std::exception& e) {
