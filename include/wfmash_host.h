@@ -185,6 +185,8 @@ typedef struct {
   int32_t  sketch_size;          /* the sketch size used */
   double   ms_index, ms_map, ms_filter, ms_total;
   double   ms_replicate;    /* copying the finished index to the other GPUs (wfmh_map_multi) */
+  double   ms_identity;     /* the identity estimate (-p aniN: reading every sequence once + one MinHash per sequence on the device) */
+  double   ms_wall;         /* the whole call: identity estimate, reading the sequences, index, mapping, post-processing, output */
 } wfmh_map_summary_t;
 
 /* The map phase on files: replaces skch::Map's constructor + mapQuery()

@@ -616,7 +616,7 @@ class MapSummary(C.Structure):
     _fields_ = [("targets", C.c_uint64), ("queries", C.c_uint64), ("subsets", C.c_uint64), ("target_bp", C.c_uint64),
                 ("query_bp", C.c_uint64), ("index_windows", C.c_uint64), ("fragments", C.c_uint64), ("l2_mappings", C.c_uint64),
                 ("written", C.c_uint64), ("percentage_identity", C.c_float), ("sketch_size", C.c_int32), ("ms_index", C.c_double), ("ms_map", C.c_double), ("ms_filter", C.c_double),
-                ("ms_total", C.c_double), ("ms_replicate", C.c_double)]
+                ("ms_total", C.c_double), ("ms_replicate", C.c_double), ("ms_identity", C.c_double), ("ms_wall", C.c_double)]
 
 
 def _handle_array(handles):

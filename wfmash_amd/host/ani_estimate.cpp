@@ -39,10 +39,10 @@ double estimate_identity_for_groups(const Parameters& params, const SequenceIdMa
   if (hs.empty()) throw std::runtime_error("no GPU handle");
   struct Role { std::string file; bool is_query = false, is_target = false; };
   std::map<std::string, Role> roles;  // the reference walks a hash map here; the result does not depend on the order
-  std::unordered_map<std::string, std::unique_ptr<wfmash_host::FastaStore>> stores;
+  std::unordered_map<std::string, std::shared_ptr<wfmash_host::FastaStore>> stores;
   auto open = [&](const std::string& file) -> wfmash_host::FastaStore& {
     auto it = stores.find(file);
-    if (it == stores.end()) it = stores.emplace(file, std::make_unique<wfmash_host::FastaStore>(file)).first;
+    if (it == stores.end()) it = stores.emplace(file, wfmash_host::open_shared(file)).first;
     return *it->second;
   };
   auto known = [&](const std::string& name) {

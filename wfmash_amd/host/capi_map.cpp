@@ -1,4 +1,5 @@
 // capi_map.cpp -- C entry points of the map phase's host side (include/wfmash_host.h).
+#include <chrono>
 #include <cstdlib>
 #include <fstream>
 #include <cstdio>
@@ -11,6 +12,7 @@
 #include "../csrc/wfa_handle.h"
 #include "ani_estimate.hpp"
 #include "capi_map.hpp"
+#include "fasta.hpp"
 #include "index_file.hpp"
 #include "map_filter.hpp"
 #include "mapper.hpp"
@@ -134,6 +136,12 @@ int wfmh_map_multi(wfm_handle_t* const* handles, int n, const char* target_fasta
     p.refSequences = {std::string(target_fasta)};
     p.querySequences = {std::string(query_fasta ? query_fasta : target_fasta)};
     p.outFileName = out_paf;
+    // the files stay open (and what is loaded of them stays loaded) from the identity estimate through the mapping
+    std::vector<std::shared_ptr<wfmash_host::FastaStore>> files;
+    for (const auto& f : p.refSequences) files.push_back(wfmash_host::open_shared(f));
+    for (const auto& f : p.querySequences) files.push_back(wfmash_host::open_shared(f));
+    const auto t_call = std::chrono::steady_clock::now();
+    double ms_identity = 0;
     if (p.auto_pct_identity) {
       // main.cpp:72-128: estimate, then derive the sketch size from the estimate unless -s was given
       std::vector<std::string> target_prefix_vec;
@@ -141,6 +149,7 @@ int wfmh_map_multi(wfm_handle_t* const* handles, int n, const char* target_fasta
       const skch::SequenceIdManager ids(p.querySequences, p.refSequences, p.query_prefix, target_prefix_vec,
                                         std::string(1, p.prefix_delim), p.query_list, p.target_list);
       p.percentageIdentity = skch::Stat::estimate_identity_for_groups(p, ids, std::vector<wfm_handle_t*>(handles, handles + n));
+      ms_identity = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call).count();
     }
     skch::Map mapper(p, std::vector<wfm_handle_t*>(handles, handles + n));
     skch::MapSummary s;
@@ -153,6 +162,8 @@ int wfmh_map_multi(wfm_handle_t* const* handles, int n, const char* target_fasta
       summary->sketch_size = mapper.parameters().sketchSize;
       summary->ms_index = s.ms_index; summary->ms_map = s.ms_map; summary->ms_filter = s.ms_filter; summary->ms_total = s.ms_total;
       summary->ms_replicate = s.ms_replicate;
+      summary->ms_identity = ms_identity;
+      summary->ms_wall = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call).count();
     }
     return rc;
   } catch (const std::exception& e) {

@@ -316,4 +316,16 @@ std::string FastaStore::fetch(const std::string& name, int64_t start, int64_t en
   return out;
 }
 
+std::shared_ptr<FastaStore> open_shared(const std::string& path) {
+  static std::mutex mu;
+  static std::unordered_map<std::string, std::weak_ptr<FastaStore>> open_files;
+  std::lock_guard<std::mutex> lk(mu);
+  auto it = open_files.find(path);
+  if (it != open_files.end())
+    if (auto sp = it->second.lock()) return sp;
+  auto sp = std::make_shared<FastaStore>(path);
+  open_files[path] = sp;
+  return sp;
+}
+
 }  // namespace wfmash_host

@@ -72,4 +72,9 @@ class FastaStore {
   mutable std::unique_ptr<std::atomic<bool>[]> loaded_;  // indexed mode: seqs_[i] holds the whole sequence (set after the load)
 };
 
+// One FastaStore per file for as long as somebody holds it: the identity estimate and the mapper of one run ask for the same
+// files one after the other (main.cpp:72-128 then computeMap.hpp:147-230), and a whole-sequence load of a pangenome is
+// gigabytes -- whoever spans both (wfmh_map_multi) keeps the pointers, and the second one finds the sequences loaded.
+std::shared_ptr<FastaStore> open_shared(const std::string& path);
+
 }  // namespace wfmash_host

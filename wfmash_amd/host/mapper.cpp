@@ -37,7 +37,7 @@ class SequenceSource {
  public:
   void add(const std::string& path) {
     if (stores_.count(path)) return;
-    stores_.emplace(path, std::make_unique<wfmash_host::FastaStore>(path));
+    stores_.emplace(path, wfmash_host::open_shared(path));
     order_.push_back(path);
   }
   // the first file holding `name`, restricted to `files`
@@ -64,7 +64,7 @@ class SequenceSource {
   }
 
  private:
-  std::unordered_map<std::string, std::unique_ptr<wfmash_host::FastaStore>> stores_;
+  std::unordered_map<std::string, std::shared_ptr<wfmash_host::FastaStore>> stores_;
   std::vector<std::string> order_;
 };
 

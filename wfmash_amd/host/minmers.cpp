@@ -957,12 +957,22 @@ int64_t add_minmers_core(wfm_handle_t* h, const char* const* seqs, const int64_t
   MapHashWork hash_work;
   MapThinWork thin_work;
 
-  MapWinnowWork winnow_work;
-  MapFinishWork finish_work;
+  // several device threads, each with a stream and work buffers of its own: a sequence costs the device path 2 - 3 ms of
+  // launches and round trips whatever its length, which the threads overlap (chromosome-sized sequences are one launch
+  // set each and fill the device alone; a yeast genome is 128 short ones)
+  const int n_dev_threads = std::max(1, std::min(16, getenv("WFM_WINNOW_DEV_THREADS") ? atoi(getenv("WFM_WINNOW_DEV_THREADS")) : 2));
+  std::vector<MapWinnowWork> winnow_works((size_t)n_dev_threads);
+  std::vector<MapFinishWork> finish_works((size_t)n_dev_threads);
   const bool dev_finish = !(getenv("WFM_FINISH_DEVICE") && atoi(getenv("WFM_FINISH_DEVICE")) == 0);
   int dev_levels = 0;
   int64_t dev_heaps = 0;
   const bool dev_winnow = !(getenv("WFM_WINNOW_DEVICE") && atoi(getenv("WFM_WINNOW_DEVICE")) == 0);
+  // Sequences under 4 M k-mers stay with the host's workers.  Round 3 tried to move the switch down with several device
+  // threads (each its own stream and buffers): on the C1 substitute (128 sequences of 0.2 - 1.5 Mbp) the index took 0.25 s with
+  // 4 device threads from 256 k k-mers on, 0.19 - 0.21 s with the closing sort left to the host, against 0.13 - 0.15 s on the
+  // host path (also with 32 host threads) -- a sequence costs the device path 2 - 4 ms of launches and stream
+  // synchronisations whatever its length, the threads contend for the queue, and the feeding thread (hash + thin: 0.9 ms per
+  // sequence) slows down beside them.  Only launch sets that span many sequences would change that.
   const int64_t dev_min = getenv("WFM_WINNOW_DEV_MIN") ? atoll(getenv("WFM_WINNOW_DEV_MIN")) : (int64_t)1 << 22;
   const int64_t dev_chunk = getenv("WFM_WINNOW_DEV_CHUNK") ? atoll(getenv("WFM_WINNOW_DEV_CHUNK")) : 0;  // 0: by sequence length
   int64_t dev_seqs = 0, dev_handed_back = 0, dev_chunks = 0, dev_replays = 0;
@@ -982,8 +992,11 @@ int64_t add_minmers_core(wfm_handle_t* h, const char* const* seqs, const int64_t
     }
     cv_room.notify_one();
   };
-  auto device_thread = [&]() {
+  std::mutex dev_stat_mu;  // the counters below
+  auto device_thread = [&](int dti) {
     (void)hipSetDevice(wfm_device(h));
+    MapWinnowWork& winnow_work = winnow_works[(size_t)dti];
+    MapFinishWork& finish_work = finish_works[(size_t)dti];
     hipStream_t st2 = nullptr;
     if (hipStreamCreateWithFlags(&st2, hipStreamNonBlocking) != hipSuccess) st2 = nullptr;
     for (;;) {
@@ -1006,8 +1019,7 @@ int64_t add_minmers_core(wfm_handle_t* h, const char* const* seqs, const int64_t
       int wrc = st2 ? map_winnow_sparse_device(h, &J->sparse, J->len, k, w, s, J->seq_id, std::max<int64_t>(dev_chunk > 0 ? dev_chunk : auto_chunk, 4 * (int64_t)w),
                                                &winnow_work, &d_recs, &n_recs, &wi, st2)
                     : 1;
-      dev_chunks += wi.chunks;
-      dev_replays += wi.replays;
+      { std::lock_guard<std::mutex> lk(dev_stat_mu); dev_chunks += wi.chunks; dev_replays += wi.replays; }
       if (wrc == WFM_OK && dev_finish) {  // the closing cut / sort / de-duplication on the device as well
         wfm_minmer_t* d_fin = nullptr;
         int64_t n_fin = 0;
@@ -1024,6 +1036,7 @@ int64_t add_minmers_core(wfm_handle_t* h, const char* const* seqs, const int64_t
         if (wrc == WFM_OK) {
           J->n_result = n_fin;
           J->dev_winnowed = true;
+          std::lock_guard<std::mutex> lk(dev_stat_mu);
           ++dev_seqs;
           dev_levels = std::max(dev_levels, fi.levels);
           dev_heaps += fi.heap_ranges;
@@ -1036,18 +1049,18 @@ int64_t add_minmers_core(wfm_handle_t* h, const char* const* seqs, const int64_t
           wrc = WFM_E_HIP;
         } else {
           J->dev_winnowed = true;
+          std::lock_guard<std::mutex> lk(dev_stat_mu);
           ++dev_seqs;
         }
       }
-      ms_winnow += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tw).count();
+      { std::lock_guard<std::mutex> lk(dev_stat_mu); ms_winnow += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tw).count(); }
       if (wrc < 0) {  // an error: the sequence ends here with no records, the call fails (the failing path has set the message)
         async_msg_set.store(true);
         async_rc.store(wrc);
         map_sparse_free(&J->sparse);
         seq_finished(J);
       } else if (wrc == 1) {  // not for the device after all: the host's chunks
-        ++dev_handed_back;
-        dev_why |= wi.why;
+        { std::lock_guard<std::mutex> lk(dev_stat_mu); ++dev_handed_back; dev_why |= wi.why; }
         {
           std::lock_guard<std::mutex> lk(mu);
           hashed.push_back(J);
@@ -1069,7 +1082,8 @@ int64_t add_minmers_core(wfm_handle_t* h, const char* const* seqs, const int64_t
   };
   std::vector<std::thread> pool;
   for (int t = 0; t < nthreads; ++t) pool.emplace_back(worker);
-  std::thread dev_thread(device_thread);
+  std::vector<std::thread> dev_threads;
+  for (int t = 0; t < n_dev_threads; ++t) dev_threads.emplace_back(device_thread, t);
   std::thread stream_thread;
   if (streamed) stream_thread = std::thread(streamer);
   int rc = WFM_OK;
@@ -1162,7 +1176,7 @@ int64_t add_minmers_core(wfm_handle_t* h, const char* const* seqs, const int64_t
     dev_done = true;
   }
   cv_dev.notify_all();
-  dev_thread.join();  // before the streamer is told that nothing more will come: the device may still hand sequences back
+  for (auto& t : dev_threads) t.join();  // before the streamer is told that nothing more will come: the device may still hand sequences back
   {
     std::lock_guard<std::mutex> lk(mu);
     hashed_done = true;
@@ -1186,11 +1200,11 @@ int64_t add_minmers_core(wfm_handle_t* h, const char* const* seqs, const int64_t
   release_stitched();
   for (auto& J : jobs)
     if (J) { if (J->on_device) { map_hashed_free(&J->dev); J->on_device = false; } map_sparse_free(&J->sparse); if (J->d_result) { map_dev_pool_put(wfm_device(h), J->d_result); J->d_result = nullptr; } }  // after an error
-  auto release_work = [hash_work, thin_work, winnow_work, finish_work]() mutable {
+  auto release_work = [hash_work, thin_work, winnow_works, finish_works]() mutable {
     map_hash_work_free(&hash_work);
     map_thin_work_free(&thin_work);
-    map_winnow_work_free(&winnow_work);
-    map_finish_work_free(&finish_work);
+    for (auto& wk : winnow_works) map_winnow_work_free(&wk);
+    for (auto& wk : finish_works) map_finish_work_free(&wk);
     map_dev_pool_trim();
   };
   if (getenv("WFM_DEBUG") && (dev_seqs || dev_handed_back))
