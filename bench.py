@@ -38,6 +38,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", default="C3", choices=["C3", "C5"])
     ap.add_argument("--pairs", type=int, default=64)
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: --pairs records per GPU (the driver's SCALE runs); strong: one file of --total-pairs records "
+                         "sharded over the ranks by dist.shard_records, the same file at every N")
+    ap.add_argument("--total-pairs", type=int, default=512, help="records of the strong-scaling file (64 x 8)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0, help="pairs in the cpu_baseline sample (0 = auto)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary figures (C5, scaled C4 rank, C2)")
@@ -70,6 +74,7 @@ def main():
     if args.gpus != world:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
     if args.rank_check:
+        shard = _shard(args, rank, world, None)
         if world > 1:
             import torch.distributed as dist
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -81,7 +86,8 @@ def main():
         else:
             seen = [0]
         sys.stdout.flush()
-        os.write(1, (json.dumps({"rank_check": True, "rank": rank, "n_gpus": world, "ranks_seen": seen}) + "\n").encode())  # one write per line
+        os.write(1, (json.dumps({"rank_check": True, "rank": rank, "n_gpus": world, "ranks_seen": seen, "scaling": args.scaling,
+                                 "records": shard}) + "\n").encode())  # one write per line
         return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
@@ -105,11 +111,13 @@ def main():
     comm_dev = dev if (dist is None or dist.get_backend() == "nccl") else torch.device("cpu")
 
     h = capi.Handle(local_rank)
-    # this rank's shard of the mapping records (distinct seeds per rank)
-    all_pairs = synth.pairs(args.config, n_pairs=args.pairs * world)
-    mine = all_pairs[rank * args.pairs:(rank + 1) * args.pairs]
+    # this rank's shard of the mapping records (weak: distinct seeds per rank; strong: its share of the one file)
+    n_all = args.pairs * world if args.scaling == "weak" else args.total_pairs
+    all_pairs = synth.pairs(args.config, n_pairs=n_all)
+    mine = [all_pairs[i] for i in _shard(args, rank, world, all_pairs)]
     seqset = h.upload(mine)
     query_bases = sum(len(q) for _, q in mine)  # "total aligned bp" = sum of query spans (computeAlignments.hpp:481,528)
+    job_bases = sum(len(q) for _, q in all_pairs)  # of all ranks
 
     def gather_payload(seqset):
         """PAF-side payload gather to rank 0 (variable-length byte buffers)."""
@@ -146,7 +154,7 @@ def main():
 
     out = None
     if rank == 0:
-        value = query_bases * world * args.steps / dt
+        value = job_bases * args.steps / dt
         seq_bytes = sum(len(p) + len(q) for p, q in mine) * 2  # forward + reversed copies
         # one more, untimed, pass with the parts of the batch one after the other on one stream (WFM_OVERLAP=0): every
         # launch then has the GPU to itself, which is what rocprofv3's per-launch durations of that mode show
@@ -163,13 +171,14 @@ def main():
             "metric": "aligned bases/sec (whole node) + CIGAR-identical rate vs CPU ref",
             "value": value, "unit": "aligned bases/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "int32", "data": "synthetic",
-            "config": {"workload": f"{args.config}: {args.pairs} synthetic "
+            "config": {"workload": f"{args.config}: {args.pairs if args.scaling == 'weak' else args.total_pairs} synthetic "
                                    f"{'5%' if args.config == 'C3' else '15%'}-divergence "
-                                   f"{'50' if args.config == 'C3' else '100'}kb segment pairs per GPU, WFA-only "
+                                   f"{'50' if args.config == 'C3' else '100'}kb segment pairs "
+                                   f"{'per GPU' if args.scaling == 'weak' else 'in all, sharded over the GPUs'}, WFA-only "
                                    "(BiWFA gap-affine-2p 5,8,2,24,1; mappings pre-supplied)",
-                       "pairs_per_gpu": args.pairs, "parallelism": f"records sharded over {world} GPU(s)"},
+                       "pairs_per_gpu": len(mine), "pairs_total": n_all, "parallelism": f"records sharded over {world} GPU(s)"},
             "roofline": roof,
             # time during which at least one launch of the kernel was running (union of the launch intervals over all
             # streams, HIP events against one origin), and the sum of the individual launch durations
@@ -213,6 +222,21 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def _shard(args, rank, world, pairs):
+    """Indices of this rank's mapping records.  weak: rank r takes records [r * pairs, (r + 1) * pairs) of a file that grows
+    with N; strong: the --total-pairs records of one file go to the ranks the way the reference's cluster sharding deals
+    them out (dist.shard_records: longest first onto the least-loaded rank; weight = WFA cost ~ (length x divergence)^2,
+    scripts/split_approx_mappings_in_chunks.py:19-27)."""
+    if args.scaling == "weak":
+        return list(range(rank * args.pairs, (rank + 1) * args.pairs))
+    from wfmash_amd.dist import shard_records
+    if pairs is None:  # --rank-check: the shard sizes only need the record count (synthetic records are equally long)
+        weights = [1.0] * args.total_pairs
+    else:
+        weights = [float(len(q)) ** 2 for _, q in pairs]
+    return shard_records(weights, world)[rank]
 
 
 class _StatAcc:

@@ -60,3 +60,29 @@ def test_two_ranks_on_one_gpu_print_one_line_for_the_job():
     j = lines[0]
     assert j["n_gpus"] == 2 and j["steps"] == 1 and j["scaling"] == "weak"
     assert j["value"] > 0 and j["roofline"]["frac"] > 0
+
+
+def test_strong_scaling_shards_one_file_over_the_ranks():
+    """--scaling strong: the same --total-pairs records at every N, dealt out by dist.shard_records -- every record on
+    exactly one rank, the shards level."""
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--rank-check", "--scaling", "strong", "--total-pairs", "13"], cwd=ROOT,
+                       env=_clean_env(), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = sorted((j for j in _json_lines(r.stdout) if j.get("rank_check")), key=lambda j: j["rank"])
+    assert [j["scaling"] for j in lines] == ["strong", "strong"]
+    assert sorted(lines[0]["records"] + lines[1]["records"]) == list(range(13))
+    assert abs(len(lines[0]["records"]) - len(lines[1]["records"])) <= 1
+    one = subprocess.run([sys.executable, BENCH, "--gpus", "1", "--rank-check", "--scaling", "strong", "--total-pairs", "13"], cwd=ROOT,
+                         env=_clean_env(), capture_output=True, text=True, timeout=600)
+    assert [j["records"] for j in _json_lines(one.stdout) if j.get("rank_check")] == [list(range(13))]
+
+
+@pytest.mark.gpu
+def test_strong_scaling_two_ranks_on_one_gpu():
+    env = dict(_clean_env(), WFM_BENCH_SHARE_GPU="1")
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "1", "--warmup", "0", "--scaling", "strong", "--total-pairs", "6",
+                        "--no-cpu-baseline"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    (j,) = [j for j in _json_lines(r.stdout) if "metric" in j]
+    assert j["n_gpus"] == 2 and j["scaling"] == "strong" and j["config"]["pairs_total"] == 6 and j["config"]["pairs_per_gpu"] == 3
+    assert j["value"] > 0
