@@ -6,6 +6,7 @@
 #include <atomic>
 #include <cctype>
 #include <chrono>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -310,16 +311,39 @@ Summary Aligner::compute() {
     outstream << "@PG\tID:wfmash\tPN:wfmash\tVN:" WFMASH_HIP_VERSION "\tCL:wfmash\n";
   }
   const size_t ngpu = gpus.size();
-  // several GPUs: no batch may hold more than an eighth of one GPU's share of the file.  One GPU: a file that would fit
-  // one or two batches is still cut into WFM_ALIGN_MIN_BATCHES, so that the host stages of one part (fetches, patches,
-  // records) run while the device works on another
+  // up to three batches per GPU in flight when there are host threads for it: the host stages of a batch (sequence
+  // fetches, CIGAR surgery, PAF text) run while the device works on another
+  const size_t per_gpu = (size_t)param.threads >= 12 * ngpu ? 3 : ((size_t)param.threads >= 2 * ngpu ? 2 : 1);
+  const size_t nworkers = ngpu * per_gpu;
+  // several GPUs: no batch may hold more than an eighth of one GPU's share of the file.  One GPU: a file of one batch
+  // stays one batch (WFM_ALIGN_MIN_BATCHES cuts it for A/B runs); a file of a few batches is cut into a multiple of the
+  // workers' number, level ones -- four batches on three workers are two rounds of which the second leaves the device to
+  // one batch's tails.  (The number of records is estimated from the file's size and its first rows.)
   uint64_t batch_bytes = ~0ull;
   static const uint64_t min_batches = getenv("WFM_ALIGN_MIN_BATCHES") ? (uint64_t)std::max(1, atoi(getenv("WFM_ALIGN_MIN_BATCHES"))) : 1;
-  if (ngpu > 1 || min_batches > 1) {
+  static const bool level_batches = !(getenv("WFM_ALIGN_LEVEL") && atoi(getenv("WFM_ALIGN_LEVEL")) == 0);
+  {
     in.seekg(0, std::ios::end);
     const uint64_t file_bytes = (uint64_t)std::max<std::streamoff>(0, in.tellg());
     in.seekg(0, std::ios::beg);
-    batch_bytes = std::max<uint64_t>(1, file_bytes / (ngpu > 1 ? 8 * ngpu : min_batches) + 1);
+    uint64_t want = ngpu > 1 ? 8 * ngpu : min_batches;
+    if (level_batches && nworkers > 1 && file_bytes > 0) {
+      uint64_t rows = 0, bytes = 0, bases = 0;
+      std::string line;
+      while (rows < 256 && std::getline(in, line)) {
+        if (line.empty()) continue;
+        ++rows; bytes += line.size() + 1; bases += row_bases(line);
+      }
+      in.clear();
+      in.seekg(0, std::ios::beg);
+      if (rows > 0) {
+        const double est_rows = (double)file_bytes / ((double)bytes / (double)rows);
+        const double est_bases = est_rows * ((double)bases / (double)rows);
+        const uint64_t need = (uint64_t)std::ceil(std::max(est_rows / (double)param.batch_records, est_bases / (double)param.batch_bases));
+        if (need >= 2 && need < 8 * nworkers) want = std::max<uint64_t>(want, (need + nworkers - 1) / nworkers * nworkers);
+      }
+    }
+    if (want > 1) batch_bytes = std::max<uint64_t>(1, file_bytes / want + 1);
   }
   std::mutex read_mu, write_mu;
   uint64_t next_seq = 0, next_write = 0;
@@ -346,11 +370,6 @@ Summary Aligner::compute() {
       outstream << it->second;
     outstream.flush();
   };
-  // up to three batches per GPU in flight when there are host threads for it: the host stages of a batch (sequence
-  // fetches, CIGAR surgery, PAF text -- about two thirds of its wall time on C4-like records) run while the device works
-  // on another (calls into a handle are serialised, wflign_hip.cpp)
-  const size_t per_gpu = (size_t)param.threads >= 12 * ngpu ? 3 : ((size_t)param.threads >= 2 * ngpu ? 2 : 1);
-  const size_t nworkers = ngpu * per_gpu;
   std::vector<Summary> part(nworkers);
   const int threads_each = std::max(1, param.threads / (int)nworkers);
   // Every worker beyond the first of a device works on a handle of its own (own stream, own arenas): its batch's device
