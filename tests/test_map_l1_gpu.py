@@ -112,3 +112,24 @@ def test_l1_rejects_ragged_fragment_lengths(gpu):
     with pytest.raises(WfmError):
         gpu.map_l1(ix, flat, [len(sk[0])], [0], [700], [1], 10, _params(500, 10, 0.9), group)
     ix.free()
+
+
+def test_l1_repeat_rich_lists_span_many_chunks(gpu, monkeypatch):
+    """Tandem repeats put hundreds to thousands of interval points into a fragment's list: position groups and candidates
+    then straddle the 64-key chunks of the wave-per-fragment sweep.  Both forms of the sweep against the oracle."""
+    rng_seed = 23
+    unit = synth.random_dna(rng_seed, 180)
+    flank = synth.random_dna(rng_seed + 1, 9000)
+    base = flank[:3000] + unit * 30 + flank[3000:6000] + unit * 12 + flank[6000:]
+    seqs, group = [], []
+    for g in range(4):
+        for hap in range(2):
+            seqs.append(synth.mutate(base, 0.004 * (g + 1), 1000 + g * 10 + hap))
+            group.append(g)
+    counts = []
+    for wave in ("1", "0"):
+        monkeypatch.setenv("WFM_L1_WAVE", wave)
+        for kw in (dict(), dict(stage2_full_scan=False), dict(stage1_topani=False, skip_prefix=False, skip_self=False)):
+            got, nfrag = _run(gpu, seqs, group, 500, 20, _params(500, 20, 0.9, **kw), max_freq=0.05)
+            counts.append(len(got))
+    assert counts[:3] == counts[3:] and min(counts) > 0

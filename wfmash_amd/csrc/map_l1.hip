@@ -209,6 +209,194 @@ __global__ void l1_sweep_kernel(const uint64_t* keys, const uint64_t* seg_off, c
   if (!out) out_count[f] = (uint32_t)emitted;
 }
 
+// ---- the same sweeps, one wave per fragment ------------------------------------------------------------------------
+// What is sequential in computeL1CandidateRegions is only the candidate bookkeeping; the overlap count after a position
+// group is a difference of two prefix counts: the OPEN points up to the group's end minus the CLOSE points the trailing
+// pointer has passed, which is every CLOSE up to the end of the group's first (seq, pos) run (keys are sorted by
+// (seq, pos, side), CLOSE first; a position group is a run of equal pos whatever the seq, mappingCore.hpp:223-226, and the
+// trailing pointer compares with the group's first key, :214-221).  A wave takes 64 keys at a time: prefix sums and
+// running maxima by lane shuffles give every group's count at its last key; the lanes that end a group are the
+// "elements" the reference's loop looks at one iteration later (prev_overlap, prev_pos, prev_seq), and the bookkeeping
+// walks them in order from wave-uniform registers -- skipping a chunk outright when no element reaches minimum_hits and
+// no candidate is open, which is nearly all of them.  The keys of the next chunk are in flight while one is worked on.
+__device__ __forceinline__ int wv_incl_sum(int v, int lane) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(v, d, 64); if (lane >= d) v += t; }
+  return v;
+}
+__device__ __forceinline__ int wv_incl_max(int v, int lane) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(v, d, 64); if (lane >= d) v = max(v, t); }
+  return v;
+}
+__device__ __forceinline__ int rl(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
+__device__ __forceinline__ int64_t rl64(int64_t v, int lane) {
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v & 0xffffffffll), lane);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)((uint64_t)v >> 32), lane);
+  return (int64_t)(((uint64_t)hi << 32) | lo);
+}
+
+struct SweepCarry {
+  int opens = 0, sends = 0;   // OPEN keys / ends of (seq, pos) runs before the chunk
+  int gs_sends = 0;           // `sends` at the start of the position group the chunk begins in
+  int32_t gs_seq = 0;         // seq of that group's first key
+  int closes_passed = 0;      // CLOSE keys the trailing pointer has passed
+  uint64_t last_key = 0;      // the key before the chunk
+};
+
+// One chunk: lane `lane` holds key k[base + lane] (`key`; `next0` = the key after the chunk's last).  Out, valid on lanes
+// that end a position group: the overlap count after the group, its position, the seq of its first key.
+__device__ __forceinline__ void l1_chunk(uint64_t key, uint64_t next0, int64_t base, int64_t n, int lane, SweepCarry& cy, int& ov, int64_t& pos,
+                                         int32_t& seq_first, bool& gend) {
+  const int64_t gi = base + lane;
+  const bool valid = gi < n;
+  uint64_t kp = __shfl_up(key, 1, 64), kn = __shfl_down(key, 1, 64);
+  if (lane == 0) kp = cy.last_key;
+  if (lane == 63) kn = next0;
+  const int64_t p = key_pos(key);
+  const int32_t sq = key_seq(key);
+  const bool open = valid && key_open(key);
+  const bool gstart = valid && (gi == 0 || key_pos(kp) != p);
+  const bool last = gi == n - 1;
+  gend = valid && (last || key_pos(kn) != p);
+  const bool send = valid && (last || key_pos(kn) != p || key_seq(kn) != sq);
+  const int O = cy.opens + wv_incl_sum(open ? 1 : 0, lane);
+  const int Cc = (int)(gi + 1) - O;  // CLOSE keys among k[0 .. gi]
+  const int S_excl = cy.sends + wv_incl_sum(send ? 1 : 0, lane) - (send ? 1 : 0);
+  const int gsl = wv_incl_max(gstart ? lane : -1, lane);  // lane of the latest group start at or before this one
+  const int s_at = __shfl(S_excl, max(gsl, 0), 64);
+  const int32_t q_at = __shfl(sq, max(gsl, 0), 64);
+  const int Sgs = gsl >= 0 ? s_at : cy.gs_sends;
+  seq_first = gsl >= 0 ? q_at : cy.gs_seq;
+  const bool first_send = send && S_excl == Sgs;  // the end of the group's first (seq, pos) run: where the trailing pointer stops
+  const int passed = max(cy.closes_passed, wv_incl_max(first_send ? Cc : -1, lane));
+  ov = O - passed;
+  pos = p;
+  cy.opens = rl(O, 63);
+  cy.sends = rl(S_excl + (send ? 1 : 0), 63);
+  cy.gs_sends = rl(Sgs, 63);
+  cy.gs_seq = rl(seq_first, 63);
+  cy.closes_passed = rl(passed, 63);
+  const int64_t nv = min<int64_t>(64, n - base);
+  cy.last_key = (uint64_t)rl64((int64_t)key, (int)nv - 1);
+}
+
+// computeL1CandidateRegions for one group's sorted points by one wave (all lanes return the same).
+__device__ int l1_group_wave(const uint64_t* k, int64_t n, int q_sketch, int minimum_hits, const DevParams& P, const int32_t* cutoffs,
+                             wfm_l1_candidate_t* emit, int emitted, int32_t frag, Cand& back, bool& have_back, int lane) {
+  if (n == 0) return emitted;
+  if (P.stage1_topani) {
+    int best = 0;
+    SweepCarry cy;
+    uint64_t nxt = lane < n ? k[lane] : 0;
+    for (int64_t base = 0; base < n; base += 64) {
+      const uint64_t key = nxt;
+      nxt = base + 64 + lane < n ? k[base + 64 + lane] : 0;
+      int ov; int64_t pos; int32_t sf; bool gend;
+      l1_chunk(key, (uint64_t)rl64((int64_t)nxt, 0), base, n, lane, cy, ov, pos, sf, gend);
+      int m = gend ? ov : 0;
+#pragma unroll
+      for (int d = 32; d >= 1; d >>= 1) m = max(m, __shfl_xor(m, d, 64));
+      best = max(best, m);
+    }
+    if (best < minimum_hits) return emitted;
+    const int idx = (int)((double)min(best, q_sketch) / P.cutoff_div);
+    minimum_hits = max(cutoffs[min(idx, P.n_cutoffs - 1)], minimum_hits);
+  }
+  bool in_cand = false;
+  Cand c{0, 0, 0, 0};
+  auto flush = [&](const Cand& lc) {
+    if (!have_back || lc.seq != back.seq || lc.start > back.end + P.w) {
+      if (have_back) {
+        if (emit && lane == 0) { wfm_l1_candidate_t o; o.seqId = back.seq; o.frag = frag; o.rangeStartPos = back.start; o.rangeEndPos = back.end; o.intersectionSize = back.isect; o.pad_ = 0; emit[emitted] = o; }
+        ++emitted;
+      }
+      back = lc; have_back = true;
+    } else {
+      back.end = lc.end;
+      back.isect = max(lc.isect, back.isect);
+    }
+  };
+  SweepCarry cy;
+  uint64_t nxt = lane < n ? k[lane] : 0;
+  for (int64_t base = 0; base < n; base += 64) {
+    const uint64_t key = nxt;
+    nxt = base + 64 + lane < n ? k[base + 64 + lane] : 0;
+    int ov; int64_t pos; int32_t sf; bool gend;
+    l1_chunk(key, (uint64_t)rl64((int64_t)nxt, 0), base, n, lane, cy, ov, pos, sf, gend);
+    // the elements of this chunk: every position group but the segment's last (the loop ends before it looks back at it)
+    const bool elem = gend && base + lane != n - 1;
+    unsigned long long E = __ballot(elem);
+    const unsigned long long H = __ballot(elem && ov >= minimum_hits);
+    if (H == 0) {
+      if (in_cand && E) { flush(c); c = Cand{0, 0, 0, 0}; in_cand = false; }
+      continue;
+    }
+    while (E) {
+      if (!in_cand) {  // nothing open: straight to the next element that reaches minimum_hits
+        const unsigned long long rest = H & E;
+        if (!rest) break;
+        E &= ~((1ull << __builtin_ctzll(rest)) - 1ull);
+      }
+      const int e = __builtin_ctzll(E);
+      E &= E - 1ull;
+      const int o = rl(ov, e);
+      if (o >= minimum_hits) {
+        const int64_t pp = rl64(pos, e);
+        const int32_t sq = rl(sf, e);
+        if (c.seq != sq && in_cand) { flush(c); c = Cand{0, 0, 0, 0}; in_cand = false; }
+        if (!in_cand) { c.start = pp; c.end = pp; c.seq = sq; c.isect = o; in_cand = true; }
+        else if (P.stage2_full_scan) { c.isect = max(c.isect, o); c.end = pp; }
+        else if (c.isect < o) { c.isect = o; c.start = pp; c.end = pp; }
+      } else {
+        if (in_cand) { flush(c); c = Cand{0, 0, 0, 0}; }
+        in_cand = false;
+      }
+    }
+  }
+  if (in_cand) flush(c);
+  return emitted;
+}
+
+__global__ __launch_bounds__(64) void l1_sweep_wave_kernel(const uint64_t* keys, const uint64_t* seg_off, const uint32_t* seg_cnt, const int32_t* qcount,
+                                                           const int32_t* q_len, const uint8_t* q_active, const int32_t* ref_group,
+                                                           const int32_t* min_hits_by_q, const int32_t* cutoffs, int64_t nfrag, DevParams P,
+                                                           uint32_t* out_count, const uint64_t* out_off, wfm_l1_candidate_t* out) {
+  const int64_t f = blockIdx.x;
+  const int lane = (int)threadIdx.x;
+  if (f >= nfrag) return;
+  int emitted = 0;
+  const int qs = qcount[f];
+  if (qs > 0 && q_active[f]) {
+    const uint64_t* k = keys + seg_off[f];
+    const int64_t n = seg_cnt[f];
+    const int min_hits = (q_len[f] == P.cached_segment_length) ? P.min_hits_cached : min_hits_by_q[min(qs, P.sketch_size)];
+    wfm_l1_candidate_t* emit = out ? out + out_off[f] : nullptr;
+    Cand back{0, 0, 0, 0};
+    bool have_back = false;
+    int64_t b = 0;
+    while (b < n) {
+      int64_t e = n;
+      if (P.skip_prefix) {  // the run of keys of one reference group (doL1Mapping's group loop, computeMap.hpp:945-984)
+        const int g = ref_group[key_seq(k[b])];
+        for (int64_t base = b; base < n; base += 64) {
+          const int64_t gi = base + lane;
+          const bool diff = gi < n && ref_group[key_seq(k[gi])] != g;
+          const unsigned long long m = __ballot(diff);
+          if (m) { e = base + __builtin_ctzll(m); break; }
+        }
+      }
+      emitted = l1_group_wave(k + b, e - b, qs, min_hits, P, cutoffs, emit, emitted, (int32_t)f, back, have_back, lane);
+      b = e;
+    }
+    if (have_back) {
+      if (emit && lane == 0) { wfm_l1_candidate_t o; o.seqId = back.seq; o.frag = (int32_t)f; o.rangeStartPos = back.start; o.rangeEndPos = back.end; o.intersectionSize = back.isect; o.pad_ = 0; emit[emitted] = o; }
+      ++emitted;
+    }
+  }
+  if (!out && lane == 0) out_count[f] = (uint32_t)emitted;
+}
+
 template <typename T>
 int exclusive_scan_u64(wfm_handle_t* h, Scratch& sc, const T* in, uint64_t* out, int64_t n, hipStream_t st) {
   size_t tmp = 0;
@@ -270,8 +458,11 @@ int map_l1_device(wfm_handle_t* h, MapScratch& sc, const wfm_index_t* ix, const 
     ALLOC(d_tmp, tmp);
     HIPCHK(h, rocprim::segmented_radix_sort_keys(d_tmp, tmp, d_keys, d_keys2, (size_t)total, (unsigned)nfrag, beg_it, end_it, 0, 64, st));
   }
-  const dim3 g((unsigned)((nfrag + 63) / 64)), b(64);
-  hipLaunchKernelGGL(l1_sweep_kernel, g, b, 0, st, d_keys2, d_off, d_cnt, d_qcount, d_qlen, d_act, d_group, d_minhits, d_cut, nfrag, P,
+  // one wave per fragment (WFM_L1_WAVE=0: the one-lane-per-fragment form, kept for A/B runs and as a cross-check in the tests)
+  const bool wave_form = !(getenv("WFM_L1_WAVE") && atoi(getenv("WFM_L1_WAVE")) == 0);
+  const dim3 g(wave_form ? (unsigned)nfrag : (unsigned)((nfrag + 63) / 64)), b(64);
+  auto sweep = wave_form ? l1_sweep_wave_kernel : l1_sweep_kernel;
+  hipLaunchKernelGGL(sweep, g, b, 0, st, d_keys2, d_off, d_cnt, d_qcount, d_qlen, d_act, d_group, d_minhits, d_cut, nfrag, P,
                      d_ocount, (const uint64_t*)nullptr, (wfm_l1_candidate_t*)nullptr);
   rc = exclusive_scan_u64<uint32_t>(h, sc, d_ocount, d_ooff, nfrag, st);
   if (rc != WFM_OK) return rc;
@@ -283,7 +474,7 @@ int map_l1_device(wfm_handle_t* h, MapScratch& sc, const wfm_index_t* ix, const 
   if (n_out > 0) {
     wfm_l1_candidate_t* d_out = nullptr;
     ALLOC(d_out, n_out);
-    hipLaunchKernelGGL(l1_sweep_kernel, g, b, 0, st, d_keys2, d_off, d_cnt, d_qcount, d_qlen, d_act, d_group, d_minhits, d_cut, nfrag, P,
+    hipLaunchKernelGGL(sweep, g, b, 0, st, d_keys2, d_off, d_cnt, d_qcount, d_qlen, d_act, d_group, d_minhits, d_cut, nfrag, P,
                        d_ocount, d_ooff, d_out);
     HIPCHK(h, hipGetLastError());
     *d_cands = d_out;
