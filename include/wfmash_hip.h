@@ -125,7 +125,7 @@ typedef struct {
   double   ms_base_busy;     /* as ms_tile_busy, for the wfa_base_kernel launches */
   double   ms_any_busy;      /* time during which any of the three kernels was running */
   uint32_t p2_launches, p2_jobs; /* phase 2 from rows computed ahead (tile kernel + wfa_p2_* kernels): launch sets, jobs */
-  uint32_t p2_more, pad2_;   /* of those jobs, the ones wfa_bp_kernel had to finish step by step */
+  uint32_t p2_more, p2_again; /* of those jobs, the ones wfa_bp_kernel had to finish step by step; further rounds of rows computed ahead (jobs x rounds) */
 } wfm_stats_t;
 
 int  wfm_device_count(void);   /* usable HIP devices of this node (0 without a GPU) */

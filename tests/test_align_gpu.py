@@ -456,3 +456,35 @@ def test_exact_bounds_on_small_batches_with_reused_rings(oracle):
                 assert r.status == 0 and r.score == e["score"] and r.ops == e["ops"].encode(), (rep, j)
     finally:
         h.close()
+
+
+def test_phase2_walks_longer_than_the_rows_computed_ahead(gpu, oracle, monkeypatch):
+    """Unrelated or rearranged sequences: the antidiagonals of the two directions touch long before any two cells share a
+    diagonal, so the overlap loop runs for hundreds of tests -- more than the 2 x 48 the rows computed ahead cover.  Such jobs
+    go further rounds of rows computed ahead (the breakpoint so far carried along) instead of the step-by-step kernel; the
+    result is the oracle's either way, whatever the number of rounds allowed."""
+    items = []
+    for i, (a, b) in enumerate([(3000, 3000), (3000, 1000), (5000, 4200), (2500, 2600), (6000, 6000)]):
+        items.append((synth.random_dna(900 + i, a), synth.random_dna(950 + i, b)))
+    u, v, w = synth.random_dna(31, 4000), synth.random_dna(32, 3000), synth.random_dna(33, 4000)
+    items.append((u + v + w, u + w + synth.mutate(v, 0.02, 5)))          # a block moved to the end
+    items.append((u + v + v + w, synth.mutate(u + v + w, 0.03, 6)))       # a duplication on one side
+    items.append((u + synth.random_dna(34, 2000) + w, u + synth.random_dna(35, 2500) + w))  # unrelated middles
+    exp = [oracle.align_biwfa(p, t, None) for p, t in items]
+    seen = []
+    for rounds in (None, "1", "2"):
+        if rounds is None:
+            monkeypatch.delenv("WFM_P2_ROUNDS", raising=False)
+        else:
+            monkeypatch.setenv("WFM_P2_ROUNDS", rounds)
+        h = capi.Handle(0)
+        try:
+            res = h.align(items)
+            st = h.stats()
+        finally:
+            h.close()
+        for (rc, ops, sc, _), r in zip(exp, res):
+            assert rc == 0 and r.status == 0 and r.score == sc and r.ops == ops
+        seen.append((st.p2_again, st.p2_more))
+    assert seen[0][0] > 0, seen          # further rounds were taken
+    assert seen[1][0] == 0 and seen[1][1] > 0, seen  # one round only: the step kernel finishes those jobs

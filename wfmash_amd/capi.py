@@ -63,7 +63,7 @@ class Stats(C.Structure):
                 ("ms_tile_busy", C.c_double), ("streams", C.c_uint32), ("pad_", C.c_uint32),
                 ("cells_tile_unique", C.c_uint64), ("ms_bp_busy", C.c_double), ("ms_base_busy", C.c_double),
                 ("ms_any_busy", C.c_double), ("p2_launches", C.c_uint32), ("p2_jobs", C.c_uint32), ("p2_more", C.c_uint32),
-                ("pad2_", C.c_uint32)]
+                ("p2_again", C.c_uint32)]
 
 
 class Minmer(C.Structure):

@@ -23,6 +23,7 @@ constexpr int WFM_DEV_UNREACHABLE = -300;
 constexpr int WFM_DEV_OVERFLOW = -2;  // base job exceeded its score budget (smax)
 constexpr int WFM_DEV_BAND = -4;      // bialign job ran out of its diagonal band (BpJob::band)
 constexpr int SUB_NONE = 1 << 29;     // "no upper bound of the score is known" (BpJob::sub, TileJob::sub, P2Job::sub)
+constexpr int WFM_DEV_P2_NOTHING = -6; // phase 2 ended without improving on the breakpoint it was handed (BpJob / P2Job::best0): that one stands
 constexpr int WFM_DEV_P2_MORE = -5;   // phase 2 did not end within the P2K rows computed ahead: the step kernel takes the job
 
 struct DevPen { int x, o1, e1, o2, e2; };
@@ -45,7 +46,8 @@ struct BpJob {
   int32_t resume_sr;
   int32_t last_fwd;                    // with resume_sr >= 0: 1 if the forward step was the last one taken
   int32_t sub;                         // upper bound of the job's score (SUB_NONE: none): rows only hold |k - (tl - pl)| <= sub - s
-  int32_t pad_;
+  int32_t best0;                       // > 0: phase 2 resumes with a breakpoint of this score in hand (found by earlier rounds of rows
+                                       // computed ahead); only a better one is reported, else WFM_DEV_P2_NOTHING
 };
 
 // ---- time-tiled phase 1 (wfa_tile_kernel) ----
@@ -100,7 +102,7 @@ struct P2Job {
   int32_t w2, koff2;                   // P2 geometry: column = k + koff2
   int32_t pl, tl;
   int32_t sf, sr, last_fwd;            // state at the meeting point
-  int32_t sub, pad_;                   // as BpJob::sub
+  int32_t sub, best0;                  // as BpJob::sub, BpJob::best0
   int32_t nblk;                        // 64-diagonal blocks of a row: block of diagonal k = (k + koff2) >> 6
   int64_t bm_off;                      // int32 element offset of the job's block maxima [dir][P2ROWS][comp][nblk]
 };
@@ -160,6 +162,9 @@ void launch_tile_reg(const uint8_t* seq, int32_t* ring, const TileJob* jobs, con
 // phase-2 rows of the jobs in mode 4 (T = P2K scores, two diagonals per thread), their per-row maxima into p2max
 void launch_tile_p2(const uint8_t* seq, int32_t* ring, const TileJob* jobs, const TileTask* tasks, int ntasks, int threads,
                     int32_t* p2, bool cut, hipStream_t st);
+// The state after 2 * P2K tests as a snapshot: the last RING rows of both directions, out of the P2 rows into the job's ring
+// (jobs whose walk ran out of rows go another round from there)
+void launch_p2_to_ring(int32_t* ring, const int32_t* p2, const P2Job* jobs, int njobs, hipStream_t st);
 void launch_p2_blockmax(const int32_t* ring, const int32_t* p2, const P2Job* jobs, int32_t* bmax, int32_t* p2max, int njobs, hipStream_t st);
 void launch_p2_overlap(const int32_t* ring, const int32_t* p2, const P2Job* jobs, const int32_t* p2max, const int32_t* bmax, int32_t* pbmax,
                        BpResult* res, int njobs, int threads, int max_nblk, DevPen pen, int scope, hipStream_t st);

@@ -463,7 +463,7 @@ __global__ __launch_bounds__(1024) void wfa_bp_kernel(const uint8_t* __restrict_
   // With a bound of the job's score the loop starts as if a breakpoint of score bound + 1 were in hand: pairs that cannot do
   // better are never looked at, and the loop ends where none can follow.  The bound of a child is exact, so its breakpoint
   // is below it; a root whose guess was too small ends here without one and is run again (WFM_DEV_BAND).
-  const int best0 = J.sub < SUB_NONE ? J.sub + 1 : INT32_MAX;
+  const int best0 = min(J.sub < SUB_NONE ? J.sub + 1 : INT32_MAX, J.best0 > 0 ? J.best0 : INT32_MAX);  // (or the breakpoint earlier rounds of phase 2 found)
   int best = best0;
   if (tid == 0) s_bp[7] = 0;  // a real breakpoint has been taken
   const long long t_mid = wall_clock64();
@@ -557,7 +557,7 @@ __global__ __launch_bounds__(1024) void wfa_bp_kernel(const uint8_t* __restrict_
     BpResult r;
     r.status = status;
     if (status == 0 && best == INT32_MAX) r.status = WFM_DEV_UNREACHABLE;
-    if (status == 0 && best0 != INT32_MAX && !s_bp[7]) r.status = WFM_DEV_BAND;  // nothing within the bound
+    if (status == 0 && best0 != INT32_MAX && !s_bp[7]) r.status = J.best0 > 0 ? WFM_DEV_P2_NOTHING : WFM_DEV_BAND;  // nothing within the bound / nothing better
     if (status == WFM_DEV_BAND) r.status = WFM_DEV_BAND;  // a breakpoint found so far may not be the best one
     r.score = best; r.score_fwd = s_bp[1]; r.score_rev = s_bp[2]; r.k_fwd = s_bp[3]; r.off_fwd = s_bp[4]; r.comp = s_bp[5];
     r.steps = sf + sr;

@@ -624,8 +624,14 @@ int run_tiled_phase(wfm_handle* h, wfm_seqset* S, const DevPen& dp, int scope, c
 // step-by-step kernel: P2K more rows of both directions by the tile kernel, all rows kept (P2Job in wfa_device.h), then
 // the reference's loop with only the tests left in it (wfa_p2_overlap_kernel).  cand: indices into jobs; res[q] is filled for every
 // candidate, with status WFM_DEV_P2_MORE where the loop had not ended after 2 * P2K tests (wfa_bp_kernel takes those).
-int run_p2_phase(wfm_handle* h, wfm_seqset* S, const DevPen& dp, int scope, const TileCfg& cfg, const std::vector<BpJob>& jobs,
-                 const std::vector<int>& cand, const std::vector<int64_t>& ring_other, std::vector<BpResult>& res, double& ms_out) {
+// A job whose walk ran out of rows goes another round when `may_continue`: its last RING rows of both directions are copied
+// from the P2 rows into its ring (wfa_p2_to_ring_kernel) -- the state the sequential loop is in after 2 * P2K tests -- the
+// breakpoint found so far is kept in carry[] and handed on as BpJob::best0, and the job's position in cand is appended to
+// `again`.  (On divergent records a few jobs per level take 120 - 230 tests from the first touch of the wavefronts to a shared
+// diagonal; finishing them step by step in wfa_bp_kernel was half of C2's device time.)
+int run_p2_phase(wfm_handle* h, wfm_seqset* S, const DevPen& dp, int scope, const TileCfg& cfg, std::vector<BpJob>& jobs,
+                 const std::vector<int>& cand, const std::vector<int64_t>& ring_other, std::vector<BpResult>& res, double& ms_out,
+                 std::vector<BpResult>& carry, std::vector<char>& has_carry, bool may_continue, std::vector<int>& again) {
   if (cand.empty()) return WFM_OK;
   const int core = cfg.Wt - 2 * P2K;
   size_t i0 = 0;
@@ -659,7 +665,7 @@ int run_p2_phase(wfm_handle* h, wfm_seqset* S, const DevPen& dp, int scope, cons
       t.p2_off = (int64_t)elems; t.w2 = (int32_t)w2; t.koff2 = koff2; t.sub = j.sub;
       P2Job q{};
       q.ring_in = j.ring_off; q.p2_off = (int64_t)elems; q.width = j.width; q.koff = j.koff; q.w2 = (int32_t)w2; q.koff2 = koff2;
-      q.pl = j.pl; q.tl = j.tl; q.sf = j.resume_s; q.sr = j.resume_sr; q.last_fwd = j.last_fwd; q.sub = j.sub;
+      q.pl = j.pl; q.tl = j.tl; q.sf = j.resume_s; q.sr = j.resume_sr; q.last_fwd = j.last_fwd; q.sub = j.sub; q.best0 = j.best0;
       q.nblk = (int32_t)nblk; q.bm_off = (int64_t)bm_elems;
       bm_elems += need_bm;
       elems += need;
@@ -737,6 +743,28 @@ int run_p2_phase(wfm_handle* h, wfm_seqset* S, const DevPen& dp, int scope, cons
       for (const BpResult& r : got) { more += r.status == WFM_DEV_P2_MORE; tk += r.ticks_p2; tc += r.ticks_p1; rd += r.pad_; tkmax = std::max(tkmax, r.ticks_p2); rdmax = std::max(rdmax, r.pad_); }
       fprintf(stderr, "[wfm] phase 2 from rows computed ahead: %zu jobs, widest %zu columns, %zu tiles of %d threads, %.3f ms, %d left to the step kernel; walk per job: %.1f rounds (max %d), %.0f us (max %.0f), of which cells stage %.0f us\n",
               n, maxw2, tasks.size(), threads_c, ms, more, rd / n, rdmax, tk / n / 100.0, tkmax / 100.0, tc / n / 100.0);
+    }
+    // another round for the jobs whose walk ran out of rows (while their rings have room for its rows)
+    std::vector<P2Job> mj;
+    for (size_t q = 0; q < n; ++q) {
+      const size_t jq = (size_t)cand[i0 + q];
+      BpJob& j = jobs[jq];
+      if (got[q].status == WFM_DEV_P2_NOTHING) { got[q] = carry[jq]; continue; }  // nothing better than what an earlier round found
+      if (got[q].status != WFM_DEV_P2_MORE) continue;
+      if (got[q].comp >= 0) {  // a breakpoint so far (better than the one handed in, if any)
+        carry[jq] = got[q]; carry[jq].status = 0; has_carry[jq] = 1;
+        j.best0 = got[q].score;
+      }
+      if (!may_continue || (j.band > 0 && std::max(j.resume_s, j.resume_sr) + 2 * P2K + 2 > j.band)) continue;  // wfa_bp_kernel goes on from here
+      mj.push_back(pj[q]);
+      j.resume_s += P2K; j.resume_sr += P2K;  // 2 * P2K tests: both directions P2K rows further, the same one stepped last
+      again.push_back((int)(i0 + q));
+    }
+    if (!mj.empty()) {
+      HIPCHK(h, hipMemcpyAsync(h->p2jobs.p, mj.data(), mj.size() * sizeof(P2Job), hipMemcpyHostToDevice, h->stream));
+      launch_p2_to_ring(h->ring.p, h->p2rows.p, h->p2jobs.p, (int)mj.size(), h->stream);
+      HIPCHK(h, hipGetLastError());
+      HIPCHK(h, hipStreamSynchronize(h->stream));  // (mj is read by the copy above)
     }
     for (size_t q = 0; q < n; ++q) res[(size_t)cand[i0 + q]] = got[q];
     i0 = i;
@@ -927,7 +955,7 @@ int align_resident_impl(wfm_handle* h, const wfm_penalties_t* pen, wfm_seqset* S
         // records and their children): for a balanced problem it starts to bind where the wavefronts meet, and costs the
         // tile kernel its bookkeeping all the way there
         j.sub = (nd.sub != SUB_NONE && (int64_t)std::abs(nd.tl - nd.pl) * 8 >= (int64_t)nd.sub) ? nd.sub : SUB_NONE;
-        j.pad_ = 0;
+        j.best0 = 0;
         band_jobs += band > 0;
         if (tile_it) { tiled.push_back((int)jobs.size()); ring2.push_back((int64_t)(ring_elems + need / 2)); }
         node_of.push_back((int32_t)i);
@@ -958,6 +986,9 @@ int align_resident_impl(wfm_handle* h, const wfm_penalties_t* pen, wfm_seqset* S
         res.assign(jobs.size(), BpResult{});
         // ---- phase 2 of the jobs the tile phase left exactly at their meeting point: rows computed ahead + scan + replay
         std::vector<int> rest;  // jobs for the step kernel: not tiled, not exact, or not finished by the rows computed ahead
+        std::vector<BpResult> carry;  // breakpoints found by rounds of phase 2 that did not end the walk
+        std::vector<char> has_carry;
+        std::vector<int> more_set;
         {
           static const bool p2_on = !(getenv("WFM_P2") && atoi(getenv("WFM_P2")) == 0);
           std::vector<int> cand;
@@ -969,12 +1000,25 @@ int align_resident_impl(wfm_handle* h, const wfm_penalties_t* pen, wfm_seqset* S
               if (j.resume_s >= 0 && j.resume_sr >= 0) { cand.push_back(tiled[q]); other.push_back(ring2[q]); is_cand[(size_t)tiled[q]] = 1; }
             }
           double pms = 0;
-          rc = run_p2_phase(h, S, dp, scope, tcfg, jobs, cand, other, res, pms);
-          if (rc != WFM_OK) return rc;
+          carry.assign(jobs.size(), BpResult{});
+          has_carry.assign(jobs.size(), 0);
+          const int p2_rounds = getenv("WFM_P2_ROUNDS") ? std::max(1, atoi(getenv("WFM_P2_ROUNDS"))) : 64;
+          std::vector<int> cand_r = cand, again;
+          std::vector<int64_t> other_r = other;
+          for (int round = 1; !cand_r.empty(); ++round) {
+            again.clear();
+            rc = run_p2_phase(h, S, dp, scope, tcfg, jobs, cand_r, other_r, res, pms, carry, has_carry, round < p2_rounds, again);
+            if (rc != WFM_OK) return rc;
+            std::vector<int> c2; std::vector<int64_t> o2;
+            for (int a : again) { c2.push_back(cand_r[(size_t)a]); o2.push_back(other_r[(size_t)a]); }
+            h->stats.p2_again += (uint32_t)again.size();
+            cand_r.swap(c2); other_r.swap(o2);
+          }
           tm.bp_ms += pms;
           for (size_t q = 0; q < jobs.size(); ++q)
-            if (!is_cand[q] || res[q].status == WFM_DEV_P2_MORE) { rest.push_back((int)q); h->stats.p2_more += is_cand[q]; }
+            if (!is_cand[q] || res[q].status == WFM_DEV_P2_MORE) { rest.push_back((int)q); h->stats.p2_more += is_cand[q]; if (is_cand[q]) more_set.push_back((int)q); }
         }
+        auto is_more = [&](int q) { return std::find(more_set.begin(), more_set.end(), q) != more_set.end(); };
         if (!rest.empty()) {
           // workgroup size: wide wavefronts want all 16 waves of a CU
           int threads = 1024;
@@ -999,12 +1043,30 @@ int align_resident_impl(wfm_handle* h, const wfm_penalties_t* pen, wfm_seqset* S
             h->bp_iv.emplace_back(t0, t0 + ms);
           }
           h->stats.bp_launches++;
-          for (size_t q = 0; q < rest.size(); ++q) res[(size_t)rest[q]] = rr[q];
+          for (size_t q = 0; q < rest.size(); ++q) {
+            if (rr[q].status == WFM_DEV_P2_NOTHING) {  // (only jobs that carry a breakpoint are handed a best0)
+              const uint64_t c = rr[q].cells; const int32_t st = rr[q].steps;
+              rr[q] = carry[(size_t)rest[q]]; rr[q].cells = c; rr[q].steps = st;
+            }
+            res[(size_t)rest[q]] = rr[q];
+          }
           if (getenv("WFM_DEBUG")) {
             uint64_t c = 0; double t1 = 0, t2 = 0; int64_t st1 = 0, st = 0; uint32_t m1 = 0, m2 = 0;
             for (const BpResult& r : rr) { c += r.cells; t1 += r.ticks_p1; t2 += r.ticks_p2; st1 += r.steps_p1; st += r.steps; m1 = std::max(m1, r.ticks_p1); m2 = std::max(m2, r.ticks_p2); }
             fprintf(stderr, "[wfm] level %u: %zu bp jobs (step kernel), %d thr, %.3f ms, cells %.3e, avg steps p1 %.0f p2 %.0f, avg ms p1 %.3f p2 %.3f, max ms p1 %.3f p2 %.3f\n", level, rr.size(), threads, ms,
                     (double)c, (double)st1 / rr.size(), (double)(st - st1) / rr.size(), t1 / rr.size() / 1e5, t2 / rr.size() / 1e5, m1 / 1e5, m2 / 1e5);
+            if (atoi(getenv("WFM_DEBUG")) > 1) {  // the slowest three
+              std::vector<size_t> ord(rr.size());
+              for (size_t q = 0; q < ord.size(); ++q) ord[q] = q;
+              std::sort(ord.begin(), ord.end(), [&](size_t a, size_t b) { return rr[a].ticks_p1 + rr[a].ticks_p2 > rr[b].ticks_p1 + rr[b].ticks_p2; });
+              for (size_t q = 0; q < std::min<size_t>(3, ord.size()); ++q) {
+                const BpResult& r = rr[ord[q]];
+                const BpJob& j = rj[ord[q]];
+                fprintf(stderr, "[wfm]   slow step-kernel job: pl %d tl %d width %d band %d sub %d resume %d/%d (%s), status %d score %d = %d + %d, steps p1 %d p2 %d, ms p1 %.3f p2 %.3f\n", j.pl, j.tl, j.width,
+                        j.band, j.sub == SUB_NONE ? -1 : j.sub, j.resume_s, j.resume_sr, is_more(rest[ord[q]]) ? "phase-2 walk ran out of rows" : (j.resume_sr >= 0 ? "exact" : "not exact"), r.status,
+                        r.score, r.score_fwd, r.score_rev, r.steps_p1, r.steps - r.steps_p1, r.ticks_p1 / 1e5, r.ticks_p2 / 1e5);
+              }
+            }
           }
         }
         h->stats.bp_jobs += (uint32_t)jobs.size();

@@ -938,7 +938,7 @@ __global__ __launch_bounds__(1024) void wfa_p2_overlap_kernel(const int32_t* __r
   for (int i = tid; i < 2 * P2ROWS * 5; i += blockDim.x) ((int*)s_rmax)[i] = p2max[(int64_t)job * 2 * P2ROWS * 5 + i];
   if (tid < 8) s_bp[tid] = 0;
   // (with a bound of the job's score the walk starts as if a breakpoint of score bound + 1 were in hand: see wfa_bp_kernel)
-  if (tid == 0) { s_state[0] = J.sf; s_state[1] = J.sr; s_state[2] = J.last_fwd; s_state[3] = J.sub < SUB_NONE ? J.sub + 1 : INT32_MAX; s_state[4] = 0; s_state[5] = 0; s_cells = 0; }
+  if (tid == 0) { s_state[0] = J.sf; s_state[1] = J.sr; s_state[2] = J.last_fwd; s_state[3] = min(J.sub < SUB_NONE ? J.sub + 1 : INT32_MAX, J.best0 > 0 ? J.best0 : INT32_MAX); s_state[4] = 0; s_state[5] = 0; s_cells = 0; }
   __syncthreads();
   const int pl = J.pl, tl = J.tl, kinv = tl - pl;
   const Rng RG = make_rng(pl, tl, J.sub);
@@ -1160,8 +1160,8 @@ __global__ __launch_bounds__(1024) void wfa_p2_overlap_kernel(const int32_t* __r
   if (tid == 0) {
     BpResult r;
     r.status = s_state[4] == 2 ? WFM_DEV_P2_MORE : 0;
-    if (r.status == 0 && !s_bp[7]) r.status = J.sub < SUB_NONE ? WFM_DEV_BAND : WFM_DEV_UNREACHABLE;  // the walk ended without a breakpoint
-    r.score = s_state[3]; r.score_fwd = s_bp[1]; r.score_rev = s_bp[2]; r.k_fwd = s_bp[3]; r.off_fwd = s_bp[4]; r.comp = s_bp[5];
+    if (r.status == 0 && !s_bp[7]) r.status = J.best0 > 0 ? WFM_DEV_P2_NOTHING : (J.sub < SUB_NONE ? WFM_DEV_BAND : WFM_DEV_UNREACHABLE);  // the walk ended without a (better) breakpoint
+    r.score = s_state[3]; r.score_fwd = s_bp[1]; r.score_rev = s_bp[2]; r.k_fwd = s_bp[3]; r.off_fwd = s_bp[4]; r.comp = s_bp[7] ? s_bp[5] : -1;
     r.steps = s_state[0] + s_state[1];
     r.cells = s_cells;
     r.steps_p1 = J.sf + J.sr;
@@ -1328,6 +1328,25 @@ void launch_tile_p2(const uint8_t* seq, int32_t* ring, const TileJob* jobs, cons
                               (int32_t*)nullptr, P2K, p2, (int32_t*)nullptr);
   else hipLaunchKernelGGL((wfa_tile_reg_kernel<2, 1024, 5, 10, 25, 2, 1, true, false>), dim3(ntasks), dim3(threads), lds, st, seq, ring, jobs, tasks,
                           (int32_t*)nullptr, P2K, p2, (int32_t*)nullptr);
+}
+// One workgroup per (job, direction, component, ring row): row s = sd + P2K - r of the P2 rows into slot s mod RING of the ring;
+// what lies outside the row's own range is NULL (the slot held an older, wider or narrower, row).
+__global__ __launch_bounds__(256) void wfa_p2_to_ring_kernel(int32_t* __restrict__ ring, const int32_t* __restrict__ p2, const P2Job* __restrict__ jobs) {
+  const int job = blockIdx.x / (2 * 5 * RING), rest = blockIdx.x % (2 * 5 * RING), d = rest / (5 * RING), cc = (rest / RING) % 5, r = rest % RING;
+  const P2Job J = jobs[job];
+  const int sd = d == 0 ? J.sf : J.sr, s = sd + P2K - r;
+  const Rng RG = make_rng(J.pl, J.tl, J.sub);
+  const int lo = rng_lo(RG, s), hi = rng_hi(RG, s);
+  const int32_t* src = p2 + J.p2_off + J.koff2 + ((int64_t)((d * 5 + cc) * P2K + (s - sd - 1))) * J.w2;
+  int32_t* dst = ring + J.ring_in + ((int64_t)((d * 5 + cc) * RING + (s & RMASK))) * J.width;
+  for (int c = threadIdx.x; c < J.width; c += blockDim.x) {
+    const int k = c - J.koff;
+    dst[c] = (k >= lo && k <= hi) ? src[k] : WF_NULL;
+  }
+}
+void launch_p2_to_ring(int32_t* ring, const int32_t* p2, const P2Job* jobs, int njobs, hipStream_t st) {
+  static_assert(P2K >= RING, "the snapshot after a round of phase 2 is taken from the P2 rows alone");
+  hipLaunchKernelGGL(wfa_p2_to_ring_kernel, dim3((unsigned)njobs * 2 * 5 * RING), dim3(256), 0, st, ring, p2, jobs);
 }
 void launch_p2_blockmax(const int32_t* ring, const int32_t* p2, const P2Job* jobs, int32_t* bmax, int32_t* p2max, int njobs, hipStream_t st) {
   hipLaunchKernelGGL(wfa_p2_blockmax_kernel, dim3(njobs * 2 * P2ROWS), dim3(256), 0, st, ring, p2, jobs, bmax, p2max);
