@@ -179,6 +179,11 @@ int  wfm_align_resident(wfm_handle_t* h, const wfm_penalties_t* pen, wfm_seqset_
 int  wfm_align_resident_rle(wfm_handle_t* h, const wfm_penalties_t* pen, wfm_seqset_t* s,
                             wfm_result_t* out, uint32_t** runs, size_t* n_runs_total);
 
+/* Device blocks of the map path are kept in a per-device cache between calls (a first hipMalloc of a gigabyte costs 30 - 40 ms
+ * on this driver, a hipFree of gigabytes stalls the next allocation; wfmash_amd/csrc/dev_cache.h).  This hands every cached
+ * block back to the driver and returns the bytes released; WFM_DEV_CACHE_GB bounds what the cache may hold (default 96). */
+size_t wfm_trim_device_cache(void);
+
 int  wfm_get_stats(const wfm_handle_t* h, wfm_stats_t* out);
 /* The intervals during which a kernel of the handle's last align call was running, merged, as (start, end) pairs in ms on a
  * clock all handles of one device share: a caller that keeps several calls in flight on handles of their own (the align

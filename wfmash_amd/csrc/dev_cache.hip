@@ -1,0 +1,114 @@
+// dev_cache.hip -- see dev_cache.h
+#include "dev_cache.h"
+
+#include <cstdlib>
+#include <map>
+#include <mutex>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/wfmash_hip.h"
+
+namespace {
+struct Live { size_t size; int dev; };
+struct Cache {
+  std::mutex mu;
+  std::unordered_map<void*, Live> live;                          // every block handed out or cached
+  std::map<std::pair<int, size_t>, std::vector<void*>> free_by;  // (device, class size) -> cached blocks
+  size_t cached = 0;
+};
+Cache& cache() { static Cache* c = new Cache; return *c; }  // (never destroyed: handles may outlive static destructors)
+
+size_t class_of(size_t bytes) {
+  if (bytes < 4096) return 4096;
+  int lg = 63 - __builtin_clzll((unsigned long long)bytes);
+  const size_t step = (size_t)1 << (lg > 3 ? lg - 3 : 0);
+  return (bytes + step - 1) / step * step;
+}
+size_t limit_bytes() {
+  static const size_t v = getenv("WFM_DEV_CACHE_GB") ? (size_t)atoll(getenv("WFM_DEV_CACHE_GB")) << 30 : (size_t)96 << 30;
+  return v;
+}
+size_t trim_locked(Cache& c, std::vector<void*>& out) {
+  size_t bytes = 0;
+  for (auto& kv : c.free_by)
+    for (void* p : kv.second) { out.push_back(p); bytes += kv.first.second; c.live.erase(p); }
+  c.free_by.clear();
+  c.cached = 0;
+  return bytes;
+}
+void put(void* p) {
+  Cache& c = cache();
+  std::vector<void*> evict;
+  {
+    std::lock_guard<std::mutex> lk(c.mu);
+    auto it = c.live.find(p);
+    if (it == c.live.end()) { evict.push_back(p); }  // not ours (should not happen): plain hipFree
+    else {
+      c.free_by[{it->second.dev, it->second.size}].push_back(p);
+      c.cached += it->second.size;
+      if (c.cached > limit_bytes()) trim_locked(c, evict);
+    }
+  }
+  for (void* q : evict) (void)hipFree(q);
+}
+}  // namespace
+
+hipError_t wfm_dmalloc(void** p, size_t bytes) {
+  Cache& c = cache();
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  const size_t cls = class_of(bytes);
+  {
+    std::lock_guard<std::mutex> lk(c.mu);
+    auto it = c.free_by.find({dev, cls});
+    if (it != c.free_by.end() && !it->second.empty()) {
+      *p = it->second.back();
+      it->second.pop_back();
+      c.cached -= cls;
+      return hipSuccess;
+    }
+  }
+  e = hipMalloc(p, cls);
+  if (e != hipSuccess) {  // give everything cached back and try once more
+    (void)hipGetLastError();
+    (void)wfm_dcache_trim();
+    e = hipMalloc(p, cls);
+    if (e != hipSuccess) return e;
+  }
+  std::lock_guard<std::mutex> lk(c.mu);
+  c.live[*p] = Live{cls, dev};
+  return hipSuccess;
+}
+
+void wfm_dfree_nosync(void* p) { if (p) put(p); }
+void wfm_dfree(void* p) {
+  if (!p) return;
+  int dev = -1, cur = 0;
+  {
+    Cache& c = cache();
+    std::lock_guard<std::mutex> lk(c.mu);
+    auto it = c.live.find(p);
+    if (it != c.live.end()) dev = it->second.dev;
+  }
+  (void)hipGetDevice(&cur);
+  if (dev >= 0 && dev != cur) (void)hipSetDevice(dev);
+  (void)hipDeviceSynchronize();
+  if (dev >= 0 && dev != cur) (void)hipSetDevice(cur);
+  put(p);
+}
+
+size_t wfm_dcache_trim(void) {
+  Cache& c = cache();
+  std::vector<void*> out;
+  size_t bytes;
+  {
+    std::lock_guard<std::mutex> lk(c.mu);
+    bytes = trim_locked(c, out);
+  }
+  for (void* q : out) (void)hipFree(q);
+  return bytes;
+}
+
+extern "C" size_t wfm_trim_device_cache(void) { return wfm_dcache_trim(); }

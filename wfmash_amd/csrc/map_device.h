@@ -12,6 +12,7 @@
 
 #include "../../include/wfmash_hip.h"
 #include "wfa_handle.h"
+#include "dev_cache.h"
 
 // device allocations that live until the owning call returns
 struct MapScratch {
@@ -19,9 +20,9 @@ struct MapScratch {
   MapScratch() = default;
   MapScratch(const MapScratch&) = delete;
   MapScratch& operator=(const MapScratch&) = delete;
-  ~MapScratch() { for (void* q : p) if (q) (void)hipFree(q); }
+  ~MapScratch() { if (!p.empty()) (void)hipDeviceSynchronize(); for (void* q : p) if (q) wfm_dfree_nosync(q); }
   template <typename T> hipError_t alloc(T** out, size_t n) {
-    hipError_t e = hipMalloc((void**)out, std::max<size_t>(n, 1) * sizeof(T));
+    hipError_t e = wfm_dmalloc((void**)out, std::max<size_t>(n, 1) * sizeof(T));
     if (e == hipSuccess) p.push_back(*out);
     return e;
   }

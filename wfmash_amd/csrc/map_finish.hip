@@ -24,6 +24,7 @@
 // The CPU suite holds a host restatement of these steps (map_sortlike_model) against std::sort, the GPU suite holds the
 // kernels against the host's finish_records (tests/test_minmers.py).
 #include <hip/hip_runtime.h>
+#include "dev_cache.h"
 #include <stdint.h>
 
 #include <algorithm>
@@ -383,10 +384,10 @@ __global__ void finish_emit_kernel(const wfm_minmer_t* R, const uint32_t* order,
 
 int grow(MapFinishWork::Buf& b, size_t bytes) {
   if (b.bytes >= bytes && b.p) return WFM_OK;
-  if (b.p) (void)hipFree(b.p);
+  if (b.p) (void)wfm_dfree(b.p);
   b.p = nullptr; b.bytes = 0;
   const size_t want = bytes + bytes / 4 + 256;
-  if (hipMalloc(&b.p, want) != hipSuccess) return WFM_E_NOMEM;
+  if (wfm_dmalloc(&b.p, want) != hipSuccess) return WFM_E_NOMEM;
   b.bytes = want;
   return WFM_OK;
 }
@@ -515,7 +516,7 @@ void map_finish_work_free(MapFinishWork* wk) {
   if (!wk) return;
   for (MapFinishWork::Buf* b : {&wk->ns, &wk->np, &wk->os, &wk->op, &wk->R, &wk->key, &wk->idx, &wk->key2, &wk->idx2, &wk->A, &wk->B, &wk->seg[0], &wk->seg[1], &wk->seg[2],
                                 &wk->seg[3], &wk->small_, &wk->heap, &wk->counts, &wk->tiles, &wk->tile_cnt, &wk->tile0, &wk->info, &wk->tmp, &wk->out}) {
-    if (b->p) (void)hipFree(b->p);
+    if (b->p) (void)wfm_dfree(b->p);
     b->p = nullptr; b->bytes = 0;
   }
 }
@@ -640,8 +641,8 @@ extern "C" int64_t wfm_finish_records(wfm_handle_t* h, const wfm_minmer_t* raw, 
   if (!h || n < 0 || (n && !raw)) return WFM_E_ARG;
   if (hipSetDevice(wfm_device(h)) != hipSuccess) return WFM_E_HIP;
   wfm_minmer_t* d_raw = nullptr;
-  if (n && hipMalloc((void**)&d_raw, (size_t)n * sizeof(wfm_minmer_t)) != hipSuccess) return WFM_E_NOMEM;
-  if (n && hipMemcpy(d_raw, raw, (size_t)n * sizeof(wfm_minmer_t), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(d_raw); return WFM_E_HIP; }
+  if (n && wfm_dmalloc((void**)&d_raw, (size_t)n * sizeof(wfm_minmer_t)) != hipSuccess) return WFM_E_NOMEM;
+  if (n && hipMemcpy(d_raw, raw, (size_t)n * sizeof(wfm_minmer_t), hipMemcpyHostToDevice) != hipSuccess) { (void)wfm_dfree(d_raw); return WFM_E_HIP; }
   MapFinishWork wk;
   wfm_minmer_t* d_out = nullptr;
   int64_t n_out = 0;
@@ -651,6 +652,6 @@ extern "C" int64_t wfm_finish_records(wfm_handle_t* h, const wfm_minmer_t* raw, 
   if (levels) *levels = inf.levels;
   if (heap_ranges) *heap_ranges = inf.heap_ranges;
   map_finish_work_free(&wk);
-  if (d_raw) (void)hipFree(d_raw);
+  if (d_raw) (void)wfm_dfree(d_raw);
   return rc == WFM_OK ? n_out : rc;
 }

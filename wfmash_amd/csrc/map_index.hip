@@ -25,6 +25,7 @@
 
 #include "../../include/wfmash_hip.h"
 #include "wfa_handle.h"
+#include "dev_cache.h"
 #include "map_device.h"
 
 struct wfm_index {
@@ -55,9 +56,9 @@ namespace {
 
 struct Scratch {
   std::vector<void*> p;
-  ~Scratch() { for (void* q : p) if (q) (void)hipFree(q); }
+  ~Scratch() { if (!p.empty()) (void)hipDeviceSynchronize(); for (void* q : p) if (q) wfm_dfree_nosync(q); }
   template <typename T> hipError_t alloc(T** out, size_t n) {
-    hipError_t e = hipMalloc((void**)out, std::max<size_t>(n, 1) * sizeof(T));
+    hipError_t e = wfm_dmalloc((void**)out, std::max<size_t>(n, 1) * sizeof(T));
     if (e == hipSuccess) p.push_back(*out);
     return e;
   }
@@ -247,10 +248,10 @@ int map_index_build_device(wfm_handle_t* h, const wfm_minmer_t* d_m, int64_t n, 
   HIPCHK(h, hipMemcpyAsync(&n_kept, d_keep_in_incl + (n - 1), 4, hipMemcpyDeviceToHost, st));
   HIPCHK(h, hipStreamSynchronize(st));
   ix->n_points = 2 * (int64_t)n_chain; ix->n_unique = n_uniq; ix->n_kept = n_kept; ix->filtered = n - (int64_t)n_kept;
-  if (hipMalloc((void**)&ix->d_uhash, std::max<size_t>(n_uniq, 1) * 8) != hipSuccess ||
-      hipMalloc((void**)&ix->d_poff, ((size_t)n_uniq + 1) * 8) != hipSuccess ||
-      hipMalloc((void**)&ix->d_points, std::max<size_t>((size_t)ix->n_points, 1) * sizeof(wfm_interval_point_t)) != hipSuccess ||
-      hipMalloc((void**)&ix->d_minmers, std::max<size_t>(n_kept, 1) * sizeof(wfm_minmer_t)) != hipSuccess) {
+  if (wfm_dmalloc((void**)&ix->d_uhash, std::max<size_t>(n_uniq, 1) * 8) != hipSuccess ||
+      wfm_dmalloc((void**)&ix->d_poff, ((size_t)n_uniq + 1) * 8) != hipSuccess ||
+      wfm_dmalloc((void**)&ix->d_points, std::max<size_t>((size_t)ix->n_points, 1) * sizeof(wfm_interval_point_t)) != hipSuccess ||
+      wfm_dmalloc((void**)&ix->d_minmers, std::max<size_t>(n_kept, 1) * sizeof(wfm_minmer_t)) != hipSuccess) {
     wfm_index_free(h, ix); wfm_set_error(h, "out of device memory (index)"); return WFM_E_NOMEM;
   }
   hipLaunchKernelGGL(emit_points, grid_for(n), dim3(256), 0, st, d_m, d_ord2, d_keep, d_chead, d_chain, ix->d_points, n);
@@ -281,10 +282,10 @@ int wfm_index_upload(wfm_handle_t* h, const uint64_t* uhash, const int64_t* poff
   ix->device = wfm_device(h);
   ix->n_windows = n_kept; ix->n_kept = n_kept; ix->n_unique = n_unique; ix->n_points = n_points;
   const int64_t zero = 0;
-  if (hipMalloc((void**)&ix->d_uhash, std::max<size_t>((size_t)n_unique, 1) * 8) != hipSuccess ||
-      hipMalloc((void**)&ix->d_poff, ((size_t)n_unique + 1) * 8) != hipSuccess ||
-      hipMalloc((void**)&ix->d_points, std::max<size_t>((size_t)n_points, 1) * sizeof(wfm_interval_point_t)) != hipSuccess ||
-      hipMalloc((void**)&ix->d_minmers, std::max<size_t>((size_t)n_kept, 1) * sizeof(wfm_minmer_t)) != hipSuccess) {
+  if (wfm_dmalloc((void**)&ix->d_uhash, std::max<size_t>((size_t)n_unique, 1) * 8) != hipSuccess ||
+      wfm_dmalloc((void**)&ix->d_poff, ((size_t)n_unique + 1) * 8) != hipSuccess ||
+      wfm_dmalloc((void**)&ix->d_points, std::max<size_t>((size_t)n_points, 1) * sizeof(wfm_interval_point_t)) != hipSuccess ||
+      wfm_dmalloc((void**)&ix->d_minmers, std::max<size_t>((size_t)n_kept, 1) * sizeof(wfm_minmer_t)) != hipSuccess) {
     wfm_index_free(h, ix); wfm_set_error(h, "out of device memory (index)"); return WFM_E_NOMEM;
   }
   hipError_t e = hipSuccess;
@@ -321,8 +322,8 @@ int wfm_index_replicate(wfm_handle_t* src, const wfm_index_t* ix, wfm_handle_t* 
   const size_t b_uhash = std::max<size_t>((size_t)ix->n_unique, 1) * 8, b_poff = ((size_t)ix->n_unique + 1) * 8,
                b_points = std::max<size_t>((size_t)ix->n_points, 1) * sizeof(wfm_interval_point_t),
                b_minmers = std::max<size_t>((size_t)ix->n_kept, 1) * sizeof(wfm_minmer_t);
-  if (hipMalloc((void**)&cp->d_uhash, b_uhash) != hipSuccess || hipMalloc((void**)&cp->d_poff, b_poff) != hipSuccess ||
-      hipMalloc((void**)&cp->d_points, b_points) != hipSuccess || hipMalloc((void**)&cp->d_minmers, b_minmers) != hipSuccess) {
+  if (wfm_dmalloc((void**)&cp->d_uhash, b_uhash) != hipSuccess || wfm_dmalloc((void**)&cp->d_poff, b_poff) != hipSuccess ||
+      wfm_dmalloc((void**)&cp->d_points, b_points) != hipSuccess || wfm_dmalloc((void**)&cp->d_minmers, b_minmers) != hipSuccess) {
     wfm_index_free(dst, cp); wfm_set_error(dst, "out of device memory (index copy)"); return WFM_E_NOMEM;
   }
   hipStream_t st = wfm_stream(dst);
@@ -340,10 +341,10 @@ int wfm_index_replicate(wfm_handle_t* src, const wfm_index_t* ix, wfm_handle_t* 
 void wfm_index_free(wfm_handle_t* h, wfm_index_t* ix) {
   if (!ix) return;
   if (h) (void)hipSetDevice(wfm_device(h));
-  if (ix->d_uhash) (void)hipFree(ix->d_uhash);
-  if (ix->d_poff) (void)hipFree(ix->d_poff);
-  if (ix->d_points) (void)hipFree(ix->d_points);
-  if (ix->d_minmers) (void)hipFree(ix->d_minmers);
+  if (ix->d_uhash) (void)wfm_dfree(ix->d_uhash);
+  if (ix->d_poff) (void)wfm_dfree(ix->d_poff);
+  if (ix->d_points) (void)wfm_dfree(ix->d_points);
+  if (ix->d_minmers) (void)wfm_dfree(ix->d_minmers);
   delete ix;
 }
 

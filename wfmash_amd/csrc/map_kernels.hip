@@ -12,6 +12,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>  // rocprim's texture iterator calls host memset
 
 #include <rocprim/rocprim.hpp>
@@ -21,6 +24,7 @@
 
 #include "../../include/wfmash_hip.h"
 #include "wfa_handle.h"
+#include "dev_cache.h"
 #include "map_device.h"
 
 namespace wfm {
@@ -300,9 +304,9 @@ using namespace wfm;
 namespace {
 struct Scoped {
   std::vector<void*> ptrs;
-  ~Scoped() { for (void* p : ptrs) if (p) (void)hipFree(p); }
+  ~Scoped() { if (!ptrs.empty()) (void)hipDeviceSynchronize(); for (void* p : ptrs) if (p) wfm_dfree_nosync(p); }
   template <typename T> hipError_t alloc(T** p, size_t bytes) {
-    hipError_t e = hipMalloc((void**)p, bytes ? bytes : 16);
+    hipError_t e = wfm_dmalloc((void**)p, bytes ? bytes : 16);
     if (e == hipSuccess) ptrs.push_back(*p);
     return e;
   }
@@ -377,16 +381,16 @@ int map_hash_sequence_device(wfm_handle_t* h, const char* seq, int64_t len, int 
   const size_t padded = (size_t)len + 64;
   uint8_t* d_raw = nullptr;
   auto fail = [&](hipError_t e, const char* what) {
-    if (d_raw) (void)hipFree(d_raw);
+    if (d_raw) (void)wfm_dfree(d_raw);
     map_hashed_free(out);
     wfm_set_error(h, std::string(what) + ": " + hipGetErrorString(e));
     return e == hipErrorOutOfMemory ? WFM_E_NOMEM : WFM_E_HIP;
   };
   hipError_t e;
-  if ((e = hipMalloc((void**)&d_raw, padded)) != hipSuccess) return fail(e, "hipMalloc");
-  if ((e = hipMalloc((void**)&out->d_norm, padded)) != hipSuccess) return fail(e, "hipMalloc");
-  if ((e = hipMalloc((void**)&out->d_hash, (size_t)out->nk * 8)) != hipSuccess) return fail(e, "hipMalloc");
-  if ((e = hipMalloc((void**)&out->d_strand, (size_t)out->nk)) != hipSuccess) return fail(e, "hipMalloc");
+  if ((e = wfm_dmalloc((void**)&d_raw, padded)) != hipSuccess) return fail(e, "hipMalloc");
+  if ((e = wfm_dmalloc((void**)&out->d_norm, padded)) != hipSuccess) return fail(e, "hipMalloc");
+  if ((e = wfm_dmalloc((void**)&out->d_hash, (size_t)out->nk * 8)) != hipSuccess) return fail(e, "hipMalloc");
+  if ((e = wfm_dmalloc((void**)&out->d_strand, (size_t)out->nk)) != hipSuccess) return fail(e, "hipMalloc");
   if ((e = hipMemsetAsync(out->d_norm, 'N', padded, st)) != hipSuccess) return fail(e, "hipMemsetAsync");
   if ((e = hipMemcpyAsync(d_raw, seq, (size_t)len, hipMemcpyHostToDevice, st)) != hipSuccess) return fail(e, "hipMemcpyAsync");
   const int64_t nthreads = (len + 15) / 16;
@@ -394,16 +398,16 @@ int map_hash_sequence_device(wfm_handle_t* h, const char* seq, int64_t len, int 
   launch_kmer_hash(out->d_norm, out->nk, k, out->d_hash, out->d_strand, st);
   if ((e = hipGetLastError()) != hipSuccess) return fail(e, "kernel launch");
   if ((e = hipStreamSynchronize(st)) != hipSuccess) return fail(e, "hipStreamSynchronize");
-  (void)hipFree(d_raw);
+  (void)wfm_dfree(d_raw);
   return WFM_OK;
 }
 
 void map_hash_work_free(MapHashWork* wk) {
   (void)hipSetDevice(wk->device);
-  if (wk->d_raw) (void)hipFree(wk->d_raw);
-  if (wk->d_norm) (void)hipFree(wk->d_norm);
-  if (wk->d_hash) (void)hipFree(wk->d_hash);
-  if (wk->d_strand) (void)hipFree(wk->d_strand);
+  if (wk->d_raw) (void)wfm_dfree(wk->d_raw);
+  if (wk->d_norm) (void)wfm_dfree(wk->d_norm);
+  if (wk->d_hash) (void)wfm_dfree(wk->d_hash);
+  if (wk->d_strand) (void)wfm_dfree(wk->d_strand);
   *wk = MapHashWork();
 }
 
@@ -417,10 +421,10 @@ int map_hash_sequence_into(wfm_handle_t* h, MapHashWork* wk, const char* seq, in
     map_hash_work_free(wk);
     wk->device = wfm_device(h);
     const size_t cap = (size_t)len + (size_t)len / 8;  // a little room: chromosomes come in similar sizes
-    hipError_t e = hipMalloc((void**)&wk->d_raw, cap + 64);
-    if (e == hipSuccess) e = hipMalloc((void**)&wk->d_norm, cap + 64);
-    if (e == hipSuccess) e = hipMalloc((void**)&wk->d_hash, cap * 8);
-    if (e == hipSuccess) e = hipMalloc((void**)&wk->d_strand, cap);
+    hipError_t e = wfm_dmalloc((void**)&wk->d_raw, cap + 64);
+    if (e == hipSuccess) e = wfm_dmalloc((void**)&wk->d_norm, cap + 64);
+    if (e == hipSuccess) e = wfm_dmalloc((void**)&wk->d_hash, cap * 8);
+    if (e == hipSuccess) e = wfm_dmalloc((void**)&wk->d_strand, cap);
     if (e != hipSuccess) {
       map_hash_work_free(wk);
       wfm_set_error(h, std::string("hipMalloc: ") + hipGetErrorString(e));
@@ -442,9 +446,9 @@ int map_hash_sequence_into(wfm_handle_t* h, MapHashWork* wk, const char* seq, in
 void map_hashed_free(MapHashedSeq* s) {
   if (s->borrowed) { s->d_norm = nullptr; s->d_hash = nullptr; s->d_strand = nullptr; return; }
   (void)hipSetDevice(s->device);
-  if (s->d_norm) (void)hipFree(s->d_norm);
-  if (s->d_hash) (void)hipFree(s->d_hash);
-  if (s->d_strand) (void)hipFree(s->d_strand);
+  if (s->d_norm) (void)wfm_dfree(s->d_norm);
+  if (s->d_hash) (void)wfm_dfree(s->d_hash);
+  if (s->d_strand) (void)wfm_dfree(s->d_strand);
   s->d_norm = nullptr; s->d_hash = nullptr; s->d_strand = nullptr;
 }
 
@@ -566,6 +570,9 @@ int64_t wfm_minhash_sketch(wfm_handle_t* h, const char* seq, int64_t len, int k,
   const int64_t nk = len - k + 1;
   if (nk <= 0) return 0;
   HIPCHK(h, hipSetDevice(wfm_device(h)));
+  const bool dbg = getenv("WFM_DEBUG") != nullptr;
+  const auto tq0 = std::chrono::steady_clock::now();
+  auto since = [&](std::chrono::steady_clock::time_point a) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count(); };
   Scoped sc;
   uint8_t* d_norm = nullptr;
   int rc = upload_normalised(h, sc, seq, len, &d_norm);
@@ -575,8 +582,12 @@ int64_t wfm_minhash_sketch(wfm_handle_t* h, const char* seq, int64_t len, int k,
   HIPCHK(h, sc.alloc(&d_sorted, (size_t)nk * 8));
   HIPCHK(h, sc.alloc(&d_st, (size_t)nk));
   hipStream_t st = wfm_stream(h);
+  if (dbg) { HIPCHK(h, hipStreamSynchronize(st)); fprintf(stderr, "[wfm] minhash_sketch of %lld bases: allocations + upload + normalise %.1f ms", (long long)len, since(tq0)); }
+  const auto tq1 = std::chrono::steady_clock::now();
   launch_kmer_hash(d_norm, nk, k, d_hash, d_st, st);
   HIPCHK(h, hipGetLastError());
+  if (dbg) { HIPCHK(h, hipStreamSynchronize(st)); fprintf(stderr, ", hashing %.1f ms", since(tq1)); }
+  const auto tq2 = std::chrono::steady_clock::now();
   bool head_ambiguous = false;
   for (int j = 0; j < k && j < len; ++j) {
     char c = seq[j];
@@ -625,6 +636,7 @@ int64_t wfm_minhash_sketch(wfm_handle_t* h, const char* seq, int64_t len, int k,
     HIPCHK(h, hipMemcpyAsync(out, d_sorted, (size_t)n * 8, hipMemcpyDeviceToHost, st));
     HIPCHK(h, hipStreamSynchronize(st));
   }
+  if (dbg) fprintf(stderr, ", select + sort + download %.1f ms (%s)\n", since(tq2), done ? "threshold" : "full sort");
   int64_t valid = n;
   while (valid > 0 && out[valid - 1] == ~0ull) --valid;  // invalid k-mers sort last
   return valid;

@@ -19,6 +19,7 @@
 // scan -> window counts -> scan (dilation by W) -> keep flags -> scan/compact (position, hash, strand).
 // All of it is streaming integer work over n k-mers, bound by HBM bandwidth: ~60 B/k-mer in total.
 #include <hip/hip_runtime.h>
+#include "dev_cache.h"
 #include <stdint.h>
 
 #include <cstring>  // rocprim's texture iterator calls host memset
@@ -104,10 +105,10 @@ int need(wfm_handle_t* h, MapScratch& sc, MapThinWork::Buf* slot, size_t bytes, 
     return WFM_OK;
   }
   if (slot->bytes < bytes) {
-    if (slot->p) (void)hipFree(slot->p);
+    if (slot->p) (void)wfm_dfree(slot->p);
     slot->p = nullptr; slot->bytes = 0;
     const size_t want = bytes + bytes / 8;
-    HIPCHK(h, hipMalloc(&slot->p, want));
+    HIPCHK(h, wfm_dmalloc(&slot->p, want));
     slot->bytes = want;
   }
   *out = slot->p;
@@ -131,7 +132,7 @@ inline dim3 grid_for(int64_t n) { return dim3((unsigned)((n + 255) / 256)); }
 void map_thin_work_free(MapThinWork* wk) {
   (void)hipSetDevice(wk->device);
   for (MapThinWork::Buf* b : {&wk->a, &wk->b, &wk->ck, &wk->ck2, &wk->cp, &wk->cp2, &wk->tmp}) {
-    if (b->p) (void)hipFree(b->p);
+    if (b->p) (void)wfm_dfree(b->p);
     b->p = nullptr; b->bytes = 0;
   }
 }
@@ -158,7 +159,7 @@ void* map_dev_pool_get(int device, size_t bytes) {
   if (hipSetDevice(device) != hipSuccess) return nullptr;
   void* p = nullptr;
   const size_t want = bytes + bytes / 8 + 256;
-  if (hipMalloc(&p, want) != hipSuccess) return nullptr;
+  if (wfm_dmalloc(&p, want) != hipSuccess) return nullptr;
   std::lock_guard<std::mutex> lk(P.mu);
   P.blks.push_back(DevPool::Blk{p, want, device, true});
   return p;
@@ -172,7 +173,7 @@ void map_dev_pool_put(int device, void* p) {
       if (b.p == p) { b.busy = false; return; }
   }
   (void)hipSetDevice(device);
-  (void)hipFree(p);  // not one of the pool's
+  (void)wfm_dfree(p);  // not one of the pool's
 }
 void map_dev_pool_trim() {
   DevPool& P = dev_pool();
@@ -181,7 +182,7 @@ void map_dev_pool_trim() {
   for (size_t i = 0; i < P.blks.size(); ++i) {
     if (P.blks[i].busy) { P.blks[o++] = P.blks[i]; continue; }
     (void)hipSetDevice(P.blks[i].device);
-    (void)hipFree(P.blks[i].p);
+    (void)wfm_dfree(P.blks[i].p);
   }
   P.blks.resize(o);
 }

@@ -11,6 +11,7 @@
 // records are gathered in emission order.  Whatever does not fit the device's fixed capacities, and every failed
 // speculation, is reported to the caller, which then winnows that sequence on the host (host/minmers.cpp).
 #include <hip/hip_runtime.h>
+#include "dev_cache.h"
 
 #include <algorithm>
 #include <chrono>
@@ -629,7 +630,7 @@ int64_t map_winnow_model(const uint32_t* pos, const uint64_t* hash, const int8_t
 void map_winnow_work_free(MapWinnowWork* wk) {
   if (!wk) return;
   for (MapWinnowWork::Buf* b : {&wk->chunks, &wk->recs, &wk->count, &wk->st_begin, &wk->st_end, &wk->wp_end, &wk->flags, &wk->off, &wk->out, &wk->todo}) {
-    if (b->p) (void)hipFree(b->p);
+    if (b->p) (void)wfm_dfree(b->p);
     b->p = nullptr; b->bytes = 0;
   }
 }
@@ -637,10 +638,10 @@ void map_winnow_work_free(MapWinnowWork* wk) {
 namespace {
 int grow(MapWinnowWork::Buf& b, size_t bytes) {
   if (b.bytes >= bytes && b.p) return WFM_OK;
-  if (b.p) (void)hipFree(b.p);
+  if (b.p) (void)wfm_dfree(b.p);
   b.p = nullptr; b.bytes = 0;
   const size_t want = bytes + bytes / 4 + 256;
-  if (hipMalloc(&b.p, want) != hipSuccess) return WFM_E_NOMEM;
+  if (wfm_dmalloc(&b.p, want) != hipSuccess) return WFM_E_NOMEM;
   b.bytes = want;
   return WFM_OK;
 }
