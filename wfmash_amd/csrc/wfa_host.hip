@@ -243,9 +243,11 @@ int run_base_jobs(wfm_handle* h, wfm_seqset* S, const wfm_penalties_t& pen, std:
                   LevelTimer& tm) {
   if (nodes.empty()) return WFM_OK;
   const int RR = ring_rows_for(std::max(pen.x, std::max(pen.o1 + pen.e1, pen.o2 + pen.e2)) + 1);
-  std::stable_sort(nodes.begin(), nodes.end(), [&](const Node& a, const Node& b) {
-    return (base_row_width(a, S->meta[a.prob]) > 2048) < (base_row_width(b, S->meta[b.prob]) > 2048);
-  });
+  // rows beyond 2 k diagonals get 1024 threads -- and rows beyond 512 when the launch is too small to fill the device anyway
+  // (the retries of the few patches that overflowed their first budget: one workgroup each, a thousand steps deep)
+  const int wide_from = nodes.size() < 128 ? 512 : 2048;
+  auto is_wide = [&](const Node& a) { return base_row_width(a, S->meta[a.prob]) > wide_from; };
+  std::stable_sort(nodes.begin(), nodes.end(), [&](const Node& a, const Node& b) { return is_wide(a) < is_wide(b); });
   const DevPen dp{pen.x, pen.o1, pen.e1, pen.o2, pen.e2};
   size_t i0 = 0;
   std::vector<BaseJob> jobs;
@@ -259,7 +261,7 @@ int run_base_jobs(wfm_handle* h, wfm_seqset* S, const wfm_penalties_t& pen, std:
       const Node& nd = nodes[i];
       const ProbMeta& pm = S->meta[nd.prob];
       {  // a chunk holds jobs of one kind: rows beyond 2 k diagonals get 1024 threads
-        const bool wide = base_row_width(nd, pm) > 2048;
+        const bool wide = is_wide(nd);
         if (jobs.empty()) chunk_wide = wide;
         else if (wide != chunk_wide) break;
       }
@@ -354,7 +356,9 @@ int run_base_jobs(wfm_handle* h, wfm_seqset* S, const wfm_penalties_t& pen, std:
             if (getenv("WFM_DEBUG")) fprintf(stderr, "[wfm] problem %d: base job pl %d tl %d cb %d ce %d overflowed its score bound %d\n", nd.prob, nd.pl, nd.tl, nd.cb, nd.ce, nd.smax);
             prob_status[nd.prob] = WFM_ST_UNREACHABLE; continue;
           }
-          again.smax = (int32_t)std::min<int64_t>((int64_t)nd.smax * 4 + 32, bound);  // (x 2 until round 3: every retry is a launch that a few jobs hold up)
+          // (x 2 until round 3, x 4 for a while: every retry is a launch that a few jobs hold up, a budget that is too large costs
+          // memory only -- 20 MB for a 2 k-wide patch at 2 k scores -- and a patch that passed 256 is as likely to need 1500 as 500)
+          again.smax = (int32_t)std::min<int64_t>((int64_t)nd.smax * 8 + 32, bound);
           retry.push_back(again);
         } else if (r.status != 0) {
           if (getenv("WFM_DEBUG")) fprintf(stderr, "[wfm] problem %d: base job pl %d tl %d status %d\n", nd.prob, nd.pl, nd.tl, r.status);
