@@ -97,7 +97,7 @@ def main():
                       "pct": round(float(s.percentage_identity), 4), "sketch": s.sketch_size, "windows": int(s.index_windows),
                       "fragments": int(s.fragments), "l2_mappings": int(s.l2_mappings), "written": int(s.written), "bad_records": len(bad), "bad_examples": bad[:3], "target_end_past_length": int(past_end),
                       "query_span_mapped_per_target": round(span / max(1, int(s.query_bp)) / max(1, a.haps - 1), 4),
-                      "ms_index": round(s.ms_index), "ms_map": round(s.ms_map), "ms_filter": round(s.ms_filter), "ms_total": round(s.ms_total),
+                      "ms_identity": round(s.ms_identity), "ms_wall": round(s.ms_wall), "ms_index": round(s.ms_index), "ms_map": round(s.ms_map), "ms_filter": round(s.ms_filter), "ms_total": round(s.ms_total),
                       "query_mbp_per_s": round(s.query_bp / 1e6 / (s.ms_total / 1e3), 2),
                       "align": align,
                       "peak_rss_gb": round(resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1e6, 1)}))

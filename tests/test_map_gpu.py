@@ -109,3 +109,33 @@ def test_sketch_large_batch_random(gpu):
     for i in rng.sample(range(len(offs)), 80):
         e = pymap.sketch_sequence(seq[offs[i]:offs[i] + lens[i]], 15, 39, 11)
         assert len(got[i]) == len(e) and (got[i]["hash"] == e["hash"]).all() and (got[i]["wpos_end"] == e["wpos_end"]).all()
+
+
+def test_sketch_table_form_equals_sort_form(gpu, monkeypatch):
+    """The threshold-and-table form of sketch_fragments against the sorting form on fragments whose number of distinct k-mers
+    is anything between a handful and all of them (duplications by 2 - 4 x, microsatellites, N runs): thresholds that
+    turn out too small are raised, tables that overflow are bisected, and the records are the same bytes."""
+    rng = random.Random(77)
+    parts = []
+    for i in range(60):
+        unit = synth.random_dna(3000 + i, rng.choice([40, 150, 400, 900]))
+        reps = rng.choice([1, 2, 2, 3, 4])
+        parts.append(unit * reps + synth.random_dna(4000 + i, rng.choice([0, 200, 700])))
+        if i % 9 == 0:
+            parts.append(b"N" * 37 + b"AC" * 120 + b"T" * 90)
+    seq = b"".join(parts)
+    offs, lens = [], []
+    for _ in range(400):
+        L = rng.choice([300, 1000, 1000, 2500, 5000, 12000])
+        o = rng.randrange(0, len(seq) - L)
+        offs.append(o); lens.append(L)
+    for k, s in [(15, 23), (15, 80), (21, 300), (28, 40), (9, 500)]:
+        monkeypatch.setenv("WFM_SKETCH_TABLE", "1")
+        a = gpu.sketch_fragments(seq, offs, lens, k, s, 5)
+        monkeypatch.setenv("WFM_SKETCH_TABLE", "0")
+        b = gpu.sketch_fragments(seq, offs, lens, k, s, 5)
+        for i, (x, y) in enumerate(zip(a, b)):
+            assert len(x) == len(y) and x.tobytes() == y.tobytes(), (k, s, i, offs[i], lens[i])
+        for i in rng.sample(range(len(offs)), 12):
+            e = pymap.sketch_sequence(seq[offs[i]:offs[i] + lens[i]], k, s, 5)
+            assert len(a[i]) == len(e) and (a[i]["hash"] == e["hash"]).all() and (a[i]["wpos"] == e["wpos"]).all() and (a[i]["strand"] == e["strand"]).all()

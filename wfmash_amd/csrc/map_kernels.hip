@@ -136,8 +136,7 @@ __global__ void kmer_hash_kernel(const uint8_t* __restrict__ seq /*normalised, p
 // complement of every byte -- A <-> T differ in bits 0, 2, 4, C <-> G in bit 2, and bit 1 tells the two pairs apart --
 // followed by a reversal of the bytes and a shift; an N is a zero byte of word ^ 'NNNNNNNN'.
 template <int K>
-__global__ void __launch_bounds__(256) kmer_hash_2w_kernel(const uint8_t* __restrict__ seq /*normalised, padded*/, int64_t nk, uint64_t* __restrict__ hash,
-                                                           int8_t* __restrict__ strand) {
+__device__ __forceinline__ void kmer_hash_2w(const uint8_t* __restrict__ p, uint64_t& h, int8_t& st) {
   static_assert(K >= 9 && K <= 24, "two or three words");
   constexpr int NWD = (K + 7) / 8;                       // words that hold the k-mer
   constexpr int LASTB = K - 8 * (NWD - 1);               // bytes of the last one
@@ -145,53 +144,59 @@ __global__ void __launch_bounds__(256) kmer_hash_2w_kernel(const uint8_t* __rest
   constexpr uint64_t ones = 0x0101010101010101ULL;
   constexpr int sh = 8 * (8 * NWD - K);                  // bits the reversed words are shifted down by
   const uint64_t c1 = 0x87c37b91114253d5ULL, c2 = 0x4cf5ad432745937fULL;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nk; i += (int64_t)gridDim.x * blockDim.x) {
-    uint64_t f[3] = {0, 0, 0};
-    uint64_t nbits = 0;
+  uint64_t f[3] = {0, 0, 0};
+  uint64_t nbits = 0;
+#pragma unroll
+  for (int q = 0; q < NWD; ++q) {
+    f[q] = ld8(p + 8 * q);
+    if (q == NWD - 1) f[q] &= last_mask;
+    const uint64_t x = f[q] ^ (ones * 'N');
+    nbits |= (x - ones) & ~x;
+  }
+  h = ~0ull;
+  st = 0;
+  if (!(nbits & (ones * 0x80))) {
+    // complement, reverse the bytes, drop the bytes that were past the k-mer
+    uint64_t b[3] = {0, 0, 0}, r[3] = {0, 0, 0};
 #pragma unroll
     for (int q = 0; q < NWD; ++q) {
-      f[q] = ld8(seq + i + 8 * q);
-      if (q == NWD - 1) f[q] &= last_mask;
-      const uint64_t x = f[q] ^ (ones * 'N');
-      nbits |= (x - ones) & ~x;
+      const uint64_t m = (~f[q] >> 1) & ones;
+      b[NWD - 1 - q] = __builtin_bswap64(f[q] ^ (ones * 4) ^ (m * 0x11));
     }
-    uint64_t h = ~0ull;
-    int8_t st = 0;
-    if (!(nbits & (ones * 0x80))) {
-      // complement, reverse the bytes, drop the bytes that were past the k-mer
-      uint64_t b[3] = {0, 0, 0}, r[3] = {0, 0, 0};
 #pragma unroll
-      for (int q = 0; q < NWD; ++q) {
-        const uint64_t m = (~f[q] >> 1) & ones;
-        b[NWD - 1 - q] = __builtin_bswap64(f[q] ^ (ones * 4) ^ (m * 0x11));
+    for (int q = 0; q < NWD; ++q) r[q] = sh == 0 ? b[q] : ((b[q] >> sh) | (q + 1 < NWD ? b[q + 1] << ((64 - sh) & 63) : 0ull));
+    uint64_t hv[2];
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+      const uint64_t* w = d == 0 ? f : r;
+      uint64_t h1 = 42u, h2 = 42u;
+      if (K >= 16) {  // one whole block
+        uint64_t k1 = w[0], k2 = w[1];
+        k1 *= c1; k1 = rotl64(k1, 31); k1 *= c2; h1 ^= k1;
+        h1 = rotl64(h1, 27); h1 += h2; h1 = h1 * 5 + 0x52dce729;
+        k2 *= c2; k2 = rotl64(k2, 33); k2 *= c1; h2 ^= k2;
+        h2 = rotl64(h2, 31); h2 += h1; h2 = h2 * 5 + 0x38495ab5;
       }
-#pragma unroll
-      for (int q = 0; q < NWD; ++q) r[q] = sh == 0 ? b[q] : ((b[q] >> sh) | (q + 1 < NWD ? b[q + 1] << ((64 - sh) & 63) : 0ull));
-      uint64_t hv[2];
-#pragma unroll
-      for (int d = 0; d < 2; ++d) {
-        const uint64_t* w = d == 0 ? f : r;
-        uint64_t h1 = 42u, h2 = 42u;
-        if (K >= 16) {  // one whole block
-          uint64_t k1 = w[0], k2 = w[1];
-          k1 *= c1; k1 = rotl64(k1, 31); k1 *= c2; h1 ^= k1;
-          h1 = rotl64(h1, 27); h1 += h2; h1 = h1 * 5 + 0x52dce729;
-          k2 *= c2; k2 = rotl64(k2, 33); k2 *= c1; h2 ^= k2;
-          h2 = rotl64(h2, 31); h2 += h1; h2 = h2 * 5 + 0x38495ab5;
-        }
-        constexpr int tail = K & 15;
-        if (tail) {
-          uint64_t k1 = K >= 16 ? w[2] : w[0], k2 = K >= 16 ? 0ull : w[1];
-          if (tail > 8) { k2 *= c2; k2 = rotl64(k2, 33); k2 *= c1; h2 ^= k2; }
-          k1 *= c1; k1 = rotl64(k1, 31); k1 *= c2; h1 ^= k1;
-        }
-        h1 ^= (uint64_t)K; h2 ^= (uint64_t)K;
-        h1 += h2; h2 += h1;
-        h1 = fmix64(h1); h2 = fmix64(h2);
-        hv[d] = h1 + h2;
+      constexpr int tail = K & 15;
+      if (tail) {
+        uint64_t k1 = K >= 16 ? w[2] : w[0], k2 = K >= 16 ? 0ull : w[1];
+        if (tail > 8) { k2 *= c2; k2 = rotl64(k2, 33); k2 *= c1; h2 ^= k2; }
+        k1 *= c1; k1 = rotl64(k1, 31); k1 *= c2; h1 ^= k1;
       }
-      if (hv[0] != hv[1]) { h = hv[0] < hv[1] ? hv[0] : hv[1]; st = hv[0] < hv[1] ? 1 : -1; }
+      h1 ^= (uint64_t)K; h2 ^= (uint64_t)K;
+      h1 += h2; h2 += h1;
+      h1 = fmix64(h1); h2 = fmix64(h2);
+      hv[d] = h1 + h2;
     }
+    if (hv[0] != hv[1]) { h = hv[0] < hv[1] ? hv[0] : hv[1]; st = hv[0] < hv[1] ? 1 : -1; }
+  }
+}
+template <int K>
+__global__ void __launch_bounds__(256) kmer_hash_2w_kernel(const uint8_t* __restrict__ seq /*normalised, padded*/, int64_t nk, uint64_t* __restrict__ hash,
+                                                           int8_t* __restrict__ strand) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nk; i += (int64_t)gridDim.x * blockDim.x) {
+    uint64_t h; int8_t st;
+    kmer_hash_2w<K>(seq + i, h, st);
     hash[i] = h;
     strand[i] = st;
   }
@@ -288,6 +293,106 @@ __global__ __launch_bounds__(256) void sketch_fragments_kernel(const uint8_t* __
   if (tid == 0) out_count[f] = cnt;
 }
 
+// sketchSequence by threshold and table (round 3).  The sort above orders all ~5000 (hash, position) pairs of a fragment to
+// find its ~25 smallest distinct hashes, in 60 - 100 KB of LDS (one workgroup per CU).  Here a threshold tau is set so that
+// about 2 s + 24 distinct hashes are expected at or below it (a canonical hash is the smaller of two uniform values: a
+// fraction t of the range holds ~2 t of the k-mers), the k-mers at or below tau go into an open-addressing table in LDS
+// keyed by hash -- first position (min), last position (max), strand sum, exactly what the sorted runs gave -- and only the
+// table is sorted.  Fewer than s distinct hashes (repeats, low complexity): tau x 4 and again, up to "every k-mer"; more
+// than the table holds: bisection between the last two thresholds.  A valid k-mer whose hash is the table's EMPTY value
+// (2^-64) sets *redo and the host runs the sorting kernel instead.  K = 0: any k <= 32 (byte-wise hashing).
+template <int K>
+__global__ __launch_bounds__(256) void sketch_fragments_table_kernel(const uint8_t* __restrict__ seq, const int64_t* __restrict__ frag_off,
+                                                                     const int32_t* __restrict__ frag_len, int k, int s, int32_t seq_id, int T,
+                                                                     wfm_minmer_t* __restrict__ out, int32_t* __restrict__ out_count, int32_t* redo) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr uint64_t EMPTY = ~0ull;
+  uint64_t* key = reinterpret_cast<uint64_t*>(smem);   // [T]
+  uint32_t* mn = reinterpret_cast<uint32_t*>(key + T);  // [T] first position
+  uint32_t* mx = mn + T;                                // [T] last position
+  int* sm = reinterpret_cast<int*>(mx + T);             // [T] strand sum
+  __shared__ int s_cnt, s_over;
+  const int f = blockIdx.x, tid = threadIdx.x;
+  const uint8_t* p = seq + frag_off[f];
+  const int nk = frag_len[f] - k + 1;
+  if (nk <= 0) { if (tid == 0) out_count[f] = 0; return; }
+  const int cap = T - T / 4;
+  constexpr uint64_t TMAX = ~0ull - 1;
+  uint64_t tau;
+  {
+    const double t = (double)(2 * s + 24) / (2.0 * (double)nk);
+    tau = t >= 0.999 ? TMAX : (uint64_t)(t * 18446744073709551616.0);
+  }
+  uint64_t lo = 0, hi = 0;  // the largest threshold known to be too small; the smallest known to overflow (0: none yet)
+  int D = 0;
+  for (;;) {
+    for (int i = tid; i < T; i += blockDim.x) { key[i] = EMPTY; mn[i] = 0xffffffffu; mx[i] = 0u; sm[i] = 0; }
+    if (tid == 0) { s_cnt = 0; s_over = 0; }
+    __syncthreads();
+    for (int i = tid; i < nk; i += blockDim.x) {
+      if (*(volatile int*)&s_over) break;
+      uint64_t h; int8_t st;
+      if (K > 0) kmer_hash_2w<(K > 0 ? K : 9)>(p + i, h, st);
+      else {
+        uint64_t fw[4], rc[4];
+        h = EMPTY; st = 0;
+        if (load_kmer(p + i, k, fw, rc)) {
+          const uint64_t hf = murmur3_x64_lo(fw, k, 42u), hb = murmur3_x64_lo(rc, k, 42u);
+          if (hf != hb) { h = hf < hb ? hf : hb; st = hf < hb ? 1 : -1; }
+        }
+      }
+      if (st == 0) continue;                   // an N inside, or its own reverse complement
+      if (h == EMPTY) { *redo = 1; continue; }
+      if (h > tau) continue;
+      uint32_t slot = (uint32_t)((h * 0x9E3779B97F4A7C15ull) >> 40) & (uint32_t)(T - 1);
+      for (int probe = 0; probe < T; ++probe) {
+        const uint64_t old = atomicCAS(reinterpret_cast<unsigned long long*>(&key[slot]), (unsigned long long)EMPTY, (unsigned long long)h);
+        if (old == EMPTY && atomicAdd(&s_cnt, 1) >= cap) s_over = 1;
+        if (old == EMPTY || old == h) {
+          atomicMin(&mn[slot], (uint32_t)i); atomicMax(&mx[slot], (uint32_t)i); atomicAdd(&sm[slot], st > 0 ? 1 : -1);
+          break;
+        }
+        slot = (slot + 1) & (uint32_t)(T - 1);
+      }
+    }
+    __syncthreads();
+    D = s_cnt;
+    const int over = s_over;
+    __syncthreads();
+    if (over) { hi = tau; tau = lo + (hi - lo) / 2; continue; }
+    if (D >= s || tau == TMAX) break;
+    lo = tau;
+    if (hi) tau = lo + (hi - lo) / 2;
+    else tau = tau > TMAX / 4 ? TMAX : tau * 4;
+  }
+  // the table by hash (bitonic, EMPTY last)
+  for (int size = 2; size <= T; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      for (int t = tid; t < (T >> 1); t += blockDim.x) {
+        const int a = 2 * t - (t & (stride - 1)), b = a + stride;
+        const bool asc = ((a & size) == 0);
+        const uint64_t ka = key[a], kb = key[b];
+        if ((ka > kb) == asc && ka != kb) {
+          key[a] = kb; key[b] = ka;
+          const uint32_t m0 = mn[a], x0 = mx[a]; const int s0 = sm[a];
+          mn[a] = mn[b]; mx[a] = mx[b]; sm[a] = sm[b];
+          mn[b] = m0; mx[b] = x0; sm[b] = s0;
+        }
+      }
+      __syncthreads();
+    }
+  }
+  const int cnt = min(D, s);
+  for (int r = tid; r < cnt; r += blockDim.x) {
+    wfm_minmer_t* o = out + (size_t)f * s + r;
+    o->hash = key[r]; o->wpos = (int64_t)mn[r]; o->wpos_end = (int64_t)mx[r]; o->seqId = seq_id;
+    const int v = sm[r];
+    o->strand = (int16_t)(v > 0 ? 1 : (v == 0 ? 0 : -1));  // FWD=1, AMBIG=0, REV=-1
+    o->pad_ = 0;
+  }
+  if (tid == 0) out_count[f] = cnt;
+}
+
 }  // namespace wfm
 
 using namespace wfm;
@@ -359,6 +464,29 @@ int map_sketch_device(wfm_handle_t* h, MapScratch& ms, const char* seq, int64_t 
   HIPCHK(h, hipMemsetAsync(d_out, 0, n * (size_t)s * sizeof(wfm_minmer_t), st));
   if (lds > 64 * 1024) {
     HIPCHK(h, hipFuncSetAttribute((const void*)sketch_fragments_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  }
+  // the table form while its table (2 x (2 s + 24) slots at least, 20 B each) fits 64 KB of LDS; WFM_SKETCH_TABLE=0: the sort
+  const bool table_on = !(getenv("WFM_SKETCH_TABLE") && atoi(getenv("WFM_SKETCH_TABLE")) == 0);
+  int T = 256;
+  while (T < 2 * (2 * s + 24)) T <<= 1;
+  if (table_on && T <= 2048 && maxk >= 1) {
+    int32_t* d_redo = nullptr;
+    HIPCHK(h, sc.alloc(&d_redo, 4));
+    HIPCHK(h, hipMemsetAsync(d_redo, 0, 4, st));
+    const size_t tl = (size_t)T * 20;
+    switch (k) {
+#define WFM_SKT(K) case K: hipLaunchKernelGGL(sketch_fragments_table_kernel<K>, dim3((unsigned)n), dim3(256), tl, st, d_norm, d_off, d_len, k, s, seq_id, T, d_out, d_cnt, d_redo); break;
+      WFM_SKT(9) WFM_SKT(10) WFM_SKT(11) WFM_SKT(12) WFM_SKT(13) WFM_SKT(14) WFM_SKT(15) WFM_SKT(16)
+      WFM_SKT(17) WFM_SKT(18) WFM_SKT(19) WFM_SKT(20) WFM_SKT(21) WFM_SKT(22) WFM_SKT(23) WFM_SKT(24)
+#undef WFM_SKT
+      default: hipLaunchKernelGGL(sketch_fragments_table_kernel<0>, dim3((unsigned)n), dim3(256), tl, st, d_norm, d_off, d_len, k, s, seq_id, T, d_out, d_cnt, d_redo);
+    }
+    HIPCHK(h, hipGetLastError());
+    int32_t redo = 0;
+    HIPCHK(h, hipMemcpyAsync(&redo, d_redo, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(h, hipStreamSynchronize(st));  // (d_norm / d_off / d_len are released on return)
+    if (!redo) { *d_out_p = d_out; *d_cnt_p = d_cnt; return WFM_OK; }
+    HIPCHK(h, hipMemsetAsync(d_out, 0, n * (size_t)s * sizeof(wfm_minmer_t), st));
   }
   uint64_t* d_gkey = nullptr; uint32_t* d_gpv = nullptr;
   if (in_global) {
