@@ -52,7 +52,9 @@ struct DevBuf {
     if (n <= cap) return 0;
     if (p) (void)hipFree(p);
     p = nullptr; cap = 0;
-    size_t want = n + n / 8 + 64;
+    // (an arena that has to grow doubles at least: every regrowth is a fresh allocation, 30 - 70 ms per GB on this driver, and a
+    // divergent batch -- C1 -- used to walk its ring arena up in five steps of 3.5 .. 12 GB)
+    size_t want = std::max(n + n / 8 + 64, cap * 2);
     const auto t0 = std::chrono::steady_clock::now();
     if (hipMalloc((void**)&p, want * sizeof(T)) != hipSuccess) {
       if (hipMalloc((void**)&p, n * sizeof(T)) != hipSuccess) { p = nullptr; return -1; }
@@ -903,6 +905,7 @@ int align_resident_impl(wfm_handle* h, const wfm_penalties_t* pen, wfm_seqset* S
       use_band = band_on && total * 4 > std::min<size_t>(h->mem_budget, (size_t)2 << 30);
       over_budget = total * 4 > h->mem_budget;
     }
+    static const size_t ring_chunk_bytes = (size_t)(getenv("WFM_RING_CHUNK_GB") ? std::max(1, atoi(getenv("WFM_RING_CHUNK_GB"))) : 4) << 30;
     const char* bre = getenv("WFM_BAND_ROOT");
     const int band_root = bre ? std::max(64, atoi(bre)) : 4096;
     size_t i0 = 0;
@@ -939,9 +942,10 @@ int align_resident_impl(wfm_handle* h, const wfm_penalties_t* pen, wfm_seqset* S
         }
         if (tile_it && width * 2 * 5 * RR * 2 * 4 > h->mem_budget) tile_it = false;  // two snapshot rings do not fit: step-by-step kernel
         const size_t need = width * 2 * 5 * RR * (tile_it ? 2 : 1);
-        // (a chunk of a level stops at 8 GB of rings even when the budget allows more: thousands of jobs fill the device
-        // long before that, and every GB of a first allocation may cost 30 ms)
-        if (!jobs.empty() && (ring_elems + need) * 4 > std::min<size_t>(h->mem_budget, (size_t)8 << 30)) break;
+        // (a chunk of a level stops at 4 GB of rings even when the budget allows more: hundreds of jobs fill the device
+        // long before that, and every GB of a first allocation costs 30 - 70 ms.  C1 substitute, three handles in a fresh
+        // process: 8 GB chunks 8.3 s cold / 5.33 s warm, 4 GB 5.67 / 5.52, 2 GB 6.22 / 6.06 -- scripts/c1_cold.sh)
+        if (!jobs.empty() && (ring_elems + need) * 4 > std::min<size_t>(h->mem_budget, ring_chunk_bytes)) break;
         if (need * 4 > h->mem_budget) { prob_status[nd.prob] = WFM_ST_OOM; continue; }
         BpJob j{};
         j.p_fwd = pm.p_fwd + nd.pb;
