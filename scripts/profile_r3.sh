@@ -46,4 +46,14 @@ WFM_DEBUG=1 rocprofv3 --kernel-trace --stats -d /tmp/p3/c2 -o t -- python $root/
 cd "$root"
 python scripts/prof_summary.py "$po/r3_c2.md" "r3: C2 (LPA.subset all-vs-all, -p 90 -P 50k), two passes in one process (scripts/legs_debug.py c2)" "$(find /tmp/p3/c2 -name '*results.db' | head -1)" --bench /tmp/p3_c2.log > /dev/null
 { echo; echo "## stage timings of the second (warm) pass (WFM_DEBUG=1)"; echo '```'; awk '/==== C2 pass 1/{f=1} f' /tmp/p3_c2.err | grep "wfmash::align\]\|wflign\]\|align_batch\|wall:\|score bounds\|add_minmers_multi\|index_build" | cut -c1-400; echo '```'; } >> "$po/r3_c2.md"
+# C1 substitute (8 yeast-like strains all-vs-all), one pass
+cd /tmp
+rocprofv3 --kernel-trace --stats -d /tmp/p3/c1 -o t -- python $root/scripts/c1_run.py --reps 1 > /tmp/p3_c1.log 2>/dev/null
+cd "$root"
+python scripts/prof_summary.py "$po/r3_c1.md" "r3: C1 substitute (8 yeast-like strains x 16 chromosomes, 96 Mbp, all-vs-all, defaults), map + align, one pass in a fresh process (scripts/c1_run.py --reps 1)" "$(find /tmp/p3/c1 -name '*results.db' | head -1)" --bench /tmp/p3_c1.log > /dev/null
+# the map phase of a full-size C4 rank (item 7's three kernels: sketch_fragments, l1_sweep, l2_slide per 249 k fragments)
+cd /tmp
+rocprofv3 --kernel-trace --stats -d /tmp/p3/map -o t -- python $root/scripts/c4_rank.py > /tmp/p3_map.log 2>/dev/null
+cd "$root"
+python scripts/prof_summary.py "$po/r3_map.md" "r3: map phase of one rank of C4 at full size (8 x 249 Mbp, one query haplotype: 249 k fragments; scripts/c4_rank.py)" "$(find /tmp/p3/map -name '*results.db' | head -1)" --bench /tmp/p3_map.log > /dev/null
 ls -la "$po"

@@ -944,8 +944,11 @@ int align_resident_impl(wfm_handle* h, const wfm_penalties_t* pen, wfm_seqset* S
         const size_t need = width * 2 * 5 * RR * (tile_it ? 2 : 1);
         // (a chunk of a level stops at 4 GB of rings even when the budget allows more: hundreds of jobs fill the device
         // long before that, and every GB of a first allocation costs 30 - 70 ms.  C1 substitute, three handles in a fresh
-        // process: 8 GB chunks 8.3 s cold / 5.33 s warm, 4 GB 5.67 / 5.52, 2 GB 6.22 / 6.06 -- scripts/c1_cold.sh)
-        if (!jobs.empty() && (ring_elems + need) * 4 > std::min<size_t>(h->mem_budget, ring_chunk_bytes)) break;
+        // process: 8 GB chunks 8.3 s cold / 5.33 s warm, 4 GB 5.67 / 5.52, 2 GB 6.22 / 6.06 -- scripts/c1_cold.sh.  A level of
+        // fewer than 512 jobs keeps 8 GB: C3's 21 roots of a part are 5.4 GB of full rings, and cut in two they fill the device worse.
+        // Tried and dropped: two launches per block, jobs without a score bound apart from those with one -- the plain kernel form
+        // has 7 % fewer instructions, the second launch cost more: C2 0.18 -> 0.21 s, C1 no better)
+        if (!jobs.empty() && (ring_elems + need) * 4 > std::min<size_t>(h->mem_budget, bp_nodes.size() >= 512 ? ring_chunk_bytes : std::max(ring_chunk_bytes, (size_t)8 << 30))) break;
         if (need * 4 > h->mem_budget) { prob_status[nd.prob] = WFM_ST_OOM; continue; }
         BpJob j{};
         j.p_fwd = pm.p_fwd + nd.pb;
