@@ -313,7 +313,8 @@ Summary Aligner::compute() {
   const size_t ngpu = gpus.size();
   // up to three batches per GPU in flight when there are host threads for it: the host stages of a batch (sequence
   // fetches, CIGAR surgery, PAF text) run while the device works on another
-  const size_t per_gpu = (size_t)param.threads >= 12 * ngpu ? 3 : ((size_t)param.threads >= 2 * ngpu ? 2 : 1);
+  static const size_t workers_env = getenv("WFM_ALIGN_WORKERS") ? (size_t)std::max(1, atoi(getenv("WFM_ALIGN_WORKERS"))) : 0;  // A/B runs
+  const size_t per_gpu = workers_env ? workers_env : ((size_t)param.threads >= 12 * ngpu ? 3 : ((size_t)param.threads >= 2 * ngpu ? 2 : 1));
   const size_t nworkers = ngpu * per_gpu;
   // several GPUs: no batch may hold more than an eighth of one GPU's share of the file.  One GPU: a file of one batch
   // stays one batch (WFM_ALIGN_MIN_BATCHES cuts it for A/B runs); a file of a few batches is cut into a multiple of the
@@ -393,7 +394,7 @@ Summary Aligner::compute() {
     auto& v = pool.by_device[dev];
     int slot = -1;
     for (size_t q = 0; q < v.size(); ++q) if (!v[q].second) { slot = (int)q; break; }
-    if (slot < 0 && v.size() < 2) {
+    if (slot < 0 && v.size() + 1 < std::max<size_t>(3, per_gpu)) {
       wfm_handle_t* nh = nullptr;
       if (wfm_create(dev, &nh) == WFM_OK) { v.emplace_back(nh, false); slot = (int)v.size() - 1; }
     }
