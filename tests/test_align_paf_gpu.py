@@ -165,3 +165,34 @@ def test_align_sam_with_md_matches_reference_restatement(gpu, tmp_path):
     assert len(body) == len(exp) and len(body) >= 20
     for a, b in zip(body, exp):
         assert a == b, (a[:150], b[:150])
+
+
+def test_align_paf_bytes_do_not_depend_on_batching_or_on_a_seekable_input(gpu, tmp_path):
+    """The align driver sizes its batches from the mapping file's size and first rows, and cuts small files into several batches
+    on request: the output is the same bytes however the file is cut (WFM_ALIGN_MIN_BATCHES, WFM_ALIGN_LEVEL: read once per
+    process, hence the subprocesses), and a mapping file that cannot be rewound (a FIFO) is read as it comes."""
+    import subprocess
+    import sys
+    import threading
+    fa, paf, seqs, lines = _make_case(tmp_path, 21)
+    ref = str(tmp_path / "ref.paf")
+    capi.align_paf(gpu, fa, paf, ref)
+    want = open(ref, "rb").read()
+    assert want.count(b"\n") >= 20
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r)\nfrom wfmash_amd import capi\nh = capi.Handle(0)\n"
+            "s = capi.align_paf(h, sys.argv[1], sys.argv[2], sys.argv[3])\nprint(int(s.batches))\nh.close()\n") % root
+    for env_add, min_batches in (({"WFM_ALIGN_MIN_BATCHES": "5"}, 4), ({"WFM_ALIGN_MIN_BATCHES": "3", "WFM_ALIGN_LEVEL": "0"}, 2)):
+        out = str(tmp_path / "cut.paf")
+        r = subprocess.run([sys.executable, "-c", code, fa, paf, out], env=dict(os.environ, **env_add), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert int(r.stdout.strip().splitlines()[-1]) >= min_batches
+        assert open(out, "rb").read() == want
+    fifo = str(tmp_path / "map.fifo")
+    os.mkfifo(fifo)
+    t = threading.Thread(target=lambda: open(fifo, "wb").write(open(paf, "rb").read()))
+    t.start()
+    out = str(tmp_path / "fifo.paf")
+    capi.align_paf(gpu, fa, fifo, out)
+    t.join()
+    assert open(out, "rb").read() == want

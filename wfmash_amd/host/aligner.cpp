@@ -324,10 +324,16 @@ Summary Aligner::compute() {
   static const uint64_t min_batches = getenv("WFM_ALIGN_MIN_BATCHES") ? (uint64_t)std::max(1, atoi(getenv("WFM_ALIGN_MIN_BATCHES"))) : 1;
   static const bool level_batches = !(getenv("WFM_ALIGN_LEVEL") && atoi(getenv("WFM_ALIGN_LEVEL")) == 0);
   {
+    // (a mapping file that cannot be rewound -- a FIFO, /dev/stdin -- is read as it comes: no size, no look ahead)
     in.seekg(0, std::ios::end);
-    const uint64_t file_bytes = (uint64_t)std::max<std::streamoff>(0, in.tellg());
-    in.seekg(0, std::ios::beg);
+    const std::streamoff end_at = in.fail() ? (std::streamoff)-1 : (std::streamoff)in.tellg();
+    in.clear();
+    if (end_at >= 0) in.seekg(0, std::ios::beg);
+    const bool seekable = end_at >= 0 && !in.fail();
+    in.clear();
+    const uint64_t file_bytes = seekable ? (uint64_t)end_at : 0;
     uint64_t want = ngpu > 1 ? 8 * ngpu : min_batches;
+    if (!seekable) want = 1;
     if (level_batches && nworkers > 1 && file_bytes > 0) {
       uint64_t rows = 0, bytes = 0, bases = 0;
       std::string line;
