@@ -424,7 +424,7 @@ int upload_normalised(wfm_handle_t* h, Scoped& sc, const char* seq, int64_t len,
   HIPCHK(h, sc.alloc(&d_raw, padded));
   HIPCHK(h, sc.alloc(d_norm, padded));
   hipStream_t st = wfm_stream(h);
-  HIPCHK(h, hipMemsetAsync(*d_norm, 'N', padded, st));
+  HIPCHK(h, hipMemsetAsync(*d_norm + len, 'N', padded - (size_t)len, st));  // (only the padding: normalize_kernel writes every base)
   HIPCHK(h, hipMemcpyAsync(d_raw, seq, (size_t)len, hipMemcpyHostToDevice, st));
   const int64_t nthreads = (len + 15) / 16;
   const int blocks = (int)((nthreads + 255) / 256);
@@ -519,7 +519,7 @@ int map_hash_sequence_device(wfm_handle_t* h, const char* seq, int64_t len, int 
   if ((e = wfm_dmalloc((void**)&out->d_norm, padded)) != hipSuccess) return fail(e, "hipMalloc");
   if ((e = wfm_dmalloc((void**)&out->d_hash, (size_t)out->nk * 8)) != hipSuccess) return fail(e, "hipMalloc");
   if ((e = wfm_dmalloc((void**)&out->d_strand, (size_t)out->nk)) != hipSuccess) return fail(e, "hipMalloc");
-  if ((e = hipMemsetAsync(out->d_norm, 'N', padded, st)) != hipSuccess) return fail(e, "hipMemsetAsync");
+  if ((e = hipMemsetAsync(out->d_norm + len, 'N', padded - (size_t)len, st)) != hipSuccess) return fail(e, "hipMemsetAsync");
   if ((e = hipMemcpyAsync(d_raw, seq, (size_t)len, hipMemcpyHostToDevice, st)) != hipSuccess) return fail(e, "hipMemcpyAsync");
   const int64_t nthreads = (len + 15) / 16;
   hipLaunchKernelGGL(normalize_kernel, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, st, d_raw, out->d_norm, len);
