@@ -1081,6 +1081,7 @@ int align_resident_impl(wfm_handle* h, const wfm_penalties_t* pen, wfm_seqset* S
           }
         }
         h->stats.bp_jobs += (uint32_t)jobs.size();
+        const int dbg_lvl = getenv("WFM_DEBUG") ? std::max(1, atoi(getenv("WFM_DEBUG"))) : 0;  // (once per chunk, not once per job)
         for (size_t q = 0; q < jobs.size(); ++q) {
           const Node nd = bp_nodes[(size_t)node_of[q]];  // a copy: retries are appended to bp_nodes below
           const BpResult& r = res[q];
@@ -1124,7 +1125,7 @@ int align_resident_impl(wfm_handle* h, const wfm_penalties_t* pen, wfm_seqset* S
               }
               prob_status[nd.prob] = WFM_ST_UNREACHABLE; continue;
             }
-            if (getenv("WFM_DEBUG") && atoi(getenv("WFM_DEBUG")) > 1) fprintf(stderr, "[wfm] problem %d level %u: job pl %d tl %d cb %d ce %d rem %d -> bp v %d h %d score %d = %d + %d comp %d\n", nd.prob, level, nd.pl, nd.tl, nd.cb, nd.ce, nd.score_rem, bp_v, bp_h, r.score, r.score_fwd, r.score_rev, r.comp);
+            if (dbg_lvl > 1) fprintf(stderr, "[wfm] problem %d level %u: job pl %d tl %d cb %d ce %d rem %d -> bp v %d h %d score %d = %d + %d comp %d\n", nd.prob, level, nd.pl, nd.tl, nd.cb, nd.ce, nd.score_rem, bp_v, bp_h, r.score, r.score_fwd, r.score_rev, r.comp);
             Node a{}, b{};
             a.prob = nd.prob; a.pb = nd.pb; a.pl = bp_v; a.tb = nd.tb; a.tl = bp_h;
             // what a child can cost: the score its parent found for it, plus the opening of a gap it begins or ends in
