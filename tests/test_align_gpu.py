@@ -460,7 +460,7 @@ def test_exact_bounds_on_small_batches_with_reused_rings(oracle):
 
 def test_phase2_walks_longer_than_the_rows_computed_ahead(gpu, oracle, monkeypatch):
     """Unrelated or rearranged sequences: the antidiagonals of the two directions touch long before any two cells share a
-    diagonal, so the overlap loop runs for hundreds of tests -- more than the 2 x 48 the rows computed ahead cover.  Such jobs
+    diagonal, so the overlap loop runs for hundreds of tests -- more than the 2 x 32 the rows computed ahead cover.  Such jobs
     go further rounds of rows computed ahead (the breakpoint so far carried along) instead of the step-by-step kernel; the
     result is the oracle's either way, whatever the number of rounds allowed."""
     items = []

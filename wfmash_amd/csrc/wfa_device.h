@@ -91,7 +91,8 @@ struct TileJob {
 // the tests left in it (doing all tests of a job side by side was tried: without the best breakpoint so far to prune
 // with, the tests after the first hit cost more than the whole sequential walk).  A job whose loop has not ended after
 // 2 * P2K tests (WFM_DEV_P2_MORE) is finished by wfa_bp_kernel from the same snapshot.
-constexpr int P2K = 48;
+constexpr int P2K = 32;            // (48 until jobs could take further rounds: most walks end within 2 x 26 tests, and the rows of the
+                                    // others are computed when they are asked for -- C3 109 -> 106 ms per step, C1 substitute 5.5 -> 5.4 s)
 constexpr int P2ROWS = 26 + P2K;   // row maxima per direction: the snapshot's rows sd-25 .. sd, then sd+1 .. sd+P2K
 constexpr int P2TESTS = 2 * P2K;
 constexpr int P2ENT = RING * 5;    // (row of the other direction, component) slots of a test; scope <= RING rows are used
