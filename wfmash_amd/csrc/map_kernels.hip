@@ -526,7 +526,7 @@ int map_hash_sequence_device(wfm_handle_t* h, const char* seq, int64_t len, int 
   launch_kmer_hash(out->d_norm, out->nk, k, out->d_hash, out->d_strand, st);
   if ((e = hipGetLastError()) != hipSuccess) return fail(e, "kernel launch");
   if ((e = hipStreamSynchronize(st)) != hipSuccess) return fail(e, "hipStreamSynchronize");
-  (void)wfm_dfree(d_raw);
+  wfm_dfree_nosync(d_raw);  // (its only user, normalize_kernel on st, has finished)
   return WFM_OK;
 }
 
