@@ -5,8 +5,11 @@ A "step" is one pass of the hot path (BiWFA gap-affine-2p alignment, penalties
 5,8,2,24,1; wflign.cpp:136-148) over one batch of synthetic mapping records:
 BASELINE.json configs[2], "synthetic 5%-divergence 64x50kb segment pairs,
 WFA-only (mappings pre-supplied), 1 GPU" (generator: SURVEY.md 8d / wfmash_amd/synth.py).
-configs[1] (LPA.subset all-vs-all) needs the reference's data file, which does
-not travel to the GPU box; it is covered as a parity case, not a bench line.
+The other configs are reported in the same line as `secondary` legs, driver-timed end to end
+through the C ABI and each with a sampled parity check against the oracles: C1 (substitute:
+synth.yeast_like, the data blob is absent), C2 (LPA.subset all-vs-all, the reference's test data,
+a committed fixture), one rank of C4 at two sizes, C5; `value` stays C3, the largest
+configuration BASELINE.json quotes on one GPU.
 
 Sequences are resident in HBM before the timed region (wfm_upload_sequences);
 the timed region is K calls of wfm_align_resident (all recursion levels, the
