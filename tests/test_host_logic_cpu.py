@@ -216,3 +216,35 @@ def test_paf_writer_run_form_matches_oracle():
         exp = W.write_alignment_paf(c, "q#1", qoff + qlen + 77, qoff, qlen, rev, "t#2", toff + tlen + 99, toff, mm, cid, clen, cpos)
         assert got == ("\t".join(exp.split()) + "\n" if exp else ""), (c, meta)
         assert got == ("\t".join(capi.host_cigar_fn("paf", c, meta).split()) + "\n" if exp else "")
+
+
+def test_batch_plan_levels_a_few_batches_over_the_workers():
+    """Aligner::plan_batch_bytes (host/aligner.cpp): a mapping file of one batch stays one batch; a file of a few batches is cut
+    into a multiple of the workers' number, never into fewer batches than the caps on records and bases demand; many batches are
+    left to the caps; several GPUs get at least eight batches each; a file that cannot be rewound is read as it comes."""
+    import math
+    import random
+    NOLIMIT = 2 ** 64 - 1
+    P = capi.host_plan_batch_bytes
+    rng = random.Random(3)
+    for _ in range(3000):
+        nworkers = rng.choice([1, 2, 3, 4, 6])
+        rows = rng.randrange(1, 257)
+        avg_line = rng.randrange(60, 400)
+        avg_bases = rng.randrange(500, 60000)
+        n_rec = rng.choice([1, 5, 300, 1536, 1537, 4000, 6000, 47719, 300000])
+        file_bytes = n_rec * avg_line
+        cap_rec, cap_bases = 1536, 160_000_000
+        b = P(file_bytes, rows, rows * avg_line, rows * avg_bases, cap_rec, cap_bases, nworkers)
+        need = math.ceil(max(n_rec / cap_rec, n_rec * avg_bases / cap_bases))
+        if nworkers == 1 or need < 2 or need >= 8 * nworkers:
+            assert b == NOLIMIT
+            continue
+        n_batches = math.ceil(file_bytes / b)
+        assert n_batches >= need and n_batches <= need + nworkers
+        want = (need + nworkers - 1) // nworkers * nworkers
+        assert b == file_bytes // want + 1
+    assert P(0, 0, 0, 0, 1536, 160_000_000, 3) == NOLIMIT                      # a FIFO: nothing known
+    assert P(10_000, 50, 5000, 50 * 3000, 1536, 160_000_000, 3, level=False) == NOLIMIT
+    assert P(10_000, 50, 5000, 50 * 3000, 1536, 160_000_000, 3, min_batches=5) == 10_000 // 5 + 1   # WFM_ALIGN_MIN_BATCHES
+    assert P(1_000_000, 0, 0, 0, 1536, 160_000_000, 6, ngpu=2) == 1_000_000 // 16 + 1               # two GPUs: sixteen batches at least

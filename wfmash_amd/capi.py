@@ -759,6 +759,14 @@ def host_cigar_fn(fn, a=b"", b=b"", query=b"", target=b"", i0=0, i1=0) -> str:
     return s
 
 
+def host_plan_batch_bytes(file_bytes, rows, row_bytes, row_bases_sum, batch_records, batch_bases, nworkers, ngpu=1, min_batches=1, level=True) -> int:
+    """Aligner::plan_batch_bytes: bytes of the mapping file one batch may hold (2**64 - 1: no limit)."""
+    L = _host()
+    L.wfmh_test_plan_batch_bytes.restype = C.c_ulonglong
+    L.wfmh_test_plan_batch_bytes.argtypes = [C.c_ulonglong] * 9 + [C.c_int]
+    return int(L.wfmh_test_plan_batch_bytes(file_bytes, rows, row_bytes, row_bases_sum, batch_records, batch_bases, nworkers, ngpu, min_batches, 1 if level else 0))
+
+
 def align_paf(handle, target_fasta, mapping_paf, out_paf, query_fasta=None, params=None):
     """wfmh_align_paf: the align phase on files (mapping PAF in, aligned PAF out)."""
     L = _host()

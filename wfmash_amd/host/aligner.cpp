@@ -280,6 +280,19 @@ std::string Aligner::align_lines(const std::vector<std::string>& lines, Summary&
 }
 
 // bases a mapping row will align, padding aside (the reader sizes batches by it)
+uint64_t Aligner::plan_batch_bytes(uint64_t file_bytes, uint64_t rows, uint64_t row_bytes, uint64_t row_bases_sum, uint64_t batch_records,
+                                   uint64_t batch_bases, uint64_t nworkers, uint64_t ngpu, uint64_t min_batches, bool level) {
+  if (file_bytes == 0) return ~0ull;
+  uint64_t want = ngpu > 1 ? 8 * ngpu : std::max<uint64_t>(1, min_batches);
+  if (level && nworkers > 1 && rows > 0 && row_bytes > 0) {
+    const double est_rows = (double)file_bytes / ((double)row_bytes / (double)rows);
+    const double est_bases = est_rows * ((double)row_bases_sum / (double)rows);
+    const uint64_t need = (uint64_t)std::ceil(std::max(est_rows / (double)std::max<uint64_t>(1, batch_records), est_bases / (double)std::max<uint64_t>(1, batch_bases)));
+    if (need >= 2 && need < 8 * nworkers) want = std::max<uint64_t>(want, (need + nworkers - 1) / nworkers * nworkers);
+  }
+  return want > 1 ? std::max<uint64_t>(1, file_bytes / want + 1) : ~0ull;
+}
+
 uint64_t Aligner::row_bases(const std::string& line) {
   uint64_t v[9] = {0};
   size_t pos = 0;
@@ -332,10 +345,8 @@ Summary Aligner::compute() {
     const bool seekable = end_at >= 0 && !in.fail();
     in.clear();
     const uint64_t file_bytes = seekable ? (uint64_t)end_at : 0;
-    uint64_t want = ngpu > 1 ? 8 * ngpu : min_batches;
-    if (!seekable) want = 1;
+    uint64_t rows = 0, bytes = 0, bases = 0;
     if (level_batches && nworkers > 1 && file_bytes > 0) {
-      uint64_t rows = 0, bytes = 0, bases = 0;
       std::string line;
       while (rows < 256 && std::getline(in, line)) {
         if (line.empty()) continue;
@@ -343,14 +354,8 @@ Summary Aligner::compute() {
       }
       in.clear();
       in.seekg(0, std::ios::beg);
-      if (rows > 0) {
-        const double est_rows = (double)file_bytes / ((double)bytes / (double)rows);
-        const double est_bases = est_rows * ((double)bases / (double)rows);
-        const uint64_t need = (uint64_t)std::ceil(std::max(est_rows / (double)param.batch_records, est_bases / (double)param.batch_bases));
-        if (need >= 2 && need < 8 * nworkers) want = std::max<uint64_t>(want, (need + nworkers - 1) / nworkers * nworkers);
-      }
     }
-    if (want > 1) batch_bytes = std::max<uint64_t>(1, file_bytes / want + 1);
+    batch_bytes = plan_batch_bytes(file_bytes, rows, bytes, bases, param.batch_records, param.batch_bases, nworkers, ngpu, min_batches, level_batches);
   }
   std::mutex read_mu, write_mu;
   uint64_t next_seq = 0, next_write = 0;

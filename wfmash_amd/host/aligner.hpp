@@ -80,6 +80,10 @@ class Aligner {
   Summary compute();  // streams param.mashmapPafFile through the GPUs into param.pafOutputFile
   // Aligns mapping lines already in memory on the first GPU; returns the PAF text.
   std::string align_lines(const std::vector<std::string>& lines, Summary& sum);
+  // Bytes of the mapping file one batch may hold (~0: no limit beyond batch_records / batch_bases).  file_bytes = 0: the
+  // file cannot be rewound or is empty.  rows / row_bytes / row_bases_sum: the first rows looked at (rows = 0: none).
+  static uint64_t plan_batch_bytes(uint64_t file_bytes, uint64_t rows, uint64_t row_bytes, uint64_t row_bases_sum, uint64_t batch_records,
+                                   uint64_t batch_bases, uint64_t nworkers, uint64_t ngpu, uint64_t min_batches, bool level);
 
  private:
   std::string align_batch(wfm_handle_t* gpu, std::vector<std::string>& lines, int threads, Summary& sum);

@@ -85,6 +85,13 @@ extern "C" {
 
 void wfmh_free(char* p) { free(p); }
 
+// test hook: the align driver's batch plan (Aligner::plan_batch_bytes), pure arithmetic
+unsigned long long wfmh_test_plan_batch_bytes(unsigned long long file_bytes, unsigned long long rows, unsigned long long row_bytes,
+                                              unsigned long long row_bases_sum, unsigned long long batch_records, unsigned long long batch_bases,
+                                              unsigned long long nworkers, unsigned long long ngpu, unsigned long long min_batches, int level) {
+  return align::Aligner::plan_batch_bytes(file_bytes, rows, row_bytes, row_bases_sum, batch_records, batch_bases, nworkers, ngpu, min_batches, level != 0);
+}
+
 char* wfmh_test_cigar(const char* fn, const char* a, const char* b, const char* query, const char* target,
                       long long i0, long long i1) {
   std::string f = fn ? fn : "", sa = a ? a : "", sb = b ? b : "", q = query ? query : "", t = target ? target : "";
