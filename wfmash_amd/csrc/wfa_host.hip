@@ -944,11 +944,11 @@ int align_resident_impl(wfm_handle* h, const wfm_penalties_t* pen, wfm_seqset* S
         const size_t need = width * 2 * 5 * RR * (tile_it ? 2 : 1);
         // (a chunk of a level stops at 4 GB of rings even when the budget allows more: hundreds of jobs fill the device
         // long before that, and every GB of a first allocation costs 30 - 70 ms.  C1 substitute, three handles in a fresh
-        // process: 8 GB chunks 8.3 s cold / 5.33 s warm, 4 GB 5.67 / 5.52, 2 GB 6.22 / 6.06 -- scripts/c1_cold.sh.  A level of
-        // fewer than 512 jobs keeps 8 GB: C3's 21 roots of a part are 5.4 GB of full rings, and cut in two they fill the device worse.
+        // process: 8 GB chunks 8.3 s cold / 5.33 s warm, 4 GB 5.67 / 5.52, 2 GB 6.22 / 6.06 -- scripts/c1_cold.sh.  A chunk of
+        // fewer than 128 jobs may grow to 8 GB: C3's 21 roots of a part are 5.4 GB of full rings, and cut in two they fill the device worse.
         // Tried and dropped: two launches per block, jobs without a score bound apart from those with one -- the plain kernel form
         // has 7 % fewer instructions, the second launch cost more: C2 0.18 -> 0.21 s, C1 no better)
-        if (!jobs.empty() && (ring_elems + need) * 4 > std::min<size_t>(h->mem_budget, bp_nodes.size() >= 512 ? ring_chunk_bytes : std::max(ring_chunk_bytes, (size_t)8 << 30))) break;
+        if (!jobs.empty() && (ring_elems + need) * 4 > std::min<size_t>(h->mem_budget, jobs.size() >= 128 ? ring_chunk_bytes : std::max(ring_chunk_bytes, (size_t)8 << 30))) break;
         if (need * 4 > h->mem_budget) { prob_status[nd.prob] = WFM_ST_OOM; continue; }
         BpJob j{};
         j.p_fwd = pm.p_fwd + nd.pb;
@@ -1551,7 +1551,14 @@ int align_resident_any(wfm_handle_t* h, const wfm_penalties_t* pen, wfm_seqset_t
   size_t parts = std::min<size_t>(std::min<size_t>((size_t)want, n / 4), h->mem_budget_full >> 28);
   // A batch of hundreds of problems fills the device on its own -- its levels are thousands of workgroups wide -- and the
   // align driver keeps further batches in flight on handles of their own: such a batch runs as one part
-  if (!getenv("WFM_STREAMS") && n >= 512) parts = 1;
+  // -- when its problems come with score hints, i.e. from a driver that knows them to be near-identical records.  Hundreds of
+  // problems nobody has said anything about (the strong-scaling bench at N = 1: 512 pairs at 5 %) are deep, run in many
+  // chunks of full rings, and gain from parts as 64 of them do (512 pairs: 1136 ms as one part)
+  if (!getenv("WFM_STREAMS") && n >= 512) {
+    size_t hinted = 0, biwfa = 0;  // (patch calls -- ends-free problems only -- stay one part)
+    for (size_t i = 0; i < n; ++i) { biwfa += s->meta[i].mode == WFM_MODE_END2END_BIWFA; hinted += s->meta[i].hint > 0; }
+    if (biwfa == 0 || hinted * 2 >= biwfa) parts = 1;
+  }
   if (!getenv("WFM_STREAMS") && parts > 2) {
     // a batch whose full rings would not fit the budget -- thousands of long records, which then run on narrow
     // rings -- is bound by the host's work between the many small launches: measured best with two parts
