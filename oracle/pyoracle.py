@@ -62,6 +62,8 @@ def lib():
         L.wfo_align_end2end_comp.argtypes = [cp, ci, cp, ci, PP, ci, ci, C.c_char_p, pi, pi, SP]
         L.wfo_find_breakpoint.restype = ci
         L.wfo_find_breakpoint.argtypes = [cp, ci, cp, ci, PP, ci, ci, C.POINTER(Breakpoint), SP]
+        L.wfo_find_breakpoint_rounds.restype = ci
+        L.wfo_find_breakpoint_rounds.argtypes = [cp, ci, cp, ci, PP, ci, ci, ci, ci, C.POINTER(Breakpoint), C.POINTER(ci), SP]
         L.wfo_find_breakpoint_bounded.restype = ci
         L.wfo_find_breakpoint_bounded.argtypes = [cp, ci, cp, ci, PP, ci, ci, ci, C.POINTER(Breakpoint), SP]
         L.wfo_ops_score.restype = C.c_int64
@@ -134,6 +136,16 @@ def find_breakpoint_bounded(pattern: bytes, text: bytes, sub: int, comp_begin=0,
     rc = lib().wfo_find_breakpoint_bounded(pattern, len(pattern), text, len(text), C.byref(p), comp_begin, comp_end, sub,
                                            C.byref(bp), C.byref(st))
     return rc, bp, st
+
+
+def find_breakpoint_rounds(pattern: bytes, text: bytes, tests_per_round: int, sub: int = -1, comp_begin=0, comp_end=0, pen=None):
+    """the breakpoint search with its overlap loop cut every tests_per_round tests the way the product's phase 2 is (the
+    breakpoint so far set aside, the next round seeded with its score); sub < 0: no score bound.  -> rc, bp, rounds"""
+    p = _pen(pen)
+    bp, st, rounds = Breakpoint(), Stats(), C.c_int(0)
+    rc = lib().wfo_find_breakpoint_rounds(pattern, len(pattern), text, len(text), C.byref(p), comp_begin, comp_end, sub, tests_per_round,
+                                          C.byref(bp), C.byref(rounds), C.byref(st))
+    return rc, bp, rounds.value
 
 
 def ops_score(ops: bytes, pen=None) -> int:

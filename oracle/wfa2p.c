@@ -590,17 +590,25 @@ static void overlap(const al_t* a0, const al_t* a1, int s0, int s1, int fwd0, wf
 
 /* wavefront_bialign_find_breakpoint */
 static int find_breakpoint_sub(const char* p, int plen, const char* t, int tlen, const wfo_penalties_t* pen,
-                               int comp_begin, int comp_end, wfo_breakpoint_t* bp, wfo_stats_t* st, int bounded, int sub);
+                               int comp_begin, int comp_end, wfo_breakpoint_t* bp, wfo_stats_t* st, int bounded, int sub,
+                               int tests_per_round, int* rounds_out);
 static int find_breakpoint(const char* p, int plen, const char* t, int tlen, const wfo_penalties_t* pen,
                            int comp_begin, int comp_end, wfo_breakpoint_t* bp, wfo_stats_t* st) {
-  return find_breakpoint_sub(p, plen, t, tlen, pen, comp_begin, comp_end, bp, st, 0, 0);
+  return find_breakpoint_sub(p, plen, t, tlen, pen, comp_begin, comp_end, bp, st, 0, 0, 0, NULL);
 }
 /* bounded != 0: the product's form of the search under an upper bound `sub` of the score -- rows cut as above, and the
  * second loop starts as if a breakpoint of score sub + 1 were in hand.  Returns ST_OK with bp->score <= sub, or
  * ST_UNREACHABLE when nothing lies within the bound. */
+/* tests_per_round > 0: the product's phase 2 in rounds (wfa_host.hip, run_p2_phase / wfa_p2_overlap_kernel): after that many
+ * tests the walk is cut -- what it has taken so far is set aside, the next round starts "as if a breakpoint of that score
+ * were in hand" with an empty record of its own, and when the loop ends in a round that took nothing the one set aside
+ * stands (WFM_DEV_P2_NOTHING). */
 static int find_breakpoint_sub(const char* p, int plen, const char* t, int tlen, const wfo_penalties_t* pen,
-                               int comp_begin, int comp_end, wfo_breakpoint_t* bp, wfo_stats_t* st, int bounded, int sub) {
+                               int comp_begin, int comp_end, wfo_breakpoint_t* bp, wfo_stats_t* st, int bounded, int sub,
+                               int tests_per_round, int* rounds_out) {
   al_t f, r;
+  wfo_breakpoint_t carry;
+  int have_carry = 0, tests = 0, rounds = 1;
   int rc = al_init(&f, p, plen, t, tlen, pen, 1, 0, st);
   if (rc != ST_OK) { al_free(&f); return rc; }
   rc = al_init(&r, p, plen, t, tlen, pen, 1, 1, st);
@@ -641,17 +649,30 @@ static int find_breakpoint_sub(const char* p, int plen, const char* t, int tlen,
     const int scope = f.scope;
     const int gopen = MAXI(pen->o1, pen->o2);
     for (;;) {
+#define WFO_ROUND_CUT()                                                                                   \
+  do {                                                                                                     \
+    if (tests_per_round > 0 && tests > 0 && tests % tests_per_round == 0) {                                \
+      if (bp->component >= 0) { carry = *bp; have_carry = 1; }                                             \
+      const int seed = bp->score;                                                                          \
+      memset(bp, 0, sizeof(*bp)); bp->score = seed; bp->component = -1;  /* a record of the round's own */ \
+      ++rounds;                                                                                            \
+    }                                                                                                      \
+  } while (0)
       if (last_fwd) {
         const int min_sr = (sr > scope - 1) ? sr - (scope - 1) : 0;
         if (sf + min_sr - gopen >= bp->score) break;
+        WFO_ROUND_CUT();
         overlap(&f, &r, sf, sr, 1, bp);
+        ++tests;
         ++sr;
         if ((rc = compute_step(&r, sr)) != ST_OK) goto done;
         extend_step(&r, sr, NULL, 1);
       }
       const int min_sf = (sf > scope - 1) ? sf - (scope - 1) : 0;
       if (min_sf + sr - gopen >= bp->score) break;
+      WFO_ROUND_CUT();
       overlap(&r, &f, sr, sf, 0, bp);
+      ++tests;
       ++sf;
       if ((rc = compute_step(&f, sf)) != ST_OK) goto done;
       extend_step(&f, sf, NULL, 1);
@@ -659,6 +680,8 @@ static int find_breakpoint_sub(const char* p, int plen, const char* t, int tlen,
       last_fwd = 1;
     }
   }
+  if (bp->component < 0 && have_carry) *bp = carry;       /* the last round took nothing: the one set aside stands */
+  if (rounds_out) *rounds_out = rounds;
   if (bounded && bp->component < 0) rc = ST_UNREACHABLE;  /* the loop ended on the stand-in, no breakpoint was taken */
 done:
   al_free(&f); al_free(&r);
@@ -729,7 +752,13 @@ int wfo_find_breakpoint(const char* pattern, int plen, const char* text, int tle
 int wfo_find_breakpoint_bounded(const char* pattern, int plen, const char* text, int tlen,
                                 const wfo_penalties_t* pen, int comp_begin, int comp_end, int sub,
                                 wfo_breakpoint_t* bp, wfo_stats_t* stats) {
-  return find_breakpoint_sub(pattern, plen, text, tlen, pen, comp_begin, comp_end, bp, stats, 1, sub);
+  return find_breakpoint_sub(pattern, plen, text, tlen, pen, comp_begin, comp_end, bp, stats, 1, sub, 0, NULL);
+}
+
+int wfo_find_breakpoint_rounds(const char* pattern, int plen, const char* text, int tlen,
+                               const wfo_penalties_t* pen, int comp_begin, int comp_end, int sub, int tests_per_round,
+                               wfo_breakpoint_t* bp, int* rounds, wfo_stats_t* stats) {
+  return find_breakpoint_sub(pattern, plen, text, tlen, pen, comp_begin, comp_end, bp, stats, sub >= 0, sub >= 0 ? sub : 0, tests_per_round, rounds);
 }
 
 int wfo_align_end2end_biwfa(const char* pattern, int plen, const char* text, int tlen,

@@ -109,6 +109,11 @@ int wfo_find_breakpoint(const char* pattern, int plen, const char* text, int tle
 int wfo_find_breakpoint_bounded(const char* pattern, int plen, const char* text, int tlen,
                                 const wfo_penalties_t* pen, int comp_begin, int comp_end, int sub,
                                 wfo_breakpoint_t* bp, wfo_stats_t* stats);
+/* The same search with its overlap loop cut every `tests_per_round` tests the way the product cuts it (phase 2 in rounds:
+ * the breakpoint so far set aside, the next round seeded with its score); sub < 0: no bound.  *rounds = rounds taken. */
+int wfo_find_breakpoint_rounds(const char* pattern, int plen, const char* text, int tlen,
+                               const wfo_penalties_t* pen, int comp_begin, int comp_end, int sub, int tests_per_round,
+                               wfo_breakpoint_t* bp, int* rounds, wfo_stats_t* stats);
 
 /* Score implied by an op string under the reference's cost model
  * (wflign_alignment.cpp:680-722: a gap run of length L costs

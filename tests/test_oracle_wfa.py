@@ -191,3 +191,40 @@ def test_a_score_bound_does_not_change_the_breakpoint(oracle):
             assert rc != 0, (i, shape, cb, ce, S, sub, bp.score)
             failed_as_expected += 1
     assert checked > 700 and failed_as_expected > 250 and fewer_cells > 200, (checked, failed_as_expected, fewer_cells)
+
+
+def test_cutting_the_overlap_loop_into_rounds_does_not_change_the_breakpoint(oracle):
+    """The product's phase 2 runs in rounds of 2 x 32 tests: a job whose loop has not ended takes another round from the state it
+    is in, the breakpoint so far set aside and its score handed on as if it were a bound (BpJob::best0); a round that ends the loop
+    without a better one reports WFM_DEV_P2_NOTHING and the one set aside stands.  The protocol on the CPU restatement of the
+    reference's loop (oracle/wfa2p.c: wfo_find_breakpoint_rounds): the same breakpoint, field for field, for any round length, with
+    and without a score bound -- on records whose loop is long (unrelated sequences, moved blocks: the antidiagonals touch long
+    before two cells share a diagonal) as well as ordinary ones."""
+    rng = random.Random(41)
+    fields = ("score", "score_forward", "score_reverse", "k_forward", "k_reverse", "offset_forward", "offset_reverse", "component")
+    multi = checked = 0
+    for i in range(120):
+        shape = i % 4
+        if shape == 0:    # unrelated
+            a, b = synth.random_dna(100 + i, rng.choice([300, 700])), synth.random_dna(300 + i, rng.choice([250, 800]))
+        elif shape == 1:  # a block moved to the end
+            u, v, w = synth.random_dna(500 + i, 300), synth.random_dna(700 + i, 200), synth.random_dna(900 + i, 300)
+            a, b = u + v + w, u + w + synth.mutate(v, 0.03, i)
+        elif shape == 2:  # ordinary divergence
+            a = synth.random_dna(1100 + i, 900)
+            b = synth.mutate(a, rng.choice([0.02, 0.1]), 7 * i)
+        else:             # padded window
+            b = synth.random_dna(1300 + i, 600)
+            a = synth.random_dna(1500 + i, 150) + synth.mutate(b, 0.01, 3 * i) + synth.random_dna(1700 + i, 90)
+        cb, ce = (rng.randrange(0, 5), rng.randrange(0, 5)) if i % 5 == 0 else (0, 0)
+        rc0, bp0, _ = oracle.find_breakpoint(a, b, cb, ce)
+        if rc0 != 0:
+            continue
+        for per_round in (1, 2, 5, 16, 64):
+            for sub in (-1, bp0.score + 2 * 24 + 8 + rng.randrange(0, 50)):
+                rc, bp, rounds = oracle.find_breakpoint_rounds(a, b, per_round, sub, cb, ce)
+                assert rc == 0, (i, shape, per_round, sub, rc)
+                assert all(getattr(bp, f) == getattr(bp0, f) for f in fields), (i, shape, per_round, sub, rounds)
+                multi += rounds > 1
+                checked += 1
+    assert checked > 900 and multi > 600, (checked, multi)
