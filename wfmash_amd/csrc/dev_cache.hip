@@ -15,7 +15,7 @@ struct Cache {
   std::mutex mu;
   std::unordered_map<void*, Live> live;                          // every block handed out or cached
   std::map<std::pair<int, size_t>, std::vector<void*>> free_by;  // (device, class size) -> cached blocks
-  size_t cached = 0;
+  size_t cached[64] = {};                                        // bytes waiting per device
 };
 Cache& cache() { static Cache* c = new Cache; return *c; }  // (never destroyed: handles may outlive static destructors)
 
@@ -25,16 +25,33 @@ size_t class_of(size_t bytes) {
   const size_t step = (size_t)1 << (lg > 3 ? lg - 3 : 0);
   return (bytes + step - 1) / step * step;
 }
-size_t limit_bytes() {
-  static const size_t v = getenv("WFM_DEV_CACHE_GB") ? (size_t)atoll(getenv("WFM_DEV_CACHE_GB")) << 30 : (size_t)96 << 30;
-  return v;
+// What may wait per device: a third of that device's memory (96 GB of an MI355X's 288), or WFM_DEV_CACHE_GB
+size_t limit_bytes(int dev) {
+  static const long long env = getenv("WFM_DEV_CACHE_GB") ? atoll(getenv("WFM_DEV_CACHE_GB")) : -1;
+  if (env >= 0) return (size_t)env << 30;
+  static size_t per_dev[64] = {};
+  if (dev < 0 || dev >= 64) return (size_t)8 << 30;
+  if (!per_dev[dev]) {
+    size_t fr = 0, tot = 0;
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    if (cur != dev) (void)hipSetDevice(dev);
+    if (hipMemGetInfo(&fr, &tot) != hipSuccess) { (void)hipGetLastError(); tot = (size_t)24 << 30; }
+    if (cur != dev) (void)hipSetDevice(cur);
+    per_dev[dev] = tot / 3;
+  }
+  return per_dev[dev];
 }
-size_t trim_locked(Cache& c, std::vector<void*>& out) {
+// dev < 0: every device
+size_t trim_locked(Cache& c, std::vector<void*>& out, int dev) {
   size_t bytes = 0;
-  for (auto& kv : c.free_by)
-    for (void* p : kv.second) { out.push_back(p); bytes += kv.first.second; c.live.erase(p); }
-  c.free_by.clear();
-  c.cached = 0;
+  for (auto it = c.free_by.begin(); it != c.free_by.end();) {
+    if (dev >= 0 && it->first.first != dev) { ++it; continue; }
+    for (void* p : it->second) { out.push_back(p); bytes += it->first.second; c.live.erase(p); }
+    const int d = it->first.first;
+    if (d >= 0 && d < 64) c.cached[d] = 0;
+    it = c.free_by.erase(it);
+  }
   return bytes;
 }
 void put(void* p) {
@@ -45,9 +62,12 @@ void put(void* p) {
     auto it = c.live.find(p);
     if (it == c.live.end()) { evict.push_back(p); }  // not ours (should not happen): plain hipFree
     else {
-      c.free_by[{it->second.dev, it->second.size}].push_back(p);
-      c.cached += it->second.size;
-      if (c.cached > limit_bytes()) trim_locked(c, evict);
+      const int dev = it->second.dev;
+      c.free_by[{dev, it->second.size}].push_back(p);
+      if (dev >= 0 && dev < 64) {
+        c.cached[dev] += it->second.size;
+        if (c.cached[dev] > limit_bytes(dev)) trim_locked(c, evict, dev);  // only the device that is over: the others are not stalled
+      }
     }
   }
   for (void* q : evict) (void)hipFree(q);
@@ -66,7 +86,7 @@ hipError_t wfm_dmalloc(void** p, size_t bytes) {
     if (it != c.free_by.end() && !it->second.empty()) {
       *p = it->second.back();
       it->second.pop_back();
-      c.cached -= cls;
+      if (dev >= 0 && dev < 64) c.cached[dev] -= cls;
       return hipSuccess;
     }
   }
@@ -105,7 +125,7 @@ size_t wfm_dcache_trim(void) {
   size_t bytes;
   {
     std::lock_guard<std::mutex> lk(c.mu);
-    bytes = trim_locked(c, out);
+    bytes = trim_locked(c, out, -1);
   }
   for (void* q : out) (void)hipFree(q);
   return bytes;

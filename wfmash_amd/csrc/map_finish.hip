@@ -382,9 +382,10 @@ __global__ void finish_emit_kernel(const wfm_minmer_t* R, const uint32_t* order,
   out[off[i]] = R[order[i]];
 }
 
-int grow(MapFinishWork::Buf& b, size_t bytes) {
+// (only the stream the block was used on is waited for: a device-wide wait would stall the other device thread's stream)
+int grow(MapFinishWork::Buf& b, size_t bytes, hipStream_t st) {
   if (b.bytes >= bytes && b.p) return WFM_OK;
-  if (b.p) (void)wfm_dfree(b.p);
+  if (b.p) { (void)hipStreamSynchronize(st); wfm_dfree_nosync(b.p); }
   b.p = nullptr; b.bytes = 0;
   const size_t want = bytes + bytes / 4 + 256;
   if (wfm_dmalloc(&b.p, want) != hipSuccess) return WFM_E_NOMEM;
@@ -396,7 +397,7 @@ template <typename T>
 int excl_scan(wfm_handle_t* h, MapFinishWork* wk, const T* in, T* out, size_t n, hipStream_t st) {
   size_t tmp = 0;
   HIPCHK(h, rocprim::exclusive_scan(nullptr, tmp, in, out, (T)0, n, rocprim::plus<T>(), st));
-  if (grow(wk->tmp, tmp)) return WFM_E_NOMEM;
+  if (grow(wk->tmp, tmp, st)) return WFM_E_NOMEM;
   HIPCHK(h, rocprim::exclusive_scan(wk->tmp.p, tmp, in, out, (T)0, n, rocprim::plus<T>(), st));
   return WFM_OK;
 }
@@ -408,10 +409,10 @@ int sortlike_loop_device(wfm_handle_t* h, MapFinishWork* wk, uint64_t* key, uint
   if (n <= 16) return WFM_OK;
   const size_t cap_small = (size_t)n / 16 + 4, cap_big = (size_t)n / (size_t)SMALL_SEG + 4, cap_huge = (size_t)n / (size_t)HUGE_SEG + 4;
   const size_t cap_tiles = (size_t)n / HUGE_TILE + cap_huge + 4;
-  if (grow(wk->A, (size_t)n * 4) || grow(wk->B, (size_t)n * 4) || grow(wk->seg[0], cap_big * sizeof(Seg)) || grow(wk->seg[1], cap_big * sizeof(Seg)) ||
-      grow(wk->seg[2], cap_huge * sizeof(Seg)) || grow(wk->seg[3], cap_huge * sizeof(Seg)) || grow(wk->small_, cap_small * sizeof(Seg)) ||
-      grow(wk->heap, cap_small * sizeof(Seg)) || grow(wk->counts, 64) || grow(wk->tiles, cap_tiles * sizeof(HugeTile)) || grow(wk->tile_cnt, cap_tiles * sizeof(int2)) ||
-      grow(wk->tile0, (cap_huge + 1) * sizeof(int)) || grow(wk->info, cap_huge * sizeof(HugeInfo))) {
+  if (grow(wk->A, (size_t)n * 4, st) || grow(wk->B, (size_t)n * 4, st) || grow(wk->seg[0], cap_big * sizeof(Seg), st) || grow(wk->seg[1], cap_big * sizeof(Seg), st) ||
+      grow(wk->seg[2], cap_huge * sizeof(Seg), st) || grow(wk->seg[3], cap_huge * sizeof(Seg), st) || grow(wk->small_, cap_small * sizeof(Seg), st) ||
+      grow(wk->heap, cap_small * sizeof(Seg), st) || grow(wk->counts, 64, st) || grow(wk->tiles, cap_tiles * sizeof(HugeTile), st) || grow(wk->tile_cnt, cap_tiles * sizeof(int2), st) ||
+      grow(wk->tile0, (cap_huge + 1) * sizeof(int), st) || grow(wk->info, cap_huge * sizeof(HugeInfo), st)) {
     wfm_set_error(h, "out of device memory (closing sort)");
     return WFM_E_NOMEM;
   }
@@ -532,7 +533,7 @@ int map_finish_records_device(wfm_handle_t* h, const wfm_minmer_t* d_raw, int64_
   if (n_raw >= ((int64_t)1 << 31)) { wfm_set_error(h, "too many records for the closing sort"); return WFM_E_UNSUPPORTED; }
   hipStream_t st = stream ? stream : wfm_stream(h);
   const size_t nr = (size_t)n_raw;
-  if (grow(wk->ns, nr * 4 + 4) || grow(wk->np, nr * 4 + 4) || grow(wk->os, nr * 4 + 4) || grow(wk->op, nr * 4 + 4)) { wfm_set_error(h, "out of device memory (closing sort)"); return WFM_E_NOMEM; }
+  if (grow(wk->ns, nr * 4 + 4, st) || grow(wk->np, nr * 4 + 4, st) || grow(wk->os, nr * 4 + 4, st) || grow(wk->op, nr * 4 + 4, st)) { wfm_set_error(h, "out of device memory (closing sort)"); return WFM_E_NOMEM; }
   const unsigned gb = (unsigned)((nr + 255) / 256);
   hipLaunchKernelGGL(finish_count_kernel, dim3(gb), dim3(256), 0, st, d_raw, n_raw, w, (uint32_t*)wk->ns.p, (uint32_t*)wk->np.p);
   HIPCHK(h, hipGetLastError());
@@ -550,8 +551,8 @@ int map_finish_records_device(wfm_handle_t* h, const wfm_minmer_t* d_raw, int64_
   if (total == 0) { if (info) *info = inf; return WFM_OK; }
   if (total >= ((int64_t)1 << 31)) { wfm_set_error(h, "too many records for the closing sort"); return WFM_E_UNSUPPORTED; }
   const size_t nt = (size_t)total;
-  if (grow(wk->R, nt * sizeof(wfm_minmer_t)) || grow(wk->key, nt * 8) || grow(wk->idx, nt * 4) || grow(wk->key2, nt * 8) || grow(wk->idx2, nt * 4) ||
-      grow(wk->out, nt * sizeof(wfm_minmer_t))) {
+  if (grow(wk->R, nt * sizeof(wfm_minmer_t), st) || grow(wk->key, nt * 8, st) || grow(wk->idx, nt * 4, st) || grow(wk->key2, nt * 8, st) || grow(wk->idx2, nt * 4, st) ||
+      grow(wk->out, nt * sizeof(wfm_minmer_t), st)) {
     wfm_set_error(h, "out of device memory (closing sort)");
     return WFM_E_NOMEM;
   }
@@ -565,12 +566,12 @@ int map_finish_records_device(wfm_handle_t* h, const wfm_minmer_t* d_raw, int64_
   {  // the insertion sort that closes std::sort: stable, over everything
     size_t tmp = 0;
     HIPCHK(h, rocprim::radix_sort_pairs(nullptr, tmp, key, (uint64_t*)wk->key2.p, idx, (uint32_t*)wk->idx2.p, nt, 0, 64, st));
-    if (grow(wk->tmp, tmp)) { wfm_set_error(h, "out of device memory (closing sort)"); return WFM_E_NOMEM; }
+    if (grow(wk->tmp, tmp, st)) { wfm_set_error(h, "out of device memory (closing sort)"); return WFM_E_NOMEM; }
     HIPCHK(h, rocprim::radix_sort_pairs(wk->tmp.p, tmp, key, (uint64_t*)wk->key2.p, idx, (uint32_t*)wk->idx2.p, nt, 0, 64, st));
   }
   const uint32_t* order = (const uint32_t*)wk->idx2.p;
   // keep flags and their offsets reuse the count buffers (nt may exceed nr: pieces)
-  if (grow(wk->ns, nt * 4 + 4) || grow(wk->os, nt * 4 + 4)) { wfm_set_error(h, "out of device memory (closing sort)"); return WFM_E_NOMEM; }
+  if (grow(wk->ns, nt * 4 + 4, st) || grow(wk->os, nt * 4 + 4, st)) { wfm_set_error(h, "out of device memory (closing sort)"); return WFM_E_NOMEM; }
   const unsigned gt = (unsigned)((nt + 255) / 256);
   hipLaunchKernelGGL(finish_flag_kernel, dim3(gt), dim3(256), 0, st, R, order, total, (uint32_t*)wk->ns.p);
   HIPCHK(h, hipGetLastError());

@@ -636,9 +636,10 @@ void map_winnow_work_free(MapWinnowWork* wk) {
 }
 
 namespace {
-int grow(MapWinnowWork::Buf& b, size_t bytes) {
+// (only the stream the block was used on is waited for: a device-wide wait would stall the other device thread's stream)
+int grow(MapWinnowWork::Buf& b, size_t bytes, hipStream_t st) {
   if (b.bytes >= bytes && b.p) return WFM_OK;
-  if (b.p) (void)wfm_dfree(b.p);
+  if (b.p) { (void)hipStreamSynchronize(st); wfm_dfree_nosync(b.p); }
   b.p = nullptr; b.bytes = 0;
   const size_t want = bytes + bytes / 4 + 256;
   if (wfm_dmalloc(&b.p, want) != hipSuccess) return WFM_E_NOMEM;
@@ -693,9 +694,9 @@ int map_winnow_sparse_device(wfm_handle_t* h, const MapSparseSeq* sp, int64_t le
     ch.first = c == 0; ch.last = c + 1 == nc; ch.pad_ = 0;
   }
   const size_t cap = (size_t)cp.state_words;
-  if (grow(wk->chunks, (size_t)nc * sizeof(Chunk)) || grow(wk->recs, (size_t)rec_total * sizeof(Rec)) || grow(wk->count, (size_t)nc * 4) ||
-      grow(wk->st_begin, (size_t)nc * cap * 4) || grow(wk->st_end, (size_t)nc * cap * 4) || grow(wk->wp_end, (size_t)nc * (size_t)s * 4) ||
-      grow(wk->flags, (size_t)nc * 4 + 64) || grow(wk->off, (size_t)nc * 8)) {
+  if (grow(wk->chunks, (size_t)nc * sizeof(Chunk), st) || grow(wk->recs, (size_t)rec_total * sizeof(Rec), st) || grow(wk->count, (size_t)nc * 4, st) ||
+      grow(wk->st_begin, (size_t)nc * cap * 4, st) || grow(wk->st_end, (size_t)nc * cap * 4, st) || grow(wk->wp_end, (size_t)nc * (size_t)s * 4, st) ||
+      grow(wk->flags, (size_t)nc * 4 + 64, st) || grow(wk->off, (size_t)nc * 8, st)) {
     wfm_set_error(h, "out of device memory (winnowing)");
     return WFM_E_NOMEM;
   }
@@ -729,7 +730,7 @@ int map_winnow_sparse_device(wfm_handle_t* h, const MapSparseSeq* sp, int64_t le
       if (flags[(size_t)c] & (wn::F_POOL_FULL | wn::F_OCC_FULL)) todo.push_back(c);
     inf.rerun_chunks = (int)todo.size();
     if (!todo.empty() && lds <= 64 * 1024) {
-      if (grow(wk->todo, todo.size() * sizeof(int))) { wfm_set_error(h, "out of device memory (winnowing)"); return WFM_E_NOMEM; }
+      if (grow(wk->todo, todo.size() * sizeof(int), st)) { wfm_set_error(h, "out of device memory (winnowing)"); return WFM_E_NOMEM; }
       HIPCHK(h, hipMemcpyAsync(wk->todo.p, todo.data(), todo.size() * sizeof(int), hipMemcpyHostToDevice, st));
       hipLaunchKernelGGL(winnow_chunks_kernel<false>, dim3((unsigned)todo.size()), dim3(64), lds, st, prm, d_chunks, (const int*)wk->todo.p, cp.S, cp.P, cp.N, d_recs, d_count,
                          d_stb, d_ste, d_wpe, d_flags);
@@ -758,7 +759,7 @@ int map_winnow_sparse_device(wfm_handle_t* h, const MapSparseSeq* sp, int64_t le
       if (todo.empty()) break;
       if (round > 2 * nc + 8) { inf.why |= wn::F_MISMATCH; break; }
       inf.replays += (int)todo.size();
-      if (grow(wk->todo, (todo.size() + next.size() + 1) * sizeof(int))) { wfm_set_error(h, "out of device memory (winnowing)"); return WFM_E_NOMEM; }
+      if (grow(wk->todo, (todo.size() + next.size() + 1) * sizeof(int), st)) { wfm_set_error(h, "out of device memory (winnowing)"); return WFM_E_NOMEM; }
       int* d_todo = (int*)wk->todo.p;
       HIPCHK(h, hipMemcpyAsync(d_todo, todo.data(), todo.size() * sizeof(int), hipMemcpyHostToDevice, st));
       if (!next.empty()) HIPCHK(h, hipMemcpyAsync(d_todo + todo.size(), next.data(), next.size() * sizeof(int), hipMemcpyHostToDevice, st));
@@ -794,7 +795,7 @@ int map_winnow_sparse_device(wfm_handle_t* h, const MapSparseSeq* sp, int64_t le
   std::vector<int64_t> off((size_t)nc);
   int64_t total = 0;
   for (int c = 0; c < nc; ++c) { off[(size_t)c] = total; total += count[(size_t)c]; }
-  if (grow(wk->out, (size_t)std::max<int64_t>(total, 1) * sizeof(wfm_minmer_t))) { wfm_set_error(h, "out of device memory (winnowing)"); return WFM_E_NOMEM; }
+  if (grow(wk->out, (size_t)std::max<int64_t>(total, 1) * sizeof(wfm_minmer_t), st)) { wfm_set_error(h, "out of device memory (winnowing)"); return WFM_E_NOMEM; }
   HIPCHK(h, hipMemcpyAsync(wk->off.p, off.data(), (size_t)nc * 8, hipMemcpyHostToDevice, st));
   hipLaunchKernelGGL(winnow_gather_kernel, dim3((unsigned)nc), dim3(256), 0, st, d_recs, d_chunks, d_count, (const int64_t*)wk->off.p, seq_id, (wfm_minmer_t*)wk->out.p);
   HIPCHK(h, hipGetLastError());

@@ -22,6 +22,7 @@
 
 #include "../../include/wfmash_hip.h"
 #include "wfa_device.h"
+#include "dev_cache.h"
 
 #ifdef WFM_PROFILE_SECTIONS
 namespace wfm { void read_sections(long long* out); }
@@ -50,14 +51,17 @@ struct DevBuf {
   size_t cap = 0;  // elements
   int ensure(size_t n) {
     if (n <= cap) return 0;
+    const size_t old_cap = cap;
     if (p) (void)hipFree(p);
     p = nullptr; cap = 0;
     // (an arena that has to grow doubles at least: every regrowth is a fresh allocation, 30 - 70 ms per GB on this driver, and a
     // divergent batch -- C1 -- used to walk its ring arena up in five steps of 3.5 .. 12 GB)
-    size_t want = std::max(n + n / 8 + 64, cap * 2);
+    size_t want = std::max(n + n / 8 + 64, old_cap * 2);
     const auto t0 = std::chrono::steady_clock::now();
     if (hipMalloc((void**)&p, want * sizeof(T)) != hipSuccess) {
-      if (hipMalloc((void**)&p, n * sizeof(T)) != hipSuccess) { p = nullptr; return -1; }
+      (void)hipGetLastError();  // the failure must not surface after a later launch
+      wfm_dcache_trim();        // blocks the map path's cache holds back are the first thing to give up
+      if (hipMalloc((void**)&p, n * sizeof(T)) != hipSuccess) { (void)hipGetLastError(); p = nullptr; return -1; }
       want = n;
     }
     cap = want;
@@ -104,13 +108,37 @@ namespace {
 // driver keeps several batches in flight, each on a handle of its own) are reported against it and can be merged
 std::mutex g_base_mu;
 hipEvent_t g_dev_base[64] = {};
-hipEvent_t device_base_event(int device) {
+int g_dev_handles[64] = {};  // live handles per device (wfm_create / wfm_destroy)
+// The origin as (event, milliseconds from the process's first origin on that device to the event).  hipEventElapsedTime
+// returns a float: against an origin hours old its resolution is a millisecond or worse, so the origin is moved up every few
+// minutes and the distance it has moved is kept as a double.
+double g_dev_base_off[64] = {};
+hipEvent_t device_base_event(int device, double* off_ms) {
   std::lock_guard<std::mutex> lk(g_base_mu);
+  if (off_ms) *off_ms = 0;
   if (device < 0 || device >= 64) return nullptr;
-  if (!g_dev_base[device]) {
+  static hipStream_t clock_stream[64] = {};  // (a stream of its own, non-blocking: an event on the null stream would wait for every handle's work)
+  if (!clock_stream[device] && hipStreamCreateWithFlags(&clock_stream[device], hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); clock_stream[device] = nullptr; }
+  hipStream_t cs = clock_stream[device];
+  auto fresh = [cs] {
     hipEvent_t e = nullptr;
-    if (hipEventCreate(&e) == hipSuccess && hipEventRecord(e, nullptr) == hipSuccess && hipEventSynchronize(e) == hipSuccess) g_dev_base[device] = e;
+    if (hipEventCreate(&e) == hipSuccess && hipEventRecord(e, cs) == hipSuccess && hipEventSynchronize(e) == hipSuccess) return e;
+    if (e) (void)hipEventDestroy(e);
+    (void)hipGetLastError();
+    return (hipEvent_t) nullptr;
+  };
+  if (!g_dev_base[device]) g_dev_base[device] = fresh();
+  else {
+    // (the age is taken with an event of the moment: cheap, and only on the rare calls that ask for the origin)
+    hipEvent_t now = fresh();
+    float age = 0;
+    if (now && hipEventElapsedTime(&age, g_dev_base[device], now) == hipSuccess && age > 240000.0f) {
+      // (handles that recorded their call's origin against the old event keep working: the old event is left alive)
+      g_dev_base_off[device] += (double)age;
+      g_dev_base[device] = now;
+    } else if (now) (void)hipEventDestroy(now);
   }
+  if (off_ms) *off_ms = g_dev_base_off[device];
   return g_dev_base[device];
 }
 }  // namespace
@@ -122,6 +150,7 @@ struct wfm_handle {
   hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
   std::vector<hipEvent_t> tile_ev;  // start/stop pairs for the tile blocks of one chunk
   std::vector<wfm_handle*> peers;   // further contexts for the other parts of a batch (created on first use)
+  bool is_peer = false;             // a part's context: it shares its owner's budget and is not counted as a handle of the device
   hipEvent_t ev_base = nullptr;     // time origin of the call (shared by the two halves)
   hipEvent_t call_base = nullptr;   // the origin this call measures against
   std::vector<std::pair<float, float>> tile_iv;  // (start, end) of every tile kernel launch of the call, ms after call_base
@@ -358,7 +387,7 @@ int run_base_jobs(wfm_handle* h, wfm_seqset* S, const wfm_penalties_t& pen, std:
             if (getenv("WFM_DEBUG")) fprintf(stderr, "[wfm] problem %d: base job pl %d tl %d cb %d ce %d overflowed its score bound %d\n", nd.prob, nd.pl, nd.tl, nd.cb, nd.ce, nd.smax);
             prob_status[nd.prob] = WFM_ST_UNREACHABLE; continue;
           }
-          // (x 2 until round 3, x 4 for a while: every retry is a launch that a few jobs hold up, a budget that is too large costs
+          // (x 8; it was x 2 until round 3 and x 4 for a while: every retry is a launch that a few jobs hold up, a budget that is too large costs
           // memory only -- 20 MB for a 2 k-wide patch at 2 k scores -- and a patch that passed 256 is as likely to need 1500 as 500)
           again.smax = (int32_t)std::min<int64_t>((int64_t)nd.smax * 8 + 32, bound);
           retry.push_back(again);
@@ -1314,7 +1343,11 @@ int wfm_create(int device, wfm_handle_t** out) {
   // per GB (64 GB: 2.5-4.4 s, 110 GB: 3.9 s, 16 GB: 0.3 ms -- scripts/malloc_cost.hip, profiles/r3_cold_start.md), which a
   // one-shot run pays in full: LPA all-vs-all (C2) aligned in 3.3 s cold and 0.33 s warm with rings sized for 115 GB.  A
   // level that needs more is worked off in chunks and on narrow rings
-  h->mem_budget = std::min<size_t>((size_t)((double)fr * 0.40), (size_t)32 << 30);
+  // Handles of one device share it (the align driver keeps up to three per device): a further handle takes its 40 % of what
+  // is free divided by the handles that are there already, so that on a smaller GPU the budgets together stay inside the memory
+  int live = 0;
+  { std::lock_guard<std::mutex> lk(g_base_mu); if (device < 64) live = g_dev_handles[device]++; }
+  h->mem_budget = std::min<size_t>((size_t)((double)fr * 0.40 / (double)(1 + live)), (size_t)32 << 30);
   const char* env = getenv("WFM_MEM_BUDGET_MB");
   if (env) h->mem_budget = (size_t)atoll(env) << 20;
   h->mem_budget_full = h->mem_budget;
@@ -1326,6 +1359,7 @@ void wfm_destroy(wfm_handle_t* h) {
   if (!h) return;
   for (wfm_handle* p : h->peers) wfm_destroy(p);
   h->peers.clear();
+  if (!h->is_peer) { std::lock_guard<std::mutex> lk(g_base_mu); if (h->device < 64 && g_dev_handles[h->device] > 0) --g_dev_handles[h->device]; }
   (void)hipSetDevice(h->device);
   h->ring.release(); h->base32.release(); h->base8.release(); h->rle.release(); h->rle_out.release();
   h->tilejobs.release(); h->tiletasks.release(); h->tilemak.release();
@@ -1432,7 +1466,11 @@ int wfm_upload_sequences(wfm_handle_t* h, const wfm_problem_t* problems, size_t 
     fill(0, n / (size_t)nt);
     for (auto& t : th) t.join();
   }
-  if (hipMalloc((void**)&S->d_seq, bytes) != hipSuccess) { delete S; h->err = "out of device memory (sequences)"; return WFM_E_NOMEM; }
+  if (hipMalloc((void**)&S->d_seq, bytes) != hipSuccess) {
+    (void)hipGetLastError();
+    wfm_dcache_trim();  // what the map path's block cache holds back goes first
+    if (hipMalloc((void**)&S->d_seq, bytes) != hipSuccess) { (void)hipGetLastError(); delete S; h->err = "out of device memory (sequences)"; return WFM_E_NOMEM; }
+  }
   S->bytes = bytes;
   S->rle_total = rle;
   hipError_t e = hipMemcpyAsync(S->d_seq, host, fwd_bytes, hipMemcpyHostToDevice, h->stream);
@@ -1507,9 +1545,11 @@ int align_resident_any(wfm_handle_t* h, const wfm_penalties_t* pen, wfm_seqset_t
   h->mem_budget = h->mem_budget_full;
   auto keep_abs = [&](std::vector<std::pair<float, float>> iv) {  // the union as intervals on the device's own clock
     h->busy_abs.clear();
-    hipEvent_t db = device_base_event(h->device);
-    float off = 0;
-    const hipError_t ee = db ? hipEventElapsedTime(&off, db, h->ev_base) : hipErrorInvalidValue;
+    double moved = 0;
+    hipEvent_t db = device_base_event(h->device, &moved);
+    float off_f = 0;
+    const hipError_t ee = db ? hipEventElapsedTime(&off_f, db, h->ev_base) : hipErrorInvalidValue;
+    const double off = moved + (double)off_f;
     if (ee != hipSuccess) {
       (void)hipGetLastError();
       if (getenv("WFM_DEBUG")) fprintf(stderr, "[wfm] busy intervals: no common clock (%s)\n", hipGetErrorString(ee));
@@ -1572,6 +1612,8 @@ int align_resident_any(wfm_handle_t* h, const wfm_penalties_t* pen, wfm_seqset_t
   while (h->peers.size() + 1 < parts) {
     wfm_handle_t* p = nullptr;
     if (wfm_create(h->device, &p) != WFM_OK) break;
+    p->is_peer = true;
+    { std::lock_guard<std::mutex> lk(g_base_mu); if (h->device < 64 && g_dev_handles[h->device] > 0) --g_dev_handles[h->device]; }
     h->peers.push_back(p);
   }
   const size_t np = h->peers.size() + 1;

@@ -1267,7 +1267,15 @@ struct DeviceSink : MinmerSink {
     if (!d || n + m > cap) {
       int64_t want = d ? std::max(cap + cap / 2, n + m) : std::max(cap, m);
       wfm_minmer_t* nd = nullptr;
-      if (hipMalloc((void**)&nd, (size_t)want * sizeof(wfm_minmer_t)) != hipSuccess) { wfm_set_error(h, "out of device memory (minmer intervals)"); return WFM_E_NOMEM; }
+      if (hipMalloc((void**)&nd, (size_t)want * sizeof(wfm_minmer_t)) != hipSuccess) {
+        (void)hipGetLastError();
+        wfm_trim_device_cache();  // cached blocks of the map path go back to the driver first
+        if (hipMalloc((void**)&nd, (size_t)want * sizeof(wfm_minmer_t)) != hipSuccess) {
+          (void)hipGetLastError();
+          wfm_set_error(h, "out of device memory (minmer intervals)");
+          return WFM_E_NOMEM;
+        }
+      }
       if (d && n && hipMemcpy(nd, d, (size_t)n * sizeof(wfm_minmer_t), hipMemcpyDeviceToDevice) != hipSuccess) { (void)hipFree(nd); return WFM_E_HIP; }
       if (d) (void)hipFree(d);
       d = nd; cap = want;
