@@ -181,7 +181,8 @@ int  wfm_align_resident_rle(wfm_handle_t* h, const wfm_penalties_t* pen, wfm_seq
 
 /* Device blocks of the map path are kept in a per-device cache between calls (a first hipMalloc of a gigabyte costs 30 - 40 ms
  * on this driver, a hipFree of gigabytes stalls the next allocation; wfmash_amd/csrc/dev_cache.h).  This hands every cached
- * block back to the driver and returns the bytes released; WFM_DEV_CACHE_GB bounds what the cache may hold (default 96). */
+ * block back to the driver and returns the bytes released; WFM_DEV_CACHE_GB bounds what the cache may hold per device
+ * (default: a third of the device's memory -- 96 GB of an MI355X's 288; only the device that passes its bound is trimmed). */
 size_t wfm_trim_device_cache(void);
 
 int  wfm_get_stats(const wfm_handle_t* h, wfm_stats_t* out);
