@@ -168,6 +168,11 @@ void wfm_free_runs(uint32_t* runs);
  * what an alignment of at most that score can touch; the entry point exists for callers that want the bound and for tests. */
 int  wfm_score_bounds(wfm_handle_t* h, const wfm_penalties_t* pen, const wfm_problem_t* problems, size_t n, int32_t* out);
 
+/* Self-test of the cross-lane primitives the packed tile kernel leans on (DPP wave shifts, wfmash_amd/csrc/wfa_tile2.hip):
+ * out128[lane] = the value 1000 + (lane - 1) taken from the previous lane (lane 0: the kernel's NULL, -2^30),
+ * out128[64 + lane] = 1000 + (lane + 1) from the next lane (lane 63: NULL). */
+int  wfm_selftest_dpp(wfm_handle_t* h, int32_t* out128);
+
 /* Same, but sequences are already resident in device memory (the timed region
  * of bench.py starts here): d_seqs is a device pointer, offsets index into it.
  * Sequences must be laid out by wfm_upload_sequences. */

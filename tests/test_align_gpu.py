@@ -88,6 +88,42 @@ def test_biwfa_with_N_runs(gpu, oracle):
     _check_batch(gpu, oracle, items)
 
 
+def test_wave_shifts_the_packed_tile_kernel_leans_on(gpu):
+    """wfa_tile2.hip takes a lane's neighbours with DPP wave_shr:1 / wave_shl:1: lane i <- lane i -+ 1, the edge lanes keep NULL."""
+    import ctypes as C
+    import numpy as np
+    out = np.zeros(128, dtype=np.int32)
+    L = capi.load()
+    L.wfm_selftest_dpp.restype = C.c_int
+    L.wfm_selftest_dpp.argtypes = [C.c_void_p, C.c_void_p]
+    assert L.wfm_selftest_dpp(gpu._p, out.ctypes.data) == 0
+    null = -(1 << 30)
+    assert out[:64].tolist() == [null] + [1000 + i for i in range(63)]
+    assert out[64:].tolist() == [1000 + i for i in range(1, 64)] + [null]
+
+
+def test_packed_and_byte_kernels_in_one_batch(gpu, oracle):
+    """A batch in which some problems are pure ACGT (2-bit mirror, wfa_tile2_kernel) and others hold an N or soft-masked bases
+    (byte kernel): both kinds of tiles run side by side in every block of a level.  N matches N and nothing else; a lower-case
+    base matches only itself (the C ABI compares bytes, as WFA2-lib does)."""
+    items = []
+    for i in range(24):
+        p = bytearray(synth.random_dna(700 + i, 6000))
+        if i % 3 == 1:
+            p[2000:2100] = b"N" * 100
+        t = bytearray(synth.mutate(bytes(p), 0.04, 7000 + i))
+        if i % 3 == 2:
+            t[3000:3050] = bytes(t[3000:3050]).lower()
+        items.append((bytes(p), bytes(t)))
+    _check_batch(gpu, oracle, items)
+    # low divergence, long runs of matches: the wave-cooperative tail of the packed extension, windows left behind
+    items = []
+    for i in range(12):
+        p = synth.random_dna(800 + i, 60000)
+        items.append((p, synth.mutate(p, 0.002, 8000 + i)))
+    _check_batch(gpu, oracle, items)
+
+
 def test_custom_penalties(gpu, oracle):
     items = _pairs(5, 40, [80, 300, 2000], [0.05, 0.2])
     _check_batch(gpu, oracle, items, pen=(4, 6, 2, 12, 1))
@@ -227,8 +263,9 @@ def test_tiled_kernels_agree_with_step_kernel(oracle, monkeypatch):
     pairs = synth.pairs("C3", n_pairs=24)[8:24]
     got = {}
     for name, env in (("step", {"WFM_TILE": "0"}), ("lds", {"WFM_TILE_REG": "0"}), ("reg", {}),
-                      ("reg_small", {"WFM_TILE_THREADS": "256", "WFM_TILE_T": "32"})):
-        for k in ("WFM_TILE", "WFM_TILE_REG", "WFM_TILE_THREADS", "WFM_TILE_T"):
+                      ("reg_small", {"WFM_TILE_THREADS": "256", "WFM_TILE_T": "32"}),
+                      ("reg_bytes", {"WFM_TILE_V2": "0"}), ("reg_bytes_small", {"WFM_TILE_V2": "0", "WFM_TILE_THREADS": "256", "WFM_TILE_T": "32"})):
+        for k in ("WFM_TILE", "WFM_TILE_REG", "WFM_TILE_THREADS", "WFM_TILE_T", "WFM_TILE_V2"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -237,7 +274,7 @@ def test_tiled_kernels_agree_with_step_kernel(oracle, monkeypatch):
             got[name] = h.align(pairs)
         finally:
             h.close()
-    for name in ("lds", "reg", "reg_small"):
+    for name in ("lds", "reg", "reg_small", "reg_bytes", "reg_bytes_small"):
         bad = [i for i in range(len(pairs)) if got[name][i].ops != got["step"][i].ops]
         assert not bad, (name, bad)
     ops_cpu, scores, _, failed = oracle.align_batch_biwfa([p for p, _ in pairs[:4]], [q for _, q in pairs[:4]])

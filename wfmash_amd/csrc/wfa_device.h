@@ -48,6 +48,7 @@ struct BpJob {
   int32_t sub;                         // upper bound of the job's score (SUB_NONE: none): rows only hold |k - (tl - pl)| <= sub - s
   int32_t best0;                       // > 0: phase 2 resumes with a breakpoint of this score in hand (found by earlier rounds of rows
                                        // computed ahead); only a better one is reported, else WFM_DEV_P2_NOTHING
+  int32_t packed;                      // 1: both sequences are pure upper-case ACGT -- the tile kernel may read the 2-bit mirror (wfa_tile2.hip)
 };
 
 // ---- time-tiled phase 1 (wfa_tile_kernel) ----
@@ -70,7 +71,7 @@ struct TileJob {
   int32_t mode;                        // 0: full blocks; 1: next block stops exactly at the meeting point; 2: stopped there
   int32_t tf, tr;                      // mode >= 1: steps of the forward / reverse direction inside the block after s0
   int32_t last_fwd;                    // mode >= 1: 1 if the forward check ended phase 1 (reverse is one step behind)
-  int32_t pad_;
+  int32_t packed;                      // as BpJob::packed (the job's tiles run wfa_tile2_kernel)
   // mode 4 (phase-2 rows, see P2Job): forward starts at score tf, reverse at tr (s0 is not used), every row goes to the
   // job's P2 rows instead of an output snapshot
   int64_t p2_off;
@@ -152,6 +153,13 @@ void launch_bound(const uint8_t* seq, const BoundJob* jobs, int32_t* out, int nj
 // reversed copies of the sequences of a BiWFA problem, made on the device (wfm_upload_sequences)
 struct SeqRev { int64_t p_fwd, p_rev, t_fwd, t_rev; int32_t plen, tlen; };
 void launch_reverse(uint8_t* seq, const SeqRev* jobs, int njobs, int pad, hipStream_t st);
+// the 2-bit mirror of the sequence buffer (word i = bytes 16 i .. 16 i + 15) and, per BiWFA problem, "pure ACGT" (flag stays nonzero)
+void launch_seq_pack(const uint8_t* seq, uint32_t* pk, int64_t nwords, int64_t nbytes, const SeqRev* jobs, int njobs, int32_t* flag, hipStream_t st);
+constexpr int64_t PK_PAD_WORDS = 2048 + 64;  // words of padding behind the mirror: a tile stages a whole window from any origin inside
+// the tile kernel on packed sequences (wfa_tile2.hip): same contract as launch_tile_reg / launch_tile_p2
+void launch_tile2(const uint32_t* pk, int32_t* ring, const TileJob* jobs, const TileTask* tasks, int32_t* mak, int ntasks, int threads, int T, hipStream_t st);
+void launch_tile2_p2(const uint32_t* pk, int32_t* ring, const TileJob* jobs, const TileTask* tasks, int ntasks, int threads, int32_t* p2, hipStream_t st);
+int selftest_dpp(int* host_out128, hipStream_t st);
 void launch_bp(const uint8_t* seq, int32_t* ring, const BpJob* jobs, BpResult* res, int njobs, int threads,
                DevPen pen, int scope, int ring_rows, hipStream_t st);
 void launch_tile_init(const uint8_t* seq, int32_t* ring, const TileJob* jobs, int32_t* mak0, int njobs, int ring_rows, hipStream_t st);

@@ -97,6 +97,8 @@ struct Node {
 
 struct wfm_seqset {
   uint8_t* d_seq = nullptr;
+  uint32_t* d_pk = nullptr;          // 2-bit mirror of d_seq (wfa_tile2.hip), PK_PAD_WORDS behind it
+  std::vector<int32_t> acgt;         // per problem: nonzero = both sequences are pure upper-case ACGT (BiWFA problems only)
   size_t bytes = 0;
   std::vector<ProbMeta> meta;
   int64_t rle_total = 0;
@@ -180,6 +182,7 @@ struct wfm_handle {
   DevBuf<BaseResult> bsres;
   DevBuf<int64_t> i64a, i64b, i64c;
   DevBuf<int32_t> i32a;
+  DevBuf<int32_t> seqflags;  // wfm_upload_sequences: per BiWFA problem, nonzero = pure ACGT
   DevBuf<unsigned long long> total;
   void* attachment = nullptr;  // owned by another translation unit (map_kernels.hip: the pinned staging ring)
   void (*attachment_free)(void*) = nullptr;
@@ -466,7 +469,7 @@ int run_tiled_phase(wfm_handle* h, wfm_seqset* S, const DevPen& dp, int scope, c
     t.p_fwd = j.p_fwd; t.t_fwd = j.t_fwd; t.p_rev = j.p_rev; t.t_rev = j.t_rev;
     t.ring_in = j.ring_off; t.ring_out = ring2[i];
     t.pl = j.pl; t.tl = j.tl; t.comp_begin = j.comp_begin; t.comp_end = j.comp_end;
-    t.width = j.width; t.koff = j.koff; t.s0 = 0; t.active = 1; t.fmax = 0; t.rmax = 0; t.nblocks = 0; t.mode = 0; t.tf = 0; t.tr = 0; t.last_fwd = 0; t.pad_ = 0;
+    t.width = j.width; t.koff = j.koff; t.s0 = 0; t.active = 1; t.fmax = 0; t.rmax = 0; t.nblocks = 0; t.mode = 0; t.tf = 0; t.tr = 0; t.last_fwd = 0; t.packed = j.packed;
     t.p2_off = 0; t.w2 = 0; t.koff2 = 0; t.sub = j.sub; t.pad2_ = 0;
   }
   bool any_cut = false;  // the kernel form with the score bounds' bookkeeping is only launched when a job carries one
@@ -507,7 +510,7 @@ int run_tiled_phase(wfm_handle* h, wfm_seqset* S, const DevPen& dp, int scope, c
     // checks, so the host only looks every `chunk` blocks.  The task list is built per chunk for the widest
     // range the chunk can reach; a block's tiles outside its current range, and all tiles of jobs that
     // finished earlier in the chunk, exit at once.
-    std::vector<TileTask> tasks;
+    std::vector<TileTask> tasks, tasks_by;
     HIPCHK(h, hipMemcpyAsync(h->tilejobs.p, tj.data(), n * sizeof(TileJob), hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemsetAsync(h->tilemak.p, 0, n * 2 * (size_t)T * sizeof(int32_t), h->stream));
     const int chunk = std::max(1, std::min(cfg.chunk, (int)h->tile_ev.size() / 2));
@@ -541,6 +544,7 @@ int run_tiled_phase(wfm_handle* h, wfm_seqset* S, const DevPen& dp, int scope, c
       // widest range of the chunk fits one tile, every job-direction is ONE tile without a halo, and the workgroups
       // are only as large as that range needs (the first blocks of a level are a few hundred diagonals wide)
       tasks.clear();
+      tasks_by.clear();
       int core_c = core;
       std::vector<int> threads_b((size_t)chunk, cfg.threads);  // workgroup size of every block of the chunk
       if (cfg.reg && cfg.C == 2) {
@@ -577,17 +581,23 @@ int run_tiled_phase(wfm_handle* h, wfm_seqset* S, const DevPen& dp, int scope, c
           h_rng_block(tj[i].pl, tj[i].tl, tj[i].sub, tj[i].s0 + b * T, tj[i].s0 + (b + 1) * T, &L, &R);
           if (R >= L) ntiles = std::max(ntiles, (R - L + core) / core);
         }
+        // the tiles of jobs on packed sequences first (wfa_tile2_kernel), the others (an N, soft-masked bases: the byte kernel) behind them
         for (int d = 0; d < 2; ++d)
-          for (int t = 0; t < ntiles; ++t) tasks.push_back(TileTask{(int32_t)i, d, t, core});  // (tile index, tile width): the kernel places it
+          for (int t = 0; t < ntiles; ++t) (tj[i].packed ? tasks : tasks_by).push_back(TileTask{(int32_t)i, d, t, core});  // (tile index, tile width): the kernel places it
       }
+      const size_t n_pk = tasks.size();
+      tasks.insert(tasks.end(), tasks_by.begin(), tasks_by.end());
       if (tasks.empty()) { h->err = "tile phase: active jobs without a tile"; return WFM_E_HIP; }
       if (h->tiletasks.ensure(tasks.size())) { h->err = "out of device memory (tile tasks)"; return WFM_E_NOMEM; }
       HIPCHK(h, hipMemcpyAsync(h->tiletasks.p, tasks.data(), tasks.size() * sizeof(TileTask), hipMemcpyHostToDevice, h->stream));
       const auto tq1 = clk();
       for (int b = 0; b < chunk; ++b) {
         HIPCHK(h, hipEventRecord(h->tile_ev[2 * b], h->stream));
-        if (cfg.reg) launch_tile_reg(S->d_seq, h->ring.p, h->tilejobs.p, h->tiletasks.p, h->tilemak.p, (int)tasks.size(), threads_b[(size_t)b], T, cfg.C, any_cut, h->stream);
-        else launch_tile(S->d_seq, h->ring.p, h->tilejobs.p, h->tiletasks.p, h->tilemak.p, (int)tasks.size(), cfg.threads, T, cfg.Wt, lds, dp, scope, ring_rows_for(scope), h->stream);
+        if (cfg.reg) {
+          if (n_pk) launch_tile2(S->d_pk, h->ring.p, h->tilejobs.p, h->tiletasks.p, h->tilemak.p, (int)n_pk, threads_b[(size_t)b], T, h->stream);
+          if (tasks.size() > n_pk)
+            launch_tile_reg(S->d_seq, h->ring.p, h->tilejobs.p, h->tiletasks.p + n_pk, h->tilemak.p, (int)(tasks.size() - n_pk), threads_b[(size_t)b], T, cfg.C, any_cut, h->stream);
+        } else launch_tile(S->d_seq, h->ring.p, h->tilejobs.p, h->tiletasks.p, h->tilemak.p, (int)tasks.size(), cfg.threads, T, cfg.Wt, lds, dp, scope, ring_rows_for(scope), h->stream);
         HIPCHK(h, hipEventRecord(h->tile_ev[2 * b + 1], h->stream));
         launch_tile_advance(h->tilejobs.p, h->tilemak.p, (int)n, T, dp, (cfg.reg && cfg.exact) ? 1 : 0, h->stream);
       }
@@ -672,12 +682,12 @@ int run_p2_phase(wfm_handle* h, wfm_seqset* S, const DevPen& dp, int scope, cons
   size_t i0 = 0;
   std::vector<TileJob> tj;
   std::vector<P2Job> pj;
-  std::vector<TileTask> tasks;
+  std::vector<TileTask> tasks, tasks_by;
   std::vector<BpResult> got;
   // the rows of a chunk of jobs may take a quarter of the budget (the rings hold the rest)
   const size_t budget = std::max<size_t>(h->mem_budget / 4, (size_t)64 << 20);
   while (i0 < cand.size()) {
-    tj.clear(); pj.clear(); tasks.clear();
+    tj.clear(); pj.clear(); tasks.clear(); tasks_by.clear();
     size_t elems = 0, i = i0, maxw2 = 0, bm_elems = 0;
     for (; i < cand.size(); ++i) {
       const BpJob& j = jobs[(size_t)cand[i]];
@@ -696,7 +706,7 @@ int run_p2_phase(wfm_handle* h, wfm_seqset* S, const DevPen& dp, int scope, cons
       t.ring_in = j.ring_off; t.ring_out = ring_other[i];
       t.pl = j.pl; t.tl = j.tl; t.comp_begin = j.comp_begin; t.comp_end = j.comp_end;
       t.width = j.width; t.koff = j.koff; t.s0 = 0; t.active = 1; t.fmax = 0; t.rmax = 0; t.nblocks = 0;
-      t.mode = 4; t.tf = j.resume_s; t.tr = j.resume_sr; t.last_fwd = j.last_fwd; t.pad_ = 0;
+      t.mode = 4; t.tf = j.resume_s; t.tr = j.resume_sr; t.last_fwd = j.last_fwd; t.packed = j.packed;
       t.p2_off = (int64_t)elems; t.w2 = (int32_t)w2; t.koff2 = koff2; t.sub = j.sub;
       P2Job q{};
       q.ring_in = j.ring_off; q.p2_off = (int64_t)elems; q.width = j.width; q.koff = j.koff; q.w2 = (int32_t)w2; q.koff2 = koff2;
@@ -727,8 +737,10 @@ int run_p2_phase(wfm_handle* h, wfm_seqset* S, const DevPen& dp, int scope, cons
         int Ld, Rd;
         h_rng_block(tj[jn].pl, tj[jn].tl, tj[jn].sub, d == 0 ? tj[jn].tf : tj[jn].tr, (d == 0 ? tj[jn].tf : tj[jn].tr) + P2K, &Ld, &Rd);
         const int ntiles = Rd >= Ld ? (Rd - Ld + core_c) / core_c : 0;
-        for (int t2 = 0; t2 < ntiles; ++t2) tasks.push_back(TileTask{(int32_t)jn, d, t2, core_c});
+        for (int t2 = 0; t2 < ntiles; ++t2) (tj[jn].packed ? tasks : tasks_by).push_back(TileTask{(int32_t)jn, d, t2, core_c});
       }
+    const size_t n_pk = tasks.size();  // (packed jobs' tiles first: see run_tiled_phase)
+    tasks.insert(tasks.end(), tasks_by.begin(), tasks_by.end());
     if (h->p2rows.ensure(elems + 16) || h->p2max.ensure(n * 2 * P2ROWS * 5) || h->p2bmax.ensure(bm_elems + 16) || h->p2pbmax.ensure(bm_elems + 16) ||
         h->p2jobs.ensure(n) || h->tilejobs.ensure(n) || h->tiletasks.ensure(tasks.size()) || h->bpres.ensure(std::max(n, jobs.size()))) {
       h->err = "out of device memory (phase-2 rows)"; return WFM_E_NOMEM;
@@ -739,7 +751,8 @@ int run_p2_phase(wfm_handle* h, wfm_seqset* S, const DevPen& dp, int scope, cons
     HIPCHK(h, hipEventRecord(h->ev0, h->stream));
     bool any_cut = false;
     for (const TileJob& t : tj) any_cut |= t.sub != SUB_NONE;
-    launch_tile_p2(S->d_seq, h->ring.p, h->tilejobs.p, h->tiletasks.p, (int)tasks.size(), threads_c, h->p2rows.p, any_cut, h->stream);
+    if (n_pk) launch_tile2_p2(S->d_pk, h->ring.p, h->tilejobs.p, h->tiletasks.p, (int)n_pk, threads_c, h->p2rows.p, h->stream);
+    if (tasks.size() > n_pk) launch_tile_p2(S->d_seq, h->ring.p, h->tilejobs.p, h->tiletasks.p + n_pk, (int)(tasks.size() - n_pk), threads_c, h->p2rows.p, any_cut, h->stream);
     launch_p2_blockmax(h->ring.p, h->p2rows.p, h->p2jobs.p, h->p2bmax.p, h->p2max.p, (int)n, h->stream);
     static const int p2_threads = getenv("WFM_P2_THREADS") ? atoi(getenv("WFM_P2_THREADS")) : 0;
     launch_p2_overlap(h->ring.p, h->p2rows.p, h->p2jobs.p, h->p2max.p, h->p2bmax.p, h->p2pbmax.p, h->bpres.p, (int)n,
@@ -906,6 +919,8 @@ int align_resident_impl(wfm_handle* h, const wfm_penalties_t* pen, wfm_seqset* S
   std::vector<int> tiled;
   std::vector<int64_t> ring2;
   const TileCfg tcfg = tile_cfg(*pen, scope);
+  // WFM_TILE_V2=0: every tile on the byte kernel (wfa_tile_reg_kernel) -- the A/B switch of the packed kernel (wfa_tile2.hip)
+  const bool tile_v2 = !(getenv("WFM_TILE_V2") && atoi(getenv("WFM_TILE_V2")) == 0);
   const int RR = ring_rows_for(scope);  // rows of every ring of this call
   uint64_t tile_cells_level = 0;
   uint64_t band_retries = 0, band_jobs = 0, roots_banded = 0, roots_out = 0, hint_retries = 0, hinted_roots = 0;
@@ -996,6 +1011,7 @@ int align_resident_impl(wfm_handle* h, const wfm_penalties_t* pen, wfm_seqset* S
         // tile kernel its bookkeeping all the way there
         j.sub = (nd.sub != SUB_NONE && (int64_t)std::abs(nd.tl - nd.pl) * 8 >= (int64_t)nd.sub) ? nd.sub : SUB_NONE;
         j.best0 = 0;
+        j.packed = (tile_v2 && (size_t)nd.prob < S->acgt.size() && S->acgt[(size_t)nd.prob]) ? 1 : 0;
         band_jobs += band > 0;
         if (tile_it) { tiled.push_back((int)jobs.size()); ring2.push_back((int64_t)(ring_elems + need / 2)); }
         node_of.push_back((int32_t)i);
@@ -1367,7 +1383,7 @@ void wfm_destroy(wfm_handle_t* h) {
   if (h->stage) { (void)hipHostFree(h->stage); h->stage = nullptr; h->stage_cap = 0; }
   h->p2rows.release(); h->p2max.release(); h->p2bmax.release(); h->p2pbmax.release(); h->p2jobs.release();
   h->bpjobs.release(); h->bpres.release(); h->bsjobs.release(); h->bsres.release();
-  h->i64a.release(); h->i64b.release(); h->i64c.release(); h->i32a.release(); h->total.release();
+  h->i64a.release(); h->i64b.release(); h->i64c.release(); h->i32a.release(); h->seqflags.release(); h->total.release();
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   if (h->ev2) (void)hipEventDestroy(h->ev2);
@@ -1473,8 +1489,15 @@ int wfm_upload_sequences(wfm_handle_t* h, const wfm_problem_t* problems, size_t 
   }
   S->bytes = bytes;
   S->rle_total = rle;
+  // the 2-bit mirror the tile kernel extends on (wfa_tile2.hip): a quarter of a byte per base, made on the device
+  const int64_t pk_words = ((int64_t)bytes + 15) / 16;
+  if (hipMalloc((void**)&S->d_pk, (size_t)(pk_words + PK_PAD_WORDS) * 4) != hipSuccess) {
+    (void)hipGetLastError();
+    (void)hipFree(S->d_seq); delete S; h->err = "out of device memory (packed sequences)"; return WFM_E_NOMEM;
+  }
   hipError_t e = hipMemcpyAsync(S->d_seq, host, fwd_bytes, hipMemcpyHostToDevice, h->stream);
   if (e == hipSuccess) e = hipMemsetAsync(S->d_seq + bytes - SEQ_PAD, 0, SEQ_PAD, h->stream);
+  if (e == hipSuccess) e = hipMemsetAsync(S->d_pk + pk_words, 0, (size_t)PK_PAD_WORDS * 4, h->stream);
   if (e == hipSuccess) {
     std::vector<SeqRev> rv;
     rv.reserve(n);
@@ -1487,9 +1510,24 @@ int wfm_upload_sequences(wfm_handle_t* h, const wfm_problem_t* problems, size_t 
       if (e == hipSuccess) e = hipMemcpyAsync(h->revjobs.p, rv.data(), rv.size() * sizeof(SeqRev), hipMemcpyHostToDevice, h->stream);
       if (e == hipSuccess) { launch_reverse(S->d_seq, h->revjobs.p, (int)rv.size(), SEQ_PAD, h->stream); e = hipGetLastError(); }
     }
+    // the mirror of everything (forward and reversed copies), and which BiWFA problems are pure ACGT
+    std::vector<int32_t> flags(rv.size(), 1);
+    if (e == hipSuccess && !rv.empty() && h->seqflags.ensure(rv.size())) e = hipErrorOutOfMemory;
+    if (e == hipSuccess && !rv.empty()) e = hipMemsetAsync(h->seqflags.p, 1, rv.size() * sizeof(int32_t), h->stream);
+    if (e == hipSuccess) {
+      launch_seq_pack(S->d_seq, S->d_pk, pk_words, (int64_t)bytes, h->revjobs.p, (int)rv.size(), rv.empty() ? nullptr : h->seqflags.p, h->stream);
+      e = hipGetLastError();
+    }
+    if (e == hipSuccess && !rv.empty()) e = hipMemcpyAsync(flags.data(), h->seqflags.p, rv.size() * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    if (e == hipSuccess) {
+      S->acgt.assign(n, 0);
+      size_t q = 0;
+      for (size_t i = 0; i < n; ++i)
+        if (problems[i].mode == WFM_MODE_END2END_BIWFA) S->acgt[i] = flags[q++];
+    }
   }
-  if (e != hipSuccess) { (void)hipFree(S->d_seq); delete S; h->err = hipGetErrorString(e); return WFM_E_HIP; }
+  if (e != hipSuccess) { (void)hipFree(S->d_seq); (void)hipFree(S->d_pk); delete S; h->err = hipGetErrorString(e); return WFM_E_HIP; }
   *out = S;
   return WFM_OK;
 }
@@ -1498,6 +1536,7 @@ void wfm_free_sequences(wfm_handle_t* h, wfm_seqset_t* s) {
   if (!s) return;
   if (h) (void)hipSetDevice(h->device);
   if (s->d_seq) (void)hipFree(s->d_seq);
+  if (s->d_pk) (void)hipFree(s->d_pk);
   delete s;
 }
 
@@ -1710,6 +1749,12 @@ int wfm_align_batch_rle(wfm_handle_t* h, const wfm_penalties_t* pen, const wfm_p
 }
 
 void wfm_free_runs(uint32_t* runs) { free(runs); }
+
+int wfm_selftest_dpp(wfm_handle_t* h, int32_t* out128) {
+  if (!h || !out128) return WFM_E_ARG;
+  HIPCHK(h, hipSetDevice(h->device));
+  return selftest_dpp(out128, h->stream) == 0 ? WFM_OK : WFM_E_HIP;
+}
 
 int wfm_score_bounds(wfm_handle_t* h, const wfm_penalties_t* pen, const wfm_problem_t* problems, size_t n, int32_t* out) {
   if (!h || !pen || !out || (n && !problems)) return WFM_E_ARG;

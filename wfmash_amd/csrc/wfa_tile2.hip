@@ -1,0 +1,542 @@
+// wfa_tile2.hip -- the register time tile of wfa_kernels.hip (wfa_tile_reg_kernel) with the two things its SQ counters asked
+// for (profiles/r3_sq.json: 197 VALU + 127 SALU instructions per wave and score step for 2 x 64 cells, VALU busy 0.55):
+//
+//  * the extension reads 2-BIT PACKED sequences.  wfm_upload_sequences keeps a packed mirror of the sequence buffer (base at
+//    byte index a = bits 2 (a & 15) .. of word a >> 4, code (c >> 1) & 3: A 0, C 1, T 2, G 3); a problem whose sequences hold
+//    anything but upper-case ACGT (an N, soft-masked bases) is flagged and stays on the byte kernel, whose comparisons are exact
+//    for any alphabet.  One probe is 16 bases = two words per sequence, one v_alignbit each, one xor, one ffbl -- where the byte
+//    form needed three words and two alignbits per sequence for 8 bases; the 8 KB windows in LDS now hold 32 k bases of each
+//    sequence (a 100-score block of a 0.1 % record crosses 20 kb), and the wave-cooperative tail of a long run compares
+//    64 lanes x 32 bases = 2048 bases per round trip instead of 512.
+//  * no range bookkeeping in the step.  A cell outside the triangle |k| <= s is NULL by induction (its sources are), a column
+//    outside [-pl, tl] or cut off by the score bound is nulled when it is WRITTEN (one compare against a per-cell constant:
+//    the last score at which the cell is inside), and a cell inside only ever reads cells that were inside at their own score
+//    (wfa_kernels.hip, Rng) -- so nothing has to be selected when a value is READ: the five closed-form source ranges per step
+//    (50 SALU) and the 18 selects per thread of the non-interior threads are gone.  The snapshot load still filters by range
+//    (the ring holds stale cells outside), and so do all readers of what the tile writes.
+//
+// Same contract as wfa_tile_reg_kernel (snapshot in -> T steps -> snapshot out + per-step maxima; P2: every row kept), same
+// results bit for bit (tests/test_align_gpu.py runs every case on both kernels).  With 64 threads the workgroup is one wave:
+// neighbours by DPP wave shifts only, no mailbox, and the barriers compile to nothing -- the form for the narrow wavefronts
+// of near-identical records (C2 / C4), where a step is a chain of latencies and not a matter of throughput.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <type_traits>
+
+#include "wfa_device.h"
+
+namespace wfm {
+
+namespace {
+
+constexpr int PK_WIN_DW = 2048;               // words per sequence window in LDS
+constexpr int PK_WIN_BASES = PK_WIN_DW * 16;  // 32768 bases
+constexpr int PK_SLACK_DW = 8;                // words past the window a probe may touch
+
+struct Rng2 { int pl, tl, kb_lo, kb_hi; };
+__device__ __forceinline__ Rng2 make_rng2(int pl, int tl, int sub) { Rng2 r; r.pl = pl; r.tl = tl; r.kb_lo = (tl - pl) - sub; r.kb_hi = (tl - pl) + sub; return r; }
+__device__ __forceinline__ int rng2_lo(const Rng2& r, int s) { return max(max(-r.pl, -s), r.kb_lo + s); }
+__device__ __forceinline__ int rng2_hi(const Rng2& r, int s) { return min(min(r.tl, s), r.kb_hi - s); }
+constexpr int RNG2_BACK = 25;  // = RNG_BACK of wfa_kernels.hip
+__device__ __forceinline__ void rng2_block(const Rng2& r, int s_from, int s_to, int& L, int& R) {
+  L = max(max(-r.pl, -s_to), r.kb_lo + s_from - RNG2_BACK);
+  R = min(min(r.tl, s_to), r.kb_hi - s_from + RNG2_BACK);
+}
+
+__device__ __forceinline__ int rdl(int v, int src) { return __builtin_amdgcn_readlane(v, src); }
+
+// lane i <- lane i - 1 (lane 0 keeps NULL) / lane i <- lane i + 1 (lane 63 keeps NULL): one VALU instruction each
+__device__ __forceinline__ int from_prev_lane(int x) { return __builtin_amdgcn_update_dpp(WF_NULL, x, 0x138, 0xf, 0xf, false); }  // wave_shr:1
+__device__ __forceinline__ int from_next_lane(int x) { return __builtin_amdgcn_update_dpp(WF_NULL, x, 0x130, 0xf, 0xf, false); }  // wave_shl:1
+
+__device__ __forceinline__ int wave_max63(int x) {
+  x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false));  // row_shr:1
+  x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false));  // row_shr:2
+  x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false));  // row_shr:4
+  x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false));  // row_shr:8
+  x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false));  // row_bcast:15
+  x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false));  // row_bcast:31
+  return x;
+}
+
+// explicit address spaces: the LDS windows and the global mirror are read by the same code shapes, and a pointer that may be
+// either would be read with flat loads
+typedef const __attribute__((address_space(3))) uint32_t* lds_words;
+typedef const __attribute__((address_space(1))) uint32_t* glb_words;
+
+// 16 / 32 bases from base offset o of a packed word array (LDS window or global mirror)
+template <typename W>
+__device__ __forceinline__ uint32_t pk16(W w, unsigned o) {
+  const W q = w + (o >> 4);
+  return __builtin_amdgcn_alignbit(q[1], q[0], o << 1);
+}
+template <typename W>
+__device__ __forceinline__ uint64_t pk32(W w, unsigned o) {
+  const W q = w + (o >> 4);
+  const uint32_t a = q[0], b = q[1], c = q[2];
+  const unsigned sh = o << 1;
+  return ((uint64_t)__builtin_amdgcn_alignbit(c, b, sh) << 32) | __builtin_amdgcn_alignbit(b, a, sh);
+}
+
+// Where a tile's sequences are read: the LDS windows while the offsets (counted from the windows' origin) stay inside, the
+// global mirror from the same origin beyond
+struct PkSrc {
+  lds_words lP, lT;
+  glb_words gP, gT;
+};
+
+// number of leading bases (of 16) on which two packed words agree: x = their xor (ffbl of 0 is -1: all 16)
+__device__ __forceinline__ unsigned first_diff16(uint32_t x) { return (unsigned)(x ? __builtin_ctz(x) : 32) >> 1; }
+
+// bases 16 .. 79 after a probe that matched 16: four more words per sequence.  Returns the run length so far (16 .. 80).
+__device__ __forceinline__ int pk_stage2(const PkSrc& S, unsigned oP, unsigned oT) {
+  uint32_t wa[5], wb[5];
+  if (max(oP, oT) <= (unsigned)(PK_WIN_BASES - 96)) {
+    const lds_words a = S.lP + (oP >> 4) + 1;
+    const lds_words b = S.lT + (oT >> 4) + 1;
+#pragma unroll
+    for (int q = 0; q < 5; ++q) { wa[q] = a[q]; wb[q] = b[q]; }
+  } else {
+    const glb_words a = S.gP + (oP >> 4) + 1;
+    const glb_words b = S.gT + (oT >> 4) + 1;
+#pragma unroll
+    for (int q = 0; q < 5; ++q) { wa[q] = a[q]; wb[q] = b[q]; }
+  }
+  const unsigned sa = oP << 1, sb = oT << 1;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const uint32_t x = __builtin_amdgcn_alignbit(wa[q + 1], wa[q], sa) ^ __builtin_amdgcn_alignbit(wb[q + 1], wb[q], sb);
+    if (x) return 16 + 16 * q + (int)(__builtin_ctz(x) >> 1);
+  }
+  return 80;
+}
+
+// Runs that go on past 80 bases are finished by the whole wave, one pending lane after the other: 64 lanes x 32 bases per
+// round trip.  Every lane of the wave makes the call (pend = false: nothing of its own).
+__device__ __forceinline__ int pk_wave_tail(const PkSrc& S, unsigned oP, unsigned oT, int n, int maxn, bool pend) {
+  unsigned long long todo = __ballot(pend);
+  const int lane = (int)(threadIdx.x & 63u);
+  while (todo) {
+    const int src = __builtin_amdgcn_readfirstlane((int)__builtin_ctzll(todo));
+    todo &= todo - 1;
+    const unsigned p0 = (unsigned)rdl((int)oP, src), t0 = (unsigned)rdl((int)oT, src);
+    const int mx = rdl(maxn, src);
+    int nn = rdl(n, src);
+    int res;
+    for (;;) {
+      const int off = nn + lane * 32;
+      const bool past = off >= mx;
+      uint64_t x = 0;
+      if (!past) {
+        const unsigned a = p0 + (unsigned)off, b = t0 + (unsigned)off;
+        if (max(a, b) <= (unsigned)(PK_WIN_BASES - 48)) x = pk32(S.lP, a) ^ pk32(S.lT, b);
+        else x = pk32(S.gP, a) ^ pk32(S.gT, b);
+      }
+      const unsigned long long hit = __ballot(past || x != 0);
+      if (hit) {
+        const int f = __builtin_amdgcn_readfirstlane((int)__builtin_ctzll(hit));
+        const unsigned xlo = (unsigned)rdl((int)(uint32_t)x, f), xhi = (unsigned)rdl((int)(uint32_t)(x >> 32), f);
+        const uint64_t xf = ((uint64_t)xhi << 32) | xlo;
+        const int at = nn + f * 32;
+        res = at >= mx ? mx : min(mx, at + (xf ? (int)(__builtin_ctzll(xf) >> 1) : 0));
+        break;
+      }
+      nn += 2048;
+    }
+    if (lane == src) n = res;
+  }
+  return n;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------
+// packed mirror of the sequence buffer + "is this problem pure ACGT" flags
+// ---------------------------------------------------------------------------
+// word i of the mirror = bytes 16 i .. 16 i + 15 of the buffer
+__global__ __launch_bounds__(256) void seq_pack_kernel(const uint8_t* __restrict__ seq, uint32_t* __restrict__ pk, int64_t nwords, int64_t nbytes) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nwords) return;
+  uint32_t v = 0;
+  if ((i + 1) * 16 <= nbytes) {
+    const uint4 q = *reinterpret_cast<const uint4*>(seq + i * 16);
+    const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const uint32_t c = (w[j] >> 1) & 0x03030303u;  // the code of each of the four bytes
+      v |= ((c & 3u) | ((c >> 6) & 0xcu) | ((c >> 12) & 0x30u) | ((c >> 18) & 0xc0u)) << (8 * j);
+    }
+  } else {
+    for (int j = 0; j < 16; ++j) {
+      const int64_t a = i * 16 + j;
+      const uint32_t c = a < nbytes ? (uint32_t)seq[a] : 0u;
+      v |= ((c >> 1) & 3u) << (2 * j);
+    }
+  }
+  pk[i] = v;
+}
+// one workgroup per (problem, pattern / text): flag[problem] = 0 when a byte is not one of A C G T
+__global__ __launch_bounds__(256) void seq_acgt_kernel(const uint8_t* __restrict__ seq, const SeqRev* __restrict__ jobs, int32_t* __restrict__ flag) {
+  const SeqRev J = jobs[blockIdx.x >> 1];
+  const bool text = blockIdx.x & 1;
+  const uint8_t* src = seq + (text ? J.t_fwd : J.p_fwd);
+  const int n = text ? J.tlen : J.plen;
+  bool bad = false;
+  for (int q = threadIdx.x; q < n; q += blockDim.x) {
+    const uint8_t c = src[q];
+    bad |= !(c == 'A' || c == 'C' || c == 'G' || c == 'T');
+  }
+  if (__any(bad) && (threadIdx.x & 63) == 0) flag[blockIdx.x >> 1] = 0;
+}
+void launch_seq_pack(const uint8_t* seq, uint32_t* pk, int64_t nwords, int64_t nbytes, const SeqRev* jobs, int njobs, int32_t* flag, hipStream_t st) {
+  if (nwords > 0) hipLaunchKernelGGL(seq_pack_kernel, dim3((unsigned)((nwords + 255) / 256)), dim3(256), 0, st, seq, pk, nwords, nbytes);
+  if (njobs > 0) hipLaunchKernelGGL(seq_acgt_kernel, dim3((unsigned)njobs * 2), dim3(256), 0, st, seq, jobs, flag);
+}
+
+// ---------------------------------------------------------------------------
+// the tile kernel
+// ---------------------------------------------------------------------------
+template <int NTMAX, bool P2>
+__global__ __launch_bounds__(NTMAX) void wfa_tile2_kernel(const uint32_t* __restrict__ pk, int32_t* __restrict__ ring_arena,
+                                                        const TileJob* __restrict__ jobs, const TileTask* __restrict__ tasks,
+                                                        int32_t* __restrict__ mak_out, int T, int32_t* __restrict__ p2_arena) {
+  constexpr int C = 2, LB = 25, H = LB + 1, NCL = 5, DEP = 6, E1 = 2;
+  constexpr bool WAVE1 = NTMAX == 64;  // one wave: no mailbox; __syncthreads() is a wave barrier for a 64-thread workgroup
+  __shared__ int s_edge[2][WAVE1 ? 1 : 16][2][4];  // [parity][wave][0: lane63 -> next wave, 1: lane0 -> previous wave][value]
+  __shared__ __attribute__((aligned(16))) uint32_t s_winP[PK_WIN_DW + PK_SLACK_DW], s_winT[PK_WIN_DW + PK_SLACK_DW];
+  __shared__ int s_wlo[2];
+  extern __shared__ __attribute__((aligned(16))) int s_makr[];  // [T + 1]
+  TileTask tk = tasks[blockIdx.x];
+  const TileJob J = jobs[tk.job];
+  if (!J.active) return;
+  const int sbase = P2 ? (tk.dir == 0 ? J.tf : J.tr) : J.s0;  // score of the snapshot this direction starts from
+  const Rng2 RG = make_rng2(J.pl, J.tl, J.sub);
+  int halo = T;  // columns computed on either side of the core (the trapezoid loses one per step)
+  {
+    const int s1 = sbase + T;
+    int L, R;
+    rng2_block(RG, sbase, s1, L, R);
+    const int idx = tk.core_lo, core = tk.core_hi;
+    tk.core_lo = L + idx * core;
+    tk.core_hi = min(R, tk.core_lo + core - 1);
+    if (tk.core_lo > R) return;
+    if (tk.core_lo == L && tk.core_hi == R) halo = 0;  // one tile for the whole range: nothing beside it to take from
+  }
+  const int dir = tk.dir, tid = threadIdx.x, NT = blockDim.x, lane = tid & 63, wv = tid >> 6, nw = NT >> 6;
+  if (tid < 2) s_wlo[tid] = INT32_MAX;
+  const int64_t aP = dir == 0 ? J.p_fwd : J.p_rev, aT = dir == 0 ? J.t_fwd : J.t_rev;  // byte index of the sequences' first bases
+  const int pl = J.pl, tl = J.tl, s0 = sbase;
+  const int kA = tk.core_lo - halo;
+  const int k0 = kA + tid * C;  // first diagonal of this thread
+  const int64_t width = J.width;
+  const int32_t* rin = ring_arena + J.ring_in + J.koff + (int64_t)dir * 5 * RING * width;
+  int32_t* rout = ring_arena + J.ring_out + J.koff + (int64_t)dir * 5 * RING * width;
+  const int kmax = tk.core_hi + halo;  // last diagonal of the tile
+  const int Tn = (!P2 && J.mode == 1) ? (dir == 0 ? J.tf : J.tr) : T;
+
+  // Mh[c][r][e] = M[sr - 5 e][k0+c], sr = the newest score <= current with (sr - s0) mod 5 == r
+  int Mh[C][NCL][DEP];
+  int I1h[C][E1], D1h[C][E1], I2h[C], D2h[C];
+  // ---- snapshot load (rows <= s0): what lies outside a row's own range is NULL, whatever the ring holds there
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    const int k = k0 + c;
+    const bool kin = k <= kmax;
+#pragma unroll
+    for (int r = 0; r < NCL; ++r)
+#pragma unroll
+      for (int e = 0; e < DEP; ++e) Mh[c][r][e] = WF_NULL;
+#pragma unroll
+    for (int d = 0; d < H; ++d) {
+      const int sc = s0 - d;
+      const int v = (kin && sc >= 0 && k >= rng2_lo(RG, sc) && k <= rng2_hi(RG, sc)) ? rin[((int64_t)(C_M * RING + (sc & RMASK))) * width + k] : WF_NULL;
+      Mh[c][(NCL - d % NCL) % NCL][d / NCL] = v;  // row s0-d: class (-d mod 5), the (d/5)-th newest of its class
+    }
+#pragma unroll
+    for (int d = 0; d < E1; ++d) {
+      const int sc = s0 - d;
+      const bool ok = kin && sc >= 0 && k >= rng2_lo(RG, sc) && k <= rng2_hi(RG, sc);
+      I1h[c][d] = ok ? rin[((int64_t)(C_I1 * RING + (sc & RMASK))) * width + k] : WF_NULL;
+      D1h[c][d] = ok ? rin[((int64_t)(C_D1 * RING + (sc & RMASK))) * width + k] : WF_NULL;
+    }
+    {
+      const bool ok = kin && s0 >= 0 && k >= rng2_lo(RG, s0) && k <= rng2_hi(RG, s0);
+      I2h[c] = ok ? rin[((int64_t)(C_I2 * RING + (s0 & RMASK))) * width + k] : WF_NULL;
+      D2h[c] = ok ? rin[((int64_t)(C_D2 * RING + (s0 & RMASK))) * width + k] : WF_NULL;
+    }
+  }
+  for (int t = tid; t <= T; t += NT) s_makr[t] = 0;
+  // ---- per-cell constants
+  unsigned hmaxu[C];  // largest offset inside the problem on this diagonal: min(tl, pl + k)
+  int s_last[C];      // the last score at which the cell is inside its row (columns outside [-pl, tl]: never)
+  int negk[C];        // -k for cells of the core, else far below any 2 m
+  bool incore[C];
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    const int k = k0 + c;
+    const bool colok = (k >= -pl) && (k <= tl);
+    hmaxu[c] = colok ? (unsigned)min(tl, pl + k) : 0u;
+    s_last[c] = colok ? min(k - RG.kb_lo, RG.kb_hi - k) : -1;
+    incore[c] = k >= tk.core_lo && k <= tk.core_hi;
+    negk[c] = incore[c] ? -k : -(1 << 29);
+  }
+  // ---- sequence windows: every offset this tile will ever extend from is >= the smallest live offset of its history
+  {
+    int hlo = INT32_MAX, vlo = INT32_MAX;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      const int k = k0 + c;
+      int lo = INT32_MAX;
+#pragma unroll
+      for (int r = 0; r < NCL; ++r)
+#pragma unroll
+        for (int e = 0; e < DEP; ++e) lo = min(lo, Mh[c][r][e] >= 0 ? Mh[c][r][e] : INT32_MAX);
+#pragma unroll
+      for (int d = 0; d < E1; ++d) { lo = min(lo, I1h[c][d] >= 0 ? I1h[c][d] : INT32_MAX); lo = min(lo, D1h[c][d] >= 0 ? D1h[c][d] : INT32_MAX); }
+      lo = min(lo, I2h[c] >= 0 ? I2h[c] : INT32_MAX);
+      lo = min(lo, D2h[c] >= 0 ? D2h[c] : INT32_MAX);
+      if (lo != INT32_MAX) { hlo = min(hlo, lo); vlo = min(vlo, lo - k); }
+    }
+    __syncthreads();  // s_wlo initialised
+    if (hlo != INT32_MAX) { atomicMin(&s_wlo[0], hlo); atomicMin(&s_wlo[1], max(vlo, 0)); }
+    __syncthreads();
+  }
+  const int wT0 = s_wlo[0] == INT32_MAX ? 0 : s_wlo[0], wP0 = s_wlo[1] == INT32_MAX ? 0 : s_wlo[1];
+  // window origins as absolute base indices, word aligned; offsets of a cell from them: oP = v + dP, oT = h + dT
+  const int64_t oriP = (aP + wP0) & ~(int64_t)15, oriT = (aT + wT0) & ~(int64_t)15;
+  const int dP = (int)(aP - oriP), dT = (int)(aT - oriT);
+  PkSrc SRC;
+  SRC.lP = (lds_words)s_winP; SRC.lT = (lds_words)s_winT;
+  SRC.gP = (glb_words)pk + (oriP >> 4); SRC.gT = (glb_words)pk + (oriT >> 4);
+  for (int i = tid; i < PK_WIN_DW + PK_SLACK_DW; i += NT) {  // (the mirror is padded by more than a window: no bound to check)
+    s_winP[i] = SRC.gP[i];
+    s_winT[i] = SRC.gT[i];
+  }
+  int cP[C];  // oP of cell c = m + cP[c]  (v = m - k)
+#pragma unroll
+  for (int c = 0; c < C; ++c) cP[c] = dP - (k0 + c);
+  __syncthreads();
+
+  for (int tb = 0; tb < Tn; tb += NCL) {
+#pragma unroll
+  for (int jj = 1; jj <= NCL; ++jj) {
+    const int t = tb + jj;
+    if (t > Tn) break;
+    const int cl = jj % NCL;  // residue class of this step's score: compile time after unrolling
+    const int s = s0 + t;
+    // rows this step reads from its class: [0] = s-5, [1] = s-10, [4] = s-25
+    int lM10, lM25, lI1, lI2, rM10, rM25, rD1, rD2;
+    if (!WAVE1) {
+      const int par = t & 1;
+      // publish the wave-edge history values needed by the neighbouring waves in this step
+      if (lane == 63) { int* e = s_edge[par][wv][0]; e[0] = Mh[C - 1][cl][1]; e[1] = Mh[C - 1][cl][4]; e[2] = I1h[C - 1][E1 - 1]; e[3] = I2h[C - 1]; }
+      if (lane == 0)  { int* e = s_edge[par][wv][1]; e[0] = Mh[0][cl][1];     e[1] = Mh[0][cl][4];     e[2] = D1h[0][E1 - 1];     e[3] = D2h[0]; }
+      __syncthreads();
+      lM10 = from_prev_lane(Mh[C - 1][cl][1]); lM25 = from_prev_lane(Mh[C - 1][cl][4]);
+      lI1 = from_prev_lane(I1h[C - 1][E1 - 1]); lI2 = from_prev_lane(I2h[C - 1]);
+      rM10 = from_next_lane(Mh[0][cl][1]); rM25 = from_next_lane(Mh[0][cl][4]);
+      rD1 = from_next_lane(D1h[0][E1 - 1]); rD2 = from_next_lane(D2h[0]);
+      if (lane == 0 && wv > 0) { const int* e = s_edge[par][wv - 1][0]; lM10 = e[0]; lM25 = e[1]; lI1 = e[2]; lI2 = e[3]; }
+      if (lane == 63 && wv + 1 < nw) { const int* e = s_edge[par][wv + 1][1]; rM10 = e[0]; rM25 = e[1]; rD1 = e[2]; rD2 = e[3]; }
+    } else {
+      lM10 = from_prev_lane(Mh[C - 1][cl][1]); lM25 = from_prev_lane(Mh[C - 1][cl][4]);
+      lI1 = from_prev_lane(I1h[C - 1][E1 - 1]); lI2 = from_prev_lane(I2h[C - 1]);
+      rM10 = from_next_lane(Mh[0][cl][1]); rM25 = from_next_lane(Mh[0][cl][4]);
+      rD1 = from_next_lane(D1h[0][E1 - 1]); rD2 = from_next_lane(D2h[0]);
+    }
+    int nM[C], nI1[C], nI2[C], nD1[C], nD2[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      const int a10 = c == 0 ? lM10 : Mh[c - 1][cl][1], b10 = c == C - 1 ? rM10 : Mh[c + 1][cl][1];
+      const int a25 = c == 0 ? lM25 : Mh[c - 1][cl][4], b25 = c == C - 1 ? rM25 : Mh[c + 1][cl][4];
+      const int i1 = c == 0 ? lI1 : I1h[c - 1][E1 - 1], d1 = c == C - 1 ? rD1 : D1h[c + 1][E1 - 1];
+      const int i2 = c == 0 ? lI2 : I2h[c - 1], d2 = c == C - 1 ? rD2 : D2h[c + 1];
+      const int mx = Mh[c][cl][0];
+      // in-bounds <=> 0 <= offset <= min(tl, pl + k)   (h <= tl and h - k <= pl)
+      const unsigned hm = hmaxu[c];
+      int ins1 = max(a10, i1) + 1, ins2 = max(a25, i2) + 1, del1 = max(b10, d1), del2 = max(b25, d2), mis = mx + 1;
+      ins1 = (unsigned)ins1 <= hm ? ins1 : WF_NULL;
+      ins2 = (unsigned)ins2 <= hm ? ins2 : WF_NULL;
+      del1 = (unsigned)del1 <= hm ? del1 : WF_NULL;
+      del2 = (unsigned)del2 <= hm ? del2 : WF_NULL;
+      mis = (unsigned)mis <= hm ? mis : WF_NULL;
+      nI1[c] = ins1; nI2[c] = ins2; nD1[c] = del1; nD2[c] = del2;
+      const int m = max(max(max(ins1, ins2), mis), max(del1, del2));
+      // a column outside [-pl, tl], or one the score bound has cut off at this score, holds no cell
+      nM[c] = s <= s_last[c] ? m : WF_NULL;
+    }
+    // ---- extension: 16 bases of every cell at once, from the LDS windows (an offset that has left them is clamped into
+    // them for the probe and done again from the global mirror below; cells that hold nothing probe offset 0)
+    int ext[C], maxn[C];
+    unsigned oP[C], oT[C];
+    bool more[C], outw = false;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      const int m = nM[c];
+      const bool live = m >= 0;
+      oP[c] = (unsigned)(m + cP[c]); oT[c] = (unsigned)(m + dT);
+      maxn[c] = live ? (int)hmaxu[c] - m : 0;
+      const unsigned qa = min(oP[c], (unsigned)(PK_WIN_BASES - 1)), qb = min(oT[c], (unsigned)(PK_WIN_BASES - 1));
+      const uint32_t x = pk16(SRC.lP, qa) ^ pk16(SRC.lT, qb);
+      const unsigned n16 = first_diff16(x);
+      ext[c] = min((int)n16, maxn[c]);
+      more[c] = live && n16 >= 16u && maxn[c] > 16;
+      outw |= live && max(oP[c], oT[c]) > (unsigned)(PK_WIN_BASES - 1);
+    }
+    if (__any(outw)) {  // rare: the probe again from the global mirror for the cells beyond the windows
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        if (nM[c] >= 0 && max(oP[c], oT[c]) > (unsigned)(PK_WIN_BASES - 1)) {
+          const uint32_t x = pk16(SRC.gP, oP[c]) ^ pk16(SRC.gT, oT[c]);
+          const unsigned n16 = first_diff16(x);
+          ext[c] = min((int)n16, maxn[c]);
+          more[c] = n16 >= 16u && maxn[c] > 16;
+        }
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      if (__any(more[c])) {
+        bool tail = false;
+        if (more[c]) {
+          const int n = pk_stage2(SRC, oP[c], oT[c]);
+          ext[c] = min(n, maxn[c]);
+          tail = n >= 80 && maxn[c] > 80;
+        }
+        // runs longer than 80 bases: the wave finishes them together (uniform control flow: every lane is here)
+        if (__any(tail)) ext[c] = pk_wave_tail(SRC, oP[c], oT[c], ext[c], maxn[c], tail);
+      }
+    }
+    int mak = 0;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      const int m = nM[c];
+      const int me = m + ext[c];
+      const bool live = m >= 0;
+      nM[c] = live ? me : WF_NULL;
+      mak = max(mak, live ? 2 * me + negk[c] : 0);  // (cells outside the core: far below zero)
+    }
+    if (P2) {
+      // every row of the core is kept: five components into the job's P2 rows
+      int32_t* prow = p2_arena + J.p2_off + J.koff2 + ((int64_t)(dir * 5) * P2K + (t - 1)) * J.w2;
+      const int64_t cstride = (int64_t)P2K * J.w2;
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        const int k = k0 + c;
+        if (incore[c] && s <= s_last[c]) {
+          prow[C_M * cstride + k] = nM[c]; prow[C_I1 * cstride + k] = nI1[c]; prow[C_I2 * cstride + k] = nI2[c];
+          prow[C_D1 * cstride + k] = nD1[c]; prow[C_D2 * cstride + k] = nD2[c];
+        }
+      }
+    }
+    // stream the last H rows of I/D of the core to the output snapshot
+    if (!P2 && t > Tn - H) {
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        const int k = k0 + c;
+        if (incore[c] && s <= s_last[c]) {
+          const int64_t ro = ((int64_t)(s & RMASK)) * width + k;
+          rout[(int64_t)C_I1 * RING * width + ro] = nI1[c];
+          rout[(int64_t)C_I2 * RING * width + ro] = nI2[c];
+          rout[(int64_t)C_D1 * RING * width + ro] = nD1[c];
+          rout[(int64_t)C_D2 * RING * width + ro] = nD2[c];
+        }
+      }
+    }
+    // advance the delay line of this step's class only
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+#pragma unroll
+      for (int e = DEP - 1; e > 0; --e) Mh[c][cl][e] = Mh[c][cl][e - 1];
+      Mh[c][cl][0] = nM[c];
+#pragma unroll
+      for (int d = E1 - 1; d > 0; --d) { I1h[c][d] = I1h[c][d - 1]; D1h[c][d] = D1h[c][d - 1]; }
+      I1h[c][0] = nI1[c]; D1h[c][0] = nD1[c];
+      I2h[c] = nI2[c]; D2h[c] = nD2[c];
+    }
+    mak = wave_max63(mak);
+    if (lane == 63 && mak > 0) {
+      if (WAVE1) s_makr[t] = mak;
+      else atomicMax(&s_makr[t], mak);
+    }
+  }
+  }
+  // ---- output snapshot: the newest H rows of M for the core ----
+  if (P2) return;
+  const int s_end = s0 + Tn;
+  if (Tn < H) {
+    // a short last block: the I/D rows of scores <= s0 that the step kernel still looks at live in the input ring
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      const int k = k0 + c;
+      if (!incore[c]) continue;
+      for (int d = Tn; d < H; ++d) {
+        const int sc = s_end - d;
+        if (sc < 0 || k < rng2_lo(RG, sc) || k > rng2_hi(RG, sc)) continue;
+        const int64_t ro = ((int64_t)(sc & RMASK)) * width + k;
+        rout[(int64_t)C_I1 * RING * width + ro] = rin[(int64_t)C_I1 * RING * width + ro];
+        rout[(int64_t)C_I2 * RING * width + ro] = rin[(int64_t)C_I2 * RING * width + ro];
+        rout[(int64_t)C_D1 * RING * width + ro] = rin[(int64_t)C_D1 * RING * width + ro];
+        rout[(int64_t)C_D2 * RING * width + ro] = rin[(int64_t)C_D2 * RING * width + ro];
+      }
+    }
+  }
+  auto write_rows = [&](auto TR) {
+    constexpr int tr = decltype(TR)::value;  // T mod 5
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      const int k = k0 + c;
+      if (!incore[c]) continue;
+#pragma unroll
+      for (int d = 0; d < H; ++d) {
+        const int r = ((tr - d) % NCL + NCL) % NCL;        // class of row s_end - d
+        const int back = ((tr - r) % NCL + NCL) % NCL;     // s_end - (newest score of class r)
+        const int e = (d - back) / NCL;
+        const int sc = s_end - d;
+        if (sc >= 0 && k >= rng2_lo(RG, sc) && k <= rng2_hi(RG, sc)) rout[((int64_t)(C_M * RING + (sc & RMASK))) * width + k] = Mh[c][r][e];
+      }
+    }
+  };
+  switch (Tn % NCL) {
+    case 0: write_rows(std::integral_constant<int, 0>{}); break;
+    case 1: write_rows(std::integral_constant<int, 1>{}); break;
+    case 2: write_rows(std::integral_constant<int, 2>{}); break;
+    case 3: write_rows(std::integral_constant<int, 3>{}); break;
+    default: write_rows(std::integral_constant<int, 4>{}); break;
+  }
+  __syncthreads();
+  int32_t* mk = mak_out + ((int64_t)tk.job * 2 + dir) * T;
+  for (int t = 1 + tid; t <= T; t += NT) if (s_makr[t] > 0) atomicMax(&mk[t - 1], s_makr[t]);
+}
+
+void launch_tile2(const uint32_t* pk, int32_t* ring, const TileJob* jobs, const TileTask* tasks, int32_t* mak, int ntasks, int threads, int T,
+                  hipStream_t st) {
+  const size_t lds = (size_t)(T + 1) * 4;
+  if (threads <= 64) hipLaunchKernelGGL((wfa_tile2_kernel<64, false>), dim3(ntasks), dim3(64), lds, st, pk, ring, jobs, tasks, mak, T, (int32_t*)nullptr);
+  else hipLaunchKernelGGL((wfa_tile2_kernel<1024, false>), dim3(ntasks), dim3(threads), lds, st, pk, ring, jobs, tasks, mak, T, (int32_t*)nullptr);
+}
+void launch_tile2_p2(const uint32_t* pk, int32_t* ring, const TileJob* jobs, const TileTask* tasks, int ntasks, int threads, int32_t* p2, hipStream_t st) {
+  const size_t lds = (size_t)(P2K + 1) * 4;
+  if (threads <= 64) hipLaunchKernelGGL((wfa_tile2_kernel<64, true>), dim3(ntasks), dim3(64), lds, st, pk, ring, jobs, tasks, (int32_t*)nullptr, P2K, p2);
+  else hipLaunchKernelGGL((wfa_tile2_kernel<1024, true>), dim3(ntasks), dim3(threads), lds, st, pk, ring, jobs, tasks, (int32_t*)nullptr, P2K, p2);
+}
+
+// ---------------------------------------------------------------------------
+// self-test of the wave shifts the kernel leans on (tests/test_align_gpu.py): out[lane] = value of lane - 1, out[64 + lane] = lane + 1
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void dpp_selftest_kernel(int* __restrict__ out) {
+  const int lane = threadIdx.x;
+  out[lane] = from_prev_lane(1000 + lane);
+  out[64 + lane] = from_next_lane(1000 + lane);
+}
+int selftest_dpp(int* host_out128, hipStream_t st) {
+  int* d = nullptr;
+  if (hipMalloc((void**)&d, 128 * sizeof(int)) != hipSuccess) return -1;
+  hipLaunchKernelGGL(dpp_selftest_kernel, dim3(1), dim3(64), 0, st, d);
+  hipError_t e = hipMemcpyAsync(host_out128, d, 128 * sizeof(int), hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  (void)hipFree(d);
+  return e == hipSuccess ? 0 : -1;
+}
+
+}  // namespace wfm
