@@ -525,3 +525,42 @@ def test_phase2_walks_longer_than_the_rows_computed_ahead(gpu, oracle, monkeypat
         seen.append((st.p2_again, st.p2_more))
     assert seen[0][0] > 0, seen          # further rounds were taken
     assert seen[1][0] == 0 and seen[1][1] > 0, seen  # one round only: the step kernel finishes those jobs
+
+
+def test_phase2_work_list_overflow_path(oracle, tmp_path):
+    """wfa_p2_overlap_kernel lists the blocks of a round's scans in LDS (3072 entries) and runs what does not fit scan by scan;
+    with a list of 4 entries (WFM_P2_WORKCAP, read once per process: a process of its own) nearly every round overflows.  Repeat
+    units (no maximum prunes a row of a direction that has crossed the text), unrelated pairs and ordinary ones."""
+    import subprocess
+    import sys
+    import textwrap
+    script = tmp_path / "p2cap.py"
+    script.write_text(textwrap.dedent(f"""
+        import sys
+        sys.path.insert(0, {str(__import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))!r})
+        from wfmash_amd import capi, synth
+        from oracle import pyoracle as O
+        items = []
+        for i in range(6):
+            unit = synth.random_dna(910 + i, 700)
+            p = synth.random_dna(920 + i, 3000) + unit * 6 + synth.random_dna(930 + i, 3000)
+            t = synth.mutate(synth.random_dna(920 + i, 3000) + unit * 4 + synth.random_dna(930 + i, 3000), 0.03, 9400 + i)
+            items.append((p, t))
+        for i in range(6):
+            p = synth.random_dna(940 + i, 9000)
+            items.append((p, synth.mutate(p, 0.06, 9500 + i)))
+        items.append((synth.random_dna(950, 5000), synth.random_dna(951, 5200)))
+        h = capi.Handle(0)
+        res = h.align(items)
+        bad = 0
+        for (p, t), r in zip(items, res):
+            rc, ops, sc, _ = O.align_biwfa(p, t)
+            assert rc == 0 and r.status == 0 and r.score == sc, (len(p), len(t), r.status, r.score, sc)
+            bad += r.ops != ops
+        h.close()
+        assert bad == 0, bad
+        print("P2CAP_OK")
+    """))
+    env = dict(__import__("os").environ, WFM_P2_WORKCAP="4")
+    r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "P2CAP_OK" in r.stdout, (r.stdout[-1000:], r.stderr[-3000:])

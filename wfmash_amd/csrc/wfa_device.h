@@ -122,6 +122,8 @@ struct BpResult {
   int32_t steps_p1;            // steps spent before the antidiagonals met
   uint32_t ticks_p1, ticks_p2; // wall_clock64 ticks (100 MHz) per phase
   int32_t pad_;
+  uint32_t ticks_list, ticks_pick;  // wfa_p2_overlap_kernel: the block-listing and the pick stages (diagnostics)
+  uint32_t work_items, pad2_;       // blocks listed over all rounds
 };
 
 struct BaseJob {

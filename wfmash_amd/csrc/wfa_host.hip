@@ -791,6 +791,11 @@ int run_p2_phase(wfm_handle* h, wfm_seqset* S, const DevPen& dp, int scope, cons
       for (const BpResult& r : got) { more += r.status == WFM_DEV_P2_MORE; tk += r.ticks_p2; tc += r.ticks_p1; rd += r.pad_; tkmax = std::max(tkmax, r.ticks_p2); rdmax = std::max(rdmax, r.pad_); }
       fprintf(stderr, "[wfm] phase 2 from rows computed ahead: %zu jobs, widest %zu columns, %zu tiles of %d threads, %.3f ms, %d left to the step kernel; walk per job: %.1f rounds (max %d), %.0f us (max %.0f), of which cells stage %.0f us\n",
               n, maxw2, tasks.size(), threads_c, ms, more, rd / n, rdmax, tk / n / 100.0, tkmax / 100.0, tc / n / 100.0);
+      size_t qs = 0;
+      for (size_t q = 0; q < n; ++q) if (got[q].ticks_p2 > got[qs].ticks_p2) qs = q;
+      fprintf(stderr, "[wfm]   slowest walk: pl %d tl %d sub %d w2 %d nblk %d: %d rounds, %.0f us = listing %.0f + cells %.0f (incl. listing) + pick %.0f, %u blocks listed, status %d\n", pj[qs].pl, pj[qs].tl,
+              pj[qs].sub == SUB_NONE ? -1 : pj[qs].sub, pj[qs].w2, pj[qs].nblk, got[qs].pad_, got[qs].ticks_p2 / 100.0, got[qs].ticks_list / 100.0, got[qs].ticks_p1 / 100.0, got[qs].ticks_pick / 100.0,
+              got[qs].work_items, got[qs].status);
     }
     // another round for the jobs whose walk ran out of rows (while their rings have room for its rows)
     std::vector<P2Job> mj;

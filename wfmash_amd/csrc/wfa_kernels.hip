@@ -19,6 +19,7 @@
 // an out-of-bounds I/D offset can only feed out-of-bounds cells.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <algorithm>
 #include <cstdlib>
 #include <type_traits>
 
@@ -861,10 +862,15 @@ __global__ __launch_bounds__(256) void wfa_p2_blockmax_kernel(const int32_t* __r
   for (int cc = 0; cc < 5; ++cc) row[cc] = s >= 0 ? p2_row(ring, p2, J, d, cc, s) : nullptr;
   for (int b = wv; b < J.nblk; b += nw) {
     const int k = (b << 6) - J.koff2 + lane;
+    // The maxima are taken over ANTIDIAGONALS, 2 h - k = h + v, not over offsets: two cells on mirrored diagonals (k0 + k1 = tl - pl)
+    // meet, o0 + o1 >= tl, iff their antidiagonals sum to >= tl + pl -- and a wavefront is flat in antidiagonals where its
+    // offsets differ by half a block's width from one end of a block to the other.  (Offset maxima, until round 4: the
+    // two directions of a job in phase 2 ARE within a block's width of touching everywhere, so hardly a block was pruned --
+    // a 2.5 kb pair of unrelated sequences in an LPA level tested 13 M cell pairs, 3.4 ms for a launch whose average walk took 0.1.)
     int v[5] = {0, 0, 0, 0, 0};
     if (k >= lo && k <= hi) {
 #pragma unroll
-      for (int cc = 0; cc < 5; ++cc) v[cc] = max(row[cc][k], 0);
+      for (int cc = 0; cc < 5; ++cc) { const int o = row[cc][k]; v[cc] = o >= 0 ? 2 * o - k : 0; }
     }
 #pragma unroll
     for (int cc = 0; cc < 5; ++cc) {
@@ -919,10 +925,12 @@ __device__ unsigned long long g_p2cnt[8];  // WFM_P2_COUNT diagnostics: tests, t
 // The tests of a round see the best breakpoint as it was when the round began: that only lets more pairs through the first
 // two stages than a test on its own would look at; what a test takes is decided in `pick`, with the best of that moment.
 constexpr int P2G = 8;
+constexpr int P2WORK = 3072;  // blocks one round's work list holds (24 KB of LDS)
+constexpr int P2CM = 256;     // widest rows (in blocks of 64 diagonals) whose column maxima are kept in LDS (40 KB); wider jobs prune by M1 only
 __global__ __launch_bounds__(1024) void wfa_p2_overlap_kernel(const int32_t* __restrict__ ring, const int32_t* __restrict__ p2,
                                                              const P2Job* __restrict__ jobs, const int32_t* __restrict__ p2max,
                                                              const int32_t* __restrict__ bmax, const int32_t* __restrict__ pbmax,
-                                                             BpResult* __restrict__ results, DevPen pen, int scope, int count) {
+                                                             BpResult* __restrict__ results, DevPen pen, int scope, int count, int work_cap) {
   const int job = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, nw = blockDim.x >> 6;
   const P2Job J = jobs[job];
   const int nblk = J.nblk;
@@ -935,16 +943,22 @@ __global__ __launch_bounds__(1024) void wfa_p2_overlap_kernel(const int32_t* __r
   __shared__ int s_bp[8];
   __shared__ unsigned long long s_cells;
   __shared__ int s_rmax[2][P2ROWS][5];
+  __shared__ int s_work[P2WORK][2];  // the blocks to look at this round: ((test, component) << 20 | block, the block's maximum in the tested row)
+  __shared__ int s_nwork, s_ovf;
+  __shared__ int s_ka[P2G * 5], s_kb[P2G * 5];  // per scan: the diagonals of the tested row that some row mirrors
+  __shared__ int s_cm[P2G * 5][P2CM];           // per scan and block of the other direction: the largest value of the scan's rows there
   for (int i = tid; i < 2 * P2ROWS * 5; i += blockDim.x) ((int*)s_rmax)[i] = p2max[(int64_t)job * 2 * P2ROWS * 5 + i];
   if (tid < 8) s_bp[tid] = 0;
   // (with a bound of the job's score the walk starts as if a breakpoint of score bound + 1 were in hand: see wfa_bp_kernel)
   if (tid == 0) { s_state[0] = J.sf; s_state[1] = J.sr; s_state[2] = J.last_fwd; s_state[3] = min(J.sub < SUB_NONE ? J.sub + 1 : INT32_MAX, J.best0 > 0 ? J.best0 : INT32_MAX); s_state[4] = 0; s_state[5] = 0; s_cells = 0; }
   __syncthreads();
   const int pl = J.pl, tl = J.tl, kinv = tl - pl;
+  const int aneed = tl + pl;  // the row / block maxima are antidiagonals (wfa_p2_blockmax_kernel): two cells can only meet when theirs sum to this
   const Rng RG = make_rng(pl, tl, J.sub);
   const int gopen = max(pen.o1, pen.o2);
   const long long t_begin = wall_clock64();
-  long long t_cells = 0;
+  long long t_cells = 0, t_list = 0, t_pick = 0;
+  long long n_items = 0;
   int rounds = 0;
   for (;;) {
     ++rounds;
@@ -971,26 +985,34 @@ __global__ __launch_bounds__(1024) void wfa_p2_overlap_kernel(const int32_t* __r
       test_of(g, d0, s0, s1);
       const int d1 = d0 ^ 1, sd0 = d0 == 0 ? J.sf : J.sr, sd1 = d1 == 0 ? J.sf : J.sr, si = s1 - i;
       if (si >= 0 && s0 + si - pen.o2 < best && s0 + si - bp_gap_open(pen, cc) < best &&
-          s_rmax[d0][s0 - (sd0 - 25)][cc] + s_rmax[d1][si - (sd1 - 25)][cc] >= tl) {
+          s_rmax[d0][s0 - (sd0 - 25)][cc] + s_rmax[d1][si - (sd1 - 25)][cc] >= aneed) {
         atomicOr(&s_pmask[g][cc], 1u << i);
         s_k[g][2] = 1;
       }
     }
     __syncthreads();
     const long long t_c0 = wall_clock64();
-    // ---- scan: one wave per (test, component) with the rows of the other direction that can still matter, ALL of them at
-    // once.  The 64-diagonal blocks of the tested row go by in ascending order (the reference's loop only ever takes the
-    // smallest diagonal on which a pair of rows meets): a block that holds a value large enough for some row is looked at
-    // -- first its maximum against the block maxima of every row, one row per lane, then, for the rows that pass, cell
-    // by cell, one diagonal per lane, four rows in flight.  A pair leaves the mask with its first hit.
-    // (Pair by pair this was the walk's whole cost: a direction that has reached the end of the text holds the value tl in
-    // every row, so no maximum prunes anything, and each of up to 26 x 5 pairs per test paid its own two or three dependent
-    // round trips to find that the rows do not share a diagonal yet; the walk of one job took 1 - 10 ms and its launch with it.)
+    // ---- scan.  Per (test, component) the rows of the other direction that can still matter are tested against the tested row
+    // block by block (64 diagonals): a block that holds a value large enough for some row is looked at -- first its maximum
+    // against the block maxima of every row, one row per lane, then, for the rows that pass, cell by cell, one diagonal per
+    // lane, four rows in flight; per (test, row, component) the SMALLEST diagonal on which the offsets meet is kept (atomicMin:
+    // the reference's loop only ever takes that one).
+    // Round 4: the blocks of all (test, component) scans of the round go through ONE work list that all waves share.  Until
+    // then a scan belonged to one wave, which walked its blocks in ascending order and dropped a row at its first hit -- and on
+    // repeat-rich records (LPA's KIV-2 copies: every row of a direction that has crossed the text holds tl, no maximum prunes)
+    // one scan of a hundred blocks kept one wave busy for milliseconds while fifteen waited at the barrier: a launch of 400 jobs
+    // took 3.4 ms for an average walk of 0.1 ms.  A row that has already met on a smaller diagonal is skipped by later blocks.
+    // (Pair by pair this was the walk's whole cost in round 2: each of up to 26 x 5 pairs per test paid its own two or three
+    // dependent round trips to find that the rows do not share a diagonal yet.)
     {
-      unsigned c_rounds = 0, c_hits = 0;
+      if (tid == 0) { s_nwork = 0; s_ovf = 0; }
+      __syncthreads();
+      const long long t_l0 = wall_clock64();
+      // -- list the blocks: one wave per (test, component)
       for (int it = wv; it < ng * 5; it += nw) {
         const int g = it / 5, cc = it % 5;
-        unsigned todo = s_pmask[g][cc];
+        const unsigned todo = s_pmask[g][cc];
+        if (lane == 0) { s_ka[it] = 1; s_kb[it] = 0; }
         if (!todo) continue;
         int d0, s0, s1;
         test_of(g, d0, s0, s1);
@@ -1003,63 +1025,139 @@ __global__ __launch_bounds__(1024) void wfa_p2_overlap_kernel(const int32_t* __r
         }
         ka = max(ka, rng_lo(RG, s0)); kb = min(kb, rng_hi(RG, s0));
         if (ka > kb) continue;
-        const int32_t* R0 = p2_row(ring, p2, J, d0, cc, s0);
+        if (lane == 0) { s_ka[it] = ka; s_kb[it] = kb; }
         const int32_t* bm0 = bmj + ((int64_t)(d0 * P2ROWS + (s0 - (sd0 - 25))) * 5 + cc) * nblk;
         int M1 = 0;  // the largest value any of the rows holds anywhere
         for (unsigned q = todo; q; q &= q - 1) M1 = max(M1, s_rmax[d1][s1 - (int)__builtin_ctz(q) - (sd1 - 25)][cc]);
+        // ... and per block of the OTHER direction the largest value any of the rows holds there: a block of the tested row is
+        // only listed when the one or two blocks it mirrors can reach tl with it.  (M1 alone lets every block through once a
+        // direction has crossed the text anywhere -- small unrelated or repeat-rich problems listed 1100 blocks per round and
+        // paid a dependent round trip for each to find that no row passes: 3.4 ms for one job of LPA's, 0.1 ms on average.)
+        const bool colmax = nblk <= P2CM;
+        if (colmax) {
+          for (int b1 = lane; b1 < nblk; b1 += 64) {
+            int cm = 0;
+            for (unsigned q = todo; q; q &= q - 1) {
+              const int si = s1 - (int)__builtin_ctz(q);
+              cm = max(cm, bmj[((int64_t)(d1 * P2ROWS + (si - (sd1 - 25))) * 5 + cc) * nblk + b1]);
+            }
+            s_cm[it][b1] = cm;
+          }
+          __threadfence_block();  // (written and read by this wave only)
+        }
         const int B_lo = (ka + J.koff2) >> 6, B_hi = (kb + J.koff2) >> 6;
-        for (int bb = B_lo; bb <= B_hi && todo; bb += 64) {
+        for (int bb = B_lo; bb <= B_hi; bb += 64) {
           const int bl = bb + lane;
           const int bv = bl <= B_hi ? bm0[bl] : 0;
-          unsigned long long m = __ballot(bl <= B_hi && bv + M1 >= tl);
-          while (m && todo) {
-            const int f = (int)__builtin_ctzll(m);
-            m &= m - 1;
-            const int b = bb + f, v0 = rdlane(bv, f);
-            const int kb_lo = max(ka, (b << 6) - J.koff2), kb_hi = min(kb, (b << 6) - J.koff2 + 63);
-            // rows whose mirrored block(s) can meet this one: one row per lane
-            bool pass = false;
-            if (lane < scope && ((todo >> lane) & 1u)) {
-              const int si = s1 - lane;
-              const int32_t* bm1 = bmj + ((int64_t)(d1 * P2ROWS + (si - (sd1 - 25))) * 5 + cc) * nblk;
-              // the part of this block the row mirrors, and the row's one or two blocks that hold it
-              const int q_lo = max(kb_lo, kinv - rng_hi(RG, si)), q_hi = min(kb_hi, kinv - rng_lo(RG, si));
-              if (q_lo <= q_hi) {
-                const int b1a = (kinv - q_hi + J.koff2) >> 6, b1b = (kinv - q_lo + J.koff2) >> 6;  // b1a <= b1b <= b1a + 1, inside the row
-                pass = v0 + max(bm1[b1a], bm1[b1b]) >= tl;
-              }
+          int other = M1;
+          if (colmax && bl <= B_hi) {
+            const int k_lo = (bl << 6) - J.koff2, k_hi = k_lo + 63;  // the block's diagonals; their mirrors lie in at most two blocks
+            const int b1a = min(max((kinv - k_hi + J.koff2) >> 6, 0), nblk - 1), b1b = min(max((kinv - k_lo + J.koff2) >> 6, 0), nblk - 1);
+            other = max(s_cm[it][b1a], s_cm[it][b1b]);
+          }
+          const bool pass = bl <= B_hi && bv + other >= aneed;
+          const unsigned long long m = __ballot(pass);
+          if (!m) continue;
+          int base = 0;
+          if (lane == 0) base = atomicAdd(&s_nwork, (int)__popcll(m));
+          base = rdlane(base, 0);
+          const int at = base + (int)__popcll(m & ((1ull << lane) - 1ull));
+          if (pass) {
+            if (at < work_cap) { s_work[at][0] = (it << 20) | bl; s_work[at][1] = bv; }
+            else s_ovf = 1;
+          }
+        }
+      }
+      __syncthreads();
+      t_list += wall_clock64() - t_l0;
+      n_items += s_nwork;
+      const int nwork = min(s_nwork, work_cap);
+      const bool ovf = s_ovf != 0;  // (more blocks than the list holds: the scans that did not fit run the old way below)
+      unsigned c_rounds = 0, c_hits = 0;
+      // one block against the rows of its scan: which rows' mirrored blocks can meet it, then the cells
+      auto do_block = [&](int g, int cc, int b, int v0, int ka, int kb, unsigned todo, int d0, int s0, int s1) -> unsigned {
+        const int d1 = d0 ^ 1, sd1 = d1 == 0 ? J.sf : J.sr;
+        const int32_t* R0 = p2_row(ring, p2, J, d0, cc, s0);
+        const int kb_lo = max(ka, (b << 6) - J.koff2), kb_hi = min(kb, (b << 6) - J.koff2 + 63);
+        // (the tested row's cells are asked for before anything depends on them: one round trip less per block)
+        const int k0 = (b << 6) - J.koff2 + lane, k1 = kinv - k0;
+        const int o0 = (k0 >= kb_lo && k0 <= kb_hi) ? R0[k0] : WF_NULL;
+        // rows whose mirrored block(s) can meet this one: one row per lane (a row that has met on a smaller diagonal is done)
+        bool pass = false;
+        if (lane < scope && ((todo >> lane) & 1u) && s_mink[g][lane * 5 + cc] > kb_lo) {
+          const int si = s1 - lane;
+          const int32_t* bm1 = bmj + ((int64_t)(d1 * P2ROWS + (si - (sd1 - 25))) * 5 + cc) * nblk;
+          // the part of this block the row mirrors, and the row's one or two blocks that hold it
+          const int q_lo = max(kb_lo, kinv - rng_hi(RG, si)), q_hi = min(kb_hi, kinv - rng_lo(RG, si));
+          if (q_lo <= q_hi) {
+            const int b1a = (kinv - q_hi + J.koff2) >> 6, b1b = (kinv - q_lo + J.koff2) >> 6;  // b1a <= b1b <= b1a + 1, inside the row
+            pass = v0 + max(bm1[b1a], bm1[b1b]) >= aneed;
+          }
+        }
+        unsigned rows = (unsigned)__ballot(pass);
+        if (!rows) return todo;
+        // the cells: one diagonal per lane against up to four rows at a time (eight in flight measured slower: the walk of
+        // a heavy job is bound by the instruction issue of its 16 waves -- ~30 instructions per row and block -- not by round trips)
+        constexpr int RG8 = 4;
+        while (rows) {
+          int ri[RG8], o1[RG8];
+#pragma unroll
+          for (int j = 0; j < RG8; ++j) {
+            ri[j] = rows ? (int)__builtin_ctz(rows) : -1;
+            if (rows) rows &= rows - 1;
+          }
+#pragma unroll
+          for (int j = 0; j < RG8; ++j) {
+            o1[j] = WF_NULL;
+            if (ri[j] >= 0) {
+              const int si = s1 - ri[j];
+              if (k1 >= rng_lo(RG, si) && k1 <= rng_hi(RG, si)) o1[j] = p2_row(ring, p2, J, d1, cc, si)[k1];
             }
-            unsigned rows = (unsigned)__ballot(pass);
-            if (!rows) continue;
-            // the cells: one diagonal per lane against up to four rows at a time
-            const int k0 = (b << 6) - J.koff2 + lane, k1 = kinv - k0;
-            const int o0 = (k0 >= kb_lo && k0 <= kb_hi) ? R0[k0] : WF_NULL;
-            while (rows) {
-              int ri[4], o1[4];
+          }
+          ++c_rounds;
 #pragma unroll
-              for (int j = 0; j < 4; ++j) {
-                ri[j] = rows ? (int)__builtin_ctz(rows) : -1;
-                if (rows) rows &= rows - 1;
-              }
-#pragma unroll
-              for (int j = 0; j < 4; ++j) {
-                o1[j] = WF_NULL;
-                if (ri[j] >= 0) {
-                  const int si = s1 - ri[j];
-                  if (k1 >= rng_lo(RG, si) && k1 <= rng_hi(RG, si)) o1[j] = p2_row(ring, p2, J, d1, cc, si)[k1];
-                }
-              }
-              ++c_rounds;
-#pragma unroll
-              for (int j = 0; j < 4; ++j) {
-                if (ri[j] < 0) continue;
-                const unsigned long long hh = __ballot(o0 + o1[j] >= tl);  // (a NULL offset is -2^30: the sum stays far below)
-                if (hh) {
-                  if (lane == 0) s_mink[g][ri[j] * 5 + cc] = (b << 6) - J.koff2 + (int)__builtin_ctzll(hh);
-                  todo &= ~(1u << ri[j]);
-                  ++c_hits;
-                }
-              }
+          for (int j = 0; j < RG8; ++j) {
+            if (ri[j] < 0) continue;
+            const unsigned long long hh = __ballot(o0 + o1[j] >= tl);  // (a NULL offset is -2^30: the sum stays far below)
+            if (hh) {
+              if (lane == 0) atomicMin(&s_mink[g][ri[j] * 5 + cc], (b << 6) - J.koff2 + (int)__builtin_ctzll(hh));
+              todo &= ~(1u << ri[j]);
+              ++c_hits;
+            }
+          }
+        }
+        return todo;
+      };
+      for (int w = wv; w < nwork; w += nw) {
+        const int it = s_work[w][0] >> 20, b = s_work[w][0] & 0xfffff, v0 = s_work[w][1];
+        const int g = it / 5, cc = it % 5;
+        int d0, s0, s1;
+        test_of(g, d0, s0, s1);
+        (void)do_block(g, cc, b, v0, s_ka[it], s_kb[it], s_pmask[g][cc], d0, s0, s1);
+      }
+      if (ovf) {
+        // the blocks that did not fit the list: scan by scan, a wave each, in ascending order (every block again: the listed
+        // ones find their rows done)
+        for (int it = wv; it < ng * 5; it += nw) {
+          const int g = it / 5, cc = it % 5;
+          unsigned todo = s_pmask[g][cc];
+          const int ka = s_ka[it], kb = s_kb[it];
+          if (!todo || ka > kb) continue;
+          int d0, s0, s1;
+          test_of(g, d0, s0, s1);
+          const int d1 = d0 ^ 1, sd0 = d0 == 0 ? J.sf : J.sr, sd1 = d1 == 0 ? J.sf : J.sr;
+          const int32_t* bm0 = bmj + ((int64_t)(d0 * P2ROWS + (s0 - (sd0 - 25))) * 5 + cc) * nblk;
+          int M1 = 0;
+          for (unsigned q = todo; q; q &= q - 1) M1 = max(M1, s_rmax[d1][s1 - (int)__builtin_ctz(q) - (sd1 - 25)][cc]);
+          const int B_lo = (ka + J.koff2) >> 6, B_hi = (kb + J.koff2) >> 6;
+          for (int bb = B_lo; bb <= B_hi && todo; bb += 64) {
+            const int bl = bb + lane;
+            const int bv = bl <= B_hi ? bm0[bl] : 0;
+            unsigned long long m = __ballot(bl <= B_hi && bv + M1 >= aneed);
+            while (m && todo) {
+              const int f = (int)__builtin_ctzll(m);
+              m &= m - 1;
+              todo = do_block(g, cc, bb + f, rdlane(bv, f), ka, kb, todo, d0, s0, s1);
             }
           }
         }
@@ -1071,6 +1169,7 @@ __global__ __launch_bounds__(1024) void wfa_p2_overlap_kernel(const int32_t* __r
     }
     __syncthreads();
     t_cells += wall_clock64() - t_c0;
+    const long long t_p0 = wall_clock64();
     // ---- pick, test after test.  The reference walks i = 0 .. scope-1 and, inside, D2, I2, D1, I1, M; it takes a hit when its
     // score is STRICTLY below the best so far (and skips ahead once a gap-open class can no longer beat it): with o2 >= o1 >= 0
     // the walk ends on the hit of smallest score, the first in that order among equals -- a minimum over (score, position)
@@ -1156,6 +1255,7 @@ __global__ __launch_bounds__(1024) void wfa_p2_overlap_kernel(const int32_t* __r
       }
     }
     __syncthreads();
+    t_pick += wall_clock64() - t_p0;
   }
   if (tid == 0) {
     BpResult r;
@@ -1166,6 +1266,7 @@ __global__ __launch_bounds__(1024) void wfa_p2_overlap_kernel(const int32_t* __r
     r.cells = s_cells;
     r.steps_p1 = J.sf + J.sr;
     r.ticks_p1 = (uint32_t)t_cells; r.ticks_p2 = (uint32_t)(wall_clock64() - t_begin); r.pad_ = rounds;  // diagnostics (WFM_DEBUG)
+    r.ticks_list = (uint32_t)t_list; r.ticks_pick = (uint32_t)t_pick; r.work_items = (uint32_t)n_items; r.pad2_ = 0;
     results[job] = r;
   }
 }
@@ -1355,7 +1456,8 @@ void launch_p2_overlap(const int32_t* ring, const int32_t* p2, const P2Job* jobs
                        BpResult* res, int njobs, int threads, int max_nblk, DevPen pen, int scope, hipStream_t st) {
   static const int count = getenv("WFM_P2_COUNT") ? atoi(getenv("WFM_P2_COUNT")) : 0;
   (void)max_nblk;  // (the walk prunes with each row's own block maxima; the running maxima over the rows are not needed any more)
-  hipLaunchKernelGGL(wfa_p2_overlap_kernel, dim3(njobs), dim3(threads), 0, st, ring, p2, jobs, p2max, bmax, pbmax, res, pen, scope, count);
+  static const int work_cap = getenv("WFM_P2_WORKCAP") ? std::max(1, std::min(P2WORK, atoi(getenv("WFM_P2_WORKCAP")))) : P2WORK;  // (tests: a small list forces the overflow path)
+  hipLaunchKernelGGL(wfa_p2_overlap_kernel, dim3(njobs), dim3(threads), 0, st, ring, p2, jobs, p2max, bmax, pbmax, res, pen, scope, count, work_cap);
 }
 void p2_counters(unsigned long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_p2cnt), sizeof(unsigned long long) * 8); }
 void launch_base(const uint8_t* seq, int32_t* a32, uint8_t* a8, uint32_t* rle, const BaseJob* jobs, BaseResult* res,
