@@ -162,6 +162,8 @@ constexpr int64_t PK_PAD_WORDS = 2048 + 64;  // words of padding behind the mirr
 void launch_tile2(const uint32_t* pk, int32_t* ring, const TileJob* jobs, const TileTask* tasks, int32_t* mak, int ntasks, int threads, int T, hipStream_t st);
 void launch_tile2_p2(const uint32_t* pk, int32_t* ring, const TileJob* jobs, const TileTask* tasks, int ntasks, int threads, int32_t* p2, hipStream_t st);
 int selftest_dpp(int* host_out128, hipStream_t st);
+// leaves and patches on registers and packed sequences (default penalties; rows of at most 2 * threads diagonals): launch_base's contract
+void launch_base2(const uint32_t* pk, int32_t* a32, uint8_t* a8, uint32_t* rle, const BaseJob* jobs, BaseResult* res, int njobs, int threads, hipStream_t st);
 void launch_bp(const uint8_t* seq, int32_t* ring, const BpJob* jobs, BpResult* res, int njobs, int threads,
                DevPen pen, int scope, int ring_rows, hipStream_t st);
 void launch_tile_init(const uint8_t* seq, int32_t* ring, const TileJob* jobs, int32_t* mak0, int njobs, int ring_rows, hipStream_t st);

@@ -98,7 +98,7 @@ struct Node {
 struct wfm_seqset {
   uint8_t* d_seq = nullptr;
   uint32_t* d_pk = nullptr;          // 2-bit mirror of d_seq (wfa_tile2.hip), PK_PAD_WORDS behind it
-  std::vector<int32_t> acgt;         // per problem: nonzero = both sequences are pure upper-case ACGT (BiWFA problems only)
+  std::vector<int32_t> acgt;         // per problem: nonzero = both sequences are pure upper-case ACGT
   size_t bytes = 0;
   std::vector<ProbMeta> meta;
   int64_t rle_total = 0;
@@ -182,7 +182,8 @@ struct wfm_handle {
   DevBuf<BaseResult> bsres;
   DevBuf<int64_t> i64a, i64b, i64c;
   DevBuf<int32_t> i32a;
-  DevBuf<int32_t> seqflags;  // wfm_upload_sequences: per BiWFA problem, nonzero = pure ACGT
+  DevBuf<int32_t> seqflags;  // wfm_upload_sequences: per problem, nonzero = pure ACGT
+  DevBuf<SeqRev> flagjobs;
   DevBuf<unsigned long long> total;
   void* attachment = nullptr;  // owned by another translation unit (map_kernels.hip: the pinned staging ring)
   void (*attachment_free)(void*) = nullptr;
@@ -280,8 +281,21 @@ int run_base_jobs(wfm_handle* h, wfm_seqset* S, const wfm_penalties_t& pen, std:
   // rows beyond 2 k diagonals get 1024 threads -- and rows beyond 512 when the launch is too small to fill the device anyway
   // (the retries of the few patches that overflowed their first budget: one workgroup each, a thousand steps deep)
   const int wide_from = nodes.size() < 128 ? 512 : 2048;
-  auto is_wide = [&](const Node& a) { return base_row_width(a, S->meta[a.prob]) > wide_from; };
-  std::stable_sort(nodes.begin(), nodes.end(), [&](const Node& a, const Node& b) { return is_wide(a) < is_wide(b); });
+  // Kinds of jobs, each in launches of its own: 0 / 1 / 2 = the register kernel on packed sequences (wfa_base2_kernel: default
+  // penalties, pure ACGT, rows up to 128 / 512 / 2048 diagonals, sequences that fit its windows), 3 / 4 = the ring kernel with
+  // 256 / 1024 threads (other penalties, an N, wider rows: a patch eroded to its 4096-base limit starts 8 k diagonals wide)
+  const bool dflt_pen = pen.x == 5 && pen.o1 == 8 && pen.e1 == 2 && pen.o2 == 24 && pen.e2 == 1;
+  const bool base_v2 = dflt_pen && !(getenv("WFM_BASE_V2") && atoi(getenv("WFM_BASE_V2")) == 0) && !(getenv("WFM_TILE_V2") && atoi(getenv("WFM_TILE_V2")) == 0);
+  // (sequences longer than the kernel's LDS windows are fine: what lies beyond is read from the global mirror.  Jobs without
+  // any cell -- an empty pattern or text -- ride along with the first kind: they are one store each)
+  auto kind_of = [&](const Node& a) {
+    const int64_t w = base_row_width(a, S->meta[a.prob]);
+    if (base_v2 && (a.pl == 0 || a.tl == 0)) return 1;
+    if (base_v2 && w <= 2048 && (size_t)a.prob < S->acgt.size() && S->acgt[(size_t)a.prob])
+      return w <= 128 ? 0 : (w <= 640 ? 1 : 2);
+    return w > wide_from ? 4 : 3;
+  };
+  std::stable_sort(nodes.begin(), nodes.end(), [&](const Node& a, const Node& b) { return kind_of(a) < kind_of(b); });
   const DevPen dp{pen.x, pen.o1, pen.e1, pen.o2, pen.e2};
   size_t i0 = 0;
   std::vector<BaseJob> jobs;
@@ -290,14 +304,14 @@ int run_base_jobs(wfm_handle* h, wfm_seqset* S, const wfm_penalties_t& pen, std:
     jobs.clear();
     size_t n32 = 0, n8 = 0;
     size_t i = i0;
-    bool chunk_wide = false;
+    int chunk_kind = 3;
     for (; i < nodes.size(); ++i) {
       const Node& nd = nodes[i];
       const ProbMeta& pm = S->meta[nd.prob];
-      {  // a chunk holds jobs of one kind: rows beyond 2 k diagonals get 1024 threads
-        const bool wide = is_wide(nd);
-        if (jobs.empty()) chunk_wide = wide;
-        else if (wide != chunk_wide) break;
+      {  // a chunk holds jobs of one kind
+        const int kind = kind_of(nd);
+        if (jobs.empty()) chunk_kind = kind;
+        else if (kind != chunk_kind) break;
       }
       BaseJob j{};
       j.p_off = pm.p_fwd + nd.pb;
@@ -349,7 +363,14 @@ int run_base_jobs(wfm_handle* h, wfm_seqset* S, const wfm_penalties_t& pen, std:
       HIPCHK(h, hipMemcpyAsync(h->bsjobs.p, jobs.data(), jobs.size() * sizeof(BaseJob), hipMemcpyHostToDevice, h->stream));
       HIPCHK(h, hipEventRecord(h->ev2, h->stream));
       // (jobs arrive sorted: the wide ones -- long patches, retries with a larger budget -- in chunks of their own)
-      launch_base(S->d_seq, h->base32.p, h->base8.p, h->rle.p, h->bsjobs.p, h->bsres.p, (int)jobs.size(), dp, chunk_wide, RR, h->stream);
+      const bool chunk_wide = chunk_kind == 4;
+      if (chunk_kind <= 2) {
+        int64_t wmax = 1;
+        for (const BaseJob& bj : jobs) if (bj.type == 0) wmax = std::max<int64_t>(wmax, bj.width);
+        const int threads = (int)std::min<int64_t>(1024, ((wmax + 1) / 2 + 63) / 64 * 64);
+        launch_base2(S->d_pk, h->base32.p, h->base8.p, h->rle.p, h->bsjobs.p, h->bsres.p, (int)jobs.size(), threads, h->stream);
+      } else
+        launch_base(S->d_seq, h->base32.p, h->base8.p, h->rle.p, h->bsjobs.p, h->bsres.p, (int)jobs.size(), dp, chunk_wide, RR, h->stream);
       HIPCHK(h, hipGetLastError());
       HIPCHK(h, hipEventRecord(h->ev3, h->stream));
       res.resize(jobs.size());
@@ -370,6 +391,11 @@ int run_base_jobs(wfm_handle* h, wfm_seqset* S, const wfm_penalties_t& pen, std:
         for (size_t q = 0; q < jobs.size(); ++q) { wsum += jobs[q].width; wmax = std::max<int64_t>(wmax, jobs[q].width); smx = std::max<int64_t>(smx, jobs[q].smax); over += res[q].status == WFM_DEV_OVERFLOW; ef += jobs[q].endsfree; }
         fprintf(stderr, "[wfm] base launch: %zu jobs (%d ends-free), %d threads, rows %lld wide on average (max %lld), score budget up to %lld, %.3f ms, %d overflowed\n", jobs.size(), ef,
                 chunk_wide ? 1024 : 256, (long long)(wsum / (int64_t)jobs.size()), (long long)wmax, (long long)smx, ms, over);
+        if (chunk_kind <= 2) {
+          double fw = 0, bk = 0; int fwm = 0, bkm = 0, scm = 0; double scs = 0;
+          for (size_t q = 0; q < jobs.size(); ++q) { const int f = (res[q].pad_ >> 16) & 0xffff, b = res[q].pad_ & 0xffff; fw += f; bk += b; fwm = std::max(fwm, f); bkm = std::max(bkm, b); scs += res[q].score; scm = std::max(scm, res[q].score); }
+          fprintf(stderr, "[wfm]   register kernel (kind %d): forward %.0f us on average (max %d), walk back %.0f us (max %d), score %.0f on average (max %d)\n", chunk_kind, fw / jobs.size(), fwm, bk / jobs.size(), bkm, scs / jobs.size(), scm);
+        }
       }
       for (size_t q = 0; q < jobs.size(); ++q) {
         const Node& nd = nodes[(size_t)jobs[q].pad_];
@@ -1388,7 +1414,7 @@ void wfm_destroy(wfm_handle_t* h) {
   if (h->stage) { (void)hipHostFree(h->stage); h->stage = nullptr; h->stage_cap = 0; }
   h->p2rows.release(); h->p2max.release(); h->p2bmax.release(); h->p2pbmax.release(); h->p2jobs.release();
   h->bpjobs.release(); h->bpres.release(); h->bsjobs.release(); h->bsres.release();
-  h->i64a.release(); h->i64b.release(); h->i64c.release(); h->i32a.release(); h->seqflags.release(); h->total.release();
+  h->i64a.release(); h->i64b.release(); h->i64c.release(); h->i32a.release(); h->seqflags.release(); h->flagjobs.release(); h->total.release();
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   if (h->ev2) (void)hipEventDestroy(h->ev2);
@@ -1515,21 +1541,26 @@ int wfm_upload_sequences(wfm_handle_t* h, const wfm_problem_t* problems, size_t 
       if (e == hipSuccess) e = hipMemcpyAsync(h->revjobs.p, rv.data(), rv.size() * sizeof(SeqRev), hipMemcpyHostToDevice, h->stream);
       if (e == hipSuccess) { launch_reverse(S->d_seq, h->revjobs.p, (int)rv.size(), SEQ_PAD, h->stream); e = hipGetLastError(); }
     }
-    // the mirror of everything (forward and reversed copies), and which BiWFA problems are pure ACGT
-    std::vector<int32_t> flags(rv.size(), 1);
-    if (e == hipSuccess && !rv.empty() && h->seqflags.ensure(rv.size())) e = hipErrorOutOfMemory;
-    if (e == hipSuccess && !rv.empty()) e = hipMemsetAsync(h->seqflags.p, 1, rv.size() * sizeof(int32_t), h->stream);
+    // the mirror of everything (forward and reversed copies), and which problems are pure ACGT
+    std::vector<int32_t> flags(n, 1);
+    std::vector<SeqRev> fj(n);
+    for (size_t i = 0; i < n; ++i) { const ProbMeta& m = S->meta[i]; fj[i] = SeqRev{m.p_fwd, m.p_fwd, m.t_fwd, m.t_fwd, m.plen, m.tlen}; }
+    if (e == hipSuccess && n && (h->seqflags.ensure(n) || h->flagjobs.ensure(n))) e = hipErrorOutOfMemory;
+    if (e == hipSuccess && n) e = hipMemsetAsync(h->seqflags.p, 1, n * sizeof(int32_t), h->stream);
+    if (e == hipSuccess && n) e = hipMemcpyAsync(h->flagjobs.p, fj.data(), n * sizeof(SeqRev), hipMemcpyHostToDevice, h->stream);
     if (e == hipSuccess) {
-      launch_seq_pack(S->d_seq, S->d_pk, pk_words, (int64_t)bytes, h->revjobs.p, (int)rv.size(), rv.empty() ? nullptr : h->seqflags.p, h->stream);
+      launch_seq_pack(S->d_seq, S->d_pk, pk_words, (int64_t)bytes, h->flagjobs.p, (int)n, n ? h->seqflags.p : nullptr, h->stream);
       e = hipGetLastError();
     }
-    if (e == hipSuccess && !rv.empty()) e = hipMemcpyAsync(flags.data(), h->seqflags.p, rv.size() * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    if (e == hipSuccess && n) e = hipMemcpyAsync(flags.data(), h->seqflags.p, n * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);  // (fj is read by the copy above)
     if (e == hipSuccess) {
-      S->acgt.assign(n, 0);
-      size_t q = 0;
-      for (size_t i = 0; i < n; ++i)
-        if (problems[i].mode == WFM_MODE_END2END_BIWFA) S->acgt[i] = flags[q++];
+      S->acgt.assign(flags.begin(), flags.end());
+      if (getenv("WFM_DEBUG") && atoi(getenv("WFM_DEBUG")) > 1) {
+        size_t bad = 0;
+        for (int32_t f : flags) bad += f == 0;
+        fprintf(stderr, "[wfm] upload: %zu problems, %zu of them with something other than upper-case ACGT (byte kernels)\n", n, bad);
+      }
     }
   }
   if (e != hipSuccess) { (void)hipFree(S->d_seq); (void)hipFree(S->d_pk); delete S; h->err = hipGetErrorString(e); return WFM_E_HIP; }

@@ -926,11 +926,12 @@ __device__ unsigned long long g_p2cnt[8];  // WFM_P2_COUNT diagnostics: tests, t
 // two stages than a test on its own would look at; what a test takes is decided in `pick`, with the best of that moment.
 constexpr int P2G = 8;
 constexpr int P2WORK = 3072;  // blocks one round's work list holds (24 KB of LDS)
-constexpr int P2CM = 256;     // widest rows (in blocks of 64 diagonals) whose column maxima are kept in LDS (40 KB); wider jobs prune by M1 only
+constexpr int P2CM = 128;     // widest rows (in blocks of 64 diagonals) whose column maxima are kept in LDS (20 KB); wider jobs prune by the rows' maxima only
+                              // (with antidiagonal maxima those prune well on their own; C3's rows of 200 blocks: 13.9 -> 12.7 ms per step without)
 __global__ __launch_bounds__(1024) void wfa_p2_overlap_kernel(const int32_t* __restrict__ ring, const int32_t* __restrict__ p2,
                                                              const P2Job* __restrict__ jobs, const int32_t* __restrict__ p2max,
                                                              const int32_t* __restrict__ bmax, const int32_t* __restrict__ pbmax,
-                                                             BpResult* __restrict__ results, DevPen pen, int scope, int count, int work_cap) {
+                                                             BpResult* __restrict__ results, DevPen pen, int scope, int count, int work_cap, int cm_max) {
   const int job = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, nw = blockDim.x >> 6;
   const P2Job J = jobs[job];
   const int nblk = J.nblk;
@@ -1033,7 +1034,7 @@ __global__ __launch_bounds__(1024) void wfa_p2_overlap_kernel(const int32_t* __r
         // only listed when the one or two blocks it mirrors can reach tl with it.  (M1 alone lets every block through once a
         // direction has crossed the text anywhere -- small unrelated or repeat-rich problems listed 1100 blocks per round and
         // paid a dependent round trip for each to find that no row passes: 3.4 ms for one job of LPA's, 0.1 ms on average.)
-        const bool colmax = nblk <= P2CM;
+        const bool colmax = nblk <= cm_max;
         if (colmax) {
           for (int b1 = lane; b1 < nblk; b1 += 64) {
             int cm = 0;
@@ -1457,7 +1458,8 @@ void launch_p2_overlap(const int32_t* ring, const int32_t* p2, const P2Job* jobs
   static const int count = getenv("WFM_P2_COUNT") ? atoi(getenv("WFM_P2_COUNT")) : 0;
   (void)max_nblk;  // (the walk prunes with each row's own block maxima; the running maxima over the rows are not needed any more)
   static const int work_cap = getenv("WFM_P2_WORKCAP") ? std::max(1, std::min(P2WORK, atoi(getenv("WFM_P2_WORKCAP")))) : P2WORK;  // (tests: a small list forces the overflow path)
-  hipLaunchKernelGGL(wfa_p2_overlap_kernel, dim3(njobs), dim3(threads), 0, st, ring, p2, jobs, p2max, bmax, pbmax, res, pen, scope, count, work_cap);
+  static const int cm_max = getenv("WFM_P2_COLMAX") ? std::max(0, std::min(P2CM, atoi(getenv("WFM_P2_COLMAX")))) : P2CM;  // rows up to this many blocks get column maxima (0: none)
+  hipLaunchKernelGGL(wfa_p2_overlap_kernel, dim3(njobs), dim3(threads), 0, st, ring, p2, jobs, p2max, bmax, pbmax, res, pen, scope, count, work_cap, cm_max);
 }
 void p2_counters(unsigned long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_p2cnt), sizeof(unsigned long long) * 8); }
 void launch_base(const uint8_t* seq, int32_t* a32, uint8_t* a8, uint32_t* rle, const BaseJob* jobs, BaseResult* res,

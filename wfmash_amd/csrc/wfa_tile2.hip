@@ -148,6 +148,49 @@ __device__ __forceinline__ int pk_wave_tail(const PkSrc& S, unsigned oP, unsigne
   return n;
 }
 
+// The extension of the two cells of a lane: m[c] >= 0 is the cell's offset (else: no cell), oP / oT the offsets of its
+// (v, h) from the windows' origin, maxn how far the sequences go; ext[c] = the number of bases that agree (<= maxn).
+// 16 bases of every cell at once from the LDS windows (an offset that has left them is clamped into them for the probe and
+// done again from the global mirror; cells that hold nothing probe whatever their garbage offset clamps to), then
+// 64 more for the cells whose 16 agreed, then the wave-cooperative tail.  Every lane of the wave makes the call.
+__device__ __forceinline__ void pk_extend2(const PkSrc& SRC, const int (&m)[2], const unsigned (&oP)[2], const unsigned (&oT)[2], const int (&maxn)[2], int (&ext)[2]) {
+  bool more[2], outw = false;
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    const bool live = m[c] >= 0;
+    const unsigned qa = min(oP[c], (unsigned)(PK_WIN_BASES - 1)), qb = min(oT[c], (unsigned)(PK_WIN_BASES - 1));
+    const uint32_t x = pk16(SRC.lP, qa) ^ pk16(SRC.lT, qb);
+    const unsigned n16 = first_diff16(x);
+    ext[c] = min((int)n16, maxn[c]);
+    more[c] = live && n16 >= 16u && maxn[c] > 16;
+    outw |= live && max(oP[c], oT[c]) > (unsigned)(PK_WIN_BASES - 1);
+  }
+  if (__any(outw)) {  // rare: the probe again from the global mirror for the cells beyond the windows
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      if (m[c] >= 0 && max(oP[c], oT[c]) > (unsigned)(PK_WIN_BASES - 1)) {
+        const uint32_t x = pk16(SRC.gP, oP[c]) ^ pk16(SRC.gT, oT[c]);
+        const unsigned n16 = first_diff16(x);
+        ext[c] = min((int)n16, maxn[c]);
+        more[c] = n16 >= 16u && maxn[c] > 16;
+      }
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    if (__any(more[c])) {
+      bool tail = false;
+      if (more[c]) {
+        const int n = pk_stage2(SRC, oP[c], oT[c]);
+        ext[c] = min(n, maxn[c]);
+        tail = n >= 80 && maxn[c] > 80;
+      }
+      // runs longer than 80 bases: the wave finishes them together (uniform control flow: every lane is here)
+      if (__any(tail)) ext[c] = pk_wave_tail(SRC, oP[c], oT[c], ext[c], maxn[c], tail);
+    }
+  }
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------
@@ -365,48 +408,16 @@ __global__ __launch_bounds__(NTMAX) void wfa_tile2_kernel(const uint32_t* __rest
       // a column outside [-pl, tl], or one the score bound has cut off at this score, holds no cell
       nM[c] = s <= s_last[c] ? m : WF_NULL;
     }
-    // ---- extension: 16 bases of every cell at once, from the LDS windows (an offset that has left them is clamped into
-    // them for the probe and done again from the global mirror below; cells that hold nothing probe offset 0)
+    // ---- extension (pk_extend2): 16 bases of every cell at once from the LDS windows, longer runs in stages
     int ext[C], maxn[C];
     unsigned oP[C], oT[C];
-    bool more[C], outw = false;
 #pragma unroll
     for (int c = 0; c < C; ++c) {
       const int m = nM[c];
-      const bool live = m >= 0;
       oP[c] = (unsigned)(m + cP[c]); oT[c] = (unsigned)(m + dT);
-      maxn[c] = live ? (int)hmaxu[c] - m : 0;
-      const unsigned qa = min(oP[c], (unsigned)(PK_WIN_BASES - 1)), qb = min(oT[c], (unsigned)(PK_WIN_BASES - 1));
-      const uint32_t x = pk16(SRC.lP, qa) ^ pk16(SRC.lT, qb);
-      const unsigned n16 = first_diff16(x);
-      ext[c] = min((int)n16, maxn[c]);
-      more[c] = live && n16 >= 16u && maxn[c] > 16;
-      outw |= live && max(oP[c], oT[c]) > (unsigned)(PK_WIN_BASES - 1);
+      maxn[c] = m >= 0 ? (int)hmaxu[c] - m : 0;
     }
-    if (__any(outw)) {  // rare: the probe again from the global mirror for the cells beyond the windows
-#pragma unroll
-      for (int c = 0; c < C; ++c) {
-        if (nM[c] >= 0 && max(oP[c], oT[c]) > (unsigned)(PK_WIN_BASES - 1)) {
-          const uint32_t x = pk16(SRC.gP, oP[c]) ^ pk16(SRC.gT, oT[c]);
-          const unsigned n16 = first_diff16(x);
-          ext[c] = min((int)n16, maxn[c]);
-          more[c] = n16 >= 16u && maxn[c] > 16;
-        }
-      }
-    }
-#pragma unroll
-    for (int c = 0; c < C; ++c) {
-      if (__any(more[c])) {
-        bool tail = false;
-        if (more[c]) {
-          const int n = pk_stage2(SRC, oP[c], oT[c]);
-          ext[c] = min(n, maxn[c]);
-          tail = n >= 80 && maxn[c] > 80;
-        }
-        // runs longer than 80 bases: the wave finishes them together (uniform control flow: every lane is here)
-        if (__any(tail)) ext[c] = pk_wave_tail(SRC, oP[c], oT[c], ext[c], maxn[c], tail);
-      }
-    }
+    pk_extend2(SRC, nM, oP, oT, maxn, ext);
     int mak = 0;
 #pragma unroll
     for (int c = 0; c < C; ++c) {
@@ -519,6 +530,339 @@ void launch_tile2_p2(const uint32_t* pk, int32_t* ring, const TileJob* jobs, con
   const size_t lds = (size_t)(P2K + 1) * 4;
   if (threads <= 64) hipLaunchKernelGGL((wfa_tile2_kernel<64, true>), dim3(ntasks), dim3(64), lds, st, pk, ring, jobs, tasks, (int32_t*)nullptr, P2K, p2);
   else hipLaunchKernelGGL((wfa_tile2_kernel<1024, true>), dim3(ntasks), dim3(threads), lds, st, pk, ring, jobs, tasks, (int32_t*)nullptr, P2K, p2);
+}
+
+// ---------------------------------------------------------------------------
+// Leaves and patches on registers (default penalties, packed sequences): wfa_base_kernel's contract
+// ---------------------------------------------------------------------------
+// r32::wfa_base_kernel keeps its rows in a global-memory ring: a score step reads nine values per cell from L2, extends on
+// bytes from L2 and writes seven values back, with a workgroup barrier in between -- 3 to 5 microseconds per step, a leaf is
+// 250 steps deep and a patch that overflowed its first budget 2000.  Here a workgroup holds the whole row of its job in the
+// tile kernel's register delay lines (two diagonals per lane, up to 2048 diagonals), takes its neighbours by wave shifts and
+// the LDS mailbox, extends on the packed windows (a leaf's or a patch's sequences fit them whole), and writes only what the
+// backtrace reads: per cell the offset before the extension and one byte of decisions, the same bits decided the same way
+// (extension wins ties over opening: BT_*_EXT; source of M on equal offsets: mismatch > D2 > D1 > I2 > I1).  The row ranges
+// the result counts as cells are the ones the ring kernel keeps (per row the union of its sources' ranges), and the
+// backtrace is its backtrace.  Jobs with other penalties, an N, wider rows or longer sequences stay with the ring kernel.
+struct RleWriter2 {
+  uint32_t* base;  // entries are written at base[-1], base[-2], ...
+  int n;
+  int cur_op;
+  uint32_t cur_len;
+  bool writes;
+  __device__ void push(int op, int len) {
+    if (len <= 0) return;
+    if (op == cur_op) { cur_len += (uint32_t)len; return; }
+    flush();
+    cur_op = op; cur_len = (uint32_t)len;
+  }
+  __device__ void flush() {
+    if (cur_len) { ++n; if (writes) base[-n] = (cur_len << 2) | (uint32_t)cur_op; }
+    cur_len = 0; cur_op = -1;
+  }
+};
+
+template <int NTMAX>
+__global__ __launch_bounds__(NTMAX) void wfa_base2_kernel(const uint32_t* __restrict__ pk, int32_t* __restrict__ arena32, uint8_t* __restrict__ arena8,
+                                                        uint32_t* __restrict__ rle, const BaseJob* __restrict__ jobs, BaseResult* __restrict__ results) {
+  constexpr int C = 2, NCL = 5, DEP = 6, E1 = 2;
+  constexpr int PX = 5, PO1 = 8, PE1 = 2, PO2 = 24, PE2 = 1;  // the penalties this form is built for (the host checks)
+  constexpr bool WAVE1 = NTMAX == 64;
+  const BaseJob J = jobs[blockIdx.x];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, nw = blockDim.x >> 6;
+  const long long t_begin = wall_clock64();
+  if (J.type != 0) {  // trivial: all-D or all-I (wavefront_bialign_alignment trivial cases)
+    if (tid == 0) {
+      BaseResult r; r.status = 0; r.cells = 0; r.nruns = 0; r.score = 0; r.pad_ = 0;
+      const int len = J.type == 1 ? J.pl : J.tl;
+      if (len > 0) { rle[J.rle_end - 1] = ((uint32_t)len << 2) | (uint32_t)(J.type == 1 ? OP_D : OP_I); r.nruns = 1; }
+      results[blockIdx.x] = r;
+    }
+    return;
+  }
+  __shared__ int s_edge[2][WAVE1 ? 1 : 16][2][4];
+  __shared__ __attribute__((aligned(16))) uint32_t s_winP[PK_WIN_DW + PK_SLACK_DW], s_winT[PK_WIN_DW + PK_SLACK_DW];
+  __shared__ int s_done, s_endk, s_endoff;
+  const int pl = J.pl, tl = J.tl, kmin = J.kmin, kmax = J.kmin + J.width - 1;
+  const int64_t width = J.width;
+  int32_t* pre_base = arena32 + J.pre_off - kmin;
+  uint8_t* bt_base = arena8 + J.bt_off - kmin;
+  const int k_end = tl - pl;
+  // ---- the sequences whole in the windows (the host sends only jobs whose sequences fit)
+  const int64_t oriP = J.p_off & ~(int64_t)15, oriT = J.t_off & ~(int64_t)15;
+  const int dP = (int)(J.p_off - oriP), dT = (int)(J.t_off - oriT);
+  PkSrc SRC;
+  SRC.lP = (lds_words)s_winP; SRC.lT = (lds_words)s_winT;
+  SRC.gP = (glb_words)pk + (oriP >> 4); SRC.gT = (glb_words)pk + (oriT >> 4);
+  {
+    const int nP = min(PK_WIN_DW + PK_SLACK_DW, (pl + dP + 15) / 16 + 8), nT = min(PK_WIN_DW + PK_SLACK_DW, (tl + dT + 15) / 16 + 8);
+    for (int i = tid; i < nP; i += blockDim.x) s_winP[i] = SRC.gP[i];
+    for (int i = tid; i < nT; i += blockDim.x) s_winT[i] = SRC.gT[i];
+  }
+  if (tid == 0) { s_done = 0; s_endk = INT32_MAX; s_endoff = 0; }
+  for (int i = tid; i < (int)(sizeof(s_edge) / sizeof(int)); i += blockDim.x) ((int*)s_edge)[i] = WF_NULL;  // (a wave that has no cell yet publishes nothing)
+  __syncthreads();
+
+  const int k0 = kmin + tid * C;
+  const int kw_lo = kmin + (tid & ~63) * C, kw_hi = kw_lo + 64 * C - 1;  // the diagonals of this thread's wave
+  int Mh[C][NCL][DEP];
+  int I1h[C][E1], D1h[C][E1], I2h[C], D2h[C];
+  unsigned hmaxu[C];
+  int cP[C], mcur[C];
+  bool colok[C];
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    const int k = k0 + c;
+#pragma unroll
+    for (int r = 0; r < NCL; ++r)
+#pragma unroll
+      for (int e = 0; e < DEP; ++e) Mh[c][r][e] = WF_NULL;
+#pragma unroll
+    for (int d = 0; d < E1; ++d) { I1h[c][d] = WF_NULL; D1h[c][d] = WF_NULL; }
+    I2h[c] = WF_NULL; D2h[c] = WF_NULL;
+    colok[c] = k >= -pl && k <= tl && k <= kmax;
+    hmaxu[c] = colok[c] ? (unsigned)min(tl, pl + k) : 0u;
+    cP[c] = dP - k;
+    mcur[c] = WF_NULL;
+  }
+  auto end_checks = [&](int c, int k, int m_ext, int ins1, int ins2, int del1, int del2) {
+    if (J.endsfree) {
+      if (m_ext >= 0) {
+        const int h = m_ext, v = m_ext - k;
+        if ((h >= tl && pl - v <= J.pef) || (v >= pl && tl - h <= J.tef)) atomicMin(&s_endk, k);
+      }
+    } else if (k == k_end) {
+      const int ev = J.comp_end == C_M ? m_ext : (J.comp_end == C_I1 ? ins1 : (J.comp_end == C_I2 ? ins2 : (J.comp_end == C_D1 ? del1 : del2)));
+      if (ev >= tl) s_done = 1;
+    }
+    (void)c;
+  };
+  // ---- row 0
+  int lo0, hi0;
+  if (J.endsfree) { lo0 = max(-J.pbf, kmin); hi0 = min(J.tbf, kmax); }
+  else { lo0 = 0; hi0 = 0; }
+  {
+    int m0[C], ext[C], maxn[C];
+    unsigned oP[C], oT[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      const int k = k0 + c;
+      const bool on = k >= lo0 && k <= hi0;
+      int m = WF_NULL;
+      if (on) {
+        if (J.endsfree) m = k > 0 ? k : 0;
+        else {
+          if (J.comp_begin == C_M) m = 0;
+          I1h[c][0] = J.comp_begin == C_I1 ? 0 : WF_NULL;
+          I2h[c] = J.comp_begin == C_I2 ? 0 : WF_NULL;
+          D1h[c][0] = J.comp_begin == C_D1 ? 0 : WF_NULL;
+          D2h[c] = J.comp_begin == C_D2 ? 0 : WF_NULL;
+        }
+      }
+      m0[c] = m;
+      oP[c] = (unsigned)(m + cP[c]); oT[c] = (unsigned)(m + dT);
+      maxn[c] = m >= 0 ? min(pl - (m - k), tl - m) : 0;
+    }
+    pk_extend2(SRC, m0, oP, oT, maxn, ext);
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      const int k = k0 + c;
+      if (k < lo0 || k > hi0) continue;
+      pre_base[k] = m0[c]; bt_base[k] = 0;
+      int m = m0[c];
+      if (m >= 0) m += ext[c];
+      if (J.endsfree) end_checks(c, k, m, WF_NULL, WF_NULL, WF_NULL, WF_NULL);
+      else if (k == k_end && J.comp_end == C_M && m >= tl) s_done = 1;
+      Mh[c][0][0] = m;
+      mcur[c] = m;
+    }
+  }
+  uint64_t cells = (uint64_t)(hi0 - lo0 + 1);
+  int s = 0, status = 0;
+  bool done = false;
+  // ---- the steps: score s = tb + jj, class jj % 5 at compile time
+  for (int tb = 0; !done && status == 0; tb += NCL) {
+#pragma unroll
+  for (int jj = 1; jj <= NCL; ++jj) {
+    const int cl = jj % NCL;
+    const int sn = tb + jj;  // the score this step computes
+    int lM10, lM25, lI1, lI2, rM10, rM25, rD1, rD2;
+    const int par = sn & 1;
+    if (!WAVE1) {
+      if (lane == 63) { int* e = s_edge[par][wv][0]; e[0] = Mh[C - 1][cl][1]; e[1] = Mh[C - 1][cl][4]; e[2] = I1h[C - 1][E1 - 1]; e[3] = I2h[C - 1]; }
+      if (lane == 0)  { int* e = s_edge[par][wv][1]; e[0] = Mh[0][cl][1];     e[1] = Mh[0][cl][4];     e[2] = D1h[0][E1 - 1];     e[3] = D2h[0]; }
+    }
+    __syncthreads();  // the previous step's end checks and row range are visible; the edges of this one are published
+    done = J.endsfree ? (s_endk != INT32_MAX) : (s_done != 0);
+    if (done) break;
+    if (sn > J.smax) { status = WFM_DEV_OVERFLOW; break; }
+    s = sn;
+    // The row's range as the ring kernel keeps it -- the union of its sources' ranges, the I / D sources reaching one diagonal
+    // further -- in closed form: row s - 1 is among the sources (e2 = 1) and holds every older row, so a row is its predecessor
+    // and one diagonal more on either side, clipped to the problem and to the job's columns
+    const int lo = max(lo0 - s, max(-pl, kmin)), hi = min(hi0 + s, min(tl, kmax));
+    const bool valid = lo <= hi;
+    if (valid) cells += (uint64_t)(hi - lo + 1);
+    // A wave whose diagonals lie outside the row (and one column around it) has nothing to do: rows only grow (a row holds its
+    // predecessor's range and one diagonal more on either side), so everything the wave holds is NULL and stays NULL, and what
+    // it would publish for its neighbours is what it published before.  The budget of a leaf is its exact score and the rows
+    // are laid out for the budget: on average a third of the waves of a launch have cells at a given step.
+    if (!valid || kw_hi < lo - 1 || kw_lo > hi + 1) continue;
+    lM10 = from_prev_lane(Mh[C - 1][cl][1]); lM25 = from_prev_lane(Mh[C - 1][cl][4]);
+    lI1 = from_prev_lane(I1h[C - 1][E1 - 1]); lI2 = from_prev_lane(I2h[C - 1]);
+    rM10 = from_next_lane(Mh[0][cl][1]); rM25 = from_next_lane(Mh[0][cl][4]);
+    rD1 = from_next_lane(D1h[0][E1 - 1]); rD2 = from_next_lane(D2h[0]);
+    if (!WAVE1) {
+      if (lane == 0 && wv > 0) { const int* e = s_edge[par][wv - 1][0]; lM10 = e[0]; lM25 = e[1]; lI1 = e[2]; lI2 = e[3]; }
+      if (lane == 63 && wv + 1 < nw) { const int* e = s_edge[par][wv + 1][1]; rM10 = e[0]; rM25 = e[1]; rD1 = e[2]; rD2 = e[3]; }
+    }
+    int nM[C], nI1[C], nI2[C], nD1[C], nD2[C], preM[C];
+    unsigned btb[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      const int k = k0 + c;
+      const int a10 = c == 0 ? lM10 : Mh[c - 1][cl][1], b10 = c == C - 1 ? rM10 : Mh[c + 1][cl][1];
+      const int a25 = c == 0 ? lM25 : Mh[c - 1][cl][4], b25 = c == C - 1 ? rM25 : Mh[c + 1][cl][4];
+      const int i1 = c == 0 ? lI1 : I1h[c - 1][E1 - 1], d1 = c == C - 1 ? rD1 : D1h[c + 1][E1 - 1];
+      const int i2 = c == 0 ? lI2 : I2h[c - 1], d2 = c == C - 1 ? rD2 : D2h[c + 1];
+      const int mx = Mh[c][cl][0];
+      unsigned bits = 0;
+      // ext wins ties (WFA2-lib: ext type > open type; piggyback: ext >= open)
+      if (i1 >= a10) bits |= BT_I1_EXT;
+      if (i2 >= a25) bits |= BT_I2_EXT;
+      if (d1 >= b10) bits |= BT_D1_EXT;
+      if (d2 >= b25) bits |= BT_D2_EXT;
+      const unsigned hm = hmaxu[c];
+      int ins1 = max(a10, i1) + 1, ins2 = max(a25, i2) + 1, del1 = max(b10, d1), del2 = max(b25, d2), mis = mx + 1;
+      ins1 = (unsigned)ins1 <= hm ? ins1 : WF_NULL;
+      ins2 = (unsigned)ins2 <= hm ? ins2 : WF_NULL;
+      del1 = (unsigned)del1 <= hm ? del1 : WF_NULL;
+      del2 = (unsigned)del2 <= hm ? del2 : WF_NULL;
+      mis = (unsigned)mis <= hm ? mis : WF_NULL;
+      // M source priority on equal offsets: mismatch > D2 > D1 > I2 > I1
+      int m = ins1; unsigned src = C_I1;
+      if (ins2 >= m) { m = ins2; src = C_I2; }
+      if (del1 >= m) { m = del1; src = C_D1; }
+      if (del2 >= m) { m = del2; src = C_D2; }
+      if (mis >= m)  { m = mis;  src = C_M; }
+      const bool on = valid && k >= lo && k <= hi;  // (outside the row's range the ring kernel computes nothing: nothing is kept there)
+      nI1[c] = on ? ins1 : WF_NULL; nI2[c] = on ? ins2 : WF_NULL; nD1[c] = on ? del1 : WF_NULL; nD2[c] = on ? del2 : WF_NULL;
+      nM[c] = (on && colok[c]) ? m : WF_NULL;
+      preM[c] = nM[c];
+      btb[c] = bits | src;
+      (void)k;
+    }
+    int ext[C], maxn[C];
+    unsigned oP[C], oT[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      const int m = nM[c];
+      oP[c] = (unsigned)(m + cP[c]); oT[c] = (unsigned)(m + dT);
+      maxn[c] = m >= 0 ? (int)hmaxu[c] - m : 0;
+    }
+    pk_extend2(SRC, nM, oP, oT, maxn, ext);
+    int32_t* pre = pre_base + (int64_t)s * width;
+    uint8_t* bt = bt_base + (int64_t)s * width;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      const int k = k0 + c;
+      const bool on = valid && k >= lo && k <= hi;
+      if (on) {
+        pre[k] = preM[c];
+        bt[k] = (uint8_t)btb[c];
+        int m = nM[c];
+        if (m >= 0) m += ext[c];
+        nM[c] = m;
+        end_checks(c, k, m, nI1[c], nI2[c], nD1[c], nD2[c]);
+      }
+      mcur[c] = nM[c];
+#pragma unroll
+      for (int e = DEP - 1; e > 0; --e) Mh[c][cl][e] = Mh[c][cl][e - 1];
+      Mh[c][cl][0] = nM[c];
+#pragma unroll
+      for (int d = E1 - 1; d > 0; --d) { I1h[c][d] = I1h[c][d - 1]; D1h[c][d] = D1h[c][d - 1]; }
+      I1h[c][0] = nI1[c]; D1h[c][0] = nD1[c];
+      I2h[c] = nI2[c]; D2h[c] = nD2[c];
+    }
+  }
+  }
+  // ---- the ends-free walk starts from the offset its end cell holds
+  if (status == 0 && J.endsfree) {
+#pragma unroll
+    for (int c = 0; c < C; ++c) if (k0 + c == s_endk) s_endoff = mcur[c];
+  }
+  __syncthreads();
+  // ---- backtrace (wavefront_backtrace_affine): the first wave, every lane with the same state, lane 0 writes; a run of gap
+  // cells is read 64 decision bytes at a time (r32::wfa_base_kernel)
+  if (tid < 64) {
+    const long long t_fwd = wall_clock64();
+    BaseResult r; r.status = status; r.score = s; r.nruns = 0; r.cells = cells; r.pad_ = 0;
+    if (status == 0) {
+      RleWriter2 w; w.base = rle + J.rle_end; w.n = 0; w.cur_op = -1; w.cur_len = 0; w.writes = lane == 0;
+      int comp = J.endsfree ? C_M : J.comp_end;
+      int k = J.endsfree ? s_endk : k_end;
+      int off = J.endsfree ? s_endoff : tl;
+      int sc = s;
+      int h = off, v = off - k;
+      if (comp == C_M) {
+        if (v < pl) w.push(OP_D, pl - v);
+        if (h < tl) w.push(OP_I, tl - h);
+      }
+      while (v > 0 && h > 0 && sc > 0) {
+        if (comp != C_M) {
+          const bool ins = comp == C_I1 || comp == C_I2;
+          const int e = (comp == C_I1 || comp == C_D1) ? PE1 : PE2, o = (comp == C_I1 || comp == C_D1) ? PO1 : PO2;
+          const unsigned mask = comp == C_I1 ? BT_I1_EXT : (comp == C_I2 ? BT_I2_EXT : (comp == C_D1 ? BT_D1_EXT : BT_D2_EXT));
+          const int scj = sc - lane * e, kj = ins ? k - lane : k + lane;
+          const bool alive = scj > 0 && (ins ? h - lane > 0 : v - lane > 0);
+          const unsigned bj = alive ? bt_base[(int64_t)scj * width + kj] : 0u;
+          const unsigned long long stop = __ballot(!(alive && (bj & mask)));
+          const int j0 = stop ? (int)__builtin_ctzll(stop) : 64;  // cells 0 .. j0-1 continue the gap
+          if (j0 > 0) {
+            w.push(ins ? OP_I : OP_D, j0);
+            sc -= j0 * e;
+            if (ins) { k -= j0; off -= j0; } else k += j0;
+            v = off - k; h = off;
+          }
+          if (j0 < 64) {
+            if (!(v > 0 && h > 0 && sc > 0)) break;   // the walk ends inside the gap
+            sc -= o + e; comp = C_M;                  // the cell that opened the gap
+            w.push(ins ? OP_I : OP_D, 1);
+            if (ins) { --k; --off; } else ++k;
+            v = off - k; h = off;
+          }
+          continue;
+        }
+        const unsigned b = bt_base[(int64_t)sc * width + k];
+        const int pre = pre_base[(int64_t)sc * width + k];
+        w.push(OP_M, off - pre);
+        off = pre; v = off - k; h = off;
+        if (v <= 0 || h <= 0) break;
+        const unsigned src = b & 7u;
+        if (src == C_M) { sc -= PX; comp = C_M; w.push(OP_X, 1); --off; }
+        else if (src == C_I1) { if (b & BT_I1_EXT) { sc -= PE1; comp = C_I1; } else { sc -= PO1 + PE1; comp = C_M; } w.push(OP_I, 1); --k; --off; }
+        else if (src == C_I2) { if (b & BT_I2_EXT) { sc -= PE2; comp = C_I2; } else { sc -= PO2 + PE2; comp = C_M; } w.push(OP_I, 1); --k; --off; }
+        else if (src == C_D1) { if (b & BT_D1_EXT) { sc -= PE1; comp = C_D1; } else { sc -= PO1 + PE1; comp = C_M; } w.push(OP_D, 1); ++k; }
+        else { if (b & BT_D2_EXT) { sc -= PE2; comp = C_D2; } else { sc -= PO2 + PE2; comp = C_M; } w.push(OP_D, 1); ++k; }
+        v = off - k; h = off;
+      }
+      if (comp == C_M && v > 0 && h > 0) { const int nm = min(v, h); w.push(OP_M, nm); v -= nm; h -= nm; }
+      if (v > 0) w.push(OP_D, v);
+      if (h > 0) w.push(OP_I, h);
+      w.flush();
+      r.nruns = w.n;
+    }
+    // diagnostics (WFM_DEBUG=2): microseconds of the forward pass and of the walk back, 16 bits each
+    r.pad_ = (int32_t)((min((t_fwd - t_begin) / 100, 65535ll) << 16) | min((wall_clock64() - t_fwd) / 100, 65535ll));
+    if (lane == 0) results[blockIdx.x] = r;
+  }
+}
+
+// threads: a multiple of 64 with threads * 2 >= the widest row of the launch (<= 1024)
+void launch_base2(const uint32_t* pk, int32_t* a32, uint8_t* a8, uint32_t* rle, const BaseJob* jobs, BaseResult* res, int njobs, int threads, hipStream_t st) {
+  if (threads <= 64) hipLaunchKernelGGL(wfa_base2_kernel<64>, dim3(njobs), dim3(64), 0, st, pk, a32, a8, rle, jobs, res);
+  else if (threads <= 256) hipLaunchKernelGGL(wfa_base2_kernel<256>, dim3(njobs), dim3(threads), 0, st, pk, a32, a8, rle, jobs, res);
+  else hipLaunchKernelGGL(wfa_base2_kernel<1024>, dim3(njobs), dim3(threads), 0, st, pk, a32, a8, rle, jobs, res);
 }
 
 // ---------------------------------------------------------------------------
