@@ -358,6 +358,10 @@ __global__ __launch_bounds__(NTMAX) void wfa_tile2_kernel(const uint32_t* __rest
   int cP[C];  // oP of cell c = m + cP[c]  (v = m - k)
 #pragma unroll
   for (int c = 0; c < C; ++c) cP[c] = dP - (k0 + c);
+  // (Tried in round 4, as in round 3 on the byte kernel, and taken out again: letting a wave skip the steps at which it holds no
+  // cell -- before the triangle reaches its diagonals, 26 scores after the score bound has cut off its last one; two scalar
+  // compares per step against wave-uniform bounds.  The kernel sits at its 128 registers: the extra control flow made it spill,
+  // C3 83.8 -> 99.2 ms per step, C2's leg 84.6 -> 90.2 ms, the scaled C4 rank 72.1 -> 76.5.)
   __syncthreads();
 
   for (int tb = 0; tb < Tn; tb += NCL) {
