@@ -39,7 +39,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", default="C3", choices=["C3", "C5"])
+    ap.add_argument("--config", default="C3", choices=["C3", "C5", "C4"],
+                    help="C3 / C5: synthetic pairs, WFA-only.  C4 (with --scaling strong): the mapping records of one query haplotype of a "
+                         "synthetic pangenome (--c4-mbp per haplotype), dealt out over the ranks by dist.shard_records on the reference's own weights")
+    ap.add_argument("--c4-mbp", type=float, default=8.0, help="haplotype length of --config C4 in Mbp (248.956422 = north_star's size)")
     ap.add_argument("--pairs", type=int, default=64)
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: --pairs records per GPU (the driver's SCALE runs); strong: one file of --total-pairs records "
@@ -47,7 +50,8 @@ def main():
     ap.add_argument("--total-pairs", type=int, default=512, help="records of the strong-scaling file (64 x 8)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0, help="pairs in the cpu_baseline sample (0 = auto)")
-    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary figures (C5, scaled C4 rank, C2)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary figures (C5, C1 substitute, C4 ranks, C2)")
+    ap.add_argument("--no-full-c4", action="store_true", help="skip the chr1-sized C4 rank among the secondary legs (2 GB of synthetic haplotypes: ~20 s to make)")
     ap.add_argument("--rank-check", action="store_true",
                     help="launch / join the ranks, print one line per rank and stop (no GPU needed: gloo)")
     args = ap.parse_args()
@@ -114,6 +118,13 @@ def main():
     comm_dev = dev if (dist is None or dist.get_backend() == "nccl") else torch.device("cpu")
 
     h = capi.Handle(local_rank)
+    if args.config == "C4":
+        _strong_c4(args, h, capi, synth, dist, rank, world, comm_dev, torch)
+        h.close()
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     # this rank's shard of the mapping records (weak: distinct seeds per rank; strong: its share of the one file)
     n_all = args.pairs * world if args.scaling == "weak" else args.total_pairs
     all_pairs = synth.pairs(args.config, n_pairs=n_all)
@@ -185,9 +196,9 @@ def main():
             "roofline": roof,
             # time during which at least one launch of the kernel was running (union of the launch intervals over all
             # streams, HIP events against one origin), and the sum of the individual launch durations
-            "kernel_busy_ms_per_step": {"wfa_tile_reg_kernel": acc.ms_tile_busy / args.steps, "wfa_bp_kernel": acc.ms_bp_busy / args.steps,
+            "kernel_busy_ms_per_step": {"wfa_tile2_kernel": acc.ms_tile_busy / args.steps, "wfa_bp_kernel": acc.ms_bp_busy / args.steps,
                                         "wfa_base_kernel": acc.ms_base_busy / args.steps, "any": acc.ms_any_busy / args.steps},
-            "kernel_ms_per_step": {"wfa_tile_reg_kernel": acc.ms_tile / args.steps, "wfa_bp_kernel": (acc.ms_bp - acc.ms_tile) / args.steps,
+            "kernel_ms_per_step": {"wfa_tile2_kernel": acc.ms_tile / args.steps, "wfa_bp_kernel": (acc.ms_bp - acc.ms_tile) / args.steps,
                                    "wfa_base_kernel": acc.ms_base / args.steps},
             "cells_per_step": acc.cells / args.steps,
             "whole_step": {"algorithmic_GBps": (48.0 * acc.cells_unique + seq_bytes * args.steps) / dt / 1e9,
@@ -218,13 +229,85 @@ def main():
             out["score_identical_rate"] = score_ident / n_s
             out["cpu_baseline_map"] = _cpu_baseline_map(h)
         if not args.no_secondary and world == 1:
-            out["secondary"] = _secondary(h, capi, synth)
+            out["secondary"] = _secondary(h, capi, synth, full_c4=not args.no_full_c4)
+            out["legs"] = _legs_summary(out)  # the last thing in the line: a reader of its tail sees every leg
         print(json.dumps(out), flush=True)
     seqset.free()
     h.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def _strong_c4(args, h, capi, synth, dist, rank, world, comm_dev, torch):
+    """Strong scaling on north_star's own records: one query haplotype of a synthetic pangenome mapped against all eight (every rank
+    makes the same sequences and the same mapping file -- the generator is seeded, the map phase deterministic), its mapping
+    records dealt out by dist.shard_records on the weight the reference's cluster sharding uses (length x (1 - identity),
+    scripts/split_approx_mappings_in_chunks.py:19-27,47; squared for WFA cost), every rank aligns its share end to end
+    (wfmh_align_paf: sequence fetch, device batches, CIGAR surgery, PAF text) and the PAF text is gathered to rank 0 inside the
+    timed region.  value = aligned bp of all ranks / the slowest rank's time."""
+    import tempfile
+    from wfmash_amd import dist as D
+    threads = max(1, (os.cpu_count() or 1) // max(1, world))
+    with tempfile.TemporaryDirectory() as td:
+        fa = os.path.join(td, "c4.fa")
+        recs = synth.pangenome_parallel(8, int(args.c4_mbp * 1e6), n_sv=6 if args.c4_mbp <= 8 else 20, workers=min(8, threads))
+        names, lengths = synth.write_fasta(fa, recs)
+        del recs
+        ql = os.path.join(td, "q.txt")
+        open(ql, "w").write(names[0] + "\n")
+        m = os.path.join(td, "m.paf")
+        t1 = time.perf_counter()
+        capi.map_paf(h, fa, m, params=capi.map_default_params(threads=threads, query_list=ql))
+        t_map = time.perf_counter() - t1
+        lines = open(m).read().splitlines(keepends=True)
+
+        def weight(line):
+            f = line.split("\t")
+            ident = next((float(x[5:]) for x in f[12:] if x.startswith("id:f:")), 0.9)
+            return (max(1.0, (int(f[3]) - int(f[2])) * max(1e-3, 1.0 - ident))) ** 2
+        shard = D.shard_records([weight(l) for l in lines], world)[rank]
+        mine = os.path.join(td, f"m.rank{rank}.paf")
+        open(mine, "w").write("".join(lines[i] for i in shard))
+        out_paf = os.path.join(td, f"a.rank{rank}.paf")
+
+        def one_pass():
+            al = capi.align_paf(h, fa, mine, out_paf, params={"threads": threads})
+            if dist is not None:
+                D.gather_files(out_paf, dist, td, dst=0, device=comm_dev if comm_dev.type == "cuda" else None)
+            return al
+
+        def sync():
+            if dist is not None:
+                dist.barrier()
+            torch.cuda.synchronize()
+        for _ in range(args.warmup):
+            one_pass()
+        sync()
+        t0 = time.perf_counter()
+        bp = 0
+        recs_n = 0
+        ms_gpu = 0.0
+        for _ in range(args.steps):
+            al = one_pass()
+            bp += int(al.aligned_bp); recs_n += int(al.records); ms_gpu += al.ms_gpu
+        sync()
+        dt = time.perf_counter() - t0
+        tot = torch.tensor([float(bp), float(recs_n), dt], dtype=torch.float64, device=comm_dev)
+        mx = tot.clone()
+        if dist is not None:
+            dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+            dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        if rank == 0:
+            dtm = float(mx[2].item())
+            print(json.dumps({
+                "metric": "aligned bases/sec (whole node) + CIGAR-identical rate vs CPU ref", "value": float(tot[0].item()) / dtm, "unit": "aligned bases/s",
+                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dtm / args.steps * 1e3, "higher_is_better": True,
+                "scaling": "strong", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+                "config": {"workload": f"C4 rank: 8 synthetic haplotypes x {args.c4_mbp} Mbp, -Y '#', the {len(lines)} mapping records of one query haplotype "
+                                       "sharded over the GPUs by dist.shard_records (weight (length x (1 - identity))^2), map once + align per step",
+                           "records_total": len(lines), "records_rank0": len(shard), "parallelism": f"records sharded over {world} GPU(s)", "host_threads_per_rank": threads},
+                "map_s": t_map, "records_per_step_all_ranks": float(tot[1].item()) / args.steps, "ms_gpu_rank0_per_step": ms_gpu / args.steps}), flush=True)
 
 
 def _shard(args, rank, world, pairs):
@@ -273,7 +356,7 @@ def _roofline(acc, excl, seq_bytes, args):
     peak = 8000.0
     tiled = acc.ms_tile > 0.5 * acc.ms_bp
     if tiled:
-        dom, cells, cells_all, busy, launches, ms_sum = "wfa_tile_reg_kernel", acc.cells_tile_unique, acc.cells_tile, acc.ms_tile_busy, acc.tile_launches, acc.ms_tile
+        dom, cells, cells_all, busy, launches, ms_sum = "wfa_tile2_kernel", acc.cells_tile_unique, acc.cells_tile, acc.ms_tile_busy, acc.tile_launches, acc.ms_tile
         e_cells, e_ms, e_launches = excl.cells_tile_unique, excl.ms_tile, excl.tile_launches
     else:
         dom, cells, cells_all, busy, launches, ms_sum = "wfa_bp_kernel", acc.cells_bp - acc.cells_tile, acc.cells_bp - acc.cells_tile, acc.ms_bp_busy, acc.bp_launches, acc.ms_bp - acc.ms_tile
@@ -284,7 +367,7 @@ def _roofline(acc, excl, seq_bytes, args):
     e_achieved = e_alg / (e_ms * 1e-3) / 1e9 if e_ms > 0 else 0.0
     traffic = hbm_frac = None  # HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/)
     src = None
-    for name in ("r3_traffic.json", "r2_traffic.json", "r1g_traffic.json"):
+    for name in ("r4_traffic.json",):
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", name)))
         except (OSError, ValueError):
@@ -296,7 +379,7 @@ def _roofline(acc, excl, seq_bytes, args):
             src = "profiles/" + name
             break
     issue = None  # issue-side figures of the same kernel from the committed SQ passes (profiles/): the 48 B/cell yardstick is
-    for name in ("r3_sq.json", "r2_sq.json"):  # saturated (C5 passes 1.0), what the kernel is really short of is issue slots and latency
+    for name in ("r4_sq.json",):  # saturated (C5 passes 1.0), what the kernel is really short of is issue slots and latency
         try:
             issue = json.load(open(os.path.join(ROOT, "profiles", name)))
             issue["source"] = "profiles/" + name
@@ -317,19 +400,9 @@ def _roofline(acc, excl, seq_bytes, args):
             "cells_computed_per_launch": cells_all / max(launches, 1),
             "avg_launch_ms": ms_sum / max(launches, 1), "launches": launches, "streams": acc.streams,
             "kernel_busy_ms_per_step": busy / max(acc.passes, 1),
-            "note": "frac = the exclusive figure (what a rocprofv3 --kernel-trace of `WFM_OVERLAP=0 python bench.py` reproduces: profiles/); "
-                    "frac_overlapped = the timed region's own figure. valu_frac = SQ_INSTS_VALU x 4 cycles / (SIMDs x kernel time), "
-                    "wait_frac = SQ_WAIT_ANY / SQ_WAVE_CYCLES, from the committed SQ passes. "
-                    "achieved = 48 B x (score,diagonal) cells of the result / time the kernel was running (SURVEY 8d); the block in "
-                    "which a job's wavefronts meet is computed twice (cells_computed_per_launch) and counted once (cells_per_launch). "
-                    "The batch runs as up to three parts on as many streams, so launches of this kernel overlap each other: avg_launch_ms "
-                    "(what rocprofv3 shows per launch in this mode) is stretched by the sharing and the running time is the union of the "
-                    "launch intervals (HIP events of all streams against one origin). frac_exclusive comes from untimed passes with "
-                    "WFM_OVERLAP=0 (one stream, launches one after the other): algorithmic_bytes_per_launch_exclusive / "
-                    "avg_launch_ms_exclusive, the figure a rocprofv3 --kernel-trace of `WFM_OVERLAP=0 python bench.py` reproduces "
-                    "(profiles/). The tiled kernel keeps the wavefront history in registers, so real HBM traffic (traffic, per launch; "
-                    "hbm_frac = traffic / launch duration / 8 TB/s) is far below the algorithmic bytes: the 48 B/cell figure is the "
-                    "contract's yardstick, not this kernel's physical bound, which is the latency of a score step"}
+            "note": "frac = exclusive (untimed WFM_OVERLAP=0 passes, what rocprofv3 --kernel-trace reproduces: profiles/r4_align_excl.md); frac_overlapped = the "
+                    "timed region (union of launch intervals over the streams). 48 B x unique (score, diagonal) cells / kernel time: the contract's yardstick (SURVEY 8d); "
+                    "the history lives in registers, so real HBM traffic is far below it and frac can pass 1 -- the kernel's own bound is VALU issue (valu_frac). DESIGN.md section 5"}
 
 
 def _cpu_baseline_map(h):
@@ -422,7 +495,7 @@ def _mapping_identity(h, capi, synth, td):
             "workload": "8 synthetic haplotypes x 0.6 Mbp, defaults: one query haplotype against the stage oracles + the reference's filter code"}
 
 
-def _secondary(h, capi, synth):
+def _secondary(h, capi, synth, full_c4=True):
     """Driver-timed figures of the other configs (the bench line's `value` stays C3): C5 align-only, C4 ranks at two sizes, the C1
     substitute and C2 (LPA.subset all-vs-all) end to end through the C ABI, each with a parity check against the oracles."""
     import tempfile
@@ -471,11 +544,16 @@ def _secondary(h, capi, synth):
             del recs, seqs
         except Exception as e:
             sec["C1_substitute"] = {"error": str(e)}
-        for tag, mbp, n_cig in (("C4_rank_scaled", 8, 48), ("C4_rank_40mbp", 40, 64)):
+        legs = [("C4_rank_scaled", 8, 48), ("C4_rank_40mbp", 40, 64)]
+        if full_c4:
+            legs.append(("C4_rank_full", 248.956422, 64))  # north_star's own size: one chr1-sized haplotype against all eight
+        for tag, mbp, n_cig in legs:
             try:  # one rank of C4: 8 haplotypes, one of them (1/8 of the queries) against the index of all eight
                 fa = os.path.join(td, f"c4_{mbp}.fa")
-                recs = [(n, s) for n, s in synth.pangenome(8, mbp * 1_000_000, n_sv=6 if mbp == 8 else 20)]
+                t_g = time.perf_counter()
+                recs = synth.pangenome_parallel(8, int(mbp * 1_000_000), n_sv=6 if mbp == 8 else 20, workers=min(8, threads))
                 names, lengths = synth.write_fasta(fa, recs)
+                t_gen = time.perf_counter() - t_g
                 ql = os.path.join(td, "q.txt")
                 open(ql, "w").write(names[0] + "\n")
                 m, a = os.path.join(td, "m.paf"), os.path.join(td, "a.paf")
@@ -486,13 +564,14 @@ def _secondary(h, capi, synth):
                 al = capi.align_paf(h, fa, m, a, params={"threads": threads})
                 t_al = time.perf_counter() - t1
                 leg = {"workload": f"8 synthetic haplotypes x {mbp} Mbp, -Y '#', defaults (ani50-2): rank 0 of 8 (one haplotype against all)",
-                       "map_s": t_map, "ms_index": ms.ms_index, "ms_map": ms.ms_map, "ms_filter": ms.ms_filter, "mapping_records": int(ms.written)}
+                       "generate_s": t_gen, "map_s": t_map, "ms_identity": ms.ms_identity, "ms_index": ms.ms_index, "ms_map": ms.ms_map, "ms_filter": ms.ms_filter, "mapping_records": int(ms.written)}
                 leg.update(_align_fields(al, t_al))
                 leg["aligned_bp_per_s_map_and_align"] = al.aligned_bp / (t_map + t_al)
                 seqs = {n: s.tobytes() for n, s in recs}
                 leg["parity"] = _sampled_cigar_identity(seqs, open(m).read().splitlines(), a, n_cig)
                 sec[tag] = leg
                 del recs, seqs
+                os.unlink(fa)
             except Exception as e:
                 sec[tag] = {"error": str(e)}
         try:  # C2: the reference's LPA test data (a committed fixture), all-vs-all -p 90 -P 50k
@@ -526,6 +605,28 @@ def _secondary(h, capi, synth):
         except Exception as e:
             sec["map_parity"] = {"error": str(e)}
     return sec
+
+
+def _legs_summary(out):
+    """Every leg in a few numbers, at the end of the JSON line: [align seconds, M aligned bp/s of the align phase, device-busy ms,
+    48 B x cells / device-busy time / 8 TB/s, sampled CIGAR-identical rate, map seconds]."""
+    def r(x, n=3):
+        return None if x is None else round(float(x), n)
+    legs = {"C3": {"ms_per_step": r(out["ms_per_step"], 2), "Mbp_per_s": r(out["value"] / 1e6, 2), "tile_frac_exclusive": r(out["roofline"]["frac"]),
+                   "tile_frac_overlapped": r(out["roofline"]["frac_overlapped"]), "whole_step_frac": r(out["whole_step"]["frac"]),
+                   "cigar_identical": out.get("cigar_identical_rate")}}
+    for tag, leg in out.get("secondary", {}).items():
+        if "error" in leg:
+            legs[tag] = {"error": leg["error"][:80]}
+        elif tag == "C5":
+            legs[tag] = {"ms_per_pass": r(leg["ms_per_pass"], 1), "Mbp_per_s": r(leg["aligned_bp_per_s"] / 1e6, 2), "frac_wall": r(leg["algorithmic_frac_wall"])}
+        elif tag == "map_parity":
+            legs[tag] = {"mapping_identical": leg.get("mapping_identical_rate"), "byte_identical": leg.get("byte_identical")}
+        else:
+            legs[tag] = {"align_s": r(leg["align_s"]), "Mbp_per_s": r(leg["aligned_bp"] / leg["align_s"] / 1e6, 1), "ms_gpu": r(leg["ms_gpu"], 1),
+                         "frac_gpu": r(leg.get("algorithmic_frac_gpu")), "cigar_identical": leg.get("parity", {}).get("cigar_identical_rate"),
+                         "records": leg.get("records"), "map_s": r(leg.get("map_s"))}
+    return legs
 
 
 def _cpu_model():
