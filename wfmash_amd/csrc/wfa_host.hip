@@ -485,6 +485,8 @@ int run_tiled_phase(wfm_handle* h, wfm_seqset* S, const DevPen& dp, int scope, c
                     double& tile_ms, uint64_t& tile_cells, uint32_t level) {
   const size_t n = tiled.size();
   if (n == 0) return WFM_OK;
+  double lane_cells = 0;  // threads x diagonals per thread x scores over all tiles launched (diagnostics)
+  const double cells_before = (double)tile_cells;
   const int core = cfg.Wt - 2 * T;
   std::vector<TileJob> tj(n);
   std::vector<int> fmax(n, 0), rmax(n, 0);
@@ -643,6 +645,7 @@ int run_tiled_phase(wfm_handle* h, wfm_seqset* S, const DevPen& dp, int scope, c
         }
       }
       blocks += (uint32_t)chunk;
+      for (int b = 0; b < chunk; ++b) lane_cells += (double)tasks.size() * threads_b[(size_t)b] * cfg.C * T;
       h->stats.tile_launches += (uint32_t)chunk;
       h->stats.tile_tasks += (uint32_t)(tasks.size() * (size_t)chunk);
       n_active = 0;
@@ -687,7 +690,8 @@ int run_tiled_phase(wfm_handle* h, wfm_seqset* S, const DevPen& dp, int scope, c
     }
     j.fmax0 = fmax[i]; j.rmax0 = rmax[i];
   }
-  if (getenv("WFM_DEBUG")) fprintf(stderr, "[wfm] level %u: tiled %zu jobs, %u blocks of %d scores (Wt %d), %.3f ms\n", level, n, blocks, T, cfg.Wt, tile_ms);
+  if (getenv("WFM_DEBUG")) fprintf(stderr, "[wfm] level %u: tiled %zu jobs, %u blocks of %d scores (Wt %d), %.3f ms; %.3e cells computed on %.3e lane-steps (%.0f %% of the lanes hold a cell)\n", level, n, blocks, T, cfg.Wt, tile_ms,
+                                   (double)tile_cells - cells_before, lane_cells, lane_cells > 0 ? 100.0 * ((double)tile_cells - cells_before) / lane_cells : 0.0);
   return WFM_OK;
 }
 

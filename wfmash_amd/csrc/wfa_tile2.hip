@@ -265,11 +265,16 @@ __global__ __launch_bounds__(NTMAX) void wfa_tile2_kernel(const uint32_t* __rest
     if (tk.core_lo > R) return;
     if (tk.core_lo == L && tk.core_hi == R) halo = 0;  // one tile for the whole range: nothing beside it to take from
   }
-  const int dir = tk.dir, tid = threadIdx.x, NT = blockDim.x, lane = tid & 63, wv = tid >> 6, nw = NT >> 6;
+  const int dir = tk.dir, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int kA = tk.core_lo - halo;
+  // A launch is sized for its widest tile; the waves a narrower one does not need end here, before the first barrier (waves that
+  // have ended drop out of s_barrier: scripts/micro/barrier_exit.hip), and give their SIMD slots to other tiles.  In a pangenome
+  // level half the lanes of a launch held no cell (20 % at the deeper levels).
+  const int nw = min((int)(blockDim.x >> 6), (tk.core_hi + halo - kA) / (64 * C) + 1), NT = nw * 64;
+  if (wv >= nw) return;
   if (tid < 2) s_wlo[tid] = INT32_MAX;
   const int64_t aP = dir == 0 ? J.p_fwd : J.p_rev, aT = dir == 0 ? J.t_fwd : J.t_rev;  // byte index of the sequences' first bases
   const int pl = J.pl, tl = J.tl, s0 = sbase;
-  const int kA = tk.core_lo - halo;
   const int k0 = kA + tid * C;  // first diagonal of this thread
   const int64_t width = J.width;
   const int32_t* rin = ring_arena + J.ring_in + J.koff + (int64_t)dir * 5 * RING * width;
@@ -573,7 +578,10 @@ __global__ __launch_bounds__(NTMAX) void wfa_base2_kernel(const uint32_t* __rest
   constexpr int PX = 5, PO1 = 8, PE1 = 2, PO2 = 24, PE2 = 1;  // the penalties this form is built for (the host checks)
   constexpr bool WAVE1 = NTMAX == 64;
   const BaseJob J = jobs[blockIdx.x];
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, nw = blockDim.x >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  // (a launch is sized for its widest job: the waves this one's rows do not reach end before the first barrier, see wfa_tile2_kernel)
+  const int nw = J.type != 0 ? 1 : min((int)(blockDim.x >> 6), (int)((J.width - 1) / (64 * 2)) + 1), NT = nw * 64;
+  if (wv >= nw) return;
   const long long t_begin = wall_clock64();
   if (J.type != 0) {  // trivial: all-D or all-I (wavefront_bialign_alignment trivial cases)
     if (tid == 0) {
@@ -600,11 +608,11 @@ __global__ __launch_bounds__(NTMAX) void wfa_base2_kernel(const uint32_t* __rest
   SRC.gP = (glb_words)pk + (oriP >> 4); SRC.gT = (glb_words)pk + (oriT >> 4);
   {
     const int nP = min(PK_WIN_DW + PK_SLACK_DW, (pl + dP + 15) / 16 + 8), nT = min(PK_WIN_DW + PK_SLACK_DW, (tl + dT + 15) / 16 + 8);
-    for (int i = tid; i < nP; i += blockDim.x) s_winP[i] = SRC.gP[i];
-    for (int i = tid; i < nT; i += blockDim.x) s_winT[i] = SRC.gT[i];
+    for (int i = tid; i < nP; i += NT) s_winP[i] = SRC.gP[i];
+    for (int i = tid; i < nT; i += NT) s_winT[i] = SRC.gT[i];
   }
   if (tid == 0) { s_done = 0; s_endk = INT32_MAX; s_endoff = 0; }
-  for (int i = tid; i < (int)(sizeof(s_edge) / sizeof(int)); i += blockDim.x) ((int*)s_edge)[i] = WF_NULL;  // (a wave that has no cell yet publishes nothing)
+  for (int i = tid; i < (int)(sizeof(s_edge) / sizeof(int)); i += NT) ((int*)s_edge)[i] = WF_NULL;  // (a wave that has no cell yet publishes nothing)
   __syncthreads();
 
   const int k0 = kmin + tid * C;
