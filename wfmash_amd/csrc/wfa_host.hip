@@ -671,11 +671,13 @@ int run_tiled_phase(wfm_handle* h, wfm_seqset* S, const DevPen& dp, int scope, c
   }
   // cells that went into the result: both directions up to where the tile phase leaves the job (the full block in which
   // the wavefronts met was computed as well, and then again up to the meeting point: tile_cells counts it, this does not)
+  uint64_t unique_level = 0;
   for (size_t i = 0; i < n; ++i) {
     const int sf_end = tj[i].mode == 2 ? tj[i].s0 + tj[i].tf : tj[i].s0, sr_end = tj[i].mode == 2 ? tj[i].s0 + tj[i].tr : tj[i].s0;
-    h->stats.cells_tile_unique += (uint64_t)h_cells_sum(tj[i].pl, tj[i].tl, tj[i].sub, s_begin[i] + 1, sf_end) +
-                                  (uint64_t)h_cells_sum(tj[i].pl, tj[i].tl, tj[i].sub, s_begin[i] + 1, sr_end);
+    unique_level += (uint64_t)h_cells_sum(tj[i].pl, tj[i].tl, tj[i].sub, s_begin[i] + 1, sf_end) +
+                    (uint64_t)h_cells_sum(tj[i].pl, tj[i].tl, tj[i].sub, s_begin[i] + 1, sr_end);
   }
+  h->stats.cells_tile_unique += unique_level;
   for (size_t i = 0; i < n; ++i) {
     BpJob& j = jobs[(size_t)tiled[i]];
     j.ring_off = tj[i].ring_in;
@@ -690,8 +692,8 @@ int run_tiled_phase(wfm_handle* h, wfm_seqset* S, const DevPen& dp, int scope, c
     }
     j.fmax0 = fmax[i]; j.rmax0 = rmax[i];
   }
-  if (getenv("WFM_DEBUG")) fprintf(stderr, "[wfm] level %u: tiled %zu jobs, %u blocks of %d scores (Wt %d), %.3f ms; %.3e cells computed on %.3e lane-steps (%.0f %% of the lanes hold a cell)\n", level, n, blocks, T, cfg.Wt, tile_ms,
-                                   (double)tile_cells - cells_before, lane_cells, lane_cells > 0 ? 100.0 * ((double)tile_cells - cells_before) / lane_cells : 0.0);
+  if (getenv("WFM_DEBUG")) fprintf(stderr, "[wfm] level %u: tiled %zu jobs, %u blocks of %d scores (Wt %d), %.3f ms; %.3e cells computed on %.3e lane-steps (%.0f %% of the lanes hold a cell), %.3e of them in the result (the block in which a job's wavefronts meet runs twice)\n", level, n, blocks, T, cfg.Wt, tile_ms,
+                                   (double)tile_cells - cells_before, lane_cells, lane_cells > 0 ? 100.0 * ((double)tile_cells - cells_before) / lane_cells : 0.0, (double)unique_level);
   return WFM_OK;
 }
 
