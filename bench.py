@@ -394,6 +394,8 @@ def _roofline(acc, excl, seq_bytes, args):
             "achieved_overlapped": achieved, "frac_overlapped": achieved / peak,
             "valu_frac": issue.get("valu_frac") if issue else None, "wait_frac": issue.get("wait_frac") if issue else None, "issue_source": issue.get("source") if issue else None,
             "traffic": traffic, "hbm_frac": hbm_frac, "traffic_source": src,
+            "counters_note": "traffic, hbm_frac, valu_frac and wait_frac are read from the committed PMC passes (profiles/r4_traffic.json, r4_sq.json: the builder's box, "
+                             "scripts/profile_r4.sh), not measured in this run; achieved / frac / the launch figures are measured live with HIP events",
             "frac_exclusive": e_achieved / peak, "achieved_exclusive": e_achieved,
             "avg_launch_ms_exclusive": e_ms / max(e_launches, 1), "launches_exclusive_per_step": e_launches / max(excl.passes, 1),
             "algorithmic_bytes_per_launch_exclusive": e_alg / max(e_launches, 1),
