@@ -264,10 +264,30 @@ struct LevelTimer {
 };
 
 // widest row a base job can reach (0 for the trivial all-gap jobs)
+// The diagonals a base job's rows have to hold under its score budget: within `smax` of where an alignment may begin (diagonal 0 of an
+// end-to-end job, [-pbf, tbf] of an ends-free one) -- and, when the alignment has to END in the far corner (no free ends there: leaves, and the
+// head patches, whose free ends are at the beginning), within `smax` of the corner's diagonal tl - pl as well: every change of diagonal costs at least
+// e2 = 1, so a cell further away lies on no alignment of score <= smax, no cell on such an alignment takes its value from one (the argument of the
+// score bounds, section 5 of DESIGN.md), and a job that needs more than its budget is run again anyway.  A head patch begins with ALL its diagonals
+// (its begin-free lengths are the eroded lengths: rows of 2 - 8 k diagonals for a budget of 256); with the corner's band its rows are 513 wide.
+inline void base_columns(const Node& nd, const ProbMeta& pm, int64_t* kmin_out, int64_t* kmax_out) {
+  int64_t kmin = nd.endsfree ? std::max<int64_t>(-nd.pl, -(int64_t)pm.pbf - nd.smax) : std::max<int64_t>(-nd.pl, -nd.smax);
+  int64_t kmax = nd.endsfree ? std::min<int64_t>(nd.tl, (int64_t)pm.tbf + nd.smax) : std::min<int64_t>(nd.tl, nd.smax);
+  static const bool corner_band = !(getenv("WFM_BASE_CORNER_BAND") && atoi(getenv("WFM_BASE_CORNER_BAND")) == 0);
+  const bool end_fixed = !nd.endsfree || (pm.pef == 0 && pm.tef == 0);
+  if (corner_band && end_fixed) {
+    const int64_t k_end = (int64_t)nd.tl - nd.pl;
+    const int64_t bmin = std::max(kmin, k_end - nd.smax), bmax = std::min(kmax, k_end + nd.smax);
+    // the first row must keep a cell inside (a budget that cannot reach the corner at all leaves the columns as they were: the job overflows as before)
+    const int64_t lo0 = nd.endsfree ? std::max<int64_t>(-(int64_t)pm.pbf, bmin) : 0, hi0 = nd.endsfree ? std::min<int64_t>((int64_t)pm.tbf, bmax) : 0;
+    if (bmin <= bmax && lo0 <= hi0 && lo0 >= bmin && hi0 <= bmax) { kmin = bmin; kmax = bmax; }
+  }
+  *kmin_out = kmin; *kmax_out = kmax;
+}
 inline int64_t base_row_width(const Node& nd, const ProbMeta& pm) {
   if (nd.tl == 0 || nd.pl == 0) return 0;
-  const int64_t kmin = nd.endsfree ? std::max<int64_t>(-nd.pl, -(int64_t)pm.pbf - nd.smax) : std::max<int64_t>(-nd.pl, -nd.smax);
-  const int64_t kmax = nd.endsfree ? std::min<int64_t>(nd.tl, (int64_t)pm.tbf + nd.smax) : std::min<int64_t>(nd.tl, nd.smax);
+  int64_t kmin, kmax;
+  base_columns(nd, pm, &kmin, &kmax);
   return kmax - kmin + 1;
 }
 
@@ -330,14 +350,9 @@ int run_base_jobs(wfm_handle* h, wfm_seqset* S, const wfm_penalties_t& pen, std:
       }
       j.type = 0;
       j.smax = nd.smax;
-      int kmin, kmax;
-      if (nd.endsfree) {
-        kmin = std::max(-nd.pl, -pm.pbf - nd.smax);
-        kmax = std::min(nd.tl, pm.tbf + nd.smax);
-      } else {
-        kmin = std::max(-nd.pl, -nd.smax);
-        kmax = std::min(nd.tl, nd.smax);
-      }
+      int64_t kmin64, kmax64;
+      base_columns(nd, pm, &kmin64, &kmax64);
+      const int kmin = (int)kmin64, kmax = (int)kmax64;
       j.kmin = kmin;
       j.width = kmax - kmin + 1;
       const size_t rows = (size_t)nd.smax + 1;
@@ -419,6 +434,10 @@ int run_base_jobs(wfm_handle* h, wfm_seqset* S, const wfm_penalties_t& pen, std:
           // (x 8; it was x 2 until round 3 and x 4 for a while: every retry is a launch that a few jobs hold up, a budget that is too large costs
           // memory only -- 20 MB for a 2 k-wide patch at 2 k scores -- and a patch that passed 256 is as likely to need 1500 as 500)
           again.smax = (int32_t)std::min<int64_t>((int64_t)nd.smax * 8 + 32, bound);
+          // ... but the second attempt stops at 1020: with the band around the end corner's diagonal the rows of a job with that budget are at most
+          // 2041 diagonals wide and fit the register kernel (wfa_base2_kernel: 2048), where a budget of 2080 put two dozen patches of an LPA batch
+          // on the ring kernel with rows of 2.6 - 3.4 k diagonals (9.7 ms of the batch's 83); the few that need more take a third attempt
+          if (nd.smax < 1020 && again.smax > 1020) again.smax = 1020;
           retry.push_back(again);
         } else if (r.status != 0) {
           if (getenv("WFM_DEBUG")) fprintf(stderr, "[wfm] problem %d: base job pl %d tl %d status %d\n", nd.prob, nd.pl, nd.tl, r.status);
