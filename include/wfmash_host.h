@@ -98,6 +98,10 @@ int64_t wfmh_test_winnow_thinned(const char* seq, int64_t len, int k, int w, int
 /* the closing sort of a sequence's records by (wpos, wpos_end) (commonFunc.hpp:696): threads == 1 is std::sort,
  * threads > 1 the same introsort with its halves on several threads -- same result, ties included */
 void wfmh_test_sort_records(wfm_minmer_t* recs, int64_t n, int threads);
+/* CPU test hooks of the 2-bit packed extension (wfmash_amd/csrc/wfa_pack.h): the run of agreeing bases from (v, h) of two sequences that begin at
+ * byte start_p / start_t of their buffers, computed on the packed mirror the way the tile kernel stages it; whether a buffer is pure upper-case ACGT */
+int wfmh_test_packed_lce(const uint8_t* buf_p, int64_t n_p, int64_t start_p, const uint8_t* buf_t, int64_t n_t, int64_t start_t, int v, int h, int maxn);
+int wfmh_test_is_acgt(const uint8_t* seq, int64_t n);
 
 /* The winnowing kernel's control flow and capacities (wfmash_amd/csrc/map_winnow_core.h: one speculative chunk of the
  * thinned stream per wave, boundary states compared, interval starts resolved) run on the host over plain arrays, then

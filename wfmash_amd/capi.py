@@ -607,7 +607,7 @@ class Handle:
 # ---------------------------------------------------------------------------
 # host-side align driver (include/wfmash_host.h)
 # ---------------------------------------------------------------------------
-HOST_EXPORTS = ["wfmh_align_default_params", "wfmh_align_paf", "wfmh_test_cigar", "wfmh_free", "wfmh_test_winnow",
+HOST_EXPORTS = ["wfmh_test_packed_lce", "wfmh_test_is_acgt", "wfmh_align_default_params", "wfmh_align_paf", "wfmh_test_cigar", "wfmh_free", "wfmh_test_winnow",
                 "wfmh_map_default_params", "wfmh_test_filter", "wfmh_map", "wfmh_test_winnow_chunked", "wfmh_test_fasta", "wfmh_test_winnow_thinned", "wfmh_test_sort_records", "wfmh_test_index_file",
                 "wfmh_map_multi", "wfmh_align_paf_multi", "wfmh_test_winnow_model", "wfmh_test_sortlike_model", "wfmh_test_finish_records"]
 

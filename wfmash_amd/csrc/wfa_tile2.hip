@@ -24,6 +24,7 @@
 #include <type_traits>
 
 #include "wfa_device.h"
+#include "wfa_pack.h"
 
 namespace wfm {
 
@@ -64,29 +65,12 @@ __device__ __forceinline__ int wave_max63(int x) {
 typedef const __attribute__((address_space(3))) uint32_t* lds_words;
 typedef const __attribute__((address_space(1))) uint32_t* glb_words;
 
-// 16 / 32 bases from base offset o of a packed word array (LDS window or global mirror)
-template <typename W>
-__device__ __forceinline__ uint32_t pk16(W w, unsigned o) {
-  const W q = w + (o >> 4);
-  return __builtin_amdgcn_alignbit(q[1], q[0], o << 1);
-}
-template <typename W>
-__device__ __forceinline__ uint64_t pk32(W w, unsigned o) {
-  const W q = w + (o >> 4);
-  const uint32_t a = q[0], b = q[1], c = q[2];
-  const unsigned sh = o << 1;
-  return ((uint64_t)__builtin_amdgcn_alignbit(c, b, sh) << 32) | __builtin_amdgcn_alignbit(b, a, sh);
-}
-
 // Where a tile's sequences are read: the LDS windows while the offsets (counted from the windows' origin) stay inside, the
 // global mirror from the same origin beyond
 struct PkSrc {
   lds_words lP, lT;
   glb_words gP, gT;
 };
-
-// number of leading bases (of 16) on which two packed words agree: x = their xor (ffbl of 0 is -1: all 16)
-__device__ __forceinline__ unsigned first_diff16(uint32_t x) { return (unsigned)(x ? __builtin_ctz(x) : 32) >> 1; }
 
 // bases 16 .. 79 after a probe that matched 16: four more words per sequence.  Returns the run length so far (16 .. 80).
 __device__ __forceinline__ int pk_stage2(const PkSrc& S, unsigned oP, unsigned oT) {
@@ -105,7 +89,7 @@ __device__ __forceinline__ int pk_stage2(const PkSrc& S, unsigned oP, unsigned o
   const unsigned sa = oP << 1, sb = oT << 1;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    const uint32_t x = __builtin_amdgcn_alignbit(wa[q + 1], wa[q], sa) ^ __builtin_amdgcn_alignbit(wb[q + 1], wb[q], sb);
+    const uint32_t x = alignbit32(wa[q + 1], wa[q], sa) ^ alignbit32(wb[q + 1], wb[q], sb);
     if (x) return 16 + 16 * q + (int)(__builtin_ctz(x) >> 1);
   }
   return 80;
@@ -213,7 +197,7 @@ __global__ __launch_bounds__(256) void seq_pack_kernel(const uint8_t* __restrict
     for (int j = 0; j < 16; ++j) {
       const int64_t a = i * 16 + j;
       const uint32_t c = a < nbytes ? (uint32_t)seq[a] : 0u;
-      v |= ((c >> 1) & 3u) << (2 * j);
+      v |= pack_code((uint8_t)c) << (2 * j);
     }
   }
   pk[i] = v;
@@ -227,7 +211,7 @@ __global__ __launch_bounds__(256) void seq_acgt_kernel(const uint8_t* __restrict
   bool bad = false;
   for (int q = threadIdx.x; q < n; q += blockDim.x) {
     const uint8_t c = src[q];
-    bad |= !(c == 'A' || c == 'C' || c == 'G' || c == 'T');
+    bad |= !pack_is_acgt(c);
   }
   if (__any(bad) && (threadIdx.x & 63) == 0) flag[blockIdx.x >> 1] = 0;
 }

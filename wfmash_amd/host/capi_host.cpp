@@ -8,11 +8,29 @@
 
 #include "../../include/wfmash_host.h"
 #include "../csrc/wfa_handle.h"
+#include "../csrc/wfa_pack.h"
 #include "aligner.hpp"
 #include "fasta.hpp"
 #include "map_stats.hpp"
 
 extern "C" {
+
+// CPU test hook of the packed extension (csrc/wfa_pack.h): both buffers are packed as wfm_upload_sequences' mirror is, the
+// sequences begin at byte start_p / start_t of their buffers (any alignment), and the staged comparison of the tile kernel --
+// 16 bases, 64, then 32 at a time, from window origins rounded down to a word -- is run from (v, h).  Returns the run length.
+int wfmh_test_packed_lce(const uint8_t* buf_p, int64_t n_p, int64_t start_p, const uint8_t* buf_t, int64_t n_t, int64_t start_t, int v, int h, int maxn) {
+  if (!buf_p || !buf_t || n_p < 0 || n_t < 0 || start_p < 0 || start_t < 0 || v < 0 || h < 0) return -1;
+  std::vector<uint32_t> wp((size_t)(n_p + 15) / 16 + 16, 0u), wt((size_t)(n_t + 15) / 16 + 16, 0u);
+  wfm::pack_words_model(buf_p, n_p, wp.data());
+  wfm::pack_words_model(buf_t, n_t, wt.data());
+  const int64_t ori_p = start_p & ~(int64_t)15, ori_t = start_t & ~(int64_t)15;
+  return wfm::pk_lce_model(wp.data() + (ori_p >> 4), wt.data() + (ori_t >> 4), (uint32_t)(v + (start_p - ori_p)), (uint32_t)(h + (start_t - ori_t)), maxn);
+}
+// 1 when every byte is one of A C G T (upper case): the problems the packed kernels take
+int wfmh_test_is_acgt(const uint8_t* seq, int64_t n) {
+  for (int64_t i = 0; i < n; ++i) if (!wfm::pack_is_acgt(seq[i])) return 0;
+  return 1;
+}
 
 void wfmh_align_default_params(wfmh_align_params_t* p) {
   if (!p) return;
