@@ -49,6 +49,10 @@ __device__ __forceinline__ int rdl(int v, int src) { return __builtin_amdgcn_rea
 // lane i <- lane i - 1 (lane 0 keeps NULL) / lane i <- lane i + 1 (lane 63 keeps NULL): one VALU instruction each
 __device__ __forceinline__ int from_prev_lane(int x) { return __builtin_amdgcn_update_dpp(WF_NULL, x, 0x138, 0xf, 0xf, false); }  // wave_shr:1
 __device__ __forceinline__ int from_next_lane(int x) { return __builtin_amdgcn_update_dpp(WF_NULL, x, 0x130, 0xf, 0xf, false); }  // wave_shl:1
+// the same with whatever for the edge lane (zero): for tiles of several waves, whose edge lanes take their values from the mailbox anyway -- no
+// register has to be set to NULL before every shift
+__device__ __forceinline__ int from_prev_lane0(int x) { return __builtin_amdgcn_update_dpp(0, x, 0x138, 0xf, 0xf, true); }
+__device__ __forceinline__ int from_next_lane0(int x) { return __builtin_amdgcn_update_dpp(0, x, 0x130, 0xf, 0xf, true); }
 
 __device__ __forceinline__ int wave_max63(int x) {
   x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false));  // row_shr:1
@@ -229,7 +233,10 @@ __global__ __launch_bounds__(NTMAX) void wfa_tile2_kernel(const uint32_t* __rest
                                                         int32_t* __restrict__ mak_out, int T, int32_t* __restrict__ p2_arena) {
   constexpr int C = 2, LB = 25, H = LB + 1, NCL = 5, DEP = 6, E1 = 2;
   constexpr bool WAVE1 = NTMAX == 64;  // one wave: no mailbox; __syncthreads() is a wave barrier for a 64-thread workgroup
-  __shared__ int s_edge[2][WAVE1 ? 1 : 16][2][4];  // [parity][wave][0: lane63 -> next wave, 1: lane0 -> previous wave][value]
+  // mailbox of the wave edges: [parity][slot][side][value].  Side 0 of slot w holds what lane 63 of wave w - 1 hands to lane 0 of wave w, side 1 of
+  // slot w what lane 0 of wave w hands to lane 63 of wave w - 1; slot 0's side 0 and the slot behind the last wave are never written and stay
+  // NULL, so the edge lanes of a tile read their mailbox like all others and the wave shifts need no NULL to fall back on
+  __shared__ int s_edge[2][WAVE1 ? 1 : 17][2][4];
   __shared__ __attribute__((aligned(16))) uint32_t s_winP[PK_WIN_DW + PK_SLACK_DW], s_winT[PK_WIN_DW + PK_SLACK_DW];
   __shared__ int s_wlo[2];
   extern __shared__ __attribute__((aligned(16))) int s_makr[];  // [T + 1]
@@ -257,6 +264,7 @@ __global__ __launch_bounds__(NTMAX) void wfa_tile2_kernel(const uint32_t* __rest
   const int nw = min((int)(blockDim.x >> 6), (tk.core_hi + halo - kA) / (64 * C) + 1), NT = nw * 64;
   if (wv >= nw) return;
   if (tid < 2) s_wlo[tid] = INT32_MAX;
+  if (!WAVE1) for (int i = tid; i < (int)(sizeof(s_edge) / sizeof(int)); i += NT) ((int*)s_edge)[i] = WF_NULL;
   const int64_t aP = dir == 0 ? J.p_fwd : J.p_rev, aT = dir == 0 ? J.t_fwd : J.t_rev;  // byte index of the sequences' first bases
   const int pl = J.pl, tl = J.tl, s0 = sbase;
   const int k0 = kA + tid * C;  // first diagonal of this thread
@@ -365,15 +373,15 @@ __global__ __launch_bounds__(NTMAX) void wfa_tile2_kernel(const uint32_t* __rest
     if (!WAVE1) {
       const int par = t & 1;
       // publish the wave-edge history values needed by the neighbouring waves in this step
-      if (lane == 63) { int* e = s_edge[par][wv][0]; e[0] = Mh[C - 1][cl][1]; e[1] = Mh[C - 1][cl][4]; e[2] = I1h[C - 1][E1 - 1]; e[3] = I2h[C - 1]; }
-      if (lane == 0)  { int* e = s_edge[par][wv][1]; e[0] = Mh[0][cl][1];     e[1] = Mh[0][cl][4];     e[2] = D1h[0][E1 - 1];     e[3] = D2h[0]; }
+      if (lane == 63) { int* e = s_edge[par][wv + 1][0]; e[0] = Mh[C - 1][cl][1]; e[1] = Mh[C - 1][cl][4]; e[2] = I1h[C - 1][E1 - 1]; e[3] = I2h[C - 1]; }
+      if (lane == 0)  { int* e = s_edge[par][wv][1];     e[0] = Mh[0][cl][1];     e[1] = Mh[0][cl][4];     e[2] = D1h[0][E1 - 1];     e[3] = D2h[0]; }
       __syncthreads();
-      lM10 = from_prev_lane(Mh[C - 1][cl][1]); lM25 = from_prev_lane(Mh[C - 1][cl][4]);
-      lI1 = from_prev_lane(I1h[C - 1][E1 - 1]); lI2 = from_prev_lane(I2h[C - 1]);
-      rM10 = from_next_lane(Mh[0][cl][1]); rM25 = from_next_lane(Mh[0][cl][4]);
-      rD1 = from_next_lane(D1h[0][E1 - 1]); rD2 = from_next_lane(D2h[0]);
-      if (lane == 0 && wv > 0) { const int* e = s_edge[par][wv - 1][0]; lM10 = e[0]; lM25 = e[1]; lI1 = e[2]; lI2 = e[3]; }
-      if (lane == 63 && wv + 1 < nw) { const int* e = s_edge[par][wv + 1][1]; rM10 = e[0]; rM25 = e[1]; rD1 = e[2]; rD2 = e[3]; }
+      lM10 = from_prev_lane0(Mh[C - 1][cl][1]); lM25 = from_prev_lane0(Mh[C - 1][cl][4]);
+      lI1 = from_prev_lane0(I1h[C - 1][E1 - 1]); lI2 = from_prev_lane0(I2h[C - 1]);
+      rM10 = from_next_lane0(Mh[0][cl][1]); rM25 = from_next_lane0(Mh[0][cl][4]);
+      rD1 = from_next_lane0(D1h[0][E1 - 1]); rD2 = from_next_lane0(D2h[0]);
+      if (lane == 0)  { const int* e = s_edge[par][wv][0];     lM10 = e[0]; lM25 = e[1]; lI1 = e[2]; lI2 = e[3]; }
+      if (lane == 63) { const int* e = s_edge[par][wv + 1][1]; rM10 = e[0]; rM25 = e[1]; rD1 = e[2]; rD2 = e[3]; }
     } else {
       lM10 = from_prev_lane(Mh[C - 1][cl][1]); lM25 = from_prev_lane(Mh[C - 1][cl][4]);
       lI1 = from_prev_lane(I1h[C - 1][E1 - 1]); lI2 = from_prev_lane(I2h[C - 1]);
