@@ -172,6 +172,9 @@ int  wfm_score_bounds(wfm_handle_t* h, const wfm_penalties_t* pen, const wfm_pro
  * out128[lane] = the value 1000 + (lane - 1) taken from the previous lane (lane 0: the kernel's NULL, -2^30),
  * out128[64 + lane] = 1000 + (lane + 1) from the next lane (lane 63: NULL). */
 int  wfm_selftest_dpp(wfm_handle_t* h, int32_t* out128);
+/* Self-test of the device arenas' growth policy: capacities (in 4-byte elements) after a first request of n0 elements, after a request of one element
+ * more than that capacity (must at least double it), and after a request that fits (must not allocate). */
+int  wfm_selftest_arena_growth(wfm_handle_t* h, size_t n0, size_t* out3);
 
 /* Same, but sequences are already resident in device memory (the timed region
  * of bench.py starts here): d_seqs is a device pointer, offsets index into it.

@@ -102,6 +102,19 @@ def test_wave_shifts_the_packed_tile_kernel_leans_on(gpu):
     assert out[64:].tolist() == [1000 + i for i in range(1, 64)] + [null]
 
 
+def test_arenas_at_least_double_when_they_grow(gpu):
+    """DevBuf::ensure (the rings, the phase-2 rows, the base arenas): a regrowth is a fresh hipMalloc, so it at least doubles; a request that fits
+    allocates nothing.  (Until round 4 the old capacity was reset before it was read: the doubling never happened.)"""
+    import ctypes as C
+    L = capi.load()
+    L.wfm_selftest_arena_growth.restype = C.c_int
+    L.wfm_selftest_arena_growth.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    out = (C.c_size_t * 3)()
+    assert L.wfm_selftest_arena_growth(gpu._p, 1 << 20, out) == 0
+    c0, c1, c2 = out[0], out[1], out[2]
+    assert c0 >= 1 << 20 and c1 >= 2 * c0 and c2 == c1
+
+
 def test_packed_and_byte_kernels_in_one_batch(gpu, oracle):
     """A batch in which some problems are pure ACGT (2-bit mirror, wfa_tile2_kernel) and others hold an N or soft-masked bases
     (byte kernel): both kinds of tiles run side by side in every block of a level.  N matches N and nothing else; a lower-case

@@ -1811,6 +1811,23 @@ int wfm_align_batch_rle(wfm_handle_t* h, const wfm_penalties_t* pen, const wfm_p
 
 void wfm_free_runs(uint32_t* runs) { free(runs); }
 
+// Self-test of the arenas' growth policy (DevBuf::ensure): capacities after ensure(n0), ensure(cap + 1), ensure(what fits): out3[0..2] in elements.
+// A regrowth must at least double (every regrowth is a fresh hipMalloc at 30 - 70 ms per GB), a request that fits must not allocate.
+int wfm_selftest_arena_growth(wfm_handle_t* h, size_t n0, size_t* out3) {
+  if (!h || !out3 || n0 == 0) return WFM_E_ARG;
+  HIPCHK(h, hipSetDevice(h->device));
+  DevBuf<int32_t> b;
+  if (b.ensure(n0)) return WFM_E_NOMEM;
+  out3[0] = b.cap;
+  if (b.ensure(b.cap + 1)) { b.release(); return WFM_E_NOMEM; }
+  out3[1] = b.cap;
+  const int32_t* before = b.p;
+  if (b.ensure(b.cap - 1) || b.p != before) { b.release(); return WFM_E_HIP; }
+  out3[2] = b.cap;
+  b.release();
+  return WFM_OK;
+}
+
 int wfm_selftest_dpp(wfm_handle_t* h, int32_t* out128) {
   if (!h || !out128) return WFM_E_ARG;
   HIPCHK(h, hipSetDevice(h->device));
