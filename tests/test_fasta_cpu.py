@@ -70,7 +70,7 @@ def write(path, data, fai=None, gzi=None):
             f.write(gzi)
 
 
-def check_store(path, seqs, expect_mode, rng):
+def check_store(path, seqs, expect_mode, rng, whole=True):
     table = capi.host_fasta(str(path)).splitlines()
     assert table[0] == expect_mode
     assert table[1:] == [f"{h.split()[0]}\t{len(s)}" for h, s in seqs]
@@ -78,13 +78,13 @@ def check_store(path, seqs, expect_mode, rng):
         name = hdr.split()[0]
         n = len(s)
         assert capi.host_fasta(str(path), name, 0, n - 1) == s
-        assert capi.host_fasta(str(path), name, 0, n - 1, whole=True) == s
+        assert capi.host_fasta(str(path), name, 0, n - 1, whole=whole) == s
         cases = [(0, 0), (n - 1, n - 1), (0, n + 100), (-5, 3), (n, n + 5), (59, 60), (60, 119), (58, 61)]
         cases += [tuple(sorted((rng.randrange(n), rng.randrange(n)))) for _ in range(12)]
         for a, b in cases:
             want = s[max(0, a):min(n, b + 1)] if a <= b else ""
             assert capi.host_fasta(str(path), name, a, b) == want, (name, a, b)
-            assert capi.host_fasta(str(path), name, a, b, whole=True) == want, (name, a, b, "whole")
+            assert capi.host_fasta(str(path), name, a, b, whole=whole) == want, (name, a, b, "whole")
     with pytest.raises(capi.WfmError):
         capi.host_fasta(str(path), "absent", 0, 1)
 
@@ -131,6 +131,30 @@ def test_bgzf_with_gzi_without_gzi_and_streamed(tmp_path):
     check_store(tmp_path / "nofai.fa.gz", seqs, "in-memory", rng)
     write(tmp_path / "plain.fa.gz", gzip.compress(data), fai)         # gzip that is not BGZF: no random access
     check_store(tmp_path / "plain.fa.gz", seqs, "in-memory", rng)
+
+
+@pytest.mark.parametrize("align,threads", [(1, 2), (7, 5), (64, 16), (4096, 3), (2 << 20, 8)])
+def test_long_sequences_filled_by_several_readers(tmp_path, monkeypatch, align, threads):
+    """A chromosome goes into a block of its own that several threads fill, each its range of the bases (fasta.cpp:
+    load_block).  Here every sequence is made 'long' (WFM_FASTA_BLOCK_MIN=1) and the readers' ranges are cut at multiples
+    of `align` bases instead of 2 MB, so the cuts fall inside lines, on line ends, and past the end of short sequences; the
+    bytes must be those of the one-reader path (the default thresholds) and of the file."""
+    seqs = make_seqs(11)
+    rng = random.Random(align * 31 + threads)
+    monkeypatch.setenv("WFM_FASTA_BLOCK_MIN", "1")
+    monkeypatch.setenv("WFM_FASTA_BLOCK_ALIGN", str(align))
+    for width, eol in ((60, "\n"), (61, "\r\n"), (1 << 20, "\n")):
+        data, fai = fasta_text(seqs, width, eol)
+        p = tmp_path / f"blk{width}{len(eol)}.fa"
+        write(p, data, fai)
+        check_store(p, seqs, "indexed", rng, whole=threads)
+    data, fai = fasta_text(seqs)
+    small, st2 = bgzf(data, block=1000, eof=False)
+    write(tmp_path / "blk.fa.gz", small, fai, gzi_bytes(st2))
+    check_store(tmp_path / "blk.fa.gz", seqs, "indexed", rng, whole=threads)
+    monkeypatch.setenv("WFM_FASTA_HUGE", "1")  # the huge-page hint changes nothing but the page size
+    for hdr, sq in seqs[:2]:
+        assert capi.host_fasta(str(tmp_path / "blk.fa.gz"), hdr.split()[0], 0, len(sq) - 1, whole=threads) == sq
 
 
 def test_stale_index_is_an_error(tmp_path):

@@ -75,13 +75,13 @@ double estimate_identity_for_groups(const Parameters& params, const SequenceIdMa
   }
   // one sketch per sequence: the sequences are spread over the GPUs at hand (a queue, one host thread per device), the
   // sketches are pooled per group afterwards in the order of the names (the pool of a group does not depend on the order)
-  struct Item { const std::string* name; const Role* role; const std::string* seq; std::vector<hash_t> sketch; };
+  struct Item { const std::string* name; const Role* role; wfmash_host::SeqView seq; std::vector<hash_t> sketch; };
   std::vector<Item> items;
   for (const auto& [name, role] : roles) {
     const wfmash_host::FastaStore& fa = open(role.file);
     const int64_t len = fa.seq_len(name);
     if (len <= 0) continue;  // "not found or empty, skipping"
-    items.push_back(Item{&name, &role, &fa.sequence(fa.find(name)), {}});
+    items.push_back(Item{&name, &role, fa.sequence(fa.find(name)), {}});
   }
   {
     std::atomic<size_t> next{0};
@@ -89,7 +89,7 @@ double estimate_identity_for_groups(const Parameters& params, const SequenceIdMa
     auto work = [&](size_t g) {
       std::vector<hash_t> sketch((size_t)kEstimationSketchSize);
       for (size_t i; (i = next.fetch_add(1)) < items.size();) {
-        const std::string& seq = *items[i].seq;
+        const wfmash_host::SeqView seq = items[i].seq;
         const int64_t n = wfm_minhash_sketch(hs[g], seq.data(), (int64_t)seq.size(), kEstimationK, kEstimationSketchSize, sketch.data());
         if (n < 0) { errors[g] = std::string("wfm_minhash_sketch failed: ") + wfm_last_error(hs[g]); return; }
         items[i].sketch.assign(sketch.begin(), sketch.begin() + n);

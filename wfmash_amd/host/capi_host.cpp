@@ -227,7 +227,7 @@ char* wfmh_test_fasta(const char* path, const char* name, int64_t start, int64_t
       const int i = fa.find(name);
       if (i < 0) r = "ERROR: no such sequence";
       else {
-        if (whole) fa.preload({i}, 2);
+        if (whole) fa.preload({i}, std::max(2, whole));  // whole > 1: that many reader threads
         r = fa.fetch(name, start, end_inclusive);
       }
     }

@@ -1,6 +1,7 @@
 #include "fasta.hpp"
 
 #include <fcntl.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
 #include <zlib.h>
@@ -62,6 +63,8 @@ FastaStore::FastaStore(const std::string& path) : path_(path) {
 
 FastaStore::~FastaStore() {
   if (fd_ >= 0) close(fd_);
+  for (Block& b : blocks_)
+    if (b.base) munmap(b.base, b.map_bytes);
 }
 
 bool FastaStore::open_indexed(const std::string& path) {
@@ -145,6 +148,7 @@ bool FastaStore::open_indexed(const std::string& path) {
   }
   fd_ = fd;
   seqs_.resize(names_.size());
+  blocks_.resize(names_.size());
   once_.reset(new std::once_flag[names_.size()]);
   loaded_.reset(new std::atomic<bool>[names_.size()]);
   for (size_t i = 0; i < names_.size(); ++i) loaded_[i].store(false, std::memory_order_relaxed);
@@ -236,18 +240,16 @@ void FastaStore::read_text(int64_t off, int64_t n, char* dst) const {
   }
 }
 
-void FastaStore::read_bases(int i, int64_t start, int64_t end, std::string& out) const {
+void FastaStore::read_bases_to(int i, int64_t start, int64_t end, char* dst) const {
   if (start >= end) return;
   const FaiEntry& e = fai_[(size_t)i];
   const int64_t first = e.offset + start / e.line_bases * e.line_width + start % e.line_bases;
   const int64_t last = e.offset + (end - 1) / e.line_bases * e.line_width + (end - 1) % e.line_bases;  // inclusive
-  // in slices, so that a chromosome does not need a second buffer of its size
-  const int64_t slice = 64ll << 20;
-  std::vector<char> buf;
-  out.reserve(out.size() + (size_t)(end - start));
+  // in slices that stay in the cache between the read and the pass that drops the line ends
+  const int64_t slice = 4ll << 20;
+  std::vector<char> buf((size_t)std::min(slice, last + 1 - first));
   for (int64_t off = first; off <= last; off += slice) {
     const int64_t n = std::min(slice, last + 1 - off);
-    buf.resize((size_t)n);
     read_text(off, n, buf.data());
     // keep the bytes whose position within its line is < line_bases
     int64_t col = (off - e.offset) % e.line_width;
@@ -255,8 +257,8 @@ void FastaStore::read_bases(int i, int64_t start, int64_t end, std::string& out)
     while (p < n) {
       if (col < e.line_bases) {
         const int64_t run = std::min(e.line_bases - col, n - p);
-        out.append(buf.data() + p, (size_t)run);
-        p += run; col += run;
+        memcpy(dst, buf.data() + p, (size_t)run);
+        dst += run; p += run; col += run;
       } else {
         const int64_t skip = std::min(e.line_width - col, n - p);
         p += skip; col += skip;
@@ -266,20 +268,84 @@ void FastaStore::read_bases(int i, int64_t start, int64_t end, std::string& out)
   }
 }
 
+void FastaStore::read_bases(int i, int64_t start, int64_t end, std::string& out) const {
+  if (start >= end) return;
+  const size_t at = out.size();
+  out.resize(at + (size_t)(end - start));
+  read_bases_to(i, start, end, &out[at]);
+}
+
+namespace {
+constexpr int64_t kHuge = 2ll << 20;
+// sequences from this length on get a block of their own (WFM_FASTA_BLOCK_MIN: the tests set it low)
+int64_t block_min() {
+  const char* e = getenv("WFM_FASTA_BLOCK_MIN");
+  return e ? std::max<int64_t>(1, atoll(e)) : (int64_t)8 << 20;
+}
+// the ranges the readers of one block take: whole huge pages (WFM_FASTA_BLOCK_ALIGN: the tests set it low)
+int64_t block_align() {
+  const char* e = getenv("WFM_FASTA_BLOCK_ALIGN");
+  return e ? std::max<int64_t>(1, atoll(e)) : kHuge;
+}
+}  // namespace
+
+// a long sequence into a block of its own, filled by 1 + helpers threads
+void FastaStore::load_block(int i, int helpers) const {
+  const int64_t len = lens_[(size_t)i];
+  Block b;
+  b.map_bytes = (size_t)((len + kHuge - 1) / kHuge * kHuge + kHuge);
+  void* m = mmap(nullptr, b.map_bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+  if (m == MAP_FAILED) throw std::bad_alloc();
+  b.base = static_cast<char*>(m);
+  b.p = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(b.base) + (uintptr_t)kHuge - 1) / (uintptr_t)kHuge * (uintptr_t)kHuge);
+  const char* he = getenv("WFM_FASTA_HUGE");
+  const bool huge = he ? atoi(he) != 0 : false;
+  if (huge) (void)madvise(b.p, b.map_bytes - (size_t)(b.p - b.base), MADV_HUGEPAGE);  // a hint: 4 kB pages work as well, only slower
+  const int64_t al = block_align();
+  const int T = (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)helpers + 1, (len + al - 1) / al));
+  std::vector<int64_t> cut((size_t)T + 1);
+  for (int t = 0; t <= T; ++t) cut[(size_t)t] = t == T ? len : len / T * t / al * al;
+  std::vector<std::string> errors((size_t)T);
+  auto part = [&](int t) {
+    try { read_bases_to(i, cut[(size_t)t], cut[(size_t)t + 1], b.p + cut[(size_t)t]); }
+    catch (const std::exception& e) { errors[(size_t)t] = e.what(); if (errors[(size_t)t].empty()) errors[(size_t)t] = "read failed"; }
+  };
+  {
+    std::vector<std::thread> pool;
+    try {
+      for (int t = 1; t < T; ++t) pool.emplace_back(part, t);
+    } catch (const std::exception&) {  // no more threads to be had: this one does the rest
+      for (int t = (int)pool.size() + 1; t < T; ++t) part(t);
+    }
+    part(0);
+    for (auto& th : pool) th.join();
+  }
+  for (const auto& e : errors)
+    if (!e.empty()) { munmap(b.base, b.map_bytes); throw std::runtime_error(e); }
+  blocks_[(size_t)i] = b;
+}
+
 int64_t FastaStore::seq_len(const std::string& name) const {
   auto it = index_.find(name);
   return it == index_.end() ? -1 : lens_[(size_t)it->second];
 }
 
-const std::string& FastaStore::sequence(int i) const {
+SeqView FastaStore::sequence(int i, int helpers) const {
   if (fd_ >= 0)
     std::call_once(once_[(size_t)i], [&] {
-      std::string s;
-      read_bases(i, 0, lens_[(size_t)i], s);
-      seqs_[(size_t)i] = std::move(s);
-      loaded_[(size_t)i].store(true, std::memory_order_release);  // fetch() may look at seqs_[i] from now on
+      const int64_t len = lens_[(size_t)i];
+      if (len >= block_min()) {
+        if (helpers < 0) helpers = (int)std::min<unsigned>(15u, std::max(1u, std::thread::hardware_concurrency()) - 1u);
+        load_block(i, helpers);
+      } else {
+        std::string s;
+        read_bases(i, 0, len, s);
+        seqs_[(size_t)i] = std::move(s);
+      }
+      loaded_[(size_t)i].store(true, std::memory_order_release);  // fetch() may look at the sequence from now on
     });
-  return seqs_[(size_t)i];
+  if (fd_ >= 0 && blocks_[(size_t)i].p) return SeqView{blocks_[(size_t)i].p, (size_t)lens_[(size_t)i]};
+  return SeqView{seqs_[(size_t)i].data(), seqs_[(size_t)i].size()};
 }
 
 void FastaStore::preload(const std::vector<int>& which, int threads) const {
@@ -289,11 +355,26 @@ void FastaStore::preload(const std::vector<int>& which, int threads) const {
     for (int i = 0; i < nseq(); ++i) todo.push_back(i);
   // longest first
   std::sort(todo.begin(), todo.end(), [&](int a, int b) { return lens_[(size_t)a] > lens_[(size_t)b]; });
+  // the threads go to the bases: a long sequence gets its share of them as readers of its block, and so many sequences
+  // are in the making at a time that the shares add up to `threads`
+  int64_t total = 0;
+  for (int i : todo) total += lens_[(size_t)i];
+  const int T = std::max(1, threads);
+  std::vector<int> helpers(todo.size(), 0);
+  int nt = (int)std::min<size_t>((size_t)T, todo.size());
+  if (total > 0 && lens_[(size_t)todo[0]] >= block_min()) {
+    int used = 0;
+    nt = 0;
+    for (size_t j = 0; j < todo.size(); ++j) {
+      const int share = (int)std::max<int64_t>(1, std::min<int64_t>(T, (int64_t)((double)lens_[(size_t)todo[j]] / (double)total * T)));
+      helpers[j] = share - 1;
+      if (used < T) { used += share; ++nt; }
+    }
+  }
   std::atomic<size_t> next{0};
   auto work = [&] {
-    for (size_t j; (j = next.fetch_add(1)) < todo.size();) sequence(todo[j]);
+    for (size_t j; (j = next.fetch_add(1)) < todo.size();) (void)sequence(todo[j], helpers[j]);
   };
-  const int nt = (int)std::min<size_t>((size_t)std::max(1, threads), todo.size());
   std::vector<std::thread> pool;
   for (int t = 1; t < nt; ++t) pool.emplace_back(work);
   work();
@@ -310,7 +391,11 @@ std::string FastaStore::fetch(const std::string& name, int64_t start, int64_t en
   if (start >= end) return std::string();
   // a whole sequence that another thread is loading right now (sequence(i)) is not touched: this fetch reads its range
   // from the file instead
-  if (fd_ < 0 || loaded_[(size_t)i].load(std::memory_order_acquire)) return seqs_[(size_t)i].substr((size_t)start, (size_t)(end - start));
+  if (fd_ < 0) return seqs_[(size_t)i].substr((size_t)start, (size_t)(end - start));
+  if (loaded_[(size_t)i].load(std::memory_order_acquire)) {
+    const Block& b = blocks_[(size_t)i];
+    return b.p ? std::string(b.p + start, (size_t)(end - start)) : seqs_[(size_t)i].substr((size_t)start, (size_t)(end - start));
+  }
   std::string out;
   read_bases(i, start, end, out);
   return out;

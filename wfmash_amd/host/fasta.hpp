@@ -9,7 +9,11 @@
 //    fetch() is true random access (pread of the lines that hold the range; for BGZF the blocks
 //    that hold it, found through `<path>.gzi` or, without one, a scan of the block headers);
 //    sequence(i) loads one whole sequence on first use, thread-safe, so callers can load many
-//    side by side (preload()).
+//    side by side (preload()).  A long sequence (a chromosome) goes into a block of its own -- 2 MB
+//    aligned and marked for huge pages -- that several threads fill side by side, each its own
+//    range of the bases (the .fai gives every base its place in the file): one thread strips the
+//    line ends of about 1 GB/s, and first-touching a quarter of a gigabyte of 4 kB pages costs as
+//    much again.
 //  * in-memory -- no .fai, or a gzip stream that is not BGZF: the file is read once through zlib.
 //    (htslib would build the .fai here, FAI_CREATE; this reader does not write next to its inputs.)
 // Both modes return identical bytes; tests/test_fasta_cpu.py holds them against each other.
@@ -24,6 +28,15 @@
 #include <vector>
 
 namespace wfmash_host {
+
+// the bases of a whole sequence, held by the FastaStore they came from
+struct SeqView {
+  const char* p = nullptr;
+  size_t n = 0;
+  const char* data() const { return p; }
+  size_t size() const { return n; }
+  bool empty() const { return n == 0; }
+};
 
 class FastaStore {
  public:
@@ -40,9 +53,11 @@ class FastaStore {
   // Bases [start, end_inclusive] of `name` (faigz uses an inclusive end), clamped
   // to the sequence; empty string if absent.
   std::string fetch(const std::string& name, int64_t start, int64_t end_inclusive) const;
-  // The whole sequence; in indexed mode it is read on first use and kept.
-  const std::string& sequence(int i) const;
-  // Reads the listed sequences (all if empty) with up to `threads` readers.
+  // The whole sequence; in indexed mode it is read on first use and kept.  helpers: further threads a long sequence
+  // may be read with (-1: up to 15, as the machine has them).
+  SeqView sequence(int i, int helpers = -1) const;
+  // Reads the listed sequences (all if empty) with up to `threads` readers: sequences side by side, and the threads
+  // that are left over inside the long ones.
   void preload(const std::vector<int>& which, int threads) const;
   // index of `name`, -1 if absent
   int find(const std::string& name) const { auto it = index_.find(name); return it == index_.end() ? -1 : it->second; }
@@ -54,14 +69,18 @@ class FastaStore {
   bool open_indexed(const std::string& path);
   // bytes [off, off+n) of the uncompressed file
   void read_text(int64_t off, int64_t n, char* dst) const;
-  // bases [start, end) of sequence i appended to out
+  // bases [start, end) of sequence i appended to out / written to dst
   void read_bases(int i, int64_t start, int64_t end, std::string& out) const;
+  void read_bases_to(int i, int64_t start, int64_t end, char* dst) const;
+  void load_block(int i, int helpers) const;
+  struct Block { char* base = nullptr; size_t map_bytes = 0; char* p = nullptr; };  // an anonymous mapping; p: 2 MB aligned
 
   std::string path_;
   std::vector<std::string> names_;
   std::vector<int64_t> lens_;
   std::unordered_map<std::string, int> index_;
   mutable std::vector<std::string> seqs_;
+  mutable std::vector<Block> blocks_;  // indexed mode: the long sequences (seqs_[i] stays empty)
   // indexed mode
   int fd_ = -1;
   bool bgzf_ = false;

@@ -41,13 +41,13 @@ class SequenceSource {
     order_.push_back(path);
   }
   // the first file holding `name`, restricted to `files`
-  const std::string* find(const std::vector<std::string>& files, const std::string& name) const {
+  bool find(const std::vector<std::string>& files, const std::string& name, wfmash_host::SeqView* seq) const {
     for (const auto& f : files) {
       const auto& st = *stores_.at(f);
       const int i = st.find(name);
-      if (i >= 0) return &st.sequence(i);
+      if (i >= 0) { *seq = st.sequence(i); return true; }
     }
-    return nullptr;
+    return false;
   }
   // indexed files: read the sequences find() will be asked for, side by side
   void preload(const std::vector<std::string>& files, const std::vector<std::string>& names, int threads) const {
@@ -213,10 +213,10 @@ int Map::mapQuery(MapSummary* summary) {
       std::vector<int64_t> sl;
       std::vector<int32_t> si;
       for (const auto& name : subset) {
-        const std::string* seq = src.find(P.refSequences, name);
-        if (!seq) { wfm_set_error(h_, "target sequence not found in FASTA: " + name); return WFM_E_ARG; }
-        if ((int64_t)seq->size() < w) continue;  // "skipping short sequence" (winSketch.hpp:216-229)
-        sp.push_back(seq->data()); sl.push_back((int64_t)seq->size()); si.push_back(ids.getSequenceId(name));
+        wfmash_host::SeqView seq;
+        if (!src.find(P.refSequences, name, &seq)) { wfm_set_error(h_, "target sequence not found in FASTA: " + name); return WFM_E_ARG; }
+        if ((int64_t)seq.size() < w) continue;  // "skipping short sequence" (winSketch.hpp:216-229)
+        sp.push_back(seq.data()); sl.push_back((int64_t)seq.size()); si.push_back(ids.getSequenceId(name));
       }
       // minmer intervals (GPU hashing + thinning, host winnowing) and the index stage; the intervals never
       // sit in one host array
@@ -277,9 +277,12 @@ int Map::mapQuery(MapSummary* summary) {
     // ---- queries, in batches of whole sequences; a GPU takes the next batch when it is free, finished batches
     // are written in the order they were formed
     struct BatchQuery { std::string name; seqno_t id; offset_t len; int64_t base; int64_t first_frag; int nfrag; };
+    // (a batch of one sequence -- a chromosome -- is mapped where the FASTA store holds it; several are laid end to end in `buffer`)
     struct Batch {
       std::vector<BatchQuery> bq;
       std::string buffer;
+      const char* bases = nullptr;
+      int64_t n_bases = 0;
       std::vector<int64_t> frag_off;
       std::vector<int32_t> frag_seq;
     };
@@ -296,19 +299,27 @@ int Map::mapQuery(MapSummary* summary) {
     auto read_batch = [&](Batch& b) -> int64_t {
       std::lock_guard<std::mutex> lk(read_mu);
       b = Batch();
-      while (qi < queryNames.size() && ((int64_t)b.buffer.size() < batch_bases || b.bq.empty())) {
+      wfmash_host::SeqView only;  // the batch's one sequence so far, not copied yet
+      while (qi < queryNames.size() && (b.n_bases < batch_bases || b.bq.empty())) {
         const std::string& name = queryNames[qi++];
-        const std::string* seq = src.find(P.querySequences, name);
-        if (!seq || seq->empty()) continue;  // "not found or empty, skipping" (computeMap.hpp:534-537)
-        BatchQuery q{name, ids.getSequenceId(name), (offset_t)seq->size(), (int64_t)b.buffer.size(), (int64_t)b.frag_off.size(), 0};
+        wfmash_host::SeqView seq;
+        if (!src.find(P.querySequences, name, &seq) || seq.empty()) continue;  // "not found or empty, skipping" (computeMap.hpp:534-537)
+        BatchQuery q{name, ids.getSequenceId(name), (offset_t)seq.size(), b.n_bases, (int64_t)b.frag_off.size(), 0};
         const int whole = (int)(q.len / w);
         for (int i = 0; i < whole; ++i) b.frag_off.push_back(q.base + (int64_t)i * w);
         q.nfrag = whole;
         if (whole >= 1 && q.len % w != 0) { b.frag_off.push_back(q.base + q.len - w); q.nfrag++; }  // anchored at the end
         b.frag_seq.insert(b.frag_seq.end(), (size_t)q.nfrag, q.id);
-        b.buffer += *seq;
+        if (b.bq.empty()) {
+          only = seq;
+        } else {
+          if (b.buffer.empty()) b.buffer.assign(only.data(), only.size());
+          b.buffer.append(seq.data(), seq.size());
+        }
+        b.n_bases += (int64_t)seq.size();
         b.bq.push_back(std::move(q));
       }
+      if (b.bq.size() == 1) b.bases = only.data(); else b.bases = b.buffer.data();
       return b.bq.empty() ? -1 : (int64_t)next_seq++;
     };
     auto write_batch = [&](uint64_t seq, BatchOut&& bo) {
@@ -351,7 +362,7 @@ int Map::mapQuery(MapSummary* summary) {
           int64_t cap = (int64_t)b.frag_off.size() * std::min<int64_t>(256, std::max<int64_t>(16, 2 * (int64_t)subset.size())) + (1 << 16);
           for (;;) {
             maps.resize((size_t)cap); mfrag.resize((size_t)cap);
-            const int64_t n = wfm_map_fragments(hg, ixs[g], b.buffer.data(), (int64_t)b.buffer.size(), b.frag_off.data(), b.frag_seq.data(),
+            const int64_t n = wfm_map_fragments(hg, ixs[g], b.bases, b.n_bases, b.frag_off.data(), b.frag_seq.data(),
                                                 (int64_t)b.frag_off.size(), &T.prm, maps.data(), mfrag.data(), cap);
             if (n < 0) {
               fail((int)n, wfm_last_error(hg));
