@@ -222,6 +222,15 @@ char* wfmh_test_filter(const char* stage, const wfm_mapping_t* maps, int64_t n, 
  * malloc'd, wfmh_free; "ERROR: ..." on failure. */
 char* wfmh_test_fasta(const char* path, const char* name, int64_t start, int64_t end_inclusive, int whole);
 
+/* The sequences a map call loaded stay in memory for the call that follows (the align phase fetches its windows from the
+ * same files; the reference keeps its faidx readers open for the whole run, src/common/faigz.h:221-505).  They are let go
+ * when the next map call hands in its own, or here.  (WFM_FASTA_KEEP=0: nothing is kept; WFM_FASTA_KEEP_GB: the most that is, 32.) */
+void wfmh_release_sequences(void);
+
+/* Test hook: the whole sequence `name` through the store the process shares per path (open_shared), which is then kept as a
+ * map call keeps its stores: a second call on a file rewritten in between must see the new bytes.  malloc'd, wfmh_free. */
+char* wfmh_test_fasta_shared(const char* path, const char* name);
+
 /* Test hook for the on-disk index format (wfmash_amd/host/index_file.hpp; no GPU needed).  op "ids": the id
  * section alone (SequenceIdManager::exportIdMapping, sequenceIds.hpp:101-115) of fasta's sequences into out_path;
  * op "rewrite": every sub-index of in_path is read and written again into out_path.  0, or -1 (message on stderr). */

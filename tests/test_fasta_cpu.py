@@ -157,6 +157,29 @@ def test_long_sequences_filled_by_several_readers(tmp_path, monkeypatch, align, 
         assert capi.host_fasta(str(tmp_path / "blk.fa.gz"), hdr.split()[0], 0, len(sq) - 1, whole=threads) == sq
 
 
+def test_kept_store_is_reused_and_a_rewritten_file_is_read_afresh(tmp_path, monkeypatch):
+    """A map call leaves its stores open for the align call that follows (fasta.hpp: keep_until_next); open_shared hands a
+    kept store out again only while the file and its .fai are the ones it was opened on."""
+    monkeypatch.setenv("WFM_FASTA_BLOCK_MIN", "1000")  # the long sequences of the set go through the block path
+    p = tmp_path / "k.fa"
+    a, b = make_seqs(21), make_seqs(22)
+    for seqs in (a, b, a):  # the third round: same bytes and size as the first, a new file all the same
+        data, fai = fasta_text(seqs)
+        write(p, data, fai)
+        for hdr, s in seqs:
+            assert capi.host_fasta_shared(str(p), hdr.split()[0]) == s
+        for hdr, s in seqs[:2]:  # again: served by the kept store
+            assert capi.host_fasta_shared(str(p), hdr.split()[0]) == s
+    capi.release_sequences()
+    os.remove(p)
+    with pytest.raises(capi.WfmError):
+        capi.host_fasta_shared(str(p), "b")
+    monkeypatch.setenv("WFM_FASTA_KEEP", "0")
+    data, fai = fasta_text(a)
+    write(p, data, fai)
+    assert capi.host_fasta_shared(str(p), "b") == a[1][1]
+
+
 def test_stale_index_is_an_error(tmp_path):
     seqs = make_seqs()
     data, fai = fasta_text(seqs)

@@ -609,7 +609,8 @@ class Handle:
 # ---------------------------------------------------------------------------
 HOST_EXPORTS = ["wfmh_test_packed_lce", "wfmh_test_is_acgt", "wfmh_align_default_params", "wfmh_align_paf", "wfmh_test_cigar", "wfmh_free", "wfmh_test_winnow",
                 "wfmh_map_default_params", "wfmh_test_filter", "wfmh_map", "wfmh_test_winnow_chunked", "wfmh_test_fasta", "wfmh_test_winnow_thinned", "wfmh_test_sort_records", "wfmh_test_index_file",
-                "wfmh_map_multi", "wfmh_align_paf_multi", "wfmh_test_winnow_model", "wfmh_test_sortlike_model", "wfmh_test_finish_records"]
+                "wfmh_map_multi", "wfmh_align_paf_multi", "wfmh_test_winnow_model", "wfmh_test_sortlike_model", "wfmh_test_finish_records",
+                "wfmh_release_sequences", "wfmh_test_fasta_shared"]
 
 
 class MapSummary(C.Structure):
@@ -648,6 +649,31 @@ def map_paf(handle, target_fasta: str, out_paf: str, query_fasta: str = None, pa
     if rc != 0:
         raise WfmError(f"wfmh_map failed ({rc}): {handle.last_error()}")
     return s
+
+
+def host_fasta_shared(path: str, name: str) -> str:
+    """wfmh_test_fasta_shared: a whole sequence through the per-path shared store, which is then kept as a map call keeps its stores."""
+    L = load()
+    L.wfmh_test_fasta_shared.restype = C.c_void_p
+    L.wfmh_test_fasta_shared.argtypes = [C.c_char_p, C.c_char_p]
+    L.wfmh_free.restype = None
+    L.wfmh_free.argtypes = [C.c_void_p]
+    p = L.wfmh_test_fasta_shared(path.encode(), name.encode())
+    if not p:
+        raise WfmError("wfmh_test_fasta_shared failed")
+    s = C.string_at(p).decode()
+    L.wfmh_free(p)
+    if s.startswith("ERROR: "):
+        raise WfmError(s)
+    return s
+
+
+def release_sequences() -> None:
+    """wfmh_release_sequences: lets go of the sequences the last map call left loaded for the align phase."""
+    L = load()
+    L.wfmh_release_sequences.restype = None
+    L.wfmh_release_sequences.argtypes = []
+    L.wfmh_release_sequences()
 
 
 class MapHostParams(C.Structure):

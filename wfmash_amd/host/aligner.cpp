@@ -80,9 +80,10 @@ Aligner::Aligner(const Parameters& p, const std::vector<wfm_handle_t*>& g) : par
   if (gpus.empty() || std::find(gpus.begin(), gpus.end(), nullptr) != gpus.end()) throw std::runtime_error("[wfmash::align] no GPU handle");
   if (param.refSequences.size() != 1 || param.querySequences.size() != 1)
     throw std::runtime_error("[wfmash::align] exactly one target and one query FASTA are expected");
-  ref.reset(new wfmash_host::FastaStore(param.refSequences.front()));
+  // (shared with whoever has the file open -- a map phase just before this leaves its sequences loaded: fasta.hpp, keep_until_next)
+  ref = wfmash_host::open_shared(param.refSequences.front());
   if (param.querySequences.front() == param.refSequences.front()) query = ref.get();
-  else { query_own.reset(new wfmash_host::FastaStore(param.querySequences.front())); query = query_own.get(); }
+  else { query_own = wfmash_host::open_shared(param.querySequences.front()); query = query_own.get(); }
 }
 
 void Aligner::parseMashmapRow(const std::string& line, MappingBoundaryRow& row, uint64_t target_padding, uint64_t query_padding) {

@@ -90,7 +90,7 @@ class Aligner {
   static uint64_t row_bases(const std::string& line);
   const Parameters& param;
   std::vector<wfm_handle_t*> gpus;
-  std::unique_ptr<wfmash_host::FastaStore> ref, query_own;
+  std::shared_ptr<wfmash_host::FastaStore> ref, query_own;
   const wfmash_host::FastaStore* query = nullptr;
 };
 

@@ -242,3 +242,23 @@ char* wfmh_test_fasta(const char* path, const char* name, int64_t start, int64_t
 }
 
 }  // extern "C"
+
+void wfmh_release_sequences(void) { wfmash_host::release_kept(); }
+
+char* wfmh_test_fasta_shared(const char* path, const char* name) {
+  std::string r;
+  try {
+    std::shared_ptr<wfmash_host::FastaStore> fa = wfmash_host::open_shared(path ? path : "");
+    const int i = name ? fa->find(name) : -1;
+    if (i < 0) r = "ERROR: no such sequence";
+    else { const wfmash_host::SeqView v = fa->sequence(i, 1); r.assign(v.data(), v.size()); }
+    wfmash_host::keep_until_next({fa});
+  } catch (const std::exception& e) {
+    r = std::string("ERROR: ") + e.what();
+  }
+  char* out = (char*)malloc(r.size() + 1);
+  if (!out) return nullptr;
+  memcpy(out, r.data(), r.size());
+  out[r.size()] = 0;
+  return out;
+}

@@ -136,35 +136,48 @@ int wfmh_map_multi(wfm_handle_t* const* handles, int n, const char* target_fasta
     p.refSequences = {std::string(target_fasta)};
     p.querySequences = {std::string(query_fasta ? query_fasta : target_fasta)};
     p.outFileName = out_paf;
-    // the files stay open (and what is loaded of them stays loaded) from the identity estimate through the mapping
-    std::vector<std::shared_ptr<wfmash_host::FastaStore>> files;
-    for (const auto& f : p.refSequences) files.push_back(wfmash_host::open_shared(f));
-    for (const auto& f : p.querySequences) files.push_back(wfmash_host::open_shared(f));
-    const auto t_call = std::chrono::steady_clock::now();
-    double ms_identity = 0;
-    if (p.auto_pct_identity) {
-      // main.cpp:72-128: estimate, then derive the sketch size from the estimate unless -s was given
-      std::vector<std::string> target_prefix_vec;
-      if (!p.target_prefix.empty()) target_prefix_vec.push_back(p.target_prefix);
-      const skch::SequenceIdManager ids(p.querySequences, p.refSequences, p.query_prefix, target_prefix_vec,
-                                        std::string(1, p.prefix_delim), p.query_list, p.target_list);
-      p.percentageIdentity = skch::Stat::estimate_identity_for_groups(p, ids, std::vector<wfm_handle_t*>(handles, handles + n));
-      ms_identity = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call).count();
+    const auto t_open = std::chrono::steady_clock::now();
+    auto ms_since = [](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count(); };
+    int rc;
+    double ms_opened = 0, ms_mapped = 0;
+    {
+      // the files stay open (and what is loaded of them stays loaded) from the identity estimate through the mapping
+      std::vector<std::shared_ptr<wfmash_host::FastaStore>> files;
+      for (const auto& f : p.refSequences) files.push_back(wfmash_host::open_shared(f));
+      for (const auto& f : p.querySequences) files.push_back(wfmash_host::open_shared(f));
+      ms_opened = ms_since(t_open);
+      const auto t_call = std::chrono::steady_clock::now();
+      double ms_identity = 0;
+      if (p.auto_pct_identity) {
+        // main.cpp:72-128: estimate, then derive the sketch size from the estimate unless -s was given
+        std::vector<std::string> target_prefix_vec;
+        if (!p.target_prefix.empty()) target_prefix_vec.push_back(p.target_prefix);
+        const skch::SequenceIdManager ids(p.querySequences, p.refSequences, p.query_prefix, target_prefix_vec,
+                                          std::string(1, p.prefix_delim), p.query_list, p.target_list);
+        p.percentageIdentity = skch::Stat::estimate_identity_for_groups(p, ids, std::vector<wfm_handle_t*>(handles, handles + n));
+        ms_identity = ms_since(t_call);
+      }
+      skch::Map mapper(p, std::vector<wfm_handle_t*>(handles, handles + n));
+      skch::MapSummary s;
+      rc = mapper.mapQuery(&s);
+      if (summary) {
+        summary->targets = s.targets; summary->queries = s.queries; summary->subsets = s.subsets;
+        summary->target_bp = s.target_bp; summary->query_bp = s.query_bp; summary->index_windows = s.index_windows;
+        summary->fragments = s.fragments; summary->l2_mappings = s.l2_mappings; summary->written = s.written;
+        summary->percentage_identity = mapper.parameters().percentageIdentity;
+        summary->sketch_size = mapper.parameters().sketchSize;
+        summary->ms_index = s.ms_index; summary->ms_map = s.ms_map; summary->ms_filter = s.ms_filter; summary->ms_total = s.ms_total;
+        summary->ms_replicate = s.ms_replicate;
+        summary->ms_identity = ms_identity;
+        summary->ms_wall = ms_since(t_call);
+      }
+      ms_mapped = ms_since(t_open);
+      // the sequences (gigabytes for a pangenome) stay loaded for the call that follows -- the align phase, as a rule, which
+      // fetches its windows from the same files -- and what was kept before goes back to the system on a thread of its own
+      wfmash_host::keep_until_next(std::move(files));
     }
-    skch::Map mapper(p, std::vector<wfm_handle_t*>(handles, handles + n));
-    skch::MapSummary s;
-    const int rc = mapper.mapQuery(&s);
-    if (summary) {
-      summary->targets = s.targets; summary->queries = s.queries; summary->subsets = s.subsets;
-      summary->target_bp = s.target_bp; summary->query_bp = s.query_bp; summary->index_windows = s.index_windows;
-      summary->fragments = s.fragments; summary->l2_mappings = s.l2_mappings; summary->written = s.written;
-      summary->percentage_identity = mapper.parameters().percentageIdentity;
-      summary->sketch_size = mapper.parameters().sketchSize;
-      summary->ms_index = s.ms_index; summary->ms_map = s.ms_map; summary->ms_filter = s.ms_filter; summary->ms_total = s.ms_total;
-      summary->ms_replicate = s.ms_replicate;
-      summary->ms_identity = ms_identity;
-      summary->ms_wall = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call).count();
-    }
+    if (getenv("WFM_DEBUG"))
+      fprintf(stderr, "[wfm] map call: files opened after %.1f ms, mapped after %.1f ms, returning after %.1f ms\n", ms_opened, ms_mapped, ms_since(t_open));
     return rc;
   } catch (const std::exception& e) {
     wfm_set_error(h, e.what());

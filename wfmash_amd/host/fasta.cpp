@@ -8,6 +8,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <sstream>
@@ -56,15 +57,39 @@ int64_t bgzf_block_size(int fd, int64_t off, int64_t file_size, int* data_begin)
 
 }  // namespace
 
+FastaStore::FileId FastaStore::file_id(const std::string& path) {
+  FileId f;
+  struct stat sb;
+  if (stat(path.c_str(), &sb) != 0) return f;  // absent: size -1
+  f.dev = (uint64_t)sb.st_dev; f.ino = (uint64_t)sb.st_ino; f.size = (int64_t)sb.st_size;
+  f.mtime_ns = (int64_t)sb.st_mtim.tv_sec * 1000000000ll + (int64_t)sb.st_mtim.tv_nsec;
+  return f;
+}
+
+bool FastaStore::same_file() const { return file_id(path_) == id_ && file_id(path_ + ".fai") == id_fai_; }
+
+int64_t FastaStore::resident_bytes() const {
+  int64_t t = 0;
+  for (size_t i = 0; i < seqs_.size(); ++i) {
+    if (fd_ >= 0 && !loaded_[i].load(std::memory_order_acquire)) continue;
+    t += fd_ >= 0 && blocks_[i].p ? (int64_t)blocks_[i].map_bytes : (int64_t)seqs_[i].capacity();
+  }
+  return t;
+}
+
 FastaStore::FastaStore(const std::string& path) : path_(path) {
+  id_ = file_id(path);
+  id_fai_ = file_id(path + ".fai");
   if (!open_indexed(path)) load_stream(path);
   for (size_t i = 0; i < names_.size(); ++i) index_.emplace(names_[i], (int)i);  // the first of equal names wins, as in faidx
 }
 
 FastaStore::~FastaStore() {
   if (fd_ >= 0) close(fd_);
+  // (in pieces: an unmap holds the address space's lock, and other threads' page faults with it, for as long as it takes)
+  const size_t piece = (size_t)64 << 20;
   for (Block& b : blocks_)
-    if (b.base) munmap(b.base, b.map_bytes);
+    for (size_t off = 0; b.base && off < b.map_bytes; off += piece) munmap(b.base + off, std::min(piece, b.map_bytes - off));
 }
 
 bool FastaStore::open_indexed(const std::string& path) {
@@ -299,8 +324,10 @@ void FastaStore::load_block(int i, int helpers) const {
   b.base = static_cast<char*>(m);
   b.p = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(b.base) + (uintptr_t)kHuge - 1) / (uintptr_t)kHuge * (uintptr_t)kHuge);
   const char* he = getenv("WFM_FASTA_HUGE");
-  const bool huge = he ? atoi(he) != 0 : false;
-  if (huge) (void)madvise(b.p, b.map_bytes - (size_t)(b.p - b.base), MADV_HUGEPAGE);  // a hint: 4 kB pages work as well, only slower
+  const bool huge = he ? atoi(he) != 0 : true;
+  // a hint (4 kB pages work as well, only slower): on the MI355X host the identity estimate of 9 x 249 Mbp took 130 - 134 ms
+  // with it and 161 - 250 ms without, the whole map call of a C4 rank 0.73 s against 0.80 - 0.94 s (WFM_FASTA_HUGE=0 turns it off)
+  if (huge) (void)madvise(b.p, b.map_bytes - (size_t)(b.p - b.base), MADV_HUGEPAGE);
   const int64_t al = block_align();
   const int T = (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)helpers + 1, (len + al - 1) / al));
   std::vector<int64_t> cut((size_t)T + 1);
@@ -407,10 +434,52 @@ std::shared_ptr<FastaStore> open_shared(const std::string& path) {
   std::lock_guard<std::mutex> lk(mu);
   auto it = open_files.find(path);
   if (it != open_files.end())
-    if (auto sp = it->second.lock()) return sp;
+    if (auto sp = it->second.lock())
+      if (sp->same_file()) return sp;  // (a file rewritten since -- a kept store outlives the call it was opened in -- is opened afresh)
   auto sp = std::make_shared<FastaStore>(path);
   open_files[path] = sp;
   return sp;
+}
+
+void release_later(std::vector<std::shared_ptr<FastaStore>> files) {
+  const char* e = getenv("WFM_FASTA_RELEASE_LATER");
+  if (e && atoi(e) == 0) { files.clear(); return; }
+  try {
+    std::thread([held = std::move(files)]() mutable { held.clear(); }).detach();
+  } catch (const std::exception&) {
+    // no thread to be had: the caller's own `files` (moved from, or still whole) goes out of scope as before
+  }
+}
+
+namespace {
+std::mutex g_kept_mu;
+std::vector<std::shared_ptr<FastaStore>> g_kept;
+}  // namespace
+
+void keep_until_next(std::vector<std::shared_ptr<FastaStore>> files) {
+  const char* e = getenv("WFM_FASTA_KEEP");
+  const char* g = getenv("WFM_FASTA_KEEP_GB");
+  const double cap_gb = g ? atof(g) : 32.0;
+  int64_t bytes = 0;
+  for (const auto& f : files) if (f) bytes += f->resident_bytes();
+  std::vector<std::shared_ptr<FastaStore>> old;
+  {
+    std::lock_guard<std::mutex> lk(g_kept_mu);
+    old.swap(g_kept);
+    if (!(e && atoi(e) == 0) && (double)bytes <= cap_gb * 1e9) g_kept = files;
+  }
+  // what the new set does not hold on to goes back to the system (the same stores, as a rule, when a run repeats)
+  release_later(std::move(old));
+  release_later(std::move(files));
+}
+
+void release_kept() {
+  std::vector<std::shared_ptr<FastaStore>> old;
+  {
+    std::lock_guard<std::mutex> lk(g_kept_mu);
+    old.swap(g_kept);
+  }
+  old.clear();
 }
 
 }  // namespace wfmash_host

@@ -62,6 +62,10 @@ class FastaStore {
   // index of `name`, -1 if absent
   int find(const std::string& name) const { auto it = index_.find(name); return it == index_.end() ? -1 : it->second; }
   bool indexed() const { return fd_ >= 0; }
+  // is the file (and its .fai) still the one this store was opened on?  (device, inode, size, modification time)
+  bool same_file() const;
+  // bytes of whole sequences held in memory right now
+  int64_t resident_bytes() const;
 
  private:
   struct FaiEntry { int64_t offset, line_bases, line_width; };
@@ -75,6 +79,9 @@ class FastaStore {
   void load_block(int i, int helpers) const;
   struct Block { char* base = nullptr; size_t map_bytes = 0; char* p = nullptr; };  // an anonymous mapping; p: 2 MB aligned
 
+  struct FileId { uint64_t dev = 0, ino = 0; int64_t size = -1, mtime_ns = 0; bool operator==(const FileId& o) const { return dev == o.dev && ino == o.ino && size == o.size && mtime_ns == o.mtime_ns; } };
+  static FileId file_id(const std::string& path);
+  FileId id_, id_fai_;
   std::string path_;
   std::vector<std::string> names_;
   std::vector<int64_t> lens_;
@@ -95,5 +102,14 @@ class FastaStore {
 // files one after the other (main.cpp:72-128 then computeMap.hpp:147-230), and a whole-sequence load of a pangenome is
 // gigabytes -- whoever spans both (wfmh_map_multi) keeps the pointers, and the second one finds the sequences loaded.
 std::shared_ptr<FastaStore> open_shared(const std::string& path);
+// Drops the pointers on a thread of its own (WFM_FASTA_RELEASE_LATER=0: here and now): handing a few gigabytes of pages
+// back to the system takes a tenth of a second that the caller need not wait for.
+void release_later(std::vector<std::shared_ptr<FastaStore>> files);
+// The stores of the call that just ended stay open until the next call hands in its own (or release_kept()): the align
+// phase that follows a map phase asks for the same files, and finds the sequences loaded (open_shared; a file that was
+// rewritten in between is opened afresh).  Stores holding more than WFM_FASTA_KEEP_GB (32) are let go at once,
+// WFM_FASTA_KEEP=0 keeps nothing.
+void keep_until_next(std::vector<std::shared_ptr<FastaStore>> files);
+void release_kept();
 
 }  // namespace wfmash_host
