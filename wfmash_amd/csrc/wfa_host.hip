@@ -49,28 +49,31 @@ template <typename T>
 struct DevBuf {
   T* p = nullptr;
   size_t cap = 0;  // elements
+  // The blocks come from, and go back to, the per-device block cache (dev_cache.h), never straight to the driver: memory a
+  // process has freed is wiped before it is handed out again, and an allocation that lands on it waits for that -- 40 ms per GB
+  // as a rule, 1.3 - 1.8 s at worst (profiles/r4_map_host.md).  An arena that is outgrown waits in the cache (its size class
+  // serves the next handle, or the next batch's sequences); at most as much again as the final arena is held that way.
   int ensure(size_t n) {
     if (n <= cap) return 0;
     const size_t old_cap = cap;
-    if (p) (void)hipFree(p);
+    if (p) wfm_dfree(p);  // (waits for the device, as hipFree did)
     p = nullptr; cap = 0;
     // (an arena that has to grow doubles at least: every regrowth is a fresh allocation, 30 - 70 ms per GB on this driver, and a
     // divergent batch -- C1 -- used to walk its ring arena up in five steps of 3.5 .. 12 GB)
     size_t want = std::max(n + n / 8 + 64, old_cap * 2);
     const auto t0 = std::chrono::steady_clock::now();
-    if (hipMalloc((void**)&p, want * sizeof(T)) != hipSuccess) {
+    if (wfm_dmalloc((void**)&p, want * sizeof(T)) != hipSuccess) {  // (the cache has given everything back and tried again by then)
       (void)hipGetLastError();  // the failure must not surface after a later launch
-      wfm_dcache_trim();        // blocks the map path's cache holds back are the first thing to give up
-      if (hipMalloc((void**)&p, n * sizeof(T)) != hipSuccess) { (void)hipGetLastError(); p = nullptr; return -1; }
+      if (wfm_dmalloc((void**)&p, n * sizeof(T)) != hipSuccess) { (void)hipGetLastError(); p = nullptr; return -1; }
       want = n;
     }
     cap = want;
     if (want * sizeof(T) >= ((size_t)256 << 20) && getenv("WFM_DEBUG"))
-      fprintf(stderr, "[wfm] hipMalloc of %.2f GB took %.1f ms\n", (double)(want * sizeof(T)) / 1073741824.0,
+      fprintf(stderr, "[wfm] device block of %.2f GB took %.1f ms\n", (double)(want * sizeof(T)) / 1073741824.0,
               std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
     return 0;
   }
-  void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+  void release() { if (p) wfm_dfree(p); p = nullptr; cap = 0; }
 };
 
 struct ProbMeta {
@@ -1538,18 +1541,15 @@ int wfm_upload_sequences(wfm_handle_t* h, const wfm_problem_t* problems, size_t 
     fill(0, n / (size_t)nt);
     for (auto& t : th) t.join();
   }
-  if (hipMalloc((void**)&S->d_seq, bytes) != hipSuccess) {
-    (void)hipGetLastError();
-    wfm_dcache_trim();  // what the map path's block cache holds back goes first
-    if (hipMalloc((void**)&S->d_seq, bytes) != hipSuccess) { (void)hipGetLastError(); delete S; h->err = "out of device memory (sequences)"; return WFM_E_NOMEM; }
-  }
+  // (from the block cache, like the arenas: a batch's sequences are about as long as the last batch's, and the block it freed serves)
+  if (wfm_dmalloc((void**)&S->d_seq, bytes) != hipSuccess) { (void)hipGetLastError(); delete S; h->err = "out of device memory (sequences)"; return WFM_E_NOMEM; }
   S->bytes = bytes;
   S->rle_total = rle;
   // the 2-bit mirror the tile kernel extends on (wfa_tile2.hip): a quarter of a byte per base, made on the device
   const int64_t pk_words = ((int64_t)bytes + 15) / 16;
-  if (hipMalloc((void**)&S->d_pk, (size_t)(pk_words + PK_PAD_WORDS) * 4) != hipSuccess) {
+  if (wfm_dmalloc((void**)&S->d_pk, (size_t)(pk_words + PK_PAD_WORDS) * 4) != hipSuccess) {
     (void)hipGetLastError();
-    (void)hipFree(S->d_seq); delete S; h->err = "out of device memory (packed sequences)"; return WFM_E_NOMEM;
+    wfm_dfree(S->d_seq); delete S; h->err = "out of device memory (packed sequences)"; return WFM_E_NOMEM;
   }
   hipError_t e = hipMemcpyAsync(S->d_seq, host, fwd_bytes, hipMemcpyHostToDevice, h->stream);
   if (e == hipSuccess) e = hipMemsetAsync(S->d_seq + bytes - SEQ_PAD, 0, SEQ_PAD, h->stream);
@@ -1588,7 +1588,7 @@ int wfm_upload_sequences(wfm_handle_t* h, const wfm_problem_t* problems, size_t 
       }
     }
   }
-  if (e != hipSuccess) { (void)hipFree(S->d_seq); (void)hipFree(S->d_pk); delete S; h->err = hipGetErrorString(e); return WFM_E_HIP; }
+  if (e != hipSuccess) { wfm_dfree(S->d_seq); wfm_dfree(S->d_pk); delete S; h->err = hipGetErrorString(e); return WFM_E_HIP; }
   *out = S;
   return WFM_OK;
 }
@@ -1596,8 +1596,10 @@ int wfm_upload_sequences(wfm_handle_t* h, const wfm_problem_t* problems, size_t 
 void wfm_free_sequences(wfm_handle_t* h, wfm_seqset_t* s) {
   if (!s) return;
   if (h) (void)hipSetDevice(h->device);
-  if (s->d_seq) (void)hipFree(s->d_seq);
-  if (s->d_pk) (void)hipFree(s->d_pk);
+  // back to the block cache; one wait for the device serves both (hipFree waited once per block)
+  if (s->d_seq || s->d_pk) (void)hipDeviceSynchronize();
+  if (s->d_seq) wfm_dfree_nosync(s->d_seq);
+  if (s->d_pk) wfm_dfree_nosync(s->d_pk);
   delete s;
 }
 
