@@ -290,6 +290,18 @@ void par_ranges(size_t n, F fn) {  // fn(lo, hi) over a partition of [0, n)
   for (auto& th : pool) th.join();
 }
 
+// the same partition with the part's number: fn(t, lo, hi); returns the number of parts
+template <class F>
+size_t par_parts(size_t n, F fn) {
+  const size_t T = n >= ((size_t)1 << 17) ? (size_t)std::max(1, std::min<int>(tl_filter_threads, 32)) : 1;
+  if (T <= 1) { fn((size_t)0, (size_t)0, n); return 1; }
+  std::vector<std::thread> pool;
+  for (size_t t = 1; t < T; ++t) pool.emplace_back(fn, t, n * t / T, n * (t + 1) / T);
+  fn((size_t)0, (size_t)0, n / T);
+  for (auto& th : pool) th.join();
+  return T;
+}
+
 template <typename T>
 std::vector<T> permuted(const std::vector<T>& in, const std::vector<uint32_t>& p) {
   std::vector<T> out(in.size());
@@ -345,8 +357,35 @@ std::vector<offset_t> chain_mappings(MappingResultsVector_t& readMappings, int m
       std::vector<uint32_t> q(n);
       uint32_t max_ref = 0;
       bool two_strands = true;
-      for (size_t i = 0; i < n; ++i) { max_ref = std::max(max_ref, key[i].ref); two_strands &= key[i].strand == 1 || key[i].strand == -1; }
-      if (two_strands && (uint64_t)max_ref * 2 + 2 <= ((uint64_t)1 << 22)) {
+      {
+        std::vector<uint32_t> part_max(33, 0);
+        std::vector<char> part_two(33, 1);
+        par_parts(n, [&](size_t t, size_t lo, size_t hi) {
+          uint32_t m = 0; bool two = true;
+          for (size_t i = lo; i < hi; ++i) { m = std::max(m, key[i].ref); two &= key[i].strand == 1 || key[i].strand == -1; }
+          part_max[t] = m; part_two[t] = two;
+        });
+        for (size_t t = 0; t < part_max.size(); ++t) { max_ref = std::max(max_ref, part_max[t]); two_strands &= part_two[t] != 0; }
+      }
+      if (two_strands && (uint64_t)max_ref * 2 + 2 <= ((uint64_t)1 << 16)) {
+        // a stable counting pass, every part of the array with a histogram of its own: group g's members of part t go behind
+        // those of the parts before it -- the order a single pass over the array leaves
+        const size_t G = (size_t)max_ref * 2 + 2;
+        auto slot = [](const Key& k) { return (size_t)k.ref * 2 + (k.strand > 0 ? 1 : 0); };
+        std::vector<std::vector<size_t>> hist(33);
+        const size_t T = par_parts(n, [&](size_t t, size_t lo, size_t hi) {
+          std::vector<size_t>& hgm = hist[t];
+          hgm.assign(G, 0);
+          for (size_t i = lo; i < hi; ++i) ++hgm[slot(key[i])];
+        });
+        size_t at = 0;
+        for (size_t g = 0; g < G; ++g)
+          for (size_t t = 0; t < T; ++t) { const size_t c = hist[t][g]; hist[t][g] = at; at += c; }
+        par_parts(n, [&](size_t t, size_t lo, size_t hi) {
+          std::vector<size_t>& pos = hist[t];
+          for (size_t i = lo; i < hi; ++i) q[pos[slot(key[i])]++] = (uint32_t)i;
+        });
+      } else if (two_strands && (uint64_t)max_ref * 2 + 2 <= ((uint64_t)1 << 22)) {
         std::vector<size_t> start((size_t)max_ref * 2 + 3, 0);
         auto slot = [](const Key& k) { return (size_t)k.ref * 2 + (k.strand > 0 ? 1 : 0); };
         for (size_t i = 0; i < n; ++i) ++start[slot(key[i]) + 1];
@@ -366,8 +405,14 @@ std::vector<offset_t> chain_mappings(MappingResultsVector_t& readMappings, int m
     if (!sorted_fast) std::sort(p.begin(), p.end(), less);
   }
   tt[ti++] = tnow();
-  readMappings = permuted(readMappings, p);
-  chainOf = permuted(chainOf, p);
+  // (one scratch array serves both permutations of the call: the second one writes into pages the first has left behind)
+  MappingResultsVector_t scratch(n);
+  auto permute_mappings = [&]() {
+    par_ranges(n, [&](size_t lo, size_t hi) { for (size_t i = lo; i < hi; ++i) scratch[i] = readMappings[p[i]]; });
+    readMappings.swap(scratch);
+  };
+  permute_mappings();
+  par_ranges(n, [&](size_t lo, size_t hi) { for (size_t i = lo; i < hi; ++i) chainOf[i] = (offset_t)p[i]; });  // chainOf was 0 .. n-1: permuted, it is p
   tt[ti++] = tnow();
 
   // Within one (target, strand) run every mapping links to its closest admissible successor.  The runs do not see each
@@ -413,9 +458,10 @@ std::vector<offset_t> chain_mappings(MappingResultsVector_t& readMappings, int m
   }
   tt[ti++] = tnow();
   ChainSets sets(n);
-  for (int pass = 0; pass < 2; ++pass)  // the loop's own unions, then the closing pass over everything (a repeat: no change)
-    for (size_t i = 0; i < n; ++i)
-      if (linkScore[i] != std::numeric_limits<double>::max()) sets.unite(chainOf[i], linkFrom[i]);
+  // (the reference unites inside the loop and once more over everything afterwards: the second round finds every pair in one
+  // set already and changes no representative, so it is not repeated here)
+  for (size_t i = 0; i < n; ++i)
+    if (linkScore[i] != std::numeric_limits<double>::max()) sets.unite(chainOf[i], linkFrom[i]);
   for (size_t i = 0; i < n; ++i) chainOf[i] = (offset_t)sets.find(chainOf[i]);
   tt[ti++] = tnow();
 
@@ -445,7 +491,7 @@ std::vector<offset_t> chain_mappings(MappingResultsVector_t& readMappings, int m
     if (!sorted_fast) std::sort(p.begin(), p.end(), less);
   }
   tt[ti++] = tnow();
-  readMappings = permuted(readMappings, p);
+  permute_mappings();
   chainOf = permuted(chainOf, p);
   tt[ti++] = tnow();
   if (tdbg && n >= 100000)
@@ -650,19 +696,29 @@ FilteredMappingsResult filterSubsetMappings(MappingResultsVector_t& mappings, co
                                             offset_t queryLen) {
   FilteredMappingsResult result;
   if (mappings.empty()) return result;
+  static const bool tdbg = getenv("WFM_FILTER_TIMES") != nullptr;
+  auto tnow = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const size_t n_in = mappings.size();
+  double tt[8] = {0}; int ti = 0; tt[ti++] = tnow();
   MappingsWithChains chained = MappingFilterUtils::mergeMappingsInRangeWithChains(mappings, (int)param.chain_gap, param);
+  tt[ti++] = tnow();
   MappingResultsVector_t& merged = chained.mappings;
   if (param.mergeMappings && param.split) {
     MappingFilterUtils::filterWeakMappings(merged, (int64_t)std::floor(param.block_length / param.windowLength), param, idManager, queryLen);
+    tt[ti++] = tnow();
     if (param.filterMode == filter::MAP || param.filterMode == filter::ONETOONE) {
       MappingResultsVector_t kept;
       // -n inf: uint32 max - 1 lands in an int as -2 (SURVEY 8a parity hazards)
       MappingFilterUtils::filterByGroup(merged, kept, param.numMappingsForSegment - 1, false, idManager, param);
       merged = std::move(kept);
     }
+    tt[ti++] = tnow();
     if (param.filterLengthMismatches) MappingFilterUtils::filterFalseHighIdentity(merged, param);
     MappingFilterUtils::sparsifyMappings(merged, param);
     MappingFilterUtils::filterByScaffolds(merged, param, idManager);
+    tt[ti++] = tnow();
+    if (tdbg && n_in >= 100000)
+      fprintf(stderr, "[filter] filterSubsetMappings n=%zu: chains + merge %.1f, weak %.1f, sweep %.1f, scaffolds %.1f ms\n", n_in, tt[1] - tt[0], tt[2] - tt[1], tt[3] - tt[2], tt[4] - tt[3]);
   } else {
     if (param.filterMode == filter::MAP || param.filterMode == filter::ONETOONE) {
       MappingResultsVector_t kept;
