@@ -187,8 +187,10 @@ int  wfm_align_resident(wfm_handle_t* h, const wfm_penalties_t* pen, wfm_seqset_
 int  wfm_align_resident_rle(wfm_handle_t* h, const wfm_penalties_t* pen, wfm_seqset_t* s,
                             wfm_result_t* out, uint32_t** runs, size_t* n_runs_total);
 
-/* Device blocks of the map path are kept in a per-device cache between calls (a first hipMalloc of a gigabyte costs 30 - 40 ms
- * on this driver, a hipFree of gigabytes stalls the next allocation; wfmash_amd/csrc/dev_cache.h).  This hands every cached
+/* Device blocks of both paths -- the map path's work buffers, the align path's arenas and a batch's sequence buffers, also
+ * those of a handle that has been destroyed -- are kept in a per-device cache between calls (a first hipMalloc of a gigabyte
+ * costs 30 - 40 ms on this driver, a hipFree of gigabytes stalls a later allocation for up to seconds while the driver wipes
+ * the memory; wfmash_amd/csrc/dev_cache.h, profiles/r4_map_host.md).  This hands every cached
  * block back to the driver and returns the bytes released; WFM_DEV_CACHE_GB bounds what the cache may hold per device
  * (default: a third of the device's memory -- 96 GB of an MI355X's 288; only the device that passes its bound is trimmed). */
 size_t wfm_trim_device_cache(void);

@@ -1,4 +1,5 @@
-// dev_cache.h -- device blocks of the map path come from, and go back to, a per-device cache instead of hipMalloc / hipFree.
+// dev_cache.h -- device blocks of the map path (and, since round 4, the arenas and sequence buffers of the align path) come from, and go
+// back to, a per-device cache instead of hipMalloc / hipFree.
 //
 // Why: on this driver a hipMalloc of memory the process has not had mapped before costs 30 - 40 ms per GB and a hipFree of
 // gigabytes makes the next allocation wait for the scrubbing (profiles/r3_cold_start.md); the map path works on whole
