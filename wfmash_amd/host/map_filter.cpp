@@ -5,8 +5,10 @@
 #include <thread>
 #include <atomic>
 #include <cmath>
+#include <exception>
 #include <limits>
 #include <map>
+#include <mutex>
 #include <numeric>
 #include <set>
 #include <tuple>
@@ -739,15 +741,27 @@ FilteredMappingsResult filterSubsetMappings(MappingResultsVector_t& mappings, co
 // MappingOutput (mappingOutput.hpp)
 // ---------------------------------------------------------------------------------------------
 void MappingOutput::mappingBoundarySanityCheck(offset_t queryLen, MappingResultsVector_t& readMappings, const SequenceIdManager& idManager) {
-  for (auto& e : readMappings) {
-    const offset_t refLen = idManager.getSequenceLength(e.refSeqId);
-    if (e.refStartPos >= refLen) e.refStartPos = refLen - 1;
-    if (e.refEndPos() < e.refStartPos) e.blockLength = 0;
-    if (e.refEndPos() >= refLen) e.blockLength = refLen - 1 - e.refStartPos;
-    if (e.queryStartPos >= queryLen) e.queryStartPos = queryLen;
-    if (e.queryEndPos() < e.queryStartPos) e.blockLength = 0;
-    if (e.queryEndPos() >= queryLen) e.blockLength = queryLen - e.queryStartPos;
-  }
+  // (every mapping on its own: a chromosome-sized query's 1.7 M of them are split over the threads this thread may use)
+  std::exception_ptr failed;  // (an id the manager does not know throws: it must reach the caller, not end a helper thread)
+  std::mutex failed_mu;
+  par_ranges(readMappings.size(), [&](size_t lo, size_t hi) {
+   try {
+    for (size_t i = lo; i < hi; ++i) {
+      MappingResult& e = readMappings[i];
+      const offset_t refLen = idManager.getSequenceLength(e.refSeqId);
+      if (e.refStartPos >= refLen) e.refStartPos = refLen - 1;
+      if (e.refEndPos() < e.refStartPos) e.blockLength = 0;
+      if (e.refEndPos() >= refLen) e.blockLength = refLen - 1 - e.refStartPos;
+      if (e.queryStartPos >= queryLen) e.queryStartPos = queryLen;
+      if (e.queryEndPos() < e.queryStartPos) e.blockLength = 0;
+      if (e.queryEndPos() >= queryLen) e.blockLength = queryLen - e.queryStartPos;
+    }
+   } catch (...) {
+    std::lock_guard<std::mutex> lk(failed_mu);
+    if (!failed) failed = std::current_exception();
+   }
+  });
+  if (failed) std::rethrow_exception(failed);
 }
 
 void MappingOutput::reportReadMappings(MappingResultsVector_t& readMappings, const ChainInfoVector_t& chainInfo, const std::string& queryName,
