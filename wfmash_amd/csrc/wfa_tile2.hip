@@ -141,13 +141,22 @@ __device__ __forceinline__ int pk_wave_tail(const PkSrc& S, unsigned oP, unsigne
 // 16 bases of every cell at once from the LDS windows (an offset that has left them is clamped into them for the probe and
 // done again from the global mirror; cells that hold nothing probe whatever their garbage offset clamps to), then
 // 64 more for the cells whose 16 agreed, then the wave-cooperative tail.  Every lane of the wave makes the call.
+// (MASKED: the probe's window words are addressed by the offset's bits 4 .. 14 instead of by the clamped offset -- one instruction less per
+// sequence; an offset beyond the window probes a word it does not mean, and is probed again from the global mirror as before.  maxn of a cell
+// that holds nothing may be anything: every use of it is behind `live`.)
+__device__ __forceinline__ uint32_t pk16_win(lds_words w, unsigned o) {
+  typedef const __attribute__((address_space(3))) char* lds_bytes;
+  const lds_words q = (lds_words)((lds_bytes)w + ((o >> 2) & (unsigned)((PK_WIN_DW - 1) * 4)));
+  return alignbit32(q[1], q[0], o << 1);
+}
+template <bool MASKED = false>
 __device__ __forceinline__ void pk_extend2(const PkSrc& SRC, const int (&m)[2], const unsigned (&oP)[2], const unsigned (&oT)[2], const int (&maxn)[2], int (&ext)[2]) {
   bool more[2], outw = false;
 #pragma unroll
   for (int c = 0; c < 2; ++c) {
     const bool live = m[c] >= 0;
     const unsigned qa = min(oP[c], (unsigned)(PK_WIN_BASES - 1)), qb = min(oT[c], (unsigned)(PK_WIN_BASES - 1));
-    const uint32_t x = pk16(SRC.lP, qa) ^ pk16(SRC.lT, qb);
+    const uint32_t x = MASKED ? (pk16_win(SRC.lP, oP[c]) ^ pk16_win(SRC.lT, oT[c])) : (pk16(SRC.lP, qa) ^ pk16(SRC.lT, qb));
     const unsigned n16 = first_diff16(x);
     ext[c] = min((int)n16, maxn[c]);
     more[c] = live && n16 >= 16u && maxn[c] > 16;
@@ -227,7 +236,16 @@ void launch_seq_pack(const uint8_t* seq, uint32_t* pk, int64_t nwords, int64_t n
 // ---------------------------------------------------------------------------
 // the tile kernel
 // ---------------------------------------------------------------------------
-template <int NTMAX, bool P2>
+// FAST (round 5, the default; WFM_TILE_FAST=0 runs the round-4 form for A/B): what profiles/r4_sq.json's 152 vector + 56 scalar instructions per
+// wave and step could lose without touching a result --
+//  * the five "is this offset inside the problem" selects of a cell are only made by a wave in which some cell's largest source has left the
+//    problem (h > tl or v > pl: the far edges of the matrix, which the two directions of a BiWFA job never reach together); otherwise every
+//    source is either inside or NULL already.  A NULL then drifts -- NULL + 1 + ... -- instead of being set back to WF_NULL at every step:
+//    every reader of a wavefront takes "negative" for NULL (max(), >= 0, o0 + o1 >= tl), and -2^30 + 17 per step stays negative for 6 * 10^7 steps;
+//  * the per-step maximum of the antidiagonals goes to a slot of the wave's own (plain store) instead of through an LDS atomic (a scalar loop);
+//  * the mailbox's buffer index is the step's number mod 3 at compile time (adjacent steps never share a buffer, two steps apart may);
+//  * the probe's window words are addressed by masking (pk_extend2<true>), dead cells keep what the arithmetic leaves them with.
+template <int NTMAX, bool P2, bool FAST>
 __global__ __launch_bounds__(NTMAX) void wfa_tile2_kernel(const uint32_t* __restrict__ pk, int32_t* __restrict__ ring_arena,
                                                         const TileJob* __restrict__ jobs, const TileTask* __restrict__ tasks,
                                                         int32_t* __restrict__ mak_out, int T, int32_t* __restrict__ p2_arena) {
@@ -236,10 +254,10 @@ __global__ __launch_bounds__(NTMAX) void wfa_tile2_kernel(const uint32_t* __rest
   // mailbox of the wave edges: [parity][slot][side][value].  Side 0 of slot w holds what lane 63 of wave w - 1 hands to lane 0 of wave w, side 1 of
   // slot w what lane 0 of wave w hands to lane 63 of wave w - 1; slot 0's side 0 and the slot behind the last wave are never written and stay
   // NULL, so the edge lanes of a tile read their mailbox like all others and the wave shifts need no NULL to fall back on
-  __shared__ int s_edge[2][WAVE1 ? 1 : 17][2][4];
+  __shared__ __attribute__((aligned(16))) int s_edge[FAST ? 3 : 2][WAVE1 ? 1 : 17][2][4];
   __shared__ __attribute__((aligned(16))) uint32_t s_winP[PK_WIN_DW + PK_SLACK_DW], s_winT[PK_WIN_DW + PK_SLACK_DW];
   __shared__ int s_wlo[2];
-  extern __shared__ __attribute__((aligned(16))) int s_makr[];  // [T + 1]
+  extern __shared__ __attribute__((aligned(16))) int s_makr[];  // [T + 1]; FAST: [waves][T + 1], a row per wave
   TileTask tk = tasks[blockIdx.x];
   const TileJob J = jobs[tk.job];
   if (!J.active) return;
@@ -305,7 +323,8 @@ __global__ __launch_bounds__(NTMAX) void wfa_tile2_kernel(const uint32_t* __rest
       D2h[c] = ok ? rin[((int64_t)(C_D2 * RING + (s0 & RMASK))) * width + k] : WF_NULL;
     }
   }
-  for (int t = tid; t <= T; t += NT) s_makr[t] = 0;
+  const int MKS = T + 1;  // stride of a wave's row of s_makr (FAST)
+  for (int t = tid; t < (FAST && !WAVE1 ? nw * MKS : MKS); t += NT) s_makr[t] = 0;
   // ---- per-cell constants
   unsigned hmaxu[C];  // largest offset inside the problem on this diagonal: min(tl, pl + k)
   int s_last[C];      // the last score at which the cell is inside its row (columns outside [-pl, tl]: never)
@@ -371,7 +390,7 @@ __global__ __launch_bounds__(NTMAX) void wfa_tile2_kernel(const uint32_t* __rest
     // rows this step reads from its class: [0] = s-5, [1] = s-10, [4] = s-25
     int lM10, lM25, lI1, lI2, rM10, rM25, rD1, rD2;
     if (!WAVE1) {
-      const int par = t & 1;
+      const int par = FAST ? jj % 3 : (t & 1);
       // publish the wave-edge history values needed by the neighbouring waves in this step
       if (lane == 63) { int* e = s_edge[par][wv + 1][0]; e[0] = Mh[C - 1][cl][1]; e[1] = Mh[C - 1][cl][4]; e[2] = I1h[C - 1][E1 - 1]; e[3] = I2h[C - 1]; }
       if (lane == 0)  { int* e = s_edge[par][wv][1];     e[0] = Mh[0][cl][1];     e[1] = Mh[0][cl][4];     e[2] = D1h[0][E1 - 1];     e[3] = D2h[0]; }
@@ -388,7 +407,7 @@ __global__ __launch_bounds__(NTMAX) void wfa_tile2_kernel(const uint32_t* __rest
       rM10 = from_next_lane(Mh[0][cl][1]); rM25 = from_next_lane(Mh[0][cl][4]);
       rD1 = from_next_lane(D1h[0][E1 - 1]); rD2 = from_next_lane(D2h[0]);
     }
-    int nM[C], nI1[C], nI2[C], nD1[C], nD2[C];
+    int nM[C], nI1[C], nI2[C], nD1[C], nD2[C], nMis[C];
 #pragma unroll
     for (int c = 0; c < C; ++c) {
       const int a10 = c == 0 ? lM10 : Mh[c - 1][cl][1], b10 = c == C - 1 ? rM10 : Mh[c + 1][cl][1];
@@ -399,16 +418,37 @@ __global__ __launch_bounds__(NTMAX) void wfa_tile2_kernel(const uint32_t* __rest
       // in-bounds <=> 0 <= offset <= min(tl, pl + k)   (h <= tl and h - k <= pl)
       const unsigned hm = hmaxu[c];
       int ins1 = max(a10, i1) + 1, ins2 = max(a25, i2) + 1, del1 = max(b10, d1), del2 = max(b25, d2), mis = mx + 1;
-      ins1 = (unsigned)ins1 <= hm ? ins1 : WF_NULL;
-      ins2 = (unsigned)ins2 <= hm ? ins2 : WF_NULL;
-      del1 = (unsigned)del1 <= hm ? del1 : WF_NULL;
-      del2 = (unsigned)del2 <= hm ? del2 : WF_NULL;
-      mis = (unsigned)mis <= hm ? mis : WF_NULL;
-      nI1[c] = ins1; nI2[c] = ins2; nD1[c] = del1; nD2[c] = del2;
-      const int m = max(max(max(ins1, ins2), mis), max(del1, del2));
-      // a column outside [-pl, tl], or one the score bound has cut off at this score, holds no cell
-      nM[c] = s <= s_last[c] ? m : WF_NULL;
+      if (!FAST) {
+        ins1 = (unsigned)ins1 <= hm ? ins1 : WF_NULL;
+        ins2 = (unsigned)ins2 <= hm ? ins2 : WF_NULL;
+        del1 = (unsigned)del1 <= hm ? del1 : WF_NULL;
+        del2 = (unsigned)del2 <= hm ? del2 : WF_NULL;
+        mis = (unsigned)mis <= hm ? mis : WF_NULL;
+      }
+      nI1[c] = ins1; nI2[c] = ins2; nD1[c] = del1; nD2[c] = del2; nMis[c] = mis;
+      nM[c] = max(max(max(ins1, ins2), mis), max(del1, del2));
     }
+    if (FAST) {
+      // some cell of the wave whose largest source lies beyond the problem: the selects of the round-4 form, for the whole wave
+      bool over = false;
+#pragma unroll
+      for (int c = 0; c < C; ++c) over |= nM[c] > (int)hmaxu[c];
+      if (__any(over)) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+          const unsigned hm = hmaxu[c];
+          nI1[c] = (unsigned)nI1[c] <= hm ? nI1[c] : WF_NULL;
+          nI2[c] = (unsigned)nI2[c] <= hm ? nI2[c] : WF_NULL;
+          nD1[c] = (unsigned)nD1[c] <= hm ? nD1[c] : WF_NULL;
+          nD2[c] = (unsigned)nD2[c] <= hm ? nD2[c] : WF_NULL;
+          const int mis = (unsigned)nMis[c] <= hm ? nMis[c] : WF_NULL;
+          nM[c] = max(max(max(nI1[c], nI2[c]), mis), max(nD1[c], nD2[c]));
+        }
+      }
+    }
+    // a column outside [-pl, tl], or one the score bound has cut off at this score, holds no cell
+#pragma unroll
+    for (int c = 0; c < C; ++c) nM[c] = s <= s_last[c] ? nM[c] : WF_NULL;
     // ---- extension (pk_extend2): 16 bases of every cell at once from the LDS windows, longer runs in stages
     int ext[C], maxn[C];
     unsigned oP[C], oT[C];
@@ -416,16 +456,16 @@ __global__ __launch_bounds__(NTMAX) void wfa_tile2_kernel(const uint32_t* __rest
     for (int c = 0; c < C; ++c) {
       const int m = nM[c];
       oP[c] = (unsigned)(m + cP[c]); oT[c] = (unsigned)(m + dT);
-      maxn[c] = m >= 0 ? (int)hmaxu[c] - m : 0;
+      maxn[c] = (FAST || m >= 0) ? (int)hmaxu[c] - m : 0;
     }
-    pk_extend2(SRC, nM, oP, oT, maxn, ext);
+    pk_extend2<FAST>(SRC, nM, oP, oT, maxn, ext);
     int mak = 0;
 #pragma unroll
     for (int c = 0; c < C; ++c) {
       const int m = nM[c];
       const int me = m + ext[c];
       const bool live = m >= 0;
-      nM[c] = live ? me : WF_NULL;
+      nM[c] = (FAST || live) ? me : WF_NULL;  // (FAST: a cell that holds nothing probed at most 16 bases: NULL + 16 is as NULL as NULL)
       mak = max(mak, live ? 2 * me + negk[c] : 0);  // (cells outside the core: far below zero)
     }
     if (P2) {
@@ -467,7 +507,8 @@ __global__ __launch_bounds__(NTMAX) void wfa_tile2_kernel(const uint32_t* __rest
       I2h[c] = nI2[c]; D2h[c] = nD2[c];
     }
     mak = wave_max63(mak);
-    if (lane == 63 && mak > 0) {
+    if (FAST) { if (lane == 63) s_makr[(WAVE1 ? 0 : wv * MKS) + t] = mak; }
+    else if (lane == 63 && mak > 0) {
       if (WAVE1) s_makr[t] = mak;
       else atomicMax(&s_makr[t], mak);
     }
@@ -518,19 +559,37 @@ __global__ __launch_bounds__(NTMAX) void wfa_tile2_kernel(const uint32_t* __rest
   }
   __syncthreads();
   int32_t* mk = mak_out + ((int64_t)tk.job * 2 + dir) * T;
-  for (int t = 1 + tid; t <= T; t += NT) if (s_makr[t] > 0) atomicMax(&mk[t - 1], s_makr[t]);
+  for (int t = 1 + tid; t <= T; t += NT) {
+    int v = s_makr[t];
+    if (FAST && !WAVE1) for (int w = 1; w < nw; ++w) v = max(v, s_makr[w * MKS + t]);
+    if (v > 0) atomicMax(&mk[t - 1], v);
+  }
 }
 
+static bool tile_fast() {
+  static const bool on = !(getenv("WFM_TILE_FAST") && atoi(getenv("WFM_TILE_FAST")) == 0);
+  return on;
+}
 void launch_tile2(const uint32_t* pk, int32_t* ring, const TileJob* jobs, const TileTask* tasks, int32_t* mak, int ntasks, int threads, int T,
                   hipStream_t st) {
-  const size_t lds = (size_t)(T + 1) * 4;
-  if (threads <= 64) hipLaunchKernelGGL((wfa_tile2_kernel<64, false>), dim3(ntasks), dim3(64), lds, st, pk, ring, jobs, tasks, mak, T, (int32_t*)nullptr);
-  else hipLaunchKernelGGL((wfa_tile2_kernel<1024, false>), dim3(ntasks), dim3(threads), lds, st, pk, ring, jobs, tasks, mak, T, (int32_t*)nullptr);
+  const size_t lds1 = (size_t)(T + 1) * 4;
+  if (tile_fast()) {
+    if (threads <= 64) hipLaunchKernelGGL((wfa_tile2_kernel<64, false, true>), dim3(ntasks), dim3(64), lds1, st, pk, ring, jobs, tasks, mak, T, (int32_t*)nullptr);
+    else hipLaunchKernelGGL((wfa_tile2_kernel<1024, false, true>), dim3(ntasks), dim3(threads), lds1 * (size_t)(threads / 64), st, pk, ring, jobs, tasks, mak, T, (int32_t*)nullptr);
+  } else {
+    if (threads <= 64) hipLaunchKernelGGL((wfa_tile2_kernel<64, false, false>), dim3(ntasks), dim3(64), lds1, st, pk, ring, jobs, tasks, mak, T, (int32_t*)nullptr);
+    else hipLaunchKernelGGL((wfa_tile2_kernel<1024, false, false>), dim3(ntasks), dim3(threads), lds1, st, pk, ring, jobs, tasks, mak, T, (int32_t*)nullptr);
+  }
 }
 void launch_tile2_p2(const uint32_t* pk, int32_t* ring, const TileJob* jobs, const TileTask* tasks, int ntasks, int threads, int32_t* p2, hipStream_t st) {
-  const size_t lds = (size_t)(P2K + 1) * 4;
-  if (threads <= 64) hipLaunchKernelGGL((wfa_tile2_kernel<64, true>), dim3(ntasks), dim3(64), lds, st, pk, ring, jobs, tasks, (int32_t*)nullptr, P2K, p2);
-  else hipLaunchKernelGGL((wfa_tile2_kernel<1024, true>), dim3(ntasks), dim3(threads), lds, st, pk, ring, jobs, tasks, (int32_t*)nullptr, P2K, p2);
+  const size_t lds1 = (size_t)(P2K + 1) * 4;
+  if (tile_fast()) {
+    if (threads <= 64) hipLaunchKernelGGL((wfa_tile2_kernel<64, true, true>), dim3(ntasks), dim3(64), lds1, st, pk, ring, jobs, tasks, (int32_t*)nullptr, P2K, p2);
+    else hipLaunchKernelGGL((wfa_tile2_kernel<1024, true, true>), dim3(ntasks), dim3(threads), lds1 * (size_t)(threads / 64), st, pk, ring, jobs, tasks, (int32_t*)nullptr, P2K, p2);
+  } else {
+    if (threads <= 64) hipLaunchKernelGGL((wfa_tile2_kernel<64, true, false>), dim3(ntasks), dim3(64), lds1, st, pk, ring, jobs, tasks, (int32_t*)nullptr, P2K, p2);
+    else hipLaunchKernelGGL((wfa_tile2_kernel<1024, true, false>), dim3(ntasks), dim3(threads), lds1, st, pk, ring, jobs, tasks, (int32_t*)nullptr, P2K, p2);
+  }
 }
 
 // ---------------------------------------------------------------------------
