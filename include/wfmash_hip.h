@@ -187,6 +187,14 @@ int  wfm_align_resident(wfm_handle_t* h, const wfm_penalties_t* pen, wfm_seqset_
 int  wfm_align_resident_rle(wfm_handle_t* h, const wfm_penalties_t* pen, wfm_seqset_t* s,
                             wfm_result_t* out, uint32_t** runs, size_t* n_runs_total);
 
+/* How many other align calls the caller keeps in flight on this handle's DEVICE while a call on this handle runs (the align
+ * driver's workers, each on a handle of its own: wfmash_amd/host/aligner.cpp).  0, the default: none -- a batch is then cut
+ * into up to three parts that run side by side on streams of their own, because the levels of a batch of near-identical
+ * records are chains of short launches (a block of 100 scores takes its 0.13 ms however few workgroups it has) and the device
+ * is only filled by several chains at once; with other calls beside it a batch of hundreds of hinted records stays one part
+ * (three chains on a device are what its hardware queues run in parallel; gpurun_out/r5f_ab.log). */
+void wfm_set_concurrent_calls(wfm_handle_t* h, int other_calls);
+
 /* Device blocks of both paths -- the map path's work buffers, the align path's arenas and a batch's sequence buffers, also
  * those of a handle that has been destroyed -- are kept in a per-device cache between calls (a first hipMalloc of a gigabyte
  * costs 30 - 40 ms on this driver, a hipFree of gigabytes stalls a later allocation for up to seconds while the driver wipes

@@ -277,8 +277,9 @@ def test_tiled_kernels_agree_with_step_kernel(oracle, monkeypatch):
     got = {}
     for name, env in (("step", {"WFM_TILE": "0"}), ("lds", {"WFM_TILE_REG": "0"}), ("reg", {}),
                       ("reg_small", {"WFM_TILE_THREADS": "256", "WFM_TILE_T": "32"}),
-                      ("reg_bytes", {"WFM_TILE_V2": "0"}), ("reg_bytes_small", {"WFM_TILE_V2": "0", "WFM_TILE_THREADS": "256", "WFM_TILE_T": "32"})):
-        for k in ("WFM_TILE", "WFM_TILE_REG", "WFM_TILE_THREADS", "WFM_TILE_T", "WFM_TILE_V2"):
+                      ("reg_bytes", {"WFM_TILE_V2": "0"}), ("reg_bytes_small", {"WFM_TILE_V2": "0", "WFM_TILE_THREADS": "256", "WFM_TILE_T": "32"}),
+                      ("reg_r4form", {"WFM_TILE_FAST": "0"})):
+        for k in ("WFM_TILE", "WFM_TILE_REG", "WFM_TILE_THREADS", "WFM_TILE_T", "WFM_TILE_V2", "WFM_TILE_FAST"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -287,7 +288,7 @@ def test_tiled_kernels_agree_with_step_kernel(oracle, monkeypatch):
             got[name] = h.align(pairs)
         finally:
             h.close()
-    for name in ("lds", "reg", "reg_small", "reg_bytes", "reg_bytes_small"):
+    for name in ("lds", "reg", "reg_small", "reg_bytes", "reg_bytes_small", "reg_r4form"):
         bad = [i for i in range(len(pairs)) if got[name][i].ops != got["step"][i].ops]
         assert not bad, (name, bad)
     ops_cpu, scores, _, failed = oracle.align_batch_biwfa([p for p, _ in pairs[:4]], [q for _, q in pairs[:4]])

@@ -162,6 +162,7 @@ struct wfm_handle {
   std::vector<std::pair<float, float>> bp_iv, base_iv;  // the same for the step kernel and the base kernel
   std::string err;
   std::string name;
+  int other_calls = 0;         // wfm_set_concurrent_calls: align calls the caller keeps in flight on this device beside this handle's
   size_t mem_budget = 0;       // arena budget in force for the call at hand
   size_t mem_budget_full = 0;  // the handle's whole budget (40 % of free HBM at creation, or WFM_MEM_BUDGET_MB)
   wfm_stats_t stats{};
@@ -485,9 +486,9 @@ TileCfg tile_cfg(const wfm_penalties_t& pen, int scope) {
   c.reg = dflt && !(getenv("WFM_TILE_REG") && atoi(getenv("WFM_TILE_REG")) == 0);
   if (c.reg) {
     if (!getenv("WFM_TILE_THREADS")) c.threads = 512;
-    if (const char* e = getenv("WFM_TILE_C")) c.C = atoi(e) == 4 ? 4 : 2;
+    // (two diagonals per lane, always: the phase-2 rows, the single-tile sizing and the packed kernel are built for it.  The WFM_TILE_C=4
+    // switch of round 1 sized the tasks for four while those stages went on with two -- wrong results; it is gone)
     if (const char* e = getenv("WFM_TILE_CHUNK")) c.chunk = std::max(1, atoi(e));
-    if (c.C == 4) c.threads = std::min(c.threads, 256);
     c.Wt = c.threads * c.C;
     return c;
   }
@@ -1070,7 +1071,7 @@ int align_resident_impl(wfm_handle* h, const wfm_penalties_t* pen, wfm_seqset* S
         // tile kernel its bookkeeping all the way there
         j.sub = (nd.sub != SUB_NONE && (int64_t)std::abs(nd.tl - nd.pl) * 8 >= (int64_t)nd.sub) ? nd.sub : SUB_NONE;
         j.best0 = 0;
-        j.packed = (tile_v2 && (size_t)nd.prob < S->acgt.size() && S->acgt[(size_t)nd.prob]) ? 1 : 0;
+        j.packed = (tile_v2 && tcfg.reg && tcfg.C == 2 && (size_t)nd.prob < S->acgt.size() && S->acgt[(size_t)nd.prob]) ? 1 : 0;
         band_jobs += band > 0;
         if (tile_it) { tiled.push_back((int)jobs.size()); ring2.push_back((int64_t)(ring_elems + need / 2)); }
         node_of.push_back((int32_t)i);
@@ -1456,6 +1457,8 @@ void wfm_destroy(wfm_handle_t* h) {
 
 const char* wfm_last_error(const wfm_handle_t* h) { return h ? h->err.c_str() : "null handle"; }
 
+void wfm_set_concurrent_calls(wfm_handle_t* h, int other_calls) { if (h) h->other_calls = other_calls > 0 ? other_calls : 0; }
+
 int wfm_device_name(const wfm_handle_t* h, char* buf, size_t buflen) {
   if (!h || !buf || !buflen) return WFM_E_ARG;
   snprintf(buf, buflen, "%s", h->name.c_str());
@@ -1699,7 +1702,10 @@ int align_resident_any(wfm_handle_t* h, const wfm_penalties_t* pen, wfm_seqset_t
   if (!getenv("WFM_STREAMS") && n >= 512) {
     size_t hinted = 0, biwfa = 0;  // (patch calls -- ends-free problems only -- stay one part)
     for (size_t i = 0; i < n; ++i) { biwfa += s->meta[i].mode == WFM_MODE_END2END_BIWFA; hinted += s->meta[i].hint > 0; }
-    if (biwfa == 0 || hinted * 2 >= biwfa) parts = 1;
+    // ... and only then: a batch that has the device to itself (a mapping file of one batch: LPA all-vs-all, a scaled pangenome rank) is a
+    // chain of short launches per level and chunk, and three such chains side by side took its device time from 80 to 58 ms (C2) and from
+    // 66 to 49 ms (scaled C4 rank) -- gpurun_out/r5b_ab.log, r5f_ab.log.  Patch calls are chains as well (budget 256 -> 1020 -> the rest).
+    if (h->other_calls > 0 && (biwfa == 0 || hinted * 2 >= biwfa)) parts = 1;
   }
   if (!getenv("WFM_STREAMS") && parts > 2) {
     // a batch whose full rings would not fit the budget -- thousands of long records, which then run on narrow

@@ -566,9 +566,9 @@ __global__ __launch_bounds__(NTMAX) void wfa_tile2_kernel(const uint32_t* __rest
   }
 }
 
-static bool tile_fast() {
-  static const bool on = !(getenv("WFM_TILE_FAST") && atoi(getenv("WFM_TILE_FAST")) == 0);
-  return on;
+static bool tile_fast() {  // (read per launch: the tests switch forms inside one process)
+  const char* e = getenv("WFM_TILE_FAST");
+  return !(e && atoi(e) == 0);
 }
 void launch_tile2(const uint32_t* pk, int32_t* ring, const TileJob* jobs, const TileTask* tasks, int32_t* mak, int ntasks, int threads, int T,
                   hipStream_t st) {

@@ -363,6 +363,9 @@ Summary Aligner::compute() {
   std::map<uint64_t, std::string> pending;
   std::string first_error;
   std::atomic<bool> failed{false};
+  bool more_rows = true;  // (under read_mu) rows are left behind the batch handed out last
+  std::vector<std::atomic<int>> in_flight(ngpu);  // batches on the device right now, per device
+  for (auto& a : in_flight) a.store(0);
   auto read_batch = [&](std::vector<std::string>& batch) -> int64_t {  // the batch's number, or -1 at the end
     std::lock_guard<std::mutex> lk(read_mu);
     batch.clear();
@@ -374,6 +377,7 @@ Summary Aligner::compute() {
       bytes += line.size() + 1;
       batch.push_back(std::move(line));
     }
+    more_rows = !batch.empty() && in.peek() != std::char_traits<char>::eof();
     return batch.empty() ? -1 : (int64_t)next_seq++;
   };
   auto write_batch = [&](uint64_t seq, std::string&& text) {
@@ -427,6 +431,13 @@ Summary Aligner::compute() {
       for (int64_t seq; !failed.load() && (seq = read_batch(batch)) >= 0;) {
         first_taken[wk % ngpu].store(1);
         const double at0 = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        // a batch that has its device to itself -- none beside it, none to come -- is cut into parts by the device layer
+        // (wfm_set_concurrent_calls: its levels are chains of short launches, and one chain does not fill a device)
+        bool more;
+        { std::lock_guard<std::mutex> lk(read_mu); more = more_rows; }
+        const int beside = in_flight[wk % ngpu].fetch_add(1);
+        wfm_set_concurrent_calls(use[wk], beside + (more && per_gpu > 1 ? 1 : 0));
+        struct Leave { std::atomic<int>& a; ~Leave() { a.fetch_sub(1); } } leave{in_flight[wk % ngpu]};
         std::string text = align_batch(use[wk], batch, threads_each, part[wk]);
         const double at1 = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         write_batch((uint64_t)seq, std::move(text));
