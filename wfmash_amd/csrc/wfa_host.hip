@@ -1198,9 +1198,12 @@ int align_resident_impl(wfm_handle* h, const wfm_penalties_t* pen, wfm_seqset* S
             // ran out of its narrow ring, or past the caller's guess of its score: once more, at the end of this level, on
             // a full ring and without the guess
             Node again = nd; again.noband = 1; again.sub = SUB_NONE; again.hinted = 0;
-            // (a root that ran past its guess joins the next level's jobs instead of holding this level up on its own:
-            // nodes are independent, only the gather at the end waits for all of them)
-            if (guessed) next_bp.push_back(again); else bp_nodes.push_back(again);
+            // (it joins the next level's jobs instead of holding this level up on its own: nodes are independent, only the gather at
+            // the end waits for all of them.  Until round 5 a job that ran out of its ring was run again at the end of its own level --
+            // three chains of 30 - 40 tile blocks one after the other in the first level of an LPA batch, 19 of its 50 ms of tile time;
+            // WFM_RETRY_SAME_LEVEL=1 restores that for A/B runs)
+            static const bool same_level = getenv("WFM_RETRY_SAME_LEVEL") && atoi(getenv("WFM_RETRY_SAME_LEVEL")) != 0;
+            if (guessed || !same_level) next_bp.push_back(again); else bp_nodes.push_back(again);
             ++band_retries;
             hint_retries += guessed;
             continue;

@@ -328,7 +328,9 @@ Summary Aligner::compute() {
   // up to three batches per GPU in flight when there are host threads for it: the host stages of a batch (sequence
   // fetches, CIGAR surgery, PAF text) run while the device works on another
   static const size_t workers_env = getenv("WFM_ALIGN_WORKERS") ? (size_t)std::max(1, atoi(getenv("WFM_ALIGN_WORKERS"))) : 0;  // A/B runs
-  const size_t per_gpu = workers_env ? workers_env : ((size_t)param.threads >= 12 * ngpu ? 3 : ((size_t)param.threads >= 2 * ngpu ? 2 : 1));
+  // (four since round 5 where the host has 16 threads per GPU: with the round's kernels a batch of a pangenome rank is 100 ms of device time in 170 ms
+  // of its worker's, and a full-size rank went from 1.37 - 1.42 s on three workers to 1.18 - 1.29 s on four -- gpurun_out/r5i.log; six gain nothing more)
+  const size_t per_gpu = workers_env ? workers_env : ((size_t)param.threads >= 16 * ngpu ? 4 : ((size_t)param.threads >= 12 * ngpu ? 3 : ((size_t)param.threads >= 2 * ngpu ? 2 : 1)));
   const size_t nworkers = ngpu * per_gpu;
   // several GPUs: no batch may hold more than an eighth of one GPU's share of the file.  One GPU: a file of one batch
   // stays one batch (WFM_ALIGN_MIN_BATCHES cuts it for A/B runs); a file of a few batches is cut into a multiple of the
