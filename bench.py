@@ -289,11 +289,58 @@ def _strong_c4(args, h, capi, synth, dist, rank, world, comm_dev, torch):
         bp = 0
         recs_n = 0
         ms_gpu = 0.0
+        cells = cells_tile = launches = 0
+        ms_tile = 0.0
         for _ in range(args.steps):
             al = one_pass()
             bp += int(al.aligned_bp); recs_n += int(al.records); ms_gpu += al.ms_gpu
+            cells += int(al.cells); cells_tile += int(al.cells_tile); launches += int(al.tile_launches); ms_tile += al.ms_tile
         sync()
         dt = time.perf_counter() - t0
+        roof = cpu = parity = None
+        if rank == 0:
+            # the dominant kernel of the path (the tile kernels), from the run's own HIP events: 48 B x the unique cells of its launches / the sum of
+            # their durations (launches of the four workers overlap: the sum is an upper bound of the kernel's own time, the figure a lower bound)
+            peak = 8000.0
+            ach = 48.0 * cells_tile / (ms_tile * 1e-3) / 1e9 if ms_tile > 0 else 0.0
+            peak_cells = 256 * 4 * 16 * 2.4e9 / 36.0
+            roof = {"bound": "hbm", "physical_bound": "valu", "kernel": "wfa_tile2_kernel (rank 0)", "achieved": ach, "peak": peak, "unit": "GB/s", "frac": ach / peak,
+                    "traffic": None, "launches_per_step": launches / max(1, args.steps), "avg_launch_ms": ms_tile / max(1, launches),
+                    "algorithmic_bytes_per_launch": 48.0 * cells_tile / max(1, launches),
+                    "valu": {"bound": "valu", "unit": "cells/s", "floor_valu_insts_per_cell": 36.0, "peak": peak_cells,
+                             "achieved": cells_tile / (ms_tile * 1e-3) if ms_tile > 0 else 0.0, "frac": (cells_tile / (ms_tile * 1e-3) / peak_cells) if ms_tile > 0 else 0.0},
+                    "whole_path": {"algorithmic_frac_gpu": 48.0 * cells / (ms_gpu * 1e-3) / 8e12 if ms_gpu else None, "gpu_share_of_align": ms_gpu * 1e-3 / dt,
+                                   "note": "48 B x the cells of ALL align kernels / the time any of them was running on rank 0's device"},
+                    "note": "launch durations are summed over workers whose launches overlap (an upper bound of the kernel's own time); the yardstick and the VALU floor are "
+                            "the C3 line's (DESIGN.md section 5)"}
+            if world == 1 and not args.no_cpu_baseline:
+                # the CPU baseline on a bounded sample of the same records: oracle/wflign_host.py over oracle/wfa2p.c, one record per thread
+                from oracle import wflign_host as W
+                from concurrent.futures import ThreadPoolExecutor
+                seqs = {}
+                name = None
+                for ln in open(fa):
+                    if ln.startswith(">"):
+                        name = ln[1:].split()[0]; seqs[name] = []
+                    else:
+                        seqs[name].append(ln.strip())
+                seqs = {k: "".join(v).encode() for k, v in seqs.items()}
+                mylines = [lines[i].rstrip("\n") for i in shard]
+                n_s = args.cpu_sample or min(len(mylines), 256)
+                sample = mylines[::max(1, len(mylines) // n_s)][:n_s]
+                nt = max(1, min(len(sample), os.cpu_count() or 1, 64))
+                t1 = time.perf_counter()
+                with ThreadPoolExecutor(nt) as ex:
+                    parts = list(ex.map(lambda i: W.align_mapping_lines(sample[i::nt], seqs, seqs), range(nt)))
+                cdt = time.perf_counter() - t1
+                want = [w for p in parts for w in p]
+                got = set(l.rstrip("\n") for l in open(out_paf))
+                same = sum(1 for w in want if w in got)
+                qbp = sum(int(l.split("\t")[3]) - int(l.split("\t")[2]) for l in sample)
+                cpu = {"value": qbp / cdt, "unit": "aligned bases/s", "cores": nt, "kind": "port", "host_cpu": _cpu_model(),
+                       "sample": f"{len(sample)} of the {len(mylines)} mapping records (every k-th), oracle/wflign_host.py over oracle/wfa2p.c (BiWFA + patches + record), "
+                                 f"{nt} threads, {cdt:.1f} s"}
+                parity = {"sampled_records": len(sample), "oracle_records": len(want), "identical": same, "cigar_identical_rate": same / max(1, len(want))}
         tot = torch.tensor([float(bp), float(recs_n), dt], dtype=torch.float64, device=comm_dev)
         mx = tot.clone()
         if dist is not None:
@@ -308,6 +355,7 @@ def _strong_c4(args, h, capi, synth, dist, rank, world, comm_dev, torch):
                 "config": {"workload": f"C4 rank: 8 synthetic haplotypes x {args.c4_mbp} Mbp, -Y '#', the {len(lines)} mapping records of one query haplotype "
                                        "sharded over the GPUs by dist.shard_records (weight (length x (1 - identity))^2), map once + align per step",
                            "records_total": len(lines), "records_rank0": len(shard), "parallelism": f"records sharded over {world} GPU(s)", "host_threads_per_rank": threads},
+                "roofline": roof, "cpu_baseline": cpu, "cigar_identical": parity,
                 "map_s": t_map, "records_per_step_all_ranks": float(tot[1].item()) / args.steps, "ms_gpu_rank0_per_step": ms_gpu / args.steps}), flush=True)
 
 
@@ -368,7 +416,7 @@ def _roofline(acc, excl, seq_bytes, args):
     e_achieved = e_alg / (e_ms * 1e-3) / 1e9 if e_ms > 0 else 0.0
     traffic = hbm_frac = None  # HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/)
     src = None
-    for name in ("r4_traffic.json",):
+    for name in ("r5_traffic.json", "r4_traffic.json"):
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", name)))
         except (OSError, ValueError):
@@ -380,22 +428,45 @@ def _roofline(acc, excl, seq_bytes, args):
             src = "profiles/" + name
             break
     issue = None  # issue-side figures of the same kernel from the committed SQ passes (profiles/): the 48 B/cell yardstick is
-    for name in ("r4_sq.json",):  # saturated (C5 passes 1.0), what the kernel is really short of is issue slots and latency
+    for name in ("r5_sq.json", "r4_sq.json"):  # saturated (C5 passes 1.0), what the kernel is really short of is issue slots and latency
         try:
             issue = json.load(open(os.path.join(ROOT, "profiles", name)))
             issue["source"] = "profiles/" + name
             break
         except (OSError, ValueError):
             continue
-    return {"bound": "hbm", "kernel": dom,
+    # The bound that can still be missed: vector-instruction issue.  A cell of the tile kernel cannot cost fewer than
+    # VALU_FLOOR vector instructions (recurrences 9, score-bound select 2, one 16-base probe of both sequences 17, extension add 1,
+    # antidiagonal 2, its share of the neighbour exchange 4, of the per-step wave maximum 1): peak = lane-instructions per second / floor.
+    VALU_FLOOR = 36.0
+    lane_insts_per_s = 256 * 4 * 16 * 2.4e9  # 256 CUs x 4 SIMDs x 16 lanes at 2.4 GHz (MI355X_MICROARCH.md)
+    peak_cells = lane_insts_per_s / VALU_FLOOR
+    e_cells_per_s = e_cells / (e_ms * 1e-3) if e_ms > 0 else 0.0
+    steps_per_wave = 100.0
+    valu = {"bound": "valu", "unit": "cells/s", "floor_valu_insts_per_cell": VALU_FLOOR, "peak": peak_cells, "achieved": e_cells_per_s,
+            "frac": e_cells_per_s / peak_cells,
+            "note": "achieved = unique (score, diagonal) cells of the tile kernel / its exclusive running time, measured live (the same events as roofline.frac); "
+                    "peak = 16384 lanes x 2.4 GHz / the instruction floor of a cell. Lanes of a tile's halo and lanes without a cell issue as well and count against it."}
+    if issue and issue.get("counters", {}).get("SQ_WAVES"):
+        c = issue["counters"]
+        valu["committed_profile"] = {"source": issue.get("source"), "valu_insts_per_wave_step": c.get("SQ_INSTS_VALU", 0) / c["SQ_WAVES"] / steps_per_wave,
+                                     "salu_insts_per_wave_step": c.get("SQ_INSTS_SALU", 0) / c["SQ_WAVES"] / steps_per_wave,
+                                     "floor_per_wave_step": VALU_FLOOR * 2, "valu_busy": issue.get("valu_frac"), "wait_frac": issue.get("wait_frac"),
+                                     "frac_valu_from_counters": (VALU_FLOOR * 2) / max(1.0, c.get("SQ_INSTS_VALU", 0) / c["SQ_WAVES"] / steps_per_wave) * (issue.get("valu_frac") or 0.0),
+                                     "note": "per wave and score step of 2 x 64 cells, from the committed SQ pass (the builder's box, not this run): floor / measured x VALU busy"}
+    return {"bound": "hbm", "physical_bound": "valu", "valu": valu,
+            "yardstick": "48 B per cell (SURVEY 8d) -- saturated: the wavefront history never leaves the registers, real traffic is a fifth of it (committed_profile.traffic), frac passes 1; "
+                         "the bound the kernel is measured against from round 5 on is `valu`",
+            "kernel": dom + (" (wfa_tile_reg_kernel for problems with an N or soft-masked bases: none in this workload)" if tiled else ""),
             # the figure rocprofv3 reproduces: launches one after the other on one stream (untimed passes with WFM_OVERLAP=0)
             "achieved": e_achieved, "peak": peak, "unit": "GB/s", "frac": e_achieved / peak,
             # the timed region itself: up to three parts of the batch on as many streams, the kernel's running time = the union of its launch intervals
             "achieved_overlapped": achieved, "frac_overlapped": achieved / peak,
-            "valu_frac": issue.get("valu_frac") if issue else None, "wait_frac": issue.get("wait_frac") if issue else None, "issue_source": issue.get("source") if issue else None,
-            "traffic": traffic, "hbm_frac": hbm_frac, "traffic_source": src,
-            "counters_note": "traffic, hbm_frac, valu_frac and wait_frac are read from the committed PMC passes (profiles/r4_traffic.json, r4_sq.json: the builder's box, "
-                             "scripts/profile_r4.sh), not measured in this run; achieved / frac / the launch figures are measured live with HIP events",
+            "traffic": traffic,
+            "committed_profile": {"traffic": traffic, "hbm_frac": hbm_frac, "traffic_source": src,
+                                  "valu_frac": issue.get("valu_frac") if issue else None, "wait_frac": issue.get("wait_frac") if issue else None, "issue_source": issue.get("source") if issue else None,
+                                  "note": "read from the committed PMC passes under profiles/ (the builder's box, scripts/profile_r5.sh), NOT measured in this run; "
+                                          "everything outside this key is measured live with HIP events"},
             "frac_exclusive": e_achieved / peak, "achieved_exclusive": e_achieved,
             "avg_launch_ms_exclusive": e_ms / max(e_launches, 1), "launches_exclusive_per_step": e_launches / max(excl.passes, 1),
             "algorithmic_bytes_per_launch_exclusive": e_alg / max(e_launches, 1),
@@ -451,12 +522,23 @@ def _align_fields(al, t_al):
             "batches": int(al.batches), "host_ms_summed_over_batches": {"rows": al.ms_rows, "fetch": al.ms_fetch, "wflign_incl_device_calls": al.ms_wflign, "text": al.ms_text}}
 
 
-def _sampled_cigar_identity(fa_seqs, map_lines, aln_path, n_sample, **oracle_kw):
+def _sampled_cigar_identity(fa_seqs, map_lines, aln_path, n_sample, tags_path=None, **oracle_kw):
     """CIGAR-identical rate of a sample of a run's records against the align oracle (oracle/wflign_host.py over oracle/wfa2p.c):
-    every k-th mapping line is aligned by the oracle; its record must be, byte for byte, a line of the run's output."""
+    the sampled mapping lines are aligned by the oracle; each record must be, byte for byte, a line of the run's output.
+    The sample is STRATIFIED where the run wrote its records' tags (WFM_RECORD_TAGS, host/aligner.cpp -> wfm_get_problem_flags): records whose
+    root or a child ran again, whose patches went to a second / third score budget or to the ring kernel, which ran on the byte kernels, whose
+    overlap walk took several rounds, the highest scores -- the paths that have broken before -- and then every k-th row."""
     from oracle import wflign_host as W
-    step = max(1, len(map_lines) // n_sample)
-    sample = map_lines[::step][:n_sample]
+    strata = None
+    rows = None
+    if tags_path and os.path.exists(tags_path):
+        from wfmash_amd import capi as _capi
+        tags = _capi.read_record_tags(tags_path)
+        if tags:
+            rows, strata = _capi.stratified_rows(tags, len(map_lines), per_stratum=max(4, n_sample // 8), top_scores=max(4, n_sample // 8), uniform=n_sample)
+    if rows is None:
+        rows = list(range(0, len(map_lines), max(1, len(map_lines) // n_sample)))[:n_sample]
+    sample = [map_lines[r] for r in rows]
     from concurrent.futures import ThreadPoolExecutor
     nt = max(1, min(len(sample), (os.cpu_count() or 1), 32))  # (the oracle is C behind ctypes: the calls run side by side)
     with ThreadPoolExecutor(nt) as ex:
@@ -464,7 +546,8 @@ def _sampled_cigar_identity(fa_seqs, map_lines, aln_path, n_sample, **oracle_kw)
     want = [w for p in parts for w in p]
     got = set(l.rstrip("\n") for l in open(aln_path))
     same = sum(1 for w in want if w in got)
-    return {"sampled_records": len(sample), "oracle_records": len(want), "identical": same, "cigar_identical_rate": same / max(1, len(want))}
+    return {"sampled_records": len(sample), "oracle_records": len(want), "identical": same, "cigar_identical_rate": same / max(1, len(want)),
+            "strata": strata if strata is not None else "uniform (no record tags)"}
 
 
 def _mapping_identity(h, capi, synth, td):
@@ -563,15 +646,18 @@ def _secondary(h, capi, synth, full_c4=True, only=None):
             ms = capi.map_paf(h, fa, m, params=capi.map_default_params(threads=threads))
             t_map = time.perf_counter() - t1
             t1 = time.perf_counter()
+            tg = os.path.join(td, "c1.tags")
+            os.environ["WFM_RECORD_TAGS"] = tg  # (one line per record, written per batch: the parity sample is drawn from it)
             al = capi.align_paf(h, fa, m, a, params={"threads": threads})
             t_al = time.perf_counter() - t1
+            os.environ.pop("WFM_RECORD_TAGS", None)
             leg = {"workload": f"C1 substitute: 8 yeast-like strains x 16 chromosomes ({sum(lengths) / 1e6:.0f} Mbp), all-vs-all, defaults (ani50-2), map + align",
                    "map_s": t_map, "ms_identity": ms.ms_identity, "ms_index": ms.ms_index, "ms_map": ms.ms_map, "ms_filter": ms.ms_filter,
                    "mapping_records": int(ms.written), "identity_threshold": float(ms.percentage_identity)}
             leg.update(_align_fields(al, t_al))
             leg["aligned_bp_per_s_end_to_end"] = al.aligned_bp / (t_map + t_al)
             seqs = {n: s.tobytes() for n, s in recs}
-            leg["parity"] = _sampled_cigar_identity(seqs, open(m).read().splitlines(), a, 32)
+            leg["parity"] = _sampled_cigar_identity(seqs, open(m).read().splitlines(), a, 32, tags_path=tg)
             sec["C1_substitute"] = leg
             del recs, seqs
         except Exception as e:
@@ -599,9 +685,14 @@ def _secondary(h, capi, synth, full_c4=True, only=None):
                     t1 = time.perf_counter()
                     ms = capi.map_paf(h, fa, m, params=capi.map_default_params(threads=threads, query_list=ql))
                     t_map = time.perf_counter() - t1
+                tg = os.path.join(td, f"{tag}.tags")
+                if os.path.exists(tg):
+                    os.unlink(tg)
+                os.environ["WFM_RECORD_TAGS"] = tg
                 t1 = time.perf_counter()
                 al = capi.align_paf(h, fa, m, a, params={"threads": threads})
                 t_al = time.perf_counter() - t1
+                os.environ.pop("WFM_RECORD_TAGS", None)
                 leg = {"workload": f"8 synthetic haplotypes x {mbp} Mbp, -Y '#', defaults (ani50-2): rank 0 of 8 (one haplotype against all)",
                        "generate_s": t_gen, "map_s": t_map, "ms_identity": ms.ms_identity, "ms_index": ms.ms_index, "ms_map": ms.ms_map, "ms_filter": ms.ms_filter, "mapping_records": int(ms.written)}
                 leg.update(_align_fields(al, t_al))
@@ -615,7 +706,7 @@ def _secondary(h, capi, synth, full_c4=True, only=None):
                     leg["second_pass"] = {"align_s": t2, "aligned_bp_per_s": al2.aligned_bp / t2, "ms_gpu": al2.ms_gpu,
                                           "algorithmic_frac_gpu": 48.0 * al2.cells / (al2.ms_gpu * 1e-3) / 8e12 if al2.ms_gpu else None}
                 seqs = {n: s.tobytes() for n, s in recs}
-                leg["parity"] = _sampled_cigar_identity(seqs, open(m).read().splitlines(), a, n_cig)
+                leg["parity"] = _sampled_cigar_identity(seqs, open(m).read().splitlines(), a, n_cig, tags_path=tg)
                 sec[tag] = leg
                 del recs, seqs
                 os.unlink(fa)
@@ -633,8 +724,11 @@ def _secondary(h, capi, synth, full_c4=True, only=None):
             ms = capi.map_paf(h, lpa, m, params=capi.map_default_params(percentage_identity=0.9, auto_pct_identity=0, max_mapping_length=50000, threads=threads))
             t_map = time.perf_counter() - t1
             t1 = time.perf_counter()
+            tg = os.path.join(td, "lpa.tags")
+            os.environ["WFM_RECORD_TAGS"] = tg
             al = capi.align_paf(h, lpa, m, a, params={"threads": threads})
             t_al = time.perf_counter() - t1
+            os.environ.pop("WFM_RECORD_TAGS", None)
             leg = {"workload": "LPA.subset.fa.gz all-vs-all, -p 90 -P 50k, map + align", "map_s": t_map, "mapping_records": int(ms.written)}
             leg.update(_align_fields(al, t_al))
             leg["aligned_bp_per_s_align"] = al.aligned_bp / t_al
@@ -647,7 +741,7 @@ def _secondary(h, capi, synth, full_c4=True, only=None):
                 else:
                     seqs[name].append(line.strip())
             seqs = {k: "".join(v).encode() for k, v in seqs.items()}
-            leg["parity"] = _sampled_cigar_identity(seqs, open(m).read().splitlines(), a, 16)
+            leg["parity"] = _sampled_cigar_identity(seqs, open(m).read().splitlines(), a, 16, tags_path=tg)
             sec["C2"] = leg
         except Exception as e:
             sec["C2"] = {"error": str(e)}

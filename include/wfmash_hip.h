@@ -195,6 +195,19 @@ int  wfm_align_resident_rle(wfm_handle_t* h, const wfm_penalties_t* pen, wfm_seq
  * (three chains on a device are what its hardware queues run in parallel; gpurun_out/r5f_ab.log). */
 void wfm_set_concurrent_calls(wfm_handle_t* h, int other_calls);
 
+/* Which of the rarer paths the problems of the handle's LAST align call took, one word of WFM_PF_* bits per problem (a
+ * diagnostic channel: the parity tests and bench.py draw their samples from it, so that the records whose root ran again,
+ * whose patches went to a second or third score budget, or which ran on the byte kernels are all checked against the oracle
+ * instead of the one in fifty a uniform sample holds).  out may be NULL; returns the number of problems of that call. */
+#define WFM_PF_ROOT_AGAIN   1u   /* the root ran past its score hint / out of its narrow ring and was run again        */
+#define WFM_PF_JOB_AGAIN    2u   /* a BiWFA child ran out of its narrow ring and was run again on a full one          */
+#define WFM_PF_BASE_RETRY   4u   /* a leaf / ends-free patch overflowed its first score budget                        */
+#define WFM_PF_BASE_RETRY2  8u   /* ... and its second (1020): the third attempt runs to the all-gap bound            */
+#define WFM_PF_BYTE_KERNEL 16u   /* an N or a soft-masked base: the byte kernels instead of the 2-bit packed ones     */
+#define WFM_PF_P2_ROUNDS   32u   /* an overlap walk went past the first round of rows computed ahead                  */
+#define WFM_PF_RING_KERNEL 64u   /* a leaf / patch ran on the global-memory ring kernel (rows beyond 2048 diagonals, other penalties) */
+size_t wfm_get_problem_flags(const wfm_handle_t* h, uint32_t* out, size_t n);
+
 /* Device blocks of both paths -- the map path's work buffers, the align path's arenas and a batch's sequence buffers, also
  * those of a handle that has been destroyed -- are kept in a per-device cache between calls (a first hipMalloc of a gigabyte
  * costs 30 - 40 ms on this driver, a hipFree of gigabytes stalls a later allocation for up to seconds while the driver wipes

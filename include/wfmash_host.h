@@ -50,6 +50,12 @@ typedef struct {
   double   ms_wflign;    /* the wflign pipeline of a batch: device calls (upload, alignment, patches) and the work on runs between them */
   double   ms_text;      /* collecting the records' text */
   uint64_t batches;
+  /* the tile kernels' share (wfa_tile2_kernel / wfa_tile_reg_kernel, the dominant kernels of the path): cells the result needs
+   * (the block a job computes twice counted once), launches, and the sum of the launches' durations -- launches of several
+   * workers overlap, so the sum is an upper bound of the time the kernel had the device to itself */
+  uint64_t cells_tile;
+  uint64_t tile_launches;
+  double   ms_tile;
 } wfmh_align_summary_t;
 
 void wfmh_align_default_params(wfmh_align_params_t* p);

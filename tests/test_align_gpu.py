@@ -578,3 +578,80 @@ def test_phase2_work_list_overflow_path(oracle, tmp_path):
     env = dict(__import__("os").environ, WFM_P2_WORKCAP="4")
     r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "P2CAP_OK" in r.stdout, (r.stdout[-1000:], r.stderr[-3000:])
+
+
+def test_cells_the_rooflines_count_against_the_oracles_own_count(oracle, monkeypatch):
+    """The numerator of every roofline figure is a count of (score, diagonal) cells made by the host in closed form
+    (wfa_host.hip: h_cells_sum over the rows' ranges [max(-pl, -s), min(tl, s)] cut by the score bounds).  Held here against
+    the oracle's own count (wfo_stats_t.cells: the width of every wavefront WFA2-lib's recursion computes, after trimming):
+    with the bounds switched off -- no hints, no walk, children without their parents' scores -- the device computes the
+    reference's rows, and its UNIQUE cells (the block in which a job's wavefronts meet is computed twice and counted once)
+    must equal the oracle's within the tolerances written here; with the bounds on it computes fewer.
+    Two inputs: C3-sized pairs (the bench line's workload: rows 16 k diagonals wide; measured 1.022 of the oracle's count, so the
+    roofline's numerator overstates the reference's work by that much) and short mixed problems (measured 1.078), where what the device computes beyond the reference's rows weighs
+    more: phase 2 computes its rows ahead in rounds of 32 where the reference stops at the row that ends its loop, a leaf's
+    rows grow by a diagonal per score on either side where the reference trims NULL ends."""
+    small = _pairs(41, 10, [2500, 6000, 12000], [0.02, 0.05, 0.1])
+    small = [(p, t) for p, t in small if len(p) > 1000 and len(t) > 1000]
+    for i in range(4):
+        small.append(_padded_record(1200 + i, 8000 + 1000 * i, 1e-3, 1e-4, pad_t=700))
+    big = synth.pairs("C3", n_pairs=2)
+
+    def run(items, env):
+        for k in ("WFM_SCORE_HINT", "WFM_BOUND", "WFM_SUB_SLACK"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        h = capi.Handle(0)
+        try:
+            res = h.align(items)
+            st = h.stats()
+            assert all(r.status == 0 for r in res)
+            return int(st.cells), int(st.cells - st.cells_tile + st.cells_tile_unique), int(st.cells_tile_unique)
+        finally:
+            h.close()
+
+    for name, items, tol in (("C3-sized", big, 1.03), ("short mixed", small, 1.10)):
+        want = 0
+        for p, t in items:
+            rc, ops, sc, st = oracle.align_biwfa(p, t)
+            assert rc == 0
+            want += int(st.cells)
+        total_u, unique_u, tile_u = run(items, {"WFM_SCORE_HINT": "0", "WFM_BOUND": "0", "WFM_SUB_SLACK": str(1 << 28)})
+        total_b, unique_b, tile_b = run(items, {})
+        print(f"cells, {name}: oracle {want}; device without bounds {unique_u} unique ({unique_u / want:.4f} of the oracle's; tile kernel {tile_u}) / "
+              f"{total_u} computed; with bounds {unique_b} unique / {total_b} computed")
+        assert want <= unique_u <= tol * want, (name, want, unique_u)
+        assert unique_u <= total_u <= 1.25 * unique_u
+        assert unique_b <= unique_u
+
+
+def test_problem_flags_name_the_rare_paths(gpu, oracle):
+    """wfm_get_problem_flags: the diagnostic channel the sampled parity checks of bench.py and tests/test_configs_gpu.py draw
+    their strata from.  A problem with an N must carry WFM_PF_BYTE_KERNEL, a patch that overflows 256 WFM_PF_BASE_RETRY, a
+    root whose hint is far too small WFM_PF_ROOT_AGAIN -- and each of them still gives the oracle's CIGAR."""
+    p = synth.random_dna(77, 6000)
+    t = synth.mutate(p, 0.03, 78)
+    pn = p[:3000] + b"N" * 7 + p[3007:]
+    items = [(p, t), (pn, t)]
+    res = gpu.align(items)
+    fl = gpu.problem_flags(2)
+    assert len(fl) == 2 and not (fl[0] & capi.WFM_PF_BYTE_KERNEL) and (fl[1] & capi.WFM_PF_BYTE_KERNEL)
+    for (a, b), r in zip(items, res):
+        rc, ops, sc, _ = oracle.align_biwfa(a, b)
+        assert r.status == 0 and r.ops == ops
+    # an ends-free patch of two unrelated kilobases: its score passes the first budget of 256
+    a, b = synth.random_dna(81, 1500), synth.random_dna(82, 1400)
+    items = [(a, b, capi.WFM_MODE_ENDSFREE, len(a), 0, len(b), 0), (a[:40], a[:40], capi.WFM_MODE_ENDSFREE, 40, 0, 40, 0)]
+    res = gpu.align(items)
+    fl = gpu.problem_flags(2)
+    assert (fl[0] & capi.WFM_PF_BASE_RETRY) and not (fl[1] & capi.WFM_PF_BASE_RETRY)
+    rc, ops, sc, _ = oracle.align_endsfree(a, len(a), 0, b, len(b), 0)
+    assert res[0].status == 0 and res[0].ops == ops
+    # a root with a hint far below its score runs again without it
+    t2, q2 = _padded_record(1300, 9000, 5e-3, 1e-4, pad_t=800)
+    res = gpu.align([(t2, q2, capi.WFM_MODE_END2END_BIWFA, 0, 0, 0, 0, 300)])
+    fl = gpu.problem_flags(1)
+    rc, ops, sc, _ = oracle.align_biwfa(t2, q2)
+    assert sc > 400 and (fl[0] & capi.WFM_PF_ROOT_AGAIN)
+    assert res[0].status == 0 and res[0].ops == ops

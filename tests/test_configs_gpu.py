@@ -63,6 +63,25 @@ def _handles(n):
     return [capi.Handle(0) for _ in range(n)]
 
 
+_ORACLE_SEQS = None
+
+
+def _oracle_chunk(lines):
+    return W.align_mapping_lines(lines, _ORACLE_SEQS, _ORACLE_SEQS)
+
+
+def _oracle_lines(lines, seqs, procs=None):
+    """oracle/wflign_host.py over many mapping rows: forked workers (the oracle is ctypes + Python, no HIP), rows in order."""
+    import multiprocessing as mp
+    global _ORACLE_SEQS
+    _ORACLE_SEQS = seqs
+    procs = procs or min(48, os.cpu_count() or 1)
+    chunks = [lines[i:i + 8] for i in range(0, len(lines), 8)]
+    with mp.get_context("fork").Pool(procs) as pool:
+        parts = pool.map(_oracle_chunk, chunks)
+    return [l for p in parts for l in p]
+
+
 # ---------------------------------------------------------------- C1 ----
 
 def test_c1_shape_small_against_the_oracles(gpu, tmp_path):
@@ -227,3 +246,34 @@ def test_c4_shape_against_the_oracles(gpu, tmp_path):
     it = iter(full)
     assert all(any(x == y for y in it) for x in got_s)  # ... and in the same order
     _check_records("".join(l + "\n" for l in full[::7]), seqs, 600)
+
+
+def test_c4_scaled_rank_every_record_against_the_align_oracle(gpu, tmp_path, monkeypatch):
+    """The bench line's scaled C4 rank (8 haplotypes of 8 Mbp with structural variants, `-Y '#'`, one query haplotype: ~1.2 k mapping
+    records of ~50 kb) with EVERY aligned record byte-identical to oracle/wflign_host.py over oracle/wfa2p.c -- not a sample: the records
+    that have broken before are the rare ones (a root that runs again, a patch on its third budget, a record across a structural
+    variant), and the run's own tags (WFM_RECORD_TAGS, wfm_get_problem_flags) must show that this input holds them."""
+    recs = [(n, s.tobytes()) for n, s in synth.pangenome(8, 8_000_000, n_sv=6)]
+    fa = str(tmp_path / "c4.fa")
+    names, lengths = synth.write_fasta(fa, recs)
+    seqs = dict(recs)
+    ql = str(tmp_path / "q.txt")
+    open(ql, "w").write(names[0] + "\n")
+    m, a, tg = str(tmp_path / "m.paf"), str(tmp_path / "a.paf"), str(tmp_path / "tags.tsv")
+    capi.map_paf(gpu, fa, m, params=capi.map_default_params(threads=32, query_list=ql))
+    lines = [l for l in open(m).read().splitlines() if l]
+    assert len(lines) >= 1000
+    monkeypatch.setenv("WFM_RECORD_TAGS", tg)
+    summ = capi.align_paf(gpu, fa, m, a, params={"threads": 32})
+    monkeypatch.delenv("WFM_RECORD_TAGS")
+    got = [l.rstrip("\n") for l in open(a)]
+    tags = capi.read_record_tags(tg)
+    assert sorted(tags) == list(range(len(lines)))
+    want = _oracle_lines(lines, seqs)
+    assert len(want) >= len(lines) - 8 and summ.written == len(got)
+    bad = [i for i, (x, y) in enumerate(zip(got, want)) if x != y]
+    assert not bad and len(got) == len(want), (len(got), len(want), bad[:5])
+    rows, counts = capi.stratified_rows(tags, len(lines))
+    print("strata of the scaled C4 rank:", counts)
+    # the input holds the rare paths: patches that overflow their first budget (records across a structural variant)
+    assert counts["patch_second_budget"] >= 8

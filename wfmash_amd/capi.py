@@ -17,6 +17,8 @@ WFM_MODE_ENDSFREE = 1
 WFM_MODE_END2END_UNI = 2
 
 DEFAULT_PEN = (5, 8, 2, 24, 1)  # parse_args.hpp:290-294
+# wfm_get_problem_flags (include/wfmash_hip.h): which of the rarer paths a problem took
+WFM_PF_ROOT_AGAIN, WFM_PF_JOB_AGAIN, WFM_PF_BASE_RETRY, WFM_PF_BASE_RETRY2, WFM_PF_BYTE_KERNEL, WFM_PF_P2_ROUNDS, WFM_PF_RING_KERNEL = 1, 2, 4, 8, 16, 32, 64
 
 EXPORTS = [
     "wfm_create", "wfm_destroy", "wfm_last_error", "wfm_device_name",
@@ -27,7 +29,7 @@ EXPORTS = [
     "wfm_map_l1", "wfm_map_l2", "wfm_map_fragments", "wfm_minhash_sketch", "wfm_add_minmers_multi",
     "wfm_prefilter_kmers", "wfm_index_build_sequences", "wfm_index_upload",
     "wfm_index_replicate", "wfm_device_count", "wfm_finish_records",
-    "wfm_align_batch_rle", "wfm_align_resident_rle", "wfm_free_runs", "wfm_score_bounds", "wfm_get_busy_intervals", "wfm_trim_device_cache", "wfm_selftest_dpp", "wfm_selftest_arena_growth", "wfm_set_concurrent_calls",
+    "wfm_align_batch_rle", "wfm_align_resident_rle", "wfm_free_runs", "wfm_score_bounds", "wfm_get_busy_intervals", "wfm_trim_device_cache", "wfm_selftest_dpp", "wfm_selftest_arena_growth", "wfm_set_concurrent_calls", "wfm_get_problem_flags",
 ]
 
 
@@ -279,6 +281,15 @@ class Handle:
         st = Stats()
         self._L.wfm_get_stats(self._p, C.byref(st))
         return st
+
+    def problem_flags(self, n):
+        """wfm_get_problem_flags: WFM_PF_* bits of the problems of the handle's last align call."""
+        f = self._L.wfm_get_problem_flags
+        f.restype = C.c_size_t
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        out = np.zeros(max(n, 1), dtype=np.uint32)
+        have = f(self._p, out.ctypes.data, n)
+        return out[:min(n, have)]
 
     def upload(self, items):
         return SeqSet(self, items)
@@ -756,7 +767,8 @@ class AlignParams(C.Structure):
 class AlignSummary(C.Structure):
     _fields_ = [("records", C.c_uint64), ("aligned_bp", C.c_uint64), ("written", C.c_uint64),
                 ("skipped", C.c_uint64), ("cells", C.c_uint64), ("ms_gpu", C.c_double), ("ms_total", C.c_double),
-                ("ms_rows", C.c_double), ("ms_fetch", C.c_double), ("ms_wflign", C.c_double), ("ms_text", C.c_double), ("batches", C.c_uint64)]
+                ("ms_rows", C.c_double), ("ms_fetch", C.c_double), ("ms_wflign", C.c_double), ("ms_text", C.c_double), ("batches", C.c_uint64),
+                ("cells_tile", C.c_uint64), ("tile_launches", C.c_uint64), ("ms_tile", C.c_double)]
 
 
 def _host():
@@ -806,6 +818,48 @@ def align_paf(handle, target_fasta, mapping_paf, out_paf, query_fasta=None, para
     if rc != 0:
         raise WfmError(f"wfmh_align_paf failed ({rc}): {handle.last_error()}")
     return summ
+
+
+def read_record_tags(path):
+    """The align driver's diagnostic channel (WFM_RECORD_TAGS=<file>, host/aligner.cpp): {row of the mapping file: (tags, score, ok)}
+    with tags = WFM_PF_* of the main alignment | of the head patch << 8 | of the tail patch << 16."""
+    out = {}
+    with open(path) as f:
+        for line in f:
+            a = line.split()
+            if len(a) >= 4:
+                out[int(a[0])] = (int(a[1]), int(a[2]), int(a[3]))
+    return out
+
+
+def stratified_rows(tags, n_rows, per_stratum=64, top_scores=32, uniform=64):
+    """Rows of a mapping file to hold against the oracle, drawn where the align path has broken before rather than uniformly:
+    every record (up to per_stratum each) whose root or a child ran again, whose patches went to a second / third budget or to the
+    ring kernel, which ran on the byte kernels, whose overlap walk took several rounds; the top_scores highest scores; then every
+    k-th row.  Returns (sorted rows, {stratum: count})."""
+    strata = {
+        "root_again": lambda t: t & WFM_PF_ROOT_AGAIN,
+        "job_again": lambda t: t & WFM_PF_JOB_AGAIN,
+        "patch_second_budget": lambda t: (t >> 8 | t >> 16) & WFM_PF_BASE_RETRY,
+        "patch_third_budget": lambda t: (t >> 8 | t >> 16) & WFM_PF_BASE_RETRY2,
+        "ring_kernel": lambda t: (t | t >> 8 | t >> 16) & WFM_PF_RING_KERNEL,
+        "byte_kernel": lambda t: (t | t >> 8 | t >> 16) & WFM_PF_BYTE_KERNEL,
+        "p2_rounds": lambda t: t & WFM_PF_P2_ROUNDS,
+        "leaf_retry": lambda t: t & (WFM_PF_BASE_RETRY | WFM_PF_BASE_RETRY2),
+    }
+    rows, counts = set(), {}
+    for name, pred in strata.items():
+        hit = sorted(r for r, (t, _, ok) in tags.items() if pred(t))
+        counts[name] = len(hit)
+        step = max(1, len(hit) // per_stratum)
+        rows.update(hit[::step][:per_stratum])
+    by_score = sorted(tags, key=lambda r: -tags[r][1])[:top_scores]
+    rows.update(by_score)
+    counts["top_scores"] = len(by_score)
+    if uniform and n_rows:
+        rows.update(range(0, n_rows, max(1, n_rows // uniform)))
+    counts["sampled"] = len(rows)
+    return sorted(r for r in rows if r < n_rows), counts
 
 
 def align_paf_multi(handles, target_fasta, mapping_paf, out_paf, query_fasta=None, params=None):

@@ -94,6 +94,7 @@ struct Node {
   int32_t noband;     // bialign jobs: 1 = ran out of a narrow ring once, gets the full one now
   int32_t sub;        // bialign jobs: upper bound of the score (SUB_NONE: none); the wavefronts are cut to what can stay under it
   int32_t hinted;     // the bound is the caller's guess (a root): the job is run again without it if the guess was too small
+  int32_t tries;      // base jobs: how many score budgets the job has overflowed so far
 };
 
 }  // namespace
@@ -162,6 +163,7 @@ struct wfm_handle {
   std::vector<std::pair<float, float>> bp_iv, base_iv;  // the same for the step kernel and the base kernel
   std::string err;
   std::string name;
+  std::vector<uint32_t> prob_flags;  // WFM_PF_* of every problem of the last align call (wfm_get_problem_flags)
   int other_calls = 0;         // wfm_set_concurrent_calls: align calls the caller keeps in flight on this device beside this handle's
   size_t mem_budget = 0;       // arena budget in force for the call at hand
   size_t mem_budget_full = 0;  // the handle's whole budget (40 % of free HBM at creation, or WFM_MEM_BUDGET_MB)
@@ -299,7 +301,7 @@ inline int64_t base_row_width(const Node& nd, const ProbMeta& pm) {
 // overflowed nodes (with a larger budget) to `retry`.
 int run_base_jobs(wfm_handle* h, wfm_seqset* S, const wfm_penalties_t& pen, std::vector<Node>& nodes,
                   std::vector<Node>& retry, std::vector<int32_t>& prob_status, std::vector<uint64_t>& prob_cells,
-                  LevelTimer& tm) {
+                  LevelTimer& tm, uint32_t* pflags) {
   if (nodes.empty()) return WFM_OK;
   const int RR = ring_rows_for(std::max(pen.x, std::max(pen.o1 + pen.e1, pen.o2 + pen.e2)) + 1);
   // rows beyond 2 k diagonals get 1024 threads -- and rows beyond 512 when the launch is too small to fill the device anyway
@@ -421,8 +423,11 @@ int run_base_jobs(wfm_handle* h, wfm_seqset* S, const wfm_penalties_t& pen, std:
         const BaseResult& r = res[q];
         prob_cells[nd.prob] += r.cells;
         h->stats.cells_base += r.cells;
+        if (pflags && chunk_kind >= 3 && jobs[q].type == 0) pflags[nd.prob] |= WFM_PF_RING_KERNEL;
         if (r.status == WFM_DEV_OVERFLOW) {
+          if (pflags) pflags[nd.prob] |= nd.tries == 0 ? WFM_PF_BASE_RETRY : WFM_PF_BASE_RETRY2;
           Node again = nd;
+          again.tries = nd.tries + 1;
           // No alignment costs more than the all-gap one.  A job whose begin or end component is a gap state is held to a
           // PIECE there (a BiWFA child that ends inside a D2 gap pays o2 + e2 per base for it, however short it is --
           // its parent counted that gap's opening on the other side of the breakpoint, so the child's own forward score
@@ -884,7 +889,8 @@ int run_p2_phase(wfm_handle* h, wfm_seqset* S, const DevPen& dp, int scope, cons
 // runs_out != nullptr: run-length output (wfm_align_batch_rle) -- the part's merged runs are appended to *runs_out and
 // ops_off counts from the part's first run (the caller shifts the parts into one buffer); ops_arena is not touched
 int align_resident_impl(wfm_handle* h, const wfm_penalties_t* pen, wfm_seqset* S, size_t first, size_t last, wfm_result_t* out,
-                        char* ops_arena, size_t arena_bytes, size_t arena_base, std::vector<uint32_t>* runs_out = nullptr) {
+                        char* ops_arena, size_t arena_bytes, size_t arena_base, std::vector<uint32_t>* runs_out = nullptr,
+                        uint32_t* pflags = nullptr) {
   int scope = 0;
   int rc = validate_pen(pen, &scope);
   if (rc != WFM_OK) { h->err = "unsupported penalties"; return rc; }
@@ -895,6 +901,10 @@ int align_resident_impl(wfm_handle* h, const wfm_penalties_t* pen, wfm_seqset* S
   if (n == 0) return 0;
   const DevPen dp{pen->x, pen->o1, pen->e1, pen->o2, pen->e2};
 
+  // (read per call, not once per process: the tests run the bounded and the unbounded forms in one process)
+  const bool use_hints = !(getenv("WFM_SCORE_HINT") && atoi(getenv("WFM_SCORE_HINT")) == 0);
+  const bool use_bound = use_hints && !(getenv("WFM_BOUND") && atoi(getenv("WFM_BOUND")) == 0);
+  const int slack_env = getenv("WFM_SUB_SLACK") ? atoi(getenv("WFM_SUB_SLACK")) : -1;  // tests: < 0 default, >= 2^28 none
   std::vector<int32_t> prob_status(S->meta.size(), WFM_ST_OK);  // indexed by problem id
   std::vector<uint64_t> prob_cells(S->meta.size(), 0);
 
@@ -912,7 +922,7 @@ int align_resident_impl(wfm_handle* h, const wfm_penalties_t* pen, wfm_seqset* S
     nd.prob = (int32_t)i; nd.pb = 0; nd.pl = pm.plen; nd.tb = 0; nd.tl = pm.tlen;
     nd.cb = C_M; nd.ce = C_M; nd.score_rem = INT_MAX; nd.endsfree = 0;
     nd.sub = SUB_NONE; nd.hinted = 0;
-    static const bool use_hints = !(getenv("WFM_SCORE_HINT") && atoi(getenv("WFM_SCORE_HINT")) == 0);
+    if (pflags && pm.mode == WFM_MODE_END2END_BIWFA && !((size_t)i < S->acgt.size() && S->acgt[i])) pflags[i] |= WFM_PF_BYTE_KERNEL;
     if (use_hints && pm.hint > 0 && pm.mode == WFM_MODE_END2END_BIWFA) { nd.sub = pm.hint; nd.hinted = 1; }
     const int64_t bound = (int64_t)gapcost(*pen, pm.plen) + gapcost(*pen, pm.tlen) + 8;
     if (pm.mode == WFM_MODE_ENDSFREE) {
@@ -935,7 +945,6 @@ int align_resident_impl(wfm_handle* h, const wfm_penalties_t* pen, wfm_seqset* S
   uint64_t bounded_roots = 0, bound_gain = 0;
   double bound_ms = 0;
   {
-    static const bool use_bound = !(getenv("WFM_BOUND") && atoi(getenv("WFM_BOUND")) == 0) && !(getenv("WFM_SCORE_HINT") && atoi(getenv("WFM_SCORE_HINT")) == 0);
     std::vector<BoundJob> bj;
     std::vector<size_t> owner;
     if (use_bound)
@@ -1126,13 +1135,19 @@ int align_resident_impl(wfm_handle* h, const wfm_penalties_t* pen, wfm_seqset* S
             rc = run_p2_phase(h, S, dp, scope, tcfg, jobs, cand_r, other_r, res, pms, carry, has_carry, round < p2_rounds, again);
             if (rc != WFM_OK) return rc;
             std::vector<int> c2; std::vector<int64_t> o2;
-            for (int a : again) { c2.push_back(cand_r[(size_t)a]); o2.push_back(other_r[(size_t)a]); }
+            for (int a : again) {
+              c2.push_back(cand_r[(size_t)a]); o2.push_back(other_r[(size_t)a]);
+              if (pflags) pflags[bp_nodes[(size_t)node_of[(size_t)cand_r[(size_t)a]]].prob] |= WFM_PF_P2_ROUNDS;
+            }
             h->stats.p2_again += (uint32_t)again.size();
             cand_r.swap(c2); other_r.swap(o2);
           }
           tm.bp_ms += pms;
           for (size_t q = 0; q < jobs.size(); ++q)
             if (!is_cand[q] || res[q].status == WFM_DEV_P2_MORE) { rest.push_back((int)q); h->stats.p2_more += is_cand[q]; if (is_cand[q]) more_set.push_back((int)q); }
+          if (pflags)  // jobs whose overlap walk went past the first round of rows computed ahead (or was finished by the step kernel)
+            for (size_t q = 0; q < jobs.size(); ++q)
+              if (is_cand[q] && res[q].status == WFM_DEV_P2_MORE) pflags[bp_nodes[(size_t)node_of[q]].prob] |= WFM_PF_P2_ROUNDS;
         }
         auto is_more = [&](int q) { return std::find(more_set.begin(), more_set.end(), q) != more_set.end(); };
         if (!rest.empty()) {
@@ -1198,6 +1213,7 @@ int align_resident_impl(wfm_handle* h, const wfm_penalties_t* pen, wfm_seqset* S
             // ran out of its narrow ring, or past the caller's guess of its score: once more, at the end of this level, on
             // a full ring and without the guess
             Node again = nd; again.noband = 1; again.sub = SUB_NONE; again.hinted = 0;
+            if (pflags) pflags[nd.prob] |= nd.score_rem == INT_MAX ? WFM_PF_ROOT_AGAIN : WFM_PF_JOB_AGAIN;
             // (it joins the next level's jobs instead of holding this level up on its own: nodes are independent, only the gather at
             // the end waits for all of them.  Until round 5 a job that ran out of its ring was run again at the end of its own level --
             // three chains of 30 - 40 tile blocks one after the other in the first level of an LPA batch, 19 of its 50 ms of tile time;
@@ -1238,7 +1254,6 @@ int align_resident_impl(wfm_handle* h, const wfm_penalties_t* pen, wfm_seqset* S
             a.prob = nd.prob; a.pb = nd.pb; a.pl = bp_v; a.tb = nd.tb; a.tl = bp_h;
             // what a child can cost: the score its parent found for it, plus the opening of a gap it begins or ends in
             // (counted on the other side of the breakpoint)
-            static const int slack_env = getenv("WFM_SUB_SLACK") ? atoi(getenv("WFM_SUB_SLACK")) : -1;  // tests: < 0 default, >= 2^28 none
             const int slack = slack_env >= 0 ? slack_env : 2 * std::max(pen->o1, pen->o2) + 8;
             a.sub = (int)std::min<int64_t>((int64_t)r.score_fwd + slack, SUB_NONE);
             b.sub = (int)std::min<int64_t>((int64_t)r.score_rev + slack, SUB_NONE);
@@ -1270,7 +1285,7 @@ int align_resident_impl(wfm_handle* h, const wfm_penalties_t* pen, wfm_seqset* S
     while (!base_nodes.empty()) {
       retry.clear();
       const auto tb0 = std::chrono::steady_clock::now();
-      rc = run_base_jobs(h, S, *pen, base_nodes, retry, prob_status, prob_cells, tm);
+      rc = run_base_jobs(h, S, *pen, base_nodes, retry, prob_status, prob_cells, tm, pflags);
       wall_base += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tb0).count();
       if (rc != WFM_OK) return rc;
       base_nodes.swap(retry);
@@ -1462,6 +1477,13 @@ const char* wfm_last_error(const wfm_handle_t* h) { return h ? h->err.c_str() : 
 
 void wfm_set_concurrent_calls(wfm_handle_t* h, int other_calls) { if (h) h->other_calls = other_calls > 0 ? other_calls : 0; }
 
+size_t wfm_get_problem_flags(const wfm_handle_t* h, uint32_t* out, size_t n) {
+  if (!h) return 0;
+  const size_t have = h->prob_flags.empty() ? 0 : h->prob_flags.size() - 1;
+  if (out) for (size_t i = 0; i < n && i < have; ++i) out[i] = h->prob_flags[i];
+  return have;
+}
+
 int wfm_device_name(const wfm_handle_t* h, char* buf, size_t buflen) {
   if (!h || !buf || !buflen) return WFM_E_ARG;
   snprintf(buf, buflen, "%s", h->name.c_str());
@@ -1639,6 +1661,7 @@ int align_resident_any(wfm_handle_t* h, const wfm_penalties_t* pen, wfm_seqset_t
   if (hipSetDevice(h->device) != hipSuccess || hipEventRecord(h->ev_base, h->stream) != hipSuccess ||
       hipEventSynchronize(h->ev_base) != hipSuccess) { h->err = "hipEventRecord failed"; return WFM_E_HIP; }
   h->call_base = h->ev_base;
+  h->prob_flags.assign(n + 1, 0u);  // (the parts of a call each write their own problems' entries)
   h->tile_iv.clear(); h->bp_iv.clear(); h->base_iv.clear();
   auto busy_ms = [](std::vector<std::pair<float, float>> iv) {  // length of the union of the intervals
     std::sort(iv.begin(), iv.end());
@@ -1684,7 +1707,7 @@ int align_resident_any(wfm_handle_t* h, const wfm_penalties_t* pen, wfm_seqset_t
     return rc;
   };
   auto run_single = [&]() {
-    const int rc = finish_single(align_resident_impl(h, pen, s, 0, n, out, ops_arena, arena_bytes, 0, runs ? &part_runs[0] : nullptr));
+    const int rc = finish_single(align_resident_impl(h, pen, s, 0, n, out, ops_arena, arena_bytes, 0, runs ? &part_runs[0] : nullptr, h->prob_flags.data()));
     if (rc < 0) return rc;
     const int hrc = hand_over_runs(std::vector<size_t>{0, n});
     return hrc != WFM_OK ? hrc : rc;
@@ -1755,9 +1778,9 @@ int align_resident_any(wfm_handle_t* h, const wfm_penalties_t* pen, wfm_seqset_t
     wfm_handle* pk = h->peers[k - 1];
     pk->call_base = h->ev_base;
     pk->tile_iv.clear(); pk->bp_iv.clear(); pk->base_iv.clear();
-    th.emplace_back([&, k, pk] { rcs[k] = align_resident_impl(pk, pen, s, cut[k], cut[k + 1], out, ops_arena, arena_bytes, base[k], runs ? &part_runs[k] : nullptr); });
+    th.emplace_back([&, k, pk] { rcs[k] = align_resident_impl(pk, pen, s, cut[k], cut[k + 1], out, ops_arena, arena_bytes, base[k], runs ? &part_runs[k] : nullptr, h->prob_flags.data()); });
   }
-  rcs[0] = align_resident_impl(h, pen, s, cut[0], cut[1], out, ops_arena, arena_bytes, 0, runs ? &part_runs[0] : nullptr);
+  rcs[0] = align_resident_impl(h, pen, s, cut[0], cut[1], out, ops_arena, arena_bytes, 0, runs ? &part_runs[0] : nullptr, h->prob_flags.data());
   for (auto& t : th) t.join();
   int failed = 0;
   for (size_t k = 0; k < np; ++k) {

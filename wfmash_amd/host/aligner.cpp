@@ -70,6 +70,7 @@ struct Fetched {
   std::string ref;    // padded reference window
   std::string qry;    // strand-adjusted query window
   uint64_t ref_start = 0, ref_total = 0, q_total = 0;
+  uint64_t row_no = 0;  // the row's number in the mapping file
 };
 
 }  // namespace
@@ -135,7 +136,22 @@ void Aligner::parseMashmapRow(const std::string& line, MappingBoundaryRow& row, 
 
 // One batch of mapping rows through the wflign pipeline on one GPU: createSeqRecord + processAlignment
 // (computeAlignments.hpp:582-723) for every row, then the records' output text in row order.
-std::string Aligner::align_batch(wfm_handle_t* gpu_handle, std::vector<std::string>& lines, int threads, Summary& sum) {
+namespace {
+// WFM_RECORD_TAGS=<file>: one line per aligned record -- the row's number in the mapping file (0-based, empty lines not counted), the record's
+// WFM_PF_* bits (main alignment | head patch << 8 | tail patch << 16) and its score.  The parity tests and bench.py draw their samples from it.
+std::mutex g_tags_mu;
+void write_record_tags(const std::vector<uint64_t>& row_no, const std::vector<wflign::BiwfaRecord>& recs) {
+  const char* path = getenv("WFM_RECORD_TAGS");
+  if (!path || !*path) return;
+  std::lock_guard<std::mutex> lk(g_tags_mu);
+  if (FILE* f = fopen(path, "a")) {
+    for (size_t k = 0; k < recs.size(); ++k) fprintf(f, "%llu\t%u\t%d\t%d\n", (unsigned long long)row_no[k], recs[k].tags, recs[k].score, recs[k].ok ? 1 : 0);
+    fclose(f);
+  }
+}
+}  // namespace
+
+std::string Aligner::align_batch(wfm_handle_t* gpu_handle, std::vector<std::string>& lines, int threads, Summary& sum, uint64_t first_row) {
   std::string out;
   const bool dbg = getenv("WFM_DEBUG") != nullptr;
   const auto tb0 = std::chrono::steady_clock::now();
@@ -154,9 +170,11 @@ std::string Aligner::align_batch(wfm_handle_t* gpu_handle, std::vector<std::stri
 
   // rows first (cheap, in order), then the sequence fetches of the whole batch on `threads` threads
   std::vector<Fetched> rows;
+  uint64_t row_no = first_row;
   for (const std::string& line : lines) {
     if (line.empty()) continue;
     Fetched f;
+    f.row_no = row_no++;
     try {
       parseMashmapRow(line, f.row, param.target_padding, param.query_padding);
       const int64_t ref_size = ref->seq_len(f.row.refId);
@@ -245,7 +263,13 @@ std::string Aligner::align_batch(wfm_handle_t* gpu_handle, std::vector<std::stri
   const int rc = wflign::do_biwfa_alignment_batch(gpu_handle, recs, pen, param.disable_chain_patching, pp, &st, fmt);
   if (rc < 0) throw std::runtime_error(std::string("[wfmash::align] GPU alignment failed: ") + st.error);
   sum.cells += st.cells; sum.ms_gpu += st.ms_gpu;
+  sum.cells_tile += st.cells_tile; sum.tile_launches += st.tile_launches; sum.ms_tile += st.ms_tile;
   sum.busy.insert(sum.busy.end(), st.busy.begin(), st.busy.end());
+  if (getenv("WFM_RECORD_TAGS")) {
+    std::vector<uint64_t> rn(fetched.size());
+    for (size_t k = 0; k < fetched.size(); ++k) rn[k] = fetched[k].row_no;
+    write_record_tags(rn, recs);
+  }
   const double ms_biwfa = since(tb2);
   const auto tb3 = std::chrono::steady_clock::now();
   for (size_t k = 0; k < recs.size(); ++k) {
@@ -275,7 +299,8 @@ std::string Aligner::align_lines(const std::vector<std::string>& lines, Summary&
       bases += row_bases(lines[i]);
       batch.push_back(lines[i++]);
     }
-    out += align_batch(gpus.front(), batch, param.threads, sum);
+    const uint64_t first_row = i - batch.size();
+    out += align_batch(gpus.front(), batch, param.threads, sum, first_row);
   }
   return out;
 }
@@ -368,9 +393,11 @@ Summary Aligner::compute() {
   bool more_rows = true;  // (under read_mu) rows are left behind the batch handed out last
   std::vector<std::atomic<int>> in_flight(ngpu);  // batches on the device right now, per device
   for (auto& a : in_flight) a.store(0);
-  auto read_batch = [&](std::vector<std::string>& batch) -> int64_t {  // the batch's number, or -1 at the end
+  uint64_t rows_read = 0;  // (under read_mu) non-empty rows handed out so far
+  auto read_batch = [&](std::vector<std::string>& batch, uint64_t& first_row) -> int64_t {  // the batch's number, or -1 at the end
     std::lock_guard<std::mutex> lk(read_mu);
     batch.clear();
+    first_row = rows_read;
     uint64_t bases = 0, bytes = 0;
     std::string line;
     while (batch.size() < param.batch_records && bases < param.batch_bases && bytes < batch_bytes && std::getline(in, line)) {
@@ -379,6 +406,7 @@ Summary Aligner::compute() {
       bytes += line.size() + 1;
       batch.push_back(std::move(line));
     }
+    rows_read += batch.size();
     more_rows = !batch.empty() && in.peek() != std::char_traits<char>::eof();
     return batch.empty() ? -1 : (int64_t)next_seq++;
   };
@@ -430,7 +458,8 @@ Summary Aligner::compute() {
     try {
       std::vector<std::string> batch;
       if (wk >= ngpu) while (!first_taken[wk % ngpu].load() && !failed.load()) std::this_thread::yield();
-      for (int64_t seq; !failed.load() && (seq = read_batch(batch)) >= 0;) {
+      uint64_t first_row = 0;
+      for (int64_t seq; !failed.load() && (seq = read_batch(batch, first_row)) >= 0;) {
         first_taken[wk % ngpu].store(1);
         const double at0 = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         // a batch that has its device to itself -- none beside it, none to come -- is cut into parts by the device layer
@@ -440,7 +469,7 @@ Summary Aligner::compute() {
         const int beside = in_flight[wk % ngpu].fetch_add(1);
         wfm_set_concurrent_calls(use[wk], beside + (more && per_gpu > 1 ? 1 : 0));
         struct Leave { std::atomic<int>& a; ~Leave() { a.fetch_sub(1); } } leave{in_flight[wk % ngpu]};
-        std::string text = align_batch(use[wk], batch, threads_each, part[wk]);
+        std::string text = align_batch(use[wk], batch, threads_each, part[wk], first_row);
         const double at1 = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         write_batch((uint64_t)seq, std::move(text));
         if (getenv("WFM_DEBUG"))
@@ -468,6 +497,7 @@ Summary Aligner::compute() {
       const Summary& p = part[wk];
       sum.records += p.records; sum.aligned_bp += p.aligned_bp; sum.written += p.written; sum.skipped += p.skipped;
       sum.cells += p.cells;
+      sum.cells_tile += p.cells_tile; sum.tile_launches += p.tile_launches; sum.ms_tile += p.ms_tile;
       sum.ms_rows += p.ms_rows; sum.ms_fetch += p.ms_fetch; sum.ms_wflign += p.ms_wflign; sum.ms_text += p.ms_text; sum.batches += p.batches;
       iv[wk % ngpu].insert(iv[wk % ngpu].end(), p.busy.begin(), p.busy.end());
     }

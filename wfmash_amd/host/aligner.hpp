@@ -63,6 +63,8 @@ struct Summary {
   uint64_t written = 0;            // PAF lines emitted
   uint64_t skipped = 0;            // invalid mapping rows
   uint64_t cells = 0;
+  uint64_t cells_tile = 0, tile_launches = 0;  // the tile kernels' share of it (unique cells), their launches and summed launch durations
+  double ms_tile = 0;
   double ms_gpu = 0, ms_total = 0;
   double ms_rows = 0, ms_fetch = 0, ms_wflign = 0, ms_text = 0;  // host stages, summed over the batches
   uint64_t batches = 0;
@@ -86,7 +88,7 @@ class Aligner {
                                    uint64_t batch_bases, uint64_t nworkers, uint64_t ngpu, uint64_t min_batches, bool level);
 
  private:
-  std::string align_batch(wfm_handle_t* gpu, std::vector<std::string>& lines, int threads, Summary& sum);
+  std::string align_batch(wfm_handle_t* gpu, std::vector<std::string>& lines, int threads, Summary& sum, uint64_t first_row = 0);
   static uint64_t row_bases(const std::string& line);
   const Parameters& param;
   std::vector<wfm_handle_t*> gpus;

@@ -617,6 +617,7 @@ std::mutex& handle_lock(wfm_handle_t* h) {
 struct GpuBatch {
   std::vector<wfm_problem_t> probs;
   std::vector<wfm_result_t> res;
+  std::vector<uint32_t> flags;  // WFM_PF_* per problem (wfm_get_problem_flags), fetched while the handle is still ours
   uint32_t* runs = nullptr;
   std::string err;  // the handle's message, copied while the handle is still ours
   ~GpuBatch() { wfm_free_runs(runs); }
@@ -628,9 +629,14 @@ struct GpuBatch {
     std::lock_guard<std::mutex> lk(handle_lock(h));
     const int rc = wfm_align_batch_rle(h, &pen, probs.data(), probs.size(), res.data(), &runs, nullptr);
     if (rc < 0) err = wfm_last_error(h);
+    flags.assign(probs.size(), 0u);
+    if (rc >= 0) wfm_get_problem_flags(h, flags.data(), flags.size());
     if (rc >= 0 && st) {
       wfm_stats_t s;
-      if (wfm_get_stats(h, &s) == WFM_OK) { st->cells += s.cells; st->ms_gpu += s.ms_any_busy; }
+      if (wfm_get_stats(h, &s) == WFM_OK) {
+        st->cells += s.cells; st->ms_gpu += s.ms_any_busy;
+        st->cells_tile += s.cells_tile_unique; st->tile_launches += s.tile_launches; st->ms_tile += s.ms_tile;
+      }
       const size_t ni = wfm_get_busy_intervals(h, nullptr, 0);
       if (ni) {
         std::vector<double> iv(2 * ni);
@@ -740,6 +746,7 @@ int do_biwfa_alignment_batch(wfm_handle_t* h, std::vector<BiwfaRecord>& recs, co
       BiwfaRecord& r = recs[i];
       r.ok = (g.res[i].status == 0);  // status != 0: the reference drops the record silently (wflign.cpp:150-152)
       r.score = g.res[i].score;
+      r.tags = g.flags[i] & 0xffu;
       r.paf.clear();
       r.ops.clear();
       if (!r.ok) return;
@@ -776,6 +783,8 @@ int do_biwfa_alignment_batch(wfm_handle_t* h, std::vector<BiwfaRecord>& recs, co
       if (!r.ok || (w.head_slot < 0 && w.tail_slot < 0)) return;
       const bool head_ok = w.head_slot >= 0 && g.res[(size_t)w.head_slot].status == 0;
       const bool tail_ok = w.tail_slot >= 0 && g.res[(size_t)w.tail_slot].status == 0;
+      if (w.head_slot >= 0) r.tags |= (g.flags[(size_t)w.head_slot] & 0xffu) << 8;
+      if (w.tail_slot >= 0) r.tags |= (g.flags[(size_t)w.tail_slot] & 0xffu) << 16;
       if (!head_ok && !tail_ok) return;
       CigarOps out, patch;
       size_t from = 0, to = r.ops.size();
@@ -809,6 +818,7 @@ int do_biwfa_alignment_batch(wfm_handle_t* h, std::vector<BiwfaRecord>& recs, co
       rc = g2.run(h, pen, stats);
       if (rc < 0) return fail(g2, rc);
       for_each_record(owner.size(), nt, [&](size_t j) {
+        recs[owner[j]].tags |= (g2.flags[j] & 0xffu) << 16;
         if (g2.res[j].status != 0) return;
         BiwfaRecord& r = recs[owner[j]];
         CigarOps patch;

@@ -114,11 +114,14 @@ struct BiwfaRecord {
   int32_t score = -1;
   CigarOps ops;                      // final CIGAR as runs (after patching + swizzle)
   std::string paf;                   // the record's line incl. newline, as the align driver writes it ("" if filtered)
+  uint32_t tags = 0;                 // WFM_PF_* of the main alignment | of the head patch << 8 | of the tail patch << 16 (diagnostics: WFM_RECORD_TAGS)
 };
 
 struct BiwfaStats {
   uint64_t cells = 0;
   double ms_gpu = 0;
+  uint64_t cells_tile = 0, tile_launches = 0;  // the tile kernels' share: unique cells, launches, summed launch durations
+  double ms_tile = 0;
   uint64_t main_failed = 0, head_patches = 0, tail_patches = 0;
   std::string error;                 // the device call's message when do_biwfa_alignment_batch returns < 0
   std::vector<std::pair<double, double>> busy;  // when kernels of this batch's device calls ran (ms on the device's clock, wfm_get_busy_intervals)
