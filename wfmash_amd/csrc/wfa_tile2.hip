@@ -380,41 +380,51 @@ __global__ __launch_bounds__(NTMAX) void wfa_tile2_kernel(const uint32_t* __rest
   // C3 83.8 -> 99.2 ms per step, C2's leg 84.6 -> 90.2 ms, the scaled C4 rank 72.1 -> 76.5.)
   __syncthreads();
 
-  for (int tb = 0; tb < Tn; tb += NCL) {
+  // FAST: ten steps per unrolled body.  A class's delay line is then visited twice per body: the first visit parks its new row in the
+  // line's last entry (the row of score s - 30, which nothing reads any more) and shifts nothing, the second reads one entry further up
+  // and shifts by two (six moves for two steps instead of ten); the two-deep I1 / D1 lines need no move at all (the row of score s - 2
+  // sits where the new one goes: entry s & 1 of the body's own count).
+  constexpr int UB = FAST ? 2 * NCL : NCL;
+  for (int tb = 0; tb < Tn; tb += UB) {
 #pragma unroll
-  for (int jj = 1; jj <= NCL; ++jj) {
+  for (int jj = 1; jj <= UB; ++jj) {
     const int t = tb + jj;
     if (t > Tn) break;
     const int cl = jj % NCL;  // residue class of this step's score: compile time after unrolling
+    const bool vB = jj > NCL;  // (FAST) the class's second visit in this body
+    const int e1x = FAST ? (jj & 1) : E1 - 1;  // where the I1 / D1 row of score s - 2 sits
     const int s = s0 + t;
-    // rows this step reads from its class: [0] = s-5, [1] = s-10, [4] = s-25
+    // rows this step reads from its class: s-5, s-10, s-25 = entries 0, 1, 4 of the line (second visit: the parked row, entries 0 and 3)
+#define M_S5(c_) (vB ? Mh[c_][cl][DEP - 1] : Mh[c_][cl][0])
+#define M_S10(c_) (vB ? Mh[c_][cl][0] : Mh[c_][cl][1])
+#define M_S25(c_) (vB ? Mh[c_][cl][3] : Mh[c_][cl][4])
     int lM10, lM25, lI1, lI2, rM10, rM25, rD1, rD2;
     if (!WAVE1) {
-      const int par = FAST ? jj % 3 : (t & 1);
+      const int par = FAST ? (jj & 1) : (t & 1);  // (a body of ten steps: its own count alternates across bodies as well)
       // publish the wave-edge history values needed by the neighbouring waves in this step
-      if (lane == 63) { int* e = s_edge[par][wv + 1][0]; e[0] = Mh[C - 1][cl][1]; e[1] = Mh[C - 1][cl][4]; e[2] = I1h[C - 1][E1 - 1]; e[3] = I2h[C - 1]; }
-      if (lane == 0)  { int* e = s_edge[par][wv][1];     e[0] = Mh[0][cl][1];     e[1] = Mh[0][cl][4];     e[2] = D1h[0][E1 - 1];     e[3] = D2h[0]; }
+      if (lane == 63) { int* e = s_edge[par][wv + 1][0]; e[0] = M_S10(C - 1); e[1] = M_S25(C - 1); e[2] = I1h[C - 1][e1x]; e[3] = I2h[C - 1]; }
+      if (lane == 0)  { int* e = s_edge[par][wv][1];     e[0] = M_S10(0);     e[1] = M_S25(0);     e[2] = D1h[0][e1x];     e[3] = D2h[0]; }
       __syncthreads();
-      lM10 = from_prev_lane0(Mh[C - 1][cl][1]); lM25 = from_prev_lane0(Mh[C - 1][cl][4]);
-      lI1 = from_prev_lane0(I1h[C - 1][E1 - 1]); lI2 = from_prev_lane0(I2h[C - 1]);
-      rM10 = from_next_lane0(Mh[0][cl][1]); rM25 = from_next_lane0(Mh[0][cl][4]);
-      rD1 = from_next_lane0(D1h[0][E1 - 1]); rD2 = from_next_lane0(D2h[0]);
+      lM10 = from_prev_lane0(M_S10(C - 1)); lM25 = from_prev_lane0(M_S25(C - 1));
+      lI1 = from_prev_lane0(I1h[C - 1][e1x]); lI2 = from_prev_lane0(I2h[C - 1]);
+      rM10 = from_next_lane0(M_S10(0)); rM25 = from_next_lane0(M_S25(0));
+      rD1 = from_next_lane0(D1h[0][e1x]); rD2 = from_next_lane0(D2h[0]);
       if (lane == 0)  { const int* e = s_edge[par][wv][0];     lM10 = e[0]; lM25 = e[1]; lI1 = e[2]; lI2 = e[3]; }
       if (lane == 63) { const int* e = s_edge[par][wv + 1][1]; rM10 = e[0]; rM25 = e[1]; rD1 = e[2]; rD2 = e[3]; }
     } else {
-      lM10 = from_prev_lane(Mh[C - 1][cl][1]); lM25 = from_prev_lane(Mh[C - 1][cl][4]);
-      lI1 = from_prev_lane(I1h[C - 1][E1 - 1]); lI2 = from_prev_lane(I2h[C - 1]);
-      rM10 = from_next_lane(Mh[0][cl][1]); rM25 = from_next_lane(Mh[0][cl][4]);
-      rD1 = from_next_lane(D1h[0][E1 - 1]); rD2 = from_next_lane(D2h[0]);
+      lM10 = from_prev_lane(M_S10(C - 1)); lM25 = from_prev_lane(M_S25(C - 1));
+      lI1 = from_prev_lane(I1h[C - 1][e1x]); lI2 = from_prev_lane(I2h[C - 1]);
+      rM10 = from_next_lane(M_S10(0)); rM25 = from_next_lane(M_S25(0));
+      rD1 = from_next_lane(D1h[0][e1x]); rD2 = from_next_lane(D2h[0]);
     }
     int nM[C], nI1[C], nI2[C], nD1[C], nD2[C], nMis[C];
 #pragma unroll
     for (int c = 0; c < C; ++c) {
-      const int a10 = c == 0 ? lM10 : Mh[c - 1][cl][1], b10 = c == C - 1 ? rM10 : Mh[c + 1][cl][1];
-      const int a25 = c == 0 ? lM25 : Mh[c - 1][cl][4], b25 = c == C - 1 ? rM25 : Mh[c + 1][cl][4];
-      const int i1 = c == 0 ? lI1 : I1h[c - 1][E1 - 1], d1 = c == C - 1 ? rD1 : D1h[c + 1][E1 - 1];
+      const int a10 = c == 0 ? lM10 : M_S10(c - 1), b10 = c == C - 1 ? rM10 : M_S10(c + 1);
+      const int a25 = c == 0 ? lM25 : M_S25(c - 1), b25 = c == C - 1 ? rM25 : M_S25(c + 1);
+      const int i1 = c == 0 ? lI1 : I1h[c - 1][e1x], d1 = c == C - 1 ? rD1 : D1h[c + 1][e1x];
       const int i2 = c == 0 ? lI2 : I2h[c - 1], d2 = c == C - 1 ? rD2 : D2h[c + 1];
-      const int mx = Mh[c][cl][0];
+      const int mx = M_S5(c);
       // in-bounds <=> 0 <= offset <= min(tl, pl + k)   (h <= tl and h - k <= pl)
       const unsigned hm = hmaxu[c];
       int ins1 = max(a10, i1) + 1, ins2 = max(a25, i2) + 1, del1 = max(b10, d1), del2 = max(b25, d2), mis = mx + 1;
@@ -429,11 +439,12 @@ __global__ __launch_bounds__(NTMAX) void wfa_tile2_kernel(const uint32_t* __rest
       nM[c] = max(max(max(ins1, ins2), mis), max(del1, del2));
     }
     if (FAST) {
-      // some cell of the wave whose largest source lies beyond the problem: the selects of the round-4 form, for the whole wave
-      bool over = false;
+      // some cell of the wave whose largest source lies beyond the problem, or whose column is outside [-pl, tl] or cut off by the score
+      // bound at this score: the selects of the round-4 form, for the whole wave (a wave inside the problem and inside the bound: none)
+      bool special = false;
 #pragma unroll
-      for (int c = 0; c < C; ++c) over |= nM[c] > (int)hmaxu[c];
-      if (__any(over)) {
+      for (int c = 0; c < C; ++c) special |= (nM[c] > (int)hmaxu[c]) | (s > s_last[c]);
+      if (__any(special)) {
 #pragma unroll
         for (int c = 0; c < C; ++c) {
           const unsigned hm = hmaxu[c];
@@ -443,12 +454,14 @@ __global__ __launch_bounds__(NTMAX) void wfa_tile2_kernel(const uint32_t* __rest
           nD2[c] = (unsigned)nD2[c] <= hm ? nD2[c] : WF_NULL;
           const int mis = (unsigned)nMis[c] <= hm ? nMis[c] : WF_NULL;
           nM[c] = max(max(max(nI1[c], nI2[c]), mis), max(nD1[c], nD2[c]));
+          nM[c] = s <= s_last[c] ? nM[c] : WF_NULL;
         }
       }
-    }
-    // a column outside [-pl, tl], or one the score bound has cut off at this score, holds no cell
+    } else {
+      // a column outside [-pl, tl], or one the score bound has cut off at this score, holds no cell
 #pragma unroll
-    for (int c = 0; c < C; ++c) nM[c] = s <= s_last[c] ? nM[c] : WF_NULL;
+      for (int c = 0; c < C; ++c) nM[c] = s <= s_last[c] ? nM[c] : WF_NULL;
+    }
     // ---- extension (pk_extend2): 16 bases of every cell at once from the LDS windows, longer runs in stages
     int ext[C], maxn[C];
     unsigned oP[C], oT[C];
@@ -498,14 +511,29 @@ __global__ __launch_bounds__(NTMAX) void wfa_tile2_kernel(const uint32_t* __rest
     // advance the delay line of this step's class only
 #pragma unroll
     for (int c = 0; c < C; ++c) {
+      if (!FAST) {
 #pragma unroll
-      for (int e = DEP - 1; e > 0; --e) Mh[c][cl][e] = Mh[c][cl][e - 1];
-      Mh[c][cl][0] = nM[c];
+        for (int e = DEP - 1; e > 0; --e) Mh[c][cl][e] = Mh[c][cl][e - 1];
+        Mh[c][cl][0] = nM[c];
 #pragma unroll
-      for (int d = E1 - 1; d > 0; --d) { I1h[c][d] = I1h[c][d - 1]; D1h[c][d] = D1h[c][d - 1]; }
-      I1h[c][0] = nI1[c]; D1h[c][0] = nD1[c];
+        for (int d = E1 - 1; d > 0; --d) { I1h[c][d] = I1h[c][d - 1]; D1h[c][d] = D1h[c][d - 1]; }
+        I1h[c][0] = nI1[c]; D1h[c][0] = nD1[c];
+      } else {
+        if (!vB) Mh[c][cl][DEP - 1] = nM[c];
+        else {
+          const int parked = Mh[c][cl][DEP - 1];
+#pragma unroll
+          for (int e = DEP - 1; e > 1; --e) Mh[c][cl][e] = Mh[c][cl][e - 2];
+          Mh[c][cl][1] = parked;
+          Mh[c][cl][0] = nM[c];
+        }
+        I1h[c][e1x] = nI1[c]; D1h[c][e1x] = nD1[c];
+      }
       I2h[c] = nI2[c]; D2h[c] = nD2[c];
     }
+#undef M_S5
+#undef M_S10
+#undef M_S25
     mak = wave_max63(mak);
     if (FAST) { if (lane == 63) s_makr[(WAVE1 ? 0 : wv * MKS) + t] = mak; }
     else if (lane == 63 && mak > 0) {
@@ -516,6 +544,23 @@ __global__ __launch_bounds__(NTMAX) void wfa_tile2_kernel(const uint32_t* __rest
   }
   // ---- output snapshot: the newest H rows of M for the core ----
   if (P2) return;
+  if (FAST) {
+    // the classes whose row of the last, partial body is still parked: their line takes it now
+    const int r10 = Tn % UB;
+#pragma unroll
+    for (int j0 = 1; j0 <= NCL; ++j0) {
+      if (r10 >= j0 && r10 < j0 + NCL) {
+        const int clx = j0 % NCL;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+          const int parked = Mh[c][clx][DEP - 1];
+#pragma unroll
+          for (int e = DEP - 1; e > 0; --e) Mh[c][clx][e] = Mh[c][clx][e - 1];
+          Mh[c][clx][0] = parked;
+        }
+      }
+    }
+  }
   const int s_end = s0 + Tn;
   if (Tn < H) {
     // a short last block: the I/D rows of scores <= s0 that the step kernel still looks at live in the input ring
