@@ -595,7 +595,7 @@ def _secondary(h, capi, synth, full_c4=True, only=None):
     # a fresh process and 0.9 - 2.0 s in this place in six bench runs (gpurun_out/bench_r4[a-g]).  Its align phase stays where it was.
     early_td = tempfile.TemporaryDirectory()
     early = None
-    if full_c4 and want("C4_rank_full"):
+    if full_c4 and want("C4_rank_full") and os.environ.get("WFM_BENCH_MAP_EARLY", "1") != "0":
         try:
             mbp = 248.956422
             fa = os.path.join(early_td.name, "c4_full.fa")

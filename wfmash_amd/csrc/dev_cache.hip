@@ -82,11 +82,16 @@ hipError_t wfm_dmalloc(void** p, size_t bytes) {
   const size_t cls = class_of(bytes);
   {
     std::lock_guard<std::mutex> lk(c.mu);
-    auto it = c.free_by.find({dev, cls});
-    if (it != c.free_by.end() && !it->second.empty()) {
+    // the block's own class, or -- for blocks of 64 MB and more -- the smallest cached block of the device that holds the request and is less
+    // than half as large again: a first hipMalloc of a gigabyte costs 30 - 70 ms on this driver whenever the process has used memory before
+    // (gpurun_out/r5s.err: "device block of 2.85 GB took 171.6 ms"), a cached block of another call's size class costs nothing
+    auto it = c.free_by.lower_bound({dev, cls});
+    while (it != c.free_by.end() && it->first.first == dev && it->second.empty()) ++it;
+    if (it != c.free_by.end() && it->first.first == dev && !it->second.empty() &&
+        (it->first.second == cls || (cls >= ((size_t)64 << 20) && it->first.second <= cls + cls / 2))) {
       *p = it->second.back();
       it->second.pop_back();
-      if (dev >= 0 && dev < 64) c.cached[dev] -= cls;
+      if (dev >= 0 && dev < 64) c.cached[dev] -= it->first.second;
       return hipSuccess;
     }
   }

@@ -53,6 +53,7 @@
 #include <vector>
 
 #include "../../include/wfmash_hip.h"
+#include "../csrc/dev_cache.h"
 #include "../csrc/map_device.h"
 #include "../csrc/wfa_handle.h"
 
@@ -1259,7 +1260,10 @@ struct DeviceSink : MinmerSink {
   wfm_minmer_t* d = nullptr;
   int64_t cap = 0, n = 0;
   DeviceSink(wfm_handle_t* hh, int64_t expect) : h(hh), cap(std::max<int64_t>(expect, 4096)) {}
-  ~DeviceSink() override { if (d) (void)hipFree(d); }
+  // (from and back to the per-device block cache like every other block of the map path: until round 5 this one -- 3 GB for a pangenome rank --
+  // went to the driver with hipMalloc / hipFree at every map call, and whatever the NEXT allocation of the process was then landed on memory the
+  // driver was still wiping: the map wall of a full-size rank read 0.6 s or 1.1 - 2 s depending on what had run before it)
+  ~DeviceSink() override { if (d) wfm_dfree(d); }
   int put(const wfm_minmer_t* recs, int64_t m) override { return append(recs, m, hipMemcpyHostToDevice); }
   int put_device(const wfm_minmer_t* d_recs, int64_t m) override { return append(d_recs, m, hipMemcpyDeviceToDevice); }
   int append(const wfm_minmer_t* recs, int64_t m, hipMemcpyKind kind) {
@@ -1267,17 +1271,13 @@ struct DeviceSink : MinmerSink {
     if (!d || n + m > cap) {
       int64_t want = d ? std::max(cap + cap / 2, n + m) : std::max(cap, m);
       wfm_minmer_t* nd = nullptr;
-      if (hipMalloc((void**)&nd, (size_t)want * sizeof(wfm_minmer_t)) != hipSuccess) {
+      if (wfm_dmalloc((void**)&nd, (size_t)want * sizeof(wfm_minmer_t)) != hipSuccess) {  // (the cache has given everything back and tried again by then)
         (void)hipGetLastError();
-        wfm_trim_device_cache();  // cached blocks of the map path go back to the driver first
-        if (hipMalloc((void**)&nd, (size_t)want * sizeof(wfm_minmer_t)) != hipSuccess) {
-          (void)hipGetLastError();
-          wfm_set_error(h, "out of device memory (minmer intervals)");
-          return WFM_E_NOMEM;
-        }
+        wfm_set_error(h, "out of device memory (minmer intervals)");
+        return WFM_E_NOMEM;
       }
-      if (d && n && hipMemcpy(nd, d, (size_t)n * sizeof(wfm_minmer_t), hipMemcpyDeviceToDevice) != hipSuccess) { (void)hipFree(nd); return WFM_E_HIP; }
-      if (d) (void)hipFree(d);
+      if (d && n && hipMemcpy(nd, d, (size_t)n * sizeof(wfm_minmer_t), hipMemcpyDeviceToDevice) != hipSuccess) { wfm_dfree(nd); return WFM_E_HIP; }
+      if (d) wfm_dfree(d);
       d = nd; cap = want;
     }
     if (hipMemcpy(d + n, recs, (size_t)m * sizeof(wfm_minmer_t), kind) != hipSuccess) { wfm_set_error(h, "upload of minmer intervals failed"); return WFM_E_HIP; }
