@@ -11,4 +11,6 @@ void wfm_set_error(wfm_handle_t* h, const std::string& msg);
 // one object another translation unit keeps with the handle; destroyed with it
 void* wfm_attachment(wfm_handle_t* h);
 void wfm_set_attachment(wfm_handle_t* h, void* p, void (*destroy)(void*));
+// called after the LAST handle of the process has been destroyed (the host layer lets go of the sequence stores it keeps between calls)
+void wfm_set_last_handle_hook(void (*f)());
 #endif

@@ -60,7 +60,9 @@ struct DevBuf {
     p = nullptr; cap = 0;
     // (an arena that has to grow doubles at least: every regrowth is a fresh allocation, 30 - 70 ms per GB on this driver, and a
     // divergent batch -- C1 -- used to walk its ring arena up in five steps of 3.5 .. 12 GB)
-    size_t want = std::max(n + n / 8 + 64, old_cap * 2);
+    // ... but never by more than 8 GB beyond what is asked for: the arenas live under per-handle budgets of up to 32 GB, and a ring arena near
+    // its budget that doubled held 64 GB + the outgrown 32 in the cache, outside every budget's accounting)
+    size_t want = std::max(n + n / 8 + 64, std::min(old_cap * 2, n + ((size_t)8 << 30) / sizeof(T)));
     const auto t0 = std::chrono::steady_clock::now();
     if (wfm_dmalloc((void**)&p, want * sizeof(T)) != hipSuccess) {  // (the cache has given everything back and tried again by then)
       (void)hipGetLastError();  // the failure must not surface after a later launch
@@ -148,6 +150,9 @@ hipEvent_t device_base_event(int device, double* off_ms) {
   return g_dev_base[device];
 }
 }  // namespace
+
+namespace { void (*g_last_handle_hook)() = nullptr; }
+void wfm_set_last_handle_hook(void (*f)()) { g_last_handle_hook = f; }
 
 struct wfm_handle {
   int device = 0;
@@ -1423,6 +1428,10 @@ int wfm_create(int device, wfm_handle_t** out) {
   if (hipSetDevice(device) != hipSuccess) return WFM_E_HIP;
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) != hipSuccess) return WFM_E_HIP;
+  // The kernels are written for the GFX9 / CDNA wave model and nothing else: DPP wave_shr / wave_shl / row_bcast, 64-lane waves, and waves that have
+  // ended dropping out of s_barrier (wfa_tile2.hip lets the waves a narrow tile does not need return before its first barrier).  Any other
+  // target fails here, loudly, instead of hanging in a kernel; wfm_selftest_dpp checks both properties on the device itself.
+  if (strncmp(prop.gcnArchName, "gfx9", 4) != 0 || prop.warpSize != 64) return WFM_E_NODEVICE;
   wfm_handle* h = new wfm_handle();
   h->device = device;
   h->name = std::string(prop.name) + " (" + prop.gcnArchName + ")";
@@ -1453,7 +1462,13 @@ void wfm_destroy(wfm_handle_t* h) {
   if (!h) return;
   for (wfm_handle* p : h->peers) wfm_destroy(p);
   h->peers.clear();
-  if (!h->is_peer) { std::lock_guard<std::mutex> lk(g_base_mu); if (h->device < 64 && g_dev_handles[h->device] > 0) --g_dev_handles[h->device]; }
+  bool last_of_process = false;
+  if (!h->is_peer) {
+    std::lock_guard<std::mutex> lk(g_base_mu);
+    if (h->device < 64 && g_dev_handles[h->device] > 0) --g_dev_handles[h->device];
+    last_of_process = true;
+    for (int d = 0; d < 64; ++d) last_of_process &= g_dev_handles[d] == 0;
+  }
   (void)hipSetDevice(h->device);
   h->ring.release(); h->base32.release(); h->base8.release(); h->rle.release(); h->rle_out.release();
   h->tilejobs.release(); h->tiletasks.release(); h->tilemak.release();
@@ -1471,6 +1486,10 @@ void wfm_destroy(wfm_handle_t* h) {
   if (h->attachment && h->attachment_free) h->attachment_free(h->attachment);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
+  // the last handle of the process: the sequence stores a map call left open for the call after it (host/fasta.cpp, keep_until_next: up to
+  // 32 GB of host memory) are let go.  The device block cache stays -- a process that creates and destroys handles in turn (the test-suite)
+  // would pay every block's first hipMalloc again -- and goes back to the driver with wfm_trim_device_cache(), see INTEGRATION.md.
+  if (last_of_process && g_last_handle_hook) g_last_handle_hook();
 }
 
 const char* wfm_last_error(const wfm_handle_t* h) { return h ? h->err.c_str() : "null handle"; }

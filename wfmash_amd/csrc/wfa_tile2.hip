@@ -981,14 +981,45 @@ __global__ __launch_bounds__(64) void dpp_selftest_kernel(int* __restrict__ out)
   out[lane] = from_prev_lane(1000 + lane);
   out[64 + lane] = from_next_lane(1000 + lane);
 }
+// ... and of the other property of the target the tile kernels lean on: waves that have ENDED drop out of s_barrier.  256 threads, the waves
+// from `keep` on return at once, the others pass values round through LDS over 64 barrier-separated steps (scripts/micro/barrier_exit.hip).
+// A target on which ended waves still count would hang here -- under a test's timeout, not inside an alignment.
+__global__ __launch_bounds__(256) void barrier_exit_selftest_kernel(int* __restrict__ out, int keep) {
+  __shared__ int s[2][4];
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (wv >= keep) return;
+  int v = wv + 1;
+  for (int t = 0; t < 64; ++t) {
+    if (lane == 0) s[t & 1][wv] = v;
+    __syncthreads();
+    v = (v + s[t & 1][(wv + 1) % keep]) & 0xffff;
+  }
+  if (lane == 0) out[wv] = v;
+}
 int selftest_dpp(int* host_out128, hipStream_t st) {
   int* d = nullptr;
-  if (hipMalloc((void**)&d, 128 * sizeof(int)) != hipSuccess) return -1;
+  if (hipMalloc((void**)&d, (128 + 16) * sizeof(int)) != hipSuccess) return -1;
   hipLaunchKernelGGL(dpp_selftest_kernel, dim3(1), dim3(64), 0, st, d);
   hipError_t e = hipMemcpyAsync(host_out128, d, 128 * sizeof(int), hipMemcpyDeviceToHost, st);
+  int got[16] = {0};
+  for (int keep = 1; keep <= 3 && e == hipSuccess; ++keep) {
+    hipLaunchKernelGGL(barrier_exit_selftest_kernel, dim3(1), dim3(256), 0, st, d + 128 + 4 * (keep - 1), keep);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(got, d + 128, 12 * sizeof(int), hipMemcpyDeviceToHost, st);
   if (e == hipSuccess) e = hipStreamSynchronize(st);
   (void)hipFree(d);
-  return e == hipSuccess ? 0 : -1;
+  if (e != hipSuccess) return -1;
+  for (int keep = 1; keep <= 3; ++keep) {  // the same exchange on the host
+    int v[4] = {1, 2, 3, 4};
+    for (int t = 0; t < 64; ++t) {
+      int nv[4];
+      for (int w = 0; w < keep; ++w) nv[w] = (v[w] + v[(w + 1) % keep]) & 0xffff;
+      for (int w = 0; w < keep; ++w) v[w] = nv[w];
+    }
+    for (int w = 0; w < keep; ++w) if (got[4 * (keep - 1) + w] != v[w]) return -2;
+  }
+  return 0;
 }
 
 }  // namespace wfm

@@ -66,7 +66,7 @@ FastaStore::FileId FastaStore::file_id(const std::string& path) {
   return f;
 }
 
-bool FastaStore::same_file() const { return file_id(path_) == id_ && file_id(path_ + ".fai") == id_fai_; }
+bool FastaStore::same_file() const { return file_id(path_) == id_ && file_id(path_ + ".fai") == id_fai_ && file_id(path_ + ".gzi") == id_gzi_; }
 
 int64_t FastaStore::resident_bytes() const {
   int64_t t = 0;
@@ -80,6 +80,7 @@ int64_t FastaStore::resident_bytes() const {
 FastaStore::FastaStore(const std::string& path) : path_(path) {
   id_ = file_id(path);
   id_fai_ = file_id(path + ".fai");
+  id_gzi_ = file_id(path + ".gzi");  // (BGZF inputs: the block table is part of what the store was opened on; absent: size -1 on both sides)
   if (!open_indexed(path)) load_stream(path);
   for (size_t i = 0; i < names_.size(); ++i) index_.emplace(names_[i], (int)i);  // the first of equal names wins, as in faidx
 }
@@ -472,6 +473,12 @@ void keep_until_next(std::vector<std::shared_ptr<FastaStore>> files) {
   release_later(std::move(old));
   release_later(std::move(files));
 }
+
+// (the device layer calls this when the last handle of the process goes: wfm_destroy)
+}  // namespace wfmash_host
+void wfm_set_last_handle_hook(void (*f)());  // csrc/wfa_handle.h
+namespace wfmash_host {
+static const int g_hook_registered = (wfm_set_last_handle_hook(&release_kept), 0);
 
 void release_kept() {
   std::vector<std::shared_ptr<FastaStore>> old;

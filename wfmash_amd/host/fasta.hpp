@@ -81,7 +81,7 @@ class FastaStore {
 
   struct FileId { uint64_t dev = 0, ino = 0; int64_t size = -1, mtime_ns = 0; bool operator==(const FileId& o) const { return dev == o.dev && ino == o.ino && size == o.size && mtime_ns == o.mtime_ns; } };
   static FileId file_id(const std::string& path);
-  FileId id_, id_fai_;
+  FileId id_, id_fai_, id_gzi_;
   std::string path_;
   std::vector<std::string> names_;
   std::vector<int64_t> lens_;
