@@ -1287,6 +1287,12 @@ int align_resident_impl(wfm_handle* h, const wfm_penalties_t* pen, wfm_seqset* S
     }
     bp_nodes.swap(next_bp);
     // ---- base jobs collected so far (incl. retries with a larger budget) ----
+    // Leaves do not feed the recursion: while bialign jobs are left they wait (round 5), and all levels' leaves go out together behind the
+    // last level -- two launches of thousands of leaves instead of two of hundreds per level, each with its wait for the device in the chain of
+    // the batch's launches (C2: 12 launches + waits per part -> 3).  WFM_LEAVES_PER_LEVEL=1: the round-4 order; a quarter of a million leaves
+    // waiting are run anyway (their arenas are chunked to the budget either way).
+    static const bool leaves_per_level = getenv("WFM_LEAVES_PER_LEVEL") && atoi(getenv("WFM_LEAVES_PER_LEVEL")) != 0;
+    if (!leaves_per_level && !bp_nodes.empty() && base_nodes.size() < ((size_t)1 << 18)) continue;
     while (!base_nodes.empty()) {
       retry.clear();
       const auto tb0 = std::chrono::steady_clock::now();

@@ -652,7 +652,7 @@ struct GpuBatch {
 // A guess of an upper bound of the score, for the device to cut its wavefronts with (wfm_problem_t::score_hint): the
 // target window is the mapped range plus padding, so the alignment opens with and ends in a gap -- two gap openings
 // and the length difference -- and in between it pays for the divergence mashmap estimated, at 6 per differing base
-// (a mismatch costs 5), with 0.1 % and 200 on top.  Too small a guess only costs that record a second run.
+// (a mismatch costs 5), with 0.1 % and 1000 on top.  Too small a guess only costs that record a second run.
 int32_t score_hint(const BiwfaRecord& r, const wflign_penalties_t& penalties) {
   double id = r.mashmap_estimated_identity > 1.0f ? r.mashmap_estimated_identity / 100.0 : r.mashmap_estimated_identity;
   id = std::min(1.0, std::max(0.5, id));
@@ -660,7 +660,10 @@ int32_t score_hint(const BiwfaRecord& r, const wflign_penalties_t& penalties) {
   const double dl = std::fabs((double)r.target_length - (double)r.query_length);
   static const double per_base = getenv("WFM_HINT_PER_BASE") ? atof(getenv("WFM_HINT_PER_BASE")) : 6.0;
   static const double id_slack = getenv("WFM_HINT_ID_SLACK") ? atof(getenv("WFM_HINT_ID_SLACK")) : 0.001;
-  static const double konst = getenv("WFM_HINT_CONST") ? atof(getenv("WFM_HINT_CONST")) : 200.0;
+  // (1000 since round 5, 200 before: a root that runs past its guess is run again from scratch, and with the device time of a batch made of chains
+  // of launches a second chain costs more than the cells a looser bound adds -- C2 55 -> 53 ms, scaled C4 rank 48.3 -> 46.5, 40 Mbp rank 214 -> 207 ms
+  // of device time, gpurun_out: the hint sweep of round 5; 2000 gains nothing more)
+  static const double konst = getenv("WFM_HINT_CONST") ? atof(getenv("WFM_HINT_CONST")) : 1000.0;
   const double hint = 2.0 * penalties.gap_opening2 + penalties.gap_extension2 * dl + (1.0 - id + id_slack) * len * per_base + konst;
   return hint < 1e9 ? (int32_t)hint : 0;
 }
