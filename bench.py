@@ -495,6 +495,7 @@ def _cpu_baseline_map(h):
         base = synth.random_backbone(0xB45E, L)
         seqs = [synth.haplotype(base, 0xB45E00 + i, n_sv=2).tobytes() for i in range(n_seq)]
         k, w, s_sz = 15, 1000, 39
+        pymap.ref_park_stderr(True)  # (the reference's ProgressMeter threads: parked once around the leg, not per call)
         t1 = time.perf_counter()
         ths = [threading.Thread(target=pymap.ref_add_minmers, args=(sq, k, w, s_sz, i)) for i, sq in enumerate(seqs)]
         for t in ths:
@@ -502,6 +503,7 @@ def _cpu_baseline_map(h):
         for t in ths:
             t.join()
         cdt = time.perf_counter() - t1
+        pymap.ref_park_stderr(False)
         t1 = time.perf_counter()
         h.add_minmers_multi(seqs, k, w, s_sz, threads=cores)
         gdt = time.perf_counter() - t1

@@ -81,6 +81,13 @@ def ref_add_minmers(seq: bytes, k: int, w: int, s: int, seq_id: int = 0, cap=Non
     return out[:n]
 
 
+def ref_park_stderr(on: bool):
+    """stderr on /dev/null for a whole multi-threaded leg of ref_add_minmers calls (the reference's ProgressMeter prints from threads of its own)."""
+    L = _load("ref")
+    if hasattr(L, "ref_park_stderr"):
+        L.ref_park_stderr(1 if on else 0)
+
+
 def ref_group_minhash(seqs, groups, k: int, sketch_size: int, want_group: int):
     """The reference's GroupedStreamingMinHash over `seqs` (list of bytes), sketch of group `want_group` ascending."""
     L = _load("ref")

@@ -47,22 +47,36 @@ int ref_sketch_sequence(char* seq, int64_t len, int k, int s, int32_t seq_id, re
   return (int)v.size();
 }
 
+// stderr parked on /dev/null for a whole multi-threaded leg (bench.py's map baseline runs 64 calls side by side: parking it per call let one
+// call's restore show the others' meters -- "ref [0.3% complete ..." all over the driver's stderr tail).  on = 1 parks, 0 restores.
+static int g_parked_fd = -1;
+void ref_park_stderr(int on) {
+  fflush(stderr);
+  if (on && g_parked_fd < 0) {
+    g_parked_fd = dup(2);
+    const int nul = open("/dev/null", O_WRONLY);
+    if (nul >= 0) { dup2(nul, 2); close(nul); }
+  } else if (!on && g_parked_fd >= 0) {
+    dup2(g_parked_fd, 2); close(g_parked_fd); g_parked_fd = -1;
+  }
+}
+
 // CommonFunc::addMinmers (commonFunc.hpp:440-708).  Returns the number of minmer intervals.
 int64_t ref_add_minmers(char* seq, int64_t len, int k, int w, int s, int32_t seq_id, ref_minmer_t* out, int64_t cap) {
   std::vector<skch::MinmerInfo> v;
   {
     // addMinmers calls progress->increment unconditionally (commonFunc.hpp:479); the meter prints
     // to stderr from its own thread, so stderr is parked on /dev/null for the duration of the call
-    fflush(stderr);
-    const int saved = dup(2), nul = open("/dev/null", O_WRONLY);
-    dup2(nul, 2);
+    // (unless the caller has parked it for a whole leg: ref_park_stderr)
+    const bool own = g_parked_fd < 0;
+    int saved = -1, nul = -1;
+    if (own) { fflush(stderr); saved = dup(2); nul = open("/dev/null", O_WRONLY); dup2(nul, 2); }
     {
       progress_meter::ProgressMeter pm((uint64_t)len * 100 + 100, "ref", false);
       skch::CommonFunc::addMinmers(v, seq, len, k, w, 4, s, seq_id, &pm);
       pm.finish();
     }
-    fflush(stderr);
-    dup2(saved, 2); close(saved); close(nul);
+    if (own) { fflush(stderr); dup2(saved, 2); close(saved); close(nul); }
   }
   int64_t n = 0;
   for (const auto& m : v) {
