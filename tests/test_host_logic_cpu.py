@@ -248,3 +248,43 @@ def test_batch_plan_levels_a_few_batches_over_the_workers():
     assert P(10_000, 50, 5000, 50 * 3000, 1536, 160_000_000, 3, level=False) == NOLIMIT
     assert P(10_000, 50, 5000, 50 * 3000, 1536, 160_000_000, 3, min_batches=5) == 10_000 // 5 + 1   # WFM_ALIGN_MIN_BATCHES
     assert P(1_000_000, 0, 0, 0, 1536, 160_000_000, 6, ngpu=2) == 1_000_000 // 16 + 1               # two GPUs: sixteen batches at least
+
+
+def test_record_tags_and_stratified_rows(tmp_path):
+    """The parity samples of bench.py and tests/test_configs_gpu.py are drawn by capi.stratified_rows from the align driver's record tags
+    (WFM_RECORD_TAGS; wfm_get_problem_flags): every stratum that has members is represented, the highest scores are in, the uniform part
+    covers the file, nothing is out of range or duplicated."""
+    from wfmash_amd import capi
+    n = 5000
+    lines = []
+    for r in range(n):
+        t = 0
+        if r % 97 == 0:
+            t |= capi.WFM_PF_ROOT_AGAIN
+        if r % 251 == 3:
+            t |= capi.WFM_PF_BASE_RETRY << 8          # head patch on its second budget
+        if r % 1009 == 5:
+            t |= (capi.WFM_PF_BASE_RETRY | capi.WFM_PF_BASE_RETRY2 | capi.WFM_PF_RING_KERNEL) << 16  # tail patch on its third, ring kernel
+        if r == 4321:
+            t |= capi.WFM_PF_BYTE_KERNEL
+        if r % 13 == 1:
+            t |= capi.WFM_PF_P2_ROUNDS
+        lines.append(f"{r}\t{t}\t{1000 + (r * 7919) % 3000}\t1\n")
+    p = tmp_path / "tags.tsv"
+    p.write_text("".join(reversed(lines)))  # (batches are written in any order)
+    tags = capi.read_record_tags(str(p))
+    assert len(tags) == n and tags[4321][0] & capi.WFM_PF_BYTE_KERNEL
+    rows, counts = capi.stratified_rows(tags, n, per_stratum=8, top_scores=8, uniform=16)
+    assert rows == sorted(set(rows)) and 0 <= rows[0] and rows[-1] < n
+    assert counts["root_again"] == len(range(0, n, 97)) and counts["patch_second_budget"] > 0 and counts["patch_third_budget"] == counts["ring_kernel"] > 0
+    assert counts["byte_kernel"] == 1 and 4321 in rows
+    picked = set(rows)
+    assert any(tags[r][0] & capi.WFM_PF_ROOT_AGAIN for r in picked)
+    assert any((tags[r][0] >> 16) & capi.WFM_PF_BASE_RETRY2 for r in picked)
+    assert any(tags[r][0] & capi.WFM_PF_P2_ROUNDS for r in picked)
+    top = sorted(tags, key=lambda r: -tags[r][1])[:8]
+    assert set(top) <= picked
+    assert len(picked) <= 8 * 8 + 8 + 17 and counts["sampled"] == len(rows)
+    # without tags (a run that wrote none): uniform rows only
+    rows2, counts2 = capi.stratified_rows({}, 100, uniform=10)
+    assert rows2 == list(range(0, 100, 10)) and counts2["root_again"] == 0
