@@ -376,6 +376,35 @@ def align_mapping_lines(lines, ref_seqs, query_seqs, target_padding=1000, query_
     return out
 
 
+_FASTA_CACHE = {}
+
+
+def read_fasta(path):
+    """{name: bytes} of a plain FASTA file (test infrastructure: the workers of a process pool read the sequences themselves)."""
+    if path not in _FASTA_CACHE:
+        seqs, name, parts = {}, None, []
+        with open(path, "rb") as f:
+            for line in f:
+                if line.startswith(b">"):
+                    if name is not None:
+                        seqs[name] = b"".join(parts)
+                    name, parts = line[1:].split()[0].decode(), []
+                else:
+                    parts.append(line.strip())
+        if name is not None:
+            seqs[name] = b"".join(parts)
+        _FASTA_CACHE[path] = seqs
+    return _FASTA_CACHE[path]
+
+
+def align_mapping_lines_fasta(args):
+    """align_mapping_lines for one chunk of rows, sequences from a FASTA path: (path, lines) -> PAF lines.  Picklable by name, so that a
+    spawned process pool can run it (a GPU test must not fork the process that holds the HIP runtime)."""
+    path, lines = args
+    seqs = read_fasta(path)
+    return align_mapping_lines(lines, seqs, seqs)
+
+
 # ---------------------------------------------------------------------------
 # SAM writer (wflign_patch.cpp:2480-2609) and MD:Z (write_tag_and_md_string :2397-2478)
 # ---------------------------------------------------------------------------

@@ -63,23 +63,13 @@ def _handles(n):
     return [capi.Handle(0) for _ in range(n)]
 
 
-_ORACLE_SEQS = None
-
-
-def _oracle_chunk(lines):
-    return W.align_mapping_lines(lines, _ORACLE_SEQS, _ORACLE_SEQS)
-
-
-def _oracle_lines(lines, seqs, procs=None):
-    """oracle/wflign_host.py over many mapping rows: forked workers (the oracle is ctypes + Python, no HIP), rows in order."""
-    import multiprocessing as mp
-    global _ORACLE_SEQS
-    _ORACLE_SEQS = seqs
-    procs = procs or min(48, os.cpu_count() or 1)
-    chunks = [lines[i:i + 8] for i in range(0, len(lines), 8)]
-    with mp.get_context("fork").Pool(procs) as pool:
-        parts = pool.map(_oracle_chunk, chunks)
-    return [l for p in parts for l in p]
+def _oracle_lines(mapping_paf, fasta_path, out_path):
+    """oracle/wflign_host.py over every row of a mapping file, many rows side by side -- in a process of its own (oracle/align_lines_cli.py
+    forks its pool there): this process holds the HIP runtime and is not forked."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "align_lines_cli.py"), fasta_path, mapping_paf, out_path],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return [l.rstrip("\n") for l in open(out_path)]
 
 
 # ---------------------------------------------------------------- C1 ----
@@ -269,7 +259,7 @@ def test_c4_scaled_rank_every_record_against_the_align_oracle(gpu, tmp_path, mon
     got = [l.rstrip("\n") for l in open(a)]
     tags = capi.read_record_tags(tg)
     assert sorted(tags) == list(range(len(lines)))
-    want = _oracle_lines(lines, seqs)
+    want = _oracle_lines(m, fa, str(tmp_path / "oracle.paf"))
     assert len(want) >= len(lines) - 8 and summ.written == len(got)
     bad = [i for i, (x, y) in enumerate(zip(got, want)) if x != y]
     assert not bad and len(got) == len(want), (len(got), len(want), bad[:5])
