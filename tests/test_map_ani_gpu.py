@@ -47,6 +47,16 @@ def test_minhash_sketch_of_a_long_sequence_selects_before_it_sorts(gpu):
         want = np.sort(h)[:n]
         got = gpu.minhash_sketch(sq, k=21, sketch_size=n)
         assert len(got) == n and (got == want).all()
+    # an ambiguous base among the first k bases blanks k-mers 0 .. k-1 (map_stats.hpp:574-580): in the one-pass form (hashing and
+    # selection in one kernel, round 5) they are skipped, in the two-pass form their hashes are overwritten
+    amb = seq[:7] + b"N" + seq[8:]
+    h, st = gpu.hash_kmers(amb, 21)
+    h = h.copy()
+    h[:21] = np.iinfo(np.uint64).max
+    h[st == 0] = np.iinfo(np.uint64).max
+    for n in (4096, 60000):
+        got = gpu.minhash_sketch(amb, k=21, sketch_size=n)
+        assert len(got) == n and (got == np.sort(h)[:n]).all()
 
 
 def test_auto_identity_drives_threshold_and_sketch_size(gpu, tmp_path):

@@ -203,6 +203,33 @@ __global__ void __launch_bounds__(256) kmer_hash_2w_kernel(const uint8_t* __rest
 }
 
 // canonical hash + strand of every k-mer start of a normalised, padded sequence
+// Hashing and thresholding in one pass (the MinHash sketch of a chromosome, wfm_minhash_sketch): the canonical hashes at most tau -- a few
+// ten thousand of 2.5 * 10^8 -- are appended to `out`, nothing else is written.  The hash array of the two-pass form (2 GB written, then read
+// again by the select) never exists.  k-mers before `skip_first` are left out (an ambiguous base among the first k bases blanks them).
+template <int K>
+__global__ void __launch_bounds__(256) kmer_hash_select_kernel(const uint8_t* __restrict__ seq /*normalised, padded*/, int64_t nk, int64_t skip_first, uint64_t tau,
+                                                               uint64_t* __restrict__ out, unsigned long long* __restrict__ count, unsigned long long cap) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nk; i += (int64_t)gridDim.x * blockDim.x) {
+    uint64_t h; int8_t st;
+    kmer_hash_2w<K>(seq + i, h, st);
+    if (i >= skip_first && h <= tau) {
+      const unsigned long long at = atomicAdd(count, 1ull);
+      if (at < cap) out[at] = h;
+    }
+  }
+}
+// false: no fused form for this k (the caller takes the two-pass path)
+static bool launch_kmer_hash_select(const uint8_t* d_norm, int64_t nk, int k, int64_t skip_first, uint64_t tau, uint64_t* d_out, unsigned long long* d_count,
+                                    unsigned long long cap, hipStream_t st) {
+  const int blocks = (int)std::min<int64_t>((nk + 255) / 256, 256 * 64);
+  switch (k) {
+#define WFM_K2S(K) case K: hipLaunchKernelGGL(kmer_hash_select_kernel<K>, dim3(blocks), dim3(256), 0, st, d_norm, nk, skip_first, tau, d_out, d_count, cap); return true;
+    WFM_K2S(15) WFM_K2S(16) WFM_K2S(17) WFM_K2S(19) WFM_K2S(21)
+#undef WFM_K2S
+    default: return false;
+  }
+}
+
 static void launch_kmer_hash(const uint8_t* d_norm, int64_t nk, int k, uint64_t* d_hash, int8_t* d_strand, hipStream_t st) {
   const int blocks = (int)std::min<int64_t>((nk + 255) / 256, 256 * 8);
   switch (k) {
@@ -705,25 +732,63 @@ int64_t wfm_minhash_sketch(wfm_handle_t* h, const char* seq, int64_t len, int k,
   uint8_t* d_norm = nullptr;
   int rc = upload_normalised(h, sc, seq, len, &d_norm);
   if (rc != WFM_OK) return rc;
-  uint64_t *d_hash = nullptr, *d_sorted = nullptr; int8_t* d_st = nullptr;
-  HIPCHK(h, sc.alloc(&d_hash, (size_t)nk * 8));
-  HIPCHK(h, sc.alloc(&d_sorted, (size_t)nk * 8));
-  HIPCHK(h, sc.alloc(&d_st, (size_t)nk));
   hipStream_t st = wfm_stream(h);
-  if (dbg) { HIPCHK(h, hipStreamSynchronize(st)); fprintf(stderr, "[wfm] minhash_sketch of %lld bases: allocations + upload + normalise %.1f ms", (long long)len, since(tq0)); }
-  const auto tq1 = std::chrono::steady_clock::now();
-  launch_kmer_hash(d_norm, nk, k, d_hash, d_st, st);
-  HIPCHK(h, hipGetLastError());
-  if (dbg) { HIPCHK(h, hipStreamSynchronize(st)); fprintf(stderr, ", hashing %.1f ms", since(tq1)); }
-  const auto tq2 = std::chrono::steady_clock::now();
   bool head_ambiguous = false;
   for (int j = 0; j < k && j < len; ++j) {
     char c = seq[j];
     if (c > 96 && c < 123) c -= 32;
     if (c != 'A' && c != 'C' && c != 'G' && c != 'T') { head_ambiguous = true; break; }
   }
-  if (head_ambiguous) HIPCHK(h, hipMemsetAsync(d_hash, 0xff, (size_t)std::min<int64_t>(k, nk) * 8, st));
   const int64_t n = std::min<int64_t>(sketch_size, nk);
+  // ---- one pass (round 5): hash and keep what is at most tau.  The sketch is the n smallest hashes with multiplicity; a canonical hash is the
+  // smaller of two uniform values, so a fraction t of the range holds ~2 t of the k-mers: tau for about 8 n of them.  The two-pass form below
+  // (hash everything: 2 GB per chromosome, select, sort) remains for short sequences, other k and the rare sequence with fewer than n below tau.
+  static const bool fused_on = !(getenv("WFM_MINHASH_FUSED") && atoi(getenv("WFM_MINHASH_FUSED")) == 0);
+  if (fused_on && nk > ((int64_t)1 << 20) && n * 64 < nk) {
+    const long double t = 4.0L * (long double)n / (long double)nk;
+    const uint64_t tau = (uint64_t)(t * 18446744073709551616.0L);
+    const unsigned long long cap = (unsigned long long)n * 64;
+    uint64_t *d_sel = nullptr, *d_srt = nullptr; unsigned long long* d_count = nullptr;
+    HIPCHK(h, sc.alloc(&d_sel, (size_t)cap * 8));
+    HIPCHK(h, sc.alloc(&d_srt, (size_t)cap * 8));
+    HIPCHK(h, sc.alloc(&d_count, sizeof(unsigned long long)));
+    HIPCHK(h, hipMemsetAsync(d_count, 0, sizeof(unsigned long long), st));
+    if (dbg) { HIPCHK(h, hipStreamSynchronize(st)); fprintf(stderr, "[wfm] minhash_sketch of %lld bases: allocations + upload + normalise %.1f ms", (long long)len, since(tq0)); }
+    const auto tf1 = std::chrono::steady_clock::now();
+    if (launch_kmer_hash_select(d_norm, nk, k, head_ambiguous ? std::min<int64_t>(k, nk) : 0, tau, d_sel, d_count, cap, st)) {
+      HIPCHK(h, hipGetLastError());
+      unsigned long long m = 0;
+      HIPCHK(h, hipMemcpyAsync(&m, d_count, sizeof(m), hipMemcpyDeviceToHost, st));
+      HIPCHK(h, hipStreamSynchronize(st));
+      if (dbg) fprintf(stderr, ", hashing + selection in one pass %.1f ms (%llu at most tau)", since(tf1), m);
+      if ((int64_t)m >= n && m <= cap) {
+        const auto tf2 = std::chrono::steady_clock::now();
+        size_t tmp = 0;
+        HIPCHK(h, rocprim::radix_sort_keys(nullptr, tmp, d_sel, d_srt, (size_t)m, 0, 64, st));
+        char* d_tmp = nullptr;
+        HIPCHK(h, sc.alloc(&d_tmp, tmp));
+        HIPCHK(h, rocprim::radix_sort_keys(d_tmp, tmp, d_sel, d_srt, (size_t)m, 0, 64, st));
+        HIPCHK(h, hipMemcpyAsync(out, d_srt, (size_t)n * 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(h, hipStreamSynchronize(st));
+        if (dbg) fprintf(stderr, ", sort + download %.1f ms\n", since(tf2));
+        int64_t valid = n;
+        while (valid > 0 && out[valid - 1] == ~0ull) --valid;
+        return valid;
+      }
+      if (dbg) fprintf(stderr, " -- outside [n, 64 n]: the two-pass form\n");
+    } else if (dbg) fprintf(stderr, " -- no one-pass form for k = %d\n", k);
+  }
+  uint64_t *d_hash = nullptr, *d_sorted = nullptr; int8_t* d_st = nullptr;
+  HIPCHK(h, sc.alloc(&d_hash, (size_t)nk * 8));
+  HIPCHK(h, sc.alloc(&d_sorted, (size_t)nk * 8));
+  HIPCHK(h, sc.alloc(&d_st, (size_t)nk));
+  if (dbg) { HIPCHK(h, hipStreamSynchronize(st)); fprintf(stderr, "[wfm] minhash_sketch of %lld bases (two passes): allocations + upload + normalise %.1f ms", (long long)len, since(tq0)); }
+  const auto tq1 = std::chrono::steady_clock::now();
+  launch_kmer_hash(d_norm, nk, k, d_hash, d_st, st);
+  HIPCHK(h, hipGetLastError());
+  if (dbg) { HIPCHK(h, hipStreamSynchronize(st)); fprintf(stderr, ", hashing %.1f ms", since(tq1)); }
+  const auto tq2 = std::chrono::steady_clock::now();
+  if (head_ambiguous) HIPCHK(h, hipMemsetAsync(d_hash, 0xff, (size_t)std::min<int64_t>(k, nk) * 8, st));
   // The sketch is the n smallest hashes (with multiplicity): sorting a chromosome's 2.5e8 hashes for 4096 of them
   // is most of the ANI estimate's time.  Hashes at most tau are selected first -- tau set so that about 8 n of
   // them are expected (a canonical hash is the smaller of two uniform values: a fraction t of the range holds
