@@ -281,10 +281,12 @@ class ChainSets {
 // Host threads this thread may use inside one call (set_filter_threads): a batch with one chromosome-sized query has
 // nothing else to give its cores to.  The passes below are split into ranges; what they compute does not depend on it.
 thread_local int tl_filter_threads = 1;
+// most threads one data-parallel pass of the filters is split over (WFM_FILTER_PAR_CAP for A/B runs: every pass spawns and joins its threads)
+static int par_cap() { static const int v = getenv("WFM_FILTER_PAR_CAP") ? std::max(1, std::min(33, atoi(getenv("WFM_FILTER_PAR_CAP")))) : 32; return v; }
 
 template <class F>
 void par_ranges(size_t n, F fn) {  // fn(lo, hi) over a partition of [0, n)
-  const size_t T = n >= ((size_t)1 << 17) ? (size_t)std::min<int>(tl_filter_threads, 32) : 1;
+  const size_t T = n >= ((size_t)1 << 17) ? (size_t)std::min<int>(tl_filter_threads, par_cap()) : 1;
   if (T <= 1) { fn((size_t)0, n); return; }
   std::vector<std::thread> pool;
   for (size_t t = 1; t < T; ++t) pool.emplace_back(fn, n * t / T, n * (t + 1) / T);
@@ -295,7 +297,7 @@ void par_ranges(size_t n, F fn) {  // fn(lo, hi) over a partition of [0, n)
 // the same partition with the part's number: fn(t, lo, hi); returns the number of parts
 template <class F>
 size_t par_parts(size_t n, F fn) {
-  const size_t T = n >= ((size_t)1 << 17) ? (size_t)std::max(1, std::min<int>(tl_filter_threads, 32)) : 1;
+  const size_t T = n >= ((size_t)1 << 17) ? (size_t)std::max(1, std::min<int>(tl_filter_threads, par_cap())) : 1;
   if (T <= 1) { fn((size_t)0, (size_t)0, n); return 1; }
   std::vector<std::thread> pool;
   for (size_t t = 1; t < T; ++t) pool.emplace_back(fn, t, n * t / T, n * (t + 1) / T);
