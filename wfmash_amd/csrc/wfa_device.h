@@ -48,7 +48,8 @@ struct BpJob {
   int32_t sub;                         // upper bound of the job's score (SUB_NONE: none): rows only hold |k - (tl - pl)| <= sub - s
   int32_t best0;                       // > 0: phase 2 resumes with a breakpoint of this score in hand (found by earlier rounds of rows
                                        // computed ahead); only a better one is reported, else WFM_DEV_P2_NOTHING
-  int32_t packed;                      // 1: both sequences are pure upper-case ACGT -- the tile kernel may read the 2-bit mirror (wfa_tile2.hip)
+  int32_t packed;                      // bit 0: both sequences are pure upper-case ACGT -- the tile kernel may read the 2-bit mirror (wfa_tile2.hip);
+                                       // bit 1: near-identical sequences (score known to be under a sixteenth of the length): long runs go to the wave's tail at once
 };
 
 // ---- time-tiled phase 1 (wfa_tile_kernel) ----

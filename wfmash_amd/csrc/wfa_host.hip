@@ -1086,6 +1086,9 @@ int align_resident_impl(wfm_handle* h, const wfm_penalties_t* pen, wfm_seqset* S
         j.sub = (nd.sub != SUB_NONE && (int64_t)std::abs(nd.tl - nd.pl) * 8 >= (int64_t)nd.sub) ? nd.sub : SUB_NONE;
         j.best0 = 0;
         j.packed = (tile_v2 && tcfg.reg && tcfg.C == 2 && (size_t)nd.prob < S->acgt.size() && S->acgt[(size_t)nd.prob]) ? 1 : 0;
+        // bit 1: near-identical sequences -- the job's score is known (a child's, a bounded or hinted root's) to be under a sixteenth of its length; the packed
+        // tile kernel then hands a lone long run to the whole wave at once (wfa_tile2.hip, tail_direct).  Whether the bound also CUTS the rows (sub below) is another matter.
+        if (j.packed && nd.sub != SUB_NONE && (int64_t)nd.sub * 16 < (int64_t)nd.pl + nd.tl) j.packed |= 2;
         band_jobs += band > 0;
         if (tile_it) { tiled.push_back((int)jobs.size()); ring2.push_back((int64_t)(ring_elems + need / 2)); }
         node_of.push_back((int32_t)i);

@@ -151,7 +151,8 @@ __device__ __forceinline__ uint32_t pk16_win(lds_words w, unsigned o) {
   return alignbit32(q[1], q[0], o << 1);
 }
 template <bool MASKED = false>
-__device__ __forceinline__ void pk_extend2(const PkSrc& SRC, const int (&m)[2], const unsigned (&oP)[2], const unsigned (&oT)[2], const int (&maxn)[2], int (&ext)[2]) {
+__device__ __forceinline__ void pk_extend2(const PkSrc& SRC, const int (&m)[2], const unsigned (&oP)[2], const unsigned (&oT)[2], const int (&maxn)[2], int (&ext)[2],
+                                           bool tail_direct = false) {
   bool more[2], outw = false;
 #pragma unroll
   for (int c = 0; c < 2; ++c) {
@@ -179,10 +180,12 @@ __device__ __forceinline__ void pk_extend2(const PkSrc& SRC, const int (&m)[2], 
     const unsigned long long mm = __ballot(more[c]);
     if (mm) {
       bool tail = false;
-      // One or two lanes whose 16 bases agreed (MASKED form, round 5): near-identical sequences, where such a run is hundreds of bases long --
-      // the wave takes it from base 16 on at once instead of giving the lane its 64 bases first (one LDS round trip less on the step's chain).
-      // More of them (divergent sequences: 44 % of the cells at 5 %): the lanes look at their next 64 bases side by side as before.
-      if (MASKED && __popcll(mm) <= (unsigned)TAIL_DIRECT_MAX) tail = more[c];
+      // One or two lanes whose 16 bases agreed, in a job of near-identical sequences (tail_direct: the job's score bound is under a sixteenth
+      // of its length, wave-uniform), where such a run is hundreds of bases long: the wave takes it from base 16 on at once instead of giving the
+      // lane its 64 bases first -- one LDS round trip less on the step's chain (scaled C4 rank 46.3 -> 44.8 ms).  Divergent sequences (44 % of
+      // the cells at 5 % have 16 bases that agree, and their runs end within the next 64): the lanes look at those side by side as before --
+      // without the job test C3 lost 2.6 % to the sparsely filled waves at the tiles' edges.
+      if (MASKED && tail_direct && __popcll(mm) <= (unsigned)TAIL_DIRECT_MAX) tail = more[c];
       else if (more[c]) {
         const int n = pk_stage2(SRC, oP[c], oT[c]);
         ext[c] = min(n, maxn[c]);
@@ -269,6 +272,7 @@ __global__ __launch_bounds__(NTMAX) void wfa_tile2_kernel(const uint32_t* __rest
   if (!J.active) return;
   const int sbase = P2 ? (tk.dir == 0 ? J.tf : J.tr) : J.s0;  // score of the snapshot this direction starts from
   const Rng2 RG = make_rng2(J.pl, J.tl, J.sub);
+  const bool lowdiv = (J.packed & 2) != 0;  // near-identical sequences: the job's known score is under a sixteenth of its length (the host says: pk_extend2, tail_direct)
   int halo = T;  // columns computed on either side of the core (the trapezoid loses one per step)
   {
     const int s1 = sbase + T;
@@ -477,7 +481,7 @@ __global__ __launch_bounds__(NTMAX) void wfa_tile2_kernel(const uint32_t* __rest
       oP[c] = (unsigned)(m + cP[c]); oT[c] = (unsigned)(m + dT);
       maxn[c] = (FAST || m >= 0) ? (int)hmaxu[c] - m : 0;
     }
-    pk_extend2<FAST>(SRC, nM, oP, oT, maxn, ext);
+    pk_extend2<FAST>(SRC, nM, oP, oT, maxn, ext, lowdiv);
     int mak = 0;
 #pragma unroll
     for (int c = 0; c < C; ++c) {
