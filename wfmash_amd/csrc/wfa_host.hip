@@ -369,7 +369,11 @@ int run_base_jobs(wfm_handle* h, wfm_seqset* S, const wfm_penalties_t& pen, std:
       const size_t rows = (size_t)nd.smax + 1;
       const size_t need32 = rows * (size_t)j.width + (size_t)5 * RR * (size_t)j.width;
       const size_t need8 = rows * (size_t)j.width;
-      if (!jobs.empty() && (n32 + need32) * 4 + (n8 + need8) > h->mem_budget) break;
+      // (a chunk of base jobs stops at 4 GB of arenas even where the budget allows more, like a chunk of rings: with the leaves of all levels going out
+      // together a batch of divergent records asked for 18 GB blocks -- 0.6 s each as a first allocation, gpurun_out/r5u_c1.err -- and thousands of
+      // leaves fill the device long before that)
+      static const size_t base_chunk_bytes = (size_t)(getenv("WFM_BASE_CHUNK_GB") ? std::max(1, atoi(getenv("WFM_BASE_CHUNK_GB"))) : 4) << 30;
+      if (!jobs.empty() && (n32 + need32) * 4 + (n8 + need8) > std::min(h->mem_budget, base_chunk_bytes)) break;
       if (need32 * 4 + need8 > h->mem_budget) {  // a single job beyond the budget
         prob_status[nd.prob] = WFM_ST_OOM;
         continue;
