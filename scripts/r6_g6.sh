@@ -1,0 +1,5 @@
+mkdir -p gpurun_out/r6f
+STEPS=10 bash scripts/ab_c3.sh "" "WFM_TILE_COARSE=0" "" "WFM_TILE_COARSE=0" > gpurun_out/r6f/ab.log 2>&1
+cat gpurun_out/r6f/ab.log
+timeout 1500 python -m pytest tests/test_align_gpu.py -x -q -m gpu > gpurun_out/r6f/align_tests.log 2>&1
+tail -5 gpurun_out/r6f/align_tests.log

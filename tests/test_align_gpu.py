@@ -622,7 +622,10 @@ def test_cells_the_rooflines_count_against_the_oracles_own_count(oracle, monkeyp
         print(f"cells, {name}: oracle {want}; device without bounds {unique_u} unique ({unique_u / want:.4f} of the oracle's; tile kernel {tile_u}) / "
               f"{total_u} computed; with bounds {unique_b} unique / {total_b} computed")
         assert want <= unique_u <= tol * want, (name, want, unique_u)
-        assert unique_u <= total_u <= 1.25 * unique_u
+        # (round 6: a root whose score nobody knows finds the block in which its directions meet with one maximum per block, runs it again
+        # with per-score maxima and then up to the meeting point -- three runs of that block instead of two, which weighs on problems of a
+        # handful of blocks like these: 1.32 measured on the short mixed set, 1.25 before)
+        assert unique_u <= total_u <= 1.35 * unique_u
         assert unique_b <= unique_u
 
 

@@ -69,7 +69,9 @@ struct TileJob {
   int32_t active;                      // 0: the meeting point lies in the block after s0 (or the job is over): tiles exit
   int32_t fmax, rmax;                  // running maximum antidiagonals of the two directions up to s0
   int32_t nblocks;                     // tile blocks executed so far (incl. the one that found the meeting point)
-  int32_t mode;                        // 0: full blocks; 1: next block stops exactly at the meeting point; 2: stopped there
+  int32_t mode;                        // 0: full blocks; 1: next block stops exactly at the meeting point; 2: stopped there;
+                                       // 5: the block after s0 runs again with per-score maxima (it ran with one maximum for the whole block
+                                       // and the wavefronts met inside it: fine_s below)
   int32_t tf, tr;                      // mode >= 1: steps of the forward / reverse direction inside the block after s0
   int32_t last_fwd;                    // mode >= 1: 1 if the forward check ended phase 1 (reverse is one step behind)
   int32_t packed;                      // as BpJob::packed (the job's tiles run wfa_tile2_kernel)
@@ -78,7 +80,11 @@ struct TileJob {
   int64_t p2_off;
   int32_t w2, koff2;
   int32_t sub;                         // as BpJob::sub
-  int32_t pad2_;
+  // Round 6: the per-score maximum antidiagonals (a six-step DPP reduction per wave and score, a seventh of the step's vector issue) are only
+  // needed in the block in which the wavefronts meet.  A block that ends below score fine_s keeps ONE maximum per direction (monotone running
+  // maxima: fm + rm >= A at the block's end <=> the directions met somewhere inside it); the advance kernel runs a block that met with a single
+  // maximum again with per-score maxima (mode 5) -- a child's score is known, so its last blocks are fine from the start and nothing runs three times.
+  int32_t fine_s;
 };
 
 // ---- phase 2 (overlap detection) without a step-by-step kernel ----
@@ -160,7 +166,8 @@ void launch_reverse(uint8_t* seq, const SeqRev* jobs, int njobs, int pad, hipStr
 void launch_seq_pack(const uint8_t* seq, uint32_t* pk, int64_t nwords, int64_t nbytes, const SeqRev* jobs, int njobs, int32_t* flag, hipStream_t st);
 constexpr int64_t PK_PAD_WORDS = 2048 + 64;  // words of padding behind the mirror: a tile stages a whole window from any origin inside
 // the tile kernel on packed sequences (wfa_tile2.hip): same contract as launch_tile_reg / launch_tile_p2
-void launch_tile2(const uint32_t* pk, int32_t* ring, const TileJob* jobs, const TileTask* tasks, int32_t* mak, int ntasks, int threads, int T, hipStream_t st);
+void launch_tile2(const uint32_t* pk, int32_t* ring, const TileJob* jobs, const TileTask* tasks, int32_t* mak, int ntasks, int threads, int T, int variants, hipStream_t st);
+bool tile2_coarse_maxima();  // wfa_tile2_kernel keeps one maximum per block below TileJob::fine_s (the FAST form; WFM_TILE_COARSE=0: per score always)
 void launch_tile2_p2(const uint32_t* pk, int32_t* ring, const TileJob* jobs, const TileTask* tasks, int ntasks, int threads, int32_t* p2, hipStream_t st);
 int selftest_dpp(int* host_out128, hipStream_t st);
 // leaves and patches on registers and packed sequences (default penalties; rows of at most 2 * threads diagonals): launch_base's contract
@@ -170,7 +177,7 @@ void launch_bp(const uint8_t* seq, int32_t* ring, const BpJob* jobs, BpResult* r
 void launch_tile_init(const uint8_t* seq, int32_t* ring, const TileJob* jobs, int32_t* mak0, int njobs, int ring_rows, hipStream_t st);
 void launch_tile(const uint8_t* seq, int32_t* ring, const TileJob* jobs, const TileTask* tasks, int32_t* mak, int ntasks,
                  int threads, int T, int Wt, size_t lds_bytes, DevPen pen, int scope, int ring_rows, hipStream_t st);
-void launch_tile_advance(TileJob* jobs, int32_t* mak, int njobs, int T, DevPen pen, int exact, hipStream_t st);
+void launch_tile_advance(TileJob* jobs, int32_t* mak, int njobs, int T, DevPen pen, int exact, int coarse, int launched, hipStream_t st);
 void launch_tile_reg(const uint8_t* seq, int32_t* ring, const TileJob* jobs, const TileTask* tasks, int32_t* mak, int ntasks,
                      int threads, int T, int C, bool cut, hipStream_t st);  // cut: some job of the launch carries a score bound
 // phase-2 rows of the jobs in mode 4 (T = P2K scores, two diagonals per thread), their per-row maxima into p2max

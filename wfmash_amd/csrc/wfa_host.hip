@@ -519,7 +519,7 @@ TileCfg tile_cfg(const wfm_penalties_t& pen, int scope) {
 // so that the step-by-step kernel has at most the finer T steps to redo.
 int run_tiled_phase(wfm_handle* h, wfm_seqset* S, const DevPen& dp, int scope, const TileCfg& cfg, int T, bool refine,
                     std::vector<BpJob>& jobs, const std::vector<int>& tiled, std::vector<int64_t>& ring2,
-                    double& tile_ms, uint64_t& tile_cells, uint32_t level) {
+                    double& tile_ms, uint64_t& tile_cells, uint32_t level, const std::vector<int32_t>* fine_from = nullptr) {
   const size_t n = tiled.size();
   if (n == 0) return WFM_OK;
   double lane_cells = 0;  // threads x diagonals per thread x scores over all tiles launched (diagnostics)
@@ -535,7 +535,8 @@ int run_tiled_phase(wfm_handle* h, wfm_seqset* S, const DevPen& dp, int scope, c
     t.ring_in = j.ring_off; t.ring_out = ring2[i];
     t.pl = j.pl; t.tl = j.tl; t.comp_begin = j.comp_begin; t.comp_end = j.comp_end;
     t.width = j.width; t.koff = j.koff; t.s0 = 0; t.active = 1; t.fmax = 0; t.rmax = 0; t.nblocks = 0; t.mode = 0; t.tf = 0; t.tr = 0; t.last_fwd = 0; t.packed = j.packed;
-    t.p2_off = 0; t.w2 = 0; t.koff2 = 0; t.sub = j.sub; t.pad2_ = 0;
+    t.p2_off = 0; t.w2 = 0; t.koff2 = 0; t.sub = j.sub;
+    t.fine_s = (fine_from && i < fine_from->size()) ? (*fine_from)[i] : INT_MAX;  // (TileJob::fine_s; a job whose score nobody knows finds its meeting block by running it again)
   }
   bool any_cut = false;  // the kernel form with the score bounds' bookkeeping is only launched when a job carries one
   for (size_t i = 0; i < n; ++i) any_cut |= tj[i].sub != SUB_NONE;
@@ -656,15 +657,26 @@ int run_tiled_phase(wfm_handle* h, wfm_seqset* S, const DevPen& dp, int scope, c
       if (h->tiletasks.ensure(tasks.size())) { h->err = "out of device memory (tile tasks)"; return WFM_E_NOMEM; }
       HIPCHK(h, hipMemcpyAsync(h->tiletasks.p, tasks.data(), tasks.size() * sizeof(TileTask), hipMemcpyHostToDevice, h->stream));
       const auto tq1 = clk();
+      // which instantiations of the packed kernel a block of the chunk can have tiles for (wfa_tile2_kernel, FINE): the one without per-score
+      // maxima always (the blocks before a job's meeting block and the run up to the meeting point); the one with them where a job that simply
+      // moved on has reached its fine_s, and in the chunk's first block for the jobs the last chunk left in mode 5
+      const bool coarse_on = cfg.reg && cfg.exact && tile2_coarse_maxima();
+      std::vector<int> variants_b((size_t)chunk, coarse_on ? 1 : 2);
+      if (coarse_on)
+        for (size_t i = 0; i < n; ++i) {
+          if (!active[i] || !(tj[i].packed & 1)) continue;
+          for (int b = 0; b < chunk; ++b)
+            if ((tj[i].mode == 5 && b == 0) || (tj[i].mode == 0 && (int64_t)tj[i].s0 + (int64_t)(b + 1) * T >= (int64_t)tj[i].fine_s)) variants_b[(size_t)b] |= 2;
+        }
       for (int b = 0; b < chunk; ++b) {
         HIPCHK(h, hipEventRecord(h->tile_ev[2 * b], h->stream));
         if (cfg.reg) {
-          if (n_pk) launch_tile2(S->d_pk, h->ring.p, h->tilejobs.p, h->tiletasks.p, h->tilemak.p, (int)n_pk, threads_b[(size_t)b], T, h->stream);
+          if (n_pk) launch_tile2(S->d_pk, h->ring.p, h->tilejobs.p, h->tiletasks.p, h->tilemak.p, (int)n_pk, threads_b[(size_t)b], T, variants_b[(size_t)b], h->stream);
           if (tasks.size() > n_pk)
             launch_tile_reg(S->d_seq, h->ring.p, h->tilejobs.p, h->tiletasks.p + n_pk, h->tilemak.p, (int)(tasks.size() - n_pk), threads_b[(size_t)b], T, cfg.C, any_cut, h->stream);
         } else launch_tile(S->d_seq, h->ring.p, h->tilejobs.p, h->tiletasks.p, h->tilemak.p, (int)tasks.size(), cfg.threads, T, cfg.Wt, lds, dp, scope, ring_rows_for(scope), h->stream);
         HIPCHK(h, hipEventRecord(h->tile_ev[2 * b + 1], h->stream));
-        launch_tile_advance(h->tilejobs.p, h->tilemak.p, (int)n, T, dp, (cfg.reg && cfg.exact) ? 1 : 0, h->stream);
+        launch_tile_advance(h->tilejobs.p, h->tilemak.p, (int)n, T, dp, (cfg.reg && cfg.exact) ? 1 : 0, coarse_on ? 1 : 0, variants_b[(size_t)b], h->stream);
       }
       HIPCHK(h, hipGetLastError());
       HIPCHK(h, hipMemcpyAsync(got.data(), h->tilejobs.p, n * sizeof(TileJob), hipMemcpyDeviceToHost, h->stream));
@@ -696,6 +708,8 @@ int run_tiled_phase(wfm_handle* h, wfm_seqset* S, const DevPen& dp, int scope, c
             tile_cells += (uint64_t)h_cells_sum(tj[i].pl, tj[i].tl, tj[i].sub, base + 1, base + steps);
           }
         }
+        if (got[i].fine_s == -1 && tj[i].fine_s != -1)  // the block in which the directions met ran once more, for its per-score maxima (TileJob::fine_s)
+          for (int d = 0; d < 2; ++d) tile_cells += (uint64_t)h_cells_sum(tj[i].pl, tj[i].tl, tj[i].sub, got[i].s0 + 1, got[i].s0 + T);
         tj[i] = got[i];
         active[i] = (char)(got[i].active != 0);
         fmax[i] = got[i].fmax; rmax[i] = got[i].rmax;
@@ -996,6 +1010,8 @@ int align_resident_impl(wfm_handle* h, const wfm_penalties_t* pen, wfm_seqset* S
   std::vector<BpJob> jobs;
   std::vector<int> tiled;
   std::vector<int64_t> ring2;
+  std::vector<int32_t> fine_from;
+  const int fine_margin = getenv("WFM_TILE_FINE_MARGIN") ? atoi(getenv("WFM_TILE_FINE_MARGIN")) : 48;
   const TileCfg tcfg = tile_cfg(*pen, scope);
   // WFM_TILE_V2=0: every tile on the byte kernel (wfa_tile_reg_kernel) -- the A/B switch of the packed kernel (wfa_tile2.hip)
   const bool tile_v2 = !(getenv("WFM_TILE_V2") && atoi(getenv("WFM_TILE_V2")) == 0);
@@ -1037,7 +1053,7 @@ int align_resident_impl(wfm_handle* h, const wfm_penalties_t* pen, wfm_seqset* S
       size_t ring_elems = 0;
       size_t i = i0;
       int maxw = 0;
-      tiled.clear(); ring2.clear();
+      tiled.clear(); ring2.clear(); fine_from.clear();
       for (; i < bp_nodes.size(); ++i) {
         const Node& nd = bp_nodes[i];
         const ProbMeta& pm = S->meta[nd.prob];
@@ -1094,7 +1110,12 @@ int align_resident_impl(wfm_handle* h, const wfm_penalties_t* pen, wfm_seqset* S
         // tile kernel then hands a lone long run to the whole wave at once (wfa_tile2.hip, tail_direct).  Whether the bound also CUTS the rows (sub below) is another matter.
         if (j.packed && nd.sub != SUB_NONE && (int64_t)nd.sub * 16 < (int64_t)nd.pl + nd.tl) j.packed |= 2;
         band_jobs += band > 0;
-        if (tile_it) { tiled.push_back((int)jobs.size()); ring2.push_back((int64_t)(ring_elems + need / 2)); }
+        if (tile_it) {
+          tiled.push_back((int)jobs.size()); ring2.push_back((int64_t)(ring_elems + need / 2));
+          // per-score maxima from here on (TileJob::fine_s): a child's directions meet near half its score (the trigger -- the sum of the two largest
+          // antidiagonals -- can fire a little earlier, never later); a root's score is anybody's guess
+          fine_from.push_back(nd.score_rem == INT_MAX ? INT_MAX : std::max(0, nd.score_rem / 2 - fine_margin));
+        }
         node_of.push_back((int32_t)i);
         ring_elems += need;
         // widest wavefront this job can reach: 2 diagonals per score of one direction (~half the total score)
@@ -1110,7 +1131,7 @@ int align_resident_impl(wfm_handle* h, const wfm_penalties_t* pen, wfm_seqset* S
         {
           double tms = 0; uint64_t tcells = 0;
           const auto tw0 = std::chrono::steady_clock::now();
-          rc = run_tiled_phase(h, S, dp, scope, tcfg, tcfg.T, false, jobs, tiled, ring2, tms, tcells, level);
+          rc = run_tiled_phase(h, S, dp, scope, tcfg, tcfg.T, false, jobs, tiled, ring2, tms, tcells, level, &fine_from);
           if (rc == WFM_OK && tcfg.T_refine > 0 && tcfg.T_refine < tcfg.T && !(tcfg.reg && tcfg.exact))
             rc = run_tiled_phase(h, S, dp, scope, tcfg, tcfg.T_refine, true, jobs, tiled, ring2, tms, tcells, level);
           wall_tile += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tw0).count();

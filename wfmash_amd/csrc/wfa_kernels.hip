@@ -763,12 +763,22 @@ __global__ __launch_bounds__(NTMAX) void wfa_tile_reg_kernel(const uint8_t* __re
 // wavefronts met inside the block (or that ran out of steps) goes inactive with its state still at the
 // block's START -- wfa_bp_kernel redoes that block step by step; the others move on to the next block.
 // one wave per job: the T per-score maxima are read once, prefix maxima replace the sequential replay
+// (round 6) `coarse`: wfa_tile2_kernel kept ONE maximum per direction for a block that ends below TileJob::fine_s (in the block's last slot: the
+// prefix maxima below make of it what the per-score maxima would have left at the block's end, and the running maxima are monotone, so "the
+// directions met in this block" is decided exactly).  Such a block runs again with per-score maxima (mode 5) before the run up to the meeting point.
 __global__ __launch_bounds__(64) void wfa_tile_advance_kernel(TileJob* __restrict__ jobs, int32_t* __restrict__ mak, int njobs, int T, DevPen pen,
-                                                              int exact) {
+                                                              int exact, int coarse, int launched) {
   const int i = blockIdx.x, lane = threadIdx.x;
   if (i >= njobs) return;
   TileJob J = jobs[i];
   if (!J.active) return;
+  if (coarse && (J.packed & 1)) {
+    // `launched`: which instantiations of wfa_tile2_kernel ran this block (bit 0 without, bit 1 with per-score maxima).  The host leaves out the
+    // one it expects no tile for; a job whose state asks for it all the same (mode 5 set by the block before, inside the host's chunk) has not
+    // moved and waits for the next chunk
+    const bool job_fine = J.mode == 5 || (J.mode == 0 && J.s0 + T >= J.fine_s);
+    if (!(launched & (job_fine ? 2 : 1))) return;
+  }
   int32_t* mf = mak + ((int64_t)i * 2 + 0) * T;
   int32_t* mr = mak + ((int64_t)i * 2 + 1) * T;
   if (J.mode == 1) {
@@ -813,7 +823,12 @@ __global__ __launch_bounds__(64) void wfa_tile_advance_kernel(TileJob* __restric
   if (lane != 0) return;
   const int64_t max_steps = (int64_t)(pen.o1 + pen.o2) * 4 + (int64_t)(J.pl + J.tl + 2) * max(pen.x, max(pen.e1, pen.e2)) * 2 + 256;
   J.nblocks += 1;
-  if (term && exact) {
+  const bool was_coarse = coarse && (J.packed & 1) && J.mode == 0 && J.s0 + T < J.fine_s;  // (wfa_tile2_kernel's own test)
+  if (term && exact && was_coarse) {
+    // the same block again, with a maximum per score this time: same input ring, same running maxima.  fine_s = -1 tells the host that this
+    // job computed the block once more than nblocks says (its cell count), and keeps every later block of the job fine
+    J.mode = 5; J.fine_s = -1; J.nblocks -= 1;
+  } else if (term && exact) {
     // redo this block, but only up to the meeting point (forward tf steps, reverse tr): same input ring
     J.mode = 1; J.tf = tf; J.tr = tr; J.last_fwd = last_fwd;
     J.fmax = fm; J.rmax = rm;
@@ -822,6 +837,7 @@ __global__ __launch_bounds__(64) void wfa_tile_advance_kernel(TileJob* __restric
   } else {
     J.fmax = fm; J.rmax = rm;
     J.s0 += T;
+    J.mode = 0;
     const int64_t t = J.ring_in; J.ring_in = J.ring_out; J.ring_out = t;
   }
   jobs[i] = J;
@@ -1413,8 +1429,8 @@ void launch_tile(const uint8_t* seq, int32_t* ring, const TileJob* jobs, const T
     hipLaunchKernelGGL(r128::wfa_tile_kernel, dim3(ntasks), dim3(threads), lds_bytes, st, seq, ring, jobs, tasks, mak, T, Wt, pen, scope);
   }
 }
-void launch_tile_advance(TileJob* jobs, int32_t* mak, int njobs, int T, DevPen pen, int exact, hipStream_t st) {
-  hipLaunchKernelGGL(wfa_tile_advance_kernel, dim3(njobs), dim3(64), 0, st, jobs, mak, njobs, T, pen, exact);
+void launch_tile_advance(TileJob* jobs, int32_t* mak, int njobs, int T, DevPen pen, int exact, int coarse, int launched, hipStream_t st) {
+  hipLaunchKernelGGL(wfa_tile_advance_kernel, dim3(njobs), dim3(64), 0, st, jobs, mak, njobs, T, pen, exact, coarse, launched);
 }
 void launch_tile_reg(const uint8_t* seq, int32_t* ring, const TileJob* jobs, const TileTask* tasks, int32_t* mak, int ntasks,
                      int threads, int T, int C, bool cut, hipStream_t st) {

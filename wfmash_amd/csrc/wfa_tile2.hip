@@ -26,6 +26,26 @@
 #include "wfa_device.h"
 #include "wfa_pack.h"
 
+// WFM_TILE_TRACE (a build switch of its own, never the shipped library: scripts/tile_trace.sh): s_memtime stamps of one step's phases, per wave, of the
+// first 48 workgroups of every launch of more than 1024 tiles; the last such launch stays in g_tile_trace.
+#ifdef WFM_TILE_TRACE
+__device__ unsigned long long g_tile_trace[48 * 16 * 128 * 4];
+extern "C" int wfm_debug_tile_trace(unsigned long long* out, size_t n) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tile_trace), n * sizeof(unsigned long long), 0, hipMemcpyDeviceToHost);
+}
+#if WFM_TILE_TRACE == 1
+#define WFM_TRACE_STAMP(slot_) do { if (trace_on) { const unsigned long long ts_ = __builtin_readcyclecounter(); if (lane == 0) g_tile_trace[(((size_t)blockIdx.x * 16 + wv) * 128 + (t & 127)) * 4 + (slot_)] = ts_; } } while (0)
+#else
+#define WFM_TRACE_STAMP(slot_) do { } while (0)
+#endif
+// WFM_TILE_TRACE=2: one stamp per ten-step body and one each at the kernel's begin, before the step loop, after it and at the end (slots 120 .. 123 of
+// the wave's row): the split of a tile's life into snapshot load, steps and snapshot store without the per-step stamps' own cost
+#define WFM_TRACE_MARK(idx_) do { if (WFM_TILE_TRACE == 2 && trace_on2) { const unsigned long long ts_ = __builtin_readcyclecounter(); if (lane == 0) g_tile_trace[(((size_t)blockIdx.x * 16 + wv) * 128 + (idx_)) * 4] = ts_; } } while (0)
+#else
+#define WFM_TRACE_STAMP(slot_) do { } while (0)
+#define WFM_TRACE_MARK(idx_) do { } while (0)
+#endif
+
 namespace wfm {
 
 namespace {
@@ -148,7 +168,11 @@ __device__ __forceinline__ int pk_wave_tail(const PkSrc& S, unsigned oP, unsigne
 __device__ __forceinline__ uint32_t pk16_win(lds_words w, unsigned o) {
   typedef const __attribute__((address_space(3))) char* lds_bytes;
   const lds_words q = (lds_words)((lds_bytes)w + ((o >> 2) & (unsigned)((PK_WIN_DW - 1) * 4)));
-  return alignbit32(q[1], q[0], o << 1);
+  // (the bit offset as o + o: v_lshlrev_b32 issues at 4 cycles per wave on gfx950, v_add_u32 at 2 -- profiles/r6_valu_issue.md; the compiler
+  // turns any source form of the doubling back into the shift)
+  unsigned sh;
+  asm("v_add_u32 %0, %1, %1" : "=v"(sh) : "v"(o));
+  return alignbit32(q[1], q[0], sh);
 }
 template <bool MASKED = false>
 __device__ __forceinline__ void pk_extend2(const PkSrc& SRC, const int (&m)[2], const unsigned (&oP)[2], const unsigned (&oT)[2], const int (&maxn)[2], int (&ext)[2],
@@ -192,6 +216,55 @@ __device__ __forceinline__ void pk_extend2(const PkSrc& SRC, const int (&m)[2], 
         tail = n >= 80 && maxn[c] > 80;
       }
       // runs longer than 80 bases: the wave finishes them together (uniform control flow: every lane is here)
+      if (__any(tail)) ext[c] = pk_wave_tail(SRC, oP[c], oT[c], ext[c], maxn[c], tail);
+    }
+  }
+}
+
+
+// Round 6: the same staged extension for the FAST form with the flag bookkeeping taken out of the step's vector stream (profiles/r6_valu_issue.md:
+// compares and selects issue at 4 cycles per wave like everything but add / sub / logic, and the round-5 form spent 14 of its 103 vector
+// instructions per step on flags: live, 16 bases agree, more than 16 left, beyond the window -- each its own compare per cell -- and on turning the
+// two `more` masks into 0 / 1 registers and back because they were alive across the rare branch).  Here: a cell goes on past its probe when it is
+// live and its clipped extension is 16 (one compare; a cell with exactly 16 bases left makes a harmless visit to stage 2, which clips again);
+// beyond the window <=> m > lim (one signed compare against a per-cell constant, false for a cell that holds nothing); the two masks stay
+// wave-level bit masks and a lane looks its own bit up inside the rare branches only (__builtin_amdgcn_ballot_w64 on the compare itself: HIP's
+// __ballot goes through a 0 / 1 register and a second compare).
+__device__ __forceinline__ void pk_extend2_fast(const PkSrc& SRC, const int (&m)[2], const unsigned (&oP)[2], const unsigned (&oT)[2], const int (&maxn)[2],
+                                                const int (&lim)[2], int (&ext)[2], bool tail_direct) {
+  unsigned long long mm[2];
+  bool outw = false;
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    const uint32_t x = pk16_win(SRC.lP, oP[c]) ^ pk16_win(SRC.lT, oT[c]);
+    ext[c] = min((int)first_diff16(x), maxn[c]);
+    mm[c] = __builtin_amdgcn_ballot_w64(m[c] >= 0) & __builtin_amdgcn_ballot_w64(ext[c] >= 16);  // (one ballot of the conjunction goes through a 0 / 1 register)
+    outw |= m[c] > lim[c];
+  }
+  if (__builtin_expect(__any(outw), 0)) {  // rare: the probe again from the global mirror for the cells beyond the windows
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      bool more = m[c] >= 0 && ext[c] >= 16;
+      if (m[c] > lim[c]) {
+        const uint32_t x = pk16(SRC.gP, oP[c]) ^ pk16(SRC.gT, oT[c]);
+        ext[c] = min((int)first_diff16(x), maxn[c]);
+        more = ext[c] >= 16;
+      }
+      mm[c] = __builtin_amdgcn_ballot_w64(more);
+    }
+  }
+  const unsigned lane = threadIdx.x & 63u;
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    if (__builtin_expect(mm[c] != 0, 0)) {
+      const bool more = (mm[c] >> lane) & 1ull;
+      bool tail = false;
+      if (tail_direct && __popcll(mm[c]) <= (unsigned)TAIL_DIRECT_MAX) tail = more;  // (pk_extend2: a lone long run of a near-identical job goes to the wave at once)
+      else if (more) {
+        const int n = pk_stage2(SRC, oP[c], oT[c]);
+        ext[c] = min(n, maxn[c]);
+        tail = n >= 80 && maxn[c] > 80;
+      }
       if (__any(tail)) ext[c] = pk_wave_tail(SRC, oP[c], oT[c], ext[c], maxn[c], tail);
     }
   }
@@ -254,10 +327,16 @@ void launch_seq_pack(const uint8_t* seq, uint32_t* pk, int64_t nwords, int64_t n
 //  * the per-step maximum of the antidiagonals goes to a slot of the wave's own (plain store) instead of through an LDS atomic (a scalar loop);
 //  * the mailbox's buffer index is the step's number mod 3 at compile time (adjacent steps never share a buffer, two steps apart may);
 //  * the probe's window words are addressed by masking (pk_extend2<true>), dead cells keep what the arithmetic leaves them with.
-template <int NTMAX, bool P2, bool FAST>
+// FINE (round 6, FAST phase-1 form only): the per-score maxima of the antidiagonals -- a six-step DPP reduction per wave and score, a seventh of
+// the step's vector issue -- are kept only by the FINE instantiation, which takes the tiles of the jobs whose block needs them (TileJob::fine_s:
+// the block in which the directions meet); the other instantiation takes all other tiles and keeps one running maximum per lane, reduced once
+// per block.  Both are launched over the same task list (the host leaves out the one no job of the block can need); a tile that is not this
+// instantiation's ends before its first load.  (One kernel with a runtime test was built first: the optimizer then neither unrolls the ten-step
+// body nor keeps the delay lines in registers; two copies of the loop in one kernel spill.)
+template <int NTMAX, bool P2, bool FAST, bool FINE = true>
 __global__ __launch_bounds__(NTMAX) void wfa_tile2_kernel(const uint32_t* __restrict__ pk, int32_t* __restrict__ ring_arena,
                                                         const TileJob* __restrict__ jobs, const TileTask* __restrict__ tasks,
-                                                        int32_t* __restrict__ mak_out, int T, int32_t* __restrict__ p2_arena) {
+                                                        int32_t* __restrict__ mak_out, int T, int32_t* __restrict__ p2_arena, int coarse) {
   constexpr int C = 2, LB = 25, H = LB + 1, NCL = 5, DEP = 6, E1 = 2;
   constexpr bool WAVE1 = NTMAX == 64;  // one wave: no mailbox; __syncthreads() is a wave barrier for a 64-thread workgroup
   // mailbox of the wave edges: [parity][slot][side][value].  Side 0 of slot w holds what lane 63 of wave w - 1 hands to lane 0 of wave w, side 1 of
@@ -291,6 +370,10 @@ __global__ __launch_bounds__(NTMAX) void wfa_tile2_kernel(const uint32_t* __rest
   // level half the lanes of a launch held no cell (20 % at the deeper levels).
   const int nw = min((int)(blockDim.x >> 6), (tk.core_hi + halo - kA) / (64 * C) + 1), NT = nw * 64;
   if (wv >= nw) return;
+#ifdef WFM_TILE_TRACE
+  const bool trace_on2 = !P2 && FAST && !WAVE1 && gridDim.x > 1024 && blockIdx.x < 48;
+#endif
+  WFM_TRACE_MARK(120);
   if (tid < 2) s_wlo[tid] = INT32_MAX;
   if (!WAVE1) for (int i = tid; i < (int)(sizeof(s_edge) / sizeof(int)); i += NT) ((int*)s_edge)[i] = WF_NULL;
   const int64_t aP = dir == 0 ? J.p_fwd : J.p_rev, aT = dir == 0 ? J.t_fwd : J.t_rev;  // byte index of the sequences' first bases
@@ -301,6 +384,17 @@ __global__ __launch_bounds__(NTMAX) void wfa_tile2_kernel(const uint32_t* __rest
   int32_t* rout = ring_arena + J.ring_out + J.koff + (int64_t)dir * 5 * RING * width;
   const int kmax = tk.core_hi + halo;  // last diagonal of the tile
   const int Tn = (!P2 && J.mode == 1) ? (dir == 0 ? J.tf : J.tr) : T;
+  // per-score maxima of the antidiagonals only where the advance kernel reads them score by score (TileJob::fine_s): the block that runs again
+  // because the directions met in it (mode 5), and the blocks from fine_s on -- the FINE instantiation's tiles.  Elsewhere one running maximum per
+  // lane and ONE wave reduction per block (mode 1, the run up to the meeting point: none at all -- nobody reads its maxima)
+  if (!P2 && FAST) {
+    const bool fine = !coarse || J.mode == 5 || (J.mode == 0 && sbase + T >= J.fine_s);
+    if (fine != FINE) return;
+  }
+  // (the running maximum of a lane lives in LDS, one ds_max_i32 per step into the lane's own word: as a register carried around the step loop it
+  // kept the optimizer from unrolling the ten-step body -- the delay lines, indexed by the step's residue class, went to scratch memory)
+  __shared__ int s_run[(!P2 && FAST && !FINE) ? NTMAX : 1];
+  if (!P2 && FAST && !FINE) s_run[tid] = 0;
 
   // Mh[c][r][e] = M[sr - 5 e][k0+c], sr = the newest score <= current with (sr - s0) mod 5 == r
   int Mh[C][NCL][DEP];
@@ -334,7 +428,7 @@ __global__ __launch_bounds__(NTMAX) void wfa_tile2_kernel(const uint32_t* __rest
     }
   }
   const int MKS = T + 1;  // stride of a wave's row of s_makr (FAST)
-  for (int t = tid; t < (FAST && !WAVE1 ? nw * MKS : MKS); t += NT) s_makr[t] = 0;
+  if (FINE && !P2) for (int t = tid; t < (FAST && !WAVE1 ? nw * MKS : MKS); t += NT) s_makr[t] = 0;
   // ---- per-cell constants
   unsigned hmaxu[C];  // largest offset inside the problem on this diagonal: min(tl, pl + k)
   int s_last[C];      // the last score at which the cell is inside its row (columns outside [-pl, tl]: never)
@@ -382,8 +476,9 @@ __global__ __launch_bounds__(NTMAX) void wfa_tile2_kernel(const uint32_t* __rest
     s_winT[i] = SRC.gT[i];
   }
   int cP[C];  // oP of cell c = m + cP[c]  (v = m - k)
+  int wlim[C];  // FAST: the largest offset whose 16-base probe stays inside both windows (pk_extend2_fast)
 #pragma unroll
-  for (int c = 0; c < C; ++c) cP[c] = dP - (k0 + c);
+  for (int c = 0; c < C; ++c) { cP[c] = dP - (k0 + c); wlim[c] = PK_WIN_BASES - 1 - max(cP[c], dT); }
   // (Tried in round 4, as in round 3 on the byte kernel, and taken out again: letting a wave skip the steps at which it holds no
   // cell -- before the triangle reaches its diagonals, 26 scores after the score bound has cut off its last one; two scalar
   // compares per step against wave-uniform bounds.  The kernel sits at its 128 registers: the extra control flow made it spill,
@@ -395,7 +490,9 @@ __global__ __launch_bounds__(NTMAX) void wfa_tile2_kernel(const uint32_t* __rest
   // and shifts by two (six moves for two steps instead of ten); the two-deep I1 / D1 lines need no move at all (the row of score s - 2
   // sits where the new one goes: entry s & 1 of the body's own count).
   constexpr int UB = FAST ? 2 * NCL : NCL;
+  WFM_TRACE_MARK(121);
   for (int tb = 0; tb < Tn; tb += UB) {
+    WFM_TRACE_MARK(tb / UB);
 #pragma unroll
   for (int jj = 1; jj <= UB; ++jj) {
     const int t = tb + jj;
@@ -409,12 +506,17 @@ __global__ __launch_bounds__(NTMAX) void wfa_tile2_kernel(const uint32_t* __rest
 #define M_S10(c_) (vB ? Mh[c_][cl][0] : Mh[c_][cl][1])
 #define M_S25(c_) (vB ? Mh[c_][cl][3] : Mh[c_][cl][4])
     int lM10, lM25, lI1, lI2, rM10, rM25, rD1, rD2;
+#ifdef WFM_TILE_TRACE
+    const bool trace_on = !P2 && FAST && !WAVE1 && gridDim.x > 1024 && blockIdx.x < 48;
+#endif
+    WFM_TRACE_STAMP(3);  // the step begins (the previous one's bookkeeping is issued)
     if (!WAVE1) {
       const int par = FAST ? (jj & 1) : (t & 1);  // (a body of ten steps: its own count alternates across bodies as well)
       // publish the wave-edge history values needed by the neighbouring waves in this step
       if (lane == 63) { int* e = s_edge[par][wv + 1][0]; e[0] = M_S10(C - 1); e[1] = M_S25(C - 1); e[2] = I1h[C - 1][e1x]; e[3] = I2h[C - 1]; }
       if (lane == 0)  { int* e = s_edge[par][wv][1];     e[0] = M_S10(0);     e[1] = M_S25(0);     e[2] = D1h[0][e1x];     e[3] = D2h[0]; }
       __syncthreads();
+      WFM_TRACE_STAMP(0);  // the barrier has let go
       lM10 = from_prev_lane0(M_S10(C - 1)); lM25 = from_prev_lane0(M_S25(C - 1));
       lI1 = from_prev_lane0(I1h[C - 1][e1x]); lI2 = from_prev_lane0(I2h[C - 1]);
       rM10 = from_next_lane0(M_S10(0)); rM25 = from_next_lane0(M_S25(0));
@@ -454,7 +556,7 @@ __global__ __launch_bounds__(NTMAX) void wfa_tile2_kernel(const uint32_t* __rest
       bool special = false;
 #pragma unroll
       for (int c = 0; c < C; ++c) special |= (nM[c] > (int)hmaxu[c]) | (s > s_last[c]);
-      if (__any(special)) {
+      if (__builtin_expect(__any(special), 0)) {
 #pragma unroll
         for (int c = 0; c < C; ++c) {
           const unsigned hm = hmaxu[c];
@@ -481,7 +583,13 @@ __global__ __launch_bounds__(NTMAX) void wfa_tile2_kernel(const uint32_t* __rest
       oP[c] = (unsigned)(m + cP[c]); oT[c] = (unsigned)(m + dT);
       maxn[c] = (FAST || m >= 0) ? (int)hmaxu[c] - m : 0;
     }
-    pk_extend2<FAST>(SRC, nM, oP, oT, maxn, ext, lowdiv);
+    WFM_TRACE_STAMP(1);  // recurrences issued
+    if (FAST) pk_extend2_fast(SRC, nM, oP, oT, maxn, wlim, ext, lowdiv);
+    else pk_extend2<false>(SRC, nM, oP, oT, maxn, ext, lowdiv);
+#ifdef WFM_TILE_TRACE
+    if (trace_on) asm volatile("" :: "v"(ext[0]), "v"(ext[1]));
+#endif
+    WFM_TRACE_STAMP(2);  // extension known
     int mak = 0;
 #pragma unroll
     for (int c = 0; c < C; ++c) {
@@ -505,7 +613,7 @@ __global__ __launch_bounds__(NTMAX) void wfa_tile2_kernel(const uint32_t* __rest
       }
     }
     // stream the last H rows of I/D of the core to the output snapshot
-    if (!P2 && t > Tn - H) {
+    if (!P2 && __builtin_expect(t > Tn - H, 0)) {
 #pragma unroll
       for (int c = 0; c < C; ++c) {
         const int k = k0 + c;
@@ -544,14 +652,20 @@ __global__ __launch_bounds__(NTMAX) void wfa_tile2_kernel(const uint32_t* __rest
 #undef M_S5
 #undef M_S10
 #undef M_S25
-    mak = wave_max63(mak);
-    if (FAST) { if (lane == 63) s_makr[(WAVE1 ? 0 : wv * MKS) + t] = mak; }
-    else if (lane == 63 && mak > 0) {
-      if (WAVE1) s_makr[t] = mak;
-      else atomicMax(&s_makr[t], mak);
+    if (!P2) {  // (the rows of phase 2 are tested cell by cell: nobody reads maxima of theirs)
+      if (FAST && !FINE) (void)__hip_atomic_fetch_max(&s_run[tid], mak, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // ds_max_i32, nothing returned
+      else {
+        mak = wave_max63(mak);
+        if (FAST) { if (lane == 63) s_makr[(WAVE1 ? 0 : wv * MKS) + t] = mak; }
+        else if (lane == 63 && mak > 0) {
+          if (WAVE1) s_makr[t] = mak;
+          else atomicMax(&s_makr[t], mak);
+        }
+      }
     }
   }
   }
+  WFM_TRACE_MARK(122);
   // ---- output snapshot: the newest H rows of M for the core ----
   if (P2) return;
   if (FAST) {
@@ -612,8 +726,18 @@ __global__ __launch_bounds__(NTMAX) void wfa_tile2_kernel(const uint32_t* __rest
     case 3: write_rows(std::integral_constant<int, 3>{}); break;
     default: write_rows(std::integral_constant<int, 4>{}); break;
   }
-  __syncthreads();
   int32_t* mk = mak_out + ((int64_t)tk.job * 2 + dir) * T;
+  WFM_TRACE_MARK(123);
+  if (!FINE) {
+    // one maximum for the whole block, in the block's last slot: the advance kernel's prefix maxima make of it what the per-score form would
+    // have left at the block's end -- enough to say whether the directions met in this block (they are run again with per-score maxima then)
+    if (J.mode != 1) {
+      const int makrun = wave_max63(s_run[tid]);
+      if (lane == 63 && makrun > 0) atomicMax(&mk[T - 1], makrun);
+    }
+    return;
+  }
+  __syncthreads();
   for (int t = 1 + tid; t <= T; t += NT) {
     int v = s_makr[t];
     if (FAST && !WAVE1) for (int w = 1; w < nw; ++w) v = max(v, s_makr[w * MKS + t]);
@@ -625,25 +749,41 @@ static bool tile_fast() {  // (read per launch: the tests switch forms inside on
   const char* e = getenv("WFM_TILE_FAST");
   return !(e && atoi(e) == 0);
 }
+bool tile2_coarse_maxima() {  // (read per launch, like tile_fast)
+  const char* e = getenv("WFM_TILE_COARSE");
+  return tile_fast() && !(e && atoi(e) == 0);
+}
+// variants: bit 0 -- the instantiation without per-score maxima, bit 1 -- the one with them (wfa_tile2_kernel, FINE); WFM_TILE_COARSE=0 / the
+// round-4 form: every tile keeps per-score maxima, one launch
 void launch_tile2(const uint32_t* pk, int32_t* ring, const TileJob* jobs, const TileTask* tasks, int32_t* mak, int ntasks, int threads, int T,
-                  hipStream_t st) {
+                  int variants, hipStream_t st) {
   const size_t lds1 = (size_t)(T + 1) * 4;
   if (tile_fast()) {
-    if (threads <= 64) hipLaunchKernelGGL((wfa_tile2_kernel<64, false, true>), dim3(ntasks), dim3(64), lds1, st, pk, ring, jobs, tasks, mak, T, (int32_t*)nullptr);
-    else hipLaunchKernelGGL((wfa_tile2_kernel<1024, false, true>), dim3(ntasks), dim3(threads), lds1 * (size_t)(threads / 64), st, pk, ring, jobs, tasks, mak, T, (int32_t*)nullptr);
+    const int coarse = tile2_coarse_maxima() ? 1 : 0;
+    if (!coarse) variants = 2;
+    // (WFM_TILE_LDS_PAD: bytes of LDS nobody uses, to take workgroups off a CU -- the occupancy experiment of DESIGN section 5, round 6)
+    const size_t pad = getenv("WFM_TILE_LDS_PAD") ? (size_t)atoi(getenv("WFM_TILE_LDS_PAD")) : 0;
+    if (variants & 1) {
+      if (threads <= 64) hipLaunchKernelGGL((wfa_tile2_kernel<64, false, true, false>), dim3(ntasks), dim3(64), 0, st, pk, ring, jobs, tasks, mak, T, (int32_t*)nullptr, coarse);
+      else hipLaunchKernelGGL((wfa_tile2_kernel<1024, false, true, false>), dim3(ntasks), dim3(threads), pad, st, pk, ring, jobs, tasks, mak, T, (int32_t*)nullptr, coarse);
+    }
+    if (variants & 2) {
+      if (threads <= 64) hipLaunchKernelGGL((wfa_tile2_kernel<64, false, true, true>), dim3(ntasks), dim3(64), lds1, st, pk, ring, jobs, tasks, mak, T, (int32_t*)nullptr, coarse);
+      else hipLaunchKernelGGL((wfa_tile2_kernel<1024, false, true, true>), dim3(ntasks), dim3(threads), lds1 * (size_t)(threads / 64), st, pk, ring, jobs, tasks, mak, T, (int32_t*)nullptr, coarse);
+    }
   } else {
-    if (threads <= 64) hipLaunchKernelGGL((wfa_tile2_kernel<64, false, false>), dim3(ntasks), dim3(64), lds1, st, pk, ring, jobs, tasks, mak, T, (int32_t*)nullptr);
-    else hipLaunchKernelGGL((wfa_tile2_kernel<1024, false, false>), dim3(ntasks), dim3(threads), lds1, st, pk, ring, jobs, tasks, mak, T, (int32_t*)nullptr);
+    if (threads <= 64) hipLaunchKernelGGL((wfa_tile2_kernel<64, false, false, true>), dim3(ntasks), dim3(64), lds1, st, pk, ring, jobs, tasks, mak, T, (int32_t*)nullptr, 0);
+    else hipLaunchKernelGGL((wfa_tile2_kernel<1024, false, false, true>), dim3(ntasks), dim3(threads), lds1, st, pk, ring, jobs, tasks, mak, T, (int32_t*)nullptr, 0);
   }
 }
 void launch_tile2_p2(const uint32_t* pk, int32_t* ring, const TileJob* jobs, const TileTask* tasks, int ntasks, int threads, int32_t* p2, hipStream_t st) {
   const size_t lds1 = (size_t)(P2K + 1) * 4;
   if (tile_fast()) {
-    if (threads <= 64) hipLaunchKernelGGL((wfa_tile2_kernel<64, true, true>), dim3(ntasks), dim3(64), lds1, st, pk, ring, jobs, tasks, (int32_t*)nullptr, P2K, p2);
-    else hipLaunchKernelGGL((wfa_tile2_kernel<1024, true, true>), dim3(ntasks), dim3(threads), lds1 * (size_t)(threads / 64), st, pk, ring, jobs, tasks, (int32_t*)nullptr, P2K, p2);
+    if (threads <= 64) hipLaunchKernelGGL((wfa_tile2_kernel<64, true, true, false>), dim3(ntasks), dim3(64), 0, st, pk, ring, jobs, tasks, (int32_t*)nullptr, P2K, p2, 0);
+    else hipLaunchKernelGGL((wfa_tile2_kernel<1024, true, true, false>), dim3(ntasks), dim3(threads), 0, st, pk, ring, jobs, tasks, (int32_t*)nullptr, P2K, p2, 0);
   } else {
-    if (threads <= 64) hipLaunchKernelGGL((wfa_tile2_kernel<64, true, false>), dim3(ntasks), dim3(64), lds1, st, pk, ring, jobs, tasks, (int32_t*)nullptr, P2K, p2);
-    else hipLaunchKernelGGL((wfa_tile2_kernel<1024, true, false>), dim3(ntasks), dim3(threads), lds1, st, pk, ring, jobs, tasks, (int32_t*)nullptr, P2K, p2);
+    if (threads <= 64) hipLaunchKernelGGL((wfa_tile2_kernel<64, true, false, true>), dim3(ntasks), dim3(64), lds1, st, pk, ring, jobs, tasks, (int32_t*)nullptr, P2K, p2, 0);
+    else hipLaunchKernelGGL((wfa_tile2_kernel<1024, true, false, true>), dim3(ntasks), dim3(threads), lds1, st, pk, ring, jobs, tasks, (int32_t*)nullptr, P2K, p2, 0);
   }
 }
 
