@@ -11,14 +11,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 os.environ.setdefault("WFM_OVERLAP", "0")
 from wfmash_amd import capi, synth
-capi.LIB_PATH = os.path.join(ROOT, "wfmash_amd", "libwfmash_hip_trace.so")
+capi.LIB_PATH = os.path.join(ROOT, "wfmash_amd", os.environ.get("TRACE_LIB", "libwfmash_hip_trace.so"))
 L = capi.load()
 L.wfm_debug_tile_trace.restype = C.c_int
 L.wfm_debug_tile_trace.argtypes = [C.c_void_p, C.c_size_t]
 h = capi.Handle(0)
 pairs = synth.pairs("C3", n_pairs=int(os.environ.get("PAIRS", "64")))
 res = h.align(pairs)
-assert all(r.status == 0 for r in res)
+print("statuses ok:", all(r.status == 0 for r in res))
 n = 48 * 16 * 128 * 4
 buf = np.zeros(n, dtype=np.uint64)
 assert L.wfm_debug_tile_trace(buf.ctypes.data_as(C.c_void_p), n) == 0
@@ -41,4 +41,13 @@ print("step loop (100 steps):                  ", f(loop))
 print("snapshot store:                         ", f(store))
 print("whole life of a wave:                   ", f(life))
 print("cycles per step (bodies 1 .. 8):        ", f(body))
+hist, edges = np.histogram(np.array(loop) / 100.0, bins=[0, 200, 400, 600, 800, 1000, 1200, 1400, 1600, 2000, 3000, 100000])
+print("waves by cycles per step of their loop:", " ".join(f"<{int(e)}:{h}" for h, e in zip(hist, edges[1:])))
+# the waves of one workgroup share their barriers: per workgroup the loop time of its slowest wave and the spread
+wg = []
+for b in range(48):
+    ls = [a[b, w, 122] - a[b, w, 121] for w in range(16) if a[b, w, 120] != 0 and 0 < a[b, w, 122] - a[b, w, 121] < 5_000_000]
+    if ls:
+        wg.append((len(ls), min(ls), max(ls)))
+print("per workgroup (waves, fastest loop, slowest loop):", wg[:24])
 h.close()

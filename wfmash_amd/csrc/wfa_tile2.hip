@@ -230,18 +230,26 @@ __device__ __forceinline__ void pk_extend2(const PkSrc& SRC, const int (&m)[2], 
 // beyond the window <=> m > lim (one signed compare against a per-cell constant, false for a cell that holds nothing); the two masks stay
 // wave-level bit masks and a lane looks its own bit up inside the rare branches only (__builtin_amdgcn_ballot_w64 on the compare itself: HIP's
 // __ballot goes through a 0 / 1 register and a second compare).
-__device__ __forceinline__ void pk_extend2_fast(const PkSrc& SRC, const int (&m)[2], const unsigned (&oP)[2], const unsigned (&oT)[2], const int (&maxn)[2],
-                                                const int (&lim)[2], int (&ext)[2], bool tail_direct) {
-  unsigned long long mm[2];
-  bool outw = false;
+// (round 6, the pipelined step: the probe's straight-line part -- addresses, window words, first difference, the wave's two masks -- apart from
+// the rare branches that follow it, so that the step's recurrences can stand between the two in ONE basic block and overlap the probe's LDS
+// round trip: pk_probe2_fast, then pk_rare2_fast.)
+struct PkProbe { unsigned long long mm[2]; bool outw; };
+__device__ __forceinline__ PkProbe pk_probe2_fast(const PkSrc& SRC, const int (&m)[2], const unsigned (&oP)[2], const unsigned (&oT)[2], const int (&maxn)[2],
+                                                  const int (&lim)[2], int (&ext)[2]) {
+  PkProbe R;
+  R.outw = false;
 #pragma unroll
   for (int c = 0; c < 2; ++c) {
     const uint32_t x = pk16_win(SRC.lP, oP[c]) ^ pk16_win(SRC.lT, oT[c]);
     ext[c] = min((int)first_diff16(x), maxn[c]);
-    mm[c] = __builtin_amdgcn_ballot_w64(m[c] >= 0) & __builtin_amdgcn_ballot_w64(ext[c] >= 16);  // (one ballot of the conjunction goes through a 0 / 1 register)
-    outw |= m[c] > lim[c];
+    R.mm[c] = __builtin_amdgcn_ballot_w64(m[c] >= 0) & __builtin_amdgcn_ballot_w64(ext[c] >= 16);  // (one ballot of the conjunction goes through a 0 / 1 register)
+    R.outw |= m[c] > lim[c];
   }
-  if (__builtin_expect(__any(outw), 0)) {  // rare: the probe again from the global mirror for the cells beyond the windows
+  return R;
+}
+__device__ __forceinline__ void pk_rare2_fast(const PkSrc& SRC, PkProbe R, const int (&m)[2], const unsigned (&oP)[2], const unsigned (&oT)[2], const int (&maxn)[2],
+                                              const int (&lim)[2], int (&ext)[2], bool tail_direct) {
+  if (__builtin_expect(__any(R.outw), 0)) {  // rare: the probe again from the global mirror for the cells beyond the windows
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
       bool more = m[c] >= 0 && ext[c] >= 16;
@@ -250,16 +258,16 @@ __device__ __forceinline__ void pk_extend2_fast(const PkSrc& SRC, const int (&m)
         ext[c] = min((int)first_diff16(x), maxn[c]);
         more = ext[c] >= 16;
       }
-      mm[c] = __builtin_amdgcn_ballot_w64(more);
+      R.mm[c] = __builtin_amdgcn_ballot_w64(more);
     }
   }
   const unsigned lane = threadIdx.x & 63u;
 #pragma unroll
   for (int c = 0; c < 2; ++c) {
-    if (__builtin_expect(mm[c] != 0, 0)) {
-      const bool more = (mm[c] >> lane) & 1ull;
+    if (__builtin_expect(R.mm[c] != 0, 0)) {
+      const bool more = (R.mm[c] >> lane) & 1ull;
       bool tail = false;
-      if (tail_direct && __popcll(mm[c]) <= (unsigned)TAIL_DIRECT_MAX) tail = more;  // (pk_extend2: a lone long run of a near-identical job goes to the wave at once)
+      if (tail_direct && __popcll(R.mm[c]) <= (unsigned)TAIL_DIRECT_MAX) tail = more;  // (pk_extend2: a lone long run of a near-identical job goes to the wave at once)
       else if (more) {
         const int n = pk_stage2(SRC, oP[c], oT[c]);
         ext[c] = min(n, maxn[c]);
@@ -268,6 +276,11 @@ __device__ __forceinline__ void pk_extend2_fast(const PkSrc& SRC, const int (&m)
       if (__any(tail)) ext[c] = pk_wave_tail(SRC, oP[c], oT[c], ext[c], maxn[c], tail);
     }
   }
+}
+__device__ __forceinline__ void pk_extend2_fast(const PkSrc& SRC, const int (&m)[2], const unsigned (&oP)[2], const unsigned (&oT)[2], const int (&maxn)[2],
+                                                const int (&lim)[2], int (&ext)[2], bool tail_direct) {
+  const PkProbe R = pk_probe2_fast(SRC, m, oP, oT, maxn, lim, ext);
+  pk_rare2_fast(SRC, R, m, oP, oT, maxn, lim, ext, tail_direct);
 }
 
 }  // namespace
@@ -339,6 +352,13 @@ __global__ __launch_bounds__(NTMAX) void wfa_tile2_kernel(const uint32_t* __rest
                                                         int32_t* __restrict__ mak_out, int T, int32_t* __restrict__ p2_arena, int coarse) {
   constexpr int C = 2, LB = 25, H = LB + 1, NCL = 5, DEP = 6, E1 = 2;
   constexpr bool WAVE1 = NTMAX == 64;  // one wave: no mailbox; __syncthreads() is a wave barrier for a 64-thread workgroup
+  // PIPE (round 6): the extension of a step's row is made one step later.  Nothing reads M[s] before step s + 5 (its own diagonal's mismatch
+  // source; the neighbours read it at s + 10 and s + 25), while the step's chain -- barrier, mailbox, recurrences, probe, first difference, the
+  // ballots' branches, publish, barrier -- was 1300 cycles long whether one workgroup or two sat on the CU (scripts/tile_trace2.py).  Now the probe
+  // of row s - 1 is issued right behind the mailbox read of step s and the recurrences of step s run during its LDS round trip: two independent
+  // chains in one basic block instead of one chain of twice the length.  The row waits in pM[] (before its extension); its delay line takes it
+  // one step late, which no reader can see (a class's line is only read at its own steps).
+  constexpr bool PIPE = FAST && !P2;
   // mailbox of the wave edges: [parity][slot][side][value].  Side 0 of slot w holds what lane 63 of wave w - 1 hands to lane 0 of wave w, side 1 of
   // slot w what lane 0 of wave w hands to lane 63 of wave w - 1; slot 0's side 0 and the slot behind the last wave are never written and stay
   // NULL, so the edge lanes of a tile read their mailbox like all others and the wave shifts need no NULL to fall back on
@@ -490,7 +510,41 @@ __global__ __launch_bounds__(NTMAX) void wfa_tile2_kernel(const uint32_t* __rest
   // and shifts by two (six moves for two steps instead of ten); the two-deep I1 / D1 lines need no move at all (the row of score s - 2
   // sits where the new one goes: entry s & 1 of the body's own count).
   constexpr int UB = FAST ? 2 * NCL : NCL;
+  // PIPE: the snapshot's newest row (score s0, class 0) becomes the pending row -- extending it again finds nothing to add -- and its line is put
+  // into the state a class's line is in between its first visit of a body and the (late) completion of its second: the second visit of class 0
+  // is what the body's first step completes
+  int pM[C];
+  if (PIPE) {
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      pM[c] = Mh[c][0][0];
+      const int l1 = Mh[c][0][1], l2 = Mh[c][0][2], l3 = Mh[c][0][3], l4 = Mh[c][0][4], l5 = Mh[c][0][5];
+      Mh[c][0][DEP - 1] = l1; Mh[c][0][0] = l2; Mh[c][0][1] = l3; Mh[c][0][2] = l4; Mh[c][0][3] = l5;
+    }
+  }
+  // mailbox (FAST): where this lane's edge values go -- lane 63: side 0 of the slot of the wave above, lane 0: side 1 of its own wave's slot
+  constexpr int EDGE_PLANE = (WAVE1 ? 1 : 17) * 2 * 4;
+  const bool edge_lane = lane == 0 || lane == 63;
+  int* const edge_wr = lane == 63 ? &s_edge[0][WAVE1 ? 0 : wv + 1][0][0] : &s_edge[0][WAVE1 ? 0 : wv][1][0];
+  // a finished row into its class's line (jjx: the step's number within the body, 1 .. UB)
+  auto line_take = [&](auto JJX, const int (&row)[C]) {
+    constexpr int jjx = decltype(JJX)::value;
+    constexpr int clx = jjx % NCL;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      if (jjx <= NCL) Mh[c][clx][DEP - 1] = row[c];
+      else {
+        const int parked = Mh[c][clx][DEP - 1];
+#pragma unroll
+        for (int e = DEP - 1; e > 1; --e) Mh[c][clx][e] = Mh[c][clx][e - 2];
+        Mh[c][clx][1] = parked;
+        Mh[c][clx][0] = row[c];
+      }
+    }
+  };
   WFM_TRACE_MARK(121);
+  // (Tried in round 6 and taken out: a second copy of the body without the tests for the block's end and for the streaming of the gap rows,
+  // for the bodies that lie whole before the block's last H scores -- five scalar instructions less in 74 of 100 steps, and 164 bytes of spills.)
   for (int tb = 0; tb < Tn; tb += UB) {
     WFM_TRACE_MARK(tb / UB);
 #pragma unroll
@@ -513,6 +567,33 @@ __global__ __launch_bounds__(NTMAX) void wfa_tile2_kernel(const uint32_t* __rest
     if (!WAVE1) {
       const int par = FAST ? (jj & 1) : (t & 1);  // (a body of ten steps: its own count alternates across bodies as well)
       // publish the wave-edge history values needed by the neighbouring waves in this step
+      if (FAST) {
+        // (round 6) one store for both edges -- lane 63 hands its left-bound values to the slot of the wave above, lane 0 its right-bound ones to
+        // its own slot: four selects, one exec mask, one ds_write_b128 -- and the reads without a mask: every lane reads both neighbour slots (uniform
+        // addresses: broadcasts), and the wave shifts take what was read as the value the edge lane KEEPS (update_dpp's `old`: lane 0 has no
+        // source under wave_shr, lane 63 none under wave_shl).  17 instructions where the masked form had 24.
+        typedef int __attribute__((ext_vector_type(4))) i4;
+        if (edge_lane) {
+          i4 w;
+          w.x = lane == 63 ? M_S10(C - 1) : M_S10(0);
+          w.y = lane == 63 ? M_S25(C - 1) : M_S25(0);
+          w.z = lane == 63 ? I1h[C - 1][e1x] : D1h[0][e1x];
+          w.w = lane == 63 ? I2h[C - 1] : D2h[0];
+          *reinterpret_cast<i4*>(edge_wr + par * EDGE_PLANE) = w;
+        }
+        __syncthreads();
+        WFM_TRACE_STAMP(0);  // the barrier has let go
+        const i4 La = *reinterpret_cast<const i4*>(&s_edge[par][wv][0][0]);
+        const i4 Ra = *reinterpret_cast<const i4*>(&s_edge[par][wv + 1][1][0]);
+        lM10 = __builtin_amdgcn_update_dpp(La.x, M_S10(C - 1), 0x138, 0xf, 0xf, false);
+        lM25 = __builtin_amdgcn_update_dpp(La.y, M_S25(C - 1), 0x138, 0xf, 0xf, false);
+        lI1 = __builtin_amdgcn_update_dpp(La.z, I1h[C - 1][e1x], 0x138, 0xf, 0xf, false);
+        lI2 = __builtin_amdgcn_update_dpp(La.w, I2h[C - 1], 0x138, 0xf, 0xf, false);
+        rM10 = __builtin_amdgcn_update_dpp(Ra.x, M_S10(0), 0x130, 0xf, 0xf, false);
+        rM25 = __builtin_amdgcn_update_dpp(Ra.y, M_S25(0), 0x130, 0xf, 0xf, false);
+        rD1 = __builtin_amdgcn_update_dpp(Ra.z, D1h[0][e1x], 0x130, 0xf, 0xf, false);
+        rD2 = __builtin_amdgcn_update_dpp(Ra.w, D2h[0], 0x130, 0xf, 0xf, false);
+      } else {
       if (lane == 63) { int* e = s_edge[par][wv + 1][0]; e[0] = M_S10(C - 1); e[1] = M_S25(C - 1); e[2] = I1h[C - 1][e1x]; e[3] = I2h[C - 1]; }
       if (lane == 0)  { int* e = s_edge[par][wv][1];     e[0] = M_S10(0);     e[1] = M_S25(0);     e[2] = D1h[0][e1x];     e[3] = D2h[0]; }
       __syncthreads();
@@ -523,6 +604,7 @@ __global__ __launch_bounds__(NTMAX) void wfa_tile2_kernel(const uint32_t* __rest
       rD1 = from_next_lane0(D1h[0][e1x]); rD2 = from_next_lane0(D2h[0]);
       if (lane == 0)  { const int* e = s_edge[par][wv][0];     lM10 = e[0]; lM25 = e[1]; lI1 = e[2]; lI2 = e[3]; }
       if (lane == 63) { const int* e = s_edge[par][wv + 1][1]; rM10 = e[0]; rM25 = e[1]; rD1 = e[2]; rD2 = e[3]; }
+      }
     } else {
       lM10 = from_prev_lane(M_S10(C - 1)); lM25 = from_prev_lane(M_S25(C - 1));
       lI1 = from_prev_lane(I1h[C - 1][e1x]); lI2 = from_prev_lane(I2h[C - 1]);
@@ -530,6 +612,15 @@ __global__ __launch_bounds__(NTMAX) void wfa_tile2_kernel(const uint32_t* __rest
       rD1 = from_next_lane(D1h[0][e1x]); rD2 = from_next_lane(D2h[0]);
     }
     int nM[C], nI1[C], nI2[C], nD1[C], nD2[C], nMis[C];
+    // PIPE: the probe of the row the step before left pending, ahead of this step's recurrences
+    int pext[C], pmaxn[C];
+    unsigned poP[C], poT[C];
+    PkProbe PR;
+    if (PIPE) {
+#pragma unroll
+      for (int c = 0; c < C; ++c) { poP[c] = (unsigned)(pM[c] + cP[c]); poT[c] = (unsigned)(pM[c] + dT); pmaxn[c] = (int)hmaxu[c] - pM[c]; }
+      PR = pk_probe2_fast(SRC, pM, poP, poT, pmaxn, wlim, pext);
+    }
 #pragma unroll
     for (int c = 0; c < C; ++c) {
       const int a10 = c == 0 ? lM10 : M_S10(c - 1), b10 = c == C - 1 ? rM10 : M_S10(c + 1);
@@ -574,6 +665,46 @@ __global__ __launch_bounds__(NTMAX) void wfa_tile2_kernel(const uint32_t* __rest
 #pragma unroll
       for (int c = 0; c < C; ++c) nM[c] = s <= s_last[c] ? nM[c] : WF_NULL;
     }
+    if (PIPE) {
+      // ---- the pending row's rare paths, then it is final: into its line (the step before's class and visit), its antidiagonals into the maxima
+      pk_rare2_fast(SRC, PR, pM, poP, poT, pmaxn, wlim, pext, lowdiv);
+      int fin[C], mak = 0;
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        fin[c] = pM[c] + pext[c];  // (a cell that holds nothing probed at most 16 bases: NULL + 16 is as NULL as NULL)
+        mak = max(mak, pM[c] >= 0 ? 2 * fin[c] + negk[c] : 0);  // (cells outside the core: far below zero)
+      }
+      switch (jj) {  // (compile time after unrolling: the step before's number within its body)
+        case 1: line_take(std::integral_constant<int, UB>{}, fin); break;
+        case 2: line_take(std::integral_constant<int, 1>{}, fin); break;
+        case 3: line_take(std::integral_constant<int, 2>{}, fin); break;
+        case 4: line_take(std::integral_constant<int, 3>{}, fin); break;
+        case 5: line_take(std::integral_constant<int, 4>{}, fin); break;
+        case 6: line_take(std::integral_constant<int, 5>{}, fin); break;
+        case 7: line_take(std::integral_constant<int, 6>{}, fin); break;
+        case 8: line_take(std::integral_constant<int, 7>{}, fin); break;
+        case 9: line_take(std::integral_constant<int, 8>{}, fin); break;
+        default: line_take(std::integral_constant<int, 9>{}, fin); break;
+      }
+      if (!FINE) (void)__hip_atomic_fetch_max(&s_run[tid], mak, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // ds_max_i32, nothing returned
+      else { mak = wave_max63(mak); if (lane == 63) s_makr[(WAVE1 ? 0 : wv * MKS) + t - 1] = mak; }
+      // ---- this step's row waits for its extension; its gap components are final
+      if (__builtin_expect(t > Tn - H, 0)) {  // stream the last H rows of I/D of the core to the output snapshot
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+          const int k = k0 + c;
+          if (incore[c] && s <= s_last[c]) {
+            const int64_t ro = ((int64_t)(s & RMASK)) * width + k;
+            rout[(int64_t)C_I1 * RING * width + ro] = nI1[c];
+            rout[(int64_t)C_I2 * RING * width + ro] = nI2[c];
+            rout[(int64_t)C_D1 * RING * width + ro] = nD1[c];
+            rout[(int64_t)C_D2 * RING * width + ro] = nD2[c];
+          }
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < C; ++c) { pM[c] = nM[c]; I1h[c][e1x] = nI1[c]; D1h[c][e1x] = nD1[c]; I2h[c] = nI2[c]; D2h[c] = nD2[c]; }
+    } else {
     // ---- extension (pk_extend2): 16 bases of every cell at once from the LDS windows, longer runs in stages
     int ext[C], maxn[C];
     unsigned oP[C], oT[C];
@@ -649,9 +780,6 @@ __global__ __launch_bounds__(NTMAX) void wfa_tile2_kernel(const uint32_t* __rest
       }
       I2h[c] = nI2[c]; D2h[c] = nD2[c];
     }
-#undef M_S5
-#undef M_S10
-#undef M_S25
     if (!P2) {  // (the rows of phase 2 are tested cell by cell: nobody reads maxima of theirs)
       if (FAST && !FINE) (void)__hip_atomic_fetch_max(&s_run[tid], mak, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // ds_max_i32, nothing returned
       else {
@@ -663,7 +791,38 @@ __global__ __launch_bounds__(NTMAX) void wfa_tile2_kernel(const uint32_t* __rest
         }
       }
     }
+    }
+#undef M_S5
+#undef M_S10
+#undef M_S25
   }
+  }
+  if (PIPE) {
+    // the last step's row is still pending: its extension, then into its line
+    int pext[C], pmaxn[C], fin[C], mak = 0;
+    unsigned poP[C], poT[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) { poP[c] = (unsigned)(pM[c] + cP[c]); poT[c] = (unsigned)(pM[c] + dT); pmaxn[c] = (int)hmaxu[c] - pM[c]; }
+    pk_extend2_fast(SRC, pM, poP, poT, pmaxn, wlim, pext, lowdiv);
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      fin[c] = pM[c] + pext[c];
+      mak = max(mak, pM[c] >= 0 ? 2 * fin[c] + negk[c] : 0);
+    }
+    switch (Tn % UB) {
+      case 1: line_take(std::integral_constant<int, 1>{}, fin); break;
+      case 2: line_take(std::integral_constant<int, 2>{}, fin); break;
+      case 3: line_take(std::integral_constant<int, 3>{}, fin); break;
+      case 4: line_take(std::integral_constant<int, 4>{}, fin); break;
+      case 5: line_take(std::integral_constant<int, 5>{}, fin); break;
+      case 6: line_take(std::integral_constant<int, 6>{}, fin); break;
+      case 7: line_take(std::integral_constant<int, 7>{}, fin); break;
+      case 8: line_take(std::integral_constant<int, 8>{}, fin); break;
+      case 9: line_take(std::integral_constant<int, 9>{}, fin); break;
+      default: line_take(std::integral_constant<int, UB>{}, fin); break;
+    }
+    if (!FINE) (void)__hip_atomic_fetch_max(&s_run[tid], mak, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    else { mak = wave_max63(mak); if (lane == 63) s_makr[(WAVE1 ? 0 : wv * MKS) + Tn] = mak; }
   }
   WFM_TRACE_MARK(122);
   // ---- output snapshot: the newest H rows of M for the core ----
