@@ -30,6 +30,15 @@ import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
+
+# The bound the tile kernel is measured against: vector-instruction issue.  A cell cannot cost fewer than VALU_FLOOR vector
+# instructions in the present scheme (recurrences 9, score-bound / column test 2, one 16-base probe of both sequences 17, extension add 1,
+# antidiagonal 2, its share of the neighbour exchange 4, of the block's maximum 1); a wave64 instruction of the step's mix occupies its SIMD for
+# VALU_MEAN_ISSUE_CYCLES on average (measured: profiles/r6_valu_issue.md -- 4.2 cycles for max / min / compare / select / alignbit / ffbl / DPP /
+# lshl, 2.2 for add / sub / and / or / xor / lshr / mov -- priced over the step's common path by scripts/isa_hot_path.py: 3.34 - 3.54).
+VALU_FLOOR = 36.0
+VALU_MEAN_ISSUE_CYCLES = 3.4
+VALU_PEAK_CELLS = 256 * 4 * 2.4e9 * 64.0 / (VALU_FLOOR * VALU_MEAN_ISSUE_CYCLES)
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
@@ -303,12 +312,14 @@ def _strong_c4(args, h, capi, synth, dist, rank, world, comm_dev, torch):
             # their durations (launches of the four workers overlap: the sum is an upper bound of the kernel's own time, the figure a lower bound)
             peak = 8000.0
             ach = 48.0 * cells_tile / (ms_tile * 1e-3) / 1e9 if ms_tile > 0 else 0.0
-            peak_cells = 256 * 4 * 16 * 2.4e9 / 36.0
-            roof = {"bound": "hbm", "physical_bound": "valu", "kernel": "wfa_tile2_kernel (rank 0)", "achieved": ach, "peak": peak, "unit": "GB/s", "frac": ach / peak,
+            peak_cells = VALU_PEAK_CELLS
+            ach_cells = cells_tile / (ms_tile * 1e-3) if ms_tile > 0 else 0.0
+            roof = {"bound": "valu", "kernel": "wfa_tile2_kernel (rank 0)", "achieved": ach_cells, "peak": peak_cells, "unit": "cells/s", "frac": ach_cells / peak_cells,
+                    "floor_valu_insts_per_cell": VALU_FLOOR, "mean_issue_cycles_per_valu_inst": VALU_MEAN_ISSUE_CYCLES,
                     "traffic": None, "launches_per_step": launches / max(1, args.steps), "avg_launch_ms": ms_tile / max(1, launches),
-                    "algorithmic_bytes_per_launch": 48.0 * cells_tile / max(1, launches),
-                    "valu": {"bound": "valu", "unit": "cells/s", "floor_valu_insts_per_cell": 36.0, "peak": peak_cells,
-                             "achieved": cells_tile / (ms_tile * 1e-3) if ms_tile > 0 else 0.0, "frac": (cells_tile / (ms_tile * 1e-3) / peak_cells) if ms_tile > 0 else 0.0},
+                    "hbm_yardstick": {"bound": "hbm", "achieved": ach, "peak": peak, "unit": "GB/s", "frac": ach / peak,
+                                      "algorithmic_bytes_per_launch": 48.0 * cells_tile / max(1, launches),
+                                      "note": "48 B per cell (SURVEY 8d): saturated -- the history lives in registers, frac passes 1 on C3 / C5 (DESIGN.md section 5)"},
                     "whole_path": {"algorithmic_frac_gpu": 48.0 * cells / (ms_gpu * 1e-3) / 8e12 if ms_gpu else None, "gpu_share_of_align": ms_gpu * 1e-3 / dt,
                                    "note": "48 B x the cells of ALL align kernels / the time any of them was running on rank 0's device"},
                     "note": "launch durations are summed over workers whose launches overlap (an upper bound of the kernel's own time); the yardstick and the VALU floor are "
@@ -416,7 +427,7 @@ def _roofline(acc, excl, seq_bytes, args):
     e_achieved = e_alg / (e_ms * 1e-3) / 1e9 if e_ms > 0 else 0.0
     traffic = hbm_frac = None  # HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/)
     src = None
-    for name in ("r5_traffic.json", "r4_traffic.json"):
+    for name in ("r6_traffic.json", "r5_traffic.json", "r4_traffic.json"):
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", name)))
         except (OSError, ValueError):
@@ -428,7 +439,7 @@ def _roofline(acc, excl, seq_bytes, args):
             src = "profiles/" + name
             break
     issue = None  # issue-side figures of the same kernel from the committed SQ passes (profiles/): the 48 B/cell yardstick is
-    for name in ("r5_sq.json", "r4_sq.json"):  # saturated (C5 passes 1.0), what the kernel is really short of is issue slots and latency
+    for name in ("r6_sq.json", "r5_sq.json", "r4_sq.json"):  # saturated (C5 passes 1.0), what the kernel is really short of is issue slots and latency
         try:
             issue = json.load(open(os.path.join(ROOT, "profiles", name)))
             issue["source"] = "profiles/" + name
@@ -438,15 +449,16 @@ def _roofline(acc, excl, seq_bytes, args):
     # The bound that can still be missed: vector-instruction issue.  A cell of the tile kernel cannot cost fewer than
     # VALU_FLOOR vector instructions (recurrences 9, score-bound select 2, one 16-base probe of both sequences 17, extension add 1,
     # antidiagonal 2, its share of the neighbour exchange 4, of the per-step wave maximum 1): peak = lane-instructions per second / floor.
-    VALU_FLOOR = 36.0
-    lane_insts_per_s = 256 * 4 * 16 * 2.4e9  # 256 CUs x 4 SIMDs x 16 lanes at 2.4 GHz (MI355X_MICROARCH.md)
-    peak_cells = lane_insts_per_s / VALU_FLOOR
+    peak_cells = VALU_PEAK_CELLS
     e_cells_per_s = e_cells / (e_ms * 1e-3) if e_ms > 0 else 0.0
     steps_per_wave = 100.0
     valu = {"bound": "valu", "unit": "cells/s", "floor_valu_insts_per_cell": VALU_FLOOR, "peak": peak_cells, "achieved": e_cells_per_s,
             "frac": e_cells_per_s / peak_cells,
             "note": "achieved = unique (score, diagonal) cells of the tile kernel / its exclusive running time, measured live (the same events as roofline.frac); "
-                    "peak = 16384 lanes x 2.4 GHz / the instruction floor of a cell. Lanes of a tile's halo and lanes without a cell issue as well and count against it."}
+                    "peak = 1024 SIMDs x 2.4 GHz x 64 lanes / (the instruction floor of a cell x the mean issue cycles of the step's instruction mix, "
+                    "profiles/r6_valu_issue.md: 4.2 cycles per wave64 instruction for max / compare / select / alignbit / ffbl / DPP, 2.2 for add / sub / logic; "
+                    "scripts/isa_hot_path.py prices the step's common path at 3.4). Lanes of a tile's halo and lanes without a cell issue as well and count against it.",
+            "mean_issue_cycles_per_valu_inst": VALU_MEAN_ISSUE_CYCLES}
     if issue and issue.get("counters", {}).get("SQ_WAVES"):
         c = issue["counters"]
         valu["committed_profile"] = {"source": issue.get("source"), "valu_insts_per_wave_step": c.get("SQ_INSTS_VALU", 0) / c["SQ_WAVES"] / steps_per_wave,
@@ -454,15 +466,14 @@ def _roofline(acc, excl, seq_bytes, args):
                                      "floor_per_wave_step": VALU_FLOOR * 2, "valu_busy": issue.get("valu_frac"), "wait_frac": issue.get("wait_frac"),
                                      "frac_valu_from_counters": (VALU_FLOOR * 2) / max(1.0, c.get("SQ_INSTS_VALU", 0) / c["SQ_WAVES"] / steps_per_wave) * (issue.get("valu_frac") or 0.0),
                                      "note": "per wave and score step of 2 x 64 cells, from the committed SQ pass (the builder's box, not this run): floor / measured x VALU busy"}
-    return {"bound": "hbm", "physical_bound": "valu", "valu": valu,
-            "yardstick": "48 B per cell (SURVEY 8d) -- saturated: the wavefront history never leaves the registers, real traffic is a fifth of it (committed_profile.traffic), frac passes 1; "
-                         "the bound the kernel is measured against from round 5 on is `valu`",
+    hbm = {"bound": "hbm", "achieved": e_achieved, "peak": peak, "unit": "GB/s", "frac": e_achieved / peak,
+           "achieved_overlapped": achieved, "frac_overlapped": achieved / peak,
+           "note": "the contract's yardstick, 48 B per cell (SURVEY 8d) -- saturated: the wavefront history never leaves the registers, real traffic is a fifth of it "
+                   "(traffic), frac passes 1; exclusive = untimed WFM_OVERLAP=0 passes (what rocprofv3 --kernel-trace reproduces), overlapped = the timed region"}
+    return {"bound": "valu", "achieved": valu["achieved"], "peak": valu["peak"], "unit": "cells/s", "frac": valu["frac"], "traffic": traffic,
+            "valu": valu, "hbm_yardstick": hbm,
             "kernel": dom + (" (wfa_tile_reg_kernel for problems with an N or soft-masked bases: none in this workload)" if tiled else ""),
             # the figure rocprofv3 reproduces: launches one after the other on one stream (untimed passes with WFM_OVERLAP=0)
-            "achieved": e_achieved, "peak": peak, "unit": "GB/s", "frac": e_achieved / peak,
-            # the timed region itself: up to three parts of the batch on as many streams, the kernel's running time = the union of its launch intervals
-            "achieved_overlapped": achieved, "frac_overlapped": achieved / peak,
-            "traffic": traffic,
             "committed_profile": {"traffic": traffic, "hbm_frac": hbm_frac, "traffic_source": src,
                                   "valu_frac": issue.get("valu_frac") if issue else None, "wait_frac": issue.get("wait_frac") if issue else None, "issue_source": issue.get("source") if issue else None,
                                   "note": "read from the committed PMC passes under profiles/ (the builder's box, scripts/profile_r5.sh), NOT measured in this run; "
@@ -474,9 +485,9 @@ def _roofline(acc, excl, seq_bytes, args):
             "cells_computed_per_launch": cells_all / max(launches, 1),
             "avg_launch_ms": ms_sum / max(launches, 1), "launches": launches, "streams": acc.streams,
             "kernel_busy_ms_per_step": busy / max(acc.passes, 1),
-            "note": "frac = exclusive (untimed WFM_OVERLAP=0 passes, what rocprofv3 --kernel-trace reproduces: profiles/r4_align_excl.md); frac_overlapped = the "
-                    "timed region (union of launch intervals over the streams). 48 B x unique (score, diagonal) cells / kernel time: the contract's yardstick (SURVEY 8d); "
-                    "the history lives in registers, so real HBM traffic is far below it and frac can pass 1 -- the kernel's own bound is VALU issue (valu_frac). DESIGN.md section 5"}
+            "note": "frac = unique (score, diagonal) cells of the dominant kernel / its exclusive running time (untimed WFM_OVERLAP=0 passes: launches one after "
+                    "the other on one stream, what rocprofv3 --kernel-trace reproduces) against the vector-issue peak of the cell's instruction floor; hbm_yardstick = "
+                    "the contract's 48 B per cell against 8 TB/s, which a kernel whose history lives in registers passes. DESIGN.md section 5"}
 
 
 def _cpu_baseline_map(h):

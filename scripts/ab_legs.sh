@@ -1,11 +1,11 @@
 #!/bin/bash
-# A/B runs of the C2 / scaled C4 legs (scripts/legs_debug.py) under environment settings given as arguments, e.g.
+# A/B runs of the C2 / scaled C4 legs (scripts/legs_run.py) under environment settings given as arguments, e.g.
 #   scripts/ab_legs.sh "" "WFM_P2_THREADS=256" "WFM_TILE_V2=0"
 # prints one line per (setting, leg, pass): align_s, ms_gpu, algorithmic_frac_gpu
 root=$(cd "$(dirname "$0")/.." && pwd)
 for setting in "$@"; do
   echo "==== setting: [$setting]"
-  env $setting WFM_DEBUG=0 python $root/scripts/legs_debug.py c4 c2 --reps 3 2>/dev/null | python -c '
+  env $setting WFM_DEBUG=0 python $root/scripts/legs_run.py c4 c2 --reps 3 2>/dev/null | python -c '
 import sys, json
 for line in sys.stdin:
     if line.startswith("{"):

@@ -1,6 +1,6 @@
 """The bench line's secondary legs (C2 = LPA.subset all-vs-all -p 90 -P 50k; scaled C4 rank = 8 x 8 Mbp, one query
 haplotype) run once each with WFM_DEBUG=1, so that the stage timings the library prints on stderr explain where the
-wall time of `align_s` / `map_s` goes.  Usage: python scripts/legs_debug.py [c2] [c4] [--threads N] [--mbp 8]"""
+wall time of `align_s` / `map_s` goes.  Usage: python scripts/legs_run.py [c2] [c4] [--threads N] [--mbp 8]"""
 import json
 import os
 import sys

@@ -42,9 +42,9 @@ cd "$root"
 python scripts/prof_summary.py "$po/r5_c4.md" "r5: one rank of the 40 Mbp C4 variant, map + align (scripts/c4_rank.py --mbp 40 --align)" "$(find /tmp/p5/c4 -name '*results.db' | head -1)" --bench /tmp/p5_c4.log > /dev/null
 # C2 with stage timings
 cd /tmp
-WFM_DEBUG=1 rocprofv3 --kernel-trace --stats -d /tmp/p5/c2 -o t -- python $root/scripts/legs_debug.py c2 --reps 2 > /tmp/p5_c2.log 2> /tmp/p5_c2.err
+WFM_DEBUG=1 rocprofv3 --kernel-trace --stats -d /tmp/p5/c2 -o t -- python $root/scripts/legs_run.py c2 --reps 2 > /tmp/p5_c2.log 2> /tmp/p5_c2.err
 cd "$root"
-python scripts/prof_summary.py "$po/r5_c2.md" "r5: C2 (LPA.subset all-vs-all, -p 90 -P 50k), two passes in one process (scripts/legs_debug.py c2)" "$(find /tmp/p5/c2 -name '*results.db' | head -1)" --bench /tmp/p5_c2.log > /dev/null
+python scripts/prof_summary.py "$po/r5_c2.md" "r5: C2 (LPA.subset all-vs-all, -p 90 -P 50k), two passes in one process (scripts/legs_run.py c2)" "$(find /tmp/p5/c2 -name '*results.db' | head -1)" --bench /tmp/p5_c2.log > /dev/null
 # C1 substitute (8 yeast-like strains all-vs-all), one pass
 cd /tmp
 rocprofv3 --kernel-trace --stats -d /tmp/p5/c1 -o t -- python $root/scripts/c1_run.py --reps 1 > /tmp/p5_c1.log 2>/dev/null

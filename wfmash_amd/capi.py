@@ -116,9 +116,12 @@ _LIB = None
 
 def load():
     """Load libwfmash_hip.so; raises if it has not been built."""
-    global _LIB
+    global _LIB, LIB_PATH
     if _LIB is not None:
         return _LIB
+    # (WFM_LIB: another build of the same library, for A/B runs of two kernels inside one process launch -- scripts/c3_time.py)
+    if os.environ.get("WFM_LIB"):
+        LIB_PATH = os.path.join(os.path.dirname(LIB_PATH), os.environ["WFM_LIB"]) if not os.path.isabs(os.environ["WFM_LIB"]) else os.environ["WFM_LIB"]
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "

@@ -1039,7 +1039,7 @@ int align_resident_impl(wfm_handle* h, const wfm_penalties_t* pen, wfm_seqset* S
       size_t total = 0;
       for (const Node& nd : bp_nodes) total += (((size_t)nd.pl + nd.tl + 9 + 3) & ~(size_t)3) * 2 * 5 * RR * 2;
       // (narrow rings whenever full ones would take more than 2 GB, not only when they would not fit: every fresh GB of a
-      // first hipMalloc costs ~30 ms on this driver, scripts/malloc_cost2.hip, and a one-shot run pays it)
+      // first hipMalloc costs ~30 ms on this driver, scripts/micro/malloc_cost2.hip, and a one-shot run pays it)
       use_band = band_on && total * 4 > std::min<size_t>(h->mem_budget, (size_t)2 << 30);
       over_budget = total * 4 > h->mem_budget;
     }
@@ -1468,7 +1468,8 @@ int wfm_create(int device, wfm_handle_t** out) {
   if (strncmp(prop.gcnArchName, "gfx9", 4) != 0 || prop.warpSize != 64) return WFM_E_NODEVICE;
   wfm_handle* h = new wfm_handle();
   h->device = device;
-  h->name = std::string(prop.name) + " (" + prop.gcnArchName + ")";
+  // (hipDeviceProp_t::name is empty on some boxes of the pool: the architecture name alone then)
+  h->name = prop.name[0] ? std::string(prop.name) + " (" + prop.gcnArchName + ")" : std::string(prop.gcnArchName);
   if (hipStreamCreate(&h->stream) != hipSuccess) { delete h; return WFM_E_HIP; }
   (void)hipEventCreate(&h->ev0); (void)hipEventCreate(&h->ev1); (void)hipEventCreate(&h->ev2); (void)hipEventCreate(&h->ev3);
   h->tile_ev.resize(64);
@@ -1477,7 +1478,7 @@ int wfm_create(int device, wfm_handle_t** out) {
   size_t fr = 0, tot = 0;
   if (hipMemGetInfo(&fr, &tot) != hipSuccess) { fr = (size_t)16 << 30; }
   // 40 % of the free HBM, but no more than 32 GB: on this driver a first hipMalloc beyond a few tens of GB costs 35-40 ms
-  // per GB (64 GB: 2.5-4.4 s, 110 GB: 3.9 s, 16 GB: 0.3 ms -- scripts/malloc_cost.hip, profiles/r3_cold_start.md), which a
+  // per GB (64 GB: 2.5-4.4 s, 110 GB: 3.9 s, 16 GB: 0.3 ms -- scripts/micro/malloc_cost.hip, profiles/r3_cold_start.md), which a
   // one-shot run pays in full: LPA all-vs-all (C2) aligned in 3.3 s cold and 0.33 s warm with rings sized for 115 GB.  A
   // level that needs more is worked off in chunks and on narrow rings
   // Handles of one device share it (the align driver keeps up to three per device): a further handle takes its 40 % of what
