@@ -49,8 +49,9 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", default="C3", choices=["C3", "C5", "C4"],
-                    help="C3 / C5: synthetic pairs, WFA-only.  C4 (with --scaling strong): the mapping records of one query haplotype of a "
-                         "synthetic pangenome (--c4-mbp per haplotype), dealt out over the ranks by dist.shard_records on the reference's own weights")
+                    help="C3 / C5: synthetic pairs, WFA-only.  C4 (strong scaling by nature): a synthetic pangenome of eight haplotypes (--c4-mbp each) "
+                         "all-vs-all, map + align inside the timed region -- queries dealt out over the ranks for the map phase, the mapping records of all "
+                         "queries for the align phase (dist.shard_queries / dist.shard_records on the reference's own weights)")
     ap.add_argument("--c4-mbp", type=float, default=8.0, help="haplotype length of --config C4 in Mbp (248.956422 = north_star's size)")
     ap.add_argument("--pairs", type=int, default=64)
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
@@ -60,7 +61,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0, help="pairs in the cpu_baseline sample (0 = auto)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary figures (C5, C1 substitute, C4 ranks, C2)")
-    ap.add_argument("--legs", default="", help="comma-separated subset of the secondary legs to run (C5,C1_substitute,C4_rank_scaled,C4_rank_40mbp,C4_rank_full,C2,map_parity); default all")
+    ap.add_argument("--legs", default="", help="comma-separated subset of the secondary legs to run (C5,C1_substitute,C4_rank_scaled,C4_rank_40mbp,C4_rank_full,C4_all_vs_all,C2,map_parity); default all")
     ap.add_argument("--no-full-c4", action="store_true", help="skip the chr1-sized C4 rank among the secondary legs (2 GB of synthetic haplotypes: ~20 s to make)")
     ap.add_argument("--rank-check", action="store_true",
                     help="launch / join the ranks, print one line per rank and stop (no GPU needed: gloo)")
@@ -250,12 +251,14 @@ def main():
 
 
 def _strong_c4(args, h, capi, synth, dist, rank, world, comm_dev, torch):
-    """Strong scaling on north_star's own records: one query haplotype of a synthetic pangenome mapped against all eight (every rank
-    makes the same sequences and the same mapping file -- the generator is seeded, the map phase deterministic), its mapping
-    records dealt out by dist.shard_records on the weight the reference's cluster sharding uses (length x (1 - identity),
+    """north_star's C4 as one job: a synthetic pangenome of eight haplotypes, ALL-VS-ALL (`-Y '#'`), both phases inside the timed region.
+    Map: the eight query haplotypes are dealt out over the ranks by length (dist.shard_queries: queries are independent tasks,
+    computeMap.hpp:565-599), every rank builds the index of all eight targets (replicated) and maps its queries; the mapping records
+    of all ranks are exchanged (dist.all_gather_text: the one real exchange step of the path); align: the records of ALL queries are dealt
+    out by dist.shard_records on the weight the reference's cluster sharding uses (length x (1 - identity),
     scripts/split_approx_mappings_in_chunks.py:19-27,47; squared for WFA cost), every rank aligns its share end to end
-    (wfmh_align_paf: sequence fetch, device batches, CIGAR surgery, PAF text) and the PAF text is gathered to rank 0 inside the
-    timed region.  value = aligned bp of all ranks / the slowest rank's time."""
+    (wfmh_align_paf: sequence fetch, device batches, CIGAR surgery, PAF text) and the PAF text is gathered to rank 0.
+    value = aligned bp of all ranks / the slowest rank's time for map + exchange + align + gather."""
     import tempfile
     from wfmash_amd import dist as D
     threads = max(1, (os.cpu_count() or 1) // max(1, world))
@@ -264,27 +267,37 @@ def _strong_c4(args, h, capi, synth, dist, rank, world, comm_dev, torch):
         recs = synth.pangenome_parallel(8, int(args.c4_mbp * 1e6), n_sv=6 if args.c4_mbp <= 8 else 20, workers=min(8, threads))
         names, lengths = synth.write_fasta(fa, recs)
         del recs
-        ql = os.path.join(td, "q.txt")
-        open(ql, "w").write(names[0] + "\n")
-        m = os.path.join(td, "m.paf")
-        t1 = time.perf_counter()
-        capi.map_paf(h, fa, m, params=capi.map_default_params(threads=threads, query_list=ql))
-        t_map = time.perf_counter() - t1
-        lines = open(m).read().splitlines(keepends=True)
+        my_queries = [names[i] for i in D.shard_queries(lengths, world)[rank]]
+        ql = os.path.join(td, f"q.rank{rank}.txt")
+        open(ql, "w").write("".join(n + "\n" for n in my_queries))
+        m_mine = os.path.join(td, f"m.rank{rank}.paf")
+        mine = os.path.join(td, f"m.align.rank{rank}.paf")
+        out_paf = os.path.join(td, f"a.rank{rank}.paf")
+        state = {"lines": [], "shard": [], "t_map": 0.0, "t_xchg": 0.0, "ms": None}
 
         def weight(line):
             f = line.split("\t")
             ident = next((float(x[5:]) for x in f[12:] if x.startswith("id:f:")), 0.9)
             return (max(1.0, (int(f[3]) - int(f[2])) * max(1e-3, 1.0 - ident))) ** 2
-        shard = D.shard_records([weight(l) for l in lines], world)[rank]
-        mine = os.path.join(td, f"m.rank{rank}.paf")
-        open(mine, "w").write("".join(lines[i] for i in shard))
-        out_paf = os.path.join(td, f"a.rank{rank}.paf")
 
         def one_pass():
+            t1 = time.perf_counter()
+            text = ""
+            if my_queries:
+                state["ms"] = capi.map_paf(h, fa, m_mine, params=capi.map_default_params(threads=threads, query_list=ql))
+                text = open(m_mine).read()
+            t2 = time.perf_counter()
+            texts = D.all_gather_text(text, dist, device=comm_dev if comm_dev.type == "cuda" else None)
+            lines = D.merge_query_blocks(texts, names).splitlines(keepends=True)
+            shard = D.shard_records([weight(l) for l in lines], world)[rank]
+            open(mine, "w").write("".join(lines[i] for i in shard))
+            t3 = time.perf_counter()
             al = capi.align_paf(h, fa, mine, out_paf, params={"threads": threads})
             if dist is not None:
                 D.gather_files(out_paf, dist, td, dst=0, device=comm_dev if comm_dev.type == "cuda" else None)
+            state.update(lines=lines, shard=shard)
+            state["t_map"] += t2 - t1
+            state["t_xchg"] += t3 - t2
             return al
 
         def sync():
@@ -294,6 +307,7 @@ def _strong_c4(args, h, capi, synth, dist, rank, world, comm_dev, torch):
         for _ in range(args.warmup):
             one_pass()
         sync()
+        state["t_map"] = state["t_xchg"] = 0.0
         t0 = time.perf_counter()
         bp = 0
         recs_n = 0
@@ -306,6 +320,7 @@ def _strong_c4(args, h, capi, synth, dist, rank, world, comm_dev, torch):
             cells += int(al.cells); cells_tile += int(al.cells_tile); launches += int(al.tile_launches); ms_tile += al.ms_tile
         sync()
         dt = time.perf_counter() - t0
+        lines, shard = state["lines"], state["shard"]
         roof = cpu = parity = None
         if rank == 0:
             # the dominant kernel of the path (the tile kernels), from the run's own HIP events: 48 B x the unique cells of its launches / the sum of
@@ -363,11 +378,15 @@ def _strong_c4(args, h, capi, synth, dist, rank, world, comm_dev, torch):
                 "metric": "aligned bases/sec (whole node) + CIGAR-identical rate vs CPU ref", "value": float(tot[0].item()) / dtm, "unit": "aligned bases/s",
                 "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dtm / args.steps * 1e3, "higher_is_better": True,
                 "scaling": "strong", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
-                "config": {"workload": f"C4 rank: 8 synthetic haplotypes x {args.c4_mbp} Mbp, -Y '#', the {len(lines)} mapping records of one query haplotype "
-                                       "sharded over the GPUs by dist.shard_records (weight (length x (1 - identity))^2), map once + align per step",
-                           "records_total": len(lines), "records_rank0": len(shard), "parallelism": f"records sharded over {world} GPU(s)", "host_threads_per_rank": threads},
+                "config": {"workload": f"C4: 8 synthetic haplotypes x {args.c4_mbp} Mbp all-vs-all, -Y '#', defaults (ani50-2); per step: map (queries sharded over the "
+                                       f"GPUs by length, index of all eight replicated) + exchange of the {len(lines)} mapping records + align (records sharded by "
+                                       "(length x (1 - identity))^2) + gather of the PAF text to rank 0",
+                           "queries_total": len(names), "queries_rank0": len(my_queries), "records_total": len(lines), "records_rank0": len(shard),
+                           "parallelism": f"queries, then records, sharded over {world} GPU(s)", "host_threads_per_rank": threads},
                 "roofline": roof, "cpu_baseline": cpu, "cigar_identical": parity,
-                "map_s": t_map, "records_per_step_all_ranks": float(tot[1].item()) / args.steps, "ms_gpu_rank0_per_step": ms_gpu / args.steps}), flush=True)
+                "map_s_rank0_per_step": state["t_map"] / args.steps, "exchange_s_rank0_per_step": state["t_xchg"] / args.steps,
+                "map_stages_ms_rank0": ({"identity": state["ms"].ms_identity, "index": state["ms"].ms_index, "map": state["ms"].ms_map, "filter": state["ms"].ms_filter} if state["ms"] else None),
+                "records_per_step_all_ranks": float(tot[1].item()) / args.steps, "ms_gpu_rank0_per_step": ms_gpu / args.steps}), flush=True)
 
 
 def _shard(args, rank, world, pairs):
@@ -601,30 +620,6 @@ def _secondary(h, capi, synth, full_c4=True, only=None):
     sec = {}
     threads = os.cpu_count() or 1
     want = lambda tag: not only or tag in only
-    # The MAP phase of the full-size rank runs first of all legs, as a run of its own would find the device: a block the process
-    # has freed is wiped by the driver before it is handed out again (about 40 ms per GB; `WFM_DEBUG=1`: "hipMalloc of 10.24 GB took
-    # 456.5 ms" against 0.3 ms on memory nobody has used), and after the other legs' arenas have grown and shrunk the work buffers of
-    # a chromosome-sized index (10 B per base and stream) land on such blocks or not from box to box: the same call took 0.6 - 0.7 s in
-    # a fresh process and 0.9 - 2.0 s in this place in six bench runs (gpurun_out/bench_r4[a-g]).  Its align phase stays where it was.
-    early_td = tempfile.TemporaryDirectory()
-    early = None
-    if full_c4 and want("C4_rank_full") and os.environ.get("WFM_BENCH_MAP_EARLY", "1") != "0":
-        try:
-            mbp = 248.956422
-            fa = os.path.join(early_td.name, "c4_full.fa")
-            t_g = time.perf_counter()
-            recs = synth.pangenome_parallel(8, int(mbp * 1_000_000), n_sv=20, workers=min(8, threads))
-            names, lengths = synth.write_fasta(fa, recs)
-            t_gen = time.perf_counter() - t_g
-            ql = os.path.join(early_td.name, "q.txt")
-            open(ql, "w").write(names[0] + "\n")
-            m = os.path.join(early_td.name, "m.paf")
-            t1 = time.perf_counter()
-            ms = capi.map_paf(h, fa, m, params=capi.map_default_params(threads=threads, query_list=ql))
-            early = {"fa": fa, "recs": recs, "m": m, "t_gen": t_gen, "t_map": time.perf_counter() - t1, "ms": ms}
-            del recs
-        except Exception as e:
-            early = {"error": str(e)}
     try:
         if not want("C5"):
             raise KeyError("skipped")
@@ -683,21 +678,17 @@ def _secondary(h, capi, synth, full_c4=True, only=None):
                 if not want(tag):
                     raise KeyError("skipped")
                 a = os.path.join(td, "a.paf")
-                if tag == "C4_rank_full" and early and "error" not in early:  # mapped before the other legs (see above)
-                    fa, recs, m, t_gen, t_map, ms = (early[k] for k in ("fa", "recs", "m", "t_gen", "t_map", "ms"))
-                    early["recs"] = None
-                else:
-                    fa = os.path.join(td, f"c4_{mbp}.fa")
-                    t_g = time.perf_counter()
-                    recs = synth.pangenome_parallel(8, int(mbp * 1_000_000), n_sv=6 if mbp == 8 else 20, workers=min(8, threads))
-                    names, lengths = synth.write_fasta(fa, recs)
-                    t_gen = time.perf_counter() - t_g
-                    ql = os.path.join(td, "q.txt")
-                    open(ql, "w").write(names[0] + "\n")
-                    m = os.path.join(td, "m.paf")
-                    t1 = time.perf_counter()
-                    ms = capi.map_paf(h, fa, m, params=capi.map_default_params(threads=threads, query_list=ql))
-                    t_map = time.perf_counter() - t1
+                fa = os.path.join(td, f"c4_{mbp}.fa")
+                t_g = time.perf_counter()
+                recs = synth.pangenome_parallel(8, int(mbp * 1_000_000), n_sv=6 if mbp == 8 else 20, workers=min(8, threads))
+                names, lengths = synth.write_fasta(fa, recs)
+                t_gen = time.perf_counter() - t_g
+                ql = os.path.join(td, "q.txt")
+                open(ql, "w").write(names[0] + "\n")
+                m = os.path.join(td, "m.paf")
+                t1 = time.perf_counter()
+                ms = capi.map_paf(h, fa, m, params=capi.map_default_params(threads=threads, query_list=ql))
+                t_map = time.perf_counter() - t1
                 tg = os.path.join(td, f"{tag}.tags")
                 if os.path.exists(tg):
                     os.unlink(tg)
@@ -710,8 +701,6 @@ def _secondary(h, capi, synth, full_c4=True, only=None):
                        "generate_s": t_gen, "map_s": t_map, "ms_identity": ms.ms_identity, "ms_index": ms.ms_index, "ms_map": ms.ms_map, "ms_filter": ms.ms_filter, "mapping_records": int(ms.written)}
                 leg.update(_align_fields(al, t_al))
                 leg["aligned_bp_per_s_map_and_align"] = al.aligned_bp / (t_map + t_al)
-                if tag == "C4_rank_full" and early and "error" not in early:
-                    leg["map_position"] = "first of the secondary legs (device memory no leg has freed yet), the align phase here"
                 if mbp < 100:  # the same align phase once more: arenas sized, handles of the workers created (the first pass is what a one-shot run pays)
                     t1 = time.perf_counter()
                     al2 = capi.align_paf(h, fa, m, a, params={"threads": threads})
@@ -721,12 +710,33 @@ def _secondary(h, capi, synth, full_c4=True, only=None):
                 seqs = {n: s.tobytes() for n, s in recs}
                 leg["parity"] = _sampled_cigar_identity(seqs, open(m).read().splitlines(), a, n_cig, tags_path=tg)
                 sec[tag] = leg
+                if tag == "C4_rank_full" and want("C4_all_vs_all"):
+                    # north_star's C4 as ONE job on one GPU -- the N = 1 point of its 1 / 2 / 4 / 8 curve (`--config C4` is the same job as a bench line
+                    # of its own, with the queries and then the records sharded over the ranks): all eight haplotypes against all eight, map + align
+                    try:
+                        m8, a8, tg8 = os.path.join(td, "m8.paf"), os.path.join(td, "a8.paf"), os.path.join(td, "c4_all.tags")
+                        t1 = time.perf_counter()
+                        ms8 = capi.map_paf(h, fa, m8, params=capi.map_default_params(threads=threads))
+                        t_map8 = time.perf_counter() - t1
+                        os.environ["WFM_RECORD_TAGS"] = tg8
+                        t1 = time.perf_counter()
+                        al8 = capi.align_paf(h, fa, m8, a8, params={"threads": threads})
+                        t_al8 = time.perf_counter() - t1
+                        os.environ.pop("WFM_RECORD_TAGS", None)
+                        leg8 = {"workload": f"C4 at north_star's size on ONE GPU: 8 synthetic haplotypes x {mbp} Mbp ALL-VS-ALL, -Y '#', defaults (ani50-2), map + align",
+                                "queries": len(names), "map_s": t_map8, "ms_identity": ms8.ms_identity, "ms_index": ms8.ms_index, "ms_map": ms8.ms_map, "ms_filter": ms8.ms_filter,
+                                "mapping_records": int(ms8.written)}
+                        leg8.update(_align_fields(al8, t_al8))
+                        leg8["wall_s"] = t_map8 + t_al8
+                        leg8["aligned_bp_per_s_map_and_align"] = al8.aligned_bp / (t_map8 + t_al8)
+                        leg8["parity"] = _sampled_cigar_identity(seqs, open(m8).read().splitlines(), a8, n_cig, tags_path=tg8)
+                        sec["C4_all_vs_all"] = leg8
+                    except Exception as e:
+                        sec["C4_all_vs_all"] = {"error": str(e)}
                 del recs, seqs
                 os.unlink(fa)
             except Exception as e:
                 sec[tag] = {"error": str(e)}
-        early = None
-        early_td.cleanup()
         try:  # C2: the reference's LPA test data (a committed fixture), all-vs-all -p 90 -P 50k
             if not want("C2"):
                 raise KeyError("skipped")
@@ -772,8 +782,8 @@ def _legs_summary(out):
     48 B x cells / device-busy time / 8 TB/s, sampled CIGAR-identical rate, map seconds]."""
     def r(x, n=3):
         return None if x is None else round(float(x), n)
-    legs = {"C3": {"ms_per_step": r(out["ms_per_step"], 2), "Mbp_per_s": r(out["value"] / 1e6, 2), "tile_frac_exclusive": r(out["roofline"]["frac"]),
-                   "tile_frac_overlapped": r(out["roofline"]["frac_overlapped"]), "whole_step_frac": r(out["whole_step"]["frac"]),
+    legs = {"C3": {"ms_per_step": r(out["ms_per_step"], 2), "Mbp_per_s": r(out["value"] / 1e6, 2), "tile_valu_frac": r(out["roofline"]["frac"]),
+                   "tile_hbm_yardstick_frac": r(out["roofline"].get("hbm_yardstick", {}).get("frac")), "whole_step_frac": r(out["whole_step"]["frac"]),
                    "cigar_identical": out.get("cigar_identical_rate")}}
     for tag, leg in out.get("secondary", {}).items():
         if "error" in leg:

@@ -156,3 +156,32 @@ def test_map_sharded_files_two_ranks(tmp_path):
         p.join(timeout=120)
         assert p.exitcode == 0
     assert open(two).read() == open(single).read()
+
+
+def _all_gather_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from wfmash_amd import dist as D
+        text = "" if rank == 1 else "q%d\tline of rank %d\n" % (rank, rank) * (3 + rank)
+        q.put((rank, D.all_gather_text(text, dist)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_all_gather_text_three_ranks_one_of_them_empty():
+    """dist.all_gather_text: the exchange between the query-sharded map phase and the record-sharded align phase of the all-vs-all bench
+    (bench.py --config C4) -- every rank ends up with every rank's mapping text in rank order, a rank without queries contributes nothing."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_all_gather_worker, args=(r, 3, port, q)) for r in range(3)]
+    for p in ps:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in ps)
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = ["q0\tline of rank 0\n" * 3, "", "q2\tline of rank 2\n" * 5]
+    assert got[0] == want and got[1] == want and got[2] == want

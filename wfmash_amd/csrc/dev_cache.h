@@ -1,5 +1,6 @@
 // dev_cache.h -- device blocks of the map path (and, since round 4, the arenas and sequence buffers of the align path) come from, and go
-// back to, a per-device cache instead of hipMalloc / hipFree.
+// back to, a per-device cache instead of hipMalloc / hipFree.  Round 6: blocks of a megabyte and more come from one heap per device on mapped
+// chunks of a reserved address range (dev_cache.hip), the size-class cache described below is what the small blocks keep.
 //
 // Why: on this driver a hipMalloc of memory the process has not had mapped before costs 30 - 40 ms per GB and a hipFree of
 // gigabytes makes the next allocation wait for the scrubbing (profiles/r3_cold_start.md); the map path works on whole
@@ -17,4 +18,6 @@ hipError_t wfm_dmalloc(void** p, size_t bytes);  // on the current device
 // can replace it anywhere; callers that have synchronised the stream the block was used on call wfm_dfree_nosync.
 void wfm_dfree(void* p);
 void wfm_dfree_nosync(void* p);
-size_t wfm_dcache_trim(void);                    // hipFree of every cached block of every device; returns the bytes released
+size_t wfm_dcache_trim(void);                    // every cached small block and the free end of every device's heap back to the driver; returns the bytes released
+void wfm_dcache_warm(void);                      // makes the current device's heap (and maps its first WFM_POOL_GB): wfm_create calls it
+size_t wfm_dcache_stats(int dev, size_t* committed, size_t* live, size_t* peak_live);  // the heap of a device: bytes mapped / handed out / most ever handed out at once

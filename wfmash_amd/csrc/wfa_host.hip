@@ -661,13 +661,19 @@ int run_tiled_phase(wfm_handle* h, wfm_seqset* S, const DevPen& dp, int scope, c
       // maxima always (the blocks before a job's meeting block and the run up to the meeting point); the one with them where a job that simply
       // moved on has reached its fine_s, and in the chunk's first block for the jobs the last chunk left in mode 5
       const bool coarse_on = cfg.reg && cfg.exact && tile2_coarse_maxima();
-      std::vector<int> variants_b((size_t)chunk, coarse_on ? 1 : 2);
-      if (coarse_on)
+      std::vector<int> variants_b((size_t)chunk, coarse_on ? 0 : 2);
+      if (coarse_on) {
         for (size_t i = 0; i < n; ++i) {
           if (!active[i] || !(tj[i].packed & 1)) continue;
-          for (int b = 0; b < chunk; ++b)
+          for (int b = 0; b < chunk; ++b) {
             if ((tj[i].mode == 5 && b == 0) || (tj[i].mode == 0 && (int64_t)tj[i].s0 + (int64_t)(b + 1) * T >= (int64_t)tj[i].fine_s)) variants_b[(size_t)b] |= 2;
+            // without maxima: a job that simply moved on and is still below its fine_s (it may also have met meanwhile: its run up to the meeting
+            // point needs no maxima either -- and is taken by the FINE instantiation where that one is launched alone)
+            if (tj[i].mode == 0 && (int64_t)tj[i].s0 + (int64_t)(b + 1) * T < (int64_t)tj[i].fine_s) variants_b[(size_t)b] |= 1;
+          }
         }
+        for (int b = 0; b < chunk; ++b) if (!variants_b[(size_t)b]) variants_b[(size_t)b] = 2;  // (only runs up to a meeting point: either would do)
+      }
       for (int b = 0; b < chunk; ++b) {
         HIPCHK(h, hipEventRecord(h->tile_ev[2 * b], h->stream));
         if (cfg.reg) {
@@ -1012,6 +1018,8 @@ int align_resident_impl(wfm_handle* h, const wfm_penalties_t* pen, wfm_seqset* S
   std::vector<int64_t> ring2;
   std::vector<int32_t> fine_from;
   const int fine_margin = getenv("WFM_TILE_FINE_MARGIN") ? atoi(getenv("WFM_TILE_FINE_MARGIN")) : 48;
+  const int coarse_min_blocks = getenv("WFM_TILE_COARSE_MIN_BLOCKS") ? atoi(getenv("WFM_TILE_COARSE_MIN_BLOCKS")) : 32;
+  const int coarse_max_jobs = getenv("WFM_TILE_COARSE_MAX_JOBS") ? atoi(getenv("WFM_TILE_COARSE_MAX_JOBS")) : 128;
   const TileCfg tcfg = tile_cfg(*pen, scope);
   // WFM_TILE_V2=0: every tile on the byte kernel (wfa_tile_reg_kernel) -- the A/B switch of the packed kernel (wfa_tile2.hip)
   const bool tile_v2 = !(getenv("WFM_TILE_V2") && atoi(getenv("WFM_TILE_V2")) == 0);
@@ -1054,6 +1062,7 @@ int align_resident_impl(wfm_handle* h, const wfm_penalties_t* pen, wfm_seqset* S
       size_t i = i0;
       int maxw = 0;
       tiled.clear(); ring2.clear(); fine_from.clear();
+      int64_t fine_min_blocks = INT64_MAX;  // fewest blocks any tiled job of the chunk is expected to run before its directions meet
       for (; i < bp_nodes.size(); ++i) {
         const Node& nd = bp_nodes[i];
         const ProbMeta& pm = S->meta[nd.prob];
@@ -1113,8 +1122,14 @@ int align_resident_impl(wfm_handle* h, const wfm_penalties_t* pen, wfm_seqset* S
         if (tile_it) {
           tiled.push_back((int)jobs.size()); ring2.push_back((int64_t)(ring_elems + need / 2));
           // per-score maxima from here on (TileJob::fine_s): a child's directions meet near half its score (the trigger -- the sum of the two largest
-          // antidiagonals -- can fire a little earlier, never later); a root's score is anybody's guess
-          fine_from.push_back(nd.score_rem == INT_MAX ? INT_MAX : std::max(0, nd.score_rem / 2 - fine_margin));
+          // antidiagonals -- can fire a little earlier, never later); a root's score is anybody's guess: it finds its meeting block with one maximum
+          // per block and runs it again (whether the chunk uses any of this is decided below, once its jobs are known)
+          int ff;
+          const int64_t est = nd.score_rem != INT_MAX ? (int64_t)nd.score_rem : (nd.sub != SUB_NONE ? (int64_t)nd.sub : (int64_t)nd.pl + nd.tl);  // its score / the guess or bound / the worst case
+          fine_min_blocks = std::min<int64_t>(fine_min_blocks, est / 2 / tcfg.T);
+          if (nd.score_rem != INT_MAX) ff = std::max(0, nd.score_rem / 2 - fine_margin);
+          else ff = INT_MAX;
+          fine_from.push_back(ff);
         }
         node_of.push_back((int32_t)i);
         ring_elems += need;
@@ -1124,6 +1139,12 @@ int align_resident_impl(wfm_handle* h, const wfm_penalties_t* pen, wfm_seqset* S
         jobs.push_back(j);
       }
       const size_t chunk_end = i;
+      // One maximum per block instead of one per score (TileJob::fine_s) pays where a launch is a few deep jobs that move in step -- C3: 21 roots
+      // of 78 blocks each, -3.7 % per step -- and costs where it is hundreds of jobs of all depths: their blocks need both instantiations of the
+      // kernel side by side (two launches per block), and a root runs its meeting block a third time behind one more look of the host: C2 +10 %
+      // device time, the scaled C4 rank +3 % (gpurun_out/r6r/ab2.log).  So: only chunks of at most coarse_max_jobs jobs, every one of them
+      // at least coarse_min_blocks blocks deep; everybody else keeps the per-score maxima from the first block on (one launch per block, as before).
+      if (tiled.size() > (size_t)coarse_max_jobs || fine_min_blocks < (int64_t)coarse_min_blocks) std::fill(fine_from.begin(), fine_from.end(), 0);
       if (!jobs.empty()) {
         if (h->ring.ensure(ring_elems + 16) || h->bpjobs.ensure(jobs.size()) || h->bpres.ensure(jobs.size())) {
           h->err = "out of device memory (ring arena)"; return WFM_E_NOMEM;
@@ -1477,6 +1498,9 @@ int wfm_create(int device, wfm_handle_t** out) {
   (void)hipEventCreate(&h->ev_base);
   size_t fr = 0, tot = 0;
   if (hipMemGetInfo(&fr, &tot) != hipSuccess) { fr = (size_t)16 << 30; }
+  // the device's heap (dev_cache.hip) exists from the first handle on, with its first gigabytes mapped: no call of either path meets memory
+  // the process has never had before it has used those (the budgets below are taken from what was free BEFORE, the heap's pool is theirs)
+  wfm_dcache_warm();
   // 40 % of the free HBM, but no more than 32 GB: on this driver a first hipMalloc beyond a few tens of GB costs 35-40 ms
   // per GB (64 GB: 2.5-4.4 s, 110 GB: 3.9 s, 16 GB: 0.3 ms -- scripts/micro/malloc_cost.hip, profiles/r3_cold_start.md), which a
   // one-shot run pays in full: LPA all-vs-all (C2) aligned in 3.3 s cold and 0.33 s warm with rings sized for 115 GB.  A

@@ -776,8 +776,9 @@ __global__ __launch_bounds__(64) void wfa_tile_advance_kernel(TileJob* __restric
     // `launched`: which instantiations of wfa_tile2_kernel ran this block (bit 0 without, bit 1 with per-score maxima).  The host leaves out the
     // one it expects no tile for; a job whose state asks for it all the same (mode 5 set by the block before, inside the host's chunk) has not
     // moved and waits for the next chunk
+    // (the FINE instantiation launched alone took every tile: nobody waits then)
     const bool job_fine = J.mode == 5 || (J.mode == 0 && J.s0 + T >= J.fine_s);
-    if (!(launched & (job_fine ? 2 : 1))) return;
+    if (launched != 2 && !(launched & (job_fine ? 2 : 1))) return;
   }
   int32_t* mf = mak + ((int64_t)i * 2 + 0) * T;
   int32_t* mr = mak + ((int64_t)i * 2 + 1) * T;
@@ -823,7 +824,7 @@ __global__ __launch_bounds__(64) void wfa_tile_advance_kernel(TileJob* __restric
   if (lane != 0) return;
   const int64_t max_steps = (int64_t)(pen.o1 + pen.o2) * 4 + (int64_t)(J.pl + J.tl + 2) * max(pen.x, max(pen.e1, pen.e2)) * 2 + 256;
   J.nblocks += 1;
-  const bool was_coarse = coarse && (J.packed & 1) && J.mode == 0 && J.s0 + T < J.fine_s;  // (wfa_tile2_kernel's own test)
+  const bool was_coarse = coarse && (launched & 1) && (J.packed & 1) && J.mode == 0 && J.s0 + T < J.fine_s;  // (wfa_tile2_kernel's own test)
   if (term && exact && was_coarse) {
     // the same block again, with a maximum per score this time: same input ring, same running maxima.  fine_s = -1 tells the host that this
     // job computed the block once more than nblocks says (its cell count), and keeps every later block of the job fine

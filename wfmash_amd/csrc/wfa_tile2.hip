@@ -407,7 +407,7 @@ __global__ __launch_bounds__(NTMAX) void wfa_tile2_kernel(const uint32_t* __rest
   // per-score maxima of the antidiagonals only where the advance kernel reads them score by score (TileJob::fine_s): the block that runs again
   // because the directions met in it (mode 5), and the blocks from fine_s on -- the FINE instantiation's tiles.  Elsewhere one running maximum per
   // lane and ONE wave reduction per block (mode 1, the run up to the meeting point: none at all -- nobody reads its maxima)
-  if (!P2 && FAST) {
+  if (!P2 && FAST && !(coarse & 2)) {  // (bit 1: the only instantiation launched for this block -- the FINE one -- takes every tile)
     const bool fine = !coarse || J.mode == 5 || (J.mode == 0 && sbase + T >= J.fine_s);
     if (fine != FINE) return;
   }
@@ -912,8 +912,8 @@ bool tile2_coarse_maxima() {  // (read per launch, like tile_fast)
   const char* e = getenv("WFM_TILE_COARSE");
   return tile_fast() && !(e && atoi(e) == 0);
 }
-// variants: bit 0 -- the instantiation without per-score maxima, bit 1 -- the one with them (wfa_tile2_kernel, FINE); WFM_TILE_COARSE=0 / the
-// round-4 form: every tile keeps per-score maxima, one launch
+// variants: bit 0 -- the instantiation without per-score maxima, bit 1 -- the one with them (wfa_tile2_kernel, FINE); the FINE one alone takes
+// every tile (per-score maxima are a superset of what any job's block needs).  WFM_TILE_COARSE=0 / the round-4 form: one launch, maxima always
 void launch_tile2(const uint32_t* pk, int32_t* ring, const TileJob* jobs, const TileTask* tasks, int32_t* mak, int ntasks, int threads, int T,
                   int variants, hipStream_t st) {
   const size_t lds1 = (size_t)(T + 1) * 4;
@@ -927,8 +927,9 @@ void launch_tile2(const uint32_t* pk, int32_t* ring, const TileJob* jobs, const 
       else hipLaunchKernelGGL((wfa_tile2_kernel<1024, false, true, false>), dim3(ntasks), dim3(threads), pad, st, pk, ring, jobs, tasks, mak, T, (int32_t*)nullptr, coarse);
     }
     if (variants & 2) {
-      if (threads <= 64) hipLaunchKernelGGL((wfa_tile2_kernel<64, false, true, true>), dim3(ntasks), dim3(64), lds1, st, pk, ring, jobs, tasks, mak, T, (int32_t*)nullptr, coarse);
-      else hipLaunchKernelGGL((wfa_tile2_kernel<1024, false, true, true>), dim3(ntasks), dim3(threads), lds1 * (size_t)(threads / 64), st, pk, ring, jobs, tasks, mak, T, (int32_t*)nullptr, coarse);
+      const int cf = coarse | (variants == 2 ? 2 : 0);
+      if (threads <= 64) hipLaunchKernelGGL((wfa_tile2_kernel<64, false, true, true>), dim3(ntasks), dim3(64), lds1, st, pk, ring, jobs, tasks, mak, T, (int32_t*)nullptr, cf);
+      else hipLaunchKernelGGL((wfa_tile2_kernel<1024, false, true, true>), dim3(ntasks), dim3(threads), lds1 * (size_t)(threads / 64), st, pk, ring, jobs, tasks, mak, T, (int32_t*)nullptr, cf);
     }
   } else {
     if (threads <= 64) hipLaunchKernelGGL((wfa_tile2_kernel<64, false, false, true>), dim3(ntasks), dim3(64), lds1, st, pk, ring, jobs, tasks, mak, T, (int32_t*)nullptr, 0);

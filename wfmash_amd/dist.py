@@ -51,6 +51,35 @@ def gather_bytes(payload: torch.Tensor, dist, dst=0):
     return None
 
 
+def all_gather_bytes(payload: torch.Tensor, dist):
+    """Every rank ends up with every rank's 1-D uint8 tensor (different lengths), in rank order: one all_gather of the sizes, one of
+    the buffers padded to the longest.  The exchange between the two phases of a sharded all-vs-all run: the map phase shards by
+    QUERY (computeMap.hpp:565-599), the align phase by RECORD WEIGHT over the records of all queries
+    (scripts/split_approx_mappings_in_chunks.py:19-27,47), so every rank needs every rank's mapping records."""
+    world = dist.get_world_size()
+    dev = payload.device
+    size = torch.tensor([payload.numel()], dtype=torch.int64, device=dev)
+    sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(sizes, size)
+    sizes = [int(s.item()) for s in sizes]
+    mx = max(max(sizes), 1)
+    buf = torch.zeros(mx, dtype=torch.uint8, device=dev)
+    buf[:payload.numel()] = payload
+    recv = [torch.zeros(mx, dtype=torch.uint8, device=dev) for _ in range(world)]
+    dist.all_gather(recv, buf)
+    return [recv[r][:sizes[r]] for r in range(world)]
+
+
+def all_gather_text(text: str, dist, device=None):
+    """all_gather_bytes for text (dist None: [text])."""
+    if dist is None:
+        return [text]
+    payload = torch.frombuffer(bytearray(text.encode()), dtype=torch.uint8) if text else torch.zeros(0, dtype=torch.uint8)
+    if device is not None:
+        payload = payload.to(device)
+    return [bytes(p.cpu().numpy().tobytes()).decode() for p in all_gather_bytes(payload, dist)]
+
+
 # ---- map path: the queries shard, the target index is replicated on every rank ----
 
 def shard_queries(lengths, world_size):
