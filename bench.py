@@ -52,6 +52,7 @@ def main():
                     help="C3 / C5: synthetic pairs, WFA-only.  C4 (strong scaling by nature): a synthetic pangenome of eight haplotypes (--c4-mbp each) "
                          "all-vs-all, map + align inside the timed region -- queries dealt out over the ranks for the map phase, the mapping records of all "
                          "queries for the align phase (dist.shard_queries / dist.shard_records on the reference's own weights)")
+    ap.add_argument("--out-paf", default="", help="--config C4: rank 0 writes the gathered alignment records of the last step here, sorted")
     ap.add_argument("--c4-mbp", type=float, default=8.0, help="haplotype length of --config C4 in Mbp (248.956422 = north_star's size)")
     ap.add_argument("--pairs", type=int, default=64)
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
@@ -293,9 +294,10 @@ def _strong_c4(args, h, capi, synth, dist, rank, world, comm_dev, torch):
             open(mine, "w").write("".join(lines[i] for i in shard))
             t3 = time.perf_counter()
             al = capi.align_paf(h, fa, mine, out_paf, params={"threads": threads})
+            paths = [out_paf]
             if dist is not None:
-                D.gather_files(out_paf, dist, td, dst=0, device=comm_dev if comm_dev.type == "cuda" else None)
-            state.update(lines=lines, shard=shard)
+                paths = D.gather_files(out_paf, dist, td, dst=0, device=comm_dev if comm_dev.type == "cuda" else None)
+            state.update(lines=lines, shard=shard, paths=paths)
             state["t_map"] += t2 - t1
             state["t_xchg"] += t3 - t2
             return al
@@ -322,6 +324,11 @@ def _strong_c4(args, h, capi, synth, dist, rank, world, comm_dev, torch):
         dt = time.perf_counter() - t0
         lines, shard = state["lines"], state["shard"]
         roof = cpu = parity = None
+        if rank == 0 and args.out_paf:  # the job's whole output (the records of all ranks, sorted: a rank's batches finish in any order) for the tests
+            recs_all = []
+            for pth in state["paths"]:
+                recs_all += open(pth).read().splitlines(keepends=True)
+            open(args.out_paf, "w").write("".join(sorted(recs_all)))
         if rank == 0:
             # the dominant kernel of the path (the tile kernels), from the run's own HIP events: 48 B x the unique cells of its launches / the sum of
             # their durations (launches of the four workers overlap: the sum is an upper bound of the kernel's own time, the figure a lower bound)

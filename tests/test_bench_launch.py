@@ -86,3 +86,23 @@ def test_strong_scaling_two_ranks_on_one_gpu():
     (j,) = [j for j in _json_lines(r.stdout) if "metric" in j]
     assert j["n_gpus"] == 2 and j["scaling"] == "strong" and j["config"]["pairs_total"] == 6 and j["config"]["pairs_per_gpu"] == 3
     assert j["value"] > 0
+
+
+@pytest.mark.gpu
+def test_c4_all_vs_all_two_ranks_give_the_records_of_one(tmp_path):
+    """bench.py --config C4 (north_star's C4 as one job: all eight haplotypes against all eight, the queries sharded over the ranks for the
+    map phase, the mapping records of all queries exchanged and sharded by weight for the align phase, the PAF gathered to rank 0): two ranks
+    sharing the one GPU of the box must produce, byte for byte, the records one rank produces."""
+    outs = []
+    for n in (1, 2):
+        out = tmp_path / f"c4.n{n}.paf"
+        env = dict(_clean_env(), WFM_BENCH_SHARE_GPU="1")
+        r = subprocess.run([sys.executable, BENCH, "--gpus", str(n), "--config", "C4", "--c4-mbp", "1.5", "--steps", "1", "--warmup", "0",
+                            "--no-cpu-baseline", "--out-paf", str(out)], cwd=ROOT, env=env, capture_output=True, text=True, timeout=1200)
+        assert r.returncode == 0, r.stderr[-3000:]
+        (j,) = [j for j in _json_lines(r.stdout) if "metric" in j]
+        assert j["n_gpus"] == n and j["scaling"] == "strong" and j["value"] > 0
+        assert j["config"]["queries_total"] == 8 and j["config"]["records_total"] > 50
+        assert j["roofline"]["bound"] == "valu"
+        outs.append(out.read_bytes())
+    assert len(outs[0]) > 10000 and outs[0] == outs[1]
