@@ -658,3 +658,53 @@ def test_problem_flags_name_the_rare_paths(gpu, oracle):
     rc, ops, sc, _ = oracle.align_biwfa(t2, q2)
     assert sc > 400 and (fl[0] & capi.WFM_PF_ROOT_AGAIN)
     assert res[0].status == 0 and res[0].ops == ops
+
+
+def test_legacy_reads_fixture_on_the_device(gpu, oracle):
+    """The only CIGARs the reference tree holds for this path (test/data/regression/reads.255bps.paf over data/reads.255bps.fa.gz: three
+    records of a writer that predates the current one -- they begin and end with indels, so they pin nothing byte for byte) as a
+    plausibility check of the HIP path: the device's alignment of every forward record's spans must equal the oracle's op for op, and its
+    score must not be worse than the legacy CIGAR's (tests/test_oracle_wfa.py::test_legacy_reads_fixture_is_plausible is the CPU twin)."""
+    import gzip
+    import os
+    import re
+    here = os.path.dirname(__file__)
+    fa = os.path.join(here, "golden", "reads.255bps.fa.gz")
+    paf = os.path.join(here, "golden", "reads.255bps.paf")
+    if not (os.path.exists(fa) and os.path.exists(paf)):
+        pytest.skip("fixture not present")
+    seqs, name = {}, None
+    for line in gzip.open(fa, "rt"):
+        line = line.strip()
+        if line.startswith(">"):
+            name = line[1:].split()[0]
+            seqs[name] = ""
+        elif name:
+            seqs[name] += line.upper()
+    items, legacy = [], []
+    for line in open(paf):
+        f = line.rstrip("\n").split("\t")
+        if f[4] != "+":
+            continue
+        query = seqs[f[0]][int(f[2]):int(f[3])].encode()
+        target = seqs[f[5]][int(f[7]):int(f[8])].encode()
+        cg = [x for x in f if x.startswith("cg:Z:")][0][5:]
+        v = h = 0
+        fixed = bytearray()
+        for cnt, op in re.findall(r"(\d+)([=XIDM])", cg):
+            for _ in range(int(cnt)):
+                if op in "=MX":
+                    fixed.append(ord("M") if target[v] == query[h] else ord("X")); v += 1; h += 1
+                elif op == "I":
+                    fixed.append(ord("I")); h += 1
+                else:
+                    fixed.append(ord("D")); v += 1
+        assert v == len(target) and h == len(query)
+        items.append((target, query))
+        legacy.append(bytes(fixed))
+    assert items
+    res = gpu.align(items)
+    for (p, t), r, lg in zip(items, res, legacy):
+        rc, ops, sc, _ = oracle.align_biwfa(p, t)
+        assert rc == 0 and r.status == 0 and r.ops == ops and r.score == sc
+        assert r.score <= oracle.ops_score(lg)
