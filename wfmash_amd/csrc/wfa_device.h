@@ -69,7 +69,7 @@ struct TileJob {
   int32_t active;                      // 0: the meeting point lies in the block after s0 (or the job is over): tiles exit
   int32_t fmax, rmax;                  // running maximum antidiagonals of the two directions up to s0
   int32_t nblocks;                     // tile blocks executed so far (incl. the one that found the meeting point)
-  int32_t mode;                        // 0: full blocks; 1: next block stops exactly at the meeting point; 2: stopped there;
+  int32_t mode;                        // 0: full blocks; 1: next block stops exactly at the meeting point; 2: stopped there; 6: the block BEFORE s0 runs again (ring_prev, below);
                                        // 5: the block after s0 runs again with per-score maxima (it ran with one maximum for the whole block
                                        // and the wavefronts met inside it: fine_s below)
   int32_t tf, tr;                      // mode >= 1: steps of the forward / reverse direction inside the block after s0
@@ -85,6 +85,15 @@ struct TileJob {
   // maxima: fm + rm >= A at the block's end <=> the directions met somewhere inside it); the advance kernel runs a block that met with a single
   // maximum again with per-score maxima (mode 5) -- a child's score is known, so its last blocks are fine from the start and nothing runs three times.
   int32_t fine_s;
+  // Round 6: a block used to write the gap components' rows of its last 26 scores into its output snapshot -- 104 values per diagonal, 60 % of the
+  // tile kernel's HBM traffic -- for ONE reader: the run up to the meeting point of the NEXT block, when that run is shorter than 26 scores and
+  // its own output (which phase 2 reads 26 rows deep in all five components) needs rows from before its start.  With a third ring the input
+  // of the block before (ring_prev) survives one block longer: blocks write the two rows (I1 / D1) and one row (I2 / D2) the next block loads,
+  // and when a run up to the meeting point is short, the block before it runs once more WITH its gap rows (mode 6: from ring_prev into ring_out)
+  // and the run starts from that.  ring_prev < 0: no third ring (the chunk did not fit one) -- every block writes the 26 rows as before.
+  int64_t ring_prev;
+  int32_t prev_ok;                     // ring_prev holds the snapshot of score s0 - T (false before the phase's second block)
+  int32_t reran;                       // mode-6 runs so far (the host's cell count)
 };
 
 // ---- phase 2 (overlap detection) without a step-by-step kernel ----

@@ -519,7 +519,8 @@ TileCfg tile_cfg(const wfm_penalties_t& pen, int scope) {
 // so that the step-by-step kernel has at most the finer T steps to redo.
 int run_tiled_phase(wfm_handle* h, wfm_seqset* S, const DevPen& dp, int scope, const TileCfg& cfg, int T, bool refine,
                     std::vector<BpJob>& jobs, const std::vector<int>& tiled, std::vector<int64_t>& ring2,
-                    double& tile_ms, uint64_t& tile_cells, uint32_t level, const std::vector<int32_t>* fine_from = nullptr) {
+                    double& tile_ms, uint64_t& tile_cells, uint32_t level, const std::vector<int32_t>* fine_from = nullptr,
+                    const std::vector<int64_t>* ring3 = nullptr) {
   const size_t n = tiled.size();
   if (n == 0) return WFM_OK;
   double lane_cells = 0;  // threads x diagonals per thread x scores over all tiles launched (diagnostics)
@@ -537,6 +538,10 @@ int run_tiled_phase(wfm_handle* h, wfm_seqset* S, const DevPen& dp, int scope, c
     t.width = j.width; t.koff = j.koff; t.s0 = 0; t.active = 1; t.fmax = 0; t.rmax = 0; t.nblocks = 0; t.mode = 0; t.tf = 0; t.tr = 0; t.last_fwd = 0; t.packed = j.packed;
     t.p2_off = 0; t.w2 = 0; t.koff2 = 0; t.sub = j.sub;
     t.fine_s = (fine_from && i < fine_from->size()) ? (*fine_from)[i] : INT_MAX;  // (TileJob::fine_s; a job whose score nobody knows finds its meeting block by running it again)
+    // a third ring (TileJob::ring_prev): packed jobs of the exact tile phase only -- the byte kernel and the step kernel's fall-backs read gap rows
+    // 26 deep from any snapshot
+    t.ring_prev = (ring3 && i < ring3->size() && (*ring3)[i] >= 0 && (j.packed & 1) && cfg.reg && cfg.exact && !refine) ? (*ring3)[i] : -1;
+    t.prev_ok = 0; t.reran = 0;
   }
   bool any_cut = false;  // the kernel form with the score bounds' bookkeeping is only launched when a job carries one
   for (size_t i = 0; i < n; ++i) any_cut |= tj[i].sub != SUB_NONE;
@@ -716,6 +721,8 @@ int run_tiled_phase(wfm_handle* h, wfm_seqset* S, const DevPen& dp, int scope, c
         }
         if (got[i].fine_s == -1 && tj[i].fine_s != -1)  // the block in which the directions met ran once more, for its per-score maxima (TileJob::fine_s)
           for (int d = 0; d < 2; ++d) tile_cells += (uint64_t)h_cells_sum(tj[i].pl, tj[i].tl, tj[i].sub, got[i].s0 + 1, got[i].s0 + T);
+        if (got[i].reran > tj[i].reran)  // the block before the meeting block ran once more, for its gap rows (TileJob::ring_prev)
+          for (int d = 0; d < 2; ++d) tile_cells += (uint64_t)h_cells_sum(tj[i].pl, tj[i].tl, tj[i].sub, got[i].s0 - T + 1, got[i].s0);
         tj[i] = got[i];
         active[i] = (char)(got[i].active != 0);
         fmax[i] = got[i].fmax; rmax[i] = got[i].rmax;
@@ -1015,7 +1022,9 @@ int align_resident_impl(wfm_handle* h, const wfm_penalties_t* pen, wfm_seqset* S
   double wall_tile = 0, wall_base = 0;
   std::vector<BpJob> jobs;
   std::vector<int> tiled;
-  std::vector<int64_t> ring2;
+  std::vector<int64_t> ring2, ring3;
+  std::vector<size_t> ring_third;  // elements of one ring of every tiled job of the chunk
+  static const bool ring3_on = !(getenv("WFM_TILE_RING3") && atoi(getenv("WFM_TILE_RING3")) == 0);
   std::vector<int32_t> fine_from;
   const int fine_margin = getenv("WFM_TILE_FINE_MARGIN") ? atoi(getenv("WFM_TILE_FINE_MARGIN")) : 48;
   const int coarse_min_blocks = getenv("WFM_TILE_COARSE_MIN_BLOCKS") ? atoi(getenv("WFM_TILE_COARSE_MIN_BLOCKS")) : 32;
@@ -1061,7 +1070,7 @@ int align_resident_impl(wfm_handle* h, const wfm_penalties_t* pen, wfm_seqset* S
       size_t ring_elems = 0;
       size_t i = i0;
       int maxw = 0;
-      tiled.clear(); ring2.clear(); fine_from.clear();
+      tiled.clear(); ring2.clear(); ring3.clear(); ring_third.clear(); fine_from.clear();
       int64_t fine_min_blocks = INT64_MAX;  // fewest blocks any tiled job of the chunk is expected to run before its directions meet
       for (; i < bp_nodes.size(); ++i) {
         const Node& nd = bp_nodes[i];
@@ -1120,7 +1129,7 @@ int align_resident_impl(wfm_handle* h, const wfm_penalties_t* pen, wfm_seqset* S
         if (j.packed && nd.sub != SUB_NONE && (int64_t)nd.sub * 16 < (int64_t)nd.pl + nd.tl) j.packed |= 2;
         band_jobs += band > 0;
         if (tile_it) {
-          tiled.push_back((int)jobs.size()); ring2.push_back((int64_t)(ring_elems + need / 2));
+          tiled.push_back((int)jobs.size()); ring2.push_back((int64_t)(ring_elems + need / 2)); ring_third.push_back(need / 2);
           // per-score maxima from here on (TileJob::fine_s): a child's directions meet near half its score (the trigger -- the sum of the two largest
           // antidiagonals -- can fire a little earlier, never later); a root's score is anybody's guess: it finds its meeting block with one maximum
           // per block and runs it again (whether the chunk uses any of this is decided below, once its jobs are known)
@@ -1145,6 +1154,16 @@ int align_resident_impl(wfm_handle* h, const wfm_penalties_t* pen, wfm_seqset* S
       // device time, the scaled C4 rank +3 % (gpurun_out/r6r/ab2.log).  So: only chunks of at most coarse_max_jobs jobs, every one of them
       // at least coarse_min_blocks blocks deep; everybody else keeps the per-score maxima from the first block on (one launch per block, as before).
       if (tiled.size() > (size_t)coarse_max_jobs || fine_min_blocks < (int64_t)coarse_min_blocks) std::fill(fine_from.begin(), fine_from.end(), 0);
+      // third rings behind the chunk's rings (TileJob::ring_prev), for all of its tiled jobs or for none: where half as much again still fits the
+      // budget (and 12 GB: fresh memory is 30 ms per GB).  The chunk's composition does not depend on it.
+      {
+        size_t third = 0;
+        for (size_t x : ring_third) third += x;
+        const bool give = ring3_on && tcfg.reg && tcfg.exact && third > 0 && (ring_elems + third) * 4 <= std::min<size_t>(h->mem_budget, (size_t)12 << 30);
+        ring3.assign(tiled.size(), -1);
+        if (give)
+          for (size_t q = 0; q < tiled.size(); ++q) { ring3[q] = (int64_t)ring_elems; ring_elems += ring_third[q]; }
+      }
       if (!jobs.empty()) {
         if (h->ring.ensure(ring_elems + 16) || h->bpjobs.ensure(jobs.size()) || h->bpres.ensure(jobs.size())) {
           h->err = "out of device memory (ring arena)"; return WFM_E_NOMEM;
@@ -1152,7 +1171,7 @@ int align_resident_impl(wfm_handle* h, const wfm_penalties_t* pen, wfm_seqset* S
         {
           double tms = 0; uint64_t tcells = 0;
           const auto tw0 = std::chrono::steady_clock::now();
-          rc = run_tiled_phase(h, S, dp, scope, tcfg, tcfg.T, false, jobs, tiled, ring2, tms, tcells, level, &fine_from);
+          rc = run_tiled_phase(h, S, dp, scope, tcfg, tcfg.T, false, jobs, tiled, ring2, tms, tcells, level, &fine_from, &ring3);
           if (rc == WFM_OK && tcfg.T_refine > 0 && tcfg.T_refine < tcfg.T && !(tcfg.reg && tcfg.exact))
             rc = run_tiled_phase(h, S, dp, scope, tcfg, tcfg.T_refine, true, jobs, tiled, ring2, tms, tcells, level);
           wall_tile += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tw0).count();

@@ -792,6 +792,17 @@ __global__ __launch_bounds__(64) void wfa_tile_advance_kernel(TileJob* __restric
     }
     return;
   }
+  if (J.mode == 6) {
+    // the block before s0 has run again, with the gap rows of its last 26 scores: ring_out holds the snapshot of s0 the short run up to the
+    // meeting point needs; what was ring_in (the same snapshot without those rows) takes that run's output
+    for (int t = lane; t < T; t += 64) { mf[t] = 0; mr[t] = 0; }
+    if (lane == 0) {
+      const int64_t t = J.ring_in; J.ring_in = J.ring_out; J.ring_out = t;
+      J.mode = 1; J.reran += 1;
+      jobs[i] = J;
+    }
+    return;
+  }
   const int A = J.pl + J.tl - 1;
   int fm = J.fmax, rm = J.rmax;  // running maxima before the chunk of 64 scores at hand (uniform)
   int tf = 0, tr = 0, last_fwd = 0;
@@ -830,8 +841,10 @@ __global__ __launch_bounds__(64) void wfa_tile_advance_kernel(TileJob* __restric
     // job computed the block once more than nblocks says (its cell count), and keeps every later block of the job fine
     J.mode = 5; J.fine_s = -1; J.nblocks -= 1;
   } else if (term && exact) {
-    // redo this block, but only up to the meeting point (forward tf steps, reverse tr): same input ring
-    J.mode = 1; J.tf = tf; J.tr = tr; J.last_fwd = last_fwd;
+    // redo this block, but only up to the meeting point (forward tf steps, reverse tr): same input ring -- unless one of the two runs is
+    // shorter than the rows phase 2 reads behind it and the snapshot holds no gap rows that deep (TileJob::ring_prev): the block before first
+    J.mode = (J.ring_prev >= 0 && J.prev_ok && min(tf, tr) < 26) ? 6 : 1;
+    J.tf = tf; J.tr = tr; J.last_fwd = last_fwd;
     J.fmax = fm; J.rmax = rm;
   } else if (term || 2 * (int64_t)(J.s0 + T) > max_steps) {
     J.active = 0;
@@ -839,7 +852,12 @@ __global__ __launch_bounds__(64) void wfa_tile_advance_kernel(TileJob* __restric
     J.fmax = fm; J.rmax = rm;
     J.s0 += T;
     J.mode = 0;
-    const int64_t t = J.ring_in; J.ring_in = J.ring_out; J.ring_out = t;
+    if (J.ring_prev >= 0) {  // three rings: the input of the block just computed stays one block longer
+      const int64_t t = J.ring_prev; J.ring_prev = J.ring_in; J.ring_in = J.ring_out; J.ring_out = t;
+      J.prev_ok = 1;
+    } else {
+      const int64_t t = J.ring_in; J.ring_in = J.ring_out; J.ring_out = t;
+    }
   }
   jobs[i] = J;
 }

@@ -369,7 +369,8 @@ __global__ __launch_bounds__(NTMAX) void wfa_tile2_kernel(const uint32_t* __rest
   TileTask tk = tasks[blockIdx.x];
   const TileJob J = jobs[tk.job];
   if (!J.active) return;
-  const int sbase = P2 ? (tk.dir == 0 ? J.tf : J.tr) : J.s0;  // score of the snapshot this direction starts from
+  // score of the snapshot this direction starts from (mode 6: the block before the job's s0 once more, from the snapshot before it -- TileJob::ring_prev)
+  const int sbase = P2 ? (tk.dir == 0 ? J.tf : J.tr) : (J.mode == 6 ? J.s0 - T : J.s0);
   const Rng2 RG = make_rng2(J.pl, J.tl, J.sub);
   const bool lowdiv = (J.packed & 2) != 0;  // near-identical sequences: the job's known score is under a sixteenth of its length (the host says: pk_extend2, tail_direct)
   int halo = T;  // columns computed on either side of the core (the trapezoid loses one per step)
@@ -400,10 +401,14 @@ __global__ __launch_bounds__(NTMAX) void wfa_tile2_kernel(const uint32_t* __rest
   const int pl = J.pl, tl = J.tl, s0 = sbase;
   const int k0 = kA + tid * C;  // first diagonal of this thread
   const int64_t width = J.width;
-  const int32_t* rin = ring_arena + J.ring_in + J.koff + (int64_t)dir * 5 * RING * width;
+  const int32_t* rin = ring_arena + ((!P2 && J.mode == 6) ? J.ring_prev : J.ring_in) + J.koff + (int64_t)dir * 5 * RING * width;
   int32_t* rout = ring_arena + J.ring_out + J.koff + (int64_t)dir * 5 * RING * width;
   const int kmax = tk.core_hi + halo;  // last diagonal of the tile
   const int Tn = (!P2 && J.mode == 1) ? (dir == 0 ? J.tf : J.tr) : T;
+  // how many of the block's last rows of the gap components go into the output snapshot: all H where somebody may read that deep (the run up to
+  // the meeting point, whose output phase 2 reads; the block that runs again for such a run's sake; jobs without a third ring), else the E1 rows
+  // the next block loads
+  const int t_stream = Tn - ((J.mode == 1 || J.mode == 6 || J.ring_prev < 0) ? H : E1);
   // per-score maxima of the antidiagonals only where the advance kernel reads them score by score (TileJob::fine_s): the block that runs again
   // because the directions met in it (mode 5), and the blocks from fine_s on -- the FINE instantiation's tiles.  Elsewhere one running maximum per
   // lane and ONE wave reduction per block (mode 1, the run up to the meeting point: none at all -- nobody reads its maxima)
@@ -689,7 +694,7 @@ __global__ __launch_bounds__(NTMAX) void wfa_tile2_kernel(const uint32_t* __rest
       if (!FINE) (void)__hip_atomic_fetch_max(&s_run[tid], mak, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // ds_max_i32, nothing returned
       else { mak = wave_max63(mak); if (lane == 63) s_makr[(WAVE1 ? 0 : wv * MKS) + t - 1] = mak; }
       // ---- this step's row waits for its extension; its gap components are final
-      if (__builtin_expect(t > Tn - H, 0)) {  // stream the last H rows of I/D of the core to the output snapshot
+      if (__builtin_expect(t > t_stream, 0)) {  // stream the last rows of I/D of the core to the output snapshot
 #pragma unroll
         for (int c = 0; c < C; ++c) {
           const int k = k0 + c;
@@ -744,7 +749,7 @@ __global__ __launch_bounds__(NTMAX) void wfa_tile2_kernel(const uint32_t* __rest
       }
     }
     // stream the last H rows of I/D of the core to the output snapshot
-    if (!P2 && __builtin_expect(t > Tn - H, 0)) {
+    if (!P2 && __builtin_expect(t > t_stream, 0)) {
 #pragma unroll
       for (int c = 0; c < C; ++c) {
         const int k = k0 + c;
@@ -890,7 +895,7 @@ __global__ __launch_bounds__(NTMAX) void wfa_tile2_kernel(const uint32_t* __rest
   if (!FINE) {
     // one maximum for the whole block, in the block's last slot: the advance kernel's prefix maxima make of it what the per-score form would
     // have left at the block's end -- enough to say whether the directions met in this block (they are run again with per-score maxima then)
-    if (J.mode != 1) {
+    if (J.mode == 0) {
       const int makrun = wave_max63(s_run[tid]);
       if (lane == 63 && makrun > 0) atomicMax(&mk[T - 1], makrun);
     }
