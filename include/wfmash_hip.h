@@ -429,6 +429,17 @@ typedef struct {
 int64_t wfm_map_fragments(wfm_handle_t* h, const wfm_index_t* ix, const char* seq, int64_t seq_len,
                           const int64_t* frag_off, const int32_t* frag_seq_id, int64_t nfrag,
                           const wfm_map_params_t* prm, wfm_mapping_t* out, int32_t* out_frag, int64_t cap);
+/* The same, and the first step of the query's post-processing with it: mergeMappingsInRange[WithChains]
+ * (mappingFilter.hpp:402-421, :593-612) begins by sorting a query's mappings by (target, strand, query position, target position);
+ * the mappings are still on the device when L2 ends, so the batch is sorted there.  frag_first[f] = the first fragment of fragment f's
+ * query (the caller adds (f - frag_first[f]) * window_length to queryStartPos: the key is made of that sum).  out_perm[i] = index into
+ * out[] of the i-th mapping in (query, target, strand, query position, target position) order; out_perm[0] = 0xffffffff when two
+ * mappings of a query share a key (std::sort leaves ties in an order of its own: the caller sorts as before) or the order could not
+ * be made.  out / out_frag stay in fragment order, the order the reference's representative ids count in. */
+int64_t wfm_map_fragments_ordered(wfm_handle_t* h, const wfm_index_t* ix, const char* seq, int64_t seq_len,
+                                  const int64_t* frag_off, const int32_t* frag_seq_id, int64_t nfrag,
+                                  const wfm_map_params_t* prm, wfm_mapping_t* out, int32_t* out_frag, int64_t cap,
+                                  const int32_t* frag_first, uint32_t* out_perm);
 
 #ifdef __cplusplus
 }

@@ -1,5 +1,8 @@
 #include "map_filter.hpp"
 
+#include <cstring>
+#include <memory>
+#include <type_traits>
 #include <algorithm>
 #include <chrono>
 #include <thread>
@@ -324,21 +327,58 @@ bool strictly_ascending(const std::vector<uint32_t>& q, Less less) {
   return ok.load();
 }
 
+// f3, its first step: the caller may have the chaining order from the device (wfm_map_fragments_ordered) and have built
+// readMappings in that order already; presorted_orig[i] = the position mapping i had in the reference's input order (fragment order:
+// the ids the chain representatives are made of).  Consumed by the next chain_mappings call of this thread.
+static thread_local const uint32_t* tl_presorted = nullptr;
+static thread_local size_t tl_presorted_n = 0;
+
 // Steps 1-4 of mergeMappingsInRange[WithChains] (mappingFilter.hpp:402-498, :593-675): sorts
 // readMappings into chains and returns each mapping's chain representative.
 std::vector<offset_t> chain_mappings(MappingResultsVector_t& readMappings, int max_dist, const Parameters& param) {
+  const uint32_t* presorted = tl_presorted_n == readMappings.size() ? tl_presorted : nullptr;
+  tl_presorted = nullptr; tl_presorted_n = 0;
   const size_t n = readMappings.size();
   static const bool tdbg = getenv("WFM_FILTER_TIMES") != nullptr;
   auto tnow = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   double tt[8] = {0}; int ti = 0; tt[ti++] = tnow();
   std::vector<offset_t> chainOf(n);
-  std::iota(chainOf.begin(), chainOf.end(), (offset_t)0);
-  std::vector<double> linkScore(n, std::numeric_limits<double>::max());
-  std::vector<int64_t> linkFrom(n, std::numeric_limits<int64_t>::min());
+  // (round 6: the link arrays and the permutations' scratch are raw memory filled by all threads -- a std::vector's constructor writes its 14 - 48 MB
+  // on one thread, 30 ms of a chromosome-sized query's 150)
+  struct RawFree { void operator()(void* q) const { free(q); } };
+  std::unique_ptr<double, RawFree> linkScore_mem((double*)malloc(std::max<size_t>(n, 1) * sizeof(double)));
+  std::unique_ptr<int64_t, RawFree> linkFrom_mem((int64_t*)malloc(std::max<size_t>(n, 1) * sizeof(int64_t)));
+  if (!linkScore_mem || !linkFrom_mem) throw std::bad_alloc();
+  double* const linkScore = linkScore_mem.get();
+  int64_t* const linkFrom = linkFrom_mem.get();
+  par_ranges(n, [&](size_t lo, size_t hi) {
+    for (size_t i = lo; i < hi; ++i) { chainOf[i] = (offset_t)i; linkScore[i] = std::numeric_limits<double>::max(); linkFrom[i] = std::numeric_limits<int64_t>::min(); }
+  });
 
   std::vector<uint32_t> p(n);
   std::iota(p.begin(), p.end(), 0u);
-  {
+  bool device_order = false;
+  if (presorted) {
+    // the device's order is THE sorted order exactly when the keys ascend strictly in it (no ties: any sort gives this permutation)
+    std::atomic<bool> ok{true};
+    par_ranges(n, [&](size_t lo, size_t hi) {
+      for (size_t i = std::max<size_t>(lo, 1); i < hi && ok.load(std::memory_order_relaxed); ++i) {
+        const MappingResult &a = readMappings[i - 1], &b = readMappings[i];
+        const int32_t sa = (int32_t)a.strand(), sb = (int32_t)b.strand();
+        if (!(std::tie(a.refSeqId, sa, a.queryStartPos, a.refStartPos) < std::tie(b.refSeqId, sb, b.queryStartPos, b.refStartPos))) ok.store(false, std::memory_order_relaxed);
+      }
+    });
+    if (ok.load()) {
+      device_order = true;
+      par_ranges(n, [&](size_t lo, size_t hi) { for (size_t i = lo; i < hi; ++i) { p[i] = presorted[i]; chainOf[i] = (offset_t)presorted[i]; } });
+    } else {
+      // back to the reference's input order, then everything as without the shortcut
+      MappingResultsVector_t orig(n);
+      par_ranges(n, [&](size_t lo, size_t hi) { for (size_t i = lo; i < hi; ++i) orig[presorted[i]] = readMappings[i]; });
+      readMappings.swap(orig);
+    }
+  }
+  if (!device_order) {
     // the comparator only reads four fields: from a compact key array (16 B per mapping) the index sort touches
     // a third of the memory; same comparisons, same permutation
     struct Key { uint32_t ref; int32_t strand; uint32_t q, r; };
@@ -409,14 +449,20 @@ std::vector<offset_t> chain_mappings(MappingResultsVector_t& readMappings, int m
     if (!sorted_fast) std::sort(p.begin(), p.end(), less);
   }
   tt[ti++] = tnow();
-  // (one scratch array serves both permutations of the call: the second one writes into pages the first has left behind)
-  MappingResultsVector_t scratch(n);
+  // (one scratch array serves both permutations of the call: the second one writes into pages the first has left behind; raw memory, copied back
+  // by all threads -- see above)
+  std::unique_ptr<MappingResult, RawFree> scratch_mem((MappingResult*)malloc(std::max<size_t>(n, 1) * sizeof(MappingResult)));
+  if (!scratch_mem) throw std::bad_alloc();
+  MappingResult* const scratch = scratch_mem.get();
+  static_assert(std::is_trivially_copyable<MappingResult>::value, "permute_mappings copies raw bytes");
   auto permute_mappings = [&]() {
-    par_ranges(n, [&](size_t lo, size_t hi) { for (size_t i = lo; i < hi; ++i) scratch[i] = readMappings[p[i]]; });
-    readMappings.swap(scratch);
+    par_ranges(n, [&](size_t lo, size_t hi) { for (size_t i = lo; i < hi; ++i) std::memcpy((void*)&scratch[i], (const void*)&readMappings[p[i]], sizeof(MappingResult)); });
+    par_ranges(n, [&](size_t lo, size_t hi) { std::memcpy((void*)&readMappings[lo], (const void*)&scratch[lo], (hi - lo) * sizeof(MappingResult)); });
   };
-  permute_mappings();
-  par_ranges(n, [&](size_t lo, size_t hi) { for (size_t i = lo; i < hi; ++i) chainOf[i] = (offset_t)p[i]; });  // chainOf was 0 .. n-1: permuted, it is p
+  if (!device_order) {
+    permute_mappings();
+    par_ranges(n, [&](size_t lo, size_t hi) { for (size_t i = lo; i < hi; ++i) chainOf[i] = (offset_t)p[i]; });  // chainOf was 0 .. n-1: permuted, it is p
+  }
   tt[ti++] = tnow();
 
   // Within one (target, strand) run every mapping links to its closest admissible successor.  The runs do not see each
@@ -695,6 +741,7 @@ void MappingFilterUtils::filterByScaffolds(MappingResultsVector_t& readMappings,
 // Map::filterSubsetMappings (computeMap.hpp:1076-1165)
 // ---------------------------------------------------------------------------------------------
 void set_filter_threads(int threads) { tl_filter_threads = std::max(1, threads); }
+void set_presorted_order(const uint32_t* orig_index, size_t n) { tl_presorted = orig_index; tl_presorted_n = n; }
 
 FilteredMappingsResult filterSubsetMappings(MappingResultsVector_t& mappings, const Parameters& param, const SequenceIdManager& idManager,
                                             offset_t queryLen) {

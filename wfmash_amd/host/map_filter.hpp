@@ -49,6 +49,10 @@ struct FilteredMappingsResult {
 };
 // host threads the CALLING thread may use inside filterSubsetMappings (default 1): a batch with a single long query
 void set_filter_threads(int threads);
+// f3, first step: the caller built the next query's mappings in chaining order from the device's permutation
+// (wfm_map_fragments_ordered); orig_index[i] = mapping i's position in the reference's input order (fragment order).  chain_mappings checks the
+// order and skips its own sort; the pointer must stay valid until the next filterSubsetMappings / mergeMappingsInRange of this thread returns.
+void set_presorted_order(const uint32_t* orig_index, size_t n);
 
 // Map::filterSubsetMappings: everything between a query's raw L2 mappings and what is printed
 FilteredMappingsResult filterSubsetMappings(MappingResultsVector_t& mappings, const Parameters& param, const SequenceIdManager& idManager,

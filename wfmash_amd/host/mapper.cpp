@@ -356,19 +356,31 @@ int Map::mapQuery(MapSummary* summary) {
         double tb = now_ms();
         std::vector<wfm_mapping_t> maps;
         std::vector<int32_t> mfrag;
+        std::vector<uint32_t> perm;        // the batch's mappings in chaining order (wfm_map_fragments_ordered), or perm[0] = ~0u
+        std::vector<int32_t> frag_first;   // per fragment: the first fragment of its query
+        static const bool dev_order = !(getenv("WFM_FILTER_DEVICE_ORDER") && atoi(getenv("WFM_FILTER_DEVICE_ORDER")) == 0);
         if (ixs[g] && !b.frag_off.empty()) {
+          if (dev_order && P.split) {
+            frag_first.resize(b.frag_off.size());
+            for (const auto& q : b.bq)
+              for (int64_t f = q.first_frag; f < q.first_frag + q.nfrag; ++f) frag_first[(size_t)f] = (int32_t)q.first_frag;
+          }
           // a fragment of a pangenome maps about once per target haplotype; a too small buffer costs a
           // second pass over the batch, so be generous
           int64_t cap = (int64_t)b.frag_off.size() * std::min<int64_t>(256, std::max<int64_t>(16, 2 * (int64_t)subset.size())) + (1 << 16);
           for (;;) {
             maps.resize((size_t)cap); mfrag.resize((size_t)cap);
-            const int64_t n = wfm_map_fragments(hg, ixs[g], b.bases, b.n_bases, b.frag_off.data(), b.frag_seq.data(),
-                                                (int64_t)b.frag_off.size(), &T.prm, maps.data(), mfrag.data(), cap);
+            if (!frag_first.empty()) perm.resize((size_t)cap);
+            const int64_t n = frag_first.empty()
+                                  ? wfm_map_fragments(hg, ixs[g], b.bases, b.n_bases, b.frag_off.data(), b.frag_seq.data(), (int64_t)b.frag_off.size(), &T.prm,
+                                                      maps.data(), mfrag.data(), cap)
+                                  : wfm_map_fragments_ordered(hg, ixs[g], b.bases, b.n_bases, b.frag_off.data(), b.frag_seq.data(), (int64_t)b.frag_off.size(),
+                                                              &T.prm, maps.data(), mfrag.data(), cap, frag_first.data(), perm.data());
             if (n < 0) {
               fail((int)n, wfm_last_error(hg));
               return;
             }
-            if (n <= cap) { maps.resize((size_t)n); mfrag.resize((size_t)n); break; }
+            if (n <= cap) { maps.resize((size_t)n); mfrag.resize((size_t)n); if (!perm.empty()) perm.resize((size_t)n); break; }
             cap = n;
           }
         }
@@ -389,6 +401,7 @@ int Map::mapQuery(MapSummary* summary) {
             while (m < maps.size() && mfrag[m] < bq[qn].first_frag + bq[qn].nfrag) ++m;
           }
         }
+        const bool have_perm = !perm.empty() && perm.size() == maps.size() && perm[0] != 0xffffffffu;
         BatchOut bo;
         bo.q.resize(bq.size());
         for (const auto& q : bq) bo.ids.push_back(q.id);
@@ -401,14 +414,52 @@ int Map::mapQuery(MapSummary* summary) {
           for (size_t qn; error_rc.load() == WFM_OK && (qn = next.fetch_add(1)) < bq.size();) {
             const BatchQuery& q = bq[qn];
             MappingResultsVector_t results;
-            results.reserve(first_map[qn + 1] - first_map[qn]);
-            for (size_t m = first_map[qn]; m < first_map[qn + 1]; ++m) {
-              MappingResult r;
-              std::memcpy(&r, &maps[m], sizeof(r));
-              r.queryStartPos += (uint32_t)((mfrag[m] - q.first_frag) * w);  // fragmentIndex * windowLength, also for the anchored one
-              results.push_back(r);
+            const size_t m0 = first_map[qn], nq = first_map[qn + 1] - first_map[qn];
+            std::vector<uint32_t> orig;  // (device order) position of every mapping in fragment order, within the query
+            if (have_perm && nq >= 2) {
+              // the query's mappings in chaining order, straight from the device's permutation (its queries are consecutive there as here)
+              results.resize(nq);
+              orig.resize(nq);
+              std::atomic<bool> inside_a{true};
+              auto fill = [&](size_t lo, size_t hi) {
+                for (size_t i = lo; i < hi; ++i) {
+                  const size_t m = perm[m0 + i];
+                  if (m < m0 || m - m0 >= nq) { inside_a.store(false); continue; }  // (a permutation that mixes queries would be a bug: sort on the host then)
+                  MappingResult r;
+                  std::memcpy(&r, &maps[m], sizeof(r));
+                  r.queryStartPos += (uint32_t)((mfrag[m] - q.first_frag) * w);
+                  results[i] = r;
+                  orig[i] = (uint32_t)(m - m0);
+                }
+              };
+              {
+                const size_t T = nq >= ((size_t)1 << 17) ? (size_t)std::max(1, std::min(32, threads_each / std::max(1, nt_filter))) : 1;
+                std::vector<std::thread> pool;
+                for (size_t t = 1; t < T; ++t) pool.emplace_back(fill, nq * t / T, nq * (t + 1) / T);
+                fill(0, nq / T);
+                for (auto& th : pool) th.join();
+              }
+              const bool inside = inside_a.load();
+              if (!inside) {
+                for (size_t i = 0; i < nq; ++i) {
+                  MappingResult r;
+                  std::memcpy(&r, &maps[m0 + i], sizeof(r));
+                  r.queryStartPos += (uint32_t)((mfrag[m0 + i] - q.first_frag) * w);
+                  results[i] = r;
+                }
+                orig.clear();
+              }
+            } else {
+              results.reserve(nq);
+              for (size_t m = first_map[qn]; m < first_map[qn + 1]; ++m) {
+                MappingResult r;
+                std::memcpy(&r, &maps[m], sizeof(r));
+                r.queryStartPos += (uint32_t)((mfrag[m] - q.first_frag) * w);  // fragmentIndex * windowLength, also for the anchored one
+                results.push_back(r);
+              }
             }
             MappingOutput::mappingBoundarySanityCheck(q.len, results, ids);
+            if (!orig.empty()) set_presorted_order(orig.data(), orig.size());
             FilteredMappingsResult fr = filterSubsetMappings(results, P, ids, q.len);
             const bool merged = P.mergeMappings && P.split;
             MappingResultsVector_t& keep = merged ? fr.mergedMappings : fr.nonMergedMappings;
