@@ -209,11 +209,10 @@ void wfm_set_concurrent_calls(wfm_handle_t* h, int other_calls);
 size_t wfm_get_problem_flags(const wfm_handle_t* h, uint32_t* out, size_t n);
 
 /* Device blocks of both paths -- the map path's work buffers, the align path's arenas and a batch's sequence buffers, also
- * those of a handle that has been destroyed -- are kept in a per-device cache between calls (a first hipMalloc of a gigabyte
- * costs 30 - 40 ms on this driver, a hipFree of gigabytes stalls a later allocation for up to seconds while the driver wipes
- * the memory; wfmash_amd/csrc/dev_cache.h, profiles/r4_map_host.md).  This hands every cached
- * block back to the driver and returns the bytes released; WFM_DEV_CACHE_GB bounds what the cache may hold per device
- * (default: a third of the device's memory -- 96 GB of an MI355X's 288; only the device that passes its bound is trimmed). */
+ * those of a handle that has been destroyed -- come from one heap per device and go back to it (wfmash_amd/csrc/dev_cache.h: an
+ * address range reserved at the first wfm_create of the device, 1 GB chunks mapped behind what is there, WFM_POOL_GB -- 24 -- at once;
+ * memory a process has never had costs ~30 ms per GB on this driver beyond its first ~30 GB, profiles/r6_vmm_fresh.md).  This hands
+ * the free chunks at every heap's end (and the cached blocks under a megabyte) back to the driver and returns the bytes released. */
 size_t wfm_trim_device_cache(void);
 
 int  wfm_get_stats(const wfm_handle_t* h, wfm_stats_t* out);
