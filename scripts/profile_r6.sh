@@ -62,3 +62,9 @@ rocprofv3 --kernel-trace --stats -d /tmp/p6/c5 -o t -- python $root/bench.py --c
 cd "$root"
 python scripts/prof_summary.py "$po/r6_c5.md" "r6: C5 (8 pairs of 100 kb at 15 %), align only (bench.py --config C5 --pairs 8)" "$(find /tmp/p6/c5 -name '*results.db' | head -1)" --bench /tmp/p6_c5.log > /dev/null
 ls -la "$po"
+# m3 for sequences under the device winnower's threshold: the host's threads against one set of launches per sequence
+python scripts/winnow_short.py --threads 32 > "$po/r6_winnow_host.jsonl" 2>/dev/null
+WFM_WINNOW_DEV_MIN=0 python scripts/winnow_short.py --threads 32 > "$po/r6_winnow_dev.jsonl" 2>/dev/null
+python scripts/winnow_short.py --threads 256 > "$po/r6_winnow_host256.jsonl" 2>/dev/null
+WFM_WINNOW_DEV_MIN=0 python scripts/winnow_short.py --threads 256 > "$po/r6_winnow_dev256.jsonl" 2>/dev/null
+cat "$po"/r6_winnow_*.jsonl

@@ -816,18 +816,37 @@ __global__ __launch_bounds__(NT) void wfa_base_kernel(const uint8_t* __restrict_
           }
           continue;
         }
-        const unsigned b = c.bt[(int64_t)sc * c.width + k];
-        const int pre = c.pre[(int64_t)sc * c.width + k];
-        w.push(OP_M, off - pre);
-        off = pre; v = off - k; h = off;
-        if (v <= 0 || h <= 0) break;
-        const unsigned src = b & 7u;
-        if (src == C_M) { sc -= pn.x; comp = C_M; w.push(OP_X, 1); --off; }
-        else if (src == C_I1) { if (b & BT_I1_EXT) { sc -= pn.e1; comp = C_I1; } else { sc -= pn.o1 + pn.e1; comp = C_M; } w.push(OP_I, 1); --k; --off; }
-        else if (src == C_I2) { if (b & BT_I2_EXT) { sc -= pn.e2; comp = C_I2; } else { sc -= pn.o2 + pn.e2; comp = C_M; } w.push(OP_I, 1); --k; --off; }
-        else if (src == C_D1) { if (b & BT_D1_EXT) { sc -= pn.e1; comp = C_D1; } else { sc -= pn.o1 + pn.e1; comp = C_M; } w.push(OP_D, 1); ++k; }
-        else { if (b & BT_D2_EXT) { sc -= pn.e2; comp = C_D2; } else { sc -= pn.o2 + pn.e2; comp = C_M; } w.push(OP_D, 1); ++k; }
-        v = off - k; h = off;
+        // (round 6) A run of mismatches stays on its diagonal, x scores apart -- and between unrelated sequences (the patches that pass every
+        // score budget) that is what a path is made of: thousands of cells, each a dependent load.  The 64 lanes read the decision byte and the
+        // offset of the next 64 cells of that line at once; the walk goes through them from registers for as long as each one's source is the
+        // mismatch.  (Measured: it is NOT what C2's 9.3 ms launches of this kernel are made of -- nor are the ring loads or the extension's
+        // round trips to L2, both tried in LDS / batched four diagonals at a time and taken out again: ~4000 score steps at 2.3 us, ~250
+        // instructions per wave and step over rows of 3.4 k diagonals.  DESIGN.md section 8.)
+        const int scj = sc - lane * pn.x;
+        const unsigned bj = scj > 0 ? (unsigned)c.bt[(int64_t)scj * c.width + k] : 0u;
+        const int pj = scj > 0 ? c.pre[(int64_t)scj * c.width + k] : 0;
+        bool stop = false;
+        for (int j = 0; j < 64; ++j) {
+          const unsigned b = (unsigned)rdlane((int)bj, j);
+          const int pre = rdlane(pj, j);
+          w.push(OP_M, off - pre);
+          off = pre; v = off - k; h = off;
+          if (v <= 0 || h <= 0) { stop = true; break; }
+          const unsigned src = b & 7u;
+          if (src == C_M) {
+            sc -= pn.x; comp = C_M; w.push(OP_X, 1); --off;
+            v = off - k; h = off;
+            if (!(v > 0 && h > 0 && sc > 0)) break;  // (the walk's own condition: it ends here)
+            continue;                                // the next cell of the line: lane j + 1 holds it
+          }
+          if (src == C_I1) { if (b & BT_I1_EXT) { sc -= pn.e1; comp = C_I1; } else { sc -= pn.o1 + pn.e1; comp = C_M; } w.push(OP_I, 1); --k; --off; }
+          else if (src == C_I2) { if (b & BT_I2_EXT) { sc -= pn.e2; comp = C_I2; } else { sc -= pn.o2 + pn.e2; comp = C_M; } w.push(OP_I, 1); --k; --off; }
+          else if (src == C_D1) { if (b & BT_D1_EXT) { sc -= pn.e1; comp = C_D1; } else { sc -= pn.o1 + pn.e1; comp = C_M; } w.push(OP_D, 1); ++k; }
+          else { if (b & BT_D2_EXT) { sc -= pn.e2; comp = C_D2; } else { sc -= pn.o2 + pn.e2; comp = C_M; } w.push(OP_D, 1); ++k; }
+          v = off - k; h = off;
+          break;  // the path leaves the line
+        }
+        if (stop) break;
       }
       if (comp == C_M && v > 0 && h > 0) { const int nm = min(v, h); w.push(OP_M, nm); v -= nm; h -= nm; }
       if (v > 0) w.push(OP_D, v);

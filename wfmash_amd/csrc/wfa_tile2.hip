@@ -1269,18 +1269,33 @@ __global__ __launch_bounds__(NTMAX) void wfa_base2_kernel(const uint32_t* __rest
           }
           continue;
         }
-        const unsigned b = bt_base[(int64_t)sc * width + k];
-        const int pre = pre_base[(int64_t)sc * width + k];
-        w.push(OP_M, off - pre);
-        off = pre; v = off - k; h = off;
-        if (v <= 0 || h <= 0) break;
-        const unsigned src = b & 7u;
-        if (src == C_M) { sc -= PX; comp = C_M; w.push(OP_X, 1); --off; }
-        else if (src == C_I1) { if (b & BT_I1_EXT) { sc -= PE1; comp = C_I1; } else { sc -= PO1 + PE1; comp = C_M; } w.push(OP_I, 1); --k; --off; }
-        else if (src == C_I2) { if (b & BT_I2_EXT) { sc -= PE2; comp = C_I2; } else { sc -= PO2 + PE2; comp = C_M; } w.push(OP_I, 1); --k; --off; }
-        else if (src == C_D1) { if (b & BT_D1_EXT) { sc -= PE1; comp = C_D1; } else { sc -= PO1 + PE1; comp = C_M; } w.push(OP_D, 1); ++k; }
-        else { if (b & BT_D2_EXT) { sc -= PE2; comp = C_D2; } else { sc -= PO2 + PE2; comp = C_M; } w.push(OP_D, 1); ++k; }
-        v = off - k; h = off;
+        // (round 6, as in the ring kernel's walk -- wfa_generic_inc.h: a run of mismatches stays on its diagonal, PX scores apart: the lanes read
+        // the next 64 cells of that line at once, the walk goes through them from registers while each one's source is the mismatch)
+        const int scj = sc - lane * PX;
+        const unsigned bj = scj > 0 ? (unsigned)bt_base[(int64_t)scj * width + k] : 0u;
+        const int pj = scj > 0 ? pre_base[(int64_t)scj * width + k] : 0;
+        bool stop = false;
+        for (int j = 0; j < 64; ++j) {
+          const unsigned b = (unsigned)rdl((int)bj, j);
+          const int pre = rdl(pj, j);
+          w.push(OP_M, off - pre);
+          off = pre; v = off - k; h = off;
+          if (v <= 0 || h <= 0) { stop = true; break; }
+          const unsigned src = b & 7u;
+          if (src == C_M) {
+            sc -= PX; comp = C_M; w.push(OP_X, 1); --off;
+            v = off - k; h = off;
+            if (!(v > 0 && h > 0 && sc > 0)) break;
+            continue;
+          }
+          if (src == C_I1) { if (b & BT_I1_EXT) { sc -= PE1; comp = C_I1; } else { sc -= PO1 + PE1; comp = C_M; } w.push(OP_I, 1); --k; --off; }
+          else if (src == C_I2) { if (b & BT_I2_EXT) { sc -= PE2; comp = C_I2; } else { sc -= PO2 + PE2; comp = C_M; } w.push(OP_I, 1); --k; --off; }
+          else if (src == C_D1) { if (b & BT_D1_EXT) { sc -= PE1; comp = C_D1; } else { sc -= PO1 + PE1; comp = C_M; } w.push(OP_D, 1); ++k; }
+          else { if (b & BT_D2_EXT) { sc -= PE2; comp = C_D2; } else { sc -= PO2 + PE2; comp = C_M; } w.push(OP_D, 1); ++k; }
+          v = off - k; h = off;
+          break;
+        }
+        if (stop) break;
       }
       if (comp == C_M && v > 0 && h > 0) { const int nm = min(v, h); w.push(OP_M, nm); v -= nm; h -= nm; }
       if (v > 0) w.push(OP_D, v);

@@ -6,6 +6,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
+#include <functional>
+#include <deque>
+#include <condition_variable>
 #include <fstream>
 #include <iostream>
 #include <map>
@@ -348,15 +352,63 @@ int Map::mapQuery(MapSummary* summary) {
       int expected = WFM_OK;
       if (error_rc.compare_exchange_strong(expected, rc)) wfm_set_error(h_, what);
     };
+    // (round 6, f3's other half: SURVEY 8f-3) a batch's post-processing -- boundary check, chaining, sweep, scaffolds, PAF text: host work of
+    // 70 ms per chromosome-sized query -- runs on a thread of its own BESIDE the device's mapping of the next batch (the reference runs a
+    // query's filters inside that query's task, computeMap.hpp:634-688, while other queries' tasks map): one batch may wait, so memory
+    // stays at two batches' mappings per GPU.  WFM_FILTER_OVERLAP=0: one after the other, as before.
+    struct Work {
+      Batch b;
+      std::vector<wfm_mapping_t> maps;
+      std::vector<int32_t> mfrag;
+      std::vector<uint32_t> perm;  // the batch's mappings in chaining order (wfm_map_fragments_ordered), or perm[0] = ~0u
+      int64_t seq = -1;
+    };
+    static const bool filter_overlap = !(getenv("WFM_FILTER_OVERLAP") && atoi(getenv("WFM_FILTER_OVERLAP")) == 0);
     auto worker_body = [&](size_t g) {
       wfm_handle_t* hg = hs_[g];
       MapSummary& ps = part[g];
-      Batch b;
-      for (int64_t seq; error_rc.load() == WFM_OK && (seq = read_batch(b)) >= 0;) {
+      std::function<void(Work&)> filter_stage;  // (defined below: the second half of what used to be one loop body)
+      std::mutex qmu;
+      std::condition_variable qcv;
+      std::deque<std::unique_ptr<Work>> queue;
+      bool no_more = false;
+      std::thread filt;
+      auto filter_loop = [&]() {
+        try {
+          for (;;) {
+            std::unique_ptr<Work> wk;
+            {
+              std::unique_lock<std::mutex> lk(qmu);
+              qcv.wait(lk, [&] { return !queue.empty() || no_more; });
+              if (queue.empty()) return;
+              wk = std::move(queue.front());
+              queue.pop_front();
+            }
+            qcv.notify_all();
+            if (error_rc.load() == WFM_OK) filter_stage(*wk);
+          }
+        } catch (const std::bad_alloc&) {
+          fail(WFM_E_NOMEM, "out of host memory while post-processing mappings");
+        } catch (const std::exception& e) {
+          fail(WFM_E_ARG, std::string("post-processing failed: ") + e.what());
+        }
+      };
+      struct Joiner {  // the filter thread is joined on every way out of this function
+        std::thread& t; std::mutex& mu; std::condition_variable& cv; bool& flag;
+        ~Joiner() { { std::lock_guard<std::mutex> lk(mu); flag = true; } cv.notify_all(); if (t.joinable()) t.join(); }
+      } joiner{filt, qmu, qcv, no_more};
+      for (;;) {
+        std::unique_ptr<Work> wkp(new Work());
+        Work& W = *wkp;
+        Batch& b = W.b;
+        if (error_rc.load() != WFM_OK) break;
+        const int64_t seq = read_batch(b);
+        if (seq < 0) break;
+        W.seq = seq;
         double tb = now_ms();
-        std::vector<wfm_mapping_t> maps;
-        std::vector<int32_t> mfrag;
-        std::vector<uint32_t> perm;        // the batch's mappings in chaining order (wfm_map_fragments_ordered), or perm[0] = ~0u
+        std::vector<wfm_mapping_t>& maps = W.maps;
+        std::vector<int32_t>& mfrag = W.mfrag;
+        std::vector<uint32_t>& perm = W.perm;
         std::vector<int32_t> frag_first;   // per fragment: the first fragment of its query
         static const bool dev_order = !(getenv("WFM_FILTER_DEVICE_ORDER") && atoi(getenv("WFM_FILTER_DEVICE_ORDER")) == 0);
         if (ixs[g] && !b.frag_off.empty()) {
@@ -387,9 +439,16 @@ int Map::mapQuery(MapSummary* summary) {
         ps.fragments += b.frag_off.size();
         ps.l2_mappings += maps.size();
         ps.ms_map += now_ms() - tb;
-
+        if (!filter_stage) {
+          filter_stage = [&, g](Work& FW) {
+        Batch& b = FW.b;
+        std::vector<wfm_mapping_t>& maps = FW.maps;
+        std::vector<int32_t>& mfrag = FW.mfrag;
+        std::vector<uint32_t>& perm = FW.perm;
+        const int64_t seq = FW.seq;
+        (void)g;
         // ---- per query: boundary check, filters, output (processFragment :124-128; query task :634-688)
-        tb = now_ms();
+        double tb = now_ms();
         // queries are independent here (the reference runs one Taskflow task per query); results are
         // written in query order afterwards
         const std::vector<BatchQuery>& bq = b.bq;
@@ -487,6 +546,16 @@ int Map::mapQuery(MapSummary* summary) {
         if (error_rc.load() != WFM_OK) return;
         write_batch((uint64_t)seq, std::move(bo));
         ps.ms_filter += now_ms() - tb;
+          };
+        }
+        if (!filter_overlap) { filter_stage(W); continue; }
+        if (!filt.joinable()) filt = std::thread(filter_loop);
+        {
+          std::unique_lock<std::mutex> lk(qmu);
+          qcv.wait(lk, [&] { return queue.size() < 1 || error_rc.load() != WFM_OK; });
+          queue.push_back(std::move(wkp));
+        }
+        qcv.notify_all();
       }
     };
     auto worker = [&](size_t g) {
