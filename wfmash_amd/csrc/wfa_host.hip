@@ -500,6 +500,9 @@ TileCfg tile_cfg(const wfm_penalties_t& pen, int scope) {
   c.reg = dflt && !(getenv("WFM_TILE_REG") && atoi(getenv("WFM_TILE_REG")) == 0);
   if (c.reg) {
     if (!getenv("WFM_TILE_THREADS")) c.threads = 512;
+    // (the FINE instantiation of the packed kernel keeps a row of T + 1 maxima per wave in dynamic LDS beside ~24 KB of static: a WFM_TILE_T that
+    // would not fit 64 KB is cut here instead of failing the launch)
+    c.T = std::min(c.T, (int)((40 * 1024) / (4 * std::max(1, c.threads / 64))) - 1);
     // (two diagonals per lane, always: the phase-2 rows, the single-tile sizing and the packed kernel are built for it.  The WFM_TILE_C=4
     // switch of round 1 sized the tasks for four while those stages went on with two -- wrong results; it is gone)
     if (const char* e = getenv("WFM_TILE_CHUNK")) c.chunk = std::max(1, atoi(e));

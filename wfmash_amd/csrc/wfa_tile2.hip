@@ -346,7 +346,7 @@ void launch_seq_pack(const uint8_t* seq, uint32_t* pk, int64_t nwords, int64_t n
 //    source is either inside or NULL already.  A NULL then drifts -- NULL + 1 + ... -- instead of being set back to WF_NULL at every step:
 //    every reader of a wavefront takes "negative" for NULL (max(), >= 0, o0 + o1 >= tl), and -2^30 + 17 per step stays negative for 6 * 10^7 steps;
 //  * the per-step maximum of the antidiagonals goes to a slot of the wave's own (plain store) instead of through an LDS atomic (a scalar loop);
-//  * the mailbox's buffer index is the step's number mod 3 at compile time (adjacent steps never share a buffer, two steps apart may);
+//  * the mailbox's buffer index is the step's parity within the ten-step body, at compile time (adjacent steps never share a buffer);
 //  * the probe's window words are addressed by masking (pk_extend2<true>), dead cells keep what the arithmetic leaves them with.
 // FINE (round 6, FAST phase-1 form only): the per-score maxima of the antidiagonals -- a six-step DPP reduction per wave and score, a seventh of
 // the step's vector issue -- are kept only by the FINE instantiation, which takes the tiles of the jobs whose block needs them (TileJob::fine_s:
@@ -370,7 +370,7 @@ __global__ __launch_bounds__(NTMAX) void wfa_tile2_kernel(const uint32_t* __rest
   // mailbox of the wave edges: [parity][slot][side][value].  Side 0 of slot w holds what lane 63 of wave w - 1 hands to lane 0 of wave w, side 1 of
   // slot w what lane 0 of wave w hands to lane 63 of wave w - 1; slot 0's side 0 and the slot behind the last wave are never written and stay
   // NULL, so the edge lanes of a tile read their mailbox like all others and the wave shifts need no NULL to fall back on
-  __shared__ __attribute__((aligned(16))) int s_edge[FAST ? 3 : 2][WAVE1 ? 1 : 17][2][4];
+  __shared__ __attribute__((aligned(16))) int s_edge[2][WAVE1 ? 1 : 17][2][4];
   __shared__ __attribute__((aligned(16))) uint32_t s_winP[PK_WIN_DW + PK_SLACK_DW], s_winT[PK_WIN_DW + PK_SLACK_DW];
   __shared__ int s_wlo[2];
   extern __shared__ __attribute__((aligned(16))) int s_makr[];  // [T + 1]; FAST: [waves][T + 1], a row per wave

@@ -464,9 +464,10 @@ Summary Aligner::compute() {
         const double at0 = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         // a batch that has its device to itself -- none beside it, none to come -- is cut into parts by the device layer
         // (wfm_set_concurrent_calls: its levels are chains of short launches, and one chain does not fill a device)
+        // (both under the readers' lock: two workers that start together must not each see the device as theirs alone)
         bool more;
-        { std::lock_guard<std::mutex> lk(read_mu); more = more_rows; }
-        const int beside = in_flight[wk % ngpu].fetch_add(1);
+        int beside;
+        { std::lock_guard<std::mutex> lk(read_mu); more = more_rows; beside = in_flight[wk % ngpu].fetch_add(1); }
         wfm_set_concurrent_calls(use[wk], beside + (more && per_gpu > 1 ? 1 : 0));
         struct Leave { std::atomic<int>& a; ~Leave() { a.fetch_sub(1); } } leave{in_flight[wk % ngpu]};
         std::string text = align_batch(use[wk], batch, threads_each, part[wk], first_row);
