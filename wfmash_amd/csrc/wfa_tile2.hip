@@ -476,6 +476,16 @@ __global__ __launch_bounds__(NTMAX) void wfa_tile2_kernel(const uint32_t* __rest
     incore[c] = k >= tk.core_lo && k <= tk.core_hi;
     negk[c] = incore[c] ? -k : -(1 << 29);
   }
+  // the first score at which some cell of this wave is outside its row (column outside [-pl, tl]: always), wave-uniform
+  int s_cut_wave;
+  {
+    int x = min(s_last[0], s_last[C - 1]);
+#pragma unroll
+    for (int c = 1; c < C - 1; ++c) x = min(x, s_last[c]);
+    x = min(x, __shfl_xor(x, 1, 64)); x = min(x, __shfl_xor(x, 2, 64)); x = min(x, __shfl_xor(x, 4, 64));
+    x = min(x, __shfl_xor(x, 8, 64)); x = min(x, __shfl_xor(x, 16, 64)); x = min(x, __shfl_xor(x, 32, 64));
+    s_cut_wave = __builtin_amdgcn_readfirstlane(x);
+  }
   // ---- sequence windows: every offset this tile will ever extend from is >= the smallest live offset of its history
   {
     int hlo = INT32_MAX, vlo = INT32_MAX;
@@ -657,10 +667,11 @@ __global__ __launch_bounds__(NTMAX) void wfa_tile2_kernel(const uint32_t* __rest
     if (FAST) {
       // some cell of the wave whose largest source lies beyond the problem, or whose column is outside [-pl, tl] or cut off by the score
       // bound at this score: the selects of the round-4 form, for the whole wave (a wave inside the problem and inside the bound: none)
+      // (round 6: "some cell is past its last score" against the wave's smallest s_last, a scalar compare: two vector compares less per step)
       bool special = false;
 #pragma unroll
-      for (int c = 0; c < C; ++c) special |= (nM[c] > (int)hmaxu[c]) | (s > s_last[c]);
-      if (__builtin_expect(__any(special), 0)) {
+      for (int c = 0; c < C; ++c) special |= nM[c] > (int)hmaxu[c];
+      if (__builtin_expect(__any(special) || s > s_cut_wave, 0)) {
 #pragma unroll
         for (int c = 0; c < C; ++c) {
           const unsigned hm = hmaxu[c];
