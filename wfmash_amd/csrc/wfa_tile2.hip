@@ -75,14 +75,6 @@ __device__ __forceinline__ int from_next_lane(int x) { return __builtin_amdgcn_u
 __device__ __forceinline__ int from_prev_lane0(int x) { return __builtin_amdgcn_update_dpp(0, x, 0x138, 0xf, 0xf, true); }
 __device__ __forceinline__ int from_next_lane0(int x) { return __builtin_amdgcn_update_dpp(0, x, 0x130, 0xf, 0xf, true); }
 
-// the maximum of every row of 16 lanes in the row's last lane (four DPP steps; the wave's maximum is two broadcast steps more: wave_max63)
-__device__ __forceinline__ int row_max15(int x) {
-  x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false));  // row_shr:1
-  x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false));  // row_shr:2
-  x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false));  // row_shr:4
-  x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false));  // row_shr:8
-  return x;
-}
 __device__ __forceinline__ int wave_max63(int x) {
   x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false));  // row_shr:1
   x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false));  // row_shr:2
@@ -476,16 +468,6 @@ __global__ __launch_bounds__(NTMAX) void wfa_tile2_kernel(const uint32_t* __rest
     incore[c] = k >= tk.core_lo && k <= tk.core_hi;
     negk[c] = incore[c] ? -k : -(1 << 29);
   }
-  // the first score at which some cell of this wave is outside its row (column outside [-pl, tl]: always), wave-uniform
-  int s_cut_wave;
-  {
-    int x = min(s_last[0], s_last[C - 1]);
-#pragma unroll
-    for (int c = 1; c < C - 1; ++c) x = min(x, s_last[c]);
-    x = min(x, __shfl_xor(x, 1, 64)); x = min(x, __shfl_xor(x, 2, 64)); x = min(x, __shfl_xor(x, 4, 64));
-    x = min(x, __shfl_xor(x, 8, 64)); x = min(x, __shfl_xor(x, 16, 64)); x = min(x, __shfl_xor(x, 32, 64));
-    s_cut_wave = __builtin_amdgcn_readfirstlane(x);
-  }
   // ---- sequence windows: every offset this tile will ever extend from is >= the smallest live offset of its history
   {
     int hlo = INT32_MAX, vlo = INT32_MAX;
@@ -667,11 +649,12 @@ __global__ __launch_bounds__(NTMAX) void wfa_tile2_kernel(const uint32_t* __rest
     if (FAST) {
       // some cell of the wave whose largest source lies beyond the problem, or whose column is outside [-pl, tl] or cut off by the score
       // bound at this score: the selects of the round-4 form, for the whole wave (a wave inside the problem and inside the bound: none)
-      // (round 6: "some cell is past its last score" against the wave's smallest s_last, a scalar compare: two vector compares less per step)
+      // (Tried in round 6 and taken out: "some cell is past its last score" against the wave's smallest s_last, a scalar compare instead of two
+      // vector compares -- the second branch cost more than the compares: C3 62.5 -> 63.2 ms per batch.)
       bool special = false;
 #pragma unroll
-      for (int c = 0; c < C; ++c) special |= nM[c] > (int)hmaxu[c];
-      if (__builtin_expect(__any(special) || s > s_cut_wave, 0)) {
+      for (int c = 0; c < C; ++c) special |= (nM[c] > (int)hmaxu[c]) | (s > s_last[c]);
+      if (__builtin_expect(__any(special), 0)) {
 #pragma unroll
         for (int c = 0; c < C; ++c) {
           const unsigned hm = hmaxu[c];
@@ -712,10 +695,10 @@ __global__ __launch_bounds__(NTMAX) void wfa_tile2_kernel(const uint32_t* __rest
       }
       if (!FINE) (void)__hip_atomic_fetch_max(&s_run[tid], mak, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // ds_max_i32, nothing returned
       else {
-        // (round 6: four row steps and an LDS maximum from the four row ends instead of six DPP steps and a masked store: ~10 instructions less
-        // in the instantiation the C1 / C2 / C4 regimes run every block of; the slots are zeroed at the tile's start, the maxima are >= 0)
-        mak = row_max15(mak);
-        if ((lane & 15) == 15) (void)__hip_atomic_fetch_max(&s_makr[(WAVE1 ? 0 : wv * MKS) + t - 1], mak, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        // (Tried in round 6 and taken out: four row steps and an LDS maximum from the four row ends instead of six DPP steps and a masked store --
+        // ten instructions less in the instantiation C1 / C2 / C4 run every block of, and nothing in their device time: gpurun_out/r6y/ab4.log.)
+        mak = wave_max63(mak);
+        if (lane == 63) s_makr[(WAVE1 ? 0 : wv * MKS) + t - 1] = mak;
       }
       // ---- this step's row waits for its extension; its gap components are final
       if (__builtin_expect(t > t_stream, 0)) {  // stream the last rows of I/D of the core to the output snapshot
@@ -851,7 +834,7 @@ __global__ __launch_bounds__(NTMAX) void wfa_tile2_kernel(const uint32_t* __rest
       default: line_take(std::integral_constant<int, UB>{}, fin); break;
     }
     if (!FINE) (void)__hip_atomic_fetch_max(&s_run[tid], mak, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    else { mak = row_max15(mak); if ((lane & 15) == 15) (void)__hip_atomic_fetch_max(&s_makr[(WAVE1 ? 0 : wv * MKS) + Tn], mak, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+    else { mak = wave_max63(mak); if (lane == 63) s_makr[(WAVE1 ? 0 : wv * MKS) + Tn] = mak; }
   }
   WFM_TRACE_MARK(122);
   // ---- output snapshot: the newest H rows of M for the core ----
