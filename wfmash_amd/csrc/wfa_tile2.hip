@@ -55,6 +55,10 @@ constexpr int PK_WIN_BASES = PK_WIN_DW * 16;  // 32768 bases
 constexpr int PK_SLACK_DW = 8;                // words past the window a probe may touch
 constexpr int TAIL_DIRECT_MAX = 2;            // pk_extend2<true>: up to this many lanes with a run past 16 bases go to the wave's tail at once
 
+// two adjacent 32-bit values at a dword-aligned address as one access (global loads and stores of 8 bytes need no more than that)
+struct __attribute__((packed, aligned(4))) Pair32 { int x, y; };
+__device__ __forceinline__ void ld_pair(const int32_t* p, int& a, int& b) { const Pair32 v = *reinterpret_cast<const Pair32*>(p); a = v.x; b = v.y; }
+__device__ __forceinline__ void st_pair(int32_t* p, int a, int b) { Pair32 v; v.x = a; v.y = b; *reinterpret_cast<Pair32*>(p) = v; }
 struct Rng2 { int pl, tl, kb_lo, kb_hi; };
 __device__ __forceinline__ Rng2 make_rng2(int pl, int tl, int sub) { Rng2 r; r.pl = pl; r.tl = tl; r.kb_lo = (tl - pl) - sub; r.kb_hi = (tl - pl) + sub; return r; }
 __device__ __forceinline__ int rng2_lo(const Rng2& r, int s) { return max(max(-r.pl, -s), r.kb_lo + s); }
@@ -425,32 +429,34 @@ __global__ __launch_bounds__(NTMAX) void wfa_tile2_kernel(const uint32_t* __rest
   int Mh[C][NCL][DEP];
   int I1h[C][E1], D1h[C][E1], I2h[C], D2h[C];
   // ---- snapshot load (rows <= s0): what lies outside a row's own range is NULL, whatever the ring holds there
+  // (round 6: a lane's two diagonals are one 8-byte load -- dword alignment is all a global load needs; with one 4-byte load per diagonal every
+  // load instruction used half of each cache line it touched and the lines came up from L2 twice, the tile's 26 rows of M for one diagonal lying
+  // between the two uses)
+  {
+    const bool kin0 = k0 <= kmax, kin1 = k0 + 1 <= kmax;
 #pragma unroll
-  for (int c = 0; c < C; ++c) {
-    const int k = k0 + c;
-    const bool kin = k <= kmax;
+    for (int c = 0; c < C; ++c)
 #pragma unroll
-    for (int r = 0; r < NCL; ++r)
+      for (int r = 0; r < NCL; ++r)
 #pragma unroll
-      for (int e = 0; e < DEP; ++e) Mh[c][r][e] = WF_NULL;
+        for (int e = 0; e < DEP; ++e) Mh[c][r][e] = WF_NULL;
+    auto ld_row = [&](int comp, int sc, int& a, int& b) {
+      const int lo = rng2_lo(RG, sc), hi = rng2_hi(RG, sc);
+      const bool ok0 = kin0 && sc >= 0 && k0 >= lo && k0 <= hi, ok1 = kin1 && sc >= 0 && k0 + 1 >= lo && k0 + 1 <= hi;
+      int x = WF_NULL, y = WF_NULL;
+      if (ok0 || ok1) ld_pair(rin + ((int64_t)(comp * RING + (sc & RMASK))) * width + k0, x, y);
+      a = ok0 ? x : WF_NULL; b = ok1 ? y : WF_NULL;
+    };
 #pragma unroll
-    for (int d = 0; d < H; ++d) {
-      const int sc = s0 - d;
-      const int v = (kin && sc >= 0 && k >= rng2_lo(RG, sc) && k <= rng2_hi(RG, sc)) ? rin[((int64_t)(C_M * RING + (sc & RMASK))) * width + k] : WF_NULL;
-      Mh[c][(NCL - d % NCL) % NCL][d / NCL] = v;  // row s0-d: class (-d mod 5), the (d/5)-th newest of its class
-    }
+    for (int d = 0; d < H; ++d)  // row s0-d: class (-d mod 5), the (d/5)-th newest of its class
+      ld_row(C_M, s0 - d, Mh[0][(NCL - d % NCL) % NCL][d / NCL], Mh[1][(NCL - d % NCL) % NCL][d / NCL]);
 #pragma unroll
     for (int d = 0; d < E1; ++d) {
-      const int sc = s0 - d;
-      const bool ok = kin && sc >= 0 && k >= rng2_lo(RG, sc) && k <= rng2_hi(RG, sc);
-      I1h[c][d] = ok ? rin[((int64_t)(C_I1 * RING + (sc & RMASK))) * width + k] : WF_NULL;
-      D1h[c][d] = ok ? rin[((int64_t)(C_D1 * RING + (sc & RMASK))) * width + k] : WF_NULL;
+      ld_row(C_I1, s0 - d, I1h[0][d], I1h[1][d]);
+      ld_row(C_D1, s0 - d, D1h[0][d], D1h[1][d]);
     }
-    {
-      const bool ok = kin && s0 >= 0 && k >= rng2_lo(RG, s0) && k <= rng2_hi(RG, s0);
-      I2h[c] = ok ? rin[((int64_t)(C_I2 * RING + (s0 & RMASK))) * width + k] : WF_NULL;
-      D2h[c] = ok ? rin[((int64_t)(C_D2 * RING + (s0 & RMASK))) * width + k] : WF_NULL;
-    }
+    ld_row(C_I2, s0, I2h[0], I2h[1]);
+    ld_row(C_D2, s0, D2h[0], D2h[1]);
   }
   const int MKS = T + 1;  // stride of a wave's row of s_makr (FAST)
   if (FINE && !P2) for (int t = tid; t < (FAST && !WAVE1 ? nw * MKS : MKS); t += NT) s_makr[t] = 0;
@@ -876,17 +882,22 @@ __global__ __launch_bounds__(NTMAX) void wfa_tile2_kernel(const uint32_t* __rest
   }
   auto write_rows = [&](auto TR) {
     constexpr int tr = decltype(TR)::value;  // T mod 5
+    if (!incore[0] && !incore[1]) return;
 #pragma unroll
-    for (int c = 0; c < C; ++c) {
-      const int k = k0 + c;
-      if (!incore[c]) continue;
-#pragma unroll
-      for (int d = 0; d < H; ++d) {
-        const int r = ((tr - d) % NCL + NCL) % NCL;        // class of row s_end - d
-        const int back = ((tr - r) % NCL + NCL) % NCL;     // s_end - (newest score of class r)
-        const int e = (d - back) / NCL;
-        const int sc = s_end - d;
-        if (sc >= 0 && k >= rng2_lo(RG, sc) && k <= rng2_hi(RG, sc)) rout[((int64_t)(C_M * RING + (sc & RMASK))) * width + k] = Mh[c][r][e];
+    for (int d = 0; d < H; ++d) {
+      constexpr int dummy = 0; (void)dummy;
+      const int r = ((tr - d) % NCL + NCL) % NCL;        // class of row s_end - d
+      const int back = ((tr - r) % NCL + NCL) % NCL;     // s_end - (newest score of class r)
+      const int e = (d - back) / NCL;
+      const int sc = s_end - d;
+      const int lo = rng2_lo(RG, sc), hi = rng2_hi(RG, sc);
+      const bool w0 = incore[0] && sc >= 0 && k0 >= lo && k0 <= hi, w1 = incore[1] && sc >= 0 && k0 + 1 >= lo && k0 + 1 <= hi;
+      int32_t* dst = rout + ((int64_t)(C_M * RING + (sc & RMASK))) * width + k0;
+      // (a lane's two diagonals as one 8-byte store wherever both are the core's and inside the row: all lanes but a handful at the edges)
+      if (w0 && w1) st_pair(dst, Mh[0][r][e], Mh[1][r][e]);
+      else {
+        if (w0) dst[0] = Mh[0][r][e];
+        if (w1) dst[1] = Mh[1][r][e];
       }
     }
   };
