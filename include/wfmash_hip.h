@@ -205,7 +205,8 @@ void wfm_set_concurrent_calls(wfm_handle_t* h, int other_calls);
 #define WFM_PF_BASE_RETRY2  8u   /* ... and its second (1020): the third attempt runs to the all-gap bound            */
 #define WFM_PF_BYTE_KERNEL 16u   /* an N or a soft-masked base: the byte kernels instead of the 2-bit packed ones     */
 #define WFM_PF_P2_ROUNDS   32u   /* an overlap walk went past the first round of rows computed ahead                  */
-#define WFM_PF_RING_KERNEL 64u   /* a leaf / patch ran on the global-memory ring kernel (rows beyond 2048 diagonals, other penalties) */
+#define WFM_PF_RING_KERNEL 64u   /* a leaf / patch ran on the global-memory ring kernel (other penalties, an N; rows beyond 2048 diagonals until round 6) */
+#define WFM_PF_BASE_TILES 128u   /* a patch with rows beyond 2048 diagonals ran as tiles of the register kernel (its third attempt)   */
 size_t wfm_get_problem_flags(const wfm_handle_t* h, uint32_t* out, size_t n);
 
 /* Device blocks of both paths -- the map path's work buffers, the align path's arenas and a batch's sequence buffers, also

@@ -193,6 +193,37 @@ def test_endsfree_patches_match_oracle(gpu, oracle):
     assert bad == 0, f"{bad}/{len(items)} ends-free CIGARs differ"
 
 
+def test_wide_patches_on_tiles_match_oracle(gpu, oracle):
+    """Ends-free patches whose score passes the second budget (1020): their third attempt has rows beyond the register kernel's 2048 diagonals
+    and runs as tiles of it (wfa_base2t_kernel: blocks of 125 scores, halos, snapshots) -- head form (band around the end corner), tail form
+    (rows as wide as the problem: nine tiles), an unrelated stretch in front, one score that ends exactly on a block's last row is not forced
+    but the scores spread over several blocks.  CIGARs identical to the oracle's; and identical to the ring kernel's (WFM_BASE_TILES=0)."""
+    import os
+    items, exp = [], []
+    for i, (L, div, pre) in enumerate([(3400, 0.10, 0), (3000, 0.14, 0), (3600, 0.08, 300), (2600, 0.2, 0), (3900, 0.07, 0)]):
+        p = synth.random_dna(5100 + i, L)
+        t = synth.random_dna(5200 + i, pre) + synth.mutate(p, div, 5300 + i)
+        for args in ((len(p), 0, len(t), 0), (0, len(p), 0, len(t))):
+            items.append((p, t, capi.WFM_MODE_ENDSFREE, args[0], args[1], args[2], args[3]))
+            exp.append(oracle.align_endsfree(p, args[0], args[1], t, args[2], args[3]))
+    res = gpu.align(items)
+    fl = gpu.problem_flags(len(items))
+    assert sum(bool(f & capi.WFM_PF_BASE_TILES) for f in fl) >= 6, fl
+    scores = set()
+    for it, r, f, (rc, ops, sc, _) in zip(items, res, fl, exp):
+        assert rc == 0 and r.status == 0
+        assert r.ops == ops, (len(it[0]), len(it[1]), it[3:], sc)
+        if f & capi.WFM_PF_BASE_TILES:
+            scores.add(r.score // 125)
+    assert len(scores) >= 3  # (walks that end in different blocks)
+    os.environ["WFM_BASE_TILES"] = "0"
+    try:
+        res0 = gpu.align(items)
+    finally:
+        del os.environ["WFM_BASE_TILES"]
+    assert all(a.ops == b.ops and a.score == b.score for a, b in zip(res, res0))
+
+
 def test_uni_mode_matches_oracle(gpu, oracle):
     items = [(p, t, capi.WFM_MODE_END2END_UNI) for p, t in _pairs(8, 40, [50, 300, 1200], [0.02, 0.1, 0.3])]
     res = gpu.align(items)

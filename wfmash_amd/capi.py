@@ -18,7 +18,7 @@ WFM_MODE_END2END_UNI = 2
 
 DEFAULT_PEN = (5, 8, 2, 24, 1)  # parse_args.hpp:290-294
 # wfm_get_problem_flags (include/wfmash_hip.h): which of the rarer paths a problem took
-WFM_PF_ROOT_AGAIN, WFM_PF_JOB_AGAIN, WFM_PF_BASE_RETRY, WFM_PF_BASE_RETRY2, WFM_PF_BYTE_KERNEL, WFM_PF_P2_ROUNDS, WFM_PF_RING_KERNEL = 1, 2, 4, 8, 16, 32, 64
+WFM_PF_ROOT_AGAIN, WFM_PF_JOB_AGAIN, WFM_PF_BASE_RETRY, WFM_PF_BASE_RETRY2, WFM_PF_BYTE_KERNEL, WFM_PF_P2_ROUNDS, WFM_PF_RING_KERNEL, WFM_PF_BASE_TILES = 1, 2, 4, 8, 16, 32, 64, 128
 
 EXPORTS = [
     "wfm_create", "wfm_destroy", "wfm_last_error", "wfm_device_name",
@@ -846,6 +846,7 @@ def stratified_rows(tags, n_rows, per_stratum=64, top_scores=32, uniform=64):
         "patch_second_budget": lambda t: (t >> 8 | t >> 16) & WFM_PF_BASE_RETRY,
         "patch_third_budget": lambda t: (t >> 8 | t >> 16) & WFM_PF_BASE_RETRY2,
         "ring_kernel": lambda t: (t | t >> 8 | t >> 16) & WFM_PF_RING_KERNEL,
+        "base_tiles": lambda t: (t >> 8 | t >> 16) & WFM_PF_BASE_TILES,
         "byte_kernel": lambda t: (t | t >> 8 | t >> 16) & WFM_PF_BYTE_KERNEL,
         "p2_rounds": lambda t: t & WFM_PF_P2_ROUNDS,
         "leaf_retry": lambda t: t & (WFM_PF_BASE_RETRY | WFM_PF_BASE_RETRY2),

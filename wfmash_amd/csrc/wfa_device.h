@@ -164,6 +164,31 @@ struct BaseResult {
   uint64_t cells;
 };
 
+// ---- base jobs whose rows are wider than one workgroup's registers hold (wfa_base2t_kernel, round 6) ----
+// A patch that overflowed its budget of 1020 ran on r32::wfa_base_kernel<1024> until round 6: one workgroup per job, 6 us per score step over rows of
+// 3 k diagonals from a global-memory ring, a dozen jobs on a device of 256 CUs for 9 ms at the end of every batch.  Here the columns of such a job are
+// cut into tiles as the tile phase of BiWFA cuts its rows: a launch is one BLOCK of T scores, every tile a workgroup that holds core + 2 T diagonals in
+// the register kernel's delay lines (wfa_base2_kernel's step, its decisions, its rows of pre / bt -- written for the core only), T columns of halo on
+// either side that it computes for itself and that go wrong one column per step from the outside, a snapshot of the last 26 rows between two blocks.
+// A tiny kernel between two launches replays the end test over the tiles of a job (the first score at which a cell ends, the smallest such diagonal),
+// and one wave per job walks back through pre / bt at the end (base2_walk: the register kernel's own walk).
+struct Base2TJob {
+  BaseJob b;                   // as for wfa_base2_kernel; b.ring_off: two snapshots of B2T_ROWS rows x width behind each other
+  int64_t snap_in, snap_out;   // int32 element offsets of the snapshot the next block loads / writes
+  int32_t ntiles, core;        // tiles of `core` diagonals from b.kmin on
+  int32_t task0;               // the job's first entry in the task list (its tiles follow each other)
+  int32_t s0;                  // score the next block starts from (0: row 0 is still to be made)
+  int32_t done;                // 0 running, 1 an end was found (end_s / end_k / end_off), 2 the budget is spent
+  int32_t end_s, end_k, end_off;
+};
+struct Base2TTask { int32_t job, tile; };
+constexpr int B2T_ROWS = 32;   // rows of a snapshot: M of the last 26 scores, I1 / D1 of the last two, I2 / D2 of the last
+constexpr int B2T_THREADS = 512;
+void launch_base2t_block(const uint32_t* pk, int32_t* a32, uint8_t* a8, const Base2TJob* jobs, const Base2TTask* tasks, unsigned long long* tile_key,
+                         int32_t* tile_off, int ntasks, int T, hipStream_t st);
+void launch_base2t_advance(Base2TJob* jobs, const unsigned long long* tile_key, const int32_t* tile_off, int njobs, int T, int32_t* active_slot, hipStream_t st);
+void launch_base2t_finish(const int32_t* a32, const uint8_t* a8, uint32_t* rle, const Base2TJob* jobs, BaseResult* res, int njobs, hipStream_t st);
+
 // ---- an upper bound of a root's score before its wavefronts are computed (wfa_bound_kernel) ----
 struct BoundJob { int64_t p_off, t_off; int32_t pl, tl; };
 void launch_bound(const uint8_t* seq, const BoundJob* jobs, int32_t* out, int njobs, DevPen pen, hipStream_t st);

@@ -191,6 +191,10 @@ struct wfm_handle {
   DevBuf<BpResult> bpres;
   DevBuf<BaseJob> bsjobs;
   DevBuf<BaseResult> bsres;
+  DevBuf<Base2TJob> b2tjobs;     // base jobs on tiles (wfa_base2t_kernel)
+  DevBuf<Base2TTask> b2ttasks;
+  DevBuf<unsigned long long> b2tkeys;
+  DevBuf<int32_t> b2toffs, b2tactive;
   DevBuf<int64_t> i64a, i64b, i64c;
   DevBuf<int32_t> i32a;
   DevBuf<int32_t> seqflags;  // wfm_upload_sequences: per problem, nonzero = pure ACGT
@@ -317,6 +321,9 @@ int run_base_jobs(wfm_handle* h, wfm_seqset* S, const wfm_penalties_t& pen, std:
   // 256 / 1024 threads (other penalties, an N, wider rows: a patch eroded to its 4096-base limit starts 8 k diagonals wide)
   const bool dflt_pen = pen.x == 5 && pen.o1 == 8 && pen.e1 == 2 && pen.o2 == 24 && pen.e2 == 1;
   const bool base_v2 = dflt_pen && !(getenv("WFM_BASE_V2") && atoi(getenv("WFM_BASE_V2")) == 0) && !(getenv("WFM_TILE_V2") && atoi(getenv("WFM_TILE_V2")) == 0);
+  // 5 = the register kernel's step on tiles (wfa_base2t_kernel): rows beyond 2048 diagonals of jobs the register kernel would take -- the third
+  // attempt of a patch, whose score passed 1020
+  const bool base_tiles = !(getenv("WFM_BASE_TILES") && atoi(getenv("WFM_BASE_TILES")) == 0);
   // (sequences longer than the kernel's LDS windows are fine: what lies beyond is read from the global mirror.  Jobs without
   // any cell -- an empty pattern or text -- ride along with the first kind: they are one store each)
   auto kind_of = [&](const Node& a) {
@@ -324,6 +331,7 @@ int run_base_jobs(wfm_handle* h, wfm_seqset* S, const wfm_penalties_t& pen, std:
     if (base_v2 && (a.pl == 0 || a.tl == 0)) return 1;
     if (base_v2 && w <= 2048 && (size_t)a.prob < S->acgt.size() && S->acgt[(size_t)a.prob])
       return w <= 128 ? 0 : (w <= 640 ? 1 : 2);
+    if (base_v2 && base_tiles && (size_t)a.prob < S->acgt.size() && S->acgt[(size_t)a.prob]) return 5;
     return w > wide_from ? 4 : 3;
   };
   std::stable_sort(nodes.begin(), nodes.end(), [&](const Node& a, const Node& b) { return kind_of(a) < kind_of(b); });
@@ -394,7 +402,45 @@ int run_base_jobs(wfm_handle* h, wfm_seqset* S, const wfm_penalties_t& pen, std:
       HIPCHK(h, hipEventRecord(h->ev2, h->stream));
       // (jobs arrive sorted: the wide ones -- long patches, retries with a larger budget -- in chunks of their own)
       const bool chunk_wide = chunk_kind == 4;
-      if (chunk_kind <= 2) {
+      if (chunk_kind == 5) {
+        // blocks of T scores, every block one launch over the tiles of all jobs and a one-thread-per-job kernel behind it; the host looks at the
+        // number of jobs still running every few blocks (a launch whose jobs are all over costs microseconds)
+        static const int T = getenv("WFM_BASE_TILE_T") ? std::max(5, std::min(400, atoi(getenv("WFM_BASE_TILE_T")) / 5 * 5)) : 125;
+        const int core = B2T_THREADS * 2 - 2 * T;
+        std::vector<Base2TJob> tj(jobs.size());
+        std::vector<Base2TTask> tasks;
+        int smax_all = 0;
+        for (size_t q = 0; q < jobs.size(); ++q) {
+          Base2TJob& t = tj[q];
+          t.b = jobs[q];
+          t.snap_in = jobs[q].ring_off; t.snap_out = jobs[q].ring_off + (int64_t)B2T_ROWS * jobs[q].width;
+          t.core = core; t.ntiles = (jobs[q].width + core - 1) / core; t.task0 = (int32_t)tasks.size();
+          t.s0 = 0; t.done = 0; t.end_s = 0; t.end_k = 0; t.end_off = 0;
+          for (int ti = 0; ti < t.ntiles; ++ti) tasks.push_back(Base2TTask{(int32_t)q, ti});
+          smax_all = std::max(smax_all, jobs[q].smax);
+        }
+        const int nblocks = (smax_all + T - 1) / T + 1;
+        if (h->b2tjobs.ensure(tj.size()) || h->b2ttasks.ensure(tasks.size()) || h->b2tkeys.ensure(tasks.size()) || h->b2toffs.ensure(tasks.size()) || h->b2tactive.ensure((size_t)nblocks)) {
+          h->err = "out of device memory (base tiles)";
+          return WFM_E_NOMEM;
+        }
+        HIPCHK(h, hipMemcpyAsync(h->b2tjobs.p, tj.data(), tj.size() * sizeof(Base2TJob), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipMemcpyAsync(h->b2ttasks.p, tasks.data(), tasks.size() * sizeof(Base2TTask), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipMemsetAsync(h->b2tactive.p, 0, (size_t)nblocks * sizeof(int32_t), h->stream));
+        constexpr int LOOK = 6;
+        for (int b = 0; b < nblocks; ) {
+          const int upto = std::min(nblocks, b + LOOK);
+          for (; b < upto; ++b) {
+            launch_base2t_block(S->d_pk, h->base32.p, h->base8.p, h->b2tjobs.p, h->b2ttasks.p, h->b2tkeys.p, h->b2toffs.p, (int)tasks.size(), T, h->stream);
+            launch_base2t_advance(h->b2tjobs.p, h->b2tkeys.p, h->b2toffs.p, (int)tj.size(), T, h->b2tactive.p + b, h->stream);
+          }
+          int32_t still = 0;
+          HIPCHK(h, hipMemcpyAsync(&still, h->b2tactive.p + (b - 1), sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+          HIPCHK(h, hipStreamSynchronize(h->stream));
+          if (!still) break;
+        }
+        launch_base2t_finish(h->base32.p, h->base8.p, h->rle.p, h->b2tjobs.p, h->bsres.p, (int)tj.size(), h->stream);
+      } else if (chunk_kind <= 2) {
         int64_t wmax = 1;
         for (const BaseJob& bj : jobs) if (bj.type == 0) wmax = std::max<int64_t>(wmax, bj.width);
         const int threads = (int)std::min<int64_t>(1024, ((wmax + 1) / 2 + 63) / 64 * 64);
@@ -420,11 +466,16 @@ int run_base_jobs(wfm_handle* h, wfm_seqset* S, const wfm_penalties_t& pen, std:
         int64_t wsum = 0, wmax = 0, smx = 0; int over = 0, ef = 0;
         for (size_t q = 0; q < jobs.size(); ++q) { wsum += jobs[q].width; wmax = std::max<int64_t>(wmax, jobs[q].width); smx = std::max<int64_t>(smx, jobs[q].smax); over += res[q].status == WFM_DEV_OVERFLOW; ef += jobs[q].endsfree; }
         fprintf(stderr, "[wfm] base launch: %zu jobs (%d ends-free), %d threads, rows %lld wide on average (max %lld), score budget up to %lld, %.3f ms, %d overflowed\n", jobs.size(), ef,
-                chunk_wide ? 1024 : 256, (long long)(wsum / (int64_t)jobs.size()), (long long)wmax, (long long)smx, ms, over);
+                chunk_kind == 5 ? B2T_THREADS : (chunk_wide ? 1024 : 256), (long long)(wsum / (int64_t)jobs.size()), (long long)wmax, (long long)smx, ms, over);
         if (chunk_kind <= 2) {
           double fw = 0, bk = 0; int fwm = 0, bkm = 0, scm = 0; double scs = 0;
           for (size_t q = 0; q < jobs.size(); ++q) { const int f = (res[q].pad_ >> 16) & 0xffff, b = res[q].pad_ & 0xffff; fw += f; bk += b; fwm = std::max(fwm, f); bkm = std::max(bkm, b); scs += res[q].score; scm = std::max(scm, res[q].score); }
           fprintf(stderr, "[wfm]   register kernel (kind %d): forward %.0f us on average (max %d), walk back %.0f us (max %d), score %.0f on average (max %d)\n", chunk_kind, fw / jobs.size(), fwm, bk / jobs.size(), bkm, scs / jobs.size(), scm);
+        }
+        else {
+          double scs = 0; int scm = 0, scn = INT_MAX;
+          for (size_t q = 0; q < jobs.size(); ++q) { scs += res[q].score; scm = std::max(scm, res[q].score); scn = std::min(scn, res[q].score); }
+          fprintf(stderr, "[wfm]   %s (kind %d): score %.0f on average (min %d, max %d)\n", chunk_kind == 5 ? "register kernel on tiles" : "ring kernel", chunk_kind, scs / jobs.size(), scn, scm);
         }
       }
       for (size_t q = 0; q < jobs.size(); ++q) {
@@ -432,7 +483,8 @@ int run_base_jobs(wfm_handle* h, wfm_seqset* S, const wfm_penalties_t& pen, std:
         const BaseResult& r = res[q];
         prob_cells[nd.prob] += r.cells;
         h->stats.cells_base += r.cells;
-        if (pflags && chunk_kind >= 3 && jobs[q].type == 0) pflags[nd.prob] |= WFM_PF_RING_KERNEL;
+        if (pflags && (chunk_kind == 3 || chunk_kind == 4) && jobs[q].type == 0) pflags[nd.prob] |= WFM_PF_RING_KERNEL;
+        if (pflags && chunk_kind == 5) pflags[nd.prob] |= WFM_PF_BASE_TILES;
         if (r.status == WFM_DEV_OVERFLOW) {
           if (pflags) pflags[nd.prob] |= nd.tries == 0 ? WFM_PF_BASE_RETRY : WFM_PF_BASE_RETRY2;
           Node again = nd;
@@ -1557,6 +1609,7 @@ void wfm_destroy(wfm_handle_t* h) {
   if (h->stage) { (void)hipHostFree(h->stage); h->stage = nullptr; h->stage_cap = 0; }
   h->p2rows.release(); h->p2max.release(); h->p2bmax.release(); h->p2pbmax.release(); h->p2jobs.release();
   h->bpjobs.release(); h->bpres.release(); h->bsjobs.release(); h->bsres.release();
+  h->b2tjobs.release(); h->b2ttasks.release(); h->b2tkeys.release(); h->b2toffs.release(); h->b2tactive.release();
   h->i64a.release(); h->i64b.release(); h->i64c.release(); h->i32a.release(); h->seqflags.release(); h->flagjobs.release(); h->total.release();
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);

@@ -396,7 +396,7 @@ __global__ __launch_bounds__(NTMAX) void wfa_tile2_kernel(const uint32_t* __rest
   const int nw = min((int)(blockDim.x >> 6), (tk.core_hi + halo - kA) / (64 * C) + 1), NT = nw * 64;
   if (wv >= nw) return;
 #ifdef WFM_TILE_TRACE
-  const bool trace_on2 = !P2 && FAST && !WAVE1 && gridDim.x > 1024 && blockIdx.x < 48;
+  const bool trace_on2 = !P2 && FAST && !WAVE1 && gridDim.x > 1024 && blockIdx.x < 48 && sbase == 3000 && J.mode == 0;  // (one launch in the middle of a deep job's run)
 #endif
   WFM_TRACE_MARK(120);
   if (tid < 2) s_wlo[tid] = INT32_MAX;
@@ -491,10 +491,12 @@ __global__ __launch_bounds__(NTMAX) void wfa_tile2_kernel(const uint32_t* __rest
       lo = min(lo, D2h[c] >= 0 ? D2h[c] : INT32_MAX);
       if (lo != INT32_MAX) { hlo = min(hlo, lo); vlo = min(vlo, lo - k); }
     }
+    WFM_TRACE_MARK(124);  // (the loaded rows have been read: the snapshot is there)
     __syncthreads();  // s_wlo initialised
     if (hlo != INT32_MAX) { atomicMin(&s_wlo[0], hlo); atomicMin(&s_wlo[1], max(vlo, 0)); }
     __syncthreads();
   }
+  WFM_TRACE_MARK(125);
   const int wT0 = s_wlo[0] == INT32_MAX ? 0 : s_wlo[0], wP0 = s_wlo[1] == INT32_MAX ? 0 : s_wlo[1];
   // window origins as absolute base indices, word aligned; offsets of a cell from them: oP = v + dP, oT = h + dT
   const int64_t oriP = (aP + wP0) & ~(int64_t)15, oriT = (aT + wT0) & ~(int64_t)15;
@@ -537,6 +539,21 @@ __global__ __launch_bounds__(NTMAX) void wfa_tile2_kernel(const uint32_t* __rest
   constexpr int EDGE_PLANE = (WAVE1 ? 1 : 17) * 2 * 4;
   const bool edge_lane = lane == 0 || lane == 63;
   int* const edge_wr = lane == 63 ? &s_edge[0][WAVE1 ? 0 : wv + 1][0][0] : &s_edge[0][WAVE1 ? 0 : wv][1][0];
+  // the gap components of a step's row into the output snapshot (the block's last rows only).  (One 8-byte store per component for a lane's two
+  // diagonals, as the M rows have it below, was built: the pair form and its fall-back for the lanes at a core's edge in every one of the ten
+  // steps of the body cost 12 - 20 bytes of spills.)
+  auto stream_gap_rows = [&](int s, const int (&vI1)[C], const int (&vI2)[C], const int (&vD1)[C], const int (&vD2)[C]) {
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      if (incore[c] && s <= s_last[c]) {
+        const int64_t ro = ((int64_t)(s & RMASK)) * width + k0 + c;
+        rout[(int64_t)C_I1 * RING * width + ro] = vI1[c];
+        rout[(int64_t)C_I2 * RING * width + ro] = vI2[c];
+        rout[(int64_t)C_D1 * RING * width + ro] = vD1[c];
+        rout[(int64_t)C_D2 * RING * width + ro] = vD2[c];
+      }
+    }
+  };
   // a finished row into its class's line (jjx: the step's number within the body, 1 .. UB)
   auto line_take = [&](auto JJX, const int (&row)[C]) {
     constexpr int jjx = decltype(JJX)::value;
@@ -708,17 +725,7 @@ __global__ __launch_bounds__(NTMAX) void wfa_tile2_kernel(const uint32_t* __rest
       }
       // ---- this step's row waits for its extension; its gap components are final
       if (__builtin_expect(t > t_stream, 0)) {  // stream the last rows of I/D of the core to the output snapshot
-#pragma unroll
-        for (int c = 0; c < C; ++c) {
-          const int k = k0 + c;
-          if (incore[c] && s <= s_last[c]) {
-            const int64_t ro = ((int64_t)(s & RMASK)) * width + k;
-            rout[(int64_t)C_I1 * RING * width + ro] = nI1[c];
-            rout[(int64_t)C_I2 * RING * width + ro] = nI2[c];
-            rout[(int64_t)C_D1 * RING * width + ro] = nD1[c];
-            rout[(int64_t)C_D2 * RING * width + ro] = nD2[c];
-          }
-        }
+        stream_gap_rows(s, nI1, nI2, nD1, nD2);
       }
 #pragma unroll
       for (int c = 0; c < C; ++c) { pM[c] = nM[c]; I1h[c][e1x] = nI1[c]; D1h[c][e1x] = nD1[c]; I2h[c] = nI2[c]; D2h[c] = nD2[c]; }
@@ -752,28 +759,24 @@ __global__ __launch_bounds__(NTMAX) void wfa_tile2_kernel(const uint32_t* __rest
       // every row of the core is kept: five components into the job's P2 rows
       int32_t* prow = p2_arena + J.p2_off + J.koff2 + ((int64_t)(dir * 5) * P2K + (t - 1)) * J.w2;
       const int64_t cstride = (int64_t)P2K * J.w2;
+      const bool w0 = incore[0] && s <= s_last[0], w1 = incore[1] && s <= s_last[1];
+      if (w0 && w1) {
+        st_pair(prow + C_M * cstride + k0, nM[0], nM[1]); st_pair(prow + C_I1 * cstride + k0, nI1[0], nI1[1]); st_pair(prow + C_I2 * cstride + k0, nI2[0], nI2[1]);
+        st_pair(prow + C_D1 * cstride + k0, nD1[0], nD1[1]); st_pair(prow + C_D2 * cstride + k0, nD2[0], nD2[1]);
+      } else {
 #pragma unroll
-      for (int c = 0; c < C; ++c) {
-        const int k = k0 + c;
-        if (incore[c] && s <= s_last[c]) {
-          prow[C_M * cstride + k] = nM[c]; prow[C_I1 * cstride + k] = nI1[c]; prow[C_I2 * cstride + k] = nI2[c];
-          prow[C_D1 * cstride + k] = nD1[c]; prow[C_D2 * cstride + k] = nD2[c];
+        for (int c = 0; c < C; ++c) {
+          const int k = k0 + c;
+          if (c == 0 ? w0 : w1) {
+            prow[C_M * cstride + k] = nM[c]; prow[C_I1 * cstride + k] = nI1[c]; prow[C_I2 * cstride + k] = nI2[c];
+            prow[C_D1 * cstride + k] = nD1[c]; prow[C_D2 * cstride + k] = nD2[c];
+          }
         }
       }
     }
     // stream the last H rows of I/D of the core to the output snapshot
     if (!P2 && __builtin_expect(t > t_stream, 0)) {
-#pragma unroll
-      for (int c = 0; c < C; ++c) {
-        const int k = k0 + c;
-        if (incore[c] && s <= s_last[c]) {
-          const int64_t ro = ((int64_t)(s & RMASK)) * width + k;
-          rout[(int64_t)C_I1 * RING * width + ro] = nI1[c];
-          rout[(int64_t)C_I2 * RING * width + ro] = nI2[c];
-          rout[(int64_t)C_D1 * RING * width + ro] = nD1[c];
-          rout[(int64_t)C_D2 * RING * width + ro] = nD2[c];
-        }
-      }
+      stream_gap_rows(s, nI1, nI2, nD1, nD2);
     }
     // advance the delay line of this step's class only
 #pragma unroll
@@ -999,6 +1002,84 @@ struct RleWriter2 {
     cur_len = 0; cur_op = -1;
   }
 };
+
+// wavefront_backtrace_affine over the rows a forward pass has left (pre: the offset of every M cell before its extension, bt: its decision byte; both
+// addressed [score][diagonal] with the job's width): every lane of the wave with the same state, lane 0 writes; a run of gap cells is read 64 decision
+// bytes at a time (r32::wfa_base_kernel).  Returns the number of runs written below rle[J.rle_end].
+__device__ __forceinline__ int base2_walk(const BaseJob& J, const int32_t* __restrict__ pre_base, const uint8_t* __restrict__ bt_base, uint32_t* __restrict__ rle,
+                                          int s, int k_from, int off_from, int lane) {
+  constexpr int PX = 5, PO1 = 8, PE1 = 2, PO2 = 24, PE2 = 1;
+  const int pl = J.pl, tl = J.tl;
+  const int64_t width = J.width;
+  RleWriter2 w; w.base = rle + J.rle_end; w.n = 0; w.cur_op = -1; w.cur_len = 0; w.writes = lane == 0;
+  int comp = J.endsfree ? C_M : J.comp_end;
+  int k = k_from;
+  int off = off_from;
+  int sc = s;
+  int h = off, v = off - k;
+  if (comp == C_M) {
+    if (v < pl) w.push(OP_D, pl - v);
+    if (h < tl) w.push(OP_I, tl - h);
+  }
+  while (v > 0 && h > 0 && sc > 0) {
+    if (comp != C_M) {
+      const bool ins = comp == C_I1 || comp == C_I2;
+      const int e = (comp == C_I1 || comp == C_D1) ? PE1 : PE2, o = (comp == C_I1 || comp == C_D1) ? PO1 : PO2;
+      const unsigned mask = comp == C_I1 ? BT_I1_EXT : (comp == C_I2 ? BT_I2_EXT : (comp == C_D1 ? BT_D1_EXT : BT_D2_EXT));
+      const int scj = sc - lane * e, kj = ins ? k - lane : k + lane;
+      const bool alive = scj > 0 && (ins ? h - lane > 0 : v - lane > 0);
+      const unsigned bj = alive ? bt_base[(int64_t)scj * width + kj] : 0u;
+      const unsigned long long stop = __ballot(!(alive && (bj & mask)));
+      const int j0 = stop ? (int)__builtin_ctzll(stop) : 64;  // cells 0 .. j0-1 continue the gap
+      if (j0 > 0) {
+        w.push(ins ? OP_I : OP_D, j0);
+        sc -= j0 * e;
+        if (ins) { k -= j0; off -= j0; } else k += j0;
+        v = off - k; h = off;
+      }
+      if (j0 < 64) {
+        if (!(v > 0 && h > 0 && sc > 0)) break;   // the walk ends inside the gap
+        sc -= o + e; comp = C_M;                  // the cell that opened the gap
+        w.push(ins ? OP_I : OP_D, 1);
+        if (ins) { --k; --off; } else ++k;
+        v = off - k; h = off;
+      }
+      continue;
+    }
+    // (round 6, as in the ring kernel's walk -- wfa_generic_inc.h: a run of mismatches stays on its diagonal, PX scores apart: the lanes read
+    // the next 64 cells of that line at once, the walk goes through them from registers while each one's source is the mismatch)
+    const int scj = sc - lane * PX;
+    const unsigned bj = scj > 0 ? (unsigned)bt_base[(int64_t)scj * width + k] : 0u;
+    const int pj = scj > 0 ? pre_base[(int64_t)scj * width + k] : 0;
+    bool stop = false;
+    for (int j = 0; j < 64; ++j) {
+      const unsigned b = (unsigned)rdl((int)bj, j);
+      const int pre = rdl(pj, j);
+      w.push(OP_M, off - pre);
+      off = pre; v = off - k; h = off;
+      if (v <= 0 || h <= 0) { stop = true; break; }
+      const unsigned src = b & 7u;
+      if (src == C_M) {
+        sc -= PX; comp = C_M; w.push(OP_X, 1); --off;
+        v = off - k; h = off;
+        if (!(v > 0 && h > 0 && sc > 0)) break;
+        continue;
+      }
+      if (src == C_I1) { if (b & BT_I1_EXT) { sc -= PE1; comp = C_I1; } else { sc -= PO1 + PE1; comp = C_M; } w.push(OP_I, 1); --k; --off; }
+      else if (src == C_I2) { if (b & BT_I2_EXT) { sc -= PE2; comp = C_I2; } else { sc -= PO2 + PE2; comp = C_M; } w.push(OP_I, 1); --k; --off; }
+      else if (src == C_D1) { if (b & BT_D1_EXT) { sc -= PE1; comp = C_D1; } else { sc -= PO1 + PE1; comp = C_M; } w.push(OP_D, 1); ++k; }
+      else { if (b & BT_D2_EXT) { sc -= PE2; comp = C_D2; } else { sc -= PO2 + PE2; comp = C_M; } w.push(OP_D, 1); ++k; }
+      v = off - k; h = off;
+      break;
+    }
+    if (stop) break;
+  }
+  if (comp == C_M && v > 0 && h > 0) { const int nm = min(v, h); w.push(OP_M, nm); v -= nm; h -= nm; }
+  if (v > 0) w.push(OP_D, v);
+  if (h > 0) w.push(OP_I, h);
+  w.flush();
+  return w.n;
+}
 
 template <int NTMAX>
 __global__ __launch_bounds__(NTMAX) void wfa_base2_kernel(const uint32_t* __restrict__ pk, int32_t* __restrict__ arena32, uint8_t* __restrict__ arena8,
@@ -1238,80 +1319,325 @@ __global__ __launch_bounds__(NTMAX) void wfa_base2_kernel(const uint32_t* __rest
   if (tid < 64) {
     const long long t_fwd = wall_clock64();
     BaseResult r; r.status = status; r.score = s; r.nruns = 0; r.cells = cells; r.pad_ = 0;
-    if (status == 0) {
-      RleWriter2 w; w.base = rle + J.rle_end; w.n = 0; w.cur_op = -1; w.cur_len = 0; w.writes = lane == 0;
-      int comp = J.endsfree ? C_M : J.comp_end;
-      int k = J.endsfree ? s_endk : k_end;
-      int off = J.endsfree ? s_endoff : tl;
-      int sc = s;
-      int h = off, v = off - k;
-      if (comp == C_M) {
-        if (v < pl) w.push(OP_D, pl - v);
-        if (h < tl) w.push(OP_I, tl - h);
-      }
-      while (v > 0 && h > 0 && sc > 0) {
-        if (comp != C_M) {
-          const bool ins = comp == C_I1 || comp == C_I2;
-          const int e = (comp == C_I1 || comp == C_D1) ? PE1 : PE2, o = (comp == C_I1 || comp == C_D1) ? PO1 : PO2;
-          const unsigned mask = comp == C_I1 ? BT_I1_EXT : (comp == C_I2 ? BT_I2_EXT : (comp == C_D1 ? BT_D1_EXT : BT_D2_EXT));
-          const int scj = sc - lane * e, kj = ins ? k - lane : k + lane;
-          const bool alive = scj > 0 && (ins ? h - lane > 0 : v - lane > 0);
-          const unsigned bj = alive ? bt_base[(int64_t)scj * width + kj] : 0u;
-          const unsigned long long stop = __ballot(!(alive && (bj & mask)));
-          const int j0 = stop ? (int)__builtin_ctzll(stop) : 64;  // cells 0 .. j0-1 continue the gap
-          if (j0 > 0) {
-            w.push(ins ? OP_I : OP_D, j0);
-            sc -= j0 * e;
-            if (ins) { k -= j0; off -= j0; } else k += j0;
-            v = off - k; h = off;
-          }
-          if (j0 < 64) {
-            if (!(v > 0 && h > 0 && sc > 0)) break;   // the walk ends inside the gap
-            sc -= o + e; comp = C_M;                  // the cell that opened the gap
-            w.push(ins ? OP_I : OP_D, 1);
-            if (ins) { --k; --off; } else ++k;
-            v = off - k; h = off;
-          }
-          continue;
-        }
-        // (round 6, as in the ring kernel's walk -- wfa_generic_inc.h: a run of mismatches stays on its diagonal, PX scores apart: the lanes read
-        // the next 64 cells of that line at once, the walk goes through them from registers while each one's source is the mismatch)
-        const int scj = sc - lane * PX;
-        const unsigned bj = scj > 0 ? (unsigned)bt_base[(int64_t)scj * width + k] : 0u;
-        const int pj = scj > 0 ? pre_base[(int64_t)scj * width + k] : 0;
-        bool stop = false;
-        for (int j = 0; j < 64; ++j) {
-          const unsigned b = (unsigned)rdl((int)bj, j);
-          const int pre = rdl(pj, j);
-          w.push(OP_M, off - pre);
-          off = pre; v = off - k; h = off;
-          if (v <= 0 || h <= 0) { stop = true; break; }
-          const unsigned src = b & 7u;
-          if (src == C_M) {
-            sc -= PX; comp = C_M; w.push(OP_X, 1); --off;
-            v = off - k; h = off;
-            if (!(v > 0 && h > 0 && sc > 0)) break;
-            continue;
-          }
-          if (src == C_I1) { if (b & BT_I1_EXT) { sc -= PE1; comp = C_I1; } else { sc -= PO1 + PE1; comp = C_M; } w.push(OP_I, 1); --k; --off; }
-          else if (src == C_I2) { if (b & BT_I2_EXT) { sc -= PE2; comp = C_I2; } else { sc -= PO2 + PE2; comp = C_M; } w.push(OP_I, 1); --k; --off; }
-          else if (src == C_D1) { if (b & BT_D1_EXT) { sc -= PE1; comp = C_D1; } else { sc -= PO1 + PE1; comp = C_M; } w.push(OP_D, 1); ++k; }
-          else { if (b & BT_D2_EXT) { sc -= PE2; comp = C_D2; } else { sc -= PO2 + PE2; comp = C_M; } w.push(OP_D, 1); ++k; }
-          v = off - k; h = off;
-          break;
-        }
-        if (stop) break;
-      }
-      if (comp == C_M && v > 0 && h > 0) { const int nm = min(v, h); w.push(OP_M, nm); v -= nm; h -= nm; }
-      if (v > 0) w.push(OP_D, v);
-      if (h > 0) w.push(OP_I, h);
-      w.flush();
-      r.nruns = w.n;
-    }
+    if (status == 0) r.nruns = base2_walk(J, pre_base, bt_base, rle, s, J.endsfree ? s_endk : k_end, J.endsfree ? s_endoff : tl, lane);
     // diagnostics (WFM_DEBUG=2): microseconds of the forward pass and of the walk back, 16 bits each
     r.pad_ = (int32_t)((min((t_fwd - t_begin) / 100, 65535ll) << 16) | min((wall_clock64() - t_fwd) / 100, 65535ll));
     if (lane == 0) results[blockIdx.x] = r;
   }
+}
+
+// ---------------------------------------------------------------------------
+// Base jobs wider than a workgroup's registers: wfa_base2_kernel's step on tiles (Base2TJob in wfa_device.h)
+// ---------------------------------------------------------------------------
+// One workgroup = one tile of one job for one block of T scores (T a multiple of 5: a block begins with class 1).  Everything a cell computes and
+// everything that is written about it is wfa_base2_kernel's -- same recurrences, same decision bits, same range of a row, same end tests -- but rows of
+// pre / bt and the end tests are the core's alone: the halo's cells are right only as far from the tile's edge as the block is old.
+template <int NTMAX>
+__global__ __launch_bounds__(NTMAX) void wfa_base2t_kernel(const uint32_t* __restrict__ pk, int32_t* __restrict__ arena32, uint8_t* __restrict__ arena8,
+                                                         const Base2TJob* __restrict__ jobs, const Base2TTask* __restrict__ tasks,
+                                                         unsigned long long* __restrict__ tile_key, int32_t* __restrict__ tile_off, int T) {
+  constexpr int C = 2, NCL = 5, DEP = 6, E1 = 2, H = 26;
+  constexpr int NW = NTMAX / 64;
+  const Base2TTask tk = tasks[blockIdx.x];
+  const Base2TJob JT = jobs[tk.job];
+  if (JT.done) return;
+  const BaseJob& J = JT.b;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  __shared__ int s_edge[2][NW][2][4];
+  __shared__ __attribute__((aligned(16))) uint32_t s_winP[PK_WIN_DW + PK_SLACK_DW], s_winT[PK_WIN_DW + PK_SLACK_DW];
+  __shared__ int s_done, s_endk, s_endoff;
+  const int pl = J.pl, tl = J.tl, kmin = J.kmin, kmax = J.kmin + J.width - 1;
+  const int64_t width = J.width;
+  int32_t* pre_base = arena32 + J.pre_off - kmin;
+  uint8_t* bt_base = arena8 + J.bt_off - kmin;
+  const int32_t* snap_in = arena32 + JT.snap_in - kmin;
+  int32_t* snap_out = arena32 + JT.snap_out - kmin;
+  const int k_end = tl - pl;
+  const int s0 = JT.s0;
+  const int core_lo = kmin + tk.tile * JT.core, core_hi = min(kmax, core_lo + JT.core - 1);
+  const int64_t oriP = J.p_off & ~(int64_t)15, oriT = J.t_off & ~(int64_t)15;
+  const int dP = (int)(J.p_off - oriP), dT = (int)(J.t_off - oriT);
+  PkSrc SRC;
+  SRC.lP = (lds_words)s_winP; SRC.lT = (lds_words)s_winT;
+  SRC.gP = (glb_words)pk + (oriP >> 4); SRC.gT = (glb_words)pk + (oriT >> 4);
+  {
+    const int nP = min(PK_WIN_DW + PK_SLACK_DW, (pl + dP + 15) / 16 + 8), nT = min(PK_WIN_DW + PK_SLACK_DW, (tl + dT + 15) / 16 + 8);
+    for (int i = tid; i < nP; i += NTMAX) s_winP[i] = SRC.gP[i];
+    for (int i = tid; i < nT; i += NTMAX) s_winT[i] = SRC.gT[i];
+  }
+  if (tid == 0) { s_done = 0; s_endk = INT32_MAX; s_endoff = 0; }
+  for (int i = tid; i < (int)(sizeof(s_edge) / sizeof(int)); i += NTMAX) ((int*)s_edge)[i] = WF_NULL;
+  __syncthreads();
+
+  const int k0 = core_lo - T + tid * C;  // (the host sizes the core: core + 2 T <= NTMAX * C)
+  const int kw_lo = core_lo - T + (tid & ~63) * C, kw_hi = kw_lo + 64 * C - 1;  // the diagonals of this thread's wave
+  int Mh[C][NCL][DEP];
+  int I1h[C][E1], D1h[C][E1], I2h[C], D2h[C];
+  unsigned hmaxu[C];
+  int cP[C], mcur[C];
+  bool colok[C], incore[C];
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    const int k = k0 + c;
+#pragma unroll
+    for (int r = 0; r < NCL; ++r)
+#pragma unroll
+      for (int e = 0; e < DEP; ++e) Mh[c][r][e] = WF_NULL;
+#pragma unroll
+    for (int d = 0; d < E1; ++d) { I1h[c][d] = WF_NULL; D1h[c][d] = WF_NULL; }
+    I2h[c] = WF_NULL; D2h[c] = WF_NULL;
+    colok[c] = k >= -pl && k <= tl && k >= kmin && k <= kmax;
+    incore[c] = k >= core_lo && k <= core_hi;
+    hmaxu[c] = colok[c] ? (unsigned)min(tl, pl + k) : 0u;
+    cP[c] = dP - k;
+    mcur[c] = WF_NULL;
+  }
+  auto end_checks = [&](int k, int m_ext, int ins1, int ins2, int del1, int del2) {
+    if (J.endsfree) {
+      if (m_ext >= 0) {
+        const int h = m_ext, v = m_ext - k;
+        if ((h >= tl && pl - v <= J.pef) || (v >= pl && tl - h <= J.tef)) atomicMin(&s_endk, k);
+      }
+    } else if (k == k_end) {
+      const int ev = J.comp_end == C_M ? m_ext : (J.comp_end == C_I1 ? ins1 : (J.comp_end == C_I2 ? ins2 : (J.comp_end == C_D1 ? del1 : del2)));
+      if (ev >= tl) s_done = 1;
+    }
+  };
+  int lo0, hi0;
+  if (J.endsfree) { lo0 = max(-J.pbf, kmin); hi0 = min(J.tbf, kmax); }
+  else { lo0 = 0; hi0 = 0; }
+  if (s0 == 0) {
+    // ---- row 0 (no cell of it has a neighbour to wait for: the halo's are right)
+    int m0[C], ext[C], maxn[C];
+    unsigned oP[C], oT[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      const int k = k0 + c;
+      const bool on = k >= lo0 && k <= hi0;
+      int m = WF_NULL;
+      if (on) {
+        if (J.endsfree) m = k > 0 ? k : 0;
+        else {
+          if (J.comp_begin == C_M) m = 0;
+          I1h[c][0] = J.comp_begin == C_I1 ? 0 : WF_NULL;
+          I2h[c] = J.comp_begin == C_I2 ? 0 : WF_NULL;
+          D1h[c][0] = J.comp_begin == C_D1 ? 0 : WF_NULL;
+          D2h[c] = J.comp_begin == C_D2 ? 0 : WF_NULL;
+        }
+      }
+      m0[c] = m;
+      oP[c] = (unsigned)(m + cP[c]); oT[c] = (unsigned)(m + dT);
+      maxn[c] = m >= 0 ? min(pl - (m - k), tl - m) : 0;
+    }
+    pk_extend2(SRC, m0, oP, oT, maxn, ext);
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      const int k = k0 + c;
+      if (k < lo0 || k > hi0) continue;
+      if (incore[c]) { pre_base[k] = m0[c]; bt_base[k] = 0; }
+      int m = m0[c];
+      if (m >= 0) m += ext[c];
+      if (incore[c]) {
+        if (J.endsfree) end_checks(k, m, WF_NULL, WF_NULL, WF_NULL, WF_NULL);
+        else if (k == k_end && J.comp_end == C_M && m >= tl) s_done = 1;
+      }
+      Mh[c][0][0] = m;
+      mcur[c] = m;
+    }
+  } else {
+    // ---- the snapshot of the block before: rows 0 .. 25 = M of scores s0, s0 - 1, ..; 26 / 27 = I1 of s0 / s0 - 1; 28 / 29 = D1; 30 = I2; 31 = D2.
+    // Every column of the job lies in one tile's core and was written there, NULL where the row had no cell
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      const int k = k0 + c;
+      if (k < kmin || k > kmax) continue;
+#pragma unroll
+      for (int d = 0; d < H; ++d) Mh[c][(NCL - d % NCL) % NCL][d / NCL] = snap_in[(int64_t)d * width + k];
+#pragma unroll
+      for (int d = 0; d < E1; ++d) { I1h[c][d] = snap_in[(int64_t)(26 + d) * width + k]; D1h[c][d] = snap_in[(int64_t)(28 + d) * width + k]; }
+      I2h[c] = snap_in[(int64_t)30 * width + k]; D2h[c] = snap_in[(int64_t)31 * width + k];
+      mcur[c] = Mh[c][0][0];
+    }
+  }
+  int s = s0;
+  bool done = false;
+  const int s_stop = min(s0 + T, J.smax);
+  for (int tb = s0; !done && tb < s_stop; tb += NCL) {
+#pragma unroll
+  for (int jj = 1; jj <= NCL; ++jj) {
+    const int cl = jj % NCL;
+    const int sn = tb + jj;
+    int lM10, lM25, lI1, lI2, rM10, rM25, rD1, rD2;
+    const int par = sn & 1;
+    if (lane == 63) { int* e = s_edge[par][wv][0]; e[0] = Mh[C - 1][cl][1]; e[1] = Mh[C - 1][cl][4]; e[2] = I1h[C - 1][E1 - 1]; e[3] = I2h[C - 1]; }
+    if (lane == 0)  { int* e = s_edge[par][wv][1]; e[0] = Mh[0][cl][1];     e[1] = Mh[0][cl][4];     e[2] = D1h[0][E1 - 1];     e[3] = D2h[0]; }
+    __syncthreads();
+    done = J.endsfree ? (s_endk != INT32_MAX) : (s_done != 0);
+    if (done || sn > s_stop) break;
+    s = sn;
+    const int lo = max(lo0 - s, max(-pl, kmin)), hi = min(hi0 + s, min(tl, kmax));
+    const bool valid = lo <= hi;
+    if (!valid || kw_hi < lo - 1 || kw_lo > hi + 1) continue;
+    lM10 = from_prev_lane(Mh[C - 1][cl][1]); lM25 = from_prev_lane(Mh[C - 1][cl][4]);
+    lI1 = from_prev_lane(I1h[C - 1][E1 - 1]); lI2 = from_prev_lane(I2h[C - 1]);
+    rM10 = from_next_lane(Mh[0][cl][1]); rM25 = from_next_lane(Mh[0][cl][4]);
+    rD1 = from_next_lane(D1h[0][E1 - 1]); rD2 = from_next_lane(D2h[0]);
+    if (lane == 0 && wv > 0) { const int* e = s_edge[par][wv - 1][0]; lM10 = e[0]; lM25 = e[1]; lI1 = e[2]; lI2 = e[3]; }
+    if (lane == 63 && wv + 1 < NW) { const int* e = s_edge[par][wv + 1][1]; rM10 = e[0]; rM25 = e[1]; rD1 = e[2]; rD2 = e[3]; }
+    int nM[C], nI1[C], nI2[C], nD1[C], nD2[C], preM[C];
+    unsigned btb[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      const int k = k0 + c;
+      const int a10 = c == 0 ? lM10 : Mh[c - 1][cl][1], b10 = c == C - 1 ? rM10 : Mh[c + 1][cl][1];
+      const int a25 = c == 0 ? lM25 : Mh[c - 1][cl][4], b25 = c == C - 1 ? rM25 : Mh[c + 1][cl][4];
+      const int i1 = c == 0 ? lI1 : I1h[c - 1][E1 - 1], d1 = c == C - 1 ? rD1 : D1h[c + 1][E1 - 1];
+      const int i2 = c == 0 ? lI2 : I2h[c - 1], d2 = c == C - 1 ? rD2 : D2h[c + 1];
+      const int mx = Mh[c][cl][0];
+      unsigned bits = 0;
+      if (i1 >= a10) bits |= BT_I1_EXT;
+      if (i2 >= a25) bits |= BT_I2_EXT;
+      if (d1 >= b10) bits |= BT_D1_EXT;
+      if (d2 >= b25) bits |= BT_D2_EXT;
+      const unsigned hm = hmaxu[c];
+      int ins1 = max(a10, i1) + 1, ins2 = max(a25, i2) + 1, del1 = max(b10, d1), del2 = max(b25, d2), mis = mx + 1;
+      ins1 = (unsigned)ins1 <= hm ? ins1 : WF_NULL;
+      ins2 = (unsigned)ins2 <= hm ? ins2 : WF_NULL;
+      del1 = (unsigned)del1 <= hm ? del1 : WF_NULL;
+      del2 = (unsigned)del2 <= hm ? del2 : WF_NULL;
+      mis = (unsigned)mis <= hm ? mis : WF_NULL;
+      int m = ins1; unsigned src = C_I1;
+      if (ins2 >= m) { m = ins2; src = C_I2; }
+      if (del1 >= m) { m = del1; src = C_D1; }
+      if (del2 >= m) { m = del2; src = C_D2; }
+      if (mis >= m)  { m = mis;  src = C_M; }
+      const bool on = k >= lo && k <= hi;
+      nI1[c] = on ? ins1 : WF_NULL; nI2[c] = on ? ins2 : WF_NULL; nD1[c] = on ? del1 : WF_NULL; nD2[c] = on ? del2 : WF_NULL;
+      nM[c] = (on && colok[c]) ? m : WF_NULL;
+      preM[c] = nM[c];
+      btb[c] = bits | src;
+    }
+    int ext[C], maxn[C];
+    unsigned oP[C], oT[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      const int m = nM[c];
+      oP[c] = (unsigned)(m + cP[c]); oT[c] = (unsigned)(m + dT);
+      maxn[c] = m >= 0 ? (int)hmaxu[c] - m : 0;
+    }
+    pk_extend2(SRC, nM, oP, oT, maxn, ext);
+    int32_t* pre = pre_base + (int64_t)s * width;
+    uint8_t* bt = bt_base + (int64_t)s * width;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      const int k = k0 + c;
+      const bool on = k >= lo && k <= hi;
+      if (on) {
+        int m = nM[c];
+        if (m >= 0) m += ext[c];
+        nM[c] = m;
+        if (incore[c]) {
+          pre[k] = preM[c];
+          bt[k] = (uint8_t)btb[c];
+          end_checks(k, m, nI1[c], nI2[c], nD1[c], nD2[c]);
+        }
+      }
+      mcur[c] = nM[c];
+#pragma unroll
+      for (int e = DEP - 1; e > 0; --e) Mh[c][cl][e] = Mh[c][cl][e - 1];
+      Mh[c][cl][0] = nM[c];
+#pragma unroll
+      for (int d = E1 - 1; d > 0; --d) { I1h[c][d] = I1h[c][d - 1]; D1h[c][d] = D1h[c][d - 1]; }
+      I1h[c][0] = nI1[c]; D1h[c][0] = nD1[c];
+      I2h[c] = nI2[c]; D2h[c] = nD2[c];
+    }
+  }
+  }
+  __syncthreads();  // (the end tests of the block's last step)
+  const bool found = J.endsfree ? (s_endk != INT32_MAX) : (s_done != 0);
+  if (found) {
+    if (J.endsfree) {
+#pragma unroll
+      for (int c = 0; c < C; ++c) if (k0 + c == s_endk) s_endoff = mcur[c];
+      __syncthreads();
+    }
+    if (tid == 0) {
+      const int ek = J.endsfree ? s_endk : k_end;
+      tile_key[blockIdx.x] = ((unsigned long long)(unsigned)s << 32) | (unsigned)(ek - kmin);
+      tile_off[blockIdx.x] = J.endsfree ? s_endoff : tl;
+    }
+    return;
+  }
+  if (tid == 0) tile_key[blockIdx.x] = ~0ull;
+  if (s != s0 + T) return;  // (the budget ended inside the block: nothing follows)
+  // ---- the core's columns of the snapshot
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    const int k = k0 + c;
+    if (!incore[c]) continue;
+#pragma unroll
+    for (int d = 0; d < H; ++d) snap_out[(int64_t)d * width + k] = Mh[c][(NCL - d % NCL) % NCL][d / NCL];
+#pragma unroll
+    for (int d = 0; d < E1; ++d) { snap_out[(int64_t)(26 + d) * width + k] = I1h[c][d]; snap_out[(int64_t)(28 + d) * width + k] = D1h[c][d]; }
+    snap_out[(int64_t)30 * width + k] = I2h[c]; snap_out[(int64_t)31 * width + k] = D2h[c];
+  }
+}
+
+// Between two blocks: the end test over the tiles of a job -- the first score at which a cell of the row ends the alignment and the smallest such
+// diagonal, as the one workgroup of wfa_base2_kernel finds it -- or the next block's score and snapshots.  One thread per job.
+__global__ __launch_bounds__(64) void wfa_base2t_advance_kernel(Base2TJob* __restrict__ jobs, const unsigned long long* __restrict__ tile_key,
+                                                               const int32_t* __restrict__ tile_off, int njobs, int T, int32_t* __restrict__ active_slot) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= njobs) return;
+  Base2TJob J = jobs[i];
+  if (J.done) return;
+  unsigned long long best = ~0ull; int at = -1;
+  for (int t = 0; t < J.ntiles; ++t) { const unsigned long long k = tile_key[J.task0 + t]; if (k < best) { best = k; at = t; } }
+  if (at >= 0) {
+    J.done = 1; J.end_s = (int)(best >> 32); J.end_k = (int)(unsigned)(best & 0xffffffffull) + J.b.kmin; J.end_off = tile_off[J.task0 + at];
+  } else if (J.s0 + T >= J.b.smax) {
+    J.done = 2; J.end_s = J.b.smax;
+  } else {
+    J.s0 += T;
+    const int64_t t = J.snap_in; J.snap_in = J.snap_out; J.snap_out = t;
+    atomicAdd(active_slot, 1);
+  }
+  jobs[i] = J;
+}
+
+// The walk back and the result of a job: one wave per job.
+__global__ __launch_bounds__(64) void wfa_base2t_finish_kernel(const int32_t* __restrict__ arena32, const uint8_t* __restrict__ arena8, uint32_t* __restrict__ rle,
+                                                              const Base2TJob* __restrict__ jobs, BaseResult* __restrict__ results) {
+  const Base2TJob JT = jobs[blockIdx.x];
+  const BaseJob& J = JT.b;
+  const int lane = threadIdx.x;
+  const int kmin = J.kmin, kmax = J.kmin + J.width - 1;
+  BaseResult r; r.status = JT.done == 1 ? 0 : WFM_DEV_OVERFLOW; r.score = JT.end_s; r.nruns = 0; r.pad_ = 0;
+  // the cells of the rows 0 .. end_s as wfa_base2_kernel counts them
+  int lo0, hi0;
+  if (J.endsfree) { lo0 = max(-J.pbf, kmin); hi0 = min(J.tbf, kmax); }
+  else { lo0 = 0; hi0 = 0; }
+  unsigned long long cells = 0;
+  for (int s = 1 + lane; s <= JT.end_s; s += 64) {
+    const int lo = max(lo0 - s, max(-J.pl, kmin)), hi = min(hi0 + s, min(J.tl, kmax));
+    if (lo <= hi) cells += (unsigned long long)(hi - lo + 1);
+  }
+  for (int d = 32; d > 0; d >>= 1) cells += __shfl_down(cells, d, 64);
+  cells = __shfl(cells, 0, 64) + (unsigned long long)(hi0 - lo0 + 1);
+  r.cells = cells;
+  if (JT.done == 1) r.nruns = base2_walk(J, arena32 + J.pre_off - kmin, arena8 + J.bt_off - kmin, rle, JT.end_s, JT.end_k, JT.end_off, lane);
+  if (lane == 0) results[blockIdx.x] = r;
+}
+
+void launch_base2t_block(const uint32_t* pk, int32_t* a32, uint8_t* a8, const Base2TJob* jobs, const Base2TTask* tasks, unsigned long long* tile_key,
+                         int32_t* tile_off, int ntasks, int T, hipStream_t st) {
+  hipLaunchKernelGGL(wfa_base2t_kernel<B2T_THREADS>, dim3(ntasks), dim3(B2T_THREADS), 0, st, pk, a32, a8, jobs, tasks, tile_key, tile_off, T);
+}
+void launch_base2t_advance(Base2TJob* jobs, const unsigned long long* tile_key, const int32_t* tile_off, int njobs, int T, int32_t* active_slot, hipStream_t st) {
+  hipLaunchKernelGGL(wfa_base2t_advance_kernel, dim3((njobs + 63) / 64), dim3(64), 0, st, jobs, tile_key, tile_off, njobs, T, active_slot);
+}
+void launch_base2t_finish(const int32_t* a32, const uint8_t* a8, uint32_t* rle, const Base2TJob* jobs, BaseResult* res, int njobs, hipStream_t st) {
+  hipLaunchKernelGGL(wfa_base2t_finish_kernel, dim3(njobs), dim3(64), 0, st, a32, a8, rle, jobs, res);
 }
 
 // threads: a multiple of 64 with threads * 2 >= the widest row of the launch (<= 1024)
