@@ -326,11 +326,14 @@ int run_base_jobs(wfm_handle* h, wfm_seqset* S, const wfm_penalties_t& pen, std:
   const bool base_tiles = !(getenv("WFM_BASE_TILES") && atoi(getenv("WFM_BASE_TILES")) == 0);
   // (sequences longer than the kernel's LDS windows are fine: what lies beyond is read from the global mirror.  Jobs without
   // any cell -- an empty pattern or text -- ride along with the first kind: they are one store each)
+  const bool few_jobs = nodes.size() < 128;
   auto kind_of = [&](const Node& a) {
     const int64_t w = base_row_width(a, S->meta[a.prob]);
     if (base_v2 && (a.pl == 0 || a.tl == 0)) return 1;
     if (base_v2 && w <= 2048 && (size_t)a.prob < S->acgt.size() && S->acgt[(size_t)a.prob])
-      return w <= 128 ? 0 : (w <= 640 ? 1 : 2);
+      // (a handful of retries: more workgroups of fewer waves per job on the tiles of the register kernel, and ONE launch with the wider ones
+      // instead of one per width class, each a few jobs and hundreds of score steps long)
+      return w <= 128 ? 0 : (base_tiles && few_jobs && (a.tries > 0 || w > 640) ? 5 : (w <= 640 ? 1 : 2));
     if (base_v2 && base_tiles && (size_t)a.prob < S->acgt.size() && S->acgt[(size_t)a.prob]) return 5;
     return w > wide_from ? 4 : 3;
   };
@@ -507,7 +510,10 @@ int run_base_jobs(wfm_handle* h, wfm_seqset* S, const wfm_penalties_t& pen, std:
           // ... but the second attempt stops at 1020: with the band around the end corner's diagonal the rows of a job with that budget are at most
           // 2041 diagonals wide and fit the register kernel (wfa_base2_kernel: 2048), where a budget of 2080 put two dozen patches of an LPA batch
           // on the ring kernel with rows of 2.6 - 3.4 k diagonals (9.7 ms of the batch's 83); the few that need more take a third attempt
-          if (nd.smax < 1020 && again.smax > 1020) again.smax = 1020;
+          // (round 6: a job the tiles of the register kernel take -- wfa_base2t_kernel, rows of any width -- has no use for the stop: its second attempt
+          // runs with the eightfold budget at once, 2.0 ms of an LPA batch's patch chain less)
+          const bool to_tiles = base_v2 && base_tiles && (size_t)nd.prob < S->acgt.size() && S->acgt[(size_t)nd.prob];
+          if (nd.smax < 1020 && again.smax > 1020 && !to_tiles) again.smax = 1020;
           retry.push_back(again);
         } else if (r.status != 0) {
           if (getenv("WFM_DEBUG")) fprintf(stderr, "[wfm] problem %d: base job pl %d tl %d status %d\n", nd.prob, nd.pl, nd.tl, r.status);

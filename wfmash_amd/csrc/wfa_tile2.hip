@@ -55,6 +55,13 @@ constexpr int PK_WIN_BASES = PK_WIN_DW * 16;  // 32768 bases
 constexpr int PK_SLACK_DW = 8;                // words past the window a probe may touch
 constexpr int TAIL_DIRECT_MAX = 2;            // pk_extend2<true>: up to this many lanes with a run past 16 bases go to the wave's tail at once
 
+// A workgroup barrier that orders LDS only: __syncthreads() also waits for every global store of the wave to be acknowledged (vmcnt(0)), which a step
+// loop that writes rows nobody reads before the kernel's end pays for at every step
+__device__ __forceinline__ void lds_barrier() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
 // two adjacent 32-bit values at a dword-aligned address as one access (global loads and stores of 8 bytes need no more than that)
 struct __attribute__((packed, aligned(4))) Pair32 { int x, y; };
 __device__ __forceinline__ void ld_pair(const int32_t* p, int& a, int& b) { const Pair32 v = *reinterpret_cast<const Pair32*>(p); a = v.x; b = v.y; }
@@ -1214,7 +1221,7 @@ __global__ __launch_bounds__(NTMAX) void wfa_base2_kernel(const uint32_t* __rest
       if (lane == 63) { int* e = s_edge[par][wv][0]; e[0] = Mh[C - 1][cl][1]; e[1] = Mh[C - 1][cl][4]; e[2] = I1h[C - 1][E1 - 1]; e[3] = I2h[C - 1]; }
       if (lane == 0)  { int* e = s_edge[par][wv][1]; e[0] = Mh[0][cl][1];     e[1] = Mh[0][cl][4];     e[2] = D1h[0][E1 - 1];     e[3] = D2h[0]; }
     }
-    __syncthreads();  // the previous step's end checks and row range are visible; the edges of this one are published
+    lds_barrier();  // the previous step's end checks and row range are visible; the edges of this one are published (the rows of pre / bt are read after the loop's end)
     done = J.endsfree ? (s_endk != INT32_MAX) : (s_done != 0);
     if (done) break;
     if (sn > J.smax) { status = WFM_DEV_OVERFLOW; break; }
@@ -1471,7 +1478,7 @@ __global__ __launch_bounds__(NTMAX) void wfa_base2t_kernel(const uint32_t* __res
     const int par = sn & 1;
     if (lane == 63) { int* e = s_edge[par][wv][0]; e[0] = Mh[C - 1][cl][1]; e[1] = Mh[C - 1][cl][4]; e[2] = I1h[C - 1][E1 - 1]; e[3] = I2h[C - 1]; }
     if (lane == 0)  { int* e = s_edge[par][wv][1]; e[0] = Mh[0][cl][1];     e[1] = Mh[0][cl][4];     e[2] = D1h[0][E1 - 1];     e[3] = D2h[0]; }
-    __syncthreads();
+    lds_barrier();
     done = J.endsfree ? (s_endk != INT32_MAX) : (s_done != 0);
     if (done || sn > s_stop) break;
     s = sn;
