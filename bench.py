@@ -46,7 +46,7 @@ if ROOT not in sys.path:
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)  # (the first passes of a process still size arenas and ramp clocks: one warm-up pass left 4 - 6 % in the first process of a box)
     ap.add_argument("--config", default="C3", choices=["C3", "C5", "C4"],
                     help="C3 / C5: synthetic pairs, WFA-only.  C4 (strong scaling by nature): a synthetic pangenome of eight haplotypes (--c4-mbp each) "

@@ -345,6 +345,13 @@ int64_t wfm_finish_records(wfm_handle_t* h, const wfm_minmer_t* raw, int64_t n, 
  * sketch_size smallest canonical k-mer hashes, duplicates included, ascending.  Returns how many
  * were written (< sketch_size for short or N-rich sequences) or a WFM_E_* code. */
 int64_t wfm_minhash_sketch(wfm_handle_t* h, const char* seq, int64_t len, int k, int sketch_size, uint64_t* out);
+/* Between wfm_map_sequence_cache(h, 1) and wfm_map_sequence_cache(h, 0) the normalised device copy of every sequence of a megabase and more that
+ * wfm_minhash_sketch / wfm_sketch_fragments / wfm_hash_kmers upload stays on its device (WFM_NORM_CACHE_GB, 16, at most per process), and a later
+ * call of those or of wfm_index_build_sequences with the same host pointer, length and first / last 32 bytes uses it instead of uploading and
+ * normalising again -- the identity estimate and the index of one map call read the same chromosomes (mashmap's main.cpp:72-128 then
+ * computeMap.hpp:405-484: two passes over the files there too).  The caller keeps the host memory alive and unchanged while the scope is open;
+ * scopes nest, the last close releases the copies.  wfmh_map_paf opens one around its whole call. */
+int wfm_map_sequence_cache(wfm_handle_t* h, int open);
 
 /* L1 stage: getSeedIntervalPoints + computeL1CandidateRegions + doL1Mapping's group loop
  * (mappingCore.hpp:82-301, computeMap.hpp:945-984) for a batch of query fragments against a

@@ -29,7 +29,7 @@ EXPORTS = [
     "wfm_map_l1", "wfm_map_l2", "wfm_map_fragments", "wfm_minhash_sketch", "wfm_add_minmers_multi",
     "wfm_prefilter_kmers", "wfm_index_build_sequences", "wfm_index_upload",
     "wfm_index_replicate", "wfm_device_count", "wfm_finish_records",
-    "wfm_align_batch_rle", "wfm_align_resident_rle", "wfm_free_runs", "wfm_score_bounds", "wfm_get_busy_intervals", "wfm_trim_device_cache", "wfm_map_fragments_ordered", "wfm_selftest_dpp", "wfm_selftest_arena_growth", "wfm_set_concurrent_calls", "wfm_get_problem_flags",
+    "wfm_align_batch_rle", "wfm_align_resident_rle", "wfm_free_runs", "wfm_score_bounds", "wfm_get_busy_intervals", "wfm_trim_device_cache", "wfm_map_fragments_ordered", "wfm_map_sequence_cache", "wfm_selftest_dpp", "wfm_selftest_arena_growth", "wfm_set_concurrent_calls", "wfm_get_problem_flags",
 ]
 
 

@@ -16,6 +16,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>  // rocprim's texture iterator calls host memset
+#include <algorithm>
+#include <mutex>
 
 #include <rocprim/rocprim.hpp>
 
@@ -444,19 +446,82 @@ struct Scoped {
   }
 };
 
-// uploads seq and returns a normalised, 64-byte padded device copy
+// ---- normalised sequences that stay on the device for the length of a map call (wfm_map_sequence_cache) ----
+// A map call uploads a target chromosome twice -- once for the sketch of the identity estimate, once for the index -- and a query three times
+// (sketch, index when it is a target too, fragments): 5 ms of PCIe and 1.8 ms of normalize_kernel per 249 Mbp each time, 54 of a full-size C4
+// rank's 281 ms of index build.  Between wfm_map_sequence_cache(h, 1) and (h, 0) the normalised copy a call makes is kept (up to
+// WFM_NORM_CACHE_GB, 16 by default, per process) and found again by the host pointer, the length and the sequence's first and last 32 bytes;
+// a consumer's stream waits for the event recorded behind the producer's normalize_kernel.  The host side opens the scope where the files are
+// opened and closes it before they are let go (host/capi_map.cpp): a pointer cannot come to mean another sequence in between.
+struct NormEntry { int device; const char* seq; int64_t len; unsigned char fp[64]; uint8_t* d_norm; hipEvent_t ready; };
+struct NormCache {
+  std::mutex mu;
+  int scopes = 0;
+  size_t bytes = 0;
+  std::vector<NormEntry> entries;
+};
+NormCache& norm_cache() { static NormCache* c = new NormCache; return *c; }
+void norm_fingerprint(const char* seq, int64_t len, unsigned char* fp) {
+  std::memset(fp, 0, 64);
+  const int64_t a = std::min<int64_t>(32, len);
+  std::memcpy(fp, seq, (size_t)a);
+  std::memcpy(fp + 32, seq + len - a, (size_t)a);
+}
+const uint8_t* norm_cache_find(int device, const char* seq, int64_t len, hipStream_t consumer) {
+  NormCache& c = norm_cache();
+  std::lock_guard<std::mutex> lk(c.mu);
+  if (!c.scopes || c.entries.empty()) return nullptr;
+  unsigned char fp[64];
+  bool have_fp = false;
+  for (const NormEntry& e : c.entries) {
+    if (e.device != device || e.seq != seq || e.len != len) continue;
+    if (!have_fp) { norm_fingerprint(seq, len, fp); have_fp = true; }
+    if (std::memcmp(fp, e.fp, 64) != 0) continue;
+    if (e.ready && hipStreamWaitEvent(consumer, e.ready, 0) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return e.d_norm;
+  }
+  return nullptr;
+}
+// the scope is open and the budget has room for another `bytes`
+bool norm_cache_wants(size_t bytes) {
+  static const size_t budget = (size_t)(getenv("WFM_NORM_CACHE_GB") ? std::max(0, atoi(getenv("WFM_NORM_CACHE_GB"))) : 16) << 30;
+  NormCache& c = norm_cache();
+  std::lock_guard<std::mutex> lk(c.mu);
+  return c.scopes > 0 && c.bytes + bytes <= budget;
+}
+void norm_cache_add(int device, const char* seq, int64_t len, uint8_t* d_norm, hipStream_t producer) {
+  NormEntry e;
+  e.device = device; e.seq = seq; e.len = len; e.d_norm = d_norm; e.ready = nullptr;
+  norm_fingerprint(seq, len, e.fp);
+  if (hipEventCreateWithFlags(&e.ready, hipEventDisableTiming) != hipSuccess || hipEventRecord(e.ready, producer) != hipSuccess) {
+    (void)hipGetLastError();
+    if (e.ready) { (void)hipEventDestroy(e.ready); e.ready = nullptr; }
+    (void)hipStreamSynchronize(producer);  // no event: the copy is complete before anybody can find it
+  }
+  NormCache& c = norm_cache();
+  std::lock_guard<std::mutex> lk(c.mu);
+  c.bytes += (size_t)len + 64;
+  c.entries.push_back(e);
+}
+
+// uploads seq and returns a normalised, 64-byte padded device copy (or the copy an earlier call of this map call has left on the device)
 int upload_normalised(wfm_handle_t* h, Scoped& sc, const char* seq, int64_t len, uint8_t** d_norm) {
   uint8_t* d_raw = nullptr;
   const size_t padded = (size_t)len + 64;
-  HIPCHK(h, sc.alloc(&d_raw, padded));
-  HIPCHK(h, sc.alloc(d_norm, padded));
   hipStream_t st = wfm_stream(h);
+  if (const uint8_t* kept = norm_cache_find(wfm_device(h), seq, len, st)) { *d_norm = const_cast<uint8_t*>(kept); return WFM_OK; }
+  HIPCHK(h, sc.alloc(&d_raw, padded));
+  const bool keep = len >= ((int64_t)1 << 20) && norm_cache_wants(padded);  // (short sequences: the copy is not what their calls cost)
+  if (keep) HIPCHK(h, wfm_dmalloc((void**)d_norm, padded));
+  else HIPCHK(h, sc.alloc(d_norm, padded));
+  struct Kept { uint8_t* p; ~Kept() { if (p) wfm_dfree(p); } } kept_guard{keep ? *d_norm : nullptr};  // (an error below: nobody else has the block yet)
   HIPCHK(h, hipMemsetAsync(*d_norm + len, 'N', padded - (size_t)len, st));  // (only the padding: normalize_kernel writes every base)
   HIPCHK(h, hipMemcpyAsync(d_raw, seq, (size_t)len, hipMemcpyHostToDevice, st));
   const int64_t nthreads = (len + 15) / 16;
   const int blocks = (int)((nthreads + 255) / 256);
   if (blocks > 0) hipLaunchKernelGGL(normalize_kernel, dim3(blocks), dim3(256), 0, st, d_raw, *d_norm, len);
   HIPCHK(h, hipGetLastError());
+  if (keep) { norm_cache_add(wfm_device(h), seq, len, *d_norm, st); kept_guard.p = nullptr; }
   return WFM_OK;
 }
 }  // namespace
@@ -587,14 +652,19 @@ int map_hash_sequence_into(wfm_handle_t* h, MapHashWork* wk, const char* seq, in
     }
     wk->cap = cap;
   }
-  HIPCHK(h, hipMemsetAsync(wk->d_norm + len, 'N', 64, st));  // the hash kernel reads whole words past the end
-  HIPCHK(h, hipMemcpyAsync(wk->d_raw, seq, (size_t)len, hipMemcpyHostToDevice, st));
-  const int64_t nthreads = (len + 15) / 16;
-  hipLaunchKernelGGL(normalize_kernel, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, st, wk->d_raw, wk->d_norm, len);
-  launch_kmer_hash(wk->d_norm, out->nk, k, wk->d_hash, wk->d_strand, st);
+  // (the normalised copy the identity estimate's sketch left on the device, if this map call keeps them: no upload, no normalize_kernel)
+  const uint8_t* d_norm = norm_cache_find(wfm_device(h), seq, len, st);
+  if (!d_norm) {
+    HIPCHK(h, hipMemsetAsync(wk->d_norm + len, 'N', 64, st));  // the hash kernel reads whole words past the end
+    HIPCHK(h, hipMemcpyAsync(wk->d_raw, seq, (size_t)len, hipMemcpyHostToDevice, st));
+    const int64_t nthreads = (len + 15) / 16;
+    hipLaunchKernelGGL(normalize_kernel, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, st, wk->d_raw, wk->d_norm, len);
+    d_norm = wk->d_norm;
+  }
+  launch_kmer_hash(d_norm, out->nk, k, wk->d_hash, wk->d_strand, st);
   HIPCHK(h, hipGetLastError());
   HIPCHK(h, hipStreamSynchronize(st));
-  out->d_norm = wk->d_norm; out->d_hash = wk->d_hash; out->d_strand = wk->d_strand;
+  out->d_norm = const_cast<uint8_t*>(d_norm); out->d_hash = wk->d_hash; out->d_strand = wk->d_strand;
   return WFM_OK;
 }
 
@@ -709,6 +779,24 @@ int wfm_hash_kmers_norm(wfm_handle_t* h, const char* seq, int64_t len, int k, ui
 }
 
 extern "C" {
+
+int wfm_map_sequence_cache(wfm_handle_t* h, int open) {
+  if (!h) return WFM_E_ARG;
+  NormCache& c = norm_cache();
+  std::vector<NormEntry> gone;
+  {
+    std::lock_guard<std::mutex> lk(c.mu);
+    if (open) { ++c.scopes; return WFM_OK; }
+    if (c.scopes > 0 && --c.scopes == 0) { gone.swap(c.entries); c.bytes = 0; }
+  }
+  for (NormEntry& e : gone) {  // (wfm_dfree waits for the device: no kernel still reads the block)
+    (void)hipSetDevice(e.device);
+    if (e.ready) (void)hipEventDestroy(e.ready);
+    wfm_dfree(e.d_norm);
+  }
+  if (!gone.empty()) (void)hipSetDevice(wfm_device(h));
+  return WFM_OK;
+}
 
 int wfm_hash_kmers(wfm_handle_t* h, const char* seq, int64_t len, int k, uint64_t* hash, int8_t* strand) {
   return wfm_hash_kmers_norm(h, seq, len, k, hash, strand, nullptr);

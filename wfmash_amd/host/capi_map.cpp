@@ -148,6 +148,13 @@ int wfmh_map_multi(wfm_handle_t* const* handles, int n, const char* target_fasta
       ms_opened = ms_since(t_open);
       const auto t_call = std::chrono::steady_clock::now();
       double ms_identity = 0;
+      // the normalised device copies of the chromosomes stay from the identity estimate's sketches to the index build and the queries' fragments
+      // (wfm_map_sequence_cache); the scope ends before the files are let go
+      struct SeqCacheScope {
+        wfm_handle_t* h;
+        explicit SeqCacheScope(wfm_handle_t* hh) : h(hh) { (void)wfm_map_sequence_cache(h, 1); }
+        ~SeqCacheScope() { (void)wfm_map_sequence_cache(h, 0); }
+      } seq_cache_scope(handles[0]);
       if (p.auto_pct_identity) {
         // main.cpp:72-128: estimate, then derive the sketch size from the estimate unless -s was given
         std::vector<std::string> target_prefix_vec;
