@@ -59,6 +59,52 @@ def test_minhash_sketch_of_a_long_sequence_selects_before_it_sorts(gpu):
         assert len(got) == n and (got == np.sort(h)[:n]).all()
 
 
+def test_sequence_cache_serves_the_same_buffer_and_only_that(gpu):
+    """wfm_map_sequence_cache: inside a scope the normalised device copy of a sequence of a megabase and more is kept and found again by pointer,
+    length and first / last bytes -- the second sketch and the k-mer hashes of the same buffer come from it and equal the uncached ones; the same
+    memory with other contents (its first bases rewritten) is a different sequence; a change the fingerprint cannot see is the caller's contract
+    (the scope's host memory does not change) and is NOT noticed; after the scope everything is uploaded again."""
+    import ctypes as C
+    rng = np.random.default_rng(5)
+    arr = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, 2_000_000)].copy()
+    L = capi.load()
+    L.wfm_map_sequence_cache.restype = C.c_int
+    L.wfm_map_sequence_cache.argtypes = [C.c_void_p, C.c_int]
+
+    def sketch(a, n=2048):
+        out = np.zeros(n, dtype=np.uint64)
+        f = L.wfm_minhash_sketch
+        f.restype = C.c_int64
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p]
+        m = f(gpu._p, a.ctypes.data, len(a), 21, n, out.ctypes.data)
+        assert m == n
+        return out
+
+    plain = sketch(arr)
+    assert L.wfm_map_sequence_cache(gpu._p, 1) == 0
+    try:
+        first = sketch(arr)      # uploads, keeps
+        second = sketch(arr)     # from the kept copy
+        assert (first == plain).all() and (second == plain).all()
+        h1, _ = gpu.hash_kmers(bytes(arr[:0]) + arr.tobytes(), 21)  # another buffer with the same contents: its own upload
+        saved = arr[:40].copy()
+        arr[:40] = np.frombuffer(b"T" * 40, dtype=np.uint8)
+        changed = sketch(arr)    # same pointer and length, other first bytes: not the kept copy
+        want = np.sort(gpu.hash_kmers(arr.tobytes(), 21)[0])[:2048]
+        assert (changed == want).all() and not (changed == plain).all()
+        arr[:40] = saved
+        mid = arr[1_000_000:1_000_040].copy()
+        arr[1_000_000:1_000_040] = np.frombuffer(b"G" * 40, dtype=np.uint8)
+        stale = sketch(arr)      # the fingerprint does not see the middle: the kept copy answers (the caller's contract)
+        assert (stale == plain).all()
+        arr[1_000_000:1_000_040] = mid
+    finally:
+        assert L.wfm_map_sequence_cache(gpu._p, 0) == 0
+    arr[1_000_000:1_000_040] = np.frombuffer(b"G" * 40, dtype=np.uint8)
+    after = sketch(arr)          # no scope: uploaded again
+    assert (after == np.sort(gpu.hash_kmers(arr.tobytes(), 21)[0])[:2048]).all()
+
+
 def test_auto_identity_drives_threshold_and_sketch_size(gpu, tmp_path):
     seqs = _pangenome(51)
     fa = str(tmp_path / "pan.fa")
