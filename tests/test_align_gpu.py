@@ -224,6 +224,42 @@ def test_wide_patches_on_tiles_match_oracle(gpu, oracle):
     assert all(a.ops == b.ops and a.score == b.score for a, b in zip(res, res0))
 
 
+def test_every_leaf_on_tiles_matches_oracle(gpu, oracle):
+    """WFM_BASE_TILES=2 sends every leaf and patch with rows beyond 128 diagonals through wfa_base2t_kernel -- the leaves of BiWFA's recursion with
+    their begin / end components (a child that begins or ends inside a gap), retried leaves, head and tail patches of all widths, mostly one tile
+    per job: the mixed batch of the ends-free test and a batch of bialign problems with long gaps, identical to the oracle."""
+    import os
+    rng = random.Random(16)
+    items, exp = [], []
+    for i in range(60):
+        p = synth.random_dna(1700 + i, rng.choice([60, 130, 400, 1500]))
+        t = synth.mutate(p, rng.choice([0.0, 0.05, 0.2, 0.5]), 1800 + i) or b"A"
+        if rng.random() < 0.4:
+            t = synth.random_dna(170 + i, rng.randrange(1, 60)) + t
+        for args in ((len(p), 0, len(t), 0), (0, len(p), 0, len(t))):
+            items.append((p, t, capi.WFM_MODE_ENDSFREE, args[0], args[1], args[2], args[3]))
+            exp.append(oracle.align_endsfree(p, args[0], args[1], t, args[2], args[3])[1])
+    pairs = _pairs(9, 40, [300, 1200, 5000], [0.02, 0.1, 0.3])
+    for i in range(12):  # long gaps: children that begin / end inside a gap
+        a = synth.random_dna(2600 + i, rng.choice([1500, 4000]))
+        cut = rng.randrange(200, len(a) - 200)
+        gap = synth.random_dna(2700 + i, rng.choice([30, 300, 900]))
+        b = synth.mutate(a[:cut], 0.03, 2800 + i) + gap + synth.mutate(a[cut:], 0.03, 2900 + i)
+        pairs.append((a, b) if i % 2 else (b, a))
+    for p, t in pairs:
+        items.append((p, t))
+        exp.append(oracle.align_biwfa(p, t)[1])
+    os.environ["WFM_BASE_TILES"] = "2"
+    try:
+        res = gpu.align(items)
+        fl = gpu.problem_flags(len(items))
+    finally:
+        del os.environ["WFM_BASE_TILES"]
+    assert sum(bool(f & capi.WFM_PF_BASE_TILES) for f in fl) >= len(items) // 3
+    bad = [i for i, (r, ops) in enumerate(zip(res, exp)) if r.status != 0 or r.ops != ops]
+    assert not bad, f"{len(bad)}/{len(items)} differ: {bad[:8]}"
+
+
 def test_uni_mode_matches_oracle(gpu, oracle):
     items = [(p, t, capi.WFM_MODE_END2END_UNI) for p, t in _pairs(8, 40, [50, 300, 1200], [0.02, 0.1, 0.3])]
     res = gpu.align(items)

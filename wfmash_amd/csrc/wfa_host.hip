@@ -324,6 +324,7 @@ int run_base_jobs(wfm_handle* h, wfm_seqset* S, const wfm_penalties_t& pen, std:
   // 5 = the register kernel's step on tiles (wfa_base2t_kernel): rows beyond 2048 diagonals of jobs the register kernel would take -- the third
   // attempt of a patch, whose score passed 1020
   const bool base_tiles = !(getenv("WFM_BASE_TILES") && atoi(getenv("WFM_BASE_TILES")) == 0);
+  const bool force_tiles = getenv("WFM_BASE_TILES") && atoi(getenv("WFM_BASE_TILES")) == 2;  // tests: every leaf and patch with rows beyond 128 diagonals
   // (sequences longer than the kernel's LDS windows are fine: what lies beyond is read from the global mirror.  Jobs without
   // any cell -- an empty pattern or text -- ride along with the first kind: they are one store each)
   const bool few_jobs = nodes.size() < 128;
@@ -333,7 +334,7 @@ int run_base_jobs(wfm_handle* h, wfm_seqset* S, const wfm_penalties_t& pen, std:
     if (base_v2 && w <= 2048 && (size_t)a.prob < S->acgt.size() && S->acgt[(size_t)a.prob])
       // (a handful of retries: more workgroups of fewer waves per job on the tiles of the register kernel, and ONE launch with the wider ones
       // instead of one per width class, each a few jobs and hundreds of score steps long)
-      return w <= 128 ? 0 : (base_tiles && few_jobs && (a.tries > 0 || w > 640) ? 5 : (w <= 640 ? 1 : 2));
+      return w <= 128 ? 0 : (base_tiles && (force_tiles || (few_jobs && (a.tries > 0 || w > 640))) ? 5 : (w <= 640 ? 1 : 2));
     if (base_v2 && base_tiles && (size_t)a.prob < S->acgt.size() && S->acgt[(size_t)a.prob]) return 5;
     return w > wide_from ? 4 : 3;
   };
