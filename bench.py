@@ -506,6 +506,9 @@ def _roofline(acc, excl, seq_bytes, args):
                                           "everything outside this key is measured live with HIP events"},
             "frac_exclusive": e_achieved / peak, "achieved_exclusive": e_achieved,
             "avg_launch_ms_exclusive": e_ms / max(e_launches, 1), "launches_exclusive_per_step": e_launches / max(excl.passes, 1),
+            # (a "launch" here is one BLOCK of 100 scores: the events stand around the one or two instantiations of the tile kernel a block launches -- with
+            # and without per-score maxima.  rocprofv3 lists the instantiations apart: their total times summed / the passes of the profiled process is this figure)
+            "tile_kernel_ms_exclusive_per_pass": e_ms / max(excl.passes, 1),
             "algorithmic_bytes_per_launch_exclusive": e_alg / max(e_launches, 1),
             "algorithmic_bytes_per_launch": alg / max(launches, 1), "cells_per_launch": cells / max(launches, 1),
             "cells_computed_per_launch": cells_all / max(launches, 1),

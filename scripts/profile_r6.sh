@@ -20,6 +20,20 @@ WFM_OVERLAP=0 rocprofv3 --pmc SQ_BUSY_CU_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST
 cd "$root"
 T=$(find /tmp/p6/t -name "*results.db" | head -1); F=$(find /tmp/p6/f -name "*results.db" | head -1); W=$(find /tmp/p6/w -name "*results.db" | head -1); S=$(find /tmp/p6/s -name "*results.db" | head -1); S2=$(find /tmp/p6/s2 -name "*results.db" | head -1)
 python scripts/prof_summary.py "$po/r6_align_excl.md" "r6: C3, WFM_OVERLAP=0 (one stream, launches one after the other): the per-launch figures bench.py reports as roofline.frac" "$T" "$F" "$W" "$S" --bench /tmp/p6_trace.log > /dev/null
+python - "$T" "$po/r6_align_excl.md" <<'PY'
+# how the table above and bench.py's live figures meet: bench.py times BLOCKS (its events stand around the one or two instantiations of the tile kernel a
+# block launches), rocprofv3 lists the instantiations apart
+import sqlite3, sys
+t, out = sys.argv[1:3]
+rows = sqlite3.connect(t).execute("select name, count(*), sum(end-start)/1e6 from kernels where name like '%wfa_tile2_kernel<1024, false, true,%' group by name").fetchall()
+passes = 6  # --warmup 1 --steps 3 + bench.py's two untimed WFM_OVERLAP=0 passes
+tot = sum(r[2] for r in rows)
+with open(out, "a") as f:
+    f.write("\n## how this meets bench.py's `roofline`\n\n")
+    f.write("The profiled process runs %d passes of the batch (warm-up 1, steps 3, and the two untimed passes bench.py itself runs with `WFM_OVERLAP=0`); all of them are one chain of launches here.\n" % passes)
+    f.write("The tile kernel's two phase-1 instantiations (with and without per-score maxima) together: %d launches, %.1f ms = **%.2f ms per pass** -- bench.py's `roofline.tile_kernel_ms_exclusive_per_pass`, which it reports as\n" % (sum(r[1] for r in rows), tot, tot / passes))
+    f.write("`launches_exclusive_per_step` BLOCKS x `avg_launch_ms_exclusive` (its events stand around the one or two instantiations a block of 100 scores launches).\n")
+PY
 python - "$T" "$F" "$W" "$po/r6_traffic.json" <<'PY'
 import json, sqlite3, sys
 t, f, w, out = sys.argv[1:5]
