@@ -561,7 +561,9 @@ def _align_fields(al, t_al):
     return {"align_s": t_al, "records": int(al.records), "aligned_bp": int(al.aligned_bp), "aligned_bp_per_s": al.aligned_bp / t_al,
             "cells": int(al.cells), "ms_gpu": al.ms_gpu, "gpu_share_of_align": al.ms_gpu * 1e-3 / t_al,
             "algorithmic_frac_gpu": 48.0 * al.cells / (al.ms_gpu * 1e-3) / 8e12 if al.ms_gpu else None,
-            "batches": int(al.batches), "host_ms_summed_over_batches": {"rows": al.ms_rows, "fetch": al.ms_fetch, "wflign_incl_device_calls": al.ms_wflign, "text": al.ms_text}}
+            "batches": int(al.batches), "host_ms_summed_over_batches": {"rows": al.ms_rows, "fetch": al.ms_fetch, "wflign_incl_device_calls": al.ms_wflign, "text": al.ms_text,
+                                                                      # (the records' tags the parity sample is drawn from are written inside the timed call: this is what it cost)
+                                                                      "record_tags": al.ms_tags}}
 
 
 def _sampled_cigar_identity(fa_seqs, map_lines, aln_path, n_sample, tags_path=None, **oracle_kw):

@@ -56,6 +56,7 @@ typedef struct {
   uint64_t cells_tile;
   uint64_t tile_launches;
   double   ms_tile;
+  double   ms_tags;      /* WFM_RECORD_TAGS (a diagnostic channel of the parity tests and bench.py): writing the records' tags, summed over the batches */
 } wfmh_align_summary_t;
 
 void wfmh_align_default_params(wfmh_align_params_t* p);

@@ -771,7 +771,7 @@ class AlignSummary(C.Structure):
     _fields_ = [("records", C.c_uint64), ("aligned_bp", C.c_uint64), ("written", C.c_uint64),
                 ("skipped", C.c_uint64), ("cells", C.c_uint64), ("ms_gpu", C.c_double), ("ms_total", C.c_double),
                 ("ms_rows", C.c_double), ("ms_fetch", C.c_double), ("ms_wflign", C.c_double), ("ms_text", C.c_double), ("batches", C.c_uint64),
-                ("cells_tile", C.c_uint64), ("tile_launches", C.c_uint64), ("ms_tile", C.c_double)]
+                ("cells_tile", C.c_uint64), ("tile_launches", C.c_uint64), ("ms_tile", C.c_double), ("ms_tags", C.c_double)]
 
 
 def _host():

@@ -1630,7 +1630,13 @@ void wfm_destroy(wfm_handle_t* h) {
   // the last handle of the process: the sequence stores a map call left open for the call after it (host/fasta.cpp, keep_until_next: up to
   // 32 GB of host memory) are let go.  The device block cache stays -- a process that creates and destroys handles in turn (the test-suite)
   // would pay every block's first hipMalloc again -- and goes back to the driver with wfm_trim_device_cache(), see INTEGRATION.md.
-  if (last_of_process && g_last_handle_hook) g_last_handle_hook();
+  if (last_of_process && g_last_handle_hook) {
+    // (counted again under the lock, and the hook runs under it: a wfm_create on another thread in between keeps the stores its map call is about to ask for)
+    std::lock_guard<std::mutex> lk(g_base_mu);
+    bool still_last = true;
+    for (int d = 0; d < 64; ++d) still_last &= g_dev_handles[d] == 0;
+    if (still_last) g_last_handle_hook();
+  }
 }
 
 const char* wfm_last_error(const wfm_handle_t* h) { return h ? h->err.c_str() : "null handle"; }

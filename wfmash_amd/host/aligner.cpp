@@ -266,9 +266,11 @@ std::string Aligner::align_batch(wfm_handle_t* gpu_handle, std::vector<std::stri
   sum.cells_tile += st.cells_tile; sum.tile_launches += st.tile_launches; sum.ms_tile += st.ms_tile;
   sum.busy.insert(sum.busy.end(), st.busy.begin(), st.busy.end());
   if (getenv("WFM_RECORD_TAGS")) {
+    const auto tt = std::chrono::steady_clock::now();
     std::vector<uint64_t> rn(fetched.size());
     for (size_t k = 0; k < fetched.size(); ++k) rn[k] = fetched[k].row_no;
     write_record_tags(rn, recs);
+    sum.ms_tags += since(tt);
   }
   const double ms_biwfa = since(tb2);
   const auto tb3 = std::chrono::steady_clock::now();
@@ -498,7 +500,7 @@ Summary Aligner::compute() {
       const Summary& p = part[wk];
       sum.records += p.records; sum.aligned_bp += p.aligned_bp; sum.written += p.written; sum.skipped += p.skipped;
       sum.cells += p.cells;
-      sum.cells_tile += p.cells_tile; sum.tile_launches += p.tile_launches; sum.ms_tile += p.ms_tile;
+      sum.cells_tile += p.cells_tile; sum.tile_launches += p.tile_launches; sum.ms_tile += p.ms_tile; sum.ms_tags += p.ms_tags;
       sum.ms_rows += p.ms_rows; sum.ms_fetch += p.ms_fetch; sum.ms_wflign += p.ms_wflign; sum.ms_text += p.ms_text; sum.batches += p.batches;
       iv[wk % ngpu].insert(iv[wk % ngpu].end(), p.busy.begin(), p.busy.end());
     }

@@ -67,6 +67,7 @@ struct Summary {
   double ms_tile = 0;
   double ms_gpu = 0, ms_total = 0;
   double ms_rows = 0, ms_fetch = 0, ms_wflign = 0, ms_text = 0;  // host stages, summed over the batches
+  double ms_tags = 0;  // WFM_RECORD_TAGS (a diagnostic): writing the records' tags, lock wait included, summed over the batches
   uint64_t batches = 0;
   std::vector<std::pair<double, double>> busy;  // a worker's device-busy intervals (merged per device at the end of compute())
 };

@@ -83,6 +83,7 @@ int wfmh_align_paf_multi(wfm_handle_t* const* handles, int n, const char* target
       summary->ms_rows = s.ms_rows; summary->ms_fetch = s.ms_fetch; summary->ms_wflign = s.ms_wflign; summary->ms_text = s.ms_text;
       summary->batches = s.batches;
       summary->cells_tile = s.cells_tile; summary->tile_launches = s.tile_launches; summary->ms_tile = s.ms_tile;
+      summary->ms_tags = s.ms_tags;
     }
     return WFM_OK;
   } catch (const std::exception& e) {

@@ -453,8 +453,9 @@ void release_later(std::vector<std::shared_ptr<FastaStore>> files) {
 }
 
 namespace {
-std::mutex g_kept_mu;
-std::vector<std::shared_ptr<FastaStore>> g_kept;
+// (heap singletons that are never destroyed: a handle that goes during static teardown -- an interpreter's exit -- still calls release_kept)
+std::mutex& g_kept_mu = *new std::mutex;
+std::vector<std::shared_ptr<FastaStore>>& g_kept = *new std::vector<std::shared_ptr<FastaStore>>;
 }  // namespace
 
 void keep_until_next(std::vector<std::shared_ptr<FastaStore>> files) {
