@@ -1137,7 +1137,7 @@ __global__ __launch_bounds__(NTMAX) void wfa_base2_kernel(const uint32_t* __rest
   int Mh[C][NCL][DEP];
   int I1h[C][E1], D1h[C][E1], I2h[C], D2h[C];
   unsigned hmaxu[C];
-  int cP[C], mcur[C];
+  int cP[C], mcur[C], wlim[C];
   bool colok[C];
 #pragma unroll
   for (int c = 0; c < C; ++c) {
@@ -1152,6 +1152,7 @@ __global__ __launch_bounds__(NTMAX) void wfa_base2_kernel(const uint32_t* __rest
     colok[c] = k >= -pl && k <= tl && k <= kmax;
     hmaxu[c] = colok[c] ? (unsigned)min(tl, pl + k) : 0u;
     cP[c] = dP - k;
+    wlim[c] = PK_WIN_BASES - 1 - max(cP[c], dT);
     mcur[c] = WF_NULL;
   }
   auto end_checks = [&](int c, int k, int m_ext, int ins1, int ins2, int del1, int del2) {
@@ -1287,11 +1288,15 @@ __global__ __launch_bounds__(NTMAX) void wfa_base2_kernel(const uint32_t* __rest
     for (int c = 0; c < C; ++c) {
       const int m = nM[c];
       oP[c] = (unsigned)(m + cP[c]); oT[c] = (unsigned)(m + dT);
-      maxn[c] = m >= 0 ? (int)hmaxu[c] - m : 0;
+      maxn[c] = (int)hmaxu[c] - m;  // (a cell that holds nothing: whatever -- pk_extend2_fast looks at m first)
     }
-    pk_extend2(SRC, nM, oP, oT, maxn, ext);
+    // (round 6: the tile kernel's lean form of the staged extension -- masks kept as masks, the rare stages out of line -- and the end tests only
+    // where a cell has reached the far edge of its diagonal, h = tl or v = pl <=> its offset is hmaxu: the step's common path went from the better
+    // part of 940 instructions to 357)
+    pk_extend2_fast(SRC, nM, oP, oT, maxn, wlim, ext, false);
     int32_t* pre = pre_base + (int64_t)s * width;
     uint8_t* bt = bt_base + (int64_t)s * width;
+    bool reached = false;
 #pragma unroll
     for (int c = 0; c < C; ++c) {
       const int k = k0 + c;
@@ -1302,8 +1307,18 @@ __global__ __launch_bounds__(NTMAX) void wfa_base2_kernel(const uint32_t* __rest
         int m = nM[c];
         if (m >= 0) m += ext[c];
         nM[c] = m;
-        end_checks(c, k, m, nI1[c], nI2[c], nD1[c], nD2[c]);
+        reached |= !J.endsfree || m >= (int)hmaxu[c];
       }
+    }
+    if (__builtin_expect(__any(reached), 0)) {
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        const int k = k0 + c;
+        if (valid && k >= lo && k <= hi) end_checks(c, k, nM[c], nI1[c], nI2[c], nD1[c], nD2[c]);
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
       mcur[c] = nM[c];
 #pragma unroll
       for (int e = DEP - 1; e > 0; --e) Mh[c][cl][e] = Mh[c][cl][e - 1];
@@ -1381,7 +1396,7 @@ __global__ __launch_bounds__(NTMAX) void wfa_base2t_kernel(const uint32_t* __res
   int Mh[C][NCL][DEP];
   int I1h[C][E1], D1h[C][E1], I2h[C], D2h[C];
   unsigned hmaxu[C];
-  int cP[C], mcur[C];
+  int cP[C], mcur[C], wlim[C];
   bool colok[C], incore[C];
 #pragma unroll
   for (int c = 0; c < C; ++c) {
@@ -1397,6 +1412,7 @@ __global__ __launch_bounds__(NTMAX) void wfa_base2t_kernel(const uint32_t* __res
     incore[c] = k >= core_lo && k <= core_hi;
     hmaxu[c] = colok[c] ? (unsigned)min(tl, pl + k) : 0u;
     cP[c] = dP - k;
+    wlim[c] = PK_WIN_BASES - 1 - max(cP[c], dT);
     mcur[c] = WF_NULL;
   }
   auto end_checks = [&](int k, int m_ext, int ins1, int ins2, int del1, int del2) {
@@ -1530,11 +1546,13 @@ __global__ __launch_bounds__(NTMAX) void wfa_base2t_kernel(const uint32_t* __res
     for (int c = 0; c < C; ++c) {
       const int m = nM[c];
       oP[c] = (unsigned)(m + cP[c]); oT[c] = (unsigned)(m + dT);
-      maxn[c] = m >= 0 ? (int)hmaxu[c] - m : 0;
+      maxn[c] = (int)hmaxu[c] - m;  // (a cell that holds nothing: whatever -- pk_extend2_fast looks at m first)
     }
-    pk_extend2(SRC, nM, oP, oT, maxn, ext);
+    pk_extend2_fast(SRC, nM, oP, oT, maxn, wlim, ext, false);
     int32_t* pre = pre_base + (int64_t)s * width;
     uint8_t* bt = bt_base + (int64_t)s * width;
+    // (wfa_base2_kernel's step: the lean extension, the end tests only where a cell has reached the far edge of its diagonal)
+    bool reached = false;
 #pragma unroll
     for (int c = 0; c < C; ++c) {
       const int k = k0 + c;
@@ -1546,9 +1564,19 @@ __global__ __launch_bounds__(NTMAX) void wfa_base2t_kernel(const uint32_t* __res
         if (incore[c]) {
           pre[k] = preM[c];
           bt[k] = (uint8_t)btb[c];
-          end_checks(k, m, nI1[c], nI2[c], nD1[c], nD2[c]);
+          reached |= !J.endsfree || m >= (int)hmaxu[c];
         }
       }
+    }
+    if (__builtin_expect(__any(reached), 0)) {
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        const int k = k0 + c;
+        if (k >= lo && k <= hi && incore[c]) end_checks(k, nM[c], nI1[c], nI2[c], nD1[c], nD2[c]);
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
       mcur[c] = nM[c];
 #pragma unroll
       for (int e = DEP - 1; e > 0; --e) Mh[c][cl][e] = Mh[c][cl][e - 1];
