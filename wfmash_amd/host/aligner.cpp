@@ -1,4 +1,5 @@
 #include "aligner.hpp"
+#include "parallel.hpp"
 #include "../csrc/wfa_handle.h"
 
 #include <algorithm>
@@ -216,10 +217,8 @@ std::string Aligner::align_batch(wfm_handle_t* gpu_handle, std::vector<std::stri
       }
     };
     const int nt = (int)std::min<size_t>((size_t)std::max(1, threads), rows.size());
-    std::vector<std::thread> pool;
-    for (int t = 1; t < nt; ++t) pool.emplace_back(work);
-    work();
-    for (auto& t : pool) t.join();
+    // (helpers from the process's pool, parallel.hpp: every one of them runs `work`, which shares the rows out by its own counter)
+    wfmash_host::parallel_for((size_t)nt, nt, [&](size_t) { work(); });
   }
   std::vector<Fetched> fetched;
   fetched.reserve(rows.size());

@@ -1,4 +1,5 @@
 #include "map_filter.hpp"
+#include "parallel.hpp"
 
 #include <cstring>
 #include <memory>
@@ -291,10 +292,7 @@ template <class F>
 void par_ranges(size_t n, F fn) {  // fn(lo, hi) over a partition of [0, n)
   const size_t T = n >= ((size_t)1 << 17) ? (size_t)std::min<int>(tl_filter_threads, par_cap()) : 1;
   if (T <= 1) { fn((size_t)0, n); return; }
-  std::vector<std::thread> pool;
-  for (size_t t = 1; t < T; ++t) pool.emplace_back(fn, n * t / T, n * (t + 1) / T);
-  fn((size_t)0, n / T);
-  for (auto& th : pool) th.join();
+  wfmash_host::parallel_for(T, (int)T, [&](size_t t) { fn(n * t / T, n * (t + 1) / T); });  // (the process's pool: parallel.hpp)
 }
 
 // the same partition with the part's number: fn(t, lo, hi); returns the number of parts
@@ -302,10 +300,7 @@ template <class F>
 size_t par_parts(size_t n, F fn) {
   const size_t T = n >= ((size_t)1 << 17) ? (size_t)std::max(1, std::min<int>(tl_filter_threads, par_cap())) : 1;
   if (T <= 1) { fn((size_t)0, (size_t)0, n); return 1; }
-  std::vector<std::thread> pool;
-  for (size_t t = 1; t < T; ++t) pool.emplace_back(fn, t, n * t / T, n * (t + 1) / T);
-  fn((size_t)0, (size_t)0, n / T);
-  for (auto& th : pool) th.join();
+  wfmash_host::parallel_for(T, (int)T, [&](size_t t) { fn(t, n * t / T, n * (t + 1) / T); });
   return T;
 }
 
@@ -501,10 +496,7 @@ std::vector<offset_t> chain_mappings(MappingResultsVector_t& readMappings, int m
       }
     };
     const size_t T = n >= ((size_t)1 << 17) ? std::min<size_t>((size_t)tl_filter_threads, runs.size()) : 1;
-    std::vector<std::thread> pool;
-    for (size_t t = 1; t < T; ++t) pool.emplace_back(work);
-    work();
-    for (auto& th : pool) th.join();
+    wfmash_host::parallel_for(T, (int)T, [&](size_t) { work(); });
   }
   tt[ti++] = tnow();
   ChainSets sets(n);

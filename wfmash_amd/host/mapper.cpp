@@ -1,4 +1,5 @@
 #include "mapper.hpp"
+#include "parallel.hpp"
 
 #include <algorithm>
 #include <atomic>
@@ -493,10 +494,7 @@ int Map::mapQuery(MapSummary* summary) {
               };
               {
                 const size_t T = nq >= ((size_t)1 << 17) ? (size_t)std::max(1, std::min(32, threads_each / std::max(1, nt_filter))) : 1;
-                std::vector<std::thread> pool;
-                for (size_t t = 1; t < T; ++t) pool.emplace_back(fill, nq * t / T, nq * (t + 1) / T);
-                fill(0, nq / T);
-                for (auto& th : pool) th.join();
+                wfmash_host::parallel_for(T, (int)T, [&](size_t t) { fill(nq * t / T, nq * (t + 1) / T); });  // (the process's pool: parallel.hpp)
               }
               const bool inside = inside_a.load();
               if (!inside) {
@@ -538,10 +536,7 @@ int Map::mapQuery(MapSummary* summary) {
         };
         {
           const int nt = (int)std::min<size_t>((size_t)threads_each, bq.size());
-          std::vector<std::thread> pool;
-          for (int t = 1; t < nt; ++t) pool.emplace_back(work);
-          work();
-          for (auto& t : pool) t.join();
+          wfmash_host::parallel_for((size_t)nt, nt, [&](size_t) { work(); });  // (work() shares the queries out by its own counter and sets its thread's filter threads itself)
         }
         if (error_rc.load() != WFM_OK) return;
         write_batch((uint64_t)seq, std::move(bo));

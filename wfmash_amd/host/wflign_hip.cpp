@@ -2,6 +2,7 @@
 // writer of the align path, restated from the reference's behaviour; all wavefront
 // arithmetic is done on the GPU through wfm_align_batch (no CPU fallback).
 #include "wflign_hip.hpp"
+#include "parallel.hpp"
 #include "../csrc/wfa_handle.h"
 
 #include <algorithm>
@@ -593,13 +594,7 @@ namespace {
 template <typename F>
 void for_each_record(size_t n, int threads, F&& fn) {
   const int nt = (int)std::min<size_t>((size_t)std::max(1, threads), (n + 7) / 8);  // no thread for fewer than 8 records
-  if (nt <= 1) { for (size_t i = 0; i < n; ++i) fn(i); return; }
-  std::atomic<size_t> next{0};
-  auto work = [&] { for (size_t i; (i = next.fetch_add(1)) < n;) fn(i); };
-  std::vector<std::thread> pool;
-  for (int t = 1; t < nt; ++t) pool.emplace_back(work);
-  work();
-  for (auto& t : pool) t.join();
+  wfmash_host::parallel_for(n, nt, fn);  // (the process's pool: a pass used to start and join its own threads, 2 - 4 ms each -- parallel.hpp)
 }
 
 // A handle runs one batch at a time; several host threads may feed the same GPU (the align driver keeps up to three
