@@ -83,6 +83,21 @@ def test_filter_input_order_fast_and_general_paths(fai):
             assert capi.host_filter("subset", arr, fai, "A#1#c1", P) == pyfilter.ref_filter("subset", arr, fai, "A#1#c1", P)
 
 
+def test_chain_representatives_in_closed_form_equal_the_disjoint_sets(fai, monkeypatch):
+    """chain_mappings names a chain by min(id of its first member, id of its second) and orders chains by a prefix sum where the first
+    order had no ties; WFM_FILTER_CLOSED_FORM=0 keeps the reference's disjoint sets and the second sort: same text on every case,
+    chain gaps from one window to whole sequences (many singletons ... few long chains)"""
+    for seed in range(300, 312):
+        for over in ({}, {"chain_gap": 500}, {"chain_gap": 200000, "block_length": 3000}, {"num_mappings_for_segment": 3}):
+            m = FC.make_mappings("live", "A#2#c1", seed, over)
+            m = np.sort(m, order=["queryStartPos", "refSeqId", "refStartPos"])  # the order the GPU stages deliver
+            P = capi.map_default_params(**over)
+            monkeypatch.setenv("WFM_FILTER_CLOSED_FORM", "1")
+            a = capi.host_filter("subset", m, fai, "A#2#c1", P)
+            monkeypatch.setenv("WFM_FILTER_CLOSED_FORM", "0")
+            assert capi.host_filter("subset", m, fai, "A#2#c1", P) == a
+
+
 def test_sequence_id_manager_groups(fai, tmp_path):
     """ids follow the .fai order, groups the sorted names up to the LAST delimiter (sequenceIds.hpp:286-338)."""
     # a mapping onto every target prints its name and length through the id manager
@@ -132,6 +147,10 @@ def test_large_query_passes_split_over_threads(tmp_path, monkeypatch):
         monkeypatch.setenv("WFM_FILTER_THREADS", threads)
         out[threads] = capi.host_filter("subset", allm, fa, names[0], P)
     assert out["1"] == out["3"] == out["8"] and out["1"].count("\n") > 5000
+    # the chains' representatives and their order in closed form (paths: min of the first two ids) against the disjoint sets and the sort
+    monkeypatch.setenv("WFM_FILTER_CLOSED_FORM", "0")
+    assert capi.host_filter("subset", allm, fa, names[0], P) == out["8"]
+    monkeypatch.delenv("WFM_FILTER_CLOSED_FORM")
     if pyfilter.have_ref():
         assert out["8"] == pyfilter.ref_filter("subset", allm, fa, names[0], P)
     else:

@@ -512,6 +512,31 @@ Summary Aligner::compute() {
       }
       if (hi > lo) total += hi - lo;
       sum.ms_gpu = std::max(sum.ms_gpu, total);
+      if (getenv("WFM_DEBUG") && !v.empty()) {
+        // where the device had no kernel running: its busy share per twentieth of the span from its first kernel to its last (the intervals
+        // are on the device's own clock; the run's wall time less that span is the head before the first kernel plus the tail after the last)
+        const double wall = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        double d_lo = v.front().first, d_hi = d_lo;
+        for (const auto& x : v) d_hi = std::max(d_hi, x.second);
+        const double span = std::max(d_hi - d_lo, 1e-6);
+        std::vector<double> busy20(20, 0.0);
+        auto add = [&](double a, double b) {
+          for (int q = 0; q < 20; ++q) {
+            const double qa = d_lo + span * q / 20, qb = d_lo + span * (q + 1) / 20;
+            const double o = std::min(b, qb) - std::max(a, qa);
+            if (o > 0) busy20[(size_t)q] += o;
+          }
+        };
+        double mlo = 0, mhi = -1;
+        for (const auto& x : v) {
+          if (x.first > mhi) { if (mhi > mlo) add(mlo, mhi); mlo = x.first; mhi = x.second; }
+          else mhi = std::max(mhi, x.second);
+        }
+        if (mhi > mlo) add(mlo, mhi);
+        fprintf(stderr, "[wfmash::align] device: first kernel to last %.1f ms of the run's %.1f (head + tail %.1f), busy %.1f; busy share per twentieth of that span:", span, wall, wall - span, total);
+        for (int q = 0; q < 20; ++q) fprintf(stderr, " %.2f", busy20[(size_t)q] / (span / 20));
+        fprintf(stderr, "\n");
+      }
     }
     // (a worker's own calls follow one another: the sum of their busy times is a lower bound of its device's)
     for (size_t wk = 0; wk < nworkers; ++wk) sum.ms_gpu = std::max(sum.ms_gpu, part[wk].ms_gpu);

@@ -295,6 +295,14 @@ void par_ranges(size_t n, F fn) {  // fn(lo, hi) over a partition of [0, n)
   wfmash_host::parallel_for(T, (int)T, [&](size_t t) { fn(n * t / T, n * (t + 1) / T); });  // (the process's pool: parallel.hpp)
 }
 
+// the same for a few heavy items (a span of a chain stands for up to thousands of mappings): split whenever there are threads
+template <class F>
+void par_ranges_any(size_t n, F fn) {
+  const size_t T = std::min<size_t>(n / 64, (size_t)std::min<int>(tl_filter_threads, par_cap()));
+  if (T <= 1) { fn((size_t)0, n); return; }
+  wfmash_host::parallel_for(T, (int)T, [&](size_t t) { fn(n * t / T, n * (t + 1) / T); });
+}
+
 // the same partition with the part's number: fn(t, lo, hi); returns the number of parts
 template <class F>
 size_t par_parts(size_t n, F fn) {
@@ -353,6 +361,7 @@ std::vector<offset_t> chain_mappings(MappingResultsVector_t& readMappings, int m
   std::vector<uint32_t> p(n);
   std::iota(p.begin(), p.end(), 0u);
   bool device_order = false;
+  bool strict_order = false;  // the first order was found without a sort: every key strictly above its predecessor (no ties anywhere)
   if (presorted) {
     // the device's order is THE sorted order exactly when the keys ascend strictly in it (no ties: any sort gives this permutation)
     std::atomic<bool> ok{true};
@@ -365,6 +374,7 @@ std::vector<offset_t> chain_mappings(MappingResultsVector_t& readMappings, int m
     });
     if (ok.load()) {
       device_order = true;
+      strict_order = true;
       par_ranges(n, [&](size_t lo, size_t hi) { for (size_t i = lo; i < hi; ++i) { p[i] = presorted[i]; chainOf[i] = (offset_t)presorted[i]; } });
     } else {
       // back to the reference's input order, then everything as without the shortcut
@@ -442,6 +452,7 @@ std::vector<offset_t> chain_mappings(MappingResultsVector_t& readMappings, int m
       if (sorted_fast) p.swap(q);
     }
     if (!sorted_fast) std::sort(p.begin(), p.end(), less);
+    strict_order = sorted_fast;
   }
   tt[ti++] = tnow();
   // (one scratch array serves both permutations of the call: the second one writes into pages the first has left behind; raw memory, copied back
@@ -491,7 +502,7 @@ std::vector<offset_t> chain_mappings(MappingResultsVector_t& readMappings, int m
               if (d2 < best && d2 < linkScore[j]) { best = d2; best_j = j; }
             }
           }
-          if (best_j != hi) { linkScore[best_j] = best; linkFrom[best_j] = chainOf[i]; }
+          if (best_j != hi) { linkScore[best_j] = best; linkFrom[best_j] = (int64_t)i; }  // (the predecessor's POSITION; its id is chainOf[i])
         }
       }
     };
@@ -499,11 +510,59 @@ std::vector<offset_t> chain_mappings(MappingResultsVector_t& readMappings, int m
     wfmash_host::parallel_for(T, (int)T, [&](size_t) { work(); });
   }
   tt[ti++] = tnow();
+  // The links form PATHS: a mapping has one predecessor at most (linkFrom) and is the best successor of one mapping at most (each i writes one
+  // best_j), always forwards inside its run.  The reference's unions (disjoint sets, by rank, equal ranks: the larger id under the smaller --
+  // ChainSets above) walk a path in its order: the first union of a path joins two singletons and leaves the SMALLER id on top with rank 1, every
+  // later one hangs a singleton of rank 0 under it.  So a chain's representative is min(id of its first member, id of its second) -- no
+  // sets, no finds; and with a first order without ties the members of a chain already stand in (query, target) order, so the second order
+  // (chain, query start, target start) is: chains by representative, members as they stand.  Runs side by side (paths do not leave a run),
+  // then a prefix sum over the representatives.  WFM_FILTER_CLOSED_FORM=0 keeps the sets and the sort (the tests hold the two against each other).
+  const bool closed_form_on = !(getenv("WFM_FILTER_CLOSED_FORM") && atoi(getenv("WFM_FILTER_CLOSED_FORM")) == 0);  // (read per call: the tests run both)
+  const bool closed_form = closed_form_on && strict_order && n > 0 && n < ((size_t)1 << 31);
+  if (closed_form) {
+    struct Raw32 { uint32_t* q; explicit Raw32(size_t k) : q((uint32_t*)malloc(std::max<size_t>(k, 1) * sizeof(uint32_t))) { if (!q) throw std::bad_alloc(); } ~Raw32() { free(q); } };
+    Raw32 head_m(n), rank_m(n), rep_m(n), start_m(n + 1);
+    uint32_t* const head = head_m.q; uint32_t* const rank = rank_m.q; uint32_t* const rep = rep_m.q; uint32_t* const start = start_m.q;
+    par_ranges(n + 1, [&](size_t lo, size_t hi) { std::memset(start + lo, 0, (hi - lo) * sizeof(uint32_t)); });
+    {
+      // start[r]: the size of the chain whose representative is r (an id is the representative of its own chain or of none: the slots of
+      // different runs' chains never meet); a chain's size is written again by every member, the last one's stands
+      std::atomic<size_t> next{0};
+      auto work = [&]() {
+        for (size_t rn; (rn = next.fetch_add(1)) < runs.size();) {
+          const size_t lo = runs[rn].first, hi = runs[rn].second;
+          for (size_t i = lo; i < hi; ++i) {
+            if (linkScore[i] != std::numeric_limits<double>::max()) {
+              const size_t pr = (size_t)linkFrom[i], hd = head[pr];
+              const uint32_t rk = rank[pr] + 1;
+              head[i] = (uint32_t)hd; rank[i] = rk;
+              if (rk == 1) { start[(size_t)chainOf[hd]] = 0; rep[hd] = (uint32_t)std::min(chainOf[hd], chainOf[i]); }
+              start[rep[hd]] = rk + 1;
+            } else { head[i] = (uint32_t)i; rank[i] = 0; rep[i] = (uint32_t)chainOf[i]; start[(size_t)chainOf[i]] = 1; }
+          }
+        }
+      };
+      const size_t T = n >= ((size_t)1 << 17) ? std::min<size_t>((size_t)tl_filter_threads, runs.size()) : 1;
+      wfmash_host::parallel_for(T, (int)T, [&](size_t) { work(); });
+    }
+    tt[ti++] = tnow();
+    {
+      // exclusive prefix sum of the chains' sizes over the representatives, in parts
+      std::vector<uint64_t> part_sum(34, 0);
+      const size_t T = par_parts(n, [&](size_t t, size_t lo, size_t hi) { uint64_t a = 0; for (size_t i = lo; i < hi; ++i) a += start[i]; part_sum[t + 1] = a; });
+      for (size_t t = 0; t < T; ++t) part_sum[t + 1] += part_sum[t];
+      par_parts(n, [&](size_t t, size_t lo, size_t hi) { uint32_t at = (uint32_t)part_sum[t]; for (size_t i = lo; i < hi; ++i) { const uint32_t c = start[i]; start[i] = at; at += c; } });
+    }
+    par_ranges(n, [&](size_t lo, size_t hi) {
+      for (size_t i = lo; i < hi; ++i) { const uint32_t r = rep[head[i]]; p[start[r] + rank[i]] = (uint32_t)i; }
+    });
+    par_ranges(n, [&](size_t lo, size_t hi) { for (size_t i = lo; i < hi; ++i) chainOf[i] = (offset_t)rep[head[i]]; });
+  } else {
   ChainSets sets(n);
   // (the reference unites inside the loop and once more over everything afterwards: the second round finds every pair in one
   // set already and changes no representative, so it is not repeated here)
   for (size_t i = 0; i < n; ++i)
-    if (linkScore[i] != std::numeric_limits<double>::max()) sets.unite(chainOf[i], linkFrom[i]);
+    if (linkScore[i] != std::numeric_limits<double>::max()) sets.unite(chainOf[i], chainOf[(size_t)linkFrom[i]]);
   for (size_t i = 0; i < n; ++i) chainOf[i] = (offset_t)sets.find(chainOf[i]);
   tt[ti++] = tnow();
 
@@ -531,6 +590,7 @@ std::vector<offset_t> chain_mappings(MappingResultsVector_t& readMappings, int m
       if (sorted_fast) p.swap(q);
     }
     if (!sorted_fast) std::sort(p.begin(), p.end(), less);
+  }
   }
   tt[ti++] = tnow();
   permute_mappings();
@@ -570,25 +630,48 @@ MappingResult merge_span(const MappingResultsVector_t& m, size_t first, size_t l
   return merged;
 }
 
-// walks the chains of a chain-sorted vector, splitting each at max_mapping_length
-template <class Emit>
-void for_each_merged_span(const MappingResultsVector_t& m, const std::vector<offset_t>& chainOf, const Parameters& param, Emit emit) {
-  for (size_t i = 0; i < m.size();) {
-    size_t j = i;
-    while (j + 1 < m.size() && chainOf[j + 1] == chainOf[i]) ++j;
-    for (size_t first = i; first <= j;) {
-      size_t last = first;
-      while (last + 1 <= j) {
-        const offset_t query_span = m[last + 1].queryEndPos() - m[first].queryStartPos;
-        const offset_t ref_span = m[last + 1].refEndPos() - m[first].refStartPos;
-        if (std::max(query_span, ref_span) >= param.max_mapping_length) break;  // int64 against uint64, as the reference
-        ++last;
+// The walk over the chains of a chain-sorted vector, splitting each at max_mapping_length (mappingFilter.hpp:500-571).
+// The same walk for a chromosome-sized query's vector, chains side by side: the parts of the vector each list the spans of the chains that BEGIN
+// in them (a chain is walked by one part, whatever it reaches into), the lists joined in part order are for_each_merged_span's sequence.
+// chain_no: the chain's number in the order of the vector (the reference's dense chain id: first appearance in a chain-sorted vector).
+struct SpanRec { size_t i, j, first, last; uint32_t chain_no; uint32_t pos; };
+std::vector<SpanRec> collect_spans(const MappingResultsVector_t& m, const std::vector<offset_t>& chainOf, const Parameters& param) {
+  const size_t n = m.size();
+  std::vector<std::vector<SpanRec>> part(33);
+  std::vector<uint32_t> chains_in(34, 0);
+  const size_t T = par_parts(n, [&](size_t t, size_t lo, size_t hi) {
+    std::vector<SpanRec>& out = part[t];
+    uint32_t chains = 0;
+    size_t i = lo;
+    while (i < hi && i > 0 && chainOf[i] == chainOf[i - 1]) ++i;  // (the chain that reaches in from the part before is that part's)
+    while (i < hi) {
+      size_t j = i;
+      while (j + 1 < n && chainOf[j + 1] == chainOf[i]) ++j;
+      uint32_t pos = 1;
+      for (size_t first = i; first <= j;) {
+        size_t last = first;
+        while (last + 1 <= j) {
+          const offset_t query_span = m[last + 1].queryEndPos() - m[first].queryStartPos;
+          const offset_t ref_span = m[last + 1].refEndPos() - m[first].refStartPos;
+          if (std::max(query_span, ref_span) >= param.max_mapping_length) break;  // int64 against uint64, as the reference
+          ++last;
+        }
+        out.push_back({i, j, first, last, chains, pos++});
+        first = last + 1;
       }
-      emit(i, j, first, last);
-      first = last + 1;
+      ++chains;
+      i = j + 1;
     }
-    i = j + 1;
-  }
+    chains_in[t + 1] = chains;
+  });
+  for (size_t t = 0; t < T; ++t) chains_in[t + 1] += chains_in[t];
+  size_t total = 0;
+  for (size_t t = 0; t < T; ++t) total += part[t].size();
+  std::vector<SpanRec> all;
+  all.reserve(total);
+  for (size_t t = 0; t < T; ++t)
+    for (SpanRec r : part[t]) { r.chain_no += chains_in[t]; all.push_back(r); }
+  return all;
 }
 
 }  // namespace
@@ -602,22 +685,17 @@ MappingsWithChains MappingFilterUtils::mergeMappingsInRangeWithChains(MappingRes
     return result;
   }
   const std::vector<offset_t> chainOf = chain_mappings(readMappings, max_dist, param);
-  std::map<uint32_t, uint32_t> denseId;  // representative -> sequential chain id
-  uint32_t nextId = 0;
-  uint32_t chainId = 0;
-  uint16_t chainPos = 1;
-  size_t current = (size_t)-1;
-  for_each_merged_span(readMappings, chainOf, param, [&](size_t i, size_t j, size_t first, size_t last) {
-    if (i != current) {
-      current = i;
-      auto it = denseId.find((uint32_t)chainOf[i]);
-      if (it == denseId.end()) it = denseId.emplace((uint32_t)chainOf[i], nextId++).first;
-      chainId = it->second;
-      chainPos = 1;
+  // (representative -> sequential chain id in the order of first appearance: the vector is sorted by chain, so that is the chain's number;
+  // chainPos counts a chain's spans from 1 in a uint16, as the reference's does)
+  const std::vector<SpanRec> spans = collect_spans(readMappings, chainOf, param);
+  result.mappings.resize(spans.size());
+  result.chainInfo.resize(spans.size());
+  par_ranges_any(spans.size(), [&](size_t lo, size_t hi) {
+    for (size_t k = lo; k < hi; ++k) {
+      const SpanRec& sp = spans[k];
+      result.mappings[k] = merge_span(readMappings, sp.first, sp.last);
+      result.chainInfo[k] = {sp.chain_no, (uint16_t)sp.pos, (uint16_t)(sp.j - sp.i + 1)};
     }
-    const uint16_t chainLen = (uint16_t)(j - i + 1);
-    result.mappings.push_back(merge_span(readMappings, first, last));
-    result.chainInfo.push_back({chainId, chainPos++, chainLen});
   });
   return result;
 }
@@ -625,9 +703,9 @@ MappingsWithChains MappingFilterUtils::mergeMappingsInRangeWithChains(MappingRes
 MappingResultsVector_t MappingFilterUtils::mergeMappingsInRange(MappingResultsVector_t& readMappings, int max_dist, const Parameters& param) {
   if (!param.split || readMappings.size() < 2) return readMappings;
   const std::vector<offset_t> chainOf = chain_mappings(readMappings, max_dist, param);
-  MappingResultsVector_t out;
-  for_each_merged_span(readMappings, chainOf, param,
-                       [&](size_t, size_t, size_t first, size_t last) { out.push_back(merge_span(readMappings, first, last)); });
+  const std::vector<SpanRec> spans = collect_spans(readMappings, chainOf, param);
+  MappingResultsVector_t out(spans.size());
+  par_ranges_any(spans.size(), [&](size_t lo, size_t hi) { for (size_t k = lo; k < hi; ++k) out[k] = merge_span(readMappings, spans[k].first, spans[k].last); });
   return out;
 }
 
