@@ -20,12 +20,13 @@ def main():
     ap.add_argument("--haps", type=int, default=8)
     ap.add_argument("--mbp", type=float, default=248.956422)
     ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--all", action="store_true", help="every haplotype as a query (the all-vs-all job's map phase) instead of rank 0's share")
     ap.add_argument("variants", nargs="*", default=[""])
     a = ap.parse_args()
     d = tempfile.mkdtemp()
     fa = os.path.join(d, "c4.fa")
     names, lengths = synth.write_fasta(fa, synth.pangenome(a.haps, int(a.mbp * 1e6)))
-    mine = [names[i] for i in dist.shard_queries(lengths, 8)[0]]
+    mine = list(names) if a.all else [names[i] for i in dist.shard_queries(lengths, 8)[0]]
     qlist = os.path.join(d, "queries.txt")
     open(qlist, "w").write("\n".join(mine) + "\n")
     P = capi.map_default_params(threads=os.cpu_count() or 1, query_list=qlist)

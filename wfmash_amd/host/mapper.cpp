@@ -363,6 +363,7 @@ int Map::mapQuery(MapSummary* summary) {
       std::vector<int32_t> mfrag;
       std::vector<uint32_t> perm;  // the batch's mappings in chaining order (wfm_map_fragments_ordered), or perm[0] = ~0u
       int64_t seq = -1;
+      MappingResultsVector_t* spare = nullptr;  // the device thread's spare vector (one filter stage runs at a time per device thread)
     };
     static const bool filter_overlap = !(getenv("WFM_FILTER_OVERLAP") && atoi(getenv("WFM_FILTER_OVERLAP")) == 0);
     auto worker_body = [&](size_t g) {
@@ -374,6 +375,7 @@ int Map::mapQuery(MapSummary* summary) {
       std::deque<std::unique_ptr<Work>> queue;
       bool no_more = false;
       std::thread filt;
+      MappingResultsVector_t spare_results;  // (see filter_stage: a chromosome-sized query's vector serves the next one)
       auto filter_loop = [&]() {
         try {
           for (;;) {
@@ -406,6 +408,7 @@ int Map::mapQuery(MapSummary* summary) {
         const int64_t seq = read_batch(b);
         if (seq < 0) break;
         W.seq = seq;
+        W.spare = &spare_results;
         double tb = now_ms();
         std::vector<wfm_mapping_t>& maps = W.maps;
         std::vector<int32_t>& mfrag = W.mfrag;
@@ -473,8 +476,14 @@ int Map::mapQuery(MapSummary* summary) {
           set_filter_threads(std::max(1, threads_each / std::max(1, nt_filter)));  // few queries: each may use the idle threads
           for (size_t qn; error_rc.load() == WFM_OK && (qn = next.fetch_add(1)) < bq.size();) {
             const BatchQuery& q = bq[qn];
+            static const bool tdbg = getenv("WFM_FILTER_TIMES") != nullptr;
+            const double tq0 = now_ms();
             MappingResultsVector_t results;
             const size_t m0 = first_map[qn], nq = first_map[qn + 1] - first_map[qn];
+            // (a chromosome-sized query is a batch of its own: its 48 MB vector is the one the query before it left behind -- resize() of a fresh
+            // vector writes every element on this thread and faults every page in, 9 of the 13 ms this step took)
+            const bool reuse = bq.size() == 1 && nq >= ((size_t)1 << 17);
+            if (reuse) results.swap(FW.spare ? *FW.spare : results);
             std::vector<uint32_t> orig;  // (device order) position of every mapping in fragment order, within the query
             if (have_perm && nq >= 2) {
               // the query's mappings in chaining order, straight from the device's permutation (its queries are consecutive there as here)
@@ -507,6 +516,7 @@ int Map::mapQuery(MapSummary* summary) {
                 orig.clear();
               }
             } else {
+              results.clear();
               results.reserve(nq);
               for (size_t m = first_map[qn]; m < first_map[qn + 1]; ++m) {
                 MappingResult r;
@@ -515,9 +525,12 @@ int Map::mapQuery(MapSummary* summary) {
                 results.push_back(r);
               }
             }
+            const double tq1 = now_ms();
             MappingOutput::mappingBoundarySanityCheck(q.len, results, ids);
+            const double tq2 = now_ms();
             if (!orig.empty()) set_presorted_order(orig.data(), orig.size());
             FilteredMappingsResult fr = filterSubsetMappings(results, P, ids, q.len);
+            const double tq3 = now_ms();
             const bool merged = P.mergeMappings && P.split;
             MappingResultsVector_t& keep = merged ? fr.mergedMappings : fr.nonMergedMappings;
             const ChainInfoVector_t& chains = merged ? fr.mergedChainInfo : fr.nonMergedChainInfo;
@@ -527,6 +540,10 @@ int Map::mapQuery(MapSummary* summary) {
               qout[qn].text = os.str();
             }
             qout[qn].keep = std::move(keep);
+            if (reuse && merged && FW.spare) FW.spare->swap(fr.nonMergedMappings);  // (the filters' input, handed back: nobody reads it after this)
+            if (tdbg && nq >= 100000)
+              fprintf(stderr, "[filter] query of %zu mappings: vector %.1f, boundary check %.1f, filterSubsetMappings %.1f, text %.1f ms (stage began %.1f ms before)\n", nq, tq1 - tq0, tq2 - tq1,
+                      tq3 - tq2, now_ms() - tq3, tq0 - tb);
           }
          } catch (const std::bad_alloc&) {
           fail(WFM_E_NOMEM, "out of host memory while post-processing mappings");
@@ -539,8 +556,10 @@ int Map::mapQuery(MapSummary* summary) {
           wfmash_host::parallel_for((size_t)nt, nt, [&](size_t) { work(); });  // (work() shares the queries out by its own counter and sets its thread's filter threads itself)
         }
         if (error_rc.load() != WFM_OK) return;
+        const double tw0 = now_ms();
         write_batch((uint64_t)seq, std::move(bo));
         ps.ms_filter += now_ms() - tb;
+        if (getenv("WFM_FILTER_TIMES") && maps.size() >= 100000) fprintf(stderr, "[filter] stage of %zu mappings: %.1f ms in all, writing %.1f\n", maps.size(), now_ms() - tb, now_ms() - tw0);
           };
         }
         if (!filter_overlap) { filter_stage(W); continue; }
