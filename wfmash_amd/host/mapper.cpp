@@ -305,10 +305,16 @@ int Map::mapQuery(MapSummary* summary) {
       std::lock_guard<std::mutex> lk(read_mu);
       b = Batch();
       wfmash_host::SeqView only;  // the batch's one sequence so far, not copied yet
+      // (a batch of ONE sequence is mapped where the FASTA store holds it; a second one makes the batch a copy of both.  For chromosome-sized
+      // queries that copy -- 2 x 249 MB into fresh pages, on the device thread, before every batch of the all-vs-all job -- was 170 ms per batch
+      // beside 150 ms of mapping: a sequence that would push the copy past kCopyBases begins a batch of its own)
+      constexpr int64_t kCopyBases = 64ll << 20;
       while (qi < queryNames.size() && (b.n_bases < batch_bases || b.bq.empty())) {
-        const std::string& name = queryNames[qi++];
+        const std::string& name = queryNames[qi];
         wfmash_host::SeqView seq;
-        if (!src.find(P.querySequences, name, &seq) || seq.empty()) continue;  // "not found or empty, skipping" (computeMap.hpp:534-537)
+        if (!src.find(P.querySequences, name, &seq) || seq.empty()) { ++qi; continue; }  // "not found or empty, skipping" (computeMap.hpp:534-537)
+        if (!b.bq.empty() && b.n_bases + (int64_t)seq.size() > kCopyBases) break;
+        ++qi;
         BatchQuery q{name, ids.getSequenceId(name), (offset_t)seq.size(), b.n_bases, (int64_t)b.frag_off.size(), 0};
         const int whole = (int)(q.len / w);
         for (int i = 0; i < whole; ++i) b.frag_off.push_back(q.base + (int64_t)i * w);
