@@ -31,6 +31,27 @@ namespace skch {
 namespace {
 
 constexpr float kConfidenceInterval = 0.95f;  // fixed::confidence_interval (map_parameters.hpp:125)
+// (what a batch's mappings come back in: sized for the most a batch can yield -- 16 per fragment and more --, filled by the copy from the device up to
+// what it did yield.  A std::vector writes all of it first: 144 MB of zeros and page faults per chromosome-sized query, on the device thread, before the
+// mapping it waits for begins.  Raw memory, untouched beyond what the copy writes)
+template <class T>
+struct RawVec {
+  T* p = nullptr; size_t n = 0, cap = 0;
+  RawVec() = default;
+  RawVec(const RawVec&) = delete;
+  RawVec& operator=(const RawVec&) = delete;
+  ~RawVec() { free(p); }
+  void resize(size_t k) {
+    if (k > cap) { free(p); p = (T*)malloc(k * sizeof(T)); if (!p) { cap = n = 0; throw std::bad_alloc(); } cap = k; }  // (never grown with content to keep: sized, then filled)
+    n = k;
+  }
+  size_t size() const { return n; }
+  bool empty() const { return n == 0; }
+  T* data() { return p; }
+  T& operator[](size_t i) { return p[i]; }
+  const T& operator[](size_t i) const { return p[i]; }
+};
+
 constexpr int64_t kBatchBases = 256ll << 20;  // query bases per wfm_map_fragments call
 
 double now_ms() {
@@ -365,9 +386,9 @@ int Map::mapQuery(MapSummary* summary) {
     // stays at two batches' mappings per GPU.  WFM_FILTER_OVERLAP=0: one after the other, as before.
     struct Work {
       Batch b;
-      std::vector<wfm_mapping_t> maps;
-      std::vector<int32_t> mfrag;
-      std::vector<uint32_t> perm;  // the batch's mappings in chaining order (wfm_map_fragments_ordered), or perm[0] = ~0u
+      RawVec<wfm_mapping_t> maps;
+      RawVec<int32_t> mfrag;
+      RawVec<uint32_t> perm;  // the batch's mappings in chaining order (wfm_map_fragments_ordered), or perm[0] = ~0u
       int64_t seq = -1;
       MappingResultsVector_t* spare = nullptr;  // the device thread's spare vector (one filter stage runs at a time per device thread)
     };
@@ -380,9 +401,13 @@ int Map::mapQuery(MapSummary* summary) {
       std::condition_variable qcv;
       std::deque<std::unique_ptr<Work>> queue;
       bool no_more = false;
-      std::thread filt;
-      MappingResultsVector_t spare_results;  // (see filter_stage: a chromosome-sized query's vector serves the next one)
+      // (two filter threads per device thread since the mapping of a chromosome-sized query became shorter than its post-processing -- 52 against 60 ms:
+      // the batches' texts are written in the batches' order whichever thread finishes first; WFM_FILTER_WORKERS=1: one, as before)
+      static const size_t n_filt = getenv("WFM_FILTER_WORKERS") ? (size_t)std::max(1, std::min(4, atoi(getenv("WFM_FILTER_WORKERS")))) : 2;
+      std::vector<std::thread> filt;
+      MappingResultsVector_t spare_results;  // (see filter_stage: a chromosome-sized query's vector serves the next one; the filter threads have one each)
       auto filter_loop = [&]() {
+        MappingResultsVector_t spare_own;
         try {
           for (;;) {
             std::unique_ptr<Work> wk;
@@ -394,6 +419,7 @@ int Map::mapQuery(MapSummary* summary) {
               queue.pop_front();
             }
             qcv.notify_all();
+            wk->spare = &spare_own;
             if (error_rc.load() == WFM_OK) filter_stage(*wk);
           }
         } catch (const std::bad_alloc&) {
@@ -402,9 +428,9 @@ int Map::mapQuery(MapSummary* summary) {
           fail(WFM_E_ARG, std::string("post-processing failed: ") + e.what());
         }
       };
-      struct Joiner {  // the filter thread is joined on every way out of this function
-        std::thread& t; std::mutex& mu; std::condition_variable& cv; bool& flag;
-        ~Joiner() { { std::lock_guard<std::mutex> lk(mu); flag = true; } cv.notify_all(); if (t.joinable()) t.join(); }
+      struct Joiner {  // the filter threads are joined on every way out of this function
+        std::vector<std::thread>& t; std::mutex& mu; std::condition_variable& cv; bool& flag;
+        ~Joiner() { { std::lock_guard<std::mutex> lk(mu); flag = true; } cv.notify_all(); for (auto& x : t) if (x.joinable()) x.join(); }
       } joiner{filt, qmu, qcv, no_more};
       for (;;) {
         std::unique_ptr<Work> wkp(new Work());
@@ -416,9 +442,9 @@ int Map::mapQuery(MapSummary* summary) {
         W.seq = seq;
         W.spare = &spare_results;
         double tb = now_ms();
-        std::vector<wfm_mapping_t>& maps = W.maps;
-        std::vector<int32_t>& mfrag = W.mfrag;
-        std::vector<uint32_t>& perm = W.perm;
+        auto& maps = W.maps;
+        auto& mfrag = W.mfrag;
+        auto& perm = W.perm;
         std::vector<int32_t> frag_first;   // per fragment: the first fragment of its query
         static const bool dev_order = !(getenv("WFM_FILTER_DEVICE_ORDER") && atoi(getenv("WFM_FILTER_DEVICE_ORDER")) == 0);
         if (ixs[g] && !b.frag_off.empty()) {
@@ -442,7 +468,7 @@ int Map::mapQuery(MapSummary* summary) {
               fail((int)n, wfm_last_error(hg));
               return;
             }
-            if (n <= cap) { maps.resize((size_t)n); mfrag.resize((size_t)n); if (!perm.empty()) perm.resize((size_t)n); break; }
+            if (n <= cap) { maps.resize((size_t)n); mfrag.resize((size_t)n); if (!perm.empty()) perm.resize((size_t)n); break; }  // (shrinking: the content stays)
             cap = n;
           }
         }
@@ -452,9 +478,9 @@ int Map::mapQuery(MapSummary* summary) {
         if (!filter_stage) {
           filter_stage = [&, g](Work& FW) {
         Batch& b = FW.b;
-        std::vector<wfm_mapping_t>& maps = FW.maps;
-        std::vector<int32_t>& mfrag = FW.mfrag;
-        std::vector<uint32_t>& perm = FW.perm;
+        auto& maps = FW.maps;
+        auto& mfrag = FW.mfrag;
+        auto& perm = FW.perm;
         const int64_t seq = FW.seq;
         (void)g;
         // ---- per query: boundary check, filters, output (processFragment :124-128; query task :634-688)
@@ -564,12 +590,12 @@ int Map::mapQuery(MapSummary* summary) {
         if (error_rc.load() != WFM_OK) return;
         const double tw0 = now_ms();
         write_batch((uint64_t)seq, std::move(bo));
-        ps.ms_filter += now_ms() - tb;
+        { std::lock_guard<std::mutex> lk(qmu); ps.ms_filter += now_ms() - tb; }
         if (getenv("WFM_FILTER_TIMES") && maps.size() >= 100000) fprintf(stderr, "[filter] stage of %zu mappings: %.1f ms in all, writing %.1f\n", maps.size(), now_ms() - tb, now_ms() - tw0);
           };
         }
         if (!filter_overlap) { filter_stage(W); continue; }
-        if (!filt.joinable()) filt = std::thread(filter_loop);
+        if (filt.size() < n_filt) filt.emplace_back(filter_loop);  // (one more per batch until there are n_filt: a call of one batch starts one)
         {
           std::unique_lock<std::mutex> lk(qmu);
           qcv.wait(lk, [&] { return queue.size() < 1 || error_rc.load() != WFM_OK; });
