@@ -704,13 +704,22 @@ struct SeqJob {
   }
 };
 
-// The hash threshold of the thinned stream: ~c x s of the W k-mers of a window stay (c = 3, WFM_PREFILTER_C);
-// 0 = no thinning (WFM_PREFILTER=0, or more than half of the k-mers would stay anyway)
+// The hash threshold of the thinned stream: ~c x s of the W k-mers of a window stay (WFM_PREFILTER_C);
+// 0 = no thinning (WFM_PREFILTER=0, or more than half of the k-mers would stay anyway).
+// c: every k-mer let through is an event of the winnower, every window that holds fewer than s candidates stays WHOLE (W events, and on the device
+// a chunk that runs again with the full capacities) -- so as few as keep such windows out of ordinary sequence: the count of candidates in a window
+// is about Poisson(c s), and c s = m with m - 5 sqrt(m) = s leaves one window in 10^8 - 10^9 short whatever s is (s = 23: c = 2.7, s = 39: 2.2), never
+// more than the 3 of rounds 3 - 5.  Measured on a full-size C4 rank (s = 23, 8 x 249 Mbp; gpurun_out/r6bj, r6bk): index build 248 - 255 ms at c = 3,
+// 236 - 246 at 2.7, 234 - 237 at 2.5, 300 at 2.4 (81 short windows per chromosome: their chunks run twice), 381 at 1.8; the records are the same bytes.
+double prefilter_c(int s) {
+  const double root = (5.0 + std::sqrt(25.0 + 4.0 * (double)std::max(1, s))) / 2.0;
+  return std::min(3.0, root * root / (double)std::max(1, s));
+}
 uint64_t prefilter_tau(int s, int64_t W) {
   const char* on = getenv("WFM_PREFILTER");
   if (on && atoi(on) == 0) return 0;
   const char* ce = getenv("WFM_PREFILTER_C");
-  const double c = ce ? atof(ce) : 3.0;
+  const double c = ce ? atof(ce) : prefilter_c(s);
   const double share = c * (double)s / (double)std::max<int64_t>(1, W);
   if (!(share > 0) || share > 0.5) return 0;
   return map_prefilter_tau(c, s, W);
