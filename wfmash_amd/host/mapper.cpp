@@ -406,10 +406,18 @@ int Map::mapQuery(MapSummary* summary) {
       static const size_t n_filt = getenv("WFM_FILTER_WORKERS") ? (size_t)std::max(1, std::min(4, atoi(getenv("WFM_FILTER_WORKERS")))) : 2;
       std::vector<std::thread> filt;
       MappingResultsVector_t spare_results;  // (see filter_stage: a chromosome-sized query's vector serves the next one; the filter threads have one each)
+      // (what a chromosome-sized query's vector will about hold, told by the device thread before its mapping call: a filter thread that has no
+      // vector from a query before it makes one while the device maps -- resize() writes every element and faults every page in, 9 ms that were
+      // the first thing the post-processing did)
+      std::atomic<size_t> spare_hint{0};
       auto filter_loop = [&]() {
         MappingResultsVector_t spare_own;
         try {
           for (;;) {
+            {
+              const size_t hint = spare_hint.load();
+              if (hint && spare_own.capacity() < hint) spare_own.resize(hint);
+            }
             std::unique_ptr<Work> wk;
             {
               std::unique_lock<std::mutex> lk(qmu);
@@ -456,6 +464,12 @@ int Map::mapQuery(MapSummary* summary) {
           // a fragment of a pangenome maps about once per target haplotype; a too small buffer costs a
           // second pass over the batch, so be generous
           int64_t cap = (int64_t)b.frag_off.size() * std::min<int64_t>(256, std::max<int64_t>(16, 2 * (int64_t)subset.size())) + (1 << 16);
+          if (filter_overlap && b.bq.size() == 1 && b.frag_off.size() >= ((size_t)1 << 16)) {
+            // (a pangenome's fragment maps about once per target sequence of another group: one per target sequence is room enough; a vector that
+            // turns out too small grows as any vector does)
+            spare_hint.store(b.frag_off.size() * (size_t)std::min<int64_t>(16, std::max<int64_t>(1, (int64_t)subset.size())));
+            if (filt.empty()) filt.emplace_back(filter_loop);
+          }
           for (;;) {
             maps.resize((size_t)cap); mfrag.resize((size_t)cap);
             if (!frag_first.empty()) perm.resize((size_t)cap);
