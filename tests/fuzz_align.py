@@ -1,10 +1,10 @@
 """Randomised parity campaign of the align path: batches of mixed problems (substitutions / indels at 0 - 40 %, block deletions, insertions,
 tandem duplications and inversions, microsatellites and homopolymers, N runs and soft-masked stretches, unrelated pairs, empty and one-base
 sequences, very unequal lengths; BiWFA end-to-end and the two ends-free patch forms) through libwfmash_hip.so, every result held against the
-CPU oracle (oracle/wfa2p.c; its calls run on a thread pool, ctypes releases the GIL).  A one-off tool for a GPU box, not part of the suite:
+CPU oracle (oracle/wfa2p.c; its calls run on a thread pool, ctypes releases the GIL).  A tool for a GPU box beside the suite (it lives under tests/ because it calls the oracle; pytest does not collect it):
 the suite's own cases came out of runs like this one.
 
-Usage: python scripts/fuzz_align.py [--rounds 20] [--items 240] [--seed 1] [--max-len 9000] [--threads N]
+Usage: python tests/fuzz_align.py [--rounds 20] [--items 240] [--seed 1] [--max-len 9000] [--threads N]
 Prints one line per round and a JSON summary; exit code 1 if anything differs (the failing problems are written to --dump as FASTA-like text)."""
 import argparse
 import json

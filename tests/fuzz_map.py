@@ -2,9 +2,9 @@
 structural variants, an interspersed repeat family and a microsatellite so that frequent k-mers, ties and low-complexity windows occur) through
 wfmh_map_paf with the defaults (identity estimate, index, L1 / L2, filters), one query haplotype per round held against the stage oracles on
 the reference's own addMinmers and the reference's own filter code (oracle/_ref: this only runs where /root/reference was there at build time
-or the built libraries travelled).  A one-off tool for a GPU box, not part of the suite.
+or the built libraries travelled).  A tool for a GPU box beside the suite (it lives under tests/ because it calls the oracles; pytest does not collect it).
 
-Usage: python scripts/fuzz_map.py [--rounds 12] [--seed 1]
+Usage: python tests/fuzz_map.py [--rounds 12] [--seed 1]
 Prints one line per round and a JSON summary; exit code 1 if a round's records differ."""
 import argparse
 import json
