@@ -3,7 +3,7 @@ mappings shaped like a full-size C4 rank's (249 k fragments x 7 target haplotype
 noise): wall time of wfmh_test_filter("subset") per thread count, the stage times of chain_mappings (WFM_FILTER_TIMES), and --
 with --check -- the text held against the reference's own filter code (oracle/_ref/libref_filter.so).  No GPU needed.
 
-Usage: python scripts/filter_bench.py [--frags 249000] [--threads 1,8,32] [--check]"""
+Usage: python tests/filter_bench.py [--frags 249000] [--threads 1,8,32] [--check]"""
 import argparse
 import os
 import sys
