@@ -80,41 +80,34 @@ def gen_pair(rng, k, max_len):
     return p, t
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--rounds", type=int, default=20)
-    ap.add_argument("--items", type=int, default=240)
-    ap.add_argument("--seed", type=int, default=1)
-    ap.add_argument("--max-len", type=int, default=9000)
-    ap.add_argument("--threads", type=int, default=min(64, os.cpu_count() or 1))
-    ap.add_argument("--dump", default="")
-    ap.add_argument("--pens", action="store_true", help="a penalty set per round (mismatch, o1, e1, o2, e2) drawn from sets within the supported scope instead of the defaults")
-    a = ap.parse_args()
+def run(rounds=20, items=240, seed=1, max_len=9000, threads=None, pens=False, dump="", quiet=False):
+    """the campaign; returns {"problems", "differ", "failed", ...}"""
+    threads = threads or min(64, os.cpu_count() or 1)
     pyoracle.lib()
     h = capi.Handle(0)
-    pool = ThreadPoolExecutor(a.threads)
+    pool = ThreadPoolExecutor(threads)
     total = bad = failed = 0
     t_gpu = t_cpu = 0.0
     dumped = []
-    for rnd in range(a.rounds):
-        rng = random.Random(a.seed * 100003 + rnd)
+    for rnd in range(rounds):
+        rng = random.Random(seed * 100003 + rnd)
         pen = None
-        if a.pens:
+        if pens:
             pen = rng.choice([None, (4, 6, 2, 12, 1), (3, 4, 1, 10, 1), (5, 8, 2, 60, 1), (6, 10, 3, 124, 1), (9, 40, 2, 100, 1), (33, 20, 2, 24, 1), (2, 3, 1, 8, 1), (7, 11, 3, 30, 2),
                               (1, 2, 1, 6, 1), (5, 8, 2, 24, 1), (6, 8, 2, 49, 1)])
-        items, calls = [], []
-        for k in range(a.items):
-            p, t = gen_pair(rng, rng.randrange(0, 12), a.max_len)
+        batch, calls = [], []
+        for k in range(items):
+            p, t = gen_pair(rng, rng.randrange(0, 12), max_len)
             mode = rng.random()
             if mode < 0.7 or not p or not t or max(len(p), len(t)) > 4000:
-                items.append((p, t))
+                batch.append((p, t))
                 calls.append(("bi", p, t))
             else:  # the patch forms of do_biwfa_alignment: free beginnings (head) or free ends (tail)
                 args = (len(p), 0, len(t), 0) if mode < 0.85 else (0, len(p), 0, len(t))
-                items.append((p, t, capi.WFM_MODE_ENDSFREE) + args)
+                batch.append((p, t, capi.WFM_MODE_ENDSFREE) + args)
                 calls.append(("ef", p, t) + args)
         t0 = time.time()
-        res = h.align(items, pen)
+        res = h.align(batch, pen)
         t_gpu += time.time() - t0
         t0 = time.time()
 
@@ -139,13 +132,29 @@ def main():
                 dumped.append({"round": rnd, "pen": pen, "kind": c[0], "args": list(c[3:]), "p": c[1].decode(), "t": c[2].decode(), "status": int(r.status),
                                "gpu_score": int(r.score), "oracle_score": int(sc)})
         bad += rb; failed += rf
-        print(f"round {rnd} (penalties {pen}): {len(items)} problems, {rb} differ, {rf} failed (gpu {t_gpu:.1f} s, oracle {t_cpu:.1f} s so far)", flush=True)
+        if not quiet:
+            print(f"round {rnd} (penalties {pen}): {len(batch)} problems, {rb} differ, {rf} failed (gpu {t_gpu:.1f} s, oracle {t_cpu:.1f} s so far)", flush=True)
     h.close()
-    print(json.dumps({"problems": total, "differ": bad, "failed": failed, "seed": a.seed, "rounds": a.rounds, "items": a.items, "max_len": a.max_len}))
-    if dumped and a.dump:
-        with open(a.dump, "w") as f:
+    pool.shutdown()
+    if dumped and dump:
+        with open(dump, "w") as f:
             json.dump(dumped, f)
-    sys.exit(1 if bad or failed else 0)
+    return {"problems": total, "differ": bad, "failed": failed, "seed": seed, "rounds": rounds, "items": items, "max_len": max_len}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--rounds", type=int, default=20)
+    ap.add_argument("--items", type=int, default=240)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--max-len", type=int, default=9000)
+    ap.add_argument("--threads", type=int, default=min(64, os.cpu_count() or 1))
+    ap.add_argument("--dump", default="")
+    ap.add_argument("--pens", action="store_true", help="a penalty set per round (mismatch, o1, e1, o2, e2) drawn from sets within the supported scope instead of the defaults")
+    a = ap.parse_args()
+    out = run(a.rounds, a.items, a.seed, a.max_len, a.threads, a.pens, a.dump)
+    print(json.dumps(out))
+    sys.exit(1 if out["differ"] or out["failed"] else 0)
 
 
 if __name__ == "__main__":
