@@ -356,8 +356,12 @@ Summary Aligner::compute() {
   static const size_t workers_env = getenv("WFM_ALIGN_WORKERS") ? (size_t)std::max(1, atoi(getenv("WFM_ALIGN_WORKERS"))) : 0;  // A/B runs
   // (four since round 5 where the host has 16 threads per GPU: with the round's kernels a batch of a pangenome rank is 100 ms of device time in 170 ms
   // of its worker's, and a full-size rank went from 1.37 - 1.42 s on three workers to 1.18 - 1.29 s on four -- gpurun_out/r5i.log; six gain nothing more)
-  const size_t per_gpu = workers_env ? workers_env : ((size_t)param.threads >= 16 * ngpu ? 4 : ((size_t)param.threads >= 12 * ngpu ? 3 : ((size_t)param.threads >= 2 * ngpu ? 2 : 1)));
-  const size_t nworkers = ngpu * per_gpu;
+  // (six since round 6 where the host has 48 threads per GPU: on the all-vs-all job at north_star's size -- 187 batches -- the device's busy time went from 7.58 to 7.30 s
+  // and the align phase from 8.3 - 8.45 to 7.8 - 8.1 s, eight workers 8.2 - 8.3 s: gpurun_out/r6cb; a rank's 28 batches are the same 1.08 - 1.12 s on four, five or six)
+  const size_t per_gpu = workers_env ? workers_env
+                                     : ((size_t)param.threads >= 48 * ngpu ? 6 : ((size_t)param.threads >= 16 * ngpu ? 4 : ((size_t)param.threads >= 12 * ngpu ? 3 : ((size_t)param.threads >= 2 * ngpu ? 2 : 1))));
+  const size_t nworkers_max = ngpu * per_gpu;
+  uint64_t est_batches = ~0ull;  // (from the file's size and its first rows; unknown for a stream)
   // several GPUs: no batch may hold more than an eighth of one GPU's share of the file.  One GPU: a file of one batch
   // stays one batch (WFM_ALIGN_MIN_BATCHES cuts it for A/B runs); a file of a few batches is cut into a multiple of the
   // workers' number, level ones -- four batches on three workers are two rounds of which the second leaves the device to
@@ -375,7 +379,7 @@ Summary Aligner::compute() {
     in.clear();
     const uint64_t file_bytes = seekable ? (uint64_t)end_at : 0;
     uint64_t rows = 0, bytes = 0, bases = 0;
-    if (level_batches && nworkers > 1 && file_bytes > 0) {
+    if (level_batches && nworkers_max > 1 && file_bytes > 0) {
       std::string line;
       while (rows < 256 && std::getline(in, line)) {
         if (line.empty()) continue;
@@ -384,8 +388,18 @@ Summary Aligner::compute() {
       in.clear();
       in.seekg(0, std::ios::beg);
     }
-    batch_bytes = plan_batch_bytes(file_bytes, rows, bytes, bases, param.batch_records, param.batch_bases, nworkers, ngpu, min_batches, level_batches);
+    batch_bytes = plan_batch_bytes(file_bytes, rows, bytes, bases, param.batch_records, param.batch_bases, nworkers_max, ngpu, min_batches, level_batches);
+    // (no more workers than the file has batches: a worker beyond the first of a device brings a handle with arenas of its own, and the host threads are shared
+    // out over the workers -- a mapping file of one batch keeps them all)
+    if (rows > 0 && bytes > 0) {
+      const double est_rows = (double)file_bytes / ((double)bytes / (double)rows);
+      const double est_bases = est_rows * ((double)bases / (double)rows);
+      uint64_t need = (uint64_t)std::ceil(std::max(est_rows / (double)std::max<uint64_t>(1, param.batch_records), est_bases / (double)std::max<uint64_t>(1, param.batch_bases)));
+      if (batch_bytes != ~0ull) need = std::max<uint64_t>(need, (file_bytes + batch_bytes - 1) / batch_bytes);
+      est_batches = std::max<uint64_t>(1, need);
+    }
   }
+  const size_t nworkers = (size_t)std::max<uint64_t>(ngpu, std::min<uint64_t>(nworkers_max, est_batches));
   std::mutex read_mu, write_mu;
   uint64_t next_seq = 0, next_write = 0;
   std::map<uint64_t, std::string> pending;
